@@ -1,0 +1,226 @@
+"""numpy front-end of the CPU oracle (oracle/sdpa_ref.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never by the product package.
+
+Arrays: fp32 -> np.float32, fp16 -> np.float16, bf16 -> np.uint16 holding the
+raw bits (numpy has no bfloat16).  Layout is BHSD (metal_sdpa_backend.cpp:188-193).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIB_PATH = _HERE / "libsdpa_ref.so"
+
+PREC_FP16, PREC_BF16, PREC_FP32 = 0, 1, 2
+MASK_NONE, MASK_BOOL, MASK_ADDITIVE = 0, 1, 2
+MSCALAR_BYTE, MSCALAR_FP16, MSCALAR_BF16, MSCALAR_FP32 = 0, 1, 2, 3
+
+
+def build(force: bool = False) -> Path:
+    """Compile libsdpa_ref.so with gcc if it is missing or stale."""
+    src = _HERE / "sdpa_ref.c"
+    if force or not _LIB_PATH.exists() or _LIB_PATH.stat().st_mtime < src.stat().st_mtime:
+        subprocess.check_call(["make", "-C", str(_HERE), "-B", "libsdpa_ref.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(str(_LIB_PATH))
+        i64p = ctypes.POINTER(ctypes.c_int64)
+        _lib.ref_sdpa_forward.restype = ctypes.c_int
+        _lib.ref_sdpa_forward.argtypes = [
+            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+            ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+            ctypes.c_float, ctypes.c_int, ctypes.c_int, i64p, i64p, i64p,
+            ctypes.c_void_p, i64p, i64p, ctypes.c_uint32, ctypes.c_int, ctypes.c_int]
+        _lib.ref_sdpa_backward.restype = ctypes.c_int
+        _lib.ref_sdpa_backward.argtypes = [ctypes.c_void_p] * 10 + [
+            ctypes.c_uint32] * 5 + [ctypes.c_float, ctypes.c_int, ctypes.c_int]
+        _lib.ref_quantize_symmetric.restype = None
+        _lib.ref_quantize_symmetric.argtypes = [
+            ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+        _lib.ref_pack_int4.restype = None
+        _lib.ref_pack_int4.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        _lib.ref_unpack_int4.restype = None
+        _lib.ref_unpack_int4.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        _lib.ref_dequantize.restype = None
+        _lib.ref_dequantize.argtypes = [
+            ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+        _lib.ref_quantized_forward.restype = ctypes.c_int
+        _lib.ref_quantized_forward.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_uint32] * 5 + [
+            ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_int]
+    return _lib
+
+
+def prec_of(a: np.ndarray) -> int:
+    if a.dtype == np.float32:
+        return PREC_FP32
+    if a.dtype == np.float16:
+        return PREC_FP16
+    if a.dtype == np.uint16:
+        return PREC_BF16
+    raise TypeError(f"unsupported operand dtype {a.dtype}")
+
+
+def f32_to_bf16_bits(x: np.ndarray) -> np.ndarray:
+    """Round-to-nearest-even fp32 -> bf16 bits (MFAFFITests.swift:616-645)."""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    r = (u + 0x7FFF + ((u >> 16) & 1)) >> 16
+    return r.astype(np.uint16)
+
+
+def bf16_bits_to_f32(b: np.ndarray) -> np.ndarray:
+    return (b.astype(np.uint32) << 16).view(np.float32)
+
+
+def to_f32(a: np.ndarray) -> np.ndarray:
+    return bf16_bits_to_f32(a) if a.dtype == np.uint16 else a.astype(np.float32)
+
+
+def _i64(arr):
+    if arr is None:
+        return None
+    a = (ctypes.c_int64 * len(arr))(*[int(x) for x in arr])
+    return a
+
+
+def _elem_strides(a: np.ndarray):
+    return [s // a.itemsize for s in a.strides]
+
+
+def sdpa_forward(q, k, v, scale=None, causal=False, mask=None, mask_type=MASK_NONE,
+                 return_lse=False):
+    """q [B,H,Sq,D], k/v [B,H,Skv,D] (any element strides, last dim contiguous or not).
+
+    mask: numpy array of <=4 dims, bool/uint8 (MASK_BOOL) or fp32/fp16/uint16-bf16
+    (MASK_ADDITIVE); broadcast right-aligned onto [B,H,Sq,Skv].
+    Returns fp32 O [B,H,Sq,D] (and fp32 LSE [B,H,Sq], natural log).
+    """
+    B, H, Sq, D = q.shape
+    Skv = k.shape[2]
+    prec = prec_of(q)
+    assert prec_of(k) == prec and prec_of(v) == prec
+    if scale is None:
+        scale = 1.0 / np.sqrt(D)
+    out = np.empty((B, H, Sq, D), np.float32)
+    lse = np.empty((B, H, Sq), np.float32)
+    mptr, mshape, mstr, mnd, mscalar = None, None, None, 0, MSCALAR_BYTE
+    if mask is not None and mask_type != MASK_NONE:
+        if mask.dtype == np.bool_:
+            mask = mask.view(np.uint8)
+        mscalar = {np.dtype(np.uint8): MSCALAR_BYTE, np.dtype(np.float16): MSCALAR_FP16,
+                   np.dtype(np.uint16): MSCALAR_BF16, np.dtype(np.float32): MSCALAR_FP32}[mask.dtype]
+        mptr = mask.ctypes.data
+        mshape, mstr, mnd = _i64(mask.shape), _i64(_elem_strides(mask)), mask.ndim
+    rc = lib().ref_sdpa_forward(
+        q.ctypes.data, k.ctypes.data, v.ctypes.data, out.ctypes.data, lse.ctypes.data,
+        B, H, Sq, Skv, D, float(scale), int(bool(causal)), prec,
+        _i64(_elem_strides(q)), _i64(_elem_strides(k)), _i64(_elem_strides(v)),
+        mptr, mshape, mstr, mnd, int(mask_type), mscalar)
+    if rc != 0:
+        raise RuntimeError(f"ref_sdpa_forward rc={rc}")
+    return (out, lse) if return_lse else out
+
+
+def sdpa_backward(dout, q, k, v, out, lse, scale=None, causal=False):
+    """Dense contiguous BHSD.  Returns fp32 (dq, dk, dv, D)."""
+    B, H, Sq, D = q.shape
+    Skv = k.shape[2]
+    prec = prec_of(q)
+    if scale is None:
+        scale = 1.0 / np.sqrt(D)
+    dout, q, k, v = (np.ascontiguousarray(a) for a in (dout, q, k, v))
+    out = np.ascontiguousarray(out, np.float32)
+    lse = np.ascontiguousarray(lse, np.float32)
+    dq = np.empty((B, H, Sq, D), np.float32)
+    dk = np.empty((B, H, Skv, D), np.float32)
+    dv = np.empty((B, H, Skv, D), np.float32)
+    dvec = np.empty((B, H, Sq), np.float32)
+    rc = lib().ref_sdpa_backward(
+        dout.ctypes.data, q.ctypes.data, k.ctypes.data, v.ctypes.data, out.ctypes.data,
+        lse.ctypes.data, dq.ctypes.data, dk.ctypes.data, dv.ctypes.data, dvec.ctypes.data,
+        B, H, Sq, Skv, D, float(scale), int(bool(causal)), prec)
+    if rc != 0:
+        raise RuntimeError(f"ref_sdpa_backward rc={rc}")
+    return dq, dk, dv, dvec
+
+
+def quantize_symmetric(x: np.ndarray, group: int | None = None, bits: int = 8):
+    """Returns (int8 values, fp32 scales); QuantizationTests.swift:72-128."""
+    x = np.ascontiguousarray(x, np.float32).ravel()
+    n = x.size
+    group = n if group is None else int(group)
+    q = np.empty(n, np.int8)
+    scales = np.empty((n + group - 1) // group, np.float32)
+    lib().ref_quantize_symmetric(x.ctypes.data, n, group, bits, q.ctypes.data, scales.ctypes.data)
+    return q, scales
+
+
+def pack_int4(q: np.ndarray) -> np.ndarray:
+    q = np.ascontiguousarray(q, np.int8).ravel()
+    out = np.empty((q.size + 1) // 2, np.uint8)
+    lib().ref_pack_int4(q.ctypes.data, q.size, out.ctypes.data)
+    return out
+
+
+def unpack_int4(packed: np.ndarray, n: int) -> np.ndarray:
+    packed = np.ascontiguousarray(packed, np.uint8).ravel()
+    out = np.empty(n, np.int8)
+    lib().ref_unpack_int4(packed.ctypes.data, n, out.ctypes.data)
+    return out
+
+
+def dequantize(q: np.ndarray, scales: np.ndarray, group: int | None = None) -> np.ndarray:
+    q = np.ascontiguousarray(q, np.int8).ravel()
+    scales = np.ascontiguousarray(scales, np.float32)
+    group = q.size if group is None else int(group)
+    out = np.empty(q.size, np.float32)
+    lib().ref_dequantize(q.ctypes.data, q.size, group, scales.ctypes.data, out.ctypes.data)
+    return out
+
+
+def quantized_forward(q, k, v, scale=None, causal=False, mask=None, bits=8, quant_mode=2,
+                      block_rows=64):
+    """MFABridge+Quantized.swift:227-358 restated: fake-quantise Q,K,V then fp64 SDPA."""
+    B, H, Sq, D = q.shape
+    Skv = k.shape[2]
+    prec = prec_of(q)
+    if scale is None:
+        scale = 1.0 / np.sqrt(D)
+    q, k, v = (np.ascontiguousarray(a) for a in (q, k, v))
+    out = np.empty((B, H, Sq, D), np.float32)
+    lse = np.empty((B, H, Sq), np.float32)
+    mptr = None
+    if mask is not None:
+        mask = np.ascontiguousarray(np.broadcast_to(mask, (B, H, Sq, Skv)), np.float32)
+        mptr = mask.ctypes.data
+    rc = lib().ref_quantized_forward(
+        q.ctypes.data, k.ctypes.data, v.ctypes.data, out.ctypes.data, lse.ctypes.data, mptr,
+        B, H, Sq, Skv, D, float(scale), int(bool(causal)), bits, quant_mode, block_rows, prec)
+    if rc != 0:
+        raise RuntimeError(f"ref_quantized_forward rc={rc}")
+    return out, lse
+
+
+def lcg_uniform(count: int, seed: int) -> np.ndarray:
+    """The reference tests' deterministic generator (MultiHeadFFITests.swift:1533-1541):
+    rng = rng*1664525 + 1013904223 (mod 2^64); value = ((rng % 1e6)/1e6 - 0.5)*2 in fp32."""
+    out = np.empty(count, np.float32)
+    rng = seed & 0xFFFFFFFFFFFFFFFF
+    for i in range(count):
+        rng = (rng * 1664525 + 1013904223) & 0xFFFFFFFFFFFFFFFF
+        out[i] = (np.float32(rng % 1_000_000) / np.float32(1_000_000.0) - np.float32(0.5)) * np.float32(2.0)
+    return out

@@ -255,8 +255,8 @@ void ref_quantize_symmetric(const float* x, size_t n, size_t group, int bits, in
 void ref_pack_int4(const int8_t* q, size_t n, uint8_t* packed) {
     for (size_t i = 0; i < n; i += 2) {
         int a = q[i] + 8, b = (i + 1 < n ? q[i + 1] : 0) + 8;
-        if (a < 0) a = 0; if (a > 15) a = 15;
-        if (b < 0) b = 0; if (b > 15) b = 15;
+        a = a < 0 ? 0 : (a > 15 ? 15 : a);
+        b = b < 0 ? 0 : (b > 15 ? 15 : b);
         packed[i / 2] = (uint8_t)((b << 4) | a);
     }
 }

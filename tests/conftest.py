@@ -1,0 +1,28 @@
+"""pytest configuration: `gpu` marker + shared paths.
+
+`-m "not gpu"` runs here (no GPU): oracle vs golden vectors, host logic, C-ABI
+symbol checks, gloo multi-process sharding.  `-m gpu` runs on the MI355X box:
+the HIP path through the C ABI against the oracle and the golden fixtures.
+"""
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+PKG = ROOT / "universal-metal-flash-attention_amd"
+for p in (str(ROOT), str(PKG)):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = ROOT / "tests" / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run via gpurun / the driver)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
