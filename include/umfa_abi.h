@@ -1,0 +1,326 @@
+/*
+ * umfa_abi.h -- the C ABI of libMFAFFI.so for AMD Instinct MI355X (gfx950).
+ *
+ * Drop-in boundary: every entry point below keeps the name, argument order,
+ * argument widths and return convention of the symbol the reference exports
+ * from its Swift bridge, so the existing ctypes / bindgen / C++ callers bind
+ * unchanged.  Citations are to the reference tree
+ * (bghira/universal-metal-flash-attention):
+ *   [H]  Sources/MFAFFI/include/mfa_ffi.h            (29 declared symbols)
+ *   [B]  Sources/MFABridge/MFABridge.swift           (@_cdecl bodies)
+ *   [Q]  Sources/MFABridge/MFABridge+Quantized.swift
+ *   [L]  Sources/MFABridge/QuantizedLayoutManifest+FFI.swift
+ *   [T]  examples/pytorch-custom-op-ffi/include/metal_sdpa_backend.h (13 undeclared symbols)
+ *   [M]  examples/pytorch-custom-op-ffi/src/mps_utils.mm
+ *
+ * ROCm reading of the opaque pointers (ABI-preserving):
+ *   "command_buffer"              -> hipStream_t the work is enqueued on
+ *   "*_buffer" in *_encode_mtl    -> raw device pointer
+ *   "metal_buffer" in *_from_mtl_buffer* -> raw device pointer (borrowed)
+ *   data_ptr in mfa_buffer_from_ptr*     -> host OR device pointer (detected);
+ *       host memory is staged to HBM before and copied back after each
+ *       synchronous op so results are visible in the caller's memory on return.
+ *
+ * Tensor layout is contiguous [batch, heads, seq, head_dim] ("BHSD",
+ * metal_sdpa_backend.cpp:188-193); attention outputs and gradients are always
+ * fp32 ([B] 1074-1433 ignores output_precision; MultiHeadFFITests.swift:171-173).
+ * The library never throws across the boundary and never falls back to the CPU:
+ * without a usable gfx950 device mfa_create_context returns 3.
+ */
+#ifndef UMFA_ABI_H
+#define UMFA_ABI_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes, [H]:17-26 -------------------------------------------- */
+typedef int mfa_error_t;
+enum {
+    MFA_SUCCESS = 0,
+    MFA_ERROR_INVALID_ARGS = 1,
+    MFA_ERROR_MEMORY_ALLOCATION = 2,
+    MFA_ERROR_DEVICE_NOT_SUPPORTED = 3,
+    MFA_ERROR_KERNEL_COMPILATION = 4,
+    MFA_ERROR_EXECUTION_FAILED = 5
+};
+
+/* ---- element encodings, [H]:33-41 ---------------------------------------- */
+typedef int mfa_precision_t;
+enum {
+    MFA_PRECISION_FP16 = 0,
+    MFA_PRECISION_BF16 = 1,
+    MFA_PRECISION_FP32 = 2,
+    MFA_PRECISION_INT8 = 3,
+    MFA_PRECISION_INT4 = 4
+};
+
+/* ---- attention masks, [H]:46-64; semantics [B]:157-242 -------------------- */
+typedef int mfa_mask_type_t;
+enum { MFA_MASK_TYPE_NONE = 0, MFA_MASK_TYPE_BOOL = 1, MFA_MASK_TYPE_ADDITIVE = 2 };
+typedef int mfa_mask_scalar_t;
+enum {
+    MFA_MASK_SCALAR_BYTE = 0,
+    MFA_MASK_SCALAR_FP16 = 1,
+    MFA_MASK_SCALAR_BF16 = 2,
+    MFA_MASK_SCALAR_FP32 = 3
+};
+
+/* ---- opaque handles, [H]:69,74,633 ---------------------------------------- */
+typedef void* mfa_context_t;
+typedef void* mfa_buffer_t;
+typedef void* mfa_mla_context_t;
+
+/* ---- quantised-kernel introspection, [H]:76-135, [L]:1-156 ---------------- */
+typedef enum {
+    MFA_QUANT_KERNEL_FORWARD = 0,
+    MFA_QUANT_KERNEL_BACKWARD_QUERY = 1,
+    MFA_QUANT_KERNEL_BACKWARD_KEY_VALUE = 2
+} mfa_quantized_kernel_t;
+
+/* 38 x int32 binding slots; the reference fills every slot with -1 ([L]:47-49). */
+typedef struct {
+    int32_t qData, kData, vData, output, gradOutput, logsumexp, gradQuery, dValues, gradKey,
+        gradValue;
+    int32_t qScale, qZeroPoint, kScale, kZeroPoint, vScale, vZeroPoint;
+    int32_t dims, steClipRange;
+    int32_t qBlockScales, qBlockZeroPoints, kBlockScales, kBlockZeroPoints, vBlockScales,
+        vBlockZeroPoints;
+    int32_t qPrecomputedSums, kPrecomputedSums, vPrecomputedSums;
+    int32_t qStrides, kStrides, vStrides, oStrides;
+    int32_t maskBuffer, numHeads, numKeyValueHeads, headDimension, sequenceLength;
+    int32_t scratch0, scratch1;
+} mfa_quantized_layout_t;
+
+typedef struct {
+    bool supports_multi_head_backward;
+    bool supports_blockwise_backward;
+    uint32_t max_heads;
+    uint32_t max_block_size;
+} mfa_quantized_capabilities_t;
+
+void mfa_get_quantized_layout(mfa_quantized_kernel_t kernel, mfa_quantized_layout_t* out_layout); /* [H]:123 */
+void mfa_get_quantized_capabilities(void* out_capabilities); /* [H]:135 -> {1,1,128,256}, [L]:126-131 */
+
+/* ---- context: process-wide singleton, +1 per create, [B]:782-805 ---------- */
+mfa_error_t mfa_create_context(mfa_context_t* context);   /* [H]:147 */
+void mfa_destroy_context(mfa_context_t context);          /* [H]:154 */
+
+/* ---- buffers, [B]:850-1070.  Wrapped memory is never freed by the library. - */
+mfa_error_t mfa_create_buffer(mfa_context_t context, size_t size_bytes, mfa_buffer_t* buffer); /* [H]:168 */
+mfa_error_t mfa_buffer_from_ptr(mfa_context_t context, void* data_ptr, size_t size_bytes,
+                                mfa_buffer_t* buffer); /* [H]:183 */
+mfa_error_t mfa_buffer_from_ptr_with_strides(mfa_context_t context, void* data_ptr,
+                                             size_t size_bytes, const int64_t* shape,
+                                             const int64_t* strides, uint32_t ndim,
+                                             mfa_buffer_t* buffer); /* [H]:193 */
+mfa_error_t mfa_buffer_from_mtl_buffer(mfa_context_t context, void* metal_buffer,
+                                       size_t size_bytes, mfa_buffer_t* buffer); /* [H]:206 */
+mfa_error_t mfa_buffer_from_mtl_buffer_with_strides(mfa_context_t context, void* metal_buffer,
+                                                    size_t size_bytes, const int64_t* shape,
+                                                    const int64_t* strides, uint32_t ndim,
+                                                    mfa_buffer_t* buffer); /* [H]:216 */
+void* mfa_buffer_contents(mfa_buffer_t buffer); /* [H]:232: host-visible pointer */
+void mfa_destroy_buffer(mfa_buffer_t buffer);   /* [H]:239 */
+
+/* ---- dense forward, synchronous, [H]:273-300, [B]:1074-1433 ---------------- */
+mfa_error_t mfa_attention_forward(
+    mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, mfa_buffer_t v, mfa_buffer_t out,
+    uint32_t batch_size, uint32_t seq_len_q, uint32_t seq_len_kv, uint32_t num_heads,
+    uint16_t head_dim, float softmax_scale, bool causal, mfa_precision_t input_precision,
+    mfa_precision_t intermediate_precision, mfa_precision_t output_precision, bool transpose_q,
+    bool transpose_k, bool transpose_v, bool transpose_o, const void* mask_ptr,
+    size_t mask_size_bytes, const int64_t* mask_shape, const int64_t* mask_strides,
+    uint32_t mask_ndim, mfa_mask_type_t mask_type, mfa_mask_scalar_t mask_scalar_type);
+
+/* Same, precisions as strings ("fp16","float16","bf16","bfloat16","fp32","float32","int8","int4";
+ * NULL/unknown -> fp32).  [T]:311-327, [B]:1438-1522. */
+mfa_error_t mfa_attention_forward_str(
+    mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, mfa_buffer_t v, mfa_buffer_t out,
+    uint32_t batch_size, uint32_t seq_len_q, uint32_t seq_len_kv, uint32_t num_heads,
+    uint16_t head_dim, float softmax_scale, bool causal, const char* input_precision,
+    const char* intermediate_precision, const char* output_precision, bool transpose_q,
+    bool transpose_k, bool transpose_v, bool transpose_o, const void* mask_ptr,
+    size_t mask_size_bytes, const int64_t* mask_shape, const int64_t* mask_strides,
+    uint32_t mask_ndim, mfa_mask_type_t mask_type, mfa_mask_scalar_t mask_scalar_type);
+
+/* ---- dense forward, asynchronous on the caller's stream, [H]:312-334, [B]:2377-2543.
+ * command_buffer = hipStream_t; *_buffer = device pointers; offsets in BYTES;
+ * q/k/v_strides = 4 x int64 ELEMENT strides in BHSD order (last must be 1) or NULL = dense;
+ * out is dense fp32 [B,H,Sq,D].  Never synchronises. */
+mfa_error_t mfa_attention_encode_mtl(
+    mfa_context_t context, void* command_buffer, void* q_buffer, int64_t q_offset,
+    const int64_t* q_strides, void* k_buffer, int64_t k_offset, const int64_t* k_strides,
+    void* v_buffer, int64_t v_offset, const int64_t* v_strides, void* out_buffer,
+    int64_t out_offset, void* mask_buffer, int64_t mask_offset, const int64_t* mask_shape,
+    const int64_t* mask_strides, uint32_t mask_ndim, mfa_mask_type_t mask_type,
+    mfa_mask_scalar_t mask_scalar_type, uint32_t batch_size, uint32_t seq_len_q,
+    uint32_t seq_len_kv, uint32_t num_heads, uint16_t head_dim, float softmax_scale, bool causal,
+    const char* input_precision, const char* intermediate_precision);
+
+/* ---- forward + log-sum-exp (fp32 [B*H*Sq], natural log), [T]:471-480, [B]:3078-3166 */
+int32_t mfa_attention_forward_with_lse(
+    mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, mfa_buffer_t v, mfa_buffer_t out,
+    mfa_buffer_t lse, uint32_t batch_size, uint32_t seq_len_q, uint32_t seq_len_kv,
+    uint32_t num_heads, uint16_t head_dim, float softmax_scale, bool causal,
+    int32_t input_precision, int32_t intermediate_precision, bool transpose_q, bool transpose_k,
+    bool transpose_v, bool transpose_o);
+
+/* ---- dense backward, [H]:407-438, [B]:3171-3282.  dq/dk/dv fp32; d_buffer fp32 [B*H*Sq]. */
+mfa_error_t mfa_attention_backward(
+    mfa_context_t context, mfa_buffer_t dout, mfa_buffer_t q, mfa_buffer_t k, mfa_buffer_t v,
+    mfa_buffer_t out, mfa_buffer_t softmax_lse, mfa_buffer_t dq, mfa_buffer_t dk, mfa_buffer_t dv,
+    mfa_buffer_t d_buffer, uint32_t batch_size, uint32_t seq_len_q, uint32_t seq_len_kv,
+    uint32_t num_heads, uint16_t head_dim, float softmax_scale, bool causal,
+    mfa_precision_t input_precision, mfa_precision_t intermediate_precision, bool transpose_q,
+    bool transpose_k, bool transpose_v, bool transpose_o);
+
+/* ---- runtime-quantised forward / backward, [T]:498-531, [Q]:227-533.
+ * target_precision 3 = INT8, 4 = INT4; quant_mode 0 = per tensor, 2 = block-wise;
+ * mask: fp32 additive [B,H,Sq,Skv] buffer or NULL. */
+int32_t mfa_quantized_forward_with_lse(
+    mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, mfa_buffer_t v, mfa_buffer_t out,
+    mfa_buffer_t lse, mfa_buffer_t mask, uint32_t batch_size, uint32_t seq_len_q,
+    uint32_t seq_len_kv, uint32_t num_heads, uint16_t head_dim, float softmax_scale, bool causal,
+    int32_t target_precision, int32_t quant_mode, int32_t input_precision);
+int32_t mfa_quantized_backward(
+    mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, mfa_buffer_t v, mfa_buffer_t out,
+    mfa_buffer_t grad_out, mfa_buffer_t lse, mfa_buffer_t grad_q, mfa_buffer_t grad_k,
+    mfa_buffer_t grad_v, mfa_buffer_t mask, uint32_t batch_size, uint32_t seq_len_q,
+    uint32_t seq_len_kv, uint32_t num_heads, uint16_t head_dim, float softmax_scale, bool causal,
+    int32_t target_precision, int32_t quant_mode, int32_t input_precision);
+
+/* ---- legacy "quantized" forwards.  In the reference all five funnel into
+ * mfa_attention_forward_quantized_direct, which ignores every quantisation
+ * argument and runs the dense forward ([Q]:12-218, [B]:2671-2899); kept so. ---- */
+#define UMFA_QUANT_LEGACY_ARGS                                                                    \
+    mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, mfa_buffer_t v, mfa_buffer_t out,      \
+        uint32_t batch_size, uint32_t seq_len_q, uint32_t seq_len_kv, uint32_t num_heads,         \
+        uint16_t head_dim, float softmax_scale, bool causal, float q_scale, int32_t q_zero_point, \
+        float k_scale, int32_t k_zero_point, float v_scale, int32_t v_zero_point
+mfa_error_t mfa_attention_forward_quantized(UMFA_QUANT_LEGACY_ARGS, mfa_precision_t q_precision,
+                                            mfa_precision_t k_precision,
+                                            mfa_precision_t v_precision,
+                                            mfa_precision_t output_precision, bool transpose_q,
+                                            bool transpose_k, bool transpose_v,
+                                            bool transpose_o); /* [H]:364 */
+mfa_error_t mfa_attention_forward_quantized_unified(
+    UMFA_QUANT_LEGACY_ARGS, mfa_precision_t q_precision, mfa_precision_t k_precision,
+    mfa_precision_t v_precision, mfa_precision_t output_precision, int32_t granularity,
+    uint32_t q_block_size, uint32_t k_block_size, uint32_t v_block_size,
+    bool enable_mixed_precision, bool force_symmetric_quantization, bool transpose_q,
+    bool transpose_k, bool transpose_v, bool transpose_o); /* [T]:380-395 */
+mfa_error_t mfa_attention_forward_quantized_enhanced(
+    UMFA_QUANT_LEGACY_ARGS, mfa_precision_t q_precision, mfa_precision_t k_precision,
+    mfa_precision_t v_precision, mfa_precision_t output_precision, int32_t granularity,
+    uint32_t q_block_size, uint32_t k_block_size, uint32_t v_block_size,
+    bool enable_mixed_precision, bool force_symmetric_quantization, bool transpose_q,
+    bool transpose_k, bool transpose_v, bool transpose_o); /* [T]:412-427 */
+mfa_error_t mfa_attention_forward_quantized_direct(UMFA_QUANT_LEGACY_ARGS, int32_t q_precision,
+                                                   int32_t k_precision, int32_t v_precision,
+                                                   int32_t output_precision, bool transpose_q,
+                                                   bool transpose_k, bool transpose_v,
+                                                   bool transpose_o); /* [T]:430-444, [Q]:12-218 */
+mfa_error_t mfa_multihead_attention_quantized_direct(UMFA_QUANT_LEGACY_ARGS, int32_t q_precision,
+                                                     int32_t k_precision,
+                                                     int32_t v_precision); /* [T]:446-455 */
+mfa_error_t mfa_set_scale_arrays(mfa_context_t context, const float* q_scales,
+                                 uint32_t q_scales_count, const float* k_scales,
+                                 uint32_t k_scales_count, const float* v_scales,
+                                 uint32_t v_scales_count); /* [T]:370-375, [B]:807-848 */
+
+/* ---- pre-quantised backward ABI ([H]:480-624).  Out of scope this round:
+ * the symbols link and return MFA_ERROR_DEVICE_NOT_SUPPORTED. ---------------- */
+#define UMFA_QBWD_TAIL                                                                            \
+    float q_scale, int32_t q_zero_point, float k_scale, int32_t k_zero_point, float v_scale,      \
+        int32_t v_zero_point, int32_t q_precision, int32_t k_precision, int32_t v_precision,      \
+        bool causal, bool transpose_q, bool transpose_k, bool transpose_v, bool transpose_o
+#define UMFA_QBWD_BLOCKS                                                                          \
+    mfa_buffer_t q_block_scales, mfa_buffer_t q_block_zero_points, mfa_buffer_t k_block_scales,   \
+        mfa_buffer_t k_block_zero_points, mfa_buffer_t v_block_scales,                            \
+        mfa_buffer_t v_block_zero_points, uint32_t q_block_size, uint32_t k_block_size,           \
+        uint32_t v_block_size, uint32_t options
+int32_t mfa_attention_backward_query_quantized(
+    mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, mfa_buffer_t v, mfa_buffer_t output,
+    mfa_buffer_t grad_output, mfa_buffer_t logsumexp, mfa_buffer_t grad_query,
+    mfa_buffer_t d_values, uint32_t batch_size, uint32_t seq_len_q, uint32_t seq_len_kv,
+    uint32_t num_heads, uint16_t head_dim, UMFA_QBWD_TAIL); /* [H]:480 */
+int32_t mfa_attention_backward_kv_quantized(
+    mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, mfa_buffer_t v,
+    mfa_buffer_t grad_output, mfa_buffer_t logsumexp, mfa_buffer_t d_values, mfa_buffer_t grad_key,
+    mfa_buffer_t grad_value, uint32_t batch_size, uint32_t seq_len_q, uint32_t seq_len_kv,
+    uint32_t num_heads, uint16_t head_dim, UMFA_QBWD_TAIL); /* [H]:511 */
+int32_t mfa_attention_backward_query_quantized_ex(
+    mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, mfa_buffer_t v, mfa_buffer_t output,
+    mfa_buffer_t grad_output, mfa_buffer_t logsumexp, mfa_buffer_t grad_query,
+    mfa_buffer_t d_values, uint32_t batch_size, uint32_t seq_len_q, uint32_t seq_len_kv,
+    uint32_t num_heads, uint32_t num_kv_heads, uint16_t head_dim, UMFA_QBWD_TAIL,
+    UMFA_QBWD_BLOCKS); /* [H]:542 */
+int32_t mfa_attention_backward_kv_quantized_ex(
+    mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, mfa_buffer_t v,
+    mfa_buffer_t grad_output, mfa_buffer_t logsumexp, mfa_buffer_t d_values, mfa_buffer_t grad_key,
+    mfa_buffer_t grad_value, uint32_t batch_size, uint32_t seq_len_q, uint32_t seq_len_kv,
+    uint32_t num_heads, uint32_t num_kv_heads, uint16_t head_dim, UMFA_QBWD_TAIL,
+    UMFA_QBWD_BLOCKS); /* [H]:584 */
+
+/* ---- utilities, [B]:1526-1617 ----------------------------------------------- */
+const char* mfa_error_string(mfa_error_t error); /* [H]:450; strdup'd, caller free()s */
+bool mfa_is_device_supported(void);              /* [H]:457: true iff a gfx950 device is usable */
+void mfa_get_version(int* major, int* minor, int* patch); /* [H]:466 -> 1.0.0 */
+double mfa_get_gpu_latency(mfa_context_t context); /* [H]:478: seconds, last synchronous op */
+int32_t mfa_has_native_bfloat(void);               /* [T]:458: 1 on gfx950 */
+int32_t mfa_has_native_bfloat_msl32(void);         /* [T]:459: 1 on gfx950 */
+
+/* ---- neighbours of the hot path that are NOT built this round:
+ * the symbols exist so existing callers link; each returns 3. ------------------ */
+int mfa_rope_rotate_encode_mtl(void* context, void* command_buffer, void* src_buffer,
+                               int64_t src_offset, int64_t src_batch_stride,
+                               int64_t src_head_stride, int64_t src_seq_stride, void* dst_buffer,
+                               int64_t dst_offset, void* cos_buffer, int64_t cos_offset,
+                               void* sin_buffer, int64_t sin_offset, int64_t table_batch_stride,
+                               bool negate_sin, uint32_t batch_size, uint32_t num_heads,
+                               uint32_t seq_len, uint32_t head_dim,
+                               const char* precision); /* [M]:9-22 */
+int32_t mfa_hadamard_rotate(mfa_buffer_t data, uint32_t block_size, uint32_t num_blocks); /* [T]:462-465 */
+mfa_error_t mfa_sparse_indexer_scores(mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k,
+                                      uint32_t batch_size, uint32_t num_heads, uint32_t seq_len_q,
+                                      uint32_t seq_len_k, uint16_t head_dim, float scale,
+                                      mfa_buffer_t scores_in, mfa_buffer_t* scores_out); /* [H]:393 */
+mfa_error_t mfa_mla_create_context(mfa_mla_context_t* context); /* [H]:644 */
+void mfa_mla_destroy_context(mfa_mla_context_t context);        /* [H]:651 */
+mfa_error_t mfa_mla_init_weights(mfa_mla_context_t context, uint32_t num_heads, uint32_t head_dim,
+                                 uint32_t kv_latent_dim); /* [H]:665 */
+mfa_error_t mfa_mla_load_weights(mfa_mla_context_t context, mfa_buffer_t wk, mfa_buffer_t wv); /* [H]:682 */
+mfa_error_t mfa_mla_forward(mfa_mla_context_t context, mfa_context_t mfa_context,
+                            mfa_buffer_t kv_latent, mfa_buffer_t* decompressed_k,
+                            mfa_buffer_t* decompressed_v, uint32_t batch_size, uint32_t num_heads,
+                            uint32_t sequence_length, uint32_t head_dim,
+                            uint32_t kv_latent_dim); /* [H]:709 */
+
+/* ---- MI355X additions (not in the reference; prefixed umfa_, safe to ignore) --
+ * Asynchronous launch of the bf16/fp16 forward with a caller-chosen output
+ * element type (0 = fp16, 1 = bf16, 2 = fp32) and optional LSE, so a PyTorch
+ * binding can skip the fp32-O round trip (metal_sdpa_backend.cpp:1418-1445). */
+mfa_error_t umfa_attention_forward_stream(
+    mfa_context_t context, void* stream, const void* q, const int64_t* q_strides, const void* k,
+    const int64_t* k_strides, const void* v, const int64_t* v_strides, void* out,
+    int32_t out_precision, float* lse, const void* mask, const int64_t* mask_shape,
+    const int64_t* mask_strides, uint32_t mask_ndim, mfa_mask_type_t mask_type,
+    mfa_mask_scalar_t mask_scalar_type, uint32_t batch_size, uint32_t seq_len_q,
+    uint32_t seq_len_kv, uint32_t num_heads, uint16_t head_dim, float softmax_scale, bool causal,
+    int32_t input_precision, int32_t intermediate_precision);
+/* Name of the kernel variant the last forward on this context dispatched to (static string). */
+const char* umfa_last_kernel_name(mfa_context_t context);
+
+#undef UMFA_QUANT_LEGACY_ARGS
+#undef UMFA_QBWD_TAIL
+#undef UMFA_QBWD_BLOCKS
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UMFA_ABI_H */

@@ -1,0 +1,114 @@
+// fa_common.h -- shared device/host definitions for the gfx950 attention kernels.
+//
+// Thread <-> matrix mapping used by every forward kernel here ("swapped QK^T",
+// cdna_hip_programming.md T12): a wave owns 32 query rows and computes
+// S^T = K Q^T with the 32x32 MFMA, so lane l holds query q = l & 31 and, in
+// accumulator register r of a 32-key block, key = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5).
+// Row max / row sum are therefore lane-local plus one lane <-> lane^32 exchange,
+// and O^T = V^T P^T takes the S^T accumulator as its B operand without any
+// cross-lane movement.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace umfa {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+enum Prec : int { P_FP16 = 0, P_BF16 = 1, P_FP32 = 2, P_INT8 = 3, P_INT4 = 4 };
+// mask kinds after host-side normalisation (mfa_mask_type_t x mfa_mask_scalar_t)
+enum MaskKind : int { MK_NONE = 0, MK_BOOL = 1, MK_F32 = 2, MK_F16 = 3, MK_BF16 = 4 };
+
+#define UMFA_LOG2E 1.4426950408889634f
+#define UMFA_LN2 0.6931471805599453f
+
+// One forward launch.  Strides are in ELEMENTS; head_dim is contiguous (stride 1).
+struct FwdParams {
+    const void* q;
+    const void* k;
+    const void* v;
+    void* o;            // dense [B,H,Sq,D], element type out_prec
+    float* lse;         // optional, [B*H*Sq], natural log
+    const void* mask;   // optional
+    int64_t qs[4], ks[4], vs[4];  // batch, head, seq, head_dim strides ([3] != 1 only on the exact path)
+    int64_t os[2];                // output seq / head_dim strides inside a (b,h) slab (dense: D, 1)
+    int64_t ms[4];                // mask strides for (b, h, q, k); 0 = broadcast
+    uint32_t B, H, Sq, Skv, D;
+    float scale;
+    int causal;
+    int mask_kind;
+    int in_prec;   // P_FP16 / P_BF16 / P_FP32
+    int out_prec;  // P_FP16 / P_BF16 / P_FP32
+    // int8 path only: per-block scales, see fa_quant
+    const float* q_scale;
+    const float* k_scale;
+    const float* v_scale;
+    uint32_t q_blk, k_blk;  // rows per scale block (0 = per tensor)
+};
+
+struct BwdParams {
+    const void* dout;
+    const void* q;
+    const void* k;
+    const void* v;
+    const float* o;
+    const float* lse;
+    float* dq;
+    float* dk;
+    float* dv;
+    float* dvec;
+    uint32_t B, H, Sq, Skv, D;
+    float scale;
+    int causal;
+    int in_prec;
+};
+
+__device__ __forceinline__ float bf16_bits_to_float(uint16_t b) {
+    return __uint_as_float(((uint32_t)b) << 16);
+}
+
+__device__ __forceinline__ float load_as_float(const void* p, int64_t idx, int prec) {
+    if (prec == P_FP32) return ((const float*)p)[idx];
+    if (prec == P_FP16) return (float)((const _Float16*)p)[idx];
+    return bf16_bits_to_float(((const uint16_t*)p)[idx]);
+}
+
+// Additive mask term in the log2 domain (already multiplied by log2 e); -inf = masked.
+// Semantics: MFABridge.swift:193-238 (bool: nonzero attends; bf16: bits << 16).
+__device__ __forceinline__ float mask_term(const void* mask, int64_t idx, int kind) {
+    switch (kind) {
+    case MK_BOOL: return ((const uint8_t*)mask)[idx] != 0 ? 0.0f : -INFINITY;
+    case MK_F32: return ((const float*)mask)[idx] * UMFA_LOG2E;
+    case MK_F16: return (float)((const _Float16*)mask)[idx] * UMFA_LOG2E;
+    case MK_BF16: return bf16_bits_to_float(((const uint16_t*)mask)[idx]) * UMFA_LOG2E;
+    default: return 0.0f;
+    }
+}
+
+// key index inside a 32-key block held by accumulator register r of lane-half hi
+__device__ __forceinline__ constexpr int acc_row(int r, int hi) {
+    return (r & 3) + 8 * (r >> 2) + 4 * hi;
+}
+
+__device__ __forceinline__ float xor32(float x) {
+    // exchange with lane ^ 32 (the other half of the wave)
+    return __shfl_xor(x, 32, 64);
+}
+
+// XCD-aware, bijective remap of a linear workgroup id (cdna_hip_programming.md T1):
+// blocks with equal id % 8 share an XCD, so give each XCD a contiguous slice of the
+// (batch*head, q-block) space and K/V of a head stay in that XCD's L2.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t id, uint32_t n) {
+    const uint32_t q = n >> 3, r = n & 7, x = id & 7;
+    const uint32_t base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + (id >> 3);
+}
+
+}  // namespace umfa

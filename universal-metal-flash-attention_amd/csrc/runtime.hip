@@ -1,0 +1,665 @@
+// runtime.hip -- host side of libMFAFFI.so on ROCm: the C ABI of include/umfa_abi.h.
+//
+// Replaces the reference's Swift bridge (Sources/MFABridge/*.swift): handle lifetime,
+// buffer wrapping, mask normalisation, kernel selection, launch and timing.  There is no
+// CPU fallback: every compute entry point needs a live gfx950 context.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/umfa_abi.h"
+#include "fa_common.h"
+#include "kernels.h"
+
+using namespace umfa;
+
+namespace {
+
+const bool g_debug = [] {
+    const char* e = getenv("MFA_DEBUG");
+    return e && e[0] == '1';
+}();
+#define DBG(...)                              \
+    do {                                      \
+        if (g_debug) {                        \
+            fprintf(stderr, "[umfa] " __VA_ARGS__); \
+            fputc('\n', stderr);              \
+        }                                     \
+    } while (0)
+
+// ---- context (MFAContext + GlobalContextStore, MFABridge.swift:91-150,652-687) -------------
+struct Context {
+    uint32_t magic = 0x4d464143;  // 'MFAC'
+    int device = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double last_latency = 0.0;
+    const char* last_kernel = "none";
+    void* scratch = nullptr;  // mask staging / quantiser workspace
+    size_t scratch_bytes = 0;
+    std::vector<float> q_scales, k_scales, v_scales;  // mfa_set_scale_arrays: stored, never read
+    std::atomic<int> refs{0};
+    std::mutex mu;
+
+    void* ensure_scratch(size_t bytes) {
+        if (bytes <= scratch_bytes) return scratch;
+        if (scratch) (void)hipFree(scratch);
+        scratch = nullptr;
+        scratch_bytes = 0;
+        size_t want = bytes + (bytes >> 2) + 256;
+        if (hipMalloc(&scratch, want) != hipSuccess) return nullptr;
+        scratch_bytes = want;
+        return scratch;
+    }
+};
+
+std::mutex g_ctx_mu;
+Context* g_ctx = nullptr;
+
+bool device_usable(int* dev_out) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return false;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        DBG("device %d is %s, not gfx950", dev, prop.gcnArchName);
+        return false;
+    }
+    if (dev_out) *dev_out = dev;
+    return true;
+}
+
+Context* as_ctx(mfa_context_t c) {
+    Context* x = (Context*)c;
+    return (x && x->magic == 0x4d464143) ? x : nullptr;
+}
+
+// ---- buffers (MFABuffer, MFABridge.swift:720-747, 850-1070) ---------------------------------
+struct Buffer {
+    uint32_t magic = 0x4d464142;  // 'MFAB'
+    void* host = nullptr;   // caller-visible memory (NULL for device-native wraps)
+    void* dev = nullptr;    // what kernels read/write
+    size_t bytes = 0;       // 0 = unknown (mfa_buffer_from_mtl_buffer with size 0)
+    bool owns_host = false, owns_dev = false;
+    std::vector<int64_t> shape, strides;
+
+    hipError_t upload(hipStream_t s) const {
+        if (!host || host == dev || bytes == 0) return hipSuccess;
+        return hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, s);
+    }
+    hipError_t download(hipStream_t s) const {
+        if (!host || host == dev || bytes == 0) return hipSuccess;
+        return hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s);
+    }
+    bool fits(size_t need) const { return bytes == 0 || need <= bytes; }
+};
+
+Buffer* as_buf(mfa_buffer_t b) {
+    Buffer* x = (Buffer*)b;
+    return (x && x->magic == 0x4d464142) ? x : nullptr;
+}
+
+bool is_device_pointer(const void* p) {
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof(a));
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // unregistered host memory on older runtimes
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+mfa_error_t wrap_pointer(void* ptr, size_t bytes, const int64_t* shape, const int64_t* strides,
+                         uint32_t ndim, bool force_device, mfa_buffer_t* out) {
+    Buffer* b = new (std::nothrow) Buffer();
+    if (!b) return MFA_ERROR_MEMORY_ALLOCATION;
+    b->bytes = bytes;
+    if (force_device || is_device_pointer(ptr)) {
+        b->dev = ptr;  // true zero copy: HBM-resident tensor (torch-ROCm path)
+    } else {
+        // discrete GPU: a host tensor needs an HBM mirror (Metal's unified memory made this free,
+        // MFABridge.swift:892-904); staged around every synchronous op.
+        b->host = ptr;
+        if (bytes > 0) {
+            if (hipMalloc(&b->dev, bytes) != hipSuccess) {
+                delete b;
+                return MFA_ERROR_MEMORY_ALLOCATION;
+            }
+            b->owns_dev = true;
+        }
+    }
+    if (shape && strides && ndim) {
+        b->shape.assign(shape, shape + ndim);
+        b->strides.assign(strides, strides + ndim);
+    }
+    *out = b;
+    return MFA_SUCCESS;
+}
+
+int parse_precision(const char* s) {  // MFABridge.swift:1438-1451
+    if (!s) return MFA_PRECISION_FP32;
+    std::string t(s);
+    for (auto& ch : t) ch = (char)tolower(ch);
+    if (t == "fp16" || t == "float16") return MFA_PRECISION_FP16;
+    if (t == "bf16" || t == "bfloat16") return MFA_PRECISION_BF16;
+    if (t == "fp32" || t == "float32") return MFA_PRECISION_FP32;
+    if (t == "int8") return MFA_PRECISION_INT8;
+    if (t == "int4") return MFA_PRECISION_INT4;
+    return MFA_PRECISION_FP32;
+}
+
+// dense path: any precision value other than 0/1 means FP32 (gemmPrecision, MFABridge.swift:1453-1462)
+int dense_prec(int p) { return p == 0 ? P_FP16 : p == 1 ? P_BF16 : P_FP32; }
+size_t elem_bytes(int prec) { return prec == P_FP32 ? 4 : 2; }
+
+// Normalise a <=4-D mask onto (b, h, q, k) strides; size-1 dims broadcast (MFABridge.swift:186-198).
+bool normalise_mask(const int64_t* shape, const int64_t* strides, uint32_t ndim, int type, int scalar,
+                    FwdParams& p) {
+    p.mask_kind = MK_NONE;
+    for (int i = 0; i < 4; ++i) p.ms[i] = 0;
+    if (type == MFA_MASK_TYPE_NONE || ndim == 0 || ndim > 4 || !shape || !strides) return false;
+    for (uint32_t i = 0; i < ndim; ++i) {
+        const int coord = 4 - (int)ndim + (int)i;
+        p.ms[coord] = shape[i] == 1 ? 0 : strides[i];
+    }
+    if (type == MFA_MASK_TYPE_BOOL) p.mask_kind = MK_BOOL;
+    else if (type == MFA_MASK_TYPE_ADDITIVE) {
+        p.mask_kind = scalar == MFA_MASK_SCALAR_FP32 ? MK_F32
+                      : scalar == MFA_MASK_SCALAR_FP16 ? MK_F16
+                      : scalar == MFA_MASK_SCALAR_BF16 ? MK_BF16
+                                                       : MK_NONE;  // additive bytes: 0.0 (MFABridge.swift:227-229)
+    }
+    return p.mask_kind != MK_NONE;
+}
+
+void dense_strides(FwdParams& p, bool tq, bool tk, bool tv, bool to) {
+    // row-major per head [S, D]; "transposed" = per-head [D, S] storage (mfa_ffi.h:266-269)
+    auto set = [](int64_t* s, uint32_t H, uint32_t S, uint32_t D, bool t) {
+        s[0] = (int64_t)H * S * D;
+        s[1] = (int64_t)S * D;
+        s[2] = t ? 1 : D;
+        s[3] = t ? S : 1;
+    };
+    set(p.qs, p.H, p.Sq, p.D, tq);
+    set(p.ks, p.H, p.Skv, p.D, tk);
+    set(p.vs, p.H, p.Skv, p.D, tv);
+    p.os[0] = to ? 1 : p.D;
+    p.os[1] = to ? p.Sq : 1;
+}
+
+// Kernel selection for the dense forward.
+hipError_t dispatch_forward(Context* ctx, const FwdParams& p, int intermediate_prec, hipStream_t stream) {
+    const char* name = "none";
+    hipError_t e;
+    const bool lowp = p.in_prec != P_FP32 && intermediate_prec != P_FP32;
+    if (lowp && fwd_16_supported(p)) e = launch_fwd_16(p, stream, &name);
+    else e = launch_fwd_exact(p, stream, &name);
+    ctx->last_kernel = name;
+    DBG("forward B%u H%u Sq%u Skv%u D%u causal%d mask%d -> %s (%s)", p.B, p.H, p.Sq, p.Skv, p.D, p.causal,
+        p.mask_kind, name, hipGetErrorString(e));
+    return e;
+}
+
+mfa_error_t map_hip(hipError_t e) {
+    if (e == hipSuccess) return MFA_SUCCESS;
+    if (e == hipErrorOutOfMemory) return MFA_ERROR_MEMORY_ALLOCATION;
+    if (e == hipErrorInvalidValue) return MFA_ERROR_INVALID_ARGS;
+    return MFA_ERROR_EXECUTION_FAILED;
+}
+
+struct Timed {  // hipEvent pair around a synchronous op -> mfa_get_gpu_latency
+    Context* c;
+    hipStream_t s;
+    Timed(Context* c_, hipStream_t s_) : c(c_), s(s_) { (void)hipEventRecord(c->ev0, s); }
+    hipError_t finish() {
+        (void)hipEventRecord(c->ev1, s);
+        hipError_t e = hipStreamSynchronize(s);
+        if (e == hipSuccess) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->last_latency = ms * 1e-3;
+        }
+        return e;
+    }
+};
+
+// Shared body of the synchronous dense forwards.
+mfa_error_t forward_sync(mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, mfa_buffer_t v, mfa_buffer_t out,
+                         mfa_buffer_t lse, uint32_t B, uint32_t Sq, uint32_t Skv, uint32_t H, uint16_t D,
+                         float scale, bool causal, int in_prec_raw, int inter_prec_raw, bool tq, bool tk, bool tv,
+                         bool to, const void* mask_ptr, size_t mask_bytes, const int64_t* mshape,
+                         const int64_t* mstrides, uint32_t mndim, int mtype, int mscalar, bool want_lse) {
+    Context* ctx = as_ctx(context);
+    Buffer *bq = as_buf(q), *bk = as_buf(k), *bv = as_buf(v), *bo = as_buf(out), *bl = as_buf(lse);
+    if (!ctx || !bq || !bk || !bv || !bo || (want_lse && !bl)) return MFA_ERROR_INVALID_ARGS;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    hipStream_t stream = nullptr;
+
+    FwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv; p.D = D;
+    p.scale = scale;
+    p.causal = causal ? 1 : 0;
+    p.in_prec = dense_prec(in_prec_raw);
+    p.out_prec = P_FP32;  // output_precision is ignored by the reference: O is fp32 (MFABridge.swift:1089)
+    const int inter = dense_prec(inter_prec_raw);
+    dense_strides(p, tq, tk, tv, to);
+
+    const size_t nq = (size_t)B * H * Sq * D, nkv = (size_t)B * H * Skv * D;
+    const size_t eb = elem_bytes(p.in_prec);
+    // bounds: refuse to overrun a wrapped buffer
+    if (!bq->fits(nq * eb) || !bk->fits(nkv * eb) || !bv->fits(nkv * eb) || !bo->fits(nq * 4)) return MFA_ERROR_INVALID_ARGS;
+    if (want_lse && !bl->fits((size_t)B * H * Sq * 4)) return MFA_ERROR_INVALID_ARGS;
+    if (nq == 0 || nkv == 0) return MFA_SUCCESS;  // nothing to compute
+    if (D > 256) return MFA_ERROR_INVALID_ARGS;
+
+    p.q = bq->dev; p.k = bk->dev; p.v = bv->dev; p.o = bo->dev;
+    p.lse = want_lse ? (float*)bl->dev : nullptr;
+
+    // mask: copy the caller's bytes to HBM (the reference copies them too, MFABridge.swift:394-408)
+    const bool mask_given = mtype != MFA_MASK_TYPE_NONE && mask_ptr && mask_bytes > 0 && mshape && mstrides && mndim > 0;
+    if (mask_given && mndim <= 4 && normalise_mask(mshape, mstrides, mndim, mtype, mscalar, p)) {
+        if (is_device_pointer(mask_ptr)) {
+            p.mask = mask_ptr;
+        } else {
+            void* d = ctx->ensure_scratch(mask_bytes);
+            if (!d) return MFA_ERROR_MEMORY_ALLOCATION;
+            if (hipMemcpyAsync(d, mask_ptr, mask_bytes, hipMemcpyHostToDevice, stream) != hipSuccess)
+                return MFA_ERROR_EXECUTION_FAILED;
+            p.mask = d;
+        }
+    }
+
+    if (bq->upload(stream) != hipSuccess || bk->upload(stream) != hipSuccess || bv->upload(stream) != hipSuccess)
+        return MFA_ERROR_EXECUTION_FAILED;
+    Timed timer(ctx, stream);
+    hipError_t e = dispatch_forward(ctx, p, inter, stream);
+    if (e != hipSuccess) return e == hipErrorInvalidValue ? MFA_ERROR_INVALID_ARGS : MFA_ERROR_EXECUTION_FAILED;
+    (void)hipEventRecord(ctx->ev1, stream);
+    if (bo->download(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+    if (want_lse && bl->download(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+    e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->last_latency = ms * 1e-3;
+    return MFA_SUCCESS;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ============================ context ============================
+mfa_error_t mfa_create_context(mfa_context_t* context) {
+    std::lock_guard<std::mutex> lock(g_ctx_mu);
+    if (!g_ctx) {
+        int dev = 0;
+        if (!device_usable(&dev)) return MFA_ERROR_DEVICE_NOT_SUPPORTED;
+        Context* c = new (std::nothrow) Context();
+        if (!c) return MFA_ERROR_MEMORY_ALLOCATION;
+        c->device = dev;
+        if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+            delete c;
+            return MFA_ERROR_MEMORY_ALLOCATION;
+        }
+        g_ctx = c;
+    }
+    g_ctx->refs.fetch_add(1);
+    if (context) *context = g_ctx;
+    return MFA_SUCCESS;
+}
+
+void mfa_destroy_context(mfa_context_t context) {
+    Context* c = as_ctx(context);
+    if (!c) return;
+    c->refs.fetch_sub(1);  // the process-wide singleton itself stays alive (GlobalContextStore)
+}
+
+// ============================ buffers ============================
+mfa_error_t mfa_create_buffer(mfa_context_t context, size_t size_bytes, mfa_buffer_t* buffer) {
+    Context* ctx = as_ctx(context);
+    if (!ctx || !buffer) return MFA_ERROR_INVALID_ARGS;
+    Buffer* b = new (std::nothrow) Buffer();
+    if (!b) return MFA_ERROR_MEMORY_ALLOCATION;
+    b->bytes = size_bytes;
+    const size_t alloc = size_bytes ? size_bytes : 16;
+    // pinned host side (mfa_buffer_contents) + HBM mirror
+    if (hipHostMalloc(&b->host, alloc, hipHostMallocDefault) != hipSuccess) {
+        delete b;
+        return MFA_ERROR_MEMORY_ALLOCATION;
+    }
+    b->owns_host = true;
+    memset(b->host, 0, alloc);
+    if (hipMalloc(&b->dev, alloc) != hipSuccess) {
+        (void)hipHostFree(b->host);
+        delete b;
+        return MFA_ERROR_MEMORY_ALLOCATION;
+    }
+    b->owns_dev = true;
+    *buffer = b;
+    return MFA_SUCCESS;
+}
+
+mfa_error_t mfa_buffer_from_ptr(mfa_context_t context, void* data_ptr, size_t size_bytes, mfa_buffer_t* buffer) {
+    if (!as_ctx(context) || !data_ptr || !buffer) return MFA_ERROR_INVALID_ARGS;
+    return wrap_pointer(data_ptr, size_bytes, nullptr, nullptr, 0, false, buffer);
+}
+
+mfa_error_t mfa_buffer_from_ptr_with_strides(mfa_context_t context, void* data_ptr, size_t size_bytes,
+                                             const int64_t* shape, const int64_t* strides, uint32_t ndim,
+                                             mfa_buffer_t* buffer) {
+    if (!as_ctx(context) || !data_ptr || !buffer || !shape || !strides || ndim == 0) return MFA_ERROR_INVALID_ARGS;
+    return wrap_pointer(data_ptr, size_bytes, shape, strides, ndim, false, buffer);
+}
+
+// "metal_buffer" = raw device pointer on ROCm; context is unused by the reference too (MFABridge.swift:981)
+mfa_error_t mfa_buffer_from_mtl_buffer(mfa_context_t, void* metal_buffer, size_t size_bytes, mfa_buffer_t* buffer) {
+    if (!metal_buffer || !buffer) return MFA_ERROR_INVALID_ARGS;
+    return wrap_pointer(metal_buffer, size_bytes, nullptr, nullptr, 0, true, buffer);
+}
+
+mfa_error_t mfa_buffer_from_mtl_buffer_with_strides(mfa_context_t, void* metal_buffer, size_t size_bytes,
+                                                    const int64_t* shape, const int64_t* strides, uint32_t ndim,
+                                                    mfa_buffer_t* buffer) {
+    if (!metal_buffer || !buffer || !shape || !strides || ndim == 0) return MFA_ERROR_INVALID_ARGS;
+    return wrap_pointer(metal_buffer, size_bytes, shape, strides, ndim, true, buffer);
+}
+
+void* mfa_buffer_contents(mfa_buffer_t buffer) {
+    Buffer* b = as_buf(buffer);
+    if (!b) return nullptr;
+    return b->host ? b->host : b->dev;
+}
+
+void mfa_destroy_buffer(mfa_buffer_t buffer) {
+    Buffer* b = as_buf(buffer);
+    if (!b) return;
+    if (b->owns_dev && b->dev) (void)hipFree(b->dev);
+    if (b->owns_host && b->host) (void)hipHostFree(b->host);
+    b->magic = 0;
+    delete b;
+}
+
+// ============================ dense forward ============================
+mfa_error_t mfa_attention_forward(mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, mfa_buffer_t v,
+                                  mfa_buffer_t out, uint32_t batch_size, uint32_t seq_len_q, uint32_t seq_len_kv,
+                                  uint32_t num_heads, uint16_t head_dim, float softmax_scale, bool causal,
+                                  mfa_precision_t input_precision, mfa_precision_t intermediate_precision,
+                                  mfa_precision_t /*output_precision*/, bool transpose_q, bool transpose_k,
+                                  bool transpose_v, bool transpose_o, const void* mask_ptr, size_t mask_size_bytes,
+                                  const int64_t* mask_shape, const int64_t* mask_strides, uint32_t mask_ndim,
+                                  mfa_mask_type_t mask_type, mfa_mask_scalar_t mask_scalar_type) {
+    return forward_sync(context, q, k, v, out, nullptr, batch_size, seq_len_q, seq_len_kv, num_heads, head_dim,
+                        softmax_scale, causal, input_precision, intermediate_precision, transpose_q, transpose_k,
+                        transpose_v, transpose_o, mask_ptr, mask_size_bytes, mask_shape, mask_strides, mask_ndim,
+                        mask_type, mask_scalar_type, false);
+}
+
+mfa_error_t mfa_attention_forward_str(mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, mfa_buffer_t v,
+                                      mfa_buffer_t out, uint32_t batch_size, uint32_t seq_len_q,
+                                      uint32_t seq_len_kv, uint32_t num_heads, uint16_t head_dim,
+                                      float softmax_scale, bool causal, const char* input_precision,
+                                      const char* intermediate_precision, const char* output_precision,
+                                      bool transpose_q, bool transpose_k, bool transpose_v, bool transpose_o,
+                                      const void* mask_ptr, size_t mask_size_bytes, const int64_t* mask_shape,
+                                      const int64_t* mask_strides, uint32_t mask_ndim, mfa_mask_type_t mask_type,
+                                      mfa_mask_scalar_t mask_scalar_type) {
+    return mfa_attention_forward(context, q, k, v, out, batch_size, seq_len_q, seq_len_kv, num_heads, head_dim,
+                                 softmax_scale, causal, parse_precision(input_precision),
+                                 parse_precision(intermediate_precision), parse_precision(output_precision),
+                                 transpose_q, transpose_k, transpose_v, transpose_o, mask_ptr, mask_size_bytes,
+                                 mask_shape, mask_strides, mask_ndim, mask_type, mask_scalar_type);
+}
+
+int32_t mfa_attention_forward_with_lse(mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, mfa_buffer_t v,
+                                       mfa_buffer_t out, mfa_buffer_t lse, uint32_t batch_size, uint32_t seq_len_q,
+                                       uint32_t seq_len_kv, uint32_t num_heads, uint16_t head_dim,
+                                       float softmax_scale, bool causal, int32_t input_precision,
+                                       int32_t intermediate_precision, bool transpose_q, bool transpose_k,
+                                       bool transpose_v, bool transpose_o) {
+    return forward_sync(context, q, k, v, out, lse, batch_size, seq_len_q, seq_len_kv, num_heads, head_dim,
+                        softmax_scale, causal, input_precision, intermediate_precision, transpose_q, transpose_k,
+                        transpose_v, transpose_o, nullptr, 0, nullptr, nullptr, 0, MFA_MASK_TYPE_NONE, 0, true);
+}
+
+mfa_error_t umfa_attention_forward_stream(mfa_context_t context, void* stream, const void* q, const int64_t* q_strides,
+                                          const void* k, const int64_t* k_strides, const void* v,
+                                          const int64_t* v_strides, void* out, int32_t out_precision, float* lse,
+                                          const void* mask, const int64_t* mask_shape, const int64_t* mask_strides,
+                                          uint32_t mask_ndim, mfa_mask_type_t mask_type,
+                                          mfa_mask_scalar_t mask_scalar_type, uint32_t batch_size, uint32_t seq_len_q,
+                                          uint32_t seq_len_kv, uint32_t num_heads, uint16_t head_dim,
+                                          float softmax_scale, bool causal, int32_t input_precision,
+                                          int32_t intermediate_precision) {
+    Context* ctx = as_ctx(context);
+    if (!ctx || !q || !k || !v || !out) return MFA_ERROR_INVALID_ARGS;
+    if (head_dim == 0 || head_dim > 256) return MFA_ERROR_INVALID_ARGS;
+    FwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.B = batch_size; p.H = num_heads; p.Sq = seq_len_q; p.Skv = seq_len_kv; p.D = head_dim;
+    p.scale = softmax_scale;
+    p.causal = causal ? 1 : 0;
+    p.in_prec = dense_prec(input_precision);
+    p.out_prec = dense_prec(out_precision);
+    dense_strides(p, false, false, false, false);
+    auto take = [](int64_t* dst, const int64_t* src) -> bool {
+        if (!src) return true;
+        for (int i = 0; i < 4; ++i) dst[i] = src[i];
+        return src[3] == 1 && src[0] >= 0 && src[1] >= 0 && src[2] >= 0;  // last dim contiguous, strides > 0
+    };
+    if (!take(p.qs, q_strides) || !take(p.ks, k_strides) || !take(p.vs, v_strides)) return MFA_ERROR_INVALID_ARGS;
+    p.q = q; p.k = k; p.v = v; p.o = out; p.lse = lse;
+    if (mask_type != MFA_MASK_TYPE_NONE) {
+        if (!mask || !mask_shape || !mask_strides || mask_ndim == 0 || mask_ndim > 4) return MFA_ERROR_INVALID_ARGS;
+        normalise_mask(mask_shape, mask_strides, mask_ndim, mask_type, mask_scalar_type, p);
+        p.mask = mask;
+    }
+    if ((size_t)batch_size * num_heads * seq_len_q * seq_len_kv == 0) return MFA_SUCCESS;
+    hipError_t e = dispatch_forward(ctx, p, dense_prec(intermediate_precision), (hipStream_t)stream);
+    return e == hipSuccess ? MFA_SUCCESS
+           : e == hipErrorInvalidValue ? MFA_ERROR_INVALID_ARGS
+                                       : MFA_ERROR_EXECUTION_FAILED;
+}
+
+// In-stream encode (MFABridge.swift:2377-2543): never commits, never waits.
+mfa_error_t mfa_attention_encode_mtl(mfa_context_t context, void* command_buffer, void* q_buffer, int64_t q_offset,
+                                     const int64_t* q_strides, void* k_buffer, int64_t k_offset,
+                                     const int64_t* k_strides, void* v_buffer, int64_t v_offset,
+                                     const int64_t* v_strides, void* out_buffer, int64_t out_offset,
+                                     void* mask_buffer, int64_t mask_offset, const int64_t* mask_shape,
+                                     const int64_t* mask_strides, uint32_t mask_ndim, mfa_mask_type_t mask_type,
+                                     mfa_mask_scalar_t mask_scalar_type, uint32_t batch_size, uint32_t seq_len_q,
+                                     uint32_t seq_len_kv, uint32_t num_heads, uint16_t head_dim, float softmax_scale,
+                                     bool causal, const char* input_precision, const char* intermediate_precision) {
+    if (!as_ctx(context) || !q_buffer || !k_buffer || !v_buffer || !out_buffer) return MFA_ERROR_INVALID_ARGS;
+    if (q_offset < 0 || k_offset < 0 || v_offset < 0 || out_offset < 0) return MFA_ERROR_INVALID_ARGS;
+    const void* mask = nullptr;
+    if (mask_type != MFA_MASK_TYPE_NONE) {
+        if (!mask_buffer || mask_offset < 0) return MFA_ERROR_INVALID_ARGS;
+        mask = (const char*)mask_buffer + mask_offset;
+    }
+    return umfa_attention_forward_stream(
+        context, command_buffer, (const char*)q_buffer + q_offset, q_strides, (const char*)k_buffer + k_offset,
+        k_strides, (const char*)v_buffer + v_offset, v_strides, (char*)out_buffer + out_offset, MFA_PRECISION_FP32,
+        nullptr, mask, mask_shape, mask_strides, mask_ndim, mask_type, mask_scalar_type, batch_size, seq_len_q,
+        seq_len_kv, num_heads, head_dim, softmax_scale, causal, parse_precision(input_precision),
+        parse_precision(intermediate_precision));
+}
+
+// ============================ utilities ============================
+const char* mfa_error_string(mfa_error_t error) {
+    const char* s = "Unknown error";
+    switch (error) {
+    case 0: s = "Success"; break;
+    case 1: s = "Invalid arguments"; break;
+    case 2: s = "Memory allocation failed"; break;
+    case 3: s = "Device not supported"; break;
+    case 4: s = "Kernel compilation failed"; break;
+    case 5: s = "Execution failed"; break;
+    }
+    return strdup(s);  // caller frees (MFABridge.swift:1538)
+}
+
+bool mfa_is_device_supported(void) { return device_usable(nullptr); }
+
+void mfa_get_version(int* major, int* minor, int* patch) {
+    if (major) *major = 1;
+    if (minor) *minor = 0;
+    if (patch) *patch = 0;
+}
+
+double mfa_get_gpu_latency(mfa_context_t context) {
+    Context* c = as_ctx(context);
+    return c ? c->last_latency : 0.0;
+}
+
+int32_t mfa_has_native_bfloat(void) { return device_usable(nullptr) ? 1 : 0; }
+int32_t mfa_has_native_bfloat_msl32(void) { return device_usable(nullptr) ? 1 : 0; }
+
+const char* umfa_last_kernel_name(mfa_context_t context) {
+    Context* c = as_ctx(context);
+    return c ? c->last_kernel : "none";
+}
+
+mfa_error_t mfa_set_scale_arrays(mfa_context_t context, const float* q_scales, uint32_t q_scales_count,
+                                 const float* k_scales, uint32_t k_scales_count, const float* v_scales,
+                                 uint32_t v_scales_count) {
+    Context* c = as_ctx(context);
+    if (!c) return MFA_ERROR_INVALID_ARGS;
+    std::lock_guard<std::mutex> lock(c->mu);
+    auto set = [](std::vector<float>& dst, const float* src, uint32_t n) {
+        if (src && n) dst.assign(src, src + n);
+        else dst.clear();
+    };
+    set(c->q_scales, q_scales, q_scales_count);
+    set(c->k_scales, k_scales, k_scales_count);
+    set(c->v_scales, v_scales, v_scales_count);
+    return MFA_SUCCESS;
+}
+
+void mfa_get_quantized_layout(mfa_quantized_kernel_t, mfa_quantized_layout_t* out_layout) {
+    if (!out_layout) return;
+    int32_t* f = (int32_t*)out_layout;
+    for (size_t i = 0; i < sizeof(mfa_quantized_layout_t) / sizeof(int32_t); ++i) f[i] = -1;
+}
+
+void mfa_get_quantized_capabilities(void* out_capabilities) {
+    if (!out_capabilities) return;
+    mfa_quantized_capabilities_t caps;
+    memset(&caps, 0, sizeof(caps));
+    caps.supports_multi_head_backward = true;
+    caps.supports_blockwise_backward = true;
+    caps.max_heads = 128;
+    caps.max_block_size = 256;
+    memcpy(out_capabilities, &caps, sizeof(caps));
+}
+
+// ============================ legacy "quantized" forwards ============================
+// All of them run the dense forward on FP32 data (MFABridge+Quantized.swift:26-35,78-80,137-154;
+// callers pass FP32 tensors, metal_sdpa_backend.cpp:2419-2422).
+mfa_error_t mfa_attention_forward_quantized_direct(
+    mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, mfa_buffer_t v, mfa_buffer_t out, uint32_t batch_size,
+    uint32_t seq_len_q, uint32_t seq_len_kv, uint32_t num_heads, uint16_t head_dim, float softmax_scale, bool causal,
+    float, int32_t, float, int32_t, float, int32_t, int32_t, int32_t, int32_t, int32_t, bool transpose_q,
+    bool transpose_k, bool transpose_v, bool transpose_o) {
+    if (!as_ctx(context) || !as_buf(q) || !as_buf(k) || !as_buf(v) || !as_buf(out)) return MFA_ERROR_INVALID_ARGS;
+    if (!batch_size || !num_heads || !seq_len_q || !seq_len_kv || !head_dim)
+        return MFA_ERROR_MEMORY_ALLOCATION;  // sic: the reference returns 2 here (MFABridge+Quantized.swift:83-99)
+    return forward_sync(context, q, k, v, out, nullptr, batch_size, seq_len_q, seq_len_kv, num_heads, head_dim,
+                        softmax_scale, causal, MFA_PRECISION_FP32, MFA_PRECISION_FP32, transpose_q, transpose_k,
+                        transpose_v, transpose_o, nullptr, 0, nullptr, nullptr, 0, MFA_MASK_TYPE_NONE, 0, false);
+}
+
+mfa_error_t mfa_attention_forward_quantized(
+    mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, mfa_buffer_t v, mfa_buffer_t out, uint32_t batch_size,
+    uint32_t seq_len_q, uint32_t seq_len_kv, uint32_t num_heads, uint16_t head_dim, float softmax_scale, bool causal,
+    float q_scale, int32_t q_zp, float k_scale, int32_t k_zp, float v_scale, int32_t v_zp, mfa_precision_t qp,
+    mfa_precision_t kp, mfa_precision_t vp, mfa_precision_t op, bool tq, bool tk, bool tv, bool to) {
+    return mfa_attention_forward_quantized_direct(context, q, k, v, out, batch_size, seq_len_q, seq_len_kv, num_heads,
+                                                  head_dim, softmax_scale, causal, q_scale, q_zp, k_scale, k_zp,
+                                                  v_scale, v_zp, qp, kp, vp, op, tq, tk, tv, to);
+}
+
+mfa_error_t mfa_attention_forward_quantized_unified(
+    mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, mfa_buffer_t v, mfa_buffer_t out, uint32_t batch_size,
+    uint32_t seq_len_q, uint32_t seq_len_kv, uint32_t num_heads, uint16_t head_dim, float softmax_scale, bool causal,
+    float q_scale, int32_t q_zp, float k_scale, int32_t k_zp, float v_scale, int32_t v_zp, mfa_precision_t qp,
+    mfa_precision_t kp, mfa_precision_t vp, mfa_precision_t op, int32_t, uint32_t, uint32_t, uint32_t, bool, bool,
+    bool tq, bool tk, bool tv, bool to) {
+    return mfa_attention_forward_quantized_direct(context, q, k, v, out, batch_size, seq_len_q, seq_len_kv, num_heads,
+                                                  head_dim, softmax_scale, causal, q_scale, q_zp, k_scale, k_zp,
+                                                  v_scale, v_zp, qp, kp, vp, op, tq, tk, tv, to);
+}
+
+mfa_error_t mfa_attention_forward_quantized_enhanced(
+    mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, mfa_buffer_t v, mfa_buffer_t out, uint32_t batch_size,
+    uint32_t seq_len_q, uint32_t seq_len_kv, uint32_t num_heads, uint16_t head_dim, float softmax_scale, bool causal,
+    float q_scale, int32_t q_zp, float k_scale, int32_t k_zp, float v_scale, int32_t v_zp, mfa_precision_t qp,
+    mfa_precision_t kp, mfa_precision_t vp, mfa_precision_t op, int32_t, uint32_t, uint32_t, uint32_t, bool, bool,
+    bool tq, bool tk, bool tv, bool to) {
+    return mfa_attention_forward_quantized_direct(context, q, k, v, out, batch_size, seq_len_q, seq_len_kv, num_heads,
+                                                  head_dim, softmax_scale, causal, q_scale, q_zp, k_scale, k_zp,
+                                                  v_scale, v_zp, qp, kp, vp, op, tq, tk, tv, to);
+}
+
+mfa_error_t mfa_multihead_attention_quantized_direct(
+    mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, mfa_buffer_t v, mfa_buffer_t out, uint32_t batch_size,
+    uint32_t seq_len_q, uint32_t seq_len_kv, uint32_t num_heads, uint16_t head_dim, float softmax_scale, bool causal,
+    float q_scale, int32_t q_zp, float k_scale, int32_t k_zp, float v_scale, int32_t v_zp, int32_t qp, int32_t kp,
+    int32_t vp) {
+    return mfa_attention_forward_quantized_direct(context, q, k, v, out, batch_size, seq_len_q, seq_len_kv, num_heads,
+                                                  head_dim, softmax_scale, causal, q_scale, q_zp, k_scale, k_zp,
+                                                  v_scale, v_zp, qp, kp, vp, MFA_PRECISION_FP32, false, false, false,
+                                                  false);
+}
+
+// ============================ not built this round: link, return 3 ============================
+#define NOT_BUILT return MFA_ERROR_DEVICE_NOT_SUPPORTED
+int32_t mfa_attention_backward_query_quantized(mfa_context_t, mfa_buffer_t, mfa_buffer_t, mfa_buffer_t, mfa_buffer_t,
+                                               mfa_buffer_t, mfa_buffer_t, mfa_buffer_t, mfa_buffer_t, uint32_t,
+                                               uint32_t, uint32_t, uint32_t, uint16_t, float, int32_t, float, int32_t,
+                                               float, int32_t, int32_t, int32_t, int32_t, bool, bool, bool, bool,
+                                               bool) { NOT_BUILT; }
+int32_t mfa_attention_backward_kv_quantized(mfa_context_t, mfa_buffer_t, mfa_buffer_t, mfa_buffer_t, mfa_buffer_t,
+                                            mfa_buffer_t, mfa_buffer_t, mfa_buffer_t, mfa_buffer_t, uint32_t, uint32_t,
+                                            uint32_t, uint32_t, uint16_t, float, int32_t, float, int32_t, float,
+                                            int32_t, int32_t, int32_t, int32_t, bool, bool, bool, bool, bool) { NOT_BUILT; }
+int32_t mfa_attention_backward_query_quantized_ex(mfa_context_t, mfa_buffer_t, mfa_buffer_t, mfa_buffer_t,
+                                                  mfa_buffer_t, mfa_buffer_t, mfa_buffer_t, mfa_buffer_t,
+                                                  mfa_buffer_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t,
+                                                  uint16_t, float, int32_t, float, int32_t, float, int32_t, int32_t,
+                                                  int32_t, int32_t, bool, bool, bool, bool, bool, mfa_buffer_t,
+                                                  mfa_buffer_t, mfa_buffer_t, mfa_buffer_t, mfa_buffer_t,
+                                                  mfa_buffer_t, uint32_t, uint32_t, uint32_t, uint32_t) { NOT_BUILT; }
+int32_t mfa_attention_backward_kv_quantized_ex(mfa_context_t, mfa_buffer_t, mfa_buffer_t, mfa_buffer_t, mfa_buffer_t,
+                                               mfa_buffer_t, mfa_buffer_t, mfa_buffer_t, mfa_buffer_t, uint32_t,
+                                               uint32_t, uint32_t, uint32_t, uint32_t, uint16_t, float, int32_t,
+                                               float, int32_t, float, int32_t, int32_t, int32_t, int32_t, bool, bool,
+                                               bool, bool, bool, mfa_buffer_t, mfa_buffer_t, mfa_buffer_t,
+                                               mfa_buffer_t, mfa_buffer_t, mfa_buffer_t, uint32_t, uint32_t, uint32_t,
+                                               uint32_t) { NOT_BUILT; }
+int mfa_rope_rotate_encode_mtl(void*, void*, void*, int64_t, int64_t, int64_t, int64_t, void*, int64_t, void*,
+                               int64_t, void*, int64_t, int64_t, bool, uint32_t, uint32_t, uint32_t, uint32_t,
+                               const char*) { NOT_BUILT; }
+int32_t mfa_hadamard_rotate(mfa_buffer_t, uint32_t, uint32_t) { NOT_BUILT; }
+mfa_error_t mfa_sparse_indexer_scores(mfa_context_t, mfa_buffer_t, mfa_buffer_t, uint32_t, uint32_t, uint32_t,
+                                      uint32_t, uint16_t, float, mfa_buffer_t, mfa_buffer_t*) { NOT_BUILT; }
+mfa_error_t mfa_mla_create_context(mfa_mla_context_t* context) {
+    if (context) *context = nullptr;
+    NOT_BUILT;
+}
+void mfa_mla_destroy_context(mfa_mla_context_t) {}
+mfa_error_t mfa_mla_init_weights(mfa_mla_context_t, uint32_t, uint32_t, uint32_t) { NOT_BUILT; }
+mfa_error_t mfa_mla_load_weights(mfa_mla_context_t, mfa_buffer_t, mfa_buffer_t) { NOT_BUILT; }
+mfa_error_t mfa_mla_forward(mfa_mla_context_t, mfa_context_t, mfa_buffer_t, mfa_buffer_t*, mfa_buffer_t*, uint32_t,
+                            uint32_t, uint32_t, uint32_t, uint32_t) { NOT_BUILT; }
+
+}  // extern "C"

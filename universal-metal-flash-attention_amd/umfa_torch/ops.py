@@ -1,0 +1,109 @@
+"""In-stream launches of the HIP kernels on torch-ROCm tensors (zero-copy).
+
+Counterpart of the reference's try_instream_flash_attention + mps_utils::encode_attention_on_torch_stream
+(metal_sdpa_backend.cpp:1308-1446, mps_utils.mm:115-247): raw device pointers, byte offsets folded into
+the pointers, BHSD element strides, launched on torch's CURRENT stream -- no host synchronisation.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from umfa._ffi import (MFA_MASK_SCALAR_BF16, MFA_MASK_SCALAR_BYTE, MFA_MASK_SCALAR_FP16, MFA_MASK_SCALAR_FP32,
+                       MFA_MASK_TYPE_ADDITIVE, MFA_MASK_TYPE_BOOL, MFA_MASK_TYPE_NONE, MFA_PRECISION_BF16,
+                       MFA_PRECISION_FP16, MFA_PRECISION_FP32, MFAError, _check_error, _lib, mfa_context_t)
+
+_PREC = {torch.float16: MFA_PRECISION_FP16, torch.bfloat16: MFA_PRECISION_BF16, torch.float32: MFA_PRECISION_FP32}
+_PREC_NAME = {torch.float16: b"fp16", torch.bfloat16: b"bf16", torch.float32: b"fp32"}
+
+_ctx = None
+
+
+def context():
+    """Process-wide context handle (created on first use; metal_sdpa_backend.cpp:936-955)."""
+    global _ctx
+    if _ctx is None:
+        if not torch.cuda.is_available():
+            raise RuntimeError("umfa_torch needs a ROCm device: there is no CPU fallback")
+        h = mfa_context_t()
+        _check_error(_lib.mfa_create_context(ctypes.byref(h)))
+        _ctx = h
+    return _ctx
+
+
+def last_kernel() -> str:
+    return _lib.umfa_last_kernel_name(context()).decode()
+
+
+def _i64(vals):
+    return (ctypes.c_int64 * len(vals))(*[int(v) for v in vals])
+
+
+def _mask_args(mask: Optional[torch.Tensor]):
+    if mask is None:
+        return None, None, None, 0, MFA_MASK_TYPE_NONE, MFA_MASK_SCALAR_BYTE
+    if mask.dtype == torch.bool:
+        mt, ms = MFA_MASK_TYPE_BOOL, MFA_MASK_SCALAR_BYTE
+    elif mask.dtype == torch.float32:
+        mt, ms = MFA_MASK_TYPE_ADDITIVE, MFA_MASK_SCALAR_FP32
+    elif mask.dtype == torch.float16:
+        mt, ms = MFA_MASK_TYPE_ADDITIVE, MFA_MASK_SCALAR_FP16
+    elif mask.dtype == torch.bfloat16:
+        mt, ms = MFA_MASK_TYPE_ADDITIVE, MFA_MASK_SCALAR_BF16
+    else:
+        raise TypeError(f"unsupported mask dtype {mask.dtype}")
+    if mask.dim() > 4:
+        raise ValueError("attention masks of more than 4 dims are not supported")
+    return (ctypes.c_void_p(mask.data_ptr()), _i64(mask.shape), _i64(mask.stride()), mask.dim(), mt, ms)
+
+
+def attention_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, scale: Optional[float] = None,
+                      causal: bool = False, mask: Optional[torch.Tensor] = None, out_dtype=None,
+                      return_lse: bool = False, intermediate_dtype=None, out: Optional[torch.Tensor] = None):
+    """q [B,H,Sq,D], k/v [B,H,Skv,D] device tensors (any BHSD strides with a contiguous last dim).
+
+    out_dtype: torch.float32 (the C-ABI contract) or q.dtype (fused cast-back epilogue).
+    Asynchronous on torch's current stream.
+    """
+    assert q.is_cuda and k.is_cuda and v.is_cuda, "device tensors required"
+    B, H, Sq, D = q.shape
+    Skv = k.shape[2]
+    if scale is None:
+        scale = D ** -0.5
+    out_dtype = out_dtype or q.dtype
+    for t in (q, k, v):
+        if t.stride(-1) != 1:
+            raise ValueError("last dimension must be contiguous")
+    if out is None:
+        out = torch.empty((B, H, Sq, D), dtype=out_dtype, device=q.device)
+    lse = torch.empty((B * H * Sq,), dtype=torch.float32, device=q.device) if return_lse else None
+    mptr, mshape, mstr, mnd, mt, ms = _mask_args(mask)
+    inter = _PREC[intermediate_dtype or q.dtype]
+    stream = torch.cuda.current_stream(q.device).cuda_stream
+    _check_error(_lib.umfa_attention_forward_stream(
+        context(), ctypes.c_void_p(stream),
+        ctypes.c_void_p(q.data_ptr()), _i64(q.stride()), ctypes.c_void_p(k.data_ptr()), _i64(k.stride()),
+        ctypes.c_void_p(v.data_ptr()), _i64(v.stride()), ctypes.c_void_p(out.data_ptr()), _PREC[out.dtype],
+        ctypes.c_void_p(lse.data_ptr()) if lse is not None else None,
+        mptr, mshape, mstr, mnd, mt, ms, B, Sq, Skv, H, D, float(scale), bool(causal), _PREC[q.dtype], inter))
+    return (out, lse) if return_lse else out
+
+
+def attention_encode(q, k, v, out32, *, scale=None, causal=False, mask=None, stream=None):
+    """The reference's exact in-stream entry (mfa_attention_encode_mtl): fp32 dense output, precisions as
+    strings, byte offsets (0 here: data_ptr() already includes the storage offset)."""
+    B, H, Sq, D = q.shape
+    Skv = k.shape[2]
+    if scale is None:
+        scale = D ** -0.5
+    mptr, mshape, mstr, mnd, mt, ms = _mask_args(mask)
+    s = stream if stream is not None else torch.cuda.current_stream(q.device).cuda_stream
+    _check_error(_lib.mfa_attention_encode_mtl(
+        context(), ctypes.c_void_p(s),
+        ctypes.c_void_p(q.data_ptr()), 0, _i64(q.stride()), ctypes.c_void_p(k.data_ptr()), 0, _i64(k.stride()),
+        ctypes.c_void_p(v.data_ptr()), 0, _i64(v.stride()), ctypes.c_void_p(out32.data_ptr()), 0,
+        mptr, 0, mshape, mstr, mnd, mt, ms, B, Sq, Skv, H, D, float(scale), bool(causal),
+        _PREC_NAME[q.dtype], _PREC_NAME[q.dtype]))
+    return out32
