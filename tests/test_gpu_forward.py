@@ -158,10 +158,13 @@ def test_relative_error_16bit(ctx, shape, dt, causal):
     bound = 1.5e-3 if dt == "fp16" else 6e-3  # P is rounded to the input type before PV
     assert rel_err(o, ref) < bound, rel_err(o, ref)
     assert np.abs(lse.cpu().numpy().reshape(ref_lse.shape) - ref_lse).max() < 2e-3
-    # fused cast-back epilogue (16-bit out) equals the fp32 output rounded once
+    # fused cast-back epilogue (16-bit out): within half an ulp of the fp32 output (the epilogue multiplies
+    # and rounds once -- v_fma_mix -- so exact ties may differ from "round the stored fp32 again")
     o16 = umfa_torch.attention_forward(tq, tk, tv, causal=causal)
     assert o16.dtype == tdt
-    assert torch.equal(o16.cpu(), torch.from_numpy(o).to(tdt))
+    half_ulp = 2.0 ** -11 if dt == "fp16" else 2.0 ** -8
+    d16 = np.abs(o16.float().cpu().numpy() - o)
+    assert (d16 <= half_ulp * 1.01 * np.abs(o) + 1e-7).all()
 
 
 def test_exact_path_on_16bit_inputs(ctx):

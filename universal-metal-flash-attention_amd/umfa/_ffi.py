@@ -74,6 +74,13 @@ _MASK_HOST = [_vp, _sz, _i64p, _i64p, _u32, _i32, _i32]
 
 
 def _load_library() -> ctypes.CDLL:
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so, so when torch is
+    # installed load it first and let libMFAFFI.so bind to that copy (same SONAME).  Two runtimes
+    # in one process cannot share streams or device pointers (and the second one sees no device).
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pure-numpy callers: the system ROCm runtime is used
+        pass
     lib = ctypes.CDLL(_find_library())
 
     def sig(name, restype, argtypes):
