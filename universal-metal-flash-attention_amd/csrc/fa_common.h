@@ -46,11 +46,6 @@ struct FwdParams {
     int mask_kind;
     int in_prec;   // P_FP16 / P_BF16 / P_FP32
     int out_prec;  // P_FP16 / P_BF16 / P_FP32
-    // int8 path only: per-block scales, see fa_quant
-    const float* q_scale;
-    const float* k_scale;
-    const float* v_scale;
-    uint32_t q_blk, k_blk;  // rows per scale block (0 = per tensor)
 };
 
 struct BwdParams {
@@ -64,10 +59,12 @@ struct BwdParams {
     float* dk;
     float* dv;
     float* dvec;
+    const float* mask;  // optional fp32 additive [B,H,Sq,Skv] (quantised backward only)
     uint32_t B, H, Sq, Skv, D;
     float scale;
     int causal;
-    int in_prec;
+    int in_prec;    // q, k, v
+    int dout_prec;  // dO
 };
 
 __device__ __forceinline__ float bf16_bits_to_float(uint16_t b) {

@@ -1,10 +1,435 @@
-// fa_quant.hip -- int8/int4 quantised path (placeholder until the int8 MFMA forward lands).
+// fa_quant.hip -- runtime-quantised attention for gfx950 (SageAttention-style: Q, K AND V quantised).
+//
+// Replaces, for mfa_quantized_forward_with_lse (MFABridge+Quantized.swift:227-358):
+//   * createQuantizedTensorFromBufferPublic x3 (three command-buffer commits in the reference,
+//     README.md:127-131) by ONE fused quantiser launch for Q, K and V (block-wise mode), and
+//   * QuantizedAttention.forwardMultiHead (INT storage, dequantise-on-load, FP32 math -- AGENTS.md:143-152)
+//     by a flash forward whose QK^T runs on the int8 MFMA (v_mfma_i32_32x32x32_i8, 2x the bf16 rate):
+//         S = (sum_d q8 k8) * sq[q-block] * sk[k-block]        exact int32 accumulation
+//     and whose PV runs on the fp16 MFMA with V de-quantised ONCE by the pre-pass to fp16
+//     (q_v * s_v has <= 7 significant bits times a scale: fp16's 11 bits hold it to 2^-12).
+// Quantiser = the reference's symmetric formula (Tests/QuantizationTests/QuantizationTests.swift:72-128):
+//   scale = absmax / 127 (INT8) or / 7 (INT4), q = clamp(round_half_away(x / scale)), zero point 0.
+// Block-wise mode (quant_mode 2): one scale per (batch, head, 64 consecutive rows) -- the block edge is
+// the kernel's 64-key tile, so a tile has ONE K scale and a wave ONE Q scale.  Tensor-wise mode
+// (quant_mode 0): one scale per tensor (the same kernels, every block scale equal).
+// INT4 uses the same kernels with values in [-8, 7] (unpacked in the internal workspace; nibble
+// packing only matters at rest, which this ABI never exposes).
+#include <climits>
+#include <cstring>
+
 #include "fa_common.h"
 #include "kernels.h"
+
 namespace umfa {
-size_t quant_workspace_bytes(uint32_t, uint32_t, uint32_t, uint32_t, uint32_t) { return 0; }
-hipError_t launch_quantized_fwd(const FwdParams&, int, int, void*, size_t, hipStream_t, const char** name) {
-    *name = "none";
-    return hipErrorNotSupported;
+
+#define LDS_AS __attribute__((address_space(3)))
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int QBLK = 64;  // rows per quantisation block
+
+struct QuantParams {
+    const void* src[3];   // q, k, v (input precision)
+    int8_t* q8;           // [B*H*Sq][DPQ]
+    int8_t* k8;           // [B*H*Skv][DPQ]
+    _Float16* v16;        // [B*H*Skv][D]
+    float* f32[3];        // optional fake-quantised fp32 copies (backward), [rows][D]
+    float* scale[3];      // per (bh, block)
+    uint32_t rows[3];     // Sq, Skv, Skv
+    uint32_t nblk[3];     // blocks per (b,h)
+    uint32_t BH, D, DPQ;
+    int in_prec;
+    float qmax;           // 127 or 7
+    int qlo, qhi;         // clamp range
+};
+
+// mode 0: write block absmax only; mode 1: quantise with scales already in scale[]; mode 2: both (fused)
+template <int MODE>
+__global__ __launch_bounds__(256) void quantize_kernel(QuantParams p) {
+    __shared__ float red[4];
+    // which tensor / (bh, block)
+    uint32_t id = blockIdx.x;
+    int t = 0;
+    while (t < 2 && id >= p.BH * p.nblk[t]) { id -= p.BH * p.nblk[t]; ++t; }
+    const uint32_t bh = id / p.nblk[t], blk = id % p.nblk[t];
+    const uint32_t row0 = blk * QBLK;
+    const uint32_t nrows = min((uint32_t)QBLK, p.rows[t] - row0);
+    const int64_t base = ((int64_t)bh * p.rows[t] + row0) * p.D;
+    const uint32_t n = nrows * p.D;
+    const int tid = threadIdx.x;
+    float sc;
+    if (MODE != 1) {
+        float amax = 0.0f;
+        for (uint32_t e = tid; e < n; e += 256) amax = fmaxf(amax, fabsf(load_as_float(p.src[t], base + e, p.in_prec)));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+        if ((tid & 63) == 0) red[tid >> 6] = amax;
+        __syncthreads();
+        amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (MODE == 0) {
+            if (tid == 0) p.scale[t][bh * p.nblk[t] + blk] = amax;  // absmax for now; reduced later
+            return;
+        }
+        sc = amax > 0.0f ? amax / p.qmax : 1.0f;
+        if (tid == 0) p.scale[t][bh * p.nblk[t] + blk] = sc;
+    } else {
+        sc = p.scale[t][bh * p.nblk[t] + blk];
+    }
+    // quantise; Q/K rows are padded with zeros to DPQ bytes
+    const uint32_t cols = t < 2 ? p.DPQ : p.D;
+    for (uint32_t e = tid; e < nrows * cols; e += 256) {
+        const uint32_t r = e / cols, d = e % cols;
+        int qv = 0;
+        if (d < p.D) {
+            const float x = load_as_float(p.src[t], base + (int64_t)r * p.D + d, p.in_prec);
+            qv = (int)roundf(x / sc);
+            qv = qv < p.qlo ? p.qlo : (qv > p.qhi ? p.qhi : qv);
+        }
+        const int64_t row = (int64_t)bh * p.rows[t] + row0 + r;
+        if (t == 0) p.q8[row * p.DPQ + d] = (int8_t)qv;
+        else if (t == 1) p.k8[row * p.DPQ + d] = (int8_t)qv;
+        else p.v16[row * p.D + d] = (_Float16)((float)qv * sc);
+        if (p.f32[t] && d < p.D) p.f32[t][row * p.D + d] = (float)qv * sc;
+    }
 }
+
+// tensor-wise: reduce block absmax -> one scale, broadcast to every block entry
+__global__ __launch_bounds__(256) void tensor_scale_kernel(float* s0, uint32_t n0, float* s1, uint32_t n1, float* s2,
+                                                           uint32_t n2, float qmax) {
+    __shared__ float red[4];
+    float* s = blockIdx.x == 0 ? s0 : blockIdx.x == 1 ? s1 : s2;
+    const uint32_t n = blockIdx.x == 0 ? n0 : blockIdx.x == 1 ? n1 : n2;
+    float amax = 0.0f;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) amax = fmaxf(amax, s[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float sc = amax > 0.0f ? amax / qmax : 1.0f;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 256) s[i] = sc;
+}
+
+// ------------------------------------------------------------------ int8 QK^T forward
+template <int DP> __device__ __forceinline__ constexpr int k8_off(int row, int ch) {  // rows of DP bytes, 16-B chunks
+    int sw = DP >= 256 ? (ch ^ (row & 15)) : DP == 128 ? (ch ^ ((row >> 1) & 7)) : (ch ^ ((row >> 2) & 3));
+    return row * DP + 16 * sw;
+}
+template <int DP> __device__ __forceinline__ constexpr int v16_off(int row, int ch) {  // rows of 2*DP bytes
+    int sw = DP >= 128 ? (ch ^ ((row & 3) << 2)) : (ch ^ (((row >> 1) & 1) << 2));
+    return row * (2 * DP) + 16 * sw;
+}
+
+struct I8FwdParams {
+    const int8_t* q8;
+    const int8_t* k8;
+    const _Float16* v16;
+    const float* q_scale;
+    const float* k_scale;
+    float* o;
+    float* lse;
+    const float* mask;  // fp32 additive [B,H,Sq,Skv] or NULL
+    uint32_t B, H, Sq, Skv, D;
+    uint32_t nqblk, nkblk;
+    float scale;
+};
+
+template <int DP, bool CAUSAL, bool HAS_MASK>
+__global__ __launch_bounds__(256, (DP <= 128 ? 2 : 1)) void fa_fwd_i8_kernel(I8FwdParams p) {
+    constexpr int BM = 128, BN = 64;
+    constexpr int NKS = DP / 32;             // int8 k-steps (32 per MFMA)
+    constexpr int NDB = DP / 32;             // 32-row blocks of O^T
+    constexpr int KT_BYTES = BN * DP;        // int8 K tile
+    constexpr int VT_BYTES = BN * DP * 2;    // fp16 V tile
+    constexpr int KCH = DP / 16, VCH = DP / 8;
+    constexpr int KLPT = BN * KCH / 256, VLPT = BN * VCH / 256;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const Kbuf = smem;                  // 2 x KT_BYTES
+    char* const Vbuf = smem + 2 * KT_BYTES;   // 2 x VT_BYTES
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, ql = lane & 31, hi = lane >> 5;
+    const uint32_t nqb = (p.Sq + BM - 1) / BM;
+    const uint32_t vid = xcd_remap(blockIdx.x, nqb * p.B * p.H);
+    const uint32_t bh = vid / nqb;
+    uint32_t qb = vid % nqb;
+    if (CAUSAL) qb = nqb - 1 - qb;
+    const uint32_t q_row = qb * BM + wave * 32 + ql;
+    const uint32_t wave_q0 = qb * BM + wave * 32;
+    const int D = (int)p.D;
+
+    const int8_t* __restrict__ qp = p.q8 + (int64_t)bh * p.Sq * DP;
+    const int8_t* __restrict__ kp = p.k8 + (int64_t)bh * p.Skv * DP;
+    const _Float16* __restrict__ vp = p.v16 + (int64_t)bh * p.Skv * D;
+
+    i32x4 qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        if (q_row < p.Sq) qf[ks] = *(const i32x4*)(qp + (int64_t)q_row * DP + 32 * ks + 16 * hi);
+        else qf[ks] = i32x4{0, 0, 0, 0};
+    }
+    const uint32_t wq_blk = wave_q0 / QBLK;
+    const float sq = (wave_q0 < p.Sq ? p.q_scale[bh * p.nqblk + wq_blk] : 0.0f) * p.scale * UMFA_LOG2E;
+
+    i32x4 kreg[KLPT], vreg[VLPT];
+    auto stage_load = [&](uint32_t t) {
+#pragma unroll
+        for (int i = 0; i < KLPT; ++i) {
+            const int c = tid + 256 * i, row = c / KCH, ch = c % KCH;
+            const uint32_t key = t * BN + row;
+            kreg[i] = key < p.Skv ? *(const i32x4*)(kp + (int64_t)key * DP + ch * 16) : i32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int i = 0; i < VLPT; ++i) {
+            const int c = tid + 256 * i, row = c / VCH, ch = c % VCH;
+            const uint32_t key = t * BN + row;
+            vreg[i] = (key < p.Skv && ch * 8 < D) ? *(const i32x4*)(vp + (int64_t)key * D + ch * 8) : i32x4{0, 0, 0, 0};
+        }
+    };
+    auto stage_write = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < KLPT; ++i) {
+            const int c = tid + 256 * i, row = c / KCH, ch = c % KCH;
+            *(i32x4*)(Kbuf + buf * KT_BYTES + k8_off<DP>(row, ch)) = kreg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < VLPT; ++i) {
+            const int c = tid + 256 * i, row = c / VCH, ch = c % VCH;
+            *(i32x4*)(Vbuf + buf * VT_BYTES + v16_off<DP>(row, ch)) = vreg[i];
+        }
+    };
+
+    uint32_t ntiles = (p.Skv + BN - 1) / BN;
+    if (CAUSAL) {
+        const uint32_t lim = (qb * BM + BM + BN - 1) / BN;
+        ntiles = ntiles < lim ? ntiles : lim;
+    }
+    f32x16 acc[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    float m = -INFINITY, l = 0.0f;
+    const int tr_qq = (lane >> 2) & 3, tr_pp = lane & 3, tr_g1 = (lane >> 4) & 1;
+    const int64_t mrow = HAS_MASK ? ((int64_t)bh * p.Sq + q_row) * p.Skv : 0;
+
+    stage_load(0);
+    stage_write(0);
+    __syncthreads();
+
+    for (uint32_t t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        const bool more = t + 1 < ntiles;
+        if (more) stage_load(t + 1);
+        const char* Kt = Kbuf + cur * KT_BYTES;
+        const char* Vt = Vbuf + cur * VT_BYTES;
+        const uint32_t key_base = t * BN;
+        const bool active = !CAUSAL || key_base <= wave_q0 + 31;
+        if (active) {
+            const float ct = sq * p.k_scale[bh * p.nkblk + t];  // dequant * softmax scale * log2e, > 0 or == 0
+            i32x16 s[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] = 0;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const i32x4 a = *(const i32x4*)(Kt + k8_off<DP>(32 * kb + ql, 2 * ks + hi));
+                    s[kb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, qf[ks], s[kb], 0, 0, 0);
+                }
+            }
+            const bool edge = (key_base + BN > p.Skv) || (CAUSAL && key_base + BN - 1 > wave_q0);
+            float tv[2][16];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const uint32_t key = key_base + 32 * kb + acc_row(r, hi);
+                    float x = (float)s[kb][r] * ct;
+                    if (HAS_MASK && key < p.Skv && q_row < p.Sq) x += p.mask[mrow + key] * UMFA_LOG2E;
+                    if (edge && (key >= p.Skv || (CAUSAL && key > q_row))) x = -INFINITY;
+                    tv[kb][r] = x;
+                    mx = fmaxf(mx, x);
+                }
+            mx = fmaxf(mx, xor32(mx));
+            const float m_new = fmaxf(m, mx);
+            const float m_use = (HAS_MASK && m_new == -INFINITY) ? 0.0f : m_new;
+            if (!__all(m_new == m)) {
+                const float alpha = __builtin_amdgcn_exp2f(m - m_use);
+                l *= alpha;
+#pragma unroll
+                for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
+                m = m_new;
+            }
+            float rs = 0.0f;
+            f16x8 pf[4];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(tv[kb][r] - m_use);
+                    rs += e;
+                    pf[2 * kb + (r >> 3)][r & 7] = (_Float16)e;
+                }
+            l += rs;
+#pragma unroll
+            for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const int row0 = 16 * st + 4 * hi + tr_qq;
+                    const int ch = 4 * i + 2 * tr_g1 + (tr_pp >> 1);
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 LDS_AS*)(Vt + v16_off<DP>(row0, ch) + 8 * (tr_pp & 1)));
+                    const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 LDS_AS*)(Vt + v16_off<DP>(row0 + 8, ch) + 8 * (tr_pp & 1)));
+                    const f16x8 a = __builtin_shufflevector(__builtin_bit_cast(f16x4_t, lo), __builtin_bit_cast(f16x4_t, hi4), 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf[st], acc[i], 0, 0, 0);
+                }
+        }
+        if (more) stage_write(cur ^ 1);
+        __syncthreads();
+    }
+
+    const float lt = l + xor32(l);
+    const float inv = lt > 0.0f ? 1.0f / lt : 0.0f;
+    if (q_row < p.Sq) {
+        float* __restrict__ op = p.o + ((int64_t)bh * p.Sq + q_row) * D;
+#pragma unroll
+        for (int i = 0; i < NDB; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = 32 * i + 8 * g + 4 * hi;
+                if (d0 < D) {
+                    f32x4 val = {acc[i][4 * g] * inv, acc[i][4 * g + 1] * inv, acc[i][4 * g + 2] * inv, acc[i][4 * g + 3] * inv};
+                    *(f32x4*)(op + d0) = val;
+                }
+            }
+        if (p.lse && hi == 0) p.lse[(int64_t)bh * p.Sq + q_row] = lt > 0.0f ? (m + log2f(lt)) * UMFA_LN2 : -INFINITY;
+    }
+}
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+static inline uint32_t dp_of(uint32_t D) { return D <= 64 ? 64 : D <= 128 ? 128 : 256; }
+
+struct WsLayout {
+    size_t q8, k8, v16, sq, sk, sv, f32q, f32k, f32v, total;
+};
+static WsLayout ws_layout(uint32_t B, uint32_t H, uint32_t Sq, uint32_t Skv, uint32_t D, bool want_f32) {
+    const size_t BH = (size_t)B * H, DP = dp_of(D);
+    const size_t nqb = (Sq + QBLK - 1) / QBLK, nkb = (Skv + QBLK - 1) / QBLK;
+    WsLayout w;
+    size_t off = 0;
+    w.q8 = off; off = align256(off + BH * Sq * DP);
+    w.k8 = off; off = align256(off + BH * Skv * DP);
+    w.v16 = off; off = align256(off + BH * Skv * D * 2);
+    w.sq = off; off = align256(off + BH * nqb * 4);
+    w.sk = off; off = align256(off + BH * nkb * 4);
+    w.sv = off; off = align256(off + BH * nkb * 4);
+    w.f32q = w.f32k = w.f32v = 0;
+    if (want_f32) {
+        w.f32q = off; off = align256(off + BH * Sq * D * 4);
+        w.f32k = off; off = align256(off + BH * Skv * D * 4);
+        w.f32v = off; off = align256(off + BH * Skv * D * 4);
+    }
+    w.total = off;
+    return w;
+}
+
+size_t quant_workspace_bytes(uint32_t B, uint32_t H, uint32_t Sq, uint32_t Skv, uint32_t D, bool want_f32) {
+    return ws_layout(B, H, Sq, Skv, D, want_f32).total;
+}
+
+bool quantized_supported(uint32_t D) { return D >= 8 && D % 8 == 0 && D <= 256; }
+
+hipError_t launch_quantize(const void* q, const void* k, const void* v, int in_prec, uint32_t B, uint32_t H,
+                           uint32_t Sq, uint32_t Skv, uint32_t D, int bits, int quant_mode, void* workspace,
+                           bool want_f32, QuantViews* views, hipStream_t stream) {
+    const WsLayout w = ws_layout(B, H, Sq, Skv, D, want_f32);
+    char* ws = (char*)workspace;
+    QuantParams qp;
+    memset(&qp, 0, sizeof(qp));
+    qp.src[0] = q; qp.src[1] = k; qp.src[2] = v;
+    qp.q8 = (int8_t*)(ws + w.q8);
+    qp.k8 = (int8_t*)(ws + w.k8);
+    qp.v16 = (_Float16*)(ws + w.v16);
+    qp.scale[0] = (float*)(ws + w.sq);
+    qp.scale[1] = (float*)(ws + w.sk);
+    qp.scale[2] = (float*)(ws + w.sv);
+    if (want_f32) {
+        qp.f32[0] = (float*)(ws + w.f32q);
+        qp.f32[1] = (float*)(ws + w.f32k);
+        qp.f32[2] = (float*)(ws + w.f32v);
+    }
+    qp.rows[0] = Sq; qp.rows[1] = Skv; qp.rows[2] = Skv;
+    for (int t = 0; t < 3; ++t) qp.nblk[t] = (qp.rows[t] + QBLK - 1) / QBLK;
+    qp.BH = B * H; qp.D = D; qp.DPQ = dp_of(D);
+    qp.in_prec = in_prec;
+    qp.qmax = bits == 4 ? 7.0f : 127.0f;
+    qp.qlo = bits == 4 ? -8 : -128;
+    qp.qhi = bits == 4 ? 7 : 127;
+    const uint32_t grid = qp.BH * (qp.nblk[0] + qp.nblk[1] + qp.nblk[2]);
+    if (quant_mode == 2) {
+        hipLaunchKernelGGL(quantize_kernel<2>, dim3(grid), dim3(256), 0, stream, qp);
+    } else {
+        hipLaunchKernelGGL(quantize_kernel<0>, dim3(grid), dim3(256), 0, stream, qp);
+        hipLaunchKernelGGL(tensor_scale_kernel, dim3(3), dim3(256), 0, stream, qp.scale[0], qp.BH * qp.nblk[0],
+                           qp.scale[1], qp.BH * qp.nblk[1], qp.scale[2], qp.BH * qp.nblk[2], qp.qmax);
+        hipLaunchKernelGGL(quantize_kernel<1>, dim3(grid), dim3(256), 0, stream, qp);
+    }
+    if (views) {
+        views->q8 = qp.q8; views->k8 = qp.k8; views->v16 = qp.v16;
+        views->q_scale = qp.scale[0]; views->k_scale = qp.scale[1]; views->v_scale = qp.scale[2];
+        views->qf = qp.f32[0]; views->kf = qp.f32[1]; views->vf = qp.f32[2];
+        views->nqblk = qp.nblk[0]; views->nkblk = qp.nblk[1]; views->dpq = qp.DPQ;
+    }
+    return hipGetLastError();
+}
+
+template <int DP, bool CAUSAL, bool HAS_MASK>
+static hipError_t launch_i8_one(const I8FwdParams& p, hipStream_t stream) {
+    const uint32_t nqb = (p.Sq + 127) / 128;
+    const size_t lds = 2 * 64 * DP + 2 * 64 * DP * 2;
+    auto kfn = fa_fwd_i8_kernel<DP, CAUSAL, HAS_MASK>;
+    static bool attr_set = false;
+    if (lds > 48 * 1024 && !attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kfn, dim3(nqb * p.B * p.H), dim3(256), lds, stream, p);
+    return hipGetLastError();
+}
+
+template <int DP>
+static hipError_t launch_i8_flags(const I8FwdParams& p, bool causal, hipStream_t stream) {
+    const bool mk = p.mask != nullptr;
+    if (causal) return mk ? launch_i8_one<DP, true, true>(p, stream) : launch_i8_one<DP, true, false>(p, stream);
+    return mk ? launch_i8_one<DP, false, true>(p, stream) : launch_i8_one<DP, false, false>(p, stream);
+}
+
+hipError_t launch_quantized_fwd(const FwdParams& fp, int bits, int quant_mode, void* workspace, hipStream_t stream,
+                                const char** name) {
+    if (!quantized_supported(fp.D)) return hipErrorInvalidValue;
+    QuantViews v;
+    hipError_t e = launch_quantize(fp.q, fp.k, fp.v, fp.in_prec, fp.B, fp.H, fp.Sq, fp.Skv, fp.D, bits, quant_mode,
+                                   workspace, false, &v, stream);
+    if (e != hipSuccess) return e;
+    I8FwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.q8 = v.q8; p.k8 = v.k8; p.v16 = (const _Float16*)v.v16;
+    p.q_scale = v.q_scale; p.k_scale = v.k_scale;
+    p.o = (float*)fp.o; p.lse = fp.lse;
+    p.mask = (const float*)fp.mask;
+    p.B = fp.B; p.H = fp.H; p.Sq = fp.Sq; p.Skv = fp.Skv; p.D = fp.D;
+    p.nqblk = v.nqblk; p.nkblk = v.nkblk;
+    p.scale = fp.scale;
+    const uint32_t dp = dp_of(fp.D);
+    if (dp == 64) { *name = bits == 4 ? "fa_fwd_i4<64>" : "fa_fwd_i8<64>"; return launch_i8_flags<64>(p, fp.causal, stream); }
+    if (dp == 128) { *name = bits == 4 ? "fa_fwd_i4<128>" : "fa_fwd_i8<128>"; return launch_i8_flags<128>(p, fp.causal, stream); }
+    *name = bits == 4 ? "fa_fwd_i4<256>" : "fa_fwd_i8<256>";
+    return launch_i8_flags<256>(p, fp.causal, stream);
+}
+
 }  // namespace umfa

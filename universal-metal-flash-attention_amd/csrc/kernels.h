@@ -18,18 +18,26 @@ bool fwd_16_supported(const FwdParams& p);
 // Backward: D = rowsum(dO o O), then dK/dV and dQ.
 hipError_t launch_bwd(const BwdParams& p, hipStream_t stream, const char** name);
 
-// int8 path: fused symmetric quantiser for Q, K, V (one launch) + int8-QK^T forward.
-struct QuantWorkspace {
-    int8_t* q8;
-    int8_t* k8;
-    void* v16;      // V fake-quantised, stored in the 16-bit input type
-    float* q_scale; // per (b,h,block)
-    float* k_scale;
-    float* v_scale;
-    uint32_t blk;   // rows per block (0: per tensor)
+// Runtime-quantised path (fa_quant.hip): fused symmetric quantiser for Q, K, V + int8-QK^T forward.
+struct QuantViews {
+    const int8_t* q8;       // [B*H*Sq][dpq] int8 (rows zero-padded to dpq)
+    const int8_t* k8;       // [B*H*Skv][dpq]
+    const void* v16;        // [B*H*Skv][D] fp16, de-quantised (q_v * s_v)
+    const float* q_scale;   // [B*H][nqblk]
+    const float* k_scale;   // [B*H][nkblk]
+    const float* v_scale;
+    const float* qf;        // optional fake-quantised fp32 copies [rows][D] (backward)
+    const float* kf;
+    const float* vf;
+    uint32_t nqblk, nkblk, dpq;
 };
-size_t quant_workspace_bytes(uint32_t B, uint32_t H, uint32_t Sq, uint32_t Skv, uint32_t D);
-hipError_t launch_quantized_fwd(const FwdParams& p, int bits, int quant_mode, void* workspace,
-                                size_t workspace_bytes, hipStream_t stream, const char** name);
+bool quantized_supported(uint32_t D);
+size_t quant_workspace_bytes(uint32_t B, uint32_t H, uint32_t Sq, uint32_t Skv, uint32_t D, bool want_f32);
+hipError_t launch_quantize(const void* q, const void* k, const void* v, int in_prec, uint32_t B, uint32_t H,
+                           uint32_t Sq, uint32_t Skv, uint32_t D, int bits, int quant_mode, void* workspace,
+                           bool want_f32, QuantViews* views, hipStream_t stream);
+// fp.q/k/v: contiguous BHSD in fp.in_prec; fp.o fp32; fp.mask: fp32 additive [B,H,Sq,Skv] or NULL.
+hipError_t launch_quantized_fwd(const FwdParams& fp, int bits, int quant_mode, void* workspace, hipStream_t stream,
+                                const char** name);
 
 }  // namespace umfa

@@ -3,146 +3,23 @@
 // Replaces the reference's Swift bridge (Sources/MFABridge/*.swift): handle lifetime,
 // buffer wrapping, mask normalisation, kernel selection, launch and timing.  There is no
 // CPU fallback: every compute entry point needs a live gfx950 context.
-#include <hip/hip_runtime.h>
-
-#include <atomic>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <mutex>
 #include <string>
-#include <vector>
 
-#include "../../include/umfa_abi.h"
-#include "fa_common.h"
-#include "kernels.h"
+#include "runtime_internal.h"
 
 using namespace umfa;
+using namespace umfa_rt;
 
-namespace {
-
+namespace umfa_rt {
 const bool g_debug = [] {
     const char* e = getenv("MFA_DEBUG");
     return e && e[0] == '1';
 }();
-#define DBG(...)                              \
-    do {                                      \
-        if (g_debug) {                        \
-            fprintf(stderr, "[umfa] " __VA_ARGS__); \
-            fputc('\n', stderr);              \
-        }                                     \
-    } while (0)
-
-// ---- context (MFAContext + GlobalContextStore, MFABridge.swift:91-150,652-687) -------------
-struct Context {
-    uint32_t magic = 0x4d464143;  // 'MFAC'
-    int device = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    double last_latency = 0.0;
-    const char* last_kernel = "none";
-    void* scratch = nullptr;  // mask staging / quantiser workspace
-    size_t scratch_bytes = 0;
-    std::vector<float> q_scales, k_scales, v_scales;  // mfa_set_scale_arrays: stored, never read
-    std::atomic<int> refs{0};
-    std::mutex mu;
-
-    void* ensure_scratch(size_t bytes) {
-        if (bytes <= scratch_bytes) return scratch;
-        if (scratch) (void)hipFree(scratch);
-        scratch = nullptr;
-        scratch_bytes = 0;
-        size_t want = bytes + (bytes >> 2) + 256;
-        if (hipMalloc(&scratch, want) != hipSuccess) return nullptr;
-        scratch_bytes = want;
-        return scratch;
-    }
-};
-
 std::mutex g_ctx_mu;
 Context* g_ctx = nullptr;
+}  // namespace umfa_rt
 
-bool device_usable(int* dev_out) {
-    int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return false;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return false;
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-        DBG("device %d is %s, not gfx950", dev, prop.gcnArchName);
-        return false;
-    }
-    if (dev_out) *dev_out = dev;
-    return true;
-}
-
-Context* as_ctx(mfa_context_t c) {
-    Context* x = (Context*)c;
-    return (x && x->magic == 0x4d464143) ? x : nullptr;
-}
-
-// ---- buffers (MFABuffer, MFABridge.swift:720-747, 850-1070) ---------------------------------
-struct Buffer {
-    uint32_t magic = 0x4d464142;  // 'MFAB'
-    void* host = nullptr;   // caller-visible memory (NULL for device-native wraps)
-    void* dev = nullptr;    // what kernels read/write
-    size_t bytes = 0;       // 0 = unknown (mfa_buffer_from_mtl_buffer with size 0)
-    bool owns_host = false, owns_dev = false;
-    std::vector<int64_t> shape, strides;
-
-    hipError_t upload(hipStream_t s) const {
-        if (!host || host == dev || bytes == 0) return hipSuccess;
-        return hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, s);
-    }
-    hipError_t download(hipStream_t s) const {
-        if (!host || host == dev || bytes == 0) return hipSuccess;
-        return hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s);
-    }
-    bool fits(size_t need) const { return bytes == 0 || need <= bytes; }
-};
-
-Buffer* as_buf(mfa_buffer_t b) {
-    Buffer* x = (Buffer*)b;
-    return (x && x->magic == 0x4d464142) ? x : nullptr;
-}
-
-bool is_device_pointer(const void* p) {
-    hipPointerAttribute_t a;
-    memset(&a, 0, sizeof(a));
-    hipError_t e = hipPointerGetAttributes(&a, p);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();  // unregistered host memory on older runtimes
-        return false;
-    }
-    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
-}
-
-mfa_error_t wrap_pointer(void* ptr, size_t bytes, const int64_t* shape, const int64_t* strides,
-                         uint32_t ndim, bool force_device, mfa_buffer_t* out) {
-    Buffer* b = new (std::nothrow) Buffer();
-    if (!b) return MFA_ERROR_MEMORY_ALLOCATION;
-    b->bytes = bytes;
-    if (force_device || is_device_pointer(ptr)) {
-        b->dev = ptr;  // true zero copy: HBM-resident tensor (torch-ROCm path)
-    } else {
-        // discrete GPU: a host tensor needs an HBM mirror (Metal's unified memory made this free,
-        // MFABridge.swift:892-904); staged around every synchronous op.
-        b->host = ptr;
-        if (bytes > 0) {
-            if (hipMalloc(&b->dev, bytes) != hipSuccess) {
-                delete b;
-                return MFA_ERROR_MEMORY_ALLOCATION;
-            }
-            b->owns_dev = true;
-        }
-    }
-    if (shape && strides && ndim) {
-        b->shape.assign(shape, shape + ndim);
-        b->strides.assign(strides, strides + ndim);
-    }
-    *out = b;
-    return MFA_SUCCESS;
-}
+namespace {
 
 int parse_precision(const char* s) {  // MFABridge.swift:1438-1451
     if (!s) return MFA_PRECISION_FP32;
@@ -156,9 +33,6 @@ int parse_precision(const char* s) {  // MFABridge.swift:1438-1451
     return MFA_PRECISION_FP32;
 }
 
-// dense path: any precision value other than 0/1 means FP32 (gemmPrecision, MFABridge.swift:1453-1462)
-int dense_prec(int p) { return p == 0 ? P_FP16 : p == 1 ? P_BF16 : P_FP32; }
-size_t elem_bytes(int prec) { return prec == P_FP32 ? 4 : 2; }
 
 // Normalise a <=4-D mask onto (b, h, q, k) strides; size-1 dims broadcast (MFABridge.swift:186-198).
 bool normalise_mask(const int64_t* shape, const int64_t* strides, uint32_t ndim, int type, int scalar,
@@ -207,28 +81,6 @@ hipError_t dispatch_forward(Context* ctx, const FwdParams& p, int intermediate_p
         p.mask_kind, name, hipGetErrorString(e));
     return e;
 }
-
-mfa_error_t map_hip(hipError_t e) {
-    if (e == hipSuccess) return MFA_SUCCESS;
-    if (e == hipErrorOutOfMemory) return MFA_ERROR_MEMORY_ALLOCATION;
-    if (e == hipErrorInvalidValue) return MFA_ERROR_INVALID_ARGS;
-    return MFA_ERROR_EXECUTION_FAILED;
-}
-
-struct Timed {  // hipEvent pair around a synchronous op -> mfa_get_gpu_latency
-    Context* c;
-    hipStream_t s;
-    Timed(Context* c_, hipStream_t s_) : c(c_), s(s_) { (void)hipEventRecord(c->ev0, s); }
-    hipError_t finish() {
-        (void)hipEventRecord(c->ev1, s);
-        hipError_t e = hipStreamSynchronize(s);
-        if (e == hipSuccess) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->last_latency = ms * 1e-3;
-        }
-        return e;
-    }
-};
 
 // Shared body of the synchronous dense forwards.
 mfa_error_t forward_sync(mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, mfa_buffer_t v, mfa_buffer_t out,
@@ -280,7 +132,7 @@ mfa_error_t forward_sync(mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, 
 
     if (bq->upload(stream) != hipSuccess || bk->upload(stream) != hipSuccess || bv->upload(stream) != hipSuccess)
         return MFA_ERROR_EXECUTION_FAILED;
-    Timed timer(ctx, stream);
+    (void)hipEventRecord(ctx->ev0, stream);  // kernel-only GPU time -> mfa_get_gpu_latency
     hipError_t e = dispatch_forward(ctx, p, inter, stream);
     if (e != hipSuccess) return e == hipErrorInvalidValue ? MFA_ERROR_INVALID_ARGS : MFA_ERROR_EXECUTION_FAILED;
     (void)hipEventRecord(ctx->ev1, stream);
