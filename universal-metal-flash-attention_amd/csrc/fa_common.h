@@ -46,6 +46,12 @@ struct FwdParams {
     int mask_kind;
     int in_prec;   // P_FP16 / P_BF16 / P_FP32
     int out_prec;  // P_FP16 / P_BF16 / P_FP32
+    // split-KV tail (fa_fwd_16): the last `n_items - n_full` items are cut into `nsplit` key ranges, one
+    // workgroup each; partial (O, m, l) go through part_buf and the last arriver (part_cnt) combines.
+    uint32_t n_full;     // items handled whole (== all items when nsplit <= 1)
+    uint32_t nsplit;     // parts per split item (0/1 = no split)
+    float* part_buf;     // [split item][part][wave 4][reg 16*NDB+2][lane 64] fp32
+    uint32_t* part_cnt;  // [split item] arrival tickets, zeroed before every launch
 };
 
 struct BwdParams {

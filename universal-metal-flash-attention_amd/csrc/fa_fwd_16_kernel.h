@@ -1,0 +1,415 @@
+// fa_fwd_16_kernel.h -- the bf16/fp16 MFMA forward kernel template (see fa_fwd_16.hip for the design notes).
+// Kept in a header so that tools/fwd_lab.hip can instantiate ONE variant for ablation/tuning builds.
+#pragma once
+#include "fa_common.h"
+
+namespace umfa {
+
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+#define LDS_AS __attribute__((address_space(3)))
+
+template <typename T> struct Mma16;
+template <> struct Mma16<__bf16> {
+    typedef bf16x8 V8;
+    typedef bf16x4_t V4;
+    static __device__ __forceinline__ f32x16 mma(V8 a, V8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ V4 tr_read(const char* lds) {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((V4 LDS_AS*)(lds));
+    }
+};
+template <> struct Mma16<_Float16> {
+    typedef f16x8 V8;
+    typedef f16x4_t V4;
+    static __device__ __forceinline__ f32x16 mma(V8 a, V8 b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ V4 tr_read(const char* lds) {
+        return __builtin_bit_cast(V4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 LDS_AS*)(lds)));
+    }
+};
+
+// LDS images.  A tile is [64 keys][DP] 16-bit elements; `ch` indexes 16-byte chunks of a row.
+// K is read by rows (ds_read_b128, 16 lanes = 16 different keys at one chunk): spread the 16
+// keys over the 16 chunk slots of a 256-byte bank row.
+template <int DP> __device__ __forceinline__ constexpr int k_off(int row, int ch) {
+    int sw = DP >= 128 ? (ch ^ (row & 15)) : DP == 64 ? (ch ^ ((row >> 1) & 7)) : (ch ^ ((row >> 2) & 3));
+    return row * (2 * DP) + 16 * sw;
+}
+// V is read transposed (ds_read_b64_tr_b16: a 32-lane half reads 4 consecutive keys x 64 bytes):
+// put the 4 keys in 4 different 64-byte bank segments.
+template <int DP> __device__ __forceinline__ constexpr int v_off(int row, int ch) {
+    int sw = DP >= 128 ? (ch ^ ((row & 3) << 2)) : DP == 64 ? (ch ^ (((row >> 1) & 1) << 2)) : ch;
+    return row * (2 * DP) + 16 * sw;
+}
+
+__device__ __forceinline__ float max_xor32(float x) {
+    // max over lane and lane^32 without LDS: v_permlane32_swap gives {x[l & 31], x[32 + (l & 31)]}
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT>
+__global__ __launch_bounds__(256, (DP <= 128 ? 2 : 1)) void fa_fwd16_kernel(FwdParams p) {
+    typedef Mma16<T> M;
+    typedef typename M::V8 V8;
+    typedef typename M::V4 V4;
+    constexpr int BM = 128, BN = 64;
+    constexpr int NCH = DP / 8;             // 16-byte chunks per row
+    constexpr int NKS = DP / 16;            // k-steps of QK^T
+    constexpr int NDB = DP / 32;            // 32-row blocks of O^T
+    constexpr int TILE_BYTES = BN * DP * 2;
+    constexpr int LPT = BN * NCH / 256;     // 16-byte loads per thread per tile
+    static_assert(LPT >= 1, "tile too small for 256 threads");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // [K buf0][K buf1][V buf0][V buf1]
+    char* const Kbuf = smem;
+    char* const Vbuf = smem + 2 * TILE_BYTES;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, ql = lane & 31, hi = lane >> 5;
+#ifdef UMFA_LAB_STAMPS
+    unsigned long long stamp[6];
+    stamp[0] = __builtin_amdgcn_s_memrealtime();
+    stamp[4] = __builtin_amdgcn_s_memtime();
+#endif
+    const uint32_t nqb = (p.Sq + BM - 1) / BM;
+    // work item = one 128-row query block of one (batch, head).  Items [0, n_full) are processed whole;
+    // the remaining ones (a partial last round of workgroups) are split into nsplit key ranges.
+    uint32_t item, part = 0, nparts = 1;
+    if (blockIdx.x < p.n_full) {
+        item = xcd_remap(blockIdx.x, p.n_full);
+    } else {
+        const uint32_t n_tail = gridDim.x - p.n_full;
+        const uint32_t j = xcd_remap(blockIdx.x - p.n_full, n_tail);
+        nparts = p.nsplit;
+        item = p.n_full + j / nparts;
+        part = j % nparts;
+    }
+    const uint32_t bh = item / nqb;
+    uint32_t qb = item % nqb;
+    if (CAUSAL) qb = nqb - 1 - qb;
+    const uint32_t b = bh / p.H, h = bh % p.H;
+    const uint32_t q_row = qb * BM + wave * 32 + ql;
+    const uint32_t wave_q0 = qb * BM + wave * 32;
+    const int D = (int)p.D;
+
+    // Hardware-bounds-checked buffer loads (T8): rows past the end of a (batch, head) slab and
+    // head_dim columns >= D read as zero with no branch; no address arithmetic beyond one add per load.
+    const T* qp = (const T*)p.q + ((int64_t)b * p.qs[0] + (int64_t)h * p.qs[1]);
+    const T* kp = (const T*)p.k + ((int64_t)b * p.ks[0] + (int64_t)h * p.ks[1]);
+    const T* vp = (const T*)p.v + ((int64_t)b * p.vs[0] + (int64_t)h * p.vs[1]);
+    const int q_stride_b = (int)p.qs[2] * 2, k_stride_b = (int)p.ks[2] * 2, v_stride_b = (int)p.vs[2] * 2;
+    const auto q_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)qp, 0, (int)((p.Sq - 1) * (uint32_t)q_stride_b + D * 2), 0x00020000);
+    const auto k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kp, 0, (int)((p.Skv - 1) * (uint32_t)k_stride_b + D * 2), 0x00020000);
+    const auto v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vp, 0, (int)((p.Skv - 1) * (uint32_t)v_stride_b + D * 2), 0x00020000);
+    constexpr int OOB = 0x7fffff00;  // an offset no slab reaches (supported(): slab < 2 GiB)
+
+    // ---- Q^T fragments (B operand of S^T = K Q^T): lane (q, hi) holds Q[q][16 ks + 8 hi .. +7]
+    V8 qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int d0 = 16 * ks + 8 * hi;
+        const int off = (q_row < p.Sq && d0 < D) ? (int)q_row * q_stride_b + d0 * 2 : OOB;
+        qf[ks] = __builtin_bit_cast(V8, __builtin_amdgcn_raw_buffer_load_b128(q_rsrc, off, 0, 0));
+    }
+
+    // ---- tile staging: thread owns chunks c = tid + 256 i  ->  (row, ch); offsets are tile-invariant
+    int koff[LPT], voff[LPT], klds[LPT], vlds[LPT];
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+        const int c = tid + 256 * i, row = c / NCH, ch = c % NCH;
+        const bool colok = ch * 8 < D;
+        koff[i] = colok ? row * k_stride_b + ch * 16 : OOB;
+        voff[i] = colok ? row * v_stride_b + ch * 16 : OOB;
+        klds[i] = k_off<DP>(row, ch);
+        vlds[i] = v_off<DP>(row, ch);
+    }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 kreg[LPT], vreg[LPT];
+    auto stage_load = [&](uint32_t t) {
+        const int ksoff = (int)(t * BN) * k_stride_b, vsoff = (int)(t * BN) * v_stride_b;
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            // the tile advance goes into voffset: soffset is excluded from the hardware range check
+            kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, koff[i] + ksoff, 0, 0);
+            vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, voff[i] + vsoff, 0, 0);
+        }
+    };
+    auto stage_write = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < LPT; ++i) {
+            *(u32x4*)(Kbuf + buf * TILE_BYTES + klds[i]) = kreg[i];
+            *(u32x4*)(Vbuf + buf * TILE_BYTES + vlds[i]) = vreg[i];
+        }
+    };
+
+    uint32_t ntiles = (p.Skv + BN - 1) / BN;
+    if (CAUSAL) {
+        const uint32_t lim = (qb * BM + BM + BN - 1) / BN;
+        ntiles = ntiles < lim ? ntiles : lim;
+    }
+    const uint32_t t_begin = (uint32_t)(((uint64_t)ntiles * part) / nparts);
+    const uint32_t t_end = (uint32_t)(((uint64_t)ntiles * (part + 1)) / nparts);
+
+    f32x16 acc[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    float m = -INFINITY;
+    float l4[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // four partial row sums: short dependent chains
+    const float c2 = p.scale * UMFA_LOG2E;
+
+    // V transposed read: lane = 16 g + 4 qq + pp supplies row key0 + qq, columns 32 db + 16 (g&1) + 4 pp
+    const int tr_qq = (lane >> 2) & 3, tr_pp = lane & 3, tr_g1 = (lane >> 4) & 1;
+    int vtr[NDB];  // per-lane byte offset of the d-block's first transposed read (rows 4 hi + qq)
+#pragma unroll
+    for (int i = 0; i < NDB; ++i) vtr[i] = v_off<DP>(4 * hi + tr_qq, 4 * i + 2 * tr_g1 + (tr_pp >> 1)) + 8 * (tr_pp & 1);
+    // the swizzles of v_off depend on row bits 0-1 only (DP >= 128) / bit 1 (DP == 64): adding a multiple
+    // of 4 rows is a pure byte offset, so every other read of the tile is vtr[i] + const
+    auto v_frag = [&](const char* Vt, int i, int st) -> V8 {
+        const V4 lo = M::tr_read(Vt + vtr[i] + (16 * st) * (2 * DP));
+        const V4 hi4 = M::tr_read(Vt + vtr[i] + (16 * st + 8) * (2 * DP));
+        return __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+
+    const int64_t mrow = HAS_MASK ? ((int64_t)b * p.ms[0] + (int64_t)h * p.ms[1] + (int64_t)q_row * p.ms[2]) : 0;
+
+    stage_load(t_begin);
+    stage_write(t_begin & 1);
+    __syncthreads();
+#ifdef UMFA_LAB_STAMPS
+    stamp[1] = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    for (uint32_t t = t_begin; t < t_end; ++t) {
+        const int cur = t & 1;
+#ifndef UMFA_ABL_NO_LOAD
+        stage_load(t + 1);  // next tile in flight under this tile's MFMAs (T14); past the end: all zeros
+#endif
+
+        const char* Kt = Kbuf + cur * TILE_BYTES;
+        const char* Vt = Vbuf + cur * TILE_BYTES;
+        const uint32_t key_base = t * BN;
+        // wave-uniform: is any part of this tile visible to this wave's rows?
+        const bool active = !CAUSAL || key_base <= wave_q0 + 31;
+
+        if (active) {
+            // ---------------- S^T = K Q^T ----------------
+            f32x16 s[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
+#pragma unroll
+#ifdef UMFA_ABL_NO_QK
+                for (int r = 0; r < 16; ++r) s[kb][r] = __builtin_bit_cast(float, (int)(Kt[r * 4 + lane] & 1) + 0x3f800000);
+#else
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const V8 a = *(const V8*)(Kt + k_off<DP>(32 * kb + ql, 2 * ks + hi));
+                    s[kb] = M::mma(a, qf[ks], s[kb]);
+                }
+#endif
+            }
+            // first V^T fragments requested before the softmax so their LDS latency hides under it
+            V8 va[4];
+#pragma unroll
+            for (int st = 0; st < 4; ++st) va[st] = v_frag(Vt, 0, st);
+
+            // ---------------- online softmax (log2 domain) ----------------
+            const bool edge = (key_base + BN > p.Skv) || (CAUSAL && key_base + BN - 1 > wave_q0);
+            float mx = -INFINITY;
+            if (HAS_MASK) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const uint32_t key = key_base + 32 * kb + acc_row(r, hi);
+                        float tv = s[kb][r] * c2;
+                        if (key < p.Skv && q_row < p.Sq)
+                            tv += mask_term(p.mask, mrow + (int64_t)key * p.ms[3], p.mask_kind);
+                        if (key >= p.Skv || (CAUSAL && key > q_row)) tv = -INFINITY;
+                        s[kb][r] = tv;
+                        mx = fmaxf(mx, tv);
+                    }
+            } else {
+                if (edge) {
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const uint32_t key = key_base + 32 * kb + acc_row(r, hi);
+                            if (key >= p.Skv || (CAUSAL && key > q_row)) s[kb][r] = -INFINITY;
+                        }
+                }
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+                mx *= c2;  // scale > 0 on this path
+            }
+            mx = max_xor32(mx);
+            const float m_new = fmaxf(m, mx);
+            const float m_use = (HAS_MASK && m_new == -INFINITY) ? 0.0f : m_new;
+            if (!__all(m_new == m)) {
+                const float alpha = __builtin_amdgcn_exp2f(m - m_use);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) l4[j] *= alpha;
+#pragma unroll
+                for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
+                m = m_new;
+            }
+            V8 pf[4];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+#ifdef UMFA_ABL_NO_EXP
+                    const float e = __builtin_fmaf(s[kb][r], c2, -m_use);
+#else
+                    const float e = HAS_MASK ? __builtin_amdgcn_exp2f(s[kb][r] - m_use)
+                                             : __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], c2, -m_use));
+#endif
+                    l4[r & 3] += e;
+                    pf[2 * kb + (r >> 3)][r & 7] = (T)e;
+                }
+
+            // ---------------- O^T += V^T P^T (fragments of block i+1 requested before block i's MFMAs) ----
+#pragma unroll
+            for (int i = 0; i < NDB; ++i) {
+                V8 vb[4];
+                if (i + 1 < NDB) {
+#pragma unroll
+                    for (int st = 0; st < 4; ++st) vb[st] = v_frag(Vt, i + 1, st);
+                }
+#ifdef UMFA_ABL_NO_PV
+#pragma unroll
+                for (int st = 0; st < 4; ++st) acc[i][st] += (float)va[st][0] * (float)pf[st][0];
+#else
+#pragma unroll
+                for (int st = 0; st < 4; ++st) acc[i] = M::mma(va[st], pf[st], acc[i]);
+#endif
+                if (i + 1 < NDB) {
+#pragma unroll
+                    for (int st = 0; st < 4; ++st) va[st] = vb[st];
+                }
+            }
+        }
+
+#ifndef UMFA_ABL_NO_LOAD
+        stage_write(cur ^ 1);
+#endif
+#ifndef UMFA_ABL_NO_BARRIER
+        __syncthreads();
+#endif
+    }
+
+#ifdef UMFA_LAB_STAMPS
+    stamp[2] = __builtin_amdgcn_s_memrealtime();
+    stamp[5] = __builtin_amdgcn_s_memtime();
+#endif
+    // ---------------- epilogue ----------------
+    float l = (l4[0] + l4[1]) + (l4[2] + l4[3]);
+    float lt = l + xor32(l);
+    if (nparts > 1) {
+        // Split-KV combine (cdna_hip_programming.md Guideline 16, counter form): every part publishes its
+        // un-normalised (O^T, m, l) with plain stores -> vmcnt(0) -> barrier -> ONE agent-scope release ->
+        // ticket; the part that draws the last ticket acquires once and folds the others into its registers.
+        constexpr int NREG = 16 * NDB + 2;
+        // every static __shared__ object would shift the dynamic LDS base (Guideline 17): reuse the tile area
+        volatile uint32_t& ticket_s = *(volatile uint32_t*)smem;
+        const uint32_t sidx = item - p.n_full;
+        float* mine = p.part_buf + (((size_t)sidx * nparts + part) * 4 + wave) * (size_t)(NREG * 64);
+#pragma unroll
+        for (int i = 0; i < NDB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[(16 * i + r) * 64 + lane] = acc[i][r];
+        mine[(16 * NDB) * 64 + lane] = m;
+        mine[(16 * NDB + 1) * 64 + lane] = lt;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // also: every wave is done with the K/V tiles, so smem[0..3] is free
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ticket_s = __hip_atomic_fetch_add(p.part_cnt + sidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        const uint32_t ticket = ticket_s;
+        if (ticket != nparts - 1) return;  // not the last part of this item
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        // fold the parts in index order (own part re-read from memory too): the result does not depend on
+        // which part arrived last, so two launches are bitwise identical
+        {
+            const float* p0 = p.part_buf + (((size_t)sidx * nparts) * 4 + wave) * (size_t)(NREG * 64);
+#pragma unroll
+            for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = p0[(16 * i + r) * 64 + lane];
+            m = p0[(16 * NDB) * 64 + lane];
+            lt = p0[(16 * NDB + 1) * 64 + lane];
+        }
+        for (uint32_t o = 1; o < nparts; ++o) {
+            const float* other = p.part_buf + (((size_t)sidx * nparts + o) * 4 + wave) * (size_t)(NREG * 64);
+            const float mo = other[(16 * NDB) * 64 + lane];
+            const float lo = other[(16 * NDB + 1) * 64 + lane];
+            const float mn = fmaxf(m, mo);
+            const float mu = mn == -INFINITY ? 0.0f : mn;
+            const float a0 = __builtin_amdgcn_exp2f(m - mu), a1 = __builtin_amdgcn_exp2f(mo - mu);
+#pragma unroll
+            for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = acc[i][r] * a0 + other[(16 * i + r) * 64 + lane] * a1;
+            lt = lt * a0 + lo * a1;
+            m = mn;
+        }
+    }
+    const float inv = lt > 0.0f ? 1.0f / lt : 0.0f;
+    if (q_row < p.Sq) {
+        OUT* __restrict__ op = (OUT*)p.o + ((int64_t)bh * p.Sq + q_row) * D;
+#pragma unroll
+        for (int i = 0; i < NDB; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = 32 * i + 8 * g + 4 * hi;
+                if (d0 < D) {  // D % 8 == 0 on this path, so a group of 4 is all-in or all-out
+                    if constexpr (sizeof(OUT) == 4) {
+                        f32x4 val = {acc[i][4 * g] * inv, acc[i][4 * g + 1] * inv, acc[i][4 * g + 2] * inv,
+                                     acc[i][4 * g + 3] * inv};
+                        *(f32x4*)(op + d0) = val;
+                    } else {
+                        typedef OUT O4 __attribute__((ext_vector_type(4)));
+                        O4 val = {(OUT)(acc[i][4 * g] * inv), (OUT)(acc[i][4 * g + 1] * inv),
+                                  (OUT)(acc[i][4 * g + 2] * inv), (OUT)(acc[i][4 * g + 3] * inv)};
+                        *(O4*)(op + d0) = val;
+                    }
+                }
+            }
+        if (p.lse && hi == 0)
+            p.lse[(int64_t)bh * p.Sq + q_row] = lt > 0.0f ? (m + log2f(lt)) * UMFA_LN2 : -INFINITY;
+    }
+#ifdef UMFA_LAB_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp[3] = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0) {  // a debug buffer of its own (lab only): [block][6]
+        unsigned long long* dbg = (unsigned long long*)p.part_buf + (size_t)blockIdx.x * 8;
+        for (int i = 0; i < 6; ++i) dbg[i] = stamp[i];
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        dbg[6] = xcc;
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        dbg[7] = hwid;
+    }
+#endif
+}
+
+}  // namespace umfa

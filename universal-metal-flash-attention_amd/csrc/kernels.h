@@ -14,6 +14,12 @@ hipError_t launch_fwd_exact(const FwdParams& p, hipStream_t stream, const char**
 // (the caller then takes the exact path).
 hipError_t launch_fwd_16(const FwdParams& p, hipStream_t stream, const char** name);
 bool fwd_16_supported(const FwdParams& p);
+// Split-KV tail plan: how many items stay whole, parts per split item, scratch sizes (0 = no split).
+struct FwdSplitPlan {
+    uint32_t n_full, nsplit;
+    size_t buf_bytes, cnt_bytes;
+};
+FwdSplitPlan fwd_16_split_plan(const FwdParams& p);
 
 // Backward: D = rowsum(dO o O), then dK/dV and dQ.
 hipError_t launch_bwd(const BwdParams& p, hipStream_t stream, const char** name);

@@ -74,8 +74,23 @@ hipError_t dispatch_forward(Context* ctx, const FwdParams& p, int intermediate_p
     const char* name = "none";
     hipError_t e;
     const bool lowp = p.in_prec != P_FP32 && intermediate_prec != P_FP32;
-    if (lowp && fwd_16_supported(p)) e = launch_fwd_16(p, stream, &name);
-    else e = launch_fwd_exact(p, stream, &name);
+    if (lowp && fwd_16_supported(p)) {
+        FwdParams pp = p;
+        const FwdSplitPlan plan = fwd_16_split_plan(p);
+        if (plan.nsplit > 1) {
+            // tickets first (16-byte multiple at the allocation start), partials behind them
+            char* buf = (char*)ctx->ensure_split(plan.cnt_bytes + plan.buf_bytes);
+            if (buf) {
+                pp.n_full = plan.n_full;
+                pp.nsplit = plan.nsplit;
+                pp.part_cnt = (uint32_t*)buf;
+                pp.part_buf = (float*)(buf + plan.cnt_bytes);
+            }
+        }
+        e = launch_fwd_16(pp, stream, &name);
+    } else {
+        e = launch_fwd_exact(p, stream, &name);
+    }
     ctx->last_kernel = name;
     DBG("forward B%u H%u Sq%u Skv%u D%u causal%d mask%d -> %s (%s)", p.B, p.H, p.Sq, p.Skv, p.D, p.causal,
         p.mask_kind, name, hipGetErrorString(e));

@@ -34,11 +34,23 @@ struct Context {
     const char* last_kernel = "none";
     void* scratch = nullptr;  // host-mask staging
     size_t scratch_bytes = 0;
+    void* split_buf = nullptr;  // split-KV partials + tickets (fa_fwd_16)
+    size_t split_bytes = 0;
     void* workspace = nullptr;  // quantiser output (int8 Q/K, fp16 V, scales, fp32 copies for backward)
     size_t workspace_bytes = 0;
     std::vector<float> q_scales, k_scales, v_scales;  // mfa_set_scale_arrays: stored, never read
     std::atomic<int> refs{0};
     std::mutex mu;
+
+    void* ensure_split(size_t bytes) {
+        if (bytes <= split_bytes) return split_buf;
+        if (split_buf) (void)hipFree(split_buf);
+        split_buf = nullptr;
+        split_bytes = 0;
+        if (hipMalloc(&split_buf, bytes + 256) != hipSuccess) return nullptr;
+        split_bytes = bytes + 256;
+        return split_buf;
+    }
 
     void* ensure_workspace(size_t bytes) {
         if (bytes <= workspace_bytes) return workspace;

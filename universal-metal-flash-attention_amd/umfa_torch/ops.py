@@ -107,3 +107,83 @@ def attention_encode(q, k, v, out32, *, scale=None, causal=False, mask=None, str
         mptr, 0, mshape, mstr, mnd, mt, ms, B, Sq, Skv, H, D, float(scale), bool(causal),
         _PREC_NAME[q.dtype], _PREC_NAME[q.dtype]))
     return out32
+
+
+class _DevBuf:
+    """mfa_buffer_t view of a device tensor (mfa_buffer_from_mtl_buffer: borrowed raw device pointer)."""
+
+    def __init__(self, t: Optional[torch.Tensor]):
+        from umfa._ffi import mfa_buffer_t
+        self.handle = mfa_buffer_t()
+        if t is not None:
+            _check_error(_lib.mfa_buffer_from_mtl_buffer(context(), ctypes.c_void_p(t.data_ptr()),
+                                                         t.numel() * t.element_size(), ctypes.byref(self.handle)))
+
+    def close(self):
+        if self.handle:
+            _lib.mfa_destroy_buffer(self.handle)
+            self.handle = None
+
+
+def quantized_attention_forward(q, k, v, *, scale=None, causal=False, mask=None, bits: int = 8,
+                                quant_mode: str = "blockwise"):
+    """Runtime-quantised SDPA on device tensors through mfa_quantized_forward_with_lse (synchronous, like the
+    reference's MetalQuantizedFlashAttentionFn::forward, metal_sdpa_backend.cpp:3142-3267).
+    Returns (O fp32 [B,H,Sq,D], LSE fp32 [B*H*Sq]); GPU seconds of quantiser + attention via gpu_latency()."""
+    B, H, Sq, D = q.shape
+    Skv = k.shape[2]
+    if scale is None:
+        scale = D ** -0.5
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    out = torch.empty((B, H, Sq, D), dtype=torch.float32, device=q.device)
+    lse = torch.empty((B * H * Sq,), dtype=torch.float32, device=q.device)
+    m32 = None
+    if mask is not None:
+        m32 = torch.zeros((B, H, Sq, Skv), dtype=torch.float32, device=q.device)
+        m32 = m32.masked_fill(~mask, float("-inf")) if mask.dtype == torch.bool else m32 + mask.float()
+        m32 = m32.contiguous()
+    torch.cuda.current_stream(q.device).synchronize()  # the entry runs on the legacy default stream
+    bufs = [_DevBuf(t) for t in (q, k, v, out, lse, m32)]
+    try:
+        _check_error(_lib.mfa_quantized_forward_with_lse(
+            context(), *(b.handle for b in bufs), B, Sq, Skv, H, D, float(scale), bool(causal),
+            4 if bits == 4 else 3, 2 if quant_mode.startswith("block") else 0, _PREC[q.dtype]))
+    finally:
+        for b in bufs:
+            b.close()
+    return out, lse
+
+
+def gpu_latency() -> float:
+    return float(_lib.mfa_get_gpu_latency(context()))
+
+
+def bench_int8(steps: int = 20, warmup: int = 3):
+    """int8 block-quantised forward vs the bf16 forward on the same tensors (quantiser pre-pass included),
+    for the FLUX shape and BASELINE config 4 (B1 H16 S8192 D128).  GPU time from the library's hipEvents."""
+    res = {}
+    for name, (B, H, S, D) in {"flux_B1_H24_S4096_D128": (1, 24, 4096, 128), "cfg4_B1_H16_S8192_D128": (1, 16, 8192, 128)}.items():
+        torch.manual_seed(0)
+        q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+        out = torch.empty(B, H, S, D, device="cuda", dtype=torch.float32)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        for _ in range(warmup):
+            attention_forward(q, k, v, out=out)
+        for a, b in ev:
+            a.record()
+            attention_forward(q, k, v, out=out)
+            b.record()
+        torch.cuda.synchronize()
+        bf = sorted(a.elapsed_time(b) for a, b in ev)
+        t8 = []
+        for i in range(warmup + steps):
+            quantized_attention_forward(q, k, v)
+            if i >= warmup:
+                t8.append(gpu_latency() * 1e3)
+        t8.sort()
+        flops = 4.0 * B * H * S * S * D
+        res[name] = {"bf16_ms": round(bf[len(bf) // 2], 4), "int8_ms_incl_quantiser": round(t8[len(t8) // 2], 4),
+                     "speedup": round(bf[len(bf) // 2] / t8[len(t8) // 2], 3),
+                     "int8_TOPs": round(flops / (t8[len(t8) // 2] * 1e-3) / 1e12, 1), "fp32_out": True}
+        del q, k, v, out
+    return res

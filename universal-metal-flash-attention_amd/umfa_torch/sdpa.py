@@ -1,0 +1,262 @@
+"""scaled_dot_product_attention routing for torch-ROCm tensors.
+
+Counterpart of MetalSDPABackend::scaled_dot_product_attention and its three autograd Functions
+(examples/pytorch-custom-op-ffi/src/metal_sdpa_backend.cpp:1643-1904, 2672-2870, 3139-3397) with the
+reference's semantics:
+  (i)   default scale 1/sqrt(D) when `scale` is None                               (:1827-1835)
+  (ii)  2-D / 3-D inputs are promoted to 4-D BHSD and squeezed back                (:1667-1683)
+  (iii) GQA (Hq % Hkv == 0) via repeat_interleave of K, V                           (:1694-1702)
+  (iv)  non-accelerator tensors, non-4-D, dtype not in {f32,f16,bf16}, mixed dtypes or dropout > 0
+        go to torch's native SDPA (counter pytorch_fallback)                        (:1720-1765)
+  (v)   the output has the input dtype                                               (:1442-1444)
+  (vi)  an all-true bool mask is the same as no mask                                 (:1771-1784)
+  (vii) nine dispatch counters                                                       (metal_sdpa_backend.h:666-681)
+The kernels read strided masks in-tile, so (vi) needs no host synchronisation here: the all-true check
+(`mask.all().item()`, a device sync in the reference) only runs when UMFA_STRIP_TRUE_MASKS=1.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from contextlib import contextmanager
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from umfa._ffi import MFA_PRECISION_INT4, MFA_PRECISION_INT8, _check_error, _lib
+
+from . import ops
+
+QUANT_NONE, QUANT_INT8, QUANT_INT4 = 0, MFA_PRECISION_INT8, MFA_PRECISION_INT4   # metal_sdpa_backend.h:650-664
+QUANT_TENSOR_WISE, QUANT_BLOCK_WISE = 0, 2
+
+_COUNTER_NAMES = ("total", "quantized_autograd", "fp32_autograd", "fp32_direct", "fp32_instream", "rope_instream",
+                  "rope_autograd", "pytorch_fallback", "mask_all_true_skipped")
+_stats = {k: 0 for k in _COUNTER_NAMES}
+_stats_lock = threading.Lock()
+_quant_precision = QUANT_NONE
+_quant_mode = QUANT_TENSOR_WISE
+_native_sdpa = F.scaled_dot_product_attention
+_SUPPORTED = (torch.float32, torch.float16, torch.bfloat16)
+
+
+def _bump(name: str) -> None:
+    with _stats_lock:
+        _stats[name] += 1
+
+
+def get_dispatch_stats() -> dict:
+    with _stats_lock:
+        return dict(_stats)
+
+
+def reset_dispatch_stats() -> None:
+    with _stats_lock:
+        for k in _stats:
+            _stats[k] = 0
+
+
+def set_quantization_mode(precision: int = QUANT_NONE, mode: int = QUANT_TENSOR_WISE) -> None:
+    """Process-global switch (metal_sdpa_backend.cpp:3420-3427): 0 = off, 3 = INT8, 4 = INT4;
+    mode 0 = tensor-wise, 2 = block-wise."""
+    global _quant_precision, _quant_mode
+    if precision not in (QUANT_NONE, QUANT_INT8, QUANT_INT4):
+        raise ValueError("precision must be 0 (off), 3 (INT8) or 4 (INT4)")
+    if mode not in (QUANT_TENSOR_WISE, QUANT_BLOCK_WISE):
+        raise ValueError("mode must be 0 (tensor-wise) or 2 (block-wise)")
+    _quant_precision, _quant_mode = precision, mode
+
+
+def get_quantization_mode():
+    return _quant_precision, _quant_mode
+
+
+def _sync_for_blocking_abi(t: torch.Tensor) -> None:
+    # the synchronous C-ABI entries run on the legacy default stream and block; make torch's current
+    # stream visible to them first (the reference calls torch::mps::synchronize(), :2693-2695)
+    torch.cuda.current_stream(t.device).synchronize()
+
+
+def _dev_bufs(*tensors):
+    return [ops._DevBuf(t) for t in tensors]
+
+
+class _FlashAttentionFn(torch.autograd.Function):
+    """MetalFlashAttentionFn (:2672-2870): fp32 O + LSE saved, backward through mfa_attention_backward."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, causal: bool, scale: float):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        o32, lse = ops.attention_forward(q, k, v, scale=scale, causal=causal, out_dtype=torch.float32,
+                                         return_lse=True)
+        ctx.save_for_backward(q, k, v, o32, lse)
+        ctx.causal, ctx.scale = causal, scale
+        return o32.to(q.dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, o32, lse = ctx.saved_tensors
+        B, H, Sq, D = q.shape
+        Skv = k.shape[2]
+        dout = dout.to(q.dtype).contiguous()
+        dq = torch.empty((B, H, Sq, D), dtype=torch.float32, device=q.device)
+        dk = torch.empty((B, H, Skv, D), dtype=torch.float32, device=q.device)
+        dv = torch.empty_like(dk)
+        dvec = torch.empty((B * H * Sq,), dtype=torch.float32, device=q.device)
+        _sync_for_blocking_abi(q)
+        bufs = _dev_bufs(dout, q, k, v, o32, lse, dq, dk, dv, dvec)
+        try:
+            prec = ops._PREC[q.dtype]
+            _check_error(_lib.mfa_attention_backward(ops.context(), *(b.handle for b in bufs), B, Sq, Skv, H, D,
+                                                     float(ctx.scale), bool(ctx.causal), prec, prec,
+                                                     False, False, False, False))
+        finally:
+            for b in bufs:
+                b.close()
+        return dq.to(q.dtype), dk.to(q.dtype), dv.to(q.dtype), None, None
+
+
+class _QuantizedFlashAttentionFn(torch.autograd.Function):
+    """MetalQuantizedFlashAttentionFn (:3139-3397): runtime quantisation of Q, K, V; STE backward."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, causal: bool, scale: float, precision: int, mode: int, mask):
+        if q.dtype not in (torch.float16, torch.bfloat16):
+            q, k, v = q.float(), k.float(), v.float()  # (:3157-3171)
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        o32, lse = ops.quantized_attention_forward(q, k, v, scale=scale, causal=causal, mask=mask,
+                                                   bits=4 if precision == QUANT_INT4 else 8,
+                                                   quant_mode="blockwise" if mode == QUANT_BLOCK_WISE else "tensor")
+        ctx.save_for_backward(q, k, v, o32, lse)
+        ctx.mask = mask
+        ctx.args = (causal, scale, precision, mode)
+        return o32
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, o32, lse = ctx.saved_tensors
+        causal, scale, precision, mode = ctx.args
+        B, H, Sq, D = q.shape
+        Skv = k.shape[2]
+        dout = dout.to(q.dtype).contiguous()
+        dq = torch.empty((B, H, Sq, D), dtype=torch.float32, device=q.device)
+        dk = torch.empty((B, H, Skv, D), dtype=torch.float32, device=q.device)
+        dv = torch.empty_like(dk)
+        m32 = None
+        if ctx.mask is not None:
+            m32 = torch.zeros((B, H, Sq, Skv), dtype=torch.float32, device=q.device)
+            m32 = (m32.masked_fill(~ctx.mask, float("-inf")) if ctx.mask.dtype == torch.bool else m32 + ctx.mask.float()).contiguous()
+        _sync_for_blocking_abi(q)
+        bufs = _dev_bufs(q, k, v, o32, dout, lse, dq, dk, dv, m32)
+        try:
+            _check_error(_lib.mfa_quantized_backward(ops.context(), *(b.handle for b in bufs), B, Sq, Skv, H, D,
+                                                     float(scale), bool(causal), int(precision), int(mode),
+                                                     ops._PREC[q.dtype]))
+        finally:
+            for b in bufs:
+                b.close()
+        return dq.to(q.dtype), dk.to(q.dtype), dv.to(q.dtype), None, None, None, None, None
+
+
+def scaled_dot_product_attention(query, key, value, attn_mask: Optional[torch.Tensor] = None, dropout_p: float = 0.0,
+                                 is_causal: bool = False, scale: Optional[float] = None, enable_gqa: bool = False):
+    if key.dim() != value.dim() or key.dim() < 2 or key.size(-2) != value.size(-2):
+        raise RuntimeError("UMFA SDPA: key and value must have matching sequence lengths")
+    # (ii) promote 2-D / 3-D
+    if 2 <= query.dim() < 4 and key.dim() == query.dim():
+        q4, k4, v4 = query, key, value
+        while q4.dim() < 4:
+            q4, k4, v4 = q4.unsqueeze(0), k4.unsqueeze(0), v4.unsqueeze(0)
+        out = scaled_dot_product_attention(q4, k4, v4, attn_mask, dropout_p, is_causal, scale, enable_gqa)
+        for _ in range(4 - query.dim()):
+            out = out.squeeze(0)
+        return out
+    _bump("total")
+    q, k, v = query, key, value
+    # (iii) GQA
+    if q.dim() >= 3 and k.dim() >= 3 and q.size(-3) != k.size(-3):
+        hq, hkv = q.size(-3), k.size(-3)
+        if hq > hkv and hq % hkv == 0:
+            k = k.repeat_interleave(hq // hkv, -3).contiguous()
+            v = v.repeat_interleave(hq // hkv, -3).contiguous()
+
+    def fallback():
+        _bump("pytorch_fallback")
+        m = attn_mask
+        if m is not None and m.dtype in (torch.float16, torch.bfloat16):
+            m = m.float()
+        return _native_sdpa(query, key, value, attn_mask=m, dropout_p=dropout_p, is_causal=is_causal, scale=scale,
+                            enable_gqa=enable_gqa)
+
+    unsupported = (not (q.is_cuda and k.is_cuda and v.is_cuda) or q.dim() != 4 or k.dim() != 4 or v.dim() != 4
+                   or q.size(0) != k.size(0) or q.size(0) != v.size(0) or q.size(1) != k.size(1)
+                   or q.size(1) != v.size(1) or q.size(3) != k.size(3) or q.size(3) != v.size(3)
+                   or q.dtype not in _SUPPORTED or k.dtype != q.dtype or v.dtype != q.dtype
+                   or q.size(3) > 256 or q.size(3) == 0)
+    if unsupported or dropout_p > 0.0:
+        return fallback()
+
+    # (vi) masks
+    mask = None
+    if attn_mask is not None:
+        mask = attn_mask
+        if mask.dtype == torch.bool and mask.numel() > 0 and os.environ.get("UMFA_STRIP_TRUE_MASKS") == "1":
+            if bool(mask.all().item()):
+                _bump("mask_all_true_skipped")
+                mask = None
+        if mask is not None and mask.dtype not in (torch.bool, torch.float32, torch.float16, torch.bfloat16):
+            return fallback()
+        if mask is not None and mask.dim() > 4:
+            return fallback()
+    # (i) scale
+    sm_scale = float(scale) if scale is not None else float(q.size(-1)) ** -0.5
+
+    if _quant_precision != QUANT_NONE:
+        _bump("quantized_autograd")
+        out = _QuantizedFlashAttentionFn.apply(q, k, v, bool(is_causal), sm_scale, _quant_precision, _quant_mode, mask)
+        return out.to(query.dtype)
+    if q.requires_grad or k.requires_grad or v.requires_grad:
+        if mask is not None or q.size(3) > 128:
+            return fallback()  # dense backward takes no mask (:1798-1803)
+        _bump("fp32_autograd")
+        return _FlashAttentionFn.apply(q, k, v, bool(is_causal), sm_scale)
+    # inference: in-stream, zero-copy, output directly in the input dtype (v)
+    for t in (q, k, v):
+        if t.stride(-1) != 1:
+            q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+            break
+    _bump("fp32_instream")
+    return ops.attention_forward(q, k, v, scale=sm_scale, causal=bool(is_causal), mask=mask, out_dtype=q.dtype)
+
+
+_registered = False
+
+
+def register_backend() -> None:
+    """Route torch.nn.functional.scaled_dot_product_attention through this module (the reference overrides the
+    aten op for the MPS key, :3464-3470; its examples/flux harness monkey-patches F.sdpa the same way)."""
+    global _registered
+    if not _registered:
+        F.scaled_dot_product_attention = scaled_dot_product_attention
+        _registered = True
+
+
+def unregister_backend() -> None:
+    global _registered
+    if _registered:
+        F.scaled_dot_product_attention = _native_sdpa
+        _registered = False
+
+
+@contextmanager
+def use_umfa_sdpa():
+    """Context manager form (reference: pytorch_custom_op_ffi.backend.use_metal_sdpa)."""
+    was = _registered
+    register_backend()
+    try:
+        yield
+    finally:
+        if not was:
+            unregister_backend()
