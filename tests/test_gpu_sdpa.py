@@ -1,0 +1,124 @@
+"""GPU: F.scaled_dot_product_attention routed through the HIP kernels vs torch's own SDPA
+(the reference's declared ground truth; tolerances conftest.py:186-199)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(autouse=True)
+def _clean():
+    import umfa_torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a device")
+    umfa_torch.reset_dispatch_stats()
+    umfa_torch.set_quantization_mode(0, 0)
+    yield
+    umfa_torch.set_quantization_mode(0, 0)
+    umfa_torch.unregister_backend()
+
+
+TOL = {torch.float32: 1e-5, torch.float16: 2e-3, torch.bfloat16: 1.5e-2}
+
+
+def ref64(q, k, v, **kw):
+    from umfa_torch import sdpa
+    m = kw.pop("attn_mask", None)
+    if m is not None and m.dtype != torch.bool:
+        m = m.double()
+    return sdpa._native_sdpa(q.double().cpu(), k.double().cpu(), v.double().cpu(),
+                             attn_mask=None if m is None else m.cpu(), **kw).float()
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(1, 12, 77, 64), (2, 4, 256, 64), (1, 24, 1536, 128)])
+def test_inference_matches_torch(dt, shape):
+    import umfa_torch
+    torch.manual_seed(42)
+    q, k, v = (torch.randn(shape, device="cuda", dtype=dt) * 0.1 for _ in range(3))  # conftest.py:149-158
+    for causal in (False, True):
+        out = umfa_torch.scaled_dot_product_attention(q, k, v, is_causal=causal)
+        assert out.dtype == dt and out.shape == q.shape  # test_scale_factor_fix.py:112-114
+        assert (out.float().cpu() - ref64(q, k, v, is_causal=causal)).abs().max() < TOL[dt]
+    s = umfa_torch.get_dispatch_stats()
+    assert s["fp32_instream"] == 2 and s["pytorch_fallback"] == 0
+
+
+def test_default_scale_and_promotion():
+    import umfa_torch
+    q, k, v = (torch.randn(32, 32, device="cuda") for _ in range(3))
+    a = umfa_torch.scaled_dot_product_attention(q, k, v)
+    b = umfa_torch.scaled_dot_product_attention(q, k, v, scale=1.0 / np.sqrt(32))
+    assert a.shape == (32, 32) and (a - b).abs().max() < 1e-7  # test_scale_factor_fix.py:68-98
+
+
+def test_gqa_and_masks():
+    import umfa_torch
+    torch.manual_seed(1)
+    q = torch.randn(2, 8, 128, 64, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(2, 2, 128, 64, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn(2, 2, 128, 64, device="cuda", dtype=torch.bfloat16)
+    out = umfa_torch.scaled_dot_product_attention(q, k, v, enable_gqa=True)
+    ref = ref64(q, k.repeat_interleave(4, 1), v.repeat_interleave(4, 1))
+    assert (out.float().cpu() - ref).abs().max() < 2e-2
+    kk, vv = k.repeat_interleave(4, 1), v.repeat_interleave(4, 1)
+    mb = torch.rand(2, 1, 128, 128, device="cuda") > 0.2
+    mb[..., 0] = True
+    out = umfa_torch.scaled_dot_product_attention(q, kk, vv, attn_mask=mb)
+    assert (out.float().cpu() - ref64(q, kk, vv, attn_mask=mb)).abs().max() < 2e-2
+    ma = torch.randn(128, 128, device="cuda", dtype=torch.bfloat16)
+    out = umfa_torch.scaled_dot_product_attention(q, kk, vv, attn_mask=ma)
+    assert (out.float().cpu() - ref64(q, kk, vv, attn_mask=ma.float())).abs().max() < 2e-2
+    # all-true bool mask == no mask (vi)
+    allt = torch.ones(128, 128, dtype=torch.bool, device="cuda")
+    a = umfa_torch.scaled_dot_product_attention(q, kk, vv, attn_mask=allt)
+    b = umfa_torch.scaled_dot_product_attention(q, kk, vv)
+    # the mask variant scales then subtracts, the plain one fuses both in one fma: equal to a bf16 ulp
+    assert torch.allclose(a.float(), b.float(), rtol=2 ** -7, atol=1e-3)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("causal", [False, True])
+def test_autograd_matches_torch(dt, causal):
+    import umfa_torch
+    torch.manual_seed(3)
+    shape = (1, 4, 160, 64)
+    q, k, v = (torch.randn(shape, device="cuda", dtype=dt, requires_grad=True) for _ in range(3))
+    do = torch.randn(shape, device="cuda", dtype=dt)
+    out = umfa_torch.scaled_dot_product_attention(q, k, v, is_causal=causal)
+    out.backward(do)
+    got = [t.grad.float().cpu() for t in (q, k, v)]
+    q2, k2, v2 = (t.detach().double().cpu().requires_grad_(True) for t in (q, k, v))
+    from umfa_torch import sdpa
+    sdpa._native_sdpa(q2, k2, v2, is_causal=causal).backward(do.double().cpu())
+    tol = 2e-4 if dt == torch.float32 else 6e-2
+    for g, r in zip(got, (q2.grad, k2.grad, v2.grad)):
+        assert (g - r.float()).abs().max() < tol * max(1.0, float(r.abs().max()))
+    assert umfa_torch.get_dispatch_stats()["fp32_autograd"] == 1
+
+
+def test_quantized_mode_routes_and_trains():
+    import umfa_torch
+    torch.manual_seed(4)
+    umfa_torch.set_quantization_mode(umfa_torch.QUANT_INT8, umfa_torch.QUANT_BLOCK_WISE)
+    q, k, v = (torch.randn(1, 2, 128, 64, device="cuda", dtype=torch.bfloat16, requires_grad=True) for _ in range(3))
+    out = umfa_torch.scaled_dot_product_attention(q, k, v)
+    assert out.dtype == torch.bfloat16
+    ref = ref64(q.detach(), k.detach(), v.detach())
+    assert (out.float().cpu() - ref).abs().max() / ref.abs().max() < 0.08
+    out.float().sum().backward()
+    assert all(torch.isfinite(t.grad).all() for t in (q, k, v))
+    s = umfa_torch.get_dispatch_stats()
+    assert s["quantized_autograd"] == 1
+
+
+def test_functional_patch_flux_style():
+    # examples/flux: monkey-patch F.scaled_dot_product_attention, run, restore
+    import torch.nn.functional as F
+    import umfa_torch
+    q, k, v = (torch.randn(1, 24, 512, 128, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    with umfa_torch.use_umfa_sdpa():
+        out = F.scaled_dot_product_attention(q, k, v)
+    assert umfa_torch.last_kernel() == "fa_fwd16<bf16,128>"
+    assert (out.float().cpu() - ref64(q, k, v)).abs().max() < 3e-2  # test_integration_flux.py:93-95 uses 0.1
