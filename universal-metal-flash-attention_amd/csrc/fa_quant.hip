@@ -43,11 +43,15 @@ struct QuantParams {
     int qlo, qhi;         // clamp range
 };
 
-// mode 0: write block absmax only; mode 1: quantise with scales already in scale[]; mode 2: both (fused)
+// mode 0: write block absmax only; mode 1: quantise with scales already in scale[]; mode 2: both (fused).
+// One workgroup per (tensor, batch*head, 64-row block).  The block (<= 64 x 256 elements) is read ONCE with
+// 16-byte loads into registers (8 elements per chunk, <= 8 chunks per thread), reduced to its absmax through
+// wave shuffles + 4 LDS words, then quantised from the registers and written with 8-byte (int8 Q/K) or
+// 16-byte (fp16 V) stores -- HBM-bound: every input byte is read once (twice in tensor-wise mode).
 template <int MODE>
 __global__ __launch_bounds__(256) void quantize_kernel(QuantParams p) {
     __shared__ float red[4];
-    // which tensor / (bh, block)
+    constexpr int MAXC = 8;  // chunks per thread: 64 rows * (256 / 8) chunks / 256 threads
     uint32_t id = blockIdx.x;
     int t = 0;
     while (t < 2 && id >= p.BH * p.nblk[t]) { id -= p.BH * p.nblk[t]; ++t; }
@@ -55,12 +59,37 @@ __global__ __launch_bounds__(256) void quantize_kernel(QuantParams p) {
     const uint32_t row0 = blk * QBLK;
     const uint32_t nrows = min((uint32_t)QBLK, p.rows[t] - row0);
     const int64_t base = ((int64_t)bh * p.rows[t] + row0) * p.D;
-    const uint32_t n = nrows * p.D;
+    const uint32_t cpr = p.D / 8;           // chunks per row (D % 8 == 0)
+    const uint32_t nchunks = nrows * cpr;   // <= 2048
     const int tid = threadIdx.x;
+
+    float x[MAXC][8];
+    float amax = 0.0f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const uint32_t ch = tid + 256 * c;
+        if (ch < nchunks) {
+            const int64_t e0 = base + (int64_t)ch * 8;
+            if (p.in_prec == P_FP32) {
+                const f32x4 lo = *(const f32x4*)((const float*)p.src[t] + e0);
+                const f32x4 hi = *(const f32x4*)((const float*)p.src[t] + e0 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { x[c][j] = lo[j]; x[c][4 + j] = hi[j]; }
+            } else if (p.in_prec == P_FP16) {
+                const f16x8 raw = *(const f16x8*)((const _Float16*)p.src[t] + e0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[c][j] = (float)raw[j];
+            } else {
+                const s16x8 raw = *(const s16x8*)((const uint16_t*)p.src[t] + e0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[c][j] = bf16_bits_to_float((uint16_t)raw[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(x[c][j]));
+        }
+    }
     float sc;
     if (MODE != 1) {
-        float amax = 0.0f;
-        for (uint32_t e = tid; e < n; e += 256) amax = fmaxf(amax, fabsf(load_as_float(p.src[t], base + e, p.in_prec)));
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
         if ((tid & 63) == 0) red[tid >> 6] = amax;
@@ -75,21 +104,47 @@ __global__ __launch_bounds__(256) void quantize_kernel(QuantParams p) {
     } else {
         sc = p.scale[t][bh * p.nblk[t] + blk];
     }
-    // quantise; Q/K rows are padded with zeros to DPQ bytes
-    const uint32_t cols = t < 2 ? p.DPQ : p.D;
-    for (uint32_t e = tid; e < nrows * cols; e += 256) {
-        const uint32_t r = e / cols, d = e % cols;
-        int qv = 0;
-        if (d < p.D) {
-            const float x = load_as_float(p.src[t], base + (int64_t)r * p.D + d, p.in_prec);
-            qv = (int)roundf(x / sc);
-            qv = qv < p.qlo ? p.qlo : (qv > p.qhi ? p.qhi : qv);
+    const int64_t orow0 = (int64_t)bh * p.rows[t] + row0;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const uint32_t ch = tid + 256 * c;
+        if (ch < nchunks) {
+            const uint32_t r = ch / cpr, d0 = (ch % cpr) * 8;
+            int q[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                int qv = (int)roundf(x[c][j] / sc);  // IEEE divide + round-half-away: bit-exact with the oracle
+                q[j] = qv < p.qlo ? p.qlo : (qv > p.qhi ? p.qhi : qv);
+            }
+            if (t < 2) {
+                uint32_t w0 = 0, w1 = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    w0 |= (uint32_t)(uint8_t)(int8_t)q[j] << (8 * j);
+                    w1 |= (uint32_t)(uint8_t)(int8_t)q[4 + j] << (8 * j);
+                }
+                int8_t* dst = (t == 0 ? p.q8 : p.k8) + (orow0 + r) * p.DPQ + d0;
+                *(uint2*)dst = make_uint2(w0, w1);
+            } else {
+                f16x8 hv;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) hv[j] = (_Float16)((float)q[j] * sc);
+                *(f16x8*)(p.v16 + (orow0 + r) * p.D + d0) = hv;
+            }
+            if (p.f32[t]) {
+                float* f = p.f32[t] + (orow0 + r) * p.D + d0;
+                *(f32x4*)f = f32x4{(float)q[0] * sc, (float)q[1] * sc, (float)q[2] * sc, (float)q[3] * sc};
+                *(f32x4*)(f + 4) = f32x4{(float)q[4] * sc, (float)q[5] * sc, (float)q[6] * sc, (float)q[7] * sc};
+            }
         }
-        const int64_t row = (int64_t)bh * p.rows[t] + row0 + r;
-        if (t == 0) p.q8[row * p.DPQ + d] = (int8_t)qv;
-        else if (t == 1) p.k8[row * p.DPQ + d] = (int8_t)qv;
-        else p.v16[row * p.D + d] = (_Float16)((float)qv * sc);
-        if (p.f32[t] && d < p.D) p.f32[t][row * p.D + d] = (float)qv * sc;
+    }
+    // zero the row padding of the int8 images (head_dim below the padded 64 / 128 / 256)
+    if (t < 2 && p.DPQ > p.D) {
+        const uint32_t padc = (p.DPQ - p.D) / 8;
+        for (uint32_t e = tid; e < nrows * padc; e += 256) {
+            const uint32_t r = e / padc, d0 = p.D + (e % padc) * 8;
+            *(uint2*)((t == 0 ? p.q8 : p.k8) + (orow0 + r) * p.DPQ + d0) = make_uint2(0u, 0u);
+        }
     }
 }
 
@@ -240,22 +295,64 @@ __global__ __launch_bounds__(256, (DP <= 128 ? 2 : 1)) void fa_fwd_i8_kernel(I8F
                 }
             }
             const bool edge = (key_base + BN > p.Skv) || (CAUSAL && key_base + BN - 1 > wave_q0);
-            float tv[2][16];
-            float mx = -INFINITY;
+            float m_use, m_new;
+            float rs = 0.0f;
+            f16x8 pf[4];
+            if (HAS_MASK) {
+                // additive mask: scores go to the log2 domain first
+                float tv[2][16];
+                float mx = -INFINITY;
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const uint32_t key = key_base + 32 * kb + acc_row(r, hi);
-                    float x = (float)s[kb][r] * ct;
-                    if (HAS_MASK && key < p.Skv && q_row < p.Sq) x += p.mask[mrow + key] * UMFA_LOG2E;
-                    if (edge && (key >= p.Skv || (CAUSAL && key > q_row))) x = -INFINITY;
-                    tv[kb][r] = x;
-                    mx = fmaxf(mx, x);
+                    for (int r = 0; r < 16; ++r) {
+                        const uint32_t key = key_base + 32 * kb + acc_row(r, hi);
+                        float x = (float)s[kb][r] * ct;
+                        if (key < p.Skv && q_row < p.Sq) x += p.mask[mrow + key] * UMFA_LOG2E;
+                        if (edge && (key >= p.Skv || (CAUSAL && key > q_row))) x = -INFINITY;
+                        tv[kb][r] = x;
+                        mx = fmaxf(mx, x);
+                    }
+                mx = fmaxf(mx, xor32(mx));
+                m_new = fmaxf(m, mx);
+                m_use = m_new == -INFINITY ? 0.0f : m_new;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float e = __builtin_amdgcn_exp2f(tv[kb][r] - m_use);
+                        rs += e;
+                        pf[2 * kb + (r >> 3)][r & 7] = (_Float16)e;
+                    }
+            } else {
+                // integer row max, then ONE conversion + fma per score: p = exp2(float(s) * ct - m)   (ct > 0)
+                if (edge) {
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const uint32_t key = key_base + 32 * kb + acc_row(r, hi);
+                            if (key >= p.Skv || (CAUSAL && key > q_row)) s[kb][r] = INT_MIN / 2;  // exp2 -> 0, never the max
+                        }
                 }
-            mx = fmaxf(mx, xor32(mx));
-            const float m_new = fmaxf(m, mx);
-            const float m_use = (HAS_MASK && m_new == -INFINITY) ? 0.0f : m_new;
+                int mxi = s[0][0];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mxi = max(mxi, s[kb][r]);
+                float mx = (float)mxi * ct;
+                mx = fmaxf(mx, xor32(mx));
+                m_new = fmaxf(m, mx);
+                m_use = m_new;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf((float)s[kb][r], ct, -m_use));
+                        rs += e;
+                        pf[2 * kb + (r >> 3)][r & 7] = (_Float16)e;
+                    }
+            }
             if (!__all(m_new == m)) {
                 const float alpha = __builtin_amdgcn_exp2f(m - m_use);
                 l *= alpha;
@@ -265,16 +362,6 @@ __global__ __launch_bounds__(256, (DP <= 128 ? 2 : 1)) void fa_fwd_i8_kernel(I8F
                     for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
                 m = m_new;
             }
-            float rs = 0.0f;
-            f16x8 pf[4];
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(tv[kb][r] - m_use);
-                    rs += e;
-                    pf[2 * kb + (r >> 3)][r & 7] = (_Float16)e;
-                }
             l += rs;
 #pragma unroll
             for (int i = 0; i < NDB; ++i)
@@ -341,7 +428,7 @@ size_t quant_workspace_bytes(uint32_t B, uint32_t H, uint32_t Sq, uint32_t Skv, 
     return ws_layout(B, H, Sq, Skv, D, want_f32).total;
 }
 
-bool quantized_supported(uint32_t D) { return D >= 8 && D % 8 == 0 && D <= 256; }
+bool quantized_supported(uint32_t D) { return D >= 8 && D % 8 == 0 && D <= 256; }  // and softmax_scale > 0
 
 hipError_t launch_quantize(const void* q, const void* k, const void* v, int in_prec, uint32_t B, uint32_t H,
                            uint32_t Sq, uint32_t Skv, uint32_t D, int bits, int quant_mode, void* workspace,

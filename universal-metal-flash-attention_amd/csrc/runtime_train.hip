@@ -93,7 +93,7 @@ int32_t mfa_quantized_forward_with_lse(mfa_context_t context, mfa_buffer_t q, mf
         return MFA_ERROR_INVALID_ARGS;
     if (bm && !bm->fits(nr * Skv * 4)) return MFA_ERROR_INVALID_ARGS;
     if (nq == 0 || nkv == 0) return MFA_SUCCESS;
-    if (!quantized_supported(D)) return MFA_ERROR_INVALID_ARGS;
+    if (!quantized_supported(D) || !(softmax_scale > 0.0f)) return MFA_ERROR_INVALID_ARGS;
     const int bits = target_precision == MFA_PRECISION_INT4 ? 4 : 8;  // unknown raw value -> INT8 (:267)
     const int mode = quant_mode == 2 ? 2 : 0;                        // default tensor-wise (:268-272)
 
