@@ -61,8 +61,15 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&dbg, (size_t)items * 64));
     p.part_buf = (float*)dbg;
 #endif
-    auto kfn = fa_fwd16_kernel<__bf16, 128, false, false, __bf16>;
-    const size_t lds = 4 * 64 * 128 * 2;
+    #ifndef UMFA_LAB_BN
+#define UMFA_LAB_BN 64
+#endif
+#ifdef UMFA_LAB_DMA
+    auto kfn = fa_fwd16_kernel<__bf16, 128, false, false, __bf16, true, UMFA_LAB_BN>;
+#else
+    auto kfn = fa_fwd16_kernel<__bf16, 128, false, false, __bf16, false, UMFA_LAB_BN>;
+#endif
+    const size_t lds = 4 * UMFA_LAB_BN * 128 * 2;
     CK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));

@@ -81,8 +81,8 @@ FwdSplitPlan fwd_16_split_plan(const FwdParams& p) {
     return plan;
 }
 
-template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT>
-static hipError_t launch_one(const FwdParams& pin, hipStream_t stream) {
+template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT, bool DMA, int BN>
+static hipError_t launch_dma(const FwdParams& pin, hipStream_t stream) {
     FwdParams p = pin;
     const uint32_t nqb = (p.Sq + 127) / 128;
     const uint32_t items = nqb * p.B * p.H;
@@ -92,8 +92,8 @@ static hipError_t launch_one(const FwdParams& pin, hipStream_t stream) {
         hipError_t e = hipMemsetAsync(p.part_cnt, 0, (((size_t)(items - p.n_full) * 4) + 15) & ~(size_t)15, stream);
         if (e != hipSuccess) return e;
     }
-    const size_t lds = 4 * 64 * DP * 2;
-    auto kfn = fa_fwd16_kernel<T, DP, CAUSAL, HAS_MASK, OUT>;
+    const size_t lds = 4 * BN * DP * 2;
+    auto kfn = fa_fwd16_kernel<T, DP, CAUSAL, HAS_MASK, OUT, DMA, BN>;
     static bool attr_set = false;  // per instantiation
     if (lds > 48 * 1024 && !attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -102,6 +102,30 @@ static hipError_t launch_one(const FwdParams& pin, hipStream_t stream) {
     }
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, stream, p);
     return hipGetLastError();
+}
+
+static bool dma_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("UMFA_NO_DMA");
+        return !(e && e[0] == '1');
+    }();
+    return on;
+}
+
+// LDS-DMA staging when head_dim fills the padded row exactly; register staging otherwise.
+template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT>
+static hipError_t launch_one(const FwdParams& p, hipStream_t stream) {
+    if ((int)p.D == DP && dma_enabled()) {
+        // 32-key tiles + LDS-DMA at head_dim 128: 166 VGPR / 32 KiB LDS -> three resident workgroups per CU
+        // (lab, same box: FLUX 768 items 264 -> 242 us; 3072 items 895 -> 870 us; never slower)
+        // (causal launches lose with it: 184 vs 146 us at the FLUX shape, so they keep 64-key tiles)
+        if constexpr (DP == 128 && !HAS_MASK && !CAUSAL) {
+            static const bool bn32 = [] { const char* e = getenv("UMFA_BN64"); return !(e && e[0] == '1'); }();
+            if (bn32) return launch_dma<T, DP, CAUSAL, HAS_MASK, OUT, true, 32>(p, stream);
+        }
+        return launch_dma<T, DP, CAUSAL, HAS_MASK, OUT, true, 64>(p, stream);
+    }
+    return launch_dma<T, DP, CAUSAL, HAS_MASK, OUT, false, 64>(p, stream);
 }
 
 template <typename T, int DP, typename OUT>

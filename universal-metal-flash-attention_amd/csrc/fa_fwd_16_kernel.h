@@ -51,12 +51,19 @@ __device__ __forceinline__ float max_xor32(float x) {
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
-template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT>
-__global__ __launch_bounds__(256, (DP <= 128 ? 2 : 1)) void fa_fwd16_kernel(FwdParams p) {
+// DMA = K/V tiles go global -> LDS directly (buffer_load ... lds, "LDS-DMA"): no staging VGPRs, no ds_write and no
+// per-tile address VALU.  Requires head_dim == DP (a 16-byte chunk past D would belong to the next row).
+// The loads are inline asm on purpose: for the builtin hipcc (ROCm 7.2) waits vmcnt(0) before every later LDS
+// read (no alias information), which serialises the tile; here the only wait is ours, before the tile's barrier.
+// BN = keys per tile (64, or 32: half the LDS and fewer live registers -> a third resident workgroup per CU).
+template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT, bool DMA = false, int BN = 64>
+__global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_fwd16_kernel(FwdParams p) {
     typedef Mma16<T> M;
     typedef typename M::V8 V8;
     typedef typename M::V4 V4;
-    constexpr int BM = 128, BN = 64;
+    constexpr int BM = 128;
+    constexpr int NKB = BN / 32;            // 32-key blocks per tile
+    constexpr int NST = BN / 16;            // 16-key MFMA k-steps of PV per tile
     constexpr int NCH = DP / 8;             // 16-byte chunks per row
     constexpr int NKS = DP / 16;            // k-steps of QK^T
     constexpr int NDB = DP / 32;            // 32-row blocks of O^T
@@ -116,33 +123,88 @@ __global__ __launch_bounds__(256, (DP <= 128 ? 2 : 1)) void fa_fwd16_kernel(FwdP
         qf[ks] = __builtin_bit_cast(V8, __builtin_amdgcn_raw_buffer_load_b128(q_rsrc, off, 0, 0));
     }
 
-    // ---- tile staging: thread owns chunks c = tid + 256 i  ->  (row, ch); offsets are tile-invariant
-    int koff[LPT], voff[LPT], klds[LPT], vlds[LPT];
-#pragma unroll
-    for (int i = 0; i < LPT; ++i) {
-        const int c = tid + 256 * i, row = c / NCH, ch = c % NCH;
-        const bool colok = ch * 8 < D;
-        koff[i] = colok ? row * k_stride_b + ch * 16 : OOB;
-        voff[i] = colok ? row * v_stride_b + ch * 16 : OOB;
-        klds[i] = k_off<DP>(row, ch);
-        vlds[i] = v_off<DP>(row, ch);
-    }
+    // ---- tile staging (register path): thread owns chunks c = tid + 256 i  ->  (row, ch); offsets are tile-invariant
+    constexpr int LPTR = DMA ? 1 : LPT;
+    int koff[LPTR], voff[LPTR], klds[LPTR], vlds[LPTR];
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 kreg[LPT], vreg[LPT];
-    auto stage_load = [&](uint32_t t) {
-        const int ksoff = (int)(t * BN) * k_stride_b, vsoff = (int)(t * BN) * v_stride_b;
+    u32x4 kreg[LPTR], vreg[LPTR];
+    if constexpr (!DMA) {
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
-            // the tile advance goes into voffset: soffset is excluded from the hardware range check
-            kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, koff[i] + ksoff, 0, 0);
-            vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, voff[i] + vsoff, 0, 0);
+            const int c = tid + 256 * i, row = c / NCH, ch = c % NCH;
+            const bool colok = ch * 8 < D;
+            koff[i] = colok ? row * k_stride_b + ch * 16 : OOB;
+            voff[i] = colok ? row * v_stride_b + ch * 16 : OOB;
+            klds[i] = k_off<DP>(row, ch);
+            vlds[i] = v_off<DP>(row, ch);
+        }
+    }
+    // ---- tile staging (LDS-DMA path).  A wave-instruction writes 1 KiB of the tile image linearly: wave w,
+    // instruction j covers image bytes [(w*IPW + j) KiB, +1 KiB) = rows (w*IPW + j)*RPI ...; lane l lands in row
+    // r = l / NCH, chunk slot c = l % NCH and therefore FETCHES source chunk c ^ swz(row) (rule 21: the swizzle
+    // goes on the source address; k_off / v_off are involutions in the chunk index).
+    constexpr int RPI = 1024 / (2 * DP);          // rows per wave-instruction
+    constexpr int IPW = TILE_BYTES / 1024 / 4;    // instructions per wave per tile (K and V each)
+    constexpr int IPWR = DMA ? IPW : 1;
+    int kdma[IPWR], vdma[IPWR];
+    i32x4 k_srd, v_srd;
+    unsigned lds_wave = 0;
+    if constexpr (DMA) {
+        const int uw = __builtin_amdgcn_readfirstlane(wave);
+        const int d_r = lane / NCH, d_c = lane % NCH;
+#pragma unroll
+        for (int j = 0; j < IPW; ++j) {
+            const int row = (uw * IPW + j) * RPI + d_r;
+            kdma[j] = row * k_stride_b + (k_off<DP>(row, d_c) - row * (2 * DP));
+            vdma[j] = row * v_stride_b + (v_off<DP>(row, d_c) - row * (2 * DP));
+        }
+        auto make_srd = [&](const T* base, uint32_t bytes) {
+            const unsigned long long a = (unsigned long long)base;
+            i32x4 d;
+            d[0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
+            d[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
+            d[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+            d[3] = 0x00020000;
+            return d;
+        };
+        k_srd = make_srd(kp, (p.Skv - 1) * (uint32_t)k_stride_b + D * 2);
+        v_srd = make_srd(vp, (p.Skv - 1) * (uint32_t)v_stride_b + D * 2);
+        lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((LDS_AS char*)smem) + uw * IPW * 1024);
+        // rows past Skv are range-checked away by the hardware; start from zeros so they can never hold NaNs
+#pragma unroll
+        for (int i = 0; i < 4 * TILE_BYTES / 4096; ++i) *(i32x4*)(smem + i * 4096 + tid * 16) = i32x4{0, 0, 0, 0};
+        __syncthreads();
+    }
+    auto stage_load = [&](uint32_t t) {
+        if constexpr (DMA) {
+            const int ktile = (int)(t * BN) * k_stride_b, vtile = (int)(t * BN) * v_stride_b;
+            const unsigned kdst = lds_wave + (t & 1) * TILE_BYTES, vdst = kdst + 2 * TILE_BYTES;
+#pragma unroll
+            for (int j = 0; j < IPW; ++j) {
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                             ::"s"(kdst + j * 1024), "v"(kdma[j] + ktile), "s"(k_srd) : "memory");
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                             ::"s"(vdst + j * 1024), "v"(vdma[j] + vtile), "s"(v_srd) : "memory");
+            }
+        } else {
+            const int ksoff = (int)(t * BN) * k_stride_b, vsoff = (int)(t * BN) * v_stride_b;
+#pragma unroll
+            for (int i = 0; i < LPT; ++i) {
+                // the tile advance goes into voffset: soffset is excluded from the hardware range check
+                kreg[i] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, koff[i] + ksoff, 0, 0);
+                vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, voff[i] + vsoff, 0, 0);
+            }
         }
     };
     auto stage_write = [&](int buf) {
+        if constexpr (DMA) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA has landed (then the barrier)
+        } else {
 #pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            *(u32x4*)(Kbuf + buf * TILE_BYTES + klds[i]) = kreg[i];
-            *(u32x4*)(Vbuf + buf * TILE_BYTES + vlds[i]) = vreg[i];
+            for (int i = 0; i < LPT; ++i) {
+                *(u32x4*)(Kbuf + buf * TILE_BYTES + klds[i]) = kreg[i];
+                *(u32x4*)(Vbuf + buf * TILE_BYTES + vlds[i]) = vreg[i];
+            }
         }
     };
 
@@ -199,9 +261,9 @@ __global__ __launch_bounds__(256, (DP <= 128 ? 2 : 1)) void fa_fwd16_kernel(FwdP
 
         if (active) {
             // ---------------- S^T = K Q^T ----------------
-            f32x16 s[2];
+            f32x16 s[NKB];
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+            for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
 #pragma unroll
@@ -215,16 +277,16 @@ __global__ __launch_bounds__(256, (DP <= 128 ? 2 : 1)) void fa_fwd16_kernel(FwdP
 #endif
             }
             // first V^T fragments requested before the softmax so their LDS latency hides under it
-            V8 va[4];
+            V8 va[NST];
 #pragma unroll
-            for (int st = 0; st < 4; ++st) va[st] = v_frag(Vt, 0, st);
+            for (int st = 0; st < NST; ++st) va[st] = v_frag(Vt, 0, st);
 
             // ---------------- online softmax (log2 domain) ----------------
             const bool edge = (key_base + BN > p.Skv) || (CAUSAL && key_base + BN - 1 > wave_q0);
             float mx = -INFINITY;
             if (HAS_MASK) {
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const uint32_t key = key_base + 32 * kb + acc_row(r, hi);
@@ -238,7 +300,7 @@ __global__ __launch_bounds__(256, (DP <= 128 ? 2 : 1)) void fa_fwd16_kernel(FwdP
             } else {
                 if (edge) {
 #pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
+                    for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const uint32_t key = key_base + 32 * kb + acc_row(r, hi);
@@ -246,7 +308,7 @@ __global__ __launch_bounds__(256, (DP <= 128 ? 2 : 1)) void fa_fwd16_kernel(FwdP
                         }
                 }
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
                 mx *= c2;  // scale > 0 on this path
@@ -264,9 +326,9 @@ __global__ __launch_bounds__(256, (DP <= 128 ? 2 : 1)) void fa_fwd16_kernel(FwdP
                     for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
                 m = m_new;
             }
-            V8 pf[4];
+            V8 pf[NST];
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
 #ifdef UMFA_ABL_NO_EXP
@@ -282,21 +344,21 @@ __global__ __launch_bounds__(256, (DP <= 128 ? 2 : 1)) void fa_fwd16_kernel(FwdP
             // ---------------- O^T += V^T P^T (fragments of block i+1 requested before block i's MFMAs) ----
 #pragma unroll
             for (int i = 0; i < NDB; ++i) {
-                V8 vb[4];
+                V8 vb[NST];
                 if (i + 1 < NDB) {
 #pragma unroll
-                    for (int st = 0; st < 4; ++st) vb[st] = v_frag(Vt, i + 1, st);
+                    for (int st = 0; st < NST; ++st) vb[st] = v_frag(Vt, i + 1, st);
                 }
 #ifdef UMFA_ABL_NO_PV
 #pragma unroll
-                for (int st = 0; st < 4; ++st) acc[i][st] += (float)va[st][0] * (float)pf[st][0];
+                for (int st = 0; st < NST; ++st) acc[i][st] += (float)va[st][0] * (float)pf[st][0];
 #else
 #pragma unroll
-                for (int st = 0; st < 4; ++st) acc[i] = M::mma(va[st], pf[st], acc[i]);
+                for (int st = 0; st < NST; ++st) acc[i] = M::mma(va[st], pf[st], acc[i]);
 #endif
                 if (i + 1 < NDB) {
 #pragma unroll
-                    for (int st = 0; st < 4; ++st) va[st] = vb[st];
+                    for (int st = 0; st < NST; ++st) va[st] = vb[st];
                 }
             }
         }
