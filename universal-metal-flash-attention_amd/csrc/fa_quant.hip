@@ -32,7 +32,7 @@ struct QuantParams {
     const void* src[3];   // q, k, v (input precision)
     int8_t* q8;           // [B*H*Sq][DPQ]
     int8_t* k8;           // [B*H*Skv][DPQ]
-    _Float16* v16;        // [B*H*Skv][D]
+    _Float16* v16;        // [B*H*Skv][DPQ] (rows zero-padded like Q/K)
     float* f32[3];        // optional fake-quantised fp32 copies (backward), [rows][D]
     float* scale[3];      // per (bh, block)
     uint32_t rows[3];     // Sq, Skv, Skv
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void quantize_kernel(QuantParams p) {
                 f16x8 hv;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) hv[j] = (_Float16)((float)q[j] * sc);
-                *(f16x8*)(p.v16 + (orow0 + r) * p.D + d0) = hv;
+                *(f16x8*)(p.v16 + (orow0 + r) * p.DPQ + d0) = hv;
             }
             if (p.f32[t]) {
                 float* f = p.f32[t] + (orow0 + r) * p.D + d0;
@@ -138,12 +138,13 @@ __global__ __launch_bounds__(256) void quantize_kernel(QuantParams p) {
             }
         }
     }
-    // zero the row padding of the int8 images (head_dim below the padded 64 / 128 / 256)
-    if (t < 2 && p.DPQ > p.D) {
+    // zero the row padding of the images (head_dim below the padded 64 / 128 / 256)
+    if (p.DPQ > p.D) {
         const uint32_t padc = (p.DPQ - p.D) / 8;
         for (uint32_t e = tid; e < nrows * padc; e += 256) {
             const uint32_t r = e / padc, d0 = p.D + (e % padc) * 8;
-            *(uint2*)((t == 0 ? p.q8 : p.k8) + (orow0 + r) * p.DPQ + d0) = make_uint2(0u, 0u);
+            if (t < 2) *(uint2*)((t == 0 ? p.q8 : p.k8) + (orow0 + r) * p.DPQ + d0) = make_uint2(0u, 0u);
+            else *(i32x4*)(p.v16 + (orow0 + r) * p.DPQ + d0) = i32x4{0, 0, 0, 0};
         }
     }
 }
@@ -190,15 +191,16 @@ struct I8FwdParams {
     float scale;
 };
 
-template <int DP, bool CAUSAL, bool HAS_MASK>
-__global__ __launch_bounds__(256, (DP <= 128 ? 2 : 1)) void fa_fwd_i8_kernel(I8FwdParams p) {
-    constexpr int BM = 128, BN = 64;
+template <int DP, bool CAUSAL, bool HAS_MASK, int BN>
+__global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_fwd_i8_kernel(I8FwdParams p) {
+    constexpr int BM = 128;
+    constexpr int NKB = BN / 32, NST = BN / 16;
     constexpr int NKS = DP / 32;             // int8 k-steps (32 per MFMA)
     constexpr int NDB = DP / 32;             // 32-row blocks of O^T
     constexpr int KT_BYTES = BN * DP;        // int8 K tile
     constexpr int VT_BYTES = BN * DP * 2;    // fp16 V tile
     constexpr int KCH = DP / 16, VCH = DP / 8;
-    constexpr int KLPT = BN * KCH / 256, VLPT = BN * VCH / 256;
+    constexpr int NPK = KT_BYTES / 1024, NPV = VT_BYTES / 1024;  // 1-KiB LDS-DMA pieces per tile
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const Kbuf = smem;                  // 2 x KT_BYTES
@@ -215,8 +217,8 @@ __global__ __launch_bounds__(256, (DP <= 128 ? 2 : 1)) void fa_fwd_i8_kernel(I8F
     const int D = (int)p.D;
 
     const int8_t* __restrict__ qp = p.q8 + (int64_t)bh * p.Sq * DP;
-    const int8_t* __restrict__ kp = p.k8 + (int64_t)bh * p.Skv * DP;
-    const _Float16* __restrict__ vp = p.v16 + (int64_t)bh * p.Skv * D;
+    const int8_t* kp = p.k8 + (int64_t)bh * p.Skv * DP;
+    const _Float16* vp = p.v16 + (int64_t)bh * p.Skv * DP;
 
     i32x4 qf[NKS];
 #pragma unroll
@@ -227,33 +229,51 @@ __global__ __launch_bounds__(256, (DP <= 128 ? 2 : 1)) void fa_fwd_i8_kernel(I8F
     const uint32_t wq_blk = wave_q0 / QBLK;
     const float sq = (wave_q0 < p.Sq ? p.q_scale[bh * p.nqblk + wq_blk] : 0.0f) * p.scale * UMFA_LOG2E;
 
-    i32x4 kreg[KLPT], vreg[VLPT];
+    // ---- LDS-DMA staging (the quantiser's images have rows of exactly DP / 2 DP bytes, zero-padded): piece n
+    // of a tile image is 1 KiB = rows n*RPI...; lane l lands in row l / CH, chunk slot l % CH and fetches the
+    // source chunk slot ^ swz(row).  Inline asm: see fa_fwd_16_kernel.h (hipcc would drain vmcnt before LDS reads).
+    const int uw = __builtin_amdgcn_readfirstlane(wave);
+    auto make_srd = [&](const void* base, uint32_t bytes) {
+        const unsigned long long a = (unsigned long long)base;
+        i32x4 d;
+        d[0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
+        d[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
+        d[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+        d[3] = 0x00020000;
+        return d;
+    };
+    const i32x4 k_srd = make_srd(kp, p.Skv * (uint32_t)DP);
+    const i32x4 v_srd = make_srd(vp, p.Skv * (uint32_t)DP * 2);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((LDS_AS char*)smem));
+    constexpr int KRPI = 1024 / DP, VRPI = 1024 / (2 * DP);  // rows per piece
+    const int k_r = lane / KCH, k_c = lane % KCH, v_r = lane / VCH, v_c = lane % VCH;
+#pragma unroll
+    for (int i = 0; i < (2 * KT_BYTES + 2 * VT_BYTES) / 4096; ++i) *(i32x4*)(smem + i * 4096 + tid * 16) = i32x4{0, 0, 0, 0};
+    __syncthreads();
     auto stage_load = [&](uint32_t t) {
+        const int buf = t & 1;
 #pragma unroll
-        for (int i = 0; i < KLPT; ++i) {
-            const int c = tid + 256 * i, row = c / KCH, ch = c % KCH;
-            const uint32_t key = t * BN + row;
-            kreg[i] = key < p.Skv ? *(const i32x4*)(kp + (int64_t)key * DP + ch * 16) : i32x4{0, 0, 0, 0};
+        for (int n0 = 0; n0 < NPK; n0 += 4) {
+            const int n = n0 + uw;
+            if (n < NPK) {
+                const int row = n * KRPI + k_r;
+                const int voff = (int)(t * BN + row) * DP + (k8_off<DP>(row, k_c) - row * DP);
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                             ::"s"(lds0 + buf * KT_BYTES + n * 1024), "v"(voff), "s"(k_srd) : "memory");
+            }
         }
 #pragma unroll
-        for (int i = 0; i < VLPT; ++i) {
-            const int c = tid + 256 * i, row = c / VCH, ch = c % VCH;
-            const uint32_t key = t * BN + row;
-            vreg[i] = (key < p.Skv && ch * 8 < D) ? *(const i32x4*)(vp + (int64_t)key * D + ch * 8) : i32x4{0, 0, 0, 0};
-        }
-    };
-    auto stage_write = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < KLPT; ++i) {
-            const int c = tid + 256 * i, row = c / KCH, ch = c % KCH;
-            *(i32x4*)(Kbuf + buf * KT_BYTES + k8_off<DP>(row, ch)) = kreg[i];
-        }
-#pragma unroll
-        for (int i = 0; i < VLPT; ++i) {
-            const int c = tid + 256 * i, row = c / VCH, ch = c % VCH;
-            *(i32x4*)(Vbuf + buf * VT_BYTES + v16_off<DP>(row, ch)) = vreg[i];
+        for (int n0 = 0; n0 < NPV; n0 += 4) {
+            const int n = n0 + uw;
+            if (n < NPV) {
+                const int row = n * VRPI + v_r;
+                const int voff = (int)(t * BN + row) * (2 * DP) + (v16_off<DP>(row, v_c) - row * (2 * DP));
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                             ::"s"(lds0 + 2 * KT_BYTES + buf * VT_BYTES + n * 1024), "v"(voff), "s"(v_srd) : "memory");
+            }
         }
     };
+    auto stage_write = [&](int) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
     uint32_t ntiles = (p.Skv + BN - 1) / BN;
     if (CAUSAL) {
@@ -282,10 +302,10 @@ __global__ __launch_bounds__(256, (DP <= 128 ? 2 : 1)) void fa_fwd_i8_kernel(I8F
         const uint32_t key_base = t * BN;
         const bool active = !CAUSAL || key_base <= wave_q0 + 31;
         if (active) {
-            const float ct = sq * p.k_scale[bh * p.nkblk + t];  // dequant * softmax scale * log2e, > 0 or == 0
-            i32x16 s[2];
+            const float ct = sq * p.k_scale[bh * p.nkblk + key_base / QBLK];  // dequant * softmax scale * log2e, >= 0
+            i32x16 s[NKB];
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+            for (int kb = 0; kb < NKB; ++kb) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[kb][r] = 0;
 #pragma unroll
@@ -297,13 +317,13 @@ __global__ __launch_bounds__(256, (DP <= 128 ? 2 : 1)) void fa_fwd_i8_kernel(I8F
             const bool edge = (key_base + BN > p.Skv) || (CAUSAL && key_base + BN - 1 > wave_q0);
             float m_use, m_new;
             float rs = 0.0f;
-            f16x8 pf[4];
+            f16x8 pf[NST];
             if (HAS_MASK) {
                 // additive mask: scores go to the log2 domain first
-                float tv[2][16];
+                float tv[NKB][16];
                 float mx = -INFINITY;
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const uint32_t key = key_base + 32 * kb + acc_row(r, hi);
@@ -317,7 +337,7 @@ __global__ __launch_bounds__(256, (DP <= 128 ? 2 : 1)) void fa_fwd_i8_kernel(I8F
                 m_new = fmaxf(m, mx);
                 m_use = m_new == -INFINITY ? 0.0f : m_new;
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float e = __builtin_amdgcn_exp2f(tv[kb][r] - m_use);
@@ -328,7 +348,7 @@ __global__ __launch_bounds__(256, (DP <= 128 ? 2 : 1)) void fa_fwd_i8_kernel(I8F
                 // integer row max, then ONE conversion + fma per score: p = exp2(float(s) * ct - m)   (ct > 0)
                 if (edge) {
 #pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
+                    for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const uint32_t key = key_base + 32 * kb + acc_row(r, hi);
@@ -337,7 +357,7 @@ __global__ __launch_bounds__(256, (DP <= 128 ? 2 : 1)) void fa_fwd_i8_kernel(I8F
                 }
                 int mxi = s[0][0];
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) mxi = max(mxi, s[kb][r]);
                 float mx = (float)mxi * ct;
@@ -345,7 +365,7 @@ __global__ __launch_bounds__(256, (DP <= 128 ? 2 : 1)) void fa_fwd_i8_kernel(I8F
                 m_new = fmaxf(m, mx);
                 m_use = m_new;
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float e = __builtin_amdgcn_exp2f(__builtin_fmaf((float)s[kb][r], ct, -m_use));
@@ -366,7 +386,7 @@ __global__ __launch_bounds__(256, (DP <= 128 ? 2 : 1)) void fa_fwd_i8_kernel(I8F
 #pragma unroll
             for (int i = 0; i < NDB; ++i)
 #pragma unroll
-                for (int st = 0; st < 4; ++st) {
+                for (int st = 0; st < NST; ++st) {
                     const int row0 = 16 * st + 4 * hi + tr_qq;
                     const int ch = 4 * i + 2 * tr_g1 + (tr_pp >> 1);
                     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 LDS_AS*)(Vt + v16_off<DP>(row0, ch) + 8 * (tr_pp & 1)));
@@ -410,7 +430,7 @@ static WsLayout ws_layout(uint32_t B, uint32_t H, uint32_t Sq, uint32_t Skv, uin
     size_t off = 0;
     w.q8 = off; off = align256(off + BH * Sq * DP);
     w.k8 = off; off = align256(off + BH * Skv * DP);
-    w.v16 = off; off = align256(off + BH * Skv * D * 2);
+    w.v16 = off; off = align256(off + BH * Skv * DP * 2);
     w.sq = off; off = align256(off + BH * nqb * 4);
     w.sk = off; off = align256(off + BH * nkb * 4);
     w.sv = off; off = align256(off + BH * nkb * 4);
@@ -476,9 +496,11 @@ hipError_t launch_quantize(const void* q, const void* k, const void* v, int in_p
 
 template <int DP, bool CAUSAL, bool HAS_MASK>
 static hipError_t launch_i8_one(const I8FwdParams& p, hipStream_t stream) {
+    // 32-key tiles (three resident workgroups per CU) where the bf16 kernel uses them too
+    constexpr int BN = (DP == 128 && !CAUSAL && !HAS_MASK) ? 32 : 64;
     const uint32_t nqb = (p.Sq + 127) / 128;
-    const size_t lds = 2 * 64 * DP + 2 * 64 * DP * 2;
-    auto kfn = fa_fwd_i8_kernel<DP, CAUSAL, HAS_MASK>;
+    const size_t lds = 2 * BN * DP + 2 * BN * DP * 2;
+    auto kfn = fa_fwd_i8_kernel<DP, CAUSAL, HAS_MASK, BN>;
     static bool attr_set = false;
     if (lds > 48 * 1024 && !attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
