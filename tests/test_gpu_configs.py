@@ -97,7 +97,7 @@ def test_config3_flux_fwd_bwd_bf16():
                                                    bits(k[:, :1, :S2].contiguous()), bits(v[:, :1, :S2].contiguous()),
                                                    o_s, l_s.ravel(), input_precision="bf16")
     for g, r in ((gdq, rdq), (gdk, rdk), (gdv, rdv)):
-        assert np.abs(g - r).max() < 5e-5 * max(1.0, np.abs(r).max())
+        assert np.abs(g - r).max() < 2e-2 * np.abs(r).max()  # bf16 MFMA backward (P, dS rounded to bf16)
 
 
 def test_config4_int8_blockwise_S8192_H16_D128():

@@ -1,0 +1,360 @@
+// fa_bwd_16.hip -- bf16 / fp16 MFMA backward for gfx950, head_dim 128 (the FLUX / config-3 shape).
+//
+// Same contract as fa_bwd.hip (mfa_attention_backward, MFABridge.swift:3171-3282: D = rowsum(dO o O), dQ, dK, dV in
+// fp32, two dispatches "backward query" then "backward key-value", no atomics) with the five products on
+// v_mfma_f32_32x32x16_{bf16,f16} instead of the fp32 MFMA (1/16 of the rate).  Orientations follow
+// cdna_hip_programming.md "Attention backward": every second product takes the first one's accumulator,
+// rounded to the input type, as its B operand with no cross-lane movement.
+//
+//   bwd16_dq    workgroup = 4 waves x 32 query rows; sweeps 32-key tiles of K and V (LDS, LDS-DMA staged).
+//               lane <-> query:   S^T = K Q^T,  dP^T = V dO^T,  P^T = exp2(c S^T - L2[q]),  dS^T = P^T o (dP^T - D[q]),
+//               dQ^T += K^T dS^T  (K^T fragments by transposed reads of the SAME K image).
+//   bwd16_dkdv  workgroup = 4 waves x 32 keys; K, V of the block stay in LDS; sweeps 32-row tiles of Q and dO.
+//               lane <-> key:     S = Q K^T,  dP = dO V^T,  P, dS as above (row constants from LDS),
+//               dV^T += dO^T P,  dK^T += Q^T dS  (Q^T / dO^T fragments by transposed reads of the same images).
+// All four tile kinds use ONE dual-use LDS image (256-byte rows, 16-byte chunks XOR-swizzled with
+// ((row&3)<<2 | (row>>2)&3)): conflict-free for ds_read_b128 row reads AND ds_read_b64_tr_b16 transposed reads
+// (tools/lds_bank_check.py).  Tiles arrive by LDS-DMA with the swizzle on the source chunk.
+// P and dS are rounded to the input type before their second product, like P in the forward.
+#include <cstring>
+
+#include "fa_common.h"
+#include "fa_fwd_16_kernel.h"  // Mma16<T>, xcd_remap
+#include "kernels.h"
+
+namespace umfa {
+
+namespace {
+
+constexpr int DP = 128, ROW_B = 256, NCH = 16, NKS = 8, NDB = 4;
+constexpr int TILE_ROWS = 32, TILE_BYTES = TILE_ROWS * ROW_B;  // 8 KiB
+
+__device__ __forceinline__ constexpr int d_off(int row, int ch) {
+    return ROW_B * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+__device__ __forceinline__ i32x4 make_srd(const void* base, uint32_t bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    i32x4 d;
+    d[0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
+    d[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
+    d[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    d[3] = 0x00020000;
+    return d;
+}
+
+// LDS-DMA of `npieces` 1-KiB pieces (4 rows each) of a [rows][256 B] slab image starting at global row `row0`.
+// Piece n goes to lds_dst + n KiB; wave w issues pieces w, w+4, ...  Rows past the slab are range-checked away.
+template <int NPIECES>
+__device__ __forceinline__ void dma_rows(const i32x4& srd, unsigned lds_dst, uint32_t row0, int uw, int lane) {
+    const int r = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int n0 = 0; n0 < NPIECES; n0 += 4) {
+        const int n = n0 + uw;
+        if (n < NPIECES) {
+            const int row = 4 * n + r;
+            const int voff = (int)(row0 + row) * ROW_B + (d_off(row, c) - row * ROW_B);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                         ::"s"(lds_dst + n * 1024), "v"(voff), "s"(srd) : "memory");
+        }
+    }
+}
+
+// transposed-read fragment: rows (row0 .. +3) and (row0+8 .. +11) x 16 columns of d-block i, as the A operand whose
+// element j is image row 16 s + 8 (j>>2) + 4 hi + (j&3) (the k order of an accumulator used as B operand)
+template <typename M>
+__device__ __forceinline__ typename M::V8 tr_frag(const char* img, int i, int s, int hi, int tr_qq, int tr_pp, int tr_g1) {
+    const int ch = 4 * i + 2 * tr_g1 + (tr_pp >> 1);
+    const int r0 = 16 * s + 4 * hi + tr_qq;
+    const typename M::V4 lo = M::tr_read(img + d_off(r0, ch) + 8 * (tr_pp & 1));
+    const typename M::V4 hi4 = M::tr_read(img + d_off(r0 + 8, ch) + 8 * (tr_pp & 1));
+    return __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void bwd16_delta_kernel(BwdParams p) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= (int64_t)p.B * p.H * p.Sq) return;
+    // 128 columns: two per lane
+    const float a0 = load_as_float(p.dout, row * DP + 2 * lane, p.dout_prec) * p.o[row * DP + 2 * lane];
+    const float a1 = load_as_float(p.dout, row * DP + 2 * lane + 1, p.dout_prec) * p.o[row * DP + 2 * lane + 1];
+    float s = a0 + a1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) p.dvec[row] = s;
+}
+
+// ------------------------------------------------------------------------------------------------ dQ
+template <typename T, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void bwd16_dq_kernel(BwdParams p) {
+    typedef Mma16<T> M;
+    typedef typename M::V8 V8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // [K buf0][K buf1][V buf0][V buf1], 8 KiB each
+    const int tid = threadIdx.x, lane = tid & 63, ql = lane & 31, hi = lane >> 5;
+    const int wave = tid >> 6, uw = __builtin_amdgcn_readfirstlane(wave);
+    const uint32_t nqb = (p.Sq + 127) / 128;
+    const uint32_t vid = xcd_remap(blockIdx.x, nqb * p.B * p.H);
+    const uint32_t bh = vid / nqb;
+    uint32_t qb = vid % nqb;
+    if (CAUSAL) qb = nqb - 1 - qb;
+    const uint32_t q_row = qb * 128 + wave * 32 + ql, wave_q0 = qb * 128 + wave * 32;
+    const bool qok = q_row < p.Sq;
+    const T* qp = (const T*)p.q + (int64_t)bh * p.Sq * DP;
+    const T* dop = (const T*)p.dout + (int64_t)bh * p.Sq * DP;
+    const T* kp = (const T*)p.k + (int64_t)bh * p.Skv * DP;
+    const T* vp = (const T*)p.v + (int64_t)bh * p.Skv * DP;
+
+    // B operands: lane (q, hi) holds Q[q][16 ks + 8 hi ..], dO[q][...]
+    V8 qf[NKS], dof[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        if (qok) {
+            qf[ks] = *(const V8*)(qp + (int64_t)q_row * DP + 16 * ks + 8 * hi);
+            dof[ks] = *(const V8*)(dop + (int64_t)q_row * DP + 16 * ks + 8 * hi);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { qf[ks][j] = (T)0.0f; dof[ks][j] = (T)0.0f; }
+        }
+    }
+    const float c = p.scale * UMFA_LOG2E;
+    const float L2 = qok ? p.lse[(int64_t)bh * p.Sq + q_row] * UMFA_LOG2E : INFINITY;  // +inf -> P = 0
+    const float delta = qok ? p.dvec[(int64_t)bh * p.Sq + q_row] : 0.0f;
+
+    const i32x4 k_srd = make_srd(kp, p.Skv * (uint32_t)ROW_B), v_srd = make_srd(vp, p.Skv * (uint32_t)ROW_B);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((LDS_AS char*)smem));
+#pragma unroll
+    for (int i = 0; i < 4 * TILE_BYTES / 4096; ++i) *(i32x4*)(smem + i * 4096 + tid * 16) = i32x4{0, 0, 0, 0};
+    __syncthreads();
+
+    uint32_t ntiles = (p.Skv + 31) / 32;
+    if (CAUSAL) {
+        const uint32_t lim = (qb * 128 + 128 + 31) / 32;
+        ntiles = ntiles < lim ? ntiles : lim;
+    }
+    f32x16 acc[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    const int tr_qq = (lane >> 2) & 3, tr_pp = lane & 3, tr_g1 = (lane >> 4) & 1;
+
+    auto stage = [&](uint32_t t) {
+        dma_rows<8>(k_srd, lds0 + (t & 1) * TILE_BYTES, t * 32, uw, lane);
+        dma_rows<8>(v_srd, lds0 + 2 * TILE_BYTES + (t & 1) * TILE_BYTES, t * 32, uw, lane);
+    };
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (uint32_t t = 0; t < ntiles; ++t) {
+        stage(t + 1);  // other buffer: its last readers passed the previous barrier
+        const char* Kt = smem + (t & 1) * TILE_BYTES;
+        const char* Vt = smem + 2 * TILE_BYTES + (t & 1) * TILE_BYTES;
+        const uint32_t key_base = t * 32;
+        if (!CAUSAL || key_base <= wave_q0 + 31) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const V8 ak = *(const V8*)(Kt + d_off(ql, 2 * ks + hi));
+                const V8 av = *(const V8*)(Vt + d_off(ql, 2 * ks + hi));
+                s = M::mma(ak, qf[ks], s);      // S^T[key][q]
+                dp = M::mma(av, dof[ks], dp);   // dP^T[key][q]
+            }
+            const bool edge = (key_base + 32 > p.Skv) || (CAUSAL && key_base + 31 > wave_q0);
+            V8 ds[2];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -L2));
+                if (edge) {
+                    const uint32_t key = key_base + acc_row(r, hi);
+                    if (key >= p.Skv || (CAUSAL && key > q_row)) pr = 0.0f;
+                }
+                ds[r >> 3][r & 7] = (T)(pr * (dp[r] - delta));
+            }
+            // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+#pragma unroll
+            for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+                    acc[i] = M::mma(tr_frag<M>(Kt, i, s2, hi, tr_qq, tr_pp, tr_g1), ds[s2], acc[i]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (qok) {
+        float* op = p.dq + ((int64_t)bh * p.Sq + q_row) * DP;
+#pragma unroll
+        for (int i = 0; i < NDB; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 val = {acc[i][4 * g] * p.scale, acc[i][4 * g + 1] * p.scale, acc[i][4 * g + 2] * p.scale,
+                             acc[i][4 * g + 3] * p.scale};
+                *(f32x4*)(op + 32 * i + 8 * g + 4 * hi) = val;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ dK, dV
+template <typename T, bool CAUSAL>
+__global__ __launch_bounds__(256, 1) void bwd16_dkdv_kernel(BwdParams p) {
+    typedef Mma16<T> M;
+    typedef typename M::V8 V8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // [K 128 rows 32 KiB][V 32 KiB][Q buf0 8][Q buf1 8][dO buf0 8][dO buf1 8][L2 2x32 f32][D 2x32 f32]
+    constexpr int KW = 0, VW = 32768, QT = 65536, DOT = QT + 2 * TILE_BYTES, VEC = DOT + 2 * TILE_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, kl = lane & 31, hi = lane >> 5;
+    const int wave = tid >> 6, uw = __builtin_amdgcn_readfirstlane(wave);
+    const uint32_t nkb = (p.Skv + 127) / 128;
+    const uint32_t vid = xcd_remap(blockIdx.x, nkb * p.B * p.H);
+    const uint32_t bh = vid / nkb, kb = vid % nkb;
+    const uint32_t key = kb * 128 + wave * 32 + kl, wave_k0 = kb * 128 + wave * 32;
+    const bool kok = key < p.Skv;
+    const T* qp = (const T*)p.q + (int64_t)bh * p.Sq * DP;
+    const T* dop = (const T*)p.dout + (int64_t)bh * p.Sq * DP;
+    const T* kp = (const T*)p.k + (int64_t)bh * p.Skv * DP;
+    const T* vp = (const T*)p.v + (int64_t)bh * p.Skv * DP;
+    const i32x4 q_srd = make_srd(qp, p.Sq * (uint32_t)ROW_B), do_srd = make_srd(dop, p.Sq * (uint32_t)ROW_B);
+    const i32x4 k_srd = make_srd(kp, p.Skv * (uint32_t)ROW_B), v_srd = make_srd(vp, p.Skv * (uint32_t)ROW_B);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((LDS_AS char*)smem));
+    float* const vec = (float*)(smem + VEC);
+
+#pragma unroll
+    for (int i = 0; i < VEC / 4096; ++i) *(i32x4*)(smem + i * 4096 + tid * 16) = i32x4{0, 0, 0, 0};
+    __syncthreads();
+    // the block's own keys / values: 128 rows each, loaded once (32 pieces each)
+    dma_rows<32>(k_srd, lds0 + KW, kb * 128, uw, lane);
+    dma_rows<32>(v_srd, lds0 + VW, kb * 128, uw, lane);
+
+    const float c = p.scale * UMFA_LOG2E;
+    const uint32_t ntiles = (p.Sq + 31) / 32;
+    const uint32_t t0 = CAUSAL ? (kb * 128) / 32 : 0;  // query tiles entirely before this key block see nothing
+    auto stage = [&](uint32_t t) {
+        dma_rows<8>(q_srd, lds0 + QT + (t & 1) * TILE_BYTES, t * 32, uw, lane);
+        dma_rows<8>(do_srd, lds0 + DOT + (t & 1) * TILE_BYTES, t * 32, uw, lane);
+        if (tid < 32) {  // row constants of the tile: L2 = LSE * log2e (+inf past Sq -> P = 0) and D
+            const uint32_t row = t * 32 + tid;
+            const bool ok = row < p.Sq;
+            vec[(t & 1) * 32 + tid] = ok ? p.lse[(int64_t)bh * p.Sq + row] * UMFA_LOG2E : INFINITY;
+            vec[64 + (t & 1) * 32 + tid] = ok ? p.dvec[(int64_t)bh * p.Sq + row] : 0.0f;
+        }
+    };
+    f32x16 dk[NDB], dv[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[i][r] = 0.0f; dv[i][r] = 0.0f; }
+    const int tr_qq = (lane >> 2) & 3, tr_pp = lane & 3, tr_g1 = (lane >> 4) & 1;
+    const char* Kw = smem + KW + wave * TILE_BYTES;  // this wave's 32 keys
+    const char* Vw = smem + VW + wave * TILE_BYTES;
+
+    if (t0 < ntiles) stage(t0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (uint32_t t = t0; t < ntiles; ++t) {
+        stage(t + 1);
+        const char* Qt = smem + QT + (t & 1) * TILE_BYTES;
+        const char* dOt = smem + DOT + (t & 1) * TILE_BYTES;
+        const float* L2v = vec + (t & 1) * 32;
+        const float* Dv = vec + 64 + (t & 1) * 32;
+        const uint32_t q_base = t * 32;
+        if (!CAUSAL || q_base + 31 >= wave_k0) {  // some query of the tile sees some key of this wave
+            // S[q][key] = Q K^T, dP[q][key] = dO V^T: rows = queries (registers), columns = keys (lanes)
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const V8 aq = *(const V8*)(Qt + d_off(kl, 2 * ks + hi));    // A: row = query kl of the tile
+                const V8 bk = *(const V8*)(Kw + d_off(kl, 2 * ks + hi));    // B: column = key kl of the wave
+                const V8 ado = *(const V8*)(dOt + d_off(kl, 2 * ks + hi));
+                const V8 bv = *(const V8*)(Vw + d_off(kl, 2 * ks + hi));
+                s = M::mma(aq, bk, s);
+                dp = M::mma(ado, bv, dp);
+            }
+            const bool edge = CAUSAL && q_base < wave_k0 + 31;  // tile straddles the diagonal of this wave's keys
+            V8 pb[2], sb[2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                // registers 4g .. 4g+3 are queries 8g + 4hi + 0..3 of the tile
+                const f32x4 l2 = *(const f32x4*)(L2v + 8 * g + 4 * hi);
+                const f32x4 dl = *(const f32x4*)(Dv + 8 * g + 4 * hi);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -l2[e]));
+                    if (edge && key > q_base + 8 * g + 4 * hi + e) pr = 0.0f;
+                    pb[r >> 3][r & 7] = (T)pr;
+                    sb[r >> 3][r & 7] = (T)(pr * (dp[r] - dl[e]));
+                }
+            }
+            // dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]
+#pragma unroll
+            for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    dv[i] = M::mma(tr_frag<M>(dOt, i, s2, hi, tr_qq, tr_pp, tr_g1), pb[s2], dv[i]);
+                    dk[i] = M::mma(tr_frag<M>(Qt, i, s2, hi, tr_qq, tr_pp, tr_g1), sb[s2], dk[i]);
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (kok) {
+        float* okp = p.dk + ((int64_t)bh * p.Skv + key) * DP;
+        float* ovp = p.dv + ((int64_t)bh * p.Skv + key) * DP;
+#pragma unroll
+        for (int i = 0; i < NDB; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = 32 * i + 8 * g + 4 * hi;
+                f32x4 kv = {dk[i][4 * g] * p.scale, dk[i][4 * g + 1] * p.scale, dk[i][4 * g + 2] * p.scale, dk[i][4 * g + 3] * p.scale};
+                f32x4 vv = {dv[i][4 * g], dv[i][4 * g + 1], dv[i][4 * g + 2], dv[i][4 * g + 3]};
+                *(f32x4*)(okp + d0) = kv;
+                *(f32x4*)(ovp + d0) = vv;
+            }
+    }
+}
+
+bool bwd_16_supported(const BwdParams& p) {
+    if (p.in_prec != P_FP16 && p.in_prec != P_BF16) return false;
+    if (p.dout_prec != p.in_prec || p.D != 128 || p.mask) return false;
+    auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    if (!al16(p.q) || !al16(p.k) || !al16(p.v) || !al16(p.dout) || !al16(p.dq) || !al16(p.dk) || !al16(p.dv)) return false;
+    // 32-bit buffer offsets inside one (batch, head) slab
+    return (uint64_t)p.Sq * 256 < (1ull << 31) && (uint64_t)p.Skv * 256 < (1ull << 31);
+}
+
+template <typename T, bool CAUSAL>
+static hipError_t launch_bwd16_t(const BwdParams& p, hipStream_t stream) {
+    const int64_t rows = (int64_t)p.B * p.H * p.Sq;
+    hipLaunchKernelGGL(bwd16_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, p);
+    const size_t lds_dq = 4 * TILE_BYTES, lds_kv = 65536 + 4 * TILE_BYTES + 512;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)bwd16_dkdv_kernel<T, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const uint32_t nqb = (p.Sq + 127) / 128, nkb = (p.Skv + 127) / 128;
+    hipLaunchKernelGGL((bwd16_dq_kernel<T, CAUSAL>), dim3(nqb * p.B * p.H), dim3(256), lds_dq, stream, p);
+    hipLaunchKernelGGL((bwd16_dkdv_kernel<T, CAUSAL>), dim3(nkb * p.B * p.H), dim3(256), lds_kv, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_bwd_16(const BwdParams& p, hipStream_t stream, const char** name) {
+    if (!bwd_16_supported(p)) return hipErrorNotSupported;
+    if (p.in_prec == P_BF16) {
+        *name = "fa_bwd16<bf16,128>";
+        return p.causal ? launch_bwd16_t<__bf16, true>(p, stream) : launch_bwd16_t<__bf16, false>(p, stream);
+    }
+    *name = "fa_bwd16<fp16,128>";
+    return p.causal ? launch_bwd16_t<_Float16, true>(p, stream) : launch_bwd16_t<_Float16, false>(p, stream);
+}
+
+}  // namespace umfa

@@ -21,8 +21,11 @@ struct FwdSplitPlan {
 };
 FwdSplitPlan fwd_16_split_plan(const FwdParams& p);
 
-// Backward: D = rowsum(dO o O), then dK/dV and dQ.
+// Backward: D = rowsum(dO o O), then dQ and dK/dV.  launch_bwd: fp32-exact (any input type, head_dim <= 128);
+// launch_bwd_16: bf16 / fp16 MFMA (head_dim 128, dO in the input type, no mask).
 hipError_t launch_bwd(const BwdParams& p, hipStream_t stream, const char** name);
+bool bwd_16_supported(const BwdParams& p);
+hipError_t launch_bwd_16(const BwdParams& p, hipStream_t stream, const char** name);
 
 // Runtime-quantised path (fa_quant.hip): fused symmetric quantiser for Q, K, V + int8-QK^T forward.
 struct QuantViews {

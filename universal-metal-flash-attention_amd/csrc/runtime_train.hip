@@ -30,7 +30,7 @@ mfa_error_t mfa_attention_backward(mfa_context_t context, mfa_buffer_t dout, mfa
                                    mfa_buffer_t dk, mfa_buffer_t dv, mfa_buffer_t d_buffer, uint32_t batch_size,
                                    uint32_t seq_len_q, uint32_t seq_len_kv, uint32_t num_heads, uint16_t head_dim,
                                    float softmax_scale, bool causal, mfa_precision_t input_precision,
-                                   mfa_precision_t /*intermediate_precision*/, bool transpose_q, bool transpose_k,
+                                   mfa_precision_t intermediate_precision, bool transpose_q, bool transpose_k,
                                    bool transpose_v, bool transpose_o) {
     Context* ctx = as_ctx(context);
     Buffer *bdo = as_buf(dout), *bq = as_buf(q), *bk = as_buf(k), *bv = as_buf(v), *bo = as_buf(out),
@@ -62,7 +62,9 @@ mfa_error_t mfa_attention_backward(mfa_context_t context, mfa_buffer_t dout, mfa
     p.in_prec = prec; p.dout_prec = prec;
     LatencyScope lat(ctx, stream);
     const char* name = "none";
-    hipError_t e = launch_bwd(p, stream, &name);
+    // 16-bit operands with 16-bit intermediates -> MFMA backward; everything else -> fp32-exact backward
+    const bool lowp = dense_prec(intermediate_precision) != P_FP32 && !getenv("UMFA_BWD_EXACT");
+    hipError_t e = (lowp && bwd_16_supported(p)) ? launch_bwd_16(p, stream, &name) : launch_bwd(p, stream, &name);
     ctx->last_kernel = name;
     if (e != hipSuccess) return e == hipErrorInvalidValue ? MFA_ERROR_INVALID_ARGS : MFA_ERROR_EXECUTION_FAILED;
     lat.stop();
