@@ -9,7 +9,7 @@
 //   bwd16_dq    workgroup = 4 waves x 32 query rows; sweeps 32-key tiles of K and V (LDS, LDS-DMA staged).
 //               lane <-> query:   S^T = K Q^T,  dP^T = V dO^T,  P^T = exp2(c S^T - L2[q]),  dS^T = P^T o (dP^T - D[q]),
 //               dQ^T += K^T dS^T  (K^T fragments by transposed reads of the SAME K image).
-//   bwd16_dkdv  workgroup = 4 waves x 32 keys; K, V of the block stay in LDS; sweeps 32-row tiles of Q and dO.
+//   bwd16_dkdv  workgroup = 4 waves x 32 keys (K, V fragments in registers); sweeps 32-row tiles of Q and dO (LDS).
 //               lane <-> key:     S = Q K^T,  dP = dO V^T,  P, dS as above (row constants from LDS),
 //               dV^T += dO^T P,  dK^T += Q^T dS  (Q^T / dO^T fragments by transposed reads of the same images).
 // All four tile kinds use ONE dual-use LDS image (256-byte rows, 16-byte chunks XOR-swizzled with
@@ -205,8 +205,9 @@ __global__ __launch_bounds__(256, 1) void bwd16_dkdv_kernel(BwdParams p) {
     typedef Mma16<T> M;
     typedef typename M::V8 V8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // [K 128 rows 32 KiB][V 32 KiB][Q buf0 8][Q buf1 8][dO buf0 8][dO buf1 8][L2 2x32 f32][D 2x32 f32]
-    constexpr int KW = 0, VW = 32768, QT = 65536, DOT = QT + 2 * TILE_BYTES, VEC = DOT + 2 * TILE_BYTES;
+    // [Q buf0 8 KiB][Q buf1][dO buf0][dO buf1][L2 2x32 f32][D 2x32 f32]; this wave's K / V fragments live in registers
+    // (one wave per SIMD: 512-register budget, accumulators in AGPRs)
+    constexpr int QT = 0, DOT = QT + 4 * TILE_BYTES, VEC = DOT + 4 * TILE_BYTES;  // 64-row tiles, double-buffered
     const int tid = threadIdx.x, lane = tid & 63, kl = lane & 31, hi = lane >> 5;
     const int wave = tid >> 6, uw = __builtin_amdgcn_readfirstlane(wave);
     const uint32_t nkb = (p.Skv + 127) / 128;
@@ -219,28 +220,39 @@ __global__ __launch_bounds__(256, 1) void bwd16_dkdv_kernel(BwdParams p) {
     const T* kp = (const T*)p.k + (int64_t)bh * p.Skv * DP;
     const T* vp = (const T*)p.v + (int64_t)bh * p.Skv * DP;
     const i32x4 q_srd = make_srd(qp, p.Sq * (uint32_t)ROW_B), do_srd = make_srd(dop, p.Sq * (uint32_t)ROW_B);
-    const i32x4 k_srd = make_srd(kp, p.Skv * (uint32_t)ROW_B), v_srd = make_srd(vp, p.Skv * (uint32_t)ROW_B);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((LDS_AS char*)smem));
     float* const vec = (float*)(smem + VEC);
 
 #pragma unroll
     for (int i = 0; i < VEC / 4096; ++i) *(i32x4*)(smem + i * 4096 + tid * 16) = i32x4{0, 0, 0, 0};
     __syncthreads();
-    // the block's own keys / values: 128 rows each, loaded once (32 pieces each)
-    dma_rows<32>(k_srd, lds0 + KW, kb * 128, uw, lane);
-    dma_rows<32>(v_srd, lds0 + VW, kb * 128, uw, lane);
+    // B operands of S = Q K^T and dP = dO V^T: lane (key, hi) holds K[key][16 ks + 8 hi ..], V[key][...]
+    V8 kf[NKS], vf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        if (kok) {
+            kf[ks] = *(const V8*)(kp + (int64_t)key * DP + 16 * ks + 8 * hi);
+            vf[ks] = *(const V8*)(vp + (int64_t)key * DP + 16 * ks + 8 * hi);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { kf[ks][j] = (T)0.0f; vf[ks][j] = (T)0.0f; }
+        }
+    }
 
     const float c = p.scale * UMFA_LOG2E;
-    const uint32_t ntiles = (p.Sq + 31) / 32;
-    const uint32_t t0 = CAUSAL ? (kb * 128) / 32 : 0;  // query tiles entirely before this key block see nothing
+    // query tiles of 64 rows = two 32-row sub-tiles per barrier: both S/dP products are issued before the first
+    // sub-tile's exp/convert work, so the wave has matrix work in flight while its VALU runs
+    constexpr int QROWS = 64, QTILE_B = QROWS * ROW_B;
+    const uint32_t ntiles = (p.Sq + QROWS - 1) / QROWS;
+    const uint32_t t0 = CAUSAL ? (kb * 128) / QROWS : 0;  // query tiles entirely before this key block see nothing
     auto stage = [&](uint32_t t) {
-        dma_rows<8>(q_srd, lds0 + QT + (t & 1) * TILE_BYTES, t * 32, uw, lane);
-        dma_rows<8>(do_srd, lds0 + DOT + (t & 1) * TILE_BYTES, t * 32, uw, lane);
-        if (tid < 32) {  // row constants of the tile: L2 = LSE * log2e (+inf past Sq -> P = 0) and D
-            const uint32_t row = t * 32 + tid;
+        dma_rows<16>(q_srd, lds0 + QT + (t & 1) * QTILE_B, t * QROWS, uw, lane);
+        dma_rows<16>(do_srd, lds0 + DOT + (t & 1) * QTILE_B, t * QROWS, uw, lane);
+        if (tid < QROWS) {  // row constants of the tile: L2 = LSE * log2e (+inf past Sq -> P = 0) and D
+            const uint32_t row = t * QROWS + tid;
             const bool ok = row < p.Sq;
-            vec[(t & 1) * 32 + tid] = ok ? p.lse[(int64_t)bh * p.Sq + row] * UMFA_LOG2E : INFINITY;
-            vec[64 + (t & 1) * 32 + tid] = ok ? p.dvec[(int64_t)bh * p.Sq + row] : 0.0f;
+            vec[(t & 1) * QROWS + tid] = ok ? p.lse[(int64_t)bh * p.Sq + row] * UMFA_LOG2E : INFINITY;
+            vec[2 * QROWS + (t & 1) * QROWS + tid] = ok ? p.dvec[(int64_t)bh * p.Sq + row] : 0.0f;
         }
     };
     f32x16 dk[NDB], dv[NDB];
@@ -249,8 +261,6 @@ __global__ __launch_bounds__(256, 1) void bwd16_dkdv_kernel(BwdParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[i][r] = 0.0f; dv[i][r] = 0.0f; }
     const int tr_qq = (lane >> 2) & 3, tr_pp = lane & 3, tr_g1 = (lane >> 4) & 1;
-    const char* Kw = smem + KW + wave * TILE_BYTES;  // this wave's 32 keys
-    const char* Vw = smem + VW + wave * TILE_BYTES;
 
     if (t0 < ntiles) stage(t0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -258,49 +268,54 @@ __global__ __launch_bounds__(256, 1) void bwd16_dkdv_kernel(BwdParams p) {
 
     for (uint32_t t = t0; t < ntiles; ++t) {
         stage(t + 1);
-        const char* Qt = smem + QT + (t & 1) * TILE_BYTES;
-        const char* dOt = smem + DOT + (t & 1) * TILE_BYTES;
-        const float* L2v = vec + (t & 1) * 32;
-        const float* Dv = vec + 64 + (t & 1) * 32;
-        const uint32_t q_base = t * 32;
-        if (!CAUSAL || q_base + 31 >= wave_k0) {  // some query of the tile sees some key of this wave
+        const char* Qt = smem + QT + (t & 1) * QTILE_B;
+        const char* dOt = smem + DOT + (t & 1) * QTILE_B;
+        const float* L2v = vec + (t & 1) * QROWS;
+        const float* Dv = vec + 2 * QROWS + (t & 1) * QROWS;
+        const uint32_t q_base = t * QROWS;
+        if (!CAUSAL || q_base + QROWS - 1 >= wave_k0) {  // some query of the tile sees some key of this wave
             // S[q][key] = Q K^T, dP[q][key] = dO V^T: rows = queries (registers), columns = keys (lanes)
-            f32x16 s, dp;
+            f32x16 s[2], dp[2];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
+            for (int u = 0; u < 2; ++u) {
 #pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                const V8 aq = *(const V8*)(Qt + d_off(kl, 2 * ks + hi));    // A: row = query kl of the tile
-                const V8 bk = *(const V8*)(Kw + d_off(kl, 2 * ks + hi));    // B: column = key kl of the wave
-                const V8 ado = *(const V8*)(dOt + d_off(kl, 2 * ks + hi));
-                const V8 bv = *(const V8*)(Vw + d_off(kl, 2 * ks + hi));
-                s = M::mma(aq, bk, s);
-                dp = M::mma(ado, bv, dp);
-            }
-            const bool edge = CAUSAL && q_base < wave_k0 + 31;  // tile straddles the diagonal of this wave's keys
-            V8 pb[2], sb[2];
+                for (int r = 0; r < 16; ++r) { s[u][r] = 0.0f; dp[u][r] = 0.0f; }
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                // registers 4g .. 4g+3 are queries 8g + 4hi + 0..3 of the tile
-                const f32x4 l2 = *(const f32x4*)(L2v + 8 * g + 4 * hi);
-                const f32x4 dl = *(const f32x4*)(Dv + 8 * g + 4 * hi);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * g + e;
-                    float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -l2[e]));
-                    if (edge && key > q_base + 8 * g + 4 * hi + e) pr = 0.0f;
-                    pb[r >> 3][r & 7] = (T)pr;
-                    sb[r >> 3][r & 7] = (T)(pr * (dp[r] - dl[e]));
+                for (int ks = 0; ks < NKS; ++ks) {
+                    const V8 aq = *(const V8*)(Qt + u * TILE_BYTES + d_off(kl, 2 * ks + hi));  // A: row = query kl of the sub-tile
+                    const V8 ado = *(const V8*)(dOt + u * TILE_BYTES + d_off(kl, 2 * ks + hi));
+                    s[u] = M::mma(aq, kf[ks], s[u]);
+                    dp[u] = M::mma(ado, vf[ks], dp[u]);
                 }
             }
-            // dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]
 #pragma unroll
-            for (int i = 0; i < NDB; ++i)
+            for (int u = 0; u < 2; ++u) {
+                const uint32_t qb0 = q_base + 32 * u;
+                const bool edge = CAUSAL && qb0 < wave_k0 + 31;  // sub-tile straddles the diagonal of this wave's keys
+                V8 pb[2], sb[2];
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    dv[i] = M::mma(tr_frag<M>(dOt, i, s2, hi, tr_qq, tr_pp, tr_g1), pb[s2], dv[i]);
-                    dk[i] = M::mma(tr_frag<M>(Qt, i, s2, hi, tr_qq, tr_pp, tr_g1), sb[s2], dk[i]);
+                for (int g = 0; g < 4; ++g) {
+                    // registers 4g .. 4g+3 are queries 8g + 4hi + 0..3 of the sub-tile
+                    const f32x4 l2 = *(const f32x4*)(L2v + 32 * u + 8 * g + 4 * hi);
+                    const f32x4 dl = *(const f32x4*)(Dv + 32 * u + 8 * g + 4 * hi);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g + e;
+                        float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], c, -l2[e]));
+                        if (edge && key > qb0 + 8 * g + 4 * hi + e) pr = 0.0f;
+                        pb[r >> 3][r & 7] = (T)pr;
+                        sb[r >> 3][r & 7] = (T)(pr * (dp[u][r] - dl[e]));
+                    }
                 }
+                // dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]
+#pragma unroll
+                for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        dv[i] = M::mma(tr_frag<M>(dOt + u * TILE_BYTES, i, s2, hi, tr_qq, tr_pp, tr_g1), pb[s2], dv[i]);
+                        dk[i] = M::mma(tr_frag<M>(Qt + u * TILE_BYTES, i, s2, hi, tr_qq, tr_pp, tr_g1), sb[s2], dk[i]);
+                    }
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -334,7 +349,7 @@ template <typename T, bool CAUSAL>
 static hipError_t launch_bwd16_t(const BwdParams& p, hipStream_t stream) {
     const int64_t rows = (int64_t)p.B * p.H * p.Sq;
     hipLaunchKernelGGL(bwd16_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, p);
-    const size_t lds_dq = 4 * TILE_BYTES, lds_kv = 65536 + 4 * TILE_BYTES + 512;
+    const size_t lds_dq = 4 * TILE_BYTES, lds_kv = 8 * TILE_BYTES + 1024;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)bwd16_dkdv_kernel<T, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
