@@ -275,8 +275,9 @@ double mfa_get_gpu_latency(mfa_context_t context); /* [H]:478: seconds, last syn
 int32_t mfa_has_native_bfloat(void);               /* [T]:458: 1 on gfx950 */
 int32_t mfa_has_native_bfloat_msl32(void);         /* [T]:459: 1 on gfx950 */
 
-/* ---- neighbours of the hot path that are NOT built this round:
- * the symbols exist so existing callers link; each returns 3. ------------------ */
+/* ---- neighbours of the attention path, SURVEY §8f rows 1 and 4 (built: csrc/fa_aux.hip) ----
+ * Rotary rotation in-stream ([M]:9-22, [B]:2286-2375): src strided BHSD (element strides), dst dense BHSD,
+ * fp32 cos/sin tables [S,D] (table_batch_stride 0) or [B,S,D]; negate_sin = inverse rotation. */
 int mfa_rope_rotate_encode_mtl(void* context, void* command_buffer, void* src_buffer,
                                int64_t src_offset, int64_t src_batch_stride,
                                int64_t src_head_stride, int64_t src_seq_stride, void* dst_buffer,
@@ -285,7 +286,12 @@ int mfa_rope_rotate_encode_mtl(void* context, void* command_buffer, void* src_bu
                                bool negate_sin, uint32_t batch_size, uint32_t num_heads,
                                uint32_t seq_len, uint32_t head_dim,
                                const char* precision); /* [M]:9-22 */
+/* In-place group-wise Walsh-Hadamard transform, 1/sqrt(N) normalised ([B]:3433-3459); element type inferred from
+ * the buffer size (4 B/elt fp32, 2 B/elt fp16); block_size a power of two <= 32768. */
 int32_t mfa_hadamard_rotate(mfa_buffer_t data, uint32_t block_size, uint32_t num_blocks); /* [T]:462-465 */
+
+/* ---- other ops of the reference that are NOT built (GEMMs, not SDPA):
+ * the symbols exist so existing callers link; each returns 3. ------------------ */
 mfa_error_t mfa_sparse_indexer_scores(mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k,
                                       uint32_t batch_size, uint32_t num_heads, uint32_t seq_len_q,
                                       uint32_t seq_len_k, uint16_t head_dim, float scale,

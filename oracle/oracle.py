@@ -224,3 +224,32 @@ def lcg_uniform(count: int, seed: int) -> np.ndarray:
         rng = (rng * 1664525 + 1013904223) & 0xFFFFFFFFFFFFFFFF
         out[i] = (np.float32(rng % 1_000_000) / np.float32(1_000_000.0) - np.float32(0.5)) * np.float32(2.0)
     return out
+
+
+def rope_rotate(x: np.ndarray, cos: np.ndarray, sin: np.ndarray, negate_sin: bool = False) -> np.ndarray:
+    """x [B,H,S,D] (any BHS element strides, contiguous head_dim); cos/sin fp32 [S,D] or [B,S,D].
+    Returns the fp32 image of the rotated tensor (MFABridge.swift:269-319)."""
+    L = lib()
+    L.ref_rope_rotate.restype = None
+    L.ref_rope_rotate.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_uint32] * 4 + [ctypes.c_int64] * 4 + [ctypes.c_int, ctypes.c_int]
+    B, H, S, D = x.shape
+    cos = np.ascontiguousarray(cos, np.float32)
+    sin = np.ascontiguousarray(sin, np.float32)
+    tb = S * D if cos.ndim == 3 else 0
+    es = _elem_strides(x)
+    assert es[3] == 1
+    out = np.empty((B, H, S, D), np.float32)
+    L.ref_rope_rotate(x.ctypes.data, out.ctypes.data, cos.ctypes.data, sin.ctypes.data, B, H, S, D, es[0], es[1], es[2],
+                      tb, int(bool(negate_sin)), prec_of(x))
+    return out
+
+
+def hadamard(x: np.ndarray, block: int) -> np.ndarray:
+    """Normalised group-wise FWHT of the flattened array (fp64 math), same shape back."""
+    L = lib()
+    L.ref_hadamard.restype = None
+    L.ref_hadamard.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t]
+    v = np.ascontiguousarray(to_f32(x) if x.dtype != np.float64 else x, np.float64).ravel().copy()
+    assert v.size % block == 0
+    L.ref_hadamard(v.ctypes.data, block, v.size // block)
+    return v.reshape(x.shape)

@@ -322,3 +322,45 @@ int ref_quantized_forward(const void* q, const void* k, const void* v, float* ou
     free(i8);
     return rc;
 }
+
+/*
+ * Rotary rotation, MFABridge.swift:269-319 (rope_rotate_*): interleaved pairs, fp32 tables [S,D] (or [B,S,D],
+ * table_batch_stride = S*D) with pair-duplicated entries of which only the even one is read; strided BHSD source
+ * (element strides, head_dim contiguous), dense BHSD destination in the same element type; negate_sin = inverse.
+ * Math in double, rounded once to the element type's fp32 image (the caller rounds to fp16/bf16).
+ */
+void ref_rope_rotate(const void* src, float* dst, const float* cos_t, const float* sin_t, uint32_t B, uint32_t H,
+                     uint32_t S, uint32_t D, int64_t sb, int64_t sh, int64_t ss, int64_t table_batch_stride,
+                     int negate_sin, int prec) {
+    for (uint32_t b = 0; b < B; ++b)
+        for (uint32_t h = 0; h < H; ++h)
+            for (uint32_t s = 0; s < S; ++s)
+                for (uint32_t pr = 0; pr < D / 2; ++pr) {
+                    int64_t si = b * sb + h * sh + s * ss + 2 * pr;
+                    size_t di = (((size_t)b * H + h) * S + s) * D + 2 * pr;
+                    size_t t = (size_t)b * table_batch_stride + (size_t)s * D + 2 * pr;
+                    double c = cos_t[t], sn = negate_sin ? -(double)sin_t[t] : (double)sin_t[t];
+                    double x0 = load_elem(src, prec, si), x1 = load_elem(src, prec, si + 1);
+                    dst[di] = (float)(x0 * c - x1 * sn);
+                    dst[di + 1] = (float)(x1 * c + x0 * sn);
+                }
+}
+
+/*
+ * Group-wise Walsh-Hadamard transform, normalised by 1/sqrt(N) (contract: MFABridge.swift:3433-3459,
+ * AGENTS.md:161-170 "double application = identity").  Sylvester (natural) ordering; in place on fp64.
+ */
+void ref_hadamard(double* x, size_t block, size_t nblocks) {
+    for (size_t bI = 0; bI < nblocks; ++bI) {
+        double* v = x + bI * block;
+        for (size_t h = 1; h < block; h <<= 1)
+            for (size_t i = 0; i < block; i += 2 * h)
+                for (size_t j = i; j < i + h; ++j) {
+                    double a = v[j], b = v[j + h];
+                    v[j] = a + b;
+                    v[j + h] = a - b;
+                }
+        double nrm = 1.0 / sqrt((double)block);
+        for (size_t i = 0; i < block; ++i) v[i] *= nrm;
+    }
+}

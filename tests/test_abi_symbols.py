@@ -107,7 +107,9 @@ def test_no_cpu_fallback_without_device(lib):
 
 def test_out_of_scope_symbols_return_3(lib):
     lib.mfa_hadamard_rotate.restype = ctypes.c_int32
-    assert lib.mfa_hadamard_rotate(None, 64, 1) == 3
+    assert lib.mfa_hadamard_rotate(None, 64, 1) == 1  # built: NULL buffer -> invalid args
+    lib.mfa_sparse_indexer_scores.restype = ctypes.c_int32
+    assert lib.mfa_sparse_indexer_scores(None, None, None, 1, 1, 1, 1, 8, ctypes.c_float(1.0), None, None) == 3
     lib.mfa_mla_create_context.restype = ctypes.c_int32
     h = ctypes.c_void_p()
     assert lib.mfa_mla_create_context(ctypes.byref(h)) == 3

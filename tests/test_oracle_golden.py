@@ -134,3 +134,20 @@ def test_quantised_forward_error_budget():
             o, _ = oracle.quantized_forward(q, k, v, bits=bits, quant_mode=mode)
             rel = np.abs(o - ref).max() / np.abs(ref).max()
             assert rel < budget, (bits, mode, rel)
+
+
+def test_rope_and_hadamard_oracle_identities():
+    # rope: rotation then inverse rotation is the identity; norms of pairs preserved (MFABridge.swift:262-267)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((1, 2, 5, 8)).astype(np.float32)
+    ang = rng.uniform(0, 6.28, (5, 4)).astype(np.float32)
+    cos, sin = np.repeat(np.cos(ang), 2, -1), np.repeat(np.sin(ang), 2, -1)
+    y = oracle.rope_rotate(x, cos, sin)
+    assert np.abs(oracle.rope_rotate(y, cos, sin, negate_sin=True) - x).max() < 1e-6
+    assert np.allclose((y.reshape(-1, 2) ** 2).sum(-1), (x.reshape(-1, 2) ** 2).sum(-1), rtol=1e-5)
+    assert np.allclose(y[0, 0, 0, 0], x[0, 0, 0, 0] * cos[0, 0] - x[0, 0, 0, 1] * sin[0, 0], atol=1e-6)
+    # hadamard: H2 = [[1,1],[1,-1]]/sqrt2, involution
+    h = oracle.hadamard(np.array([1.0, 0.0, 0.0, 0.0], np.float32), 4)
+    assert np.allclose(h, [0.5, 0.5, 0.5, 0.5])
+    v = rng.standard_normal(64).astype(np.float32)
+    assert np.abs(oracle.hadamard(oracle.hadamard(v, 16).astype(np.float32), 16) - v).max() < 1e-6

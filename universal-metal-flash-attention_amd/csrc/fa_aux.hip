@@ -1,0 +1,153 @@
+// fa_aux.hip -- the two bandwidth-bound neighbours of the attention path.
+//
+// rope_rotate    replaces rope_rotate_{float,half,bfloat} (MFABridge.swift:269-319): interleaved-pair rotary,
+//                fp32 math, fp32 cos/sin tables [S,D] or [B,S,D] with pair-duplicated entries (only the even one
+//                is read), strided BHSD source -> dense BHSD destination, negate_sin = inverse rotation.
+// hadamard       replaces HadamardRotation.rotate (absent submodule; contract from MFABridge.swift:3433-3459 and
+//                AGENTS.md:161-170): in-place Fast Walsh-Hadamard Transform of `num_blocks` consecutive groups
+//                of `block_size` (a power of two) elements, normalised by 1/sqrt(N) so that applying it twice is
+//                the identity.  Parity unpinned beyond that contract (no source, no vectors in the reference).
+// Both are HBM-bound: rope reads 1 + writes 1 element (+ tables, L2-resident across heads); FWHT reads and
+// writes each element once, all log2(N) butterfly stages run in LDS.
+#include "fa_common.h"
+#include "kernels.h"
+
+namespace umfa {
+
+// ---------------------------------------------------------------------------------------------- RoPE
+// one thread = 8 consecutive elements (4 pairs) of one row: 16-byte load/store for 16-bit types
+template <typename T>
+__global__ __launch_bounds__(256) void rope_rotate_kernel(RopeParams p) {
+    const uint32_t chunks_per_row = p.D / 8;
+    const uint64_t total = (uint64_t)p.B * p.H * p.S * chunks_per_row;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t ch = (uint32_t)(i % chunks_per_row);
+        const uint64_t row = i / chunks_per_row;
+        const uint32_t s = (uint32_t)(row % p.S);
+        const uint64_t bh = row / p.S;
+        const uint32_t h = (uint32_t)(bh % p.H), b = (uint32_t)(bh / p.H);
+        const T* src = (const T*)p.src + (int64_t)b * p.src_batch_stride + (int64_t)h * p.src_head_stride +
+                       (int64_t)s * p.src_seq_stride + ch * 8;
+        T* dst = (T*)p.dst + row * p.D + ch * 8;
+        const int64_t t = (int64_t)b * p.table_batch_stride + (int64_t)s * p.D + ch * 8;
+        float x[8];
+        if constexpr (sizeof(T) == 2) {
+            typedef T T8 __attribute__((ext_vector_type(8)));
+            const T8 v = *(const T8*)src;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = (float)v[j];
+        } else {
+            const f32x4 a = *(const f32x4*)src, c = *(const f32x4*)(src + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { x[j] = a[j]; x[4 + j] = c[j]; }
+        }
+        const f32x4 c0 = *(const f32x4*)(p.cos_table + t), c1 = *(const f32x4*)(p.cos_table + t + 4);
+        const f32x4 s0 = *(const f32x4*)(p.sin_table + t), s1 = *(const f32x4*)(p.sin_table + t + 4);
+        const float cs[4] = {c0[0], c0[2], c1[0], c1[2]};  // even entries only (MFABridge.swift:264-266)
+        float sn[4] = {s0[0], s0[2], s1[0], s1[2]};
+        float y[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (p.negate_sin) sn[k] = -sn[k];
+            // no fma contraction: the reference computes x0*c - x1*sn with separately rounded products only if
+            // its compiler does not fuse either; either form is within 1 ulp of the fp64 value (tests allow 2 ulp)
+            y[2 * k] = x[2 * k] * cs[k] - x[2 * k + 1] * sn[k];
+            y[2 * k + 1] = x[2 * k + 1] * cs[k] + x[2 * k] * sn[k];
+        }
+        if constexpr (sizeof(T) == 2) {
+            typedef T T8 __attribute__((ext_vector_type(8)));
+            T8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (T)y[j];
+            *(T8*)dst = o;
+        } else {
+            *(f32x4*)dst = f32x4{y[0], y[1], y[2], y[3]};
+            *(f32x4*)(dst + 4) = f32x4{y[4], y[5], y[6], y[7]};
+        }
+    }
+}
+
+// generic fallback: one thread per pair (head_dim or strides not multiples of 8)
+template <typename T>
+__global__ __launch_bounds__(256) void rope_rotate_pair_kernel(RopeParams p) {
+    const uint32_t pairs = p.D / 2;
+    const uint64_t total = (uint64_t)p.B * p.H * p.S * pairs;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256) {
+        const uint32_t pr = (uint32_t)(i % pairs);
+        const uint64_t row = i / pairs;
+        const uint32_t s = (uint32_t)(row % p.S);
+        const uint64_t bh = row / p.S;
+        const uint32_t h = (uint32_t)(bh % p.H), b = (uint32_t)(bh / p.H);
+        const T* src = (const T*)p.src + (int64_t)b * p.src_batch_stride + (int64_t)h * p.src_head_stride +
+                       (int64_t)s * p.src_seq_stride + pr * 2;
+        T* dst = (T*)p.dst + row * p.D + pr * 2;
+        const int64_t t = (int64_t)b * p.table_batch_stride + (int64_t)s * p.D + pr * 2;
+        const float c = p.cos_table[t];
+        float sn = p.sin_table[t];
+        if (p.negate_sin) sn = -sn;
+        const float x0 = (float)src[0], x1 = (float)src[1];
+        dst[0] = (T)(x0 * c - x1 * sn);
+        dst[1] = (T)(x1 * c + x0 * sn);
+    }
+}
+
+template <typename T>
+static hipError_t launch_rope_t(const RopeParams& p, hipStream_t stream) {
+    const bool vec = p.D % 8 == 0 && p.src_batch_stride % 8 == 0 && p.src_head_stride % 8 == 0 &&
+                     p.src_seq_stride % 8 == 0 && p.table_batch_stride % 4 == 0 && ((uintptr_t)p.src & 15) == 0 &&
+                     ((uintptr_t)p.dst & 15) == 0 && ((uintptr_t)p.cos_table & 15) == 0 && ((uintptr_t)p.sin_table & 15) == 0;
+    const uint64_t work = (uint64_t)p.B * p.H * p.S * (vec ? p.D / 8 : p.D / 2);
+    if (work == 0) return hipSuccess;
+    const unsigned grid = (unsigned)((work + 255) / 256 < 2048 * 8 ? (work + 255) / 256 : 2048 * 8);
+    if (vec) hipLaunchKernelGGL(rope_rotate_kernel<T>, dim3(grid), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(rope_rotate_pair_kernel<T>, dim3(grid), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_rope(const RopeParams& p, int prec, hipStream_t stream) {
+    if (p.D % 2) return hipErrorInvalidValue;
+    if (prec == P_FP16) return launch_rope_t<_Float16>(p, stream);
+    if (prec == P_BF16) return launch_rope_t<__bf16>(p, stream);
+    return launch_rope_t<float>(p, stream);
+}
+
+// ---------------------------------------------------------------------------------------------- FWHT
+template <typename T>
+__global__ __launch_bounds__(256) void hadamard_kernel(T* data, uint32_t n, uint32_t log2n, float norm) {
+    extern __shared__ __attribute__((aligned(16))) float buf[];
+    T* blk = data + (size_t)blockIdx.x * n;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) buf[i] = (float)blk[i];
+    __syncthreads();
+    for (uint32_t st = 0; st < log2n; ++st) {
+        const uint32_t half = 1u << st;
+        for (uint32_t j = threadIdx.x; j < n / 2; j += 256) {
+            const uint32_t lo = ((j >> st) << (st + 1)) | (j & (half - 1)), hi2 = lo + half;
+            const float a = buf[lo], b = buf[hi2];
+            buf[lo] = a + b;
+            buf[hi2] = a - b;
+        }
+        __syncthreads();
+    }
+    for (uint32_t i = threadIdx.x; i < n; i += 256) blk[i] = (T)(buf[i] * norm);
+}
+
+hipError_t launch_hadamard(void* data, uint32_t block_size, uint32_t num_blocks, int prec, hipStream_t stream) {
+    if (block_size == 0 || (block_size & (block_size - 1)) || block_size > 32768) return hipErrorInvalidValue;
+    uint32_t lg = 0;
+    while ((1u << lg) < block_size) ++lg;
+    const float norm = 1.0f / sqrtf((float)block_size);
+    const size_t lds = (size_t)block_size * sizeof(float);
+    if (prec == P_FP32) {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)hadamard_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(hadamard_kernel<float>, dim3(num_blocks), dim3(256), lds, stream, (float*)data, block_size, lg, norm);
+    } else if (prec == P_FP16) {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)hadamard_kernel<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(hadamard_kernel<_Float16>, dim3(num_blocks), dim3(256), lds, stream, (_Float16*)data, block_size, lg, norm);
+    } else {
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)hadamard_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(hadamard_kernel<__bf16>, dim3(num_blocks), dim3(256), lds, stream, (__bf16*)data, block_size, lg, norm);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace umfa

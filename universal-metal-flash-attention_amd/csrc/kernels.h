@@ -27,6 +27,20 @@ hipError_t launch_bwd(const BwdParams& p, hipStream_t stream, const char** name)
 bool bwd_16_supported(const BwdParams& p);
 hipError_t launch_bwd_16(const BwdParams& p, hipStream_t stream, const char** name);
 
+// Neighbours of the attention path (fa_aux.hip): rotary rotation and group-wise Hadamard transform.
+struct RopeParams {
+    const void* src;
+    void* dst;
+    const float* cos_table;
+    const float* sin_table;
+    int64_t src_batch_stride, src_head_stride, src_seq_stride;  // elements; head_dim contiguous
+    int64_t table_batch_stride;                                  // 0: one [S,D] table for every batch
+    uint32_t B, H, S, D;
+    int negate_sin;
+};
+hipError_t launch_rope(const RopeParams& p, int prec, hipStream_t stream);
+hipError_t launch_hadamard(void* data, uint32_t block_size, uint32_t num_blocks, int prec, hipStream_t stream);
+
 // Runtime-quantised path (fa_quant.hip): fused symmetric quantiser for Q, K, V + int8-QK^T forward.
 struct QuantViews {
     const int8_t* q8;       // [B*H*Sq][dpq] int8 (rows zero-padded to dpq)

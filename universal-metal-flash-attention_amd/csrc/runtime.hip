@@ -513,10 +513,47 @@ int32_t mfa_attention_backward_kv_quantized_ex(mfa_context_t, mfa_buffer_t, mfa_
                                                bool, bool, bool, mfa_buffer_t, mfa_buffer_t, mfa_buffer_t,
                                                mfa_buffer_t, mfa_buffer_t, mfa_buffer_t, uint32_t, uint32_t, uint32_t,
                                                uint32_t) { NOT_BUILT; }
-int mfa_rope_rotate_encode_mtl(void*, void*, void*, int64_t, int64_t, int64_t, int64_t, void*, int64_t, void*,
-                               int64_t, void*, int64_t, int64_t, bool, uint32_t, uint32_t, uint32_t, uint32_t,
-                               const char*) { NOT_BUILT; }
-int32_t mfa_hadamard_rotate(mfa_buffer_t, uint32_t, uint32_t) { NOT_BUILT; }
+// In-stream rotary rotation (MFABridge.swift:2286-2375): never commits, never waits.
+int mfa_rope_rotate_encode_mtl(void* context, void* command_buffer, void* src_buffer, int64_t src_offset,
+                               int64_t src_batch_stride, int64_t src_head_stride, int64_t src_seq_stride,
+                               void* dst_buffer, int64_t dst_offset, void* cos_buffer, int64_t cos_offset,
+                               void* sin_buffer, int64_t sin_offset, int64_t table_batch_stride, bool negate_sin,
+                               uint32_t batch_size, uint32_t num_heads, uint32_t seq_len, uint32_t head_dim,
+                               const char* precision) {
+    if (!as_ctx(context) || !src_buffer || !dst_buffer || !cos_buffer || !sin_buffer) return MFA_ERROR_INVALID_ARGS;
+    if (src_offset < 0 || dst_offset < 0 || cos_offset < 0 || sin_offset < 0 || (head_dim & 1)) return MFA_ERROR_INVALID_ARGS;
+    RopeParams p;
+    memset(&p, 0, sizeof(p));
+    p.src = (const char*)src_buffer + src_offset;
+    p.dst = (char*)dst_buffer + dst_offset;
+    p.cos_table = (const float*)((const char*)cos_buffer + cos_offset);
+    p.sin_table = (const float*)((const char*)sin_buffer + sin_offset);
+    p.src_batch_stride = src_batch_stride; p.src_head_stride = src_head_stride; p.src_seq_stride = src_seq_stride;
+    p.table_batch_stride = table_batch_stride;
+    p.B = batch_size; p.H = num_heads; p.S = seq_len; p.D = head_dim;
+    p.negate_sin = negate_sin ? 1 : 0;
+    const hipError_t e = launch_rope(p, dense_prec(parse_precision(precision)), (hipStream_t)command_buffer);
+    return e == hipSuccess ? MFA_SUCCESS : e == hipErrorInvalidValue ? MFA_ERROR_INVALID_ARGS : MFA_ERROR_EXECUTION_FAILED;
+}
+
+// Group-wise Hadamard rotation, in place, synchronous (MFABridge.swift:3433-3459).  The ABI carries no element
+// type: it is inferred from the buffer size (4 bytes per element -> fp32, 2 -> fp16).
+int32_t mfa_hadamard_rotate(mfa_buffer_t data, uint32_t block_size, uint32_t num_blocks) {
+    Buffer* b = as_buf(data);
+    if (!b || block_size == 0 || num_blocks == 0) return MFA_ERROR_INVALID_ARGS;
+    std::lock_guard<std::mutex> lock(g_ctx_mu);
+    if (!g_ctx) return MFA_ERROR_INVALID_ARGS;  // the reference uses the global context (MFABridge.swift:3445)
+    const size_t n = (size_t)block_size * num_blocks;
+    int prec = P_FP32;
+    if (b->bytes == n * 2) prec = P_FP16;
+    else if (b->bytes != 0 && b->bytes < n * 4) return MFA_ERROR_INVALID_ARGS;
+    hipStream_t stream = nullptr;
+    if (b->upload(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+    const hipError_t e = launch_hadamard(b->dev, block_size, num_blocks, prec, stream);
+    if (e != hipSuccess) return e == hipErrorInvalidValue ? MFA_ERROR_INVALID_ARGS : MFA_ERROR_EXECUTION_FAILED;
+    if (b->download(stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+    return MFA_SUCCESS;
+}
 mfa_error_t mfa_sparse_indexer_scores(mfa_context_t, mfa_buffer_t, mfa_buffer_t, uint32_t, uint32_t, uint32_t,
                                       uint32_t, uint16_t, float, mfa_buffer_t, mfa_buffer_t*) { NOT_BUILT; }
 mfa_error_t mfa_mla_create_context(mfa_mla_context_t* context) {

@@ -187,3 +187,45 @@ def bench_int8(steps: int = 20, warmup: int = 3):
                      "int8_TOPs": round(flops / (t8[len(t8) // 2] * 1e-3) / 1e12, 1), "fp32_out": True}
         del q, k, v, out
     return res
+
+
+def rope_rotate(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, *, negate_sin: bool = False) -> torch.Tensor:
+    """Interleaved-pair rotary rotation in-stream (mfa_rope_rotate_encode_mtl, MFABridge.swift:2286-2375).
+    x [B,H,S,D] with a contiguous last dim; cos/sin fp32 [S,D] (shared) or [B,S,D], pair-duplicated.
+    Returns a dense [B,H,S,D] tensor of x's dtype.  negate_sin=True is the inverse rotation (backward of Q/K)."""
+    B, H, S, D = x.shape
+    assert x.is_cuda and x.stride(-1) == 1 and cos.dtype == torch.float32 and sin.dtype == torch.float32
+    cos, sin = cos.contiguous(), sin.contiguous()
+    tb = S * D if cos.dim() == 3 else 0
+    out = torch.empty((B, H, S, D), dtype=x.dtype, device=x.device)
+    lib = _lib
+    lib.mfa_rope_rotate_encode_mtl.restype = ctypes.c_int
+    lib.mfa_rope_rotate_encode_mtl.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                               ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
+                                               ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                               ctypes.c_int64, ctypes.c_int64, ctypes.c_bool, ctypes.c_uint32,
+                                               ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_char_p]
+    stream = torch.cuda.current_stream(x.device).cuda_stream
+    _check_error(lib.mfa_rope_rotate_encode_mtl(context(), ctypes.c_void_p(stream), ctypes.c_void_p(x.data_ptr()), 0,
+                                                x.stride(0), x.stride(1), x.stride(2), ctypes.c_void_p(out.data_ptr()), 0,
+                                                ctypes.c_void_p(cos.data_ptr()), 0, ctypes.c_void_p(sin.data_ptr()), 0,
+                                                tb, bool(negate_sin), B, H, S, D, _PREC_NAME[x.dtype]))
+    return out
+
+
+def hadamard_rotate(t: torch.Tensor, block_size: int) -> torch.Tensor:
+    """In-place group-wise Hadamard rotation of a contiguous fp32 / fp16 tensor (reference: hadamard_rotate_inplace,
+    metal_sdpa_backend.cpp:3400-3418).  Applying it twice is the identity."""
+    assert t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.float16)
+    if t.numel() % block_size:
+        raise RuntimeError("Tensor size not divisible by block_size")
+    _lib.mfa_hadamard_rotate.restype = ctypes.c_int32
+    _lib.mfa_hadamard_rotate.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32]
+    context()
+    torch.cuda.current_stream(t.device).synchronize()
+    buf = _DevBuf(t)
+    try:
+        _check_error(_lib.mfa_hadamard_rotate(buf.handle, block_size, t.numel() // block_size))
+    finally:
+        buf.close()
+    return t
