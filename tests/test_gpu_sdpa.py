@@ -122,3 +122,49 @@ def test_functional_patch_flux_style():
         out = F.scaled_dot_product_attention(q, k, v)
     assert umfa_torch.last_kernel() == "fa_fwd16<bf16,128>"
     assert (out.float().cpu() - ref64(q, k, v)).abs().max() < 3e-2  # test_integration_flux.py:93-95 uses 0.1
+
+
+def _rope_tables(S, D, B=None):
+    g = torch.Generator().manual_seed(5)
+    ang = torch.rand((S, D // 2) if B is None else (B, S, D // 2), generator=g) * 6.283
+    return ang.cos().repeat_interleave(2, -1).cuda(), ang.sin().repeat_interleave(2, -1).cuda()
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_rope_sdpa_matches_eager(dt):
+    import umfa_torch
+    from umfa_torch import sdpa
+    torch.manual_seed(6)
+    B, H, S, D = 2, 4, 192, 64
+    q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=dt) for _ in range(3))
+    for batched in (False, True):
+        cos, sin = _rope_tables(S, D, B if batched else None)
+        out = umfa_torch.rope_scaled_dot_product_attention(q, k, v, cos, sin, is_causal=True)
+        ref = ref64(sdpa.apply_rope_eager_bhsd(q.float(), cos, sin), sdpa.apply_rope_eager_bhsd(k.float(), cos, sin), v,
+                    is_causal=True)
+        assert (out.float().cpu() - ref).abs().max() < (2e-5 if dt == torch.float32 else 3e-2)
+    assert umfa_torch.get_dispatch_stats()["rope_instream"] == 2
+
+
+def test_rope_sdpa_autograd():
+    import umfa_torch
+    from umfa_torch import sdpa
+    torch.manual_seed(7)
+    B, H, S, D = 1, 2, 96, 64
+    q, k, v = (torch.randn(B, H, S, D, device="cuda", requires_grad=True) for _ in range(3))
+    cos, sin = _rope_tables(S, D)
+    do = torch.randn(B, H, S, D, device="cuda")
+    umfa_torch.rope_scaled_dot_product_attention(q, k, v, cos, sin).backward(do)
+    got = [t.grad.clone() for t in (q, k, v)]
+    q2, k2, v2 = (t.detach().double().requires_grad_(True) for t in (q, k, v))
+    cb, sb = cos.double().unsqueeze(0).unsqueeze(0), sin.double().unsqueeze(0).unsqueeze(0)
+
+    def rope64(x):
+        pairs = x.reshape(*x.shape[:-1], D // 2, 2)
+        rot = torch.stack((-pairs[..., 1], pairs[..., 0]), -1).reshape(x.shape)
+        return x * cb + rot * sb
+    sdpa._native_sdpa(rope64(q2), rope64(k2), v2).backward(do.double())
+    for g, r in zip(got, (q2.grad, k2.grad, v2.grad)):
+        assert (g.double() - r).abs().max() < 2e-4 * max(1.0, float(r.abs().max()))
+    s = umfa_torch.get_dispatch_stats()
+    assert s["rope_autograd"] == 1

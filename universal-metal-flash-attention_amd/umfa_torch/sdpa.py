@@ -260,3 +260,99 @@ def use_umfa_sdpa():
     finally:
         if not was:
             unregister_backend()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# RoPE + SDPA (MetalSDPABackend::rope_scaled_dot_product_attention, metal_sdpa_backend.cpp:1472-1641; autograd
+# MetalRopeFlashAttentionFn :2883-3133): rotate Q and K in-stream with the rotary kernel, then the flash forward;
+# backward = flash backward followed by the INVERSE rotation (negate_sin) of dQ and dK.
+def apply_rope_eager_bhsd(x, cos_t, sin_t):
+    """Eager interleaved-pair RoPE in fp32 (the reference's fallback / spec, :1451-1468)."""
+    cos_b = (cos_t.unsqueeze(0) if cos_t.dim() == 2 else cos_t).unsqueeze(1)
+    sin_b = (sin_t.unsqueeze(0) if sin_t.dim() == 2 else sin_t).unsqueeze(1)
+    xf = x.float()
+    pairs = xf.reshape(*xf.shape[:-1], xf.shape[-1] // 2, 2)
+    rotated = torch.stack((-pairs[..., 1], pairs[..., 0]), -1).reshape(xf.shape)
+    S = x.shape[2]
+    return (xf * cos_b[..., :S, :] + rotated * sin_b[..., :S, :]).to(x.dtype)
+
+
+class _RopeFlashAttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, cos_t, sin_t, causal: bool, scale: float):
+        q_rot = ops.rope_rotate(q, cos_t, sin_t)
+        k_rot = ops.rope_rotate(k, cos_t, sin_t)
+        v = v.contiguous()
+        o32, lse = ops.attention_forward(q_rot, k_rot, v, scale=scale, causal=causal, out_dtype=torch.float32,
+                                         return_lse=True)
+        ctx.save_for_backward(q_rot, k_rot, v, o32, lse, cos_t, sin_t)
+        ctx.causal, ctx.scale = causal, scale
+        return o32.to(q.dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        q_rot, k_rot, v, o32, lse, cos_t, sin_t = ctx.saved_tensors
+        B, H, Sq, D = q_rot.shape
+        Skv = k_rot.shape[2]
+        dout = dout.to(q_rot.dtype).contiguous()
+        dq = torch.empty((B, H, Sq, D), dtype=torch.float32, device=q_rot.device)
+        dk = torch.empty((B, H, Skv, D), dtype=torch.float32, device=q_rot.device)
+        dv = torch.empty_like(dk)
+        dvec = torch.empty((B * H * Sq,), dtype=torch.float32, device=q_rot.device)
+        _sync_for_blocking_abi(q_rot)
+        bufs = _dev_bufs(dout, q_rot, k_rot, v, o32, lse, dq, dk, dv, dvec)
+        try:
+            prec = ops._PREC[q_rot.dtype]
+            _check_error(_lib.mfa_attention_backward(ops.context(), *(b.handle for b in bufs), B, Sq, Skv, H, D,
+                                                     float(ctx.scale), bool(ctx.causal), prec, prec,
+                                                     False, False, False, False))
+        finally:
+            for b in bufs:
+                b.close()
+        # RoPE is orthonormal: the gradient w.r.t. the un-rotated tensor is the inverse rotation of the gradient
+        dq = ops.rope_rotate(dq, cos_t, sin_t, negate_sin=True)
+        dk = ops.rope_rotate(dk, cos_t, sin_t, negate_sin=True)
+        return dq.to(q_rot.dtype), dk.to(q_rot.dtype), dv.to(q_rot.dtype), None, None, None, None
+
+
+def rope_scaled_dot_product_attention(query, key, value, rope_cos, rope_sin, attn_mask=None, is_causal: bool = False,
+                                      scale: Optional[float] = None):
+    def eager():
+        cos_f, sin_f = rope_cos.to(query.device, torch.float32), rope_sin.to(query.device, torch.float32)
+        return scaled_dot_product_attention(apply_rope_eager_bhsd(query, cos_f, sin_f),
+                                            apply_rope_eager_bhsd(key, cos_f, sin_f), value, attn_mask, 0.0,
+                                            is_causal, scale, True)
+
+    needs_grad = torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or value.requires_grad)
+    ok = (query.is_cuda and key.is_cuda and value.is_cuda and query.dim() == 4 and key.dim() == 4 and value.dim() == 4
+          and query.dtype in _SUPPORTED and key.dtype == query.dtype and value.dtype == query.dtype)
+    if not ok:
+        return eager()
+    B, Hq, Sq, D = query.shape
+    Hkv, Skv = key.shape[1], key.shape[2]
+    if (D % 2 or D > 256 or key.shape[0] != B or value.shape[:3] != key.shape[:3] or key.shape[3] != D
+            or value.shape[3] != D or (Hq != Hkv and (Hkv == 0 or Hq % Hkv)) or Sq != Skv):
+        return eager()
+    cos_t, sin_t = rope_cos, rope_sin
+    if cos_t.dim() == 3 and cos_t.shape[0] == 1:
+        cos_t, sin_t = cos_t.squeeze(0), sin_t.squeeze(0)
+    cos_t = cos_t.to(query.device, torch.float32).contiguous()
+    sin_t = sin_t.to(query.device, torch.float32).contiguous()
+    if cos_t.shape != sin_t.shape or cos_t.dim() not in (2, 3) or cos_t.shape[-1] != D or cos_t.shape[-2] != Sq:
+        return eager()  # tables longer than Sq are sliced by the eager path only
+    if cos_t.dim() == 3 and cos_t.shape[0] != B:
+        return eager()
+    sm_scale = float(scale) if scale is not None else float(D) ** -0.5
+    if needs_grad:
+        if attn_mask is not None or Hq != Hkv or D > 128:
+            return eager()
+        _bump("total")
+        _bump("rope_autograd")
+        _bump("rope_instream")
+        return _RopeFlashAttentionFn.apply(query, key, value, cos_t, sin_t, bool(is_causal), sm_scale)
+    q_src = query if query.stride(-1) == 1 else query.contiguous()
+    k_src = key if key.stride(-1) == 1 else key.contiguous()
+    q_rot = ops.rope_rotate(q_src, cos_t, sin_t)
+    k_rot = ops.rope_rotate(k_src, cos_t, sin_t)
+    _bump("rope_instream")
+    return scaled_dot_product_attention(q_rot, k_rot, value, attn_mask, 0.0, is_causal, sm_scale, True)
