@@ -1,0 +1,113 @@
+"""GPU parity of the 64-rows-per-wave persistent forward (fa_fwd16_w64, head_dim 128, no mask, non-causal,
+Sq % 256 == 0, Skv % 64 == 0) against the CPU oracle, through the in-stream C ABI.  The shapes are chosen to
+cover: one-tile and odd/even tile counts (the two score sets swap roles), items cut into many parts by the
+slice boundaries (small grids: every workgroup gets one tile), whole items, the mix of both (FLUX), strided
+inputs, fp16, fp32 and 16-bit outputs, LSE, run-to-run bitwise determinism and the deferred-max rescale."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _oracle():
+    from oracle import oracle
+    return oracle
+
+
+def bits(t):
+    return t.cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def npy(t):
+    return bits(t) if t.dtype == torch.bfloat16 else t.cpu().contiguous().numpy()
+
+
+def rel_err(a, ref):
+    return float(np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+TOL = {torch.bfloat16: 6e-3, torch.float16: 1.5e-3}
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 256, 64), (1, 2, 256, 128), (1, 1, 256, 192), (2, 3, 512, 256), (1, 2, 256, 1024),
+                                   (1, 5, 768, 448)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_w64_small_shapes_vs_oracle(shape, dt):
+    import umfa_torch
+    B, H, Sq, Skv = shape
+    torch.manual_seed(Sq + Skv)
+    q = torch.randn(B, H, Sq, 128, device="cuda", dtype=dt)
+    k = torch.randn(B, H, Skv, 128, device="cuda", dtype=dt)
+    v = torch.randn(B, H, Skv, 128, device="cuda", dtype=dt)
+    o, lse = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32, return_lse=True)
+    assert umfa_torch.last_kernel().startswith("fa_fwd16_w64"), umfa_torch.last_kernel()
+    ref, ref_lse = _oracle().sdpa_forward(npy(q), npy(k), npy(v), return_lse=True)
+    assert rel_err(o.cpu().numpy(), ref) < TOL[dt]
+    assert np.abs(lse.cpu().numpy().reshape(ref_lse.shape) - ref_lse).max() < 2e-2
+    # 16-bit epilogue = the fp32 result rounded once (half an ulp of the 16-bit type)
+    o16 = umfa_torch.attention_forward(q, k, v)
+    assert o16.dtype == dt
+    assert (o16.float() - o).abs().max() <= (2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11) * o.abs().max() * 1.01
+    # bitwise reproducible, including the index-order fold of split items
+    assert torch.equal(o, umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32))
+
+
+def test_w64_flux_shape_matches_oracle_rows_and_is_deterministic():
+    import umfa_torch
+    torch.manual_seed(0)
+    B, H, S, D = 1, 24, 4096, 128
+    q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    o, lse = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32, return_lse=True)
+    assert umfa_torch.last_kernel() == "fa_fwd16_w64<bf16,128>"
+    assert torch.isfinite(o).all()
+    assert torch.equal(o, umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32))
+    orc = _oracle()
+    # heads 0 (whole items), 1 and 2 (items cut by a slice boundary at this shape: 1.5 items per workgroup), 23
+    for head in (0, 1, 2, 13, 23):
+        kk, vv = bits(k[0:1, head:head + 1]), bits(v[0:1, head:head + 1])
+        for r in (0, 255, 256, 300, 511, 512, 1000, 2047, 2048, 3333, 4095):
+            ref, rl = orc.sdpa_forward(bits(q[0:1, head:head + 1, r:r + 1]), kk, vv, return_lse=True)
+            assert rel_err(o[0, head, r].cpu().numpy(), ref[0, 0, 0]) < 6e-3, (head, r)
+            assert abs(float(lse[head * S + r]) - float(rl[0, 0, 0])) < 2e-2
+    # against the 32-rows-per-wave kernel on the same inputs (different tiling, same arithmetic rules)
+    ref16 = torch.nn.functional.scaled_dot_product_attention(q.float(), k.float(), v.float())
+    assert rel_err(o.cpu().numpy(), ref16.cpu().numpy()) < 6e-3
+
+
+def test_w64_strided_inputs_and_cross_attention():
+    import umfa_torch
+    torch.manual_seed(3)
+    B, H, Sq, Skv, D = 2, 4, 512, 320, 128
+    qkv = torch.randn(B, Sq, 3, H, D, device="cuda", dtype=torch.bfloat16)  # packed projection layout
+    q = qkv[:, :, 0].permute(0, 2, 1, 3)
+    kfull = torch.randn(B, Skv, H, 2 * D, device="cuda", dtype=torch.bfloat16)
+    k = kfull[..., :D].permute(0, 2, 1, 3)
+    v = kfull[..., D:].permute(0, 2, 1, 3)
+    o = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32, scale=0.05)
+    assert umfa_torch.last_kernel().startswith("fa_fwd16_w64")
+    ref = _oracle().sdpa_forward(bits(q), bits(k), bits(v), scale=0.05)
+    assert rel_err(o.cpu().numpy(), ref) < 6e-3
+
+
+def test_w64_deferred_max_rescale_paths():
+    """Scores that keep rising along the key axis force the reference max to move many times (every rise of more
+    than 2^6 triggers the O rescale); scores that fall leave it untouched; both must match the oracle."""
+    import umfa_torch
+    torch.manual_seed(4)
+    B, H, Sq, Skv, D = 1, 2, 256, 1024, 128
+    q = torch.randn(B, H, Sq, D, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn(B, H, Skv, D, device="cuda", dtype=torch.bfloat16)
+    base = torch.randn(B, H, Skv, D, device="cuda")
+    ramp = torch.linspace(0.0, 1.0, Skv, device="cuda").view(1, 1, Skv, 1)
+    # a common direction whose weight grows with the key index: q.k grows by ~40 natural-log units over the row
+    direction = q.float().mean(dim=2, keepdim=True)
+    direction = direction / direction.norm(dim=-1, keepdim=True)
+    for sign in (+1.0, -1.0):
+        k = (base * 0.3 + sign * ramp * 60.0 * direction * 11.3).to(torch.bfloat16)
+        o, lse = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32, return_lse=True)
+        assert umfa_torch.last_kernel().startswith("fa_fwd16_w64")
+        ref, rl = _oracle().sdpa_forward(bits(q), bits(k), bits(v), return_lse=True)
+        assert np.isfinite(o.cpu().numpy()).all()
+        assert rel_err(o.cpu().numpy(), ref) < 8e-3, sign
+        assert np.abs(lse.cpu().numpy().reshape(rl.shape) - rl).max() < 5e-2

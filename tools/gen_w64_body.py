@@ -1,0 +1,298 @@
+#!/usr/bin/env python3
+"""Generate csrc/fa_fwd16_w64_body.inc: the hand-placed instruction stream of one key/value-tile iteration of the
+64-rows-per-wave forward kernel (fa_fwd16_w64.hip).
+
+Why a generator: every MFMA is an inline-asm statement whose operand classes pin O^T and Q^T to accumulator registers
+("a") and the scores to arch VGPRs ("v"), and the VALU / LDS work of the online softmax is placed BETWEEN those
+statements in a fixed order (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost': an MFMA
+32x32x16 holds the SIMD's vector issue for 8 of its 32 cycles, so ~24 cycles of other issue fit in each gap).
+The placement is computed here (earliest-deadline-first under a per-gap cycle budget) and written out as plain C++.
+
+One iteration i (tile = 64 keys, wave = 64 query rows = 2 q-blocks):
+  gaps  0..31  S_new = K(i) Q^T           (32 MFMA, kb-major so K(kb=0) registers free up at gap 16)
+  gaps 32..63  O^T += V(i-1)^T P(i-1)^T   (32 MFMA, 16-key-step-major)
+  fillers: exp/sum/pack of S_old -> P(i-1); transposed V(i-1) fragment reads; K(i) fragment reads a few gaps ahead
+           of their MFMA (the first NPRE are issued by the includer right after the previous tile's barrier);
+           row max of S_new, deferred-max decision, e = s*c - m in place.
+Sections in the output, selected by W64_PART: 0 = first tile of a segment (no S_old), 1 / 2 = steady state (odd /
+even tile: the two score sets swap roles), 3 / 4 = drain (no S_new).  The includer defines W64_VOFF, W64_KOFF,
+W64_MFMA, W64_CVT and the variables the statements name (kf, vf, oacc, l4, mx, nm, c2).
+"""
+import sys
+from pathlib import Path
+
+BUDGET = 24          # issue cycles available beside one MFMA
+COST = {"NOP": 32, "EXP": 8, "ADD": 4, "CVT": 4, "VREAD": 8, "KREAD": 4, "MAX": 4, "DEC": 44, "FMA": 4}
+
+NPRE = 3  # K fragments (kb=0, ks<NPRE) read before the iteration starts
+
+
+# ---- register map.  The kernel is compiled with amdgpu_num_vgpr(128), which on gfx950 confines the COMPILER to
+# v[0:127] + a[0:127]; the upper halves are ours and are addressed by literal number in the asm text:
+#   score tile (kb, qb) of set A at v[128 + 16 t : +15], of set B at v[192 + 16 t : +15], t = 2 kb + qb; the packed
+#   P fragment of 16-key step `st` overwrites the first 4 registers of the matching 8-register half of its tile
+#   (in-place compaction by v_cvt_pk);  O^T block (qb, db) at a[128 + 16 (4 qb + db) : +15].
+# The Q^T fragments are compiler values constrained to the accumulator class ("a"): 64 of the compiler's a[0:127].
+S_BASE, O_BASE = 128, 128
+
+
+def base(setname, kb, qb):
+    return S_BASE + (0 if setname == "a" else 64) + 16 * (2 * kb + qb)
+
+
+def tup(setname, kb, qb):
+    b = base(setname, kb, qb)
+    return f"v[{b}:{b + 15}]"
+
+
+def oreg(qb, db):
+    r = O_BASE + 16 * (4 * qb + db)
+    return f"a[{r}:{r + 15}]"
+
+
+class Roles:
+    def __init__(self, new, old):
+        self.new, self.old = new, old
+
+
+def qk_mfma(R, kb, ks, qb):
+    t = tup(R.new, kb, qb)
+    c = "0" if ks == 0 else t
+    return f'asm volatile(W64_MFMA " {t}, %0, %1, {c}" :: "v"(kf[{kb}][{ks}]), "a"(qf[{qb}][{ks}]));'
+
+
+def pv_mfma(R, st, db, qb):
+    b = base(R.old, st >> 1, qb) + 8 * (st & 1)
+    o = oreg(qb, db)
+    return f'asm volatile(W64_MFMA " {o}, %0, v[{b}:{b + 3}], {o}" :: "v"(vf[{st}][{db}]));'
+
+
+def op_text(R, op):
+    kind = op[0]
+    if kind == "EXP":
+        _, kb, qb, r = op
+        v = base(R.old, kb, qb) + r
+        return f'asm volatile("v_exp_f32 v{v}, v{v}");'
+    if kind == "ADD":
+        _, kb, qb, r = op
+        v = base(R.old, kb, qb) + r
+        return f'asm volatile("v_add_f32 %0, %0, v{v}" : "+v"(l4[{qb}][{r & 3}]));'
+    if kind == "CVT":
+        _, kb, qb, r = op
+        b = base(R.old, kb, qb)
+        d = b + 8 * (r >> 3) + ((r & 7) >> 1)
+        return f'asm volatile(W64_CVT " v{d}, v{b + r}, v{b + r + 1}");'
+    if kind == "VREAD":
+        _, st, db = op
+        return f"vf[{st}][{db}] = v_frag(W64_VOFF, {db}, {st});"
+    if kind == "KREAD":
+        _, kb, ks = op
+        return f"kf[{kb}][{ks}] = k_frag(W64_KOFF + {kb * 8192}, {ks});"
+    if kind == "MAX":
+        _, kb, qb, r, first = op
+        v = base(R.new, kb, qb) + r
+        if first:
+            return f'asm volatile("v_max_f32 %0, v{v}, v{v + 1}" : "=v"(mx[{qb}]));'
+        return f'asm volatile("v_max3_f32 %0, %0, v{v}, v{v + 1}" : "+v"(mx[{qb}]));'
+    if kind == "DEC":
+        return "W64_DECIDE();"
+    if kind == "NOP":
+        return 'asm volatile("s_nop 15\\n\\ts_nop 15");  // MFMA result -> VALU read distance when no MFMA follows'
+    if kind == "FMA":
+        _, kb, qb, r = op
+        v = base(R.new, kb, qb) + r
+        return f'asm volatile("v_fma_f32 v{v}, v{v}, %0, %1" :: "s"(c2), "v"(nm[{qb}]));'
+    raise ValueError(kind)
+
+
+def exp_stream_iter():
+    ops = []
+    pairs = [(kb, qb, r) for kb in (0, 1) for half in (0, 1) for qb in (0, 1) for r in range(8 * half, 8 * half + 8, 2)]
+    prev = None
+    for cur in pairs + [None]:
+        if cur is not None:
+            kb, qb, r = cur
+            dl = 32 + 8 * (2 * kb + (r >> 3)) - 2
+            ops.append((("EXP", kb, qb, r), 0, dl))
+            ops.append((("EXP", kb, qb, r + 1), 0, dl))
+        if prev is not None:
+            kb, qb, r = prev
+            dl = 32 + 8 * (2 * kb + (r >> 3)) - 2
+            ops.append((("ADD", kb, qb, r), 0, dl))
+            ops.append((("ADD", kb, qb, r + 1), 0, dl))
+            ops.append((("CVT", kb, qb, r), 0, dl))
+        prev = cur
+    return ops
+
+
+def vread_stream():
+    ops = []
+    for st in range(4):
+        for db in range(4):
+            use = 32 + st * 8 + db * 2
+            ops.append((("VREAD", st, db), max(0, use - 8), use - 4))
+    return ops
+
+
+def kread_stream():
+    ops = []
+    for kb in (0, 1):
+        for ks in range(8):
+            if kb == 0 and ks < NPRE:
+                continue
+            use = kb * 16 + ks * 2
+            ops.append((("KREAD", kb, ks), max(0, use - 7), max(0, use - 4)))
+    return ops
+
+
+def start_stream(have_new, mfma_follows=True):
+    """row max of S_new -> decision -> e = s*c - m in place (sequential stream)."""
+    if not have_new:
+        return []
+    ops = []
+    for kb in (0, 1):
+        if kb == 1 and not mfma_follows:
+            ops.append((("NOP",), 32, 63))
+        for qb in (0, 1):
+            for r in range(0, 16, 2):
+                ops.append((("MAX", kb, qb, r, kb == 0 and r == 0), kb * 16 + 14 + qb + 2, 63))
+    ops.append((("DEC",), 34, 63))
+    for kb in (0, 1):
+        for qb in (0, 1):
+            for r in range(16):
+                ops.append((("FMA", kb, qb, r), 36, 63))
+    return ops
+
+
+def schedule(streams, gaps):
+    """EDF under a per-gap budget.  streams: list of [ (op, earliest, deadline) ... ] each consumed in order."""
+    pos = [0] * len(streams)
+    out = [[] for _ in range(gaps)]
+    for g in range(gaps):
+        used = 0
+        while True:
+            best = None
+            for si, s in enumerate(streams):
+                if pos[si] >= len(s):
+                    continue
+                op, earliest, deadline = s[pos[si]]
+                if earliest > g:
+                    continue
+                remaining = sum(COST[o[0][0]] for o in s[pos[si]:])
+                # how far this stream is behind an even spread up to its last deadline
+                last_dl = min(gaps - 1, max(d for _, _, d in s[pos[si]:]))
+                need_rate = remaining / max(1, (last_dl - g + 1))
+                forced = deadline <= g
+                key = (0 if forced else 1, -need_rate)
+                if best is None or key < best[0]:
+                    best = (key, si, forced)
+            if best is None:
+                break
+            _, si, forced = best
+            op, earliest, deadline = streams[si][pos[si]]
+            c = COST[op[0]]
+            if not forced and used + c > BUDGET and used > 0:
+                break
+            if not forced and used >= BUDGET:
+                break
+            out[g].append(op)
+            used += c
+            pos[si] += 1
+    for si, s in enumerate(streams):
+        assert pos[si] == len(s), f"stream {si} not fully placed ({pos[si]}/{len(s)})"
+    return out
+
+
+def emit_part(lines, R, have_new, have_old):
+    mf = []
+    if have_new:
+        for kb in (0, 1):
+            for ks in range(8):
+                for qb in (0, 1):
+                    mf.append(qk_mfma(R, kb, ks, qb))
+    else:
+        mf += [None] * 32
+    if have_old:
+        for st in range(4):
+            for db in range(4):
+                for qb in (0, 1):
+                    mf.append(pv_mfma(R, st, db, qb))
+    else:
+        mf += [None] * 32
+    streams = []
+    if have_old:
+        streams.append(exp_stream_iter())
+        streams.append(vread_stream())
+    if have_new:
+        streams.append(start_stream(True, have_old))
+        streams.append(kread_stream())
+    placed = schedule(streams, 64)
+    cyc = 0
+    for g in range(64):
+        if mf[g] is not None:
+            lines.append(mf[g])
+        for op in placed[g]:
+            lines.append("    " + op_text(R, op))
+        fill = sum(COST[o[0]] for o in placed[g])
+        cyc += max(32 if mf[g] else 0, (8 if mf[g] else 0) + fill)
+        if mf[g] is not None or placed[g]:
+            lines.append(f"__builtin_amdgcn_sched_barrier(0);  // gap {g}: filler issue {fill} cyc")
+    lines.append(f"// modelled issue time of this part: {cyc} cycles")
+
+
+def emit_helpers(lines):
+    """Helpers that touch the asm-owned O^T registers a[128:255] by literal number."""
+    a = lines.append
+    a("// GENERATED by tools/gen_w64_body.py -- helpers that address the asm-owned O^T registers a[128:255].")
+    a("__device__ __forceinline__ void zero_o() {")
+    a("    asm volatile(" + " ".join(f'"v_accvgpr_write_b32 a{O_BASE + r}, 0\\n\\t"' for r in range(128)) + ' "s_nop 0" ::: "memory", "v255", "a255");')
+    a("}")
+    for qb in (0, 1):
+        b0 = O_BASE + qb * 64
+        a(f"// O^T of q-block {qb} *= alpha (rare path of the deferred max)")
+        a(f"__device__ __forceinline__ void scale_o{qb}(float alpha) {{")
+        a("    float t0, t1, t2, t3;")
+        for r in range(b0, b0 + 64, 4):
+            a(f'    asm volatile("v_accvgpr_read_b32 %0, a{r}\\n\\tv_accvgpr_read_b32 %1, a{r + 1}\\n\\tv_accvgpr_read_b32 %2, a{r + 2}\\n\\t"'
+              f' "v_accvgpr_read_b32 %3, a{r + 3}\\n\\ts_nop 1\\n\\tv_mul_f32 %0, %0, %4\\n\\tv_mul_f32 %1, %1, %4\\n\\tv_mul_f32 %2, %2, %4\\n\\t"'
+              f' "v_mul_f32 %3, %3, %4\\n\\ts_nop 1\\n\\tv_accvgpr_write_b32 a{r}, %0\\n\\tv_accvgpr_write_b32 a{r + 1}, %1\\n\\t"'
+              f' "v_accvgpr_write_b32 a{r + 2}, %2\\n\\tv_accvgpr_write_b32 a{r + 3}, %3"'
+              ' : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(alpha));')
+        a("}")
+        a(f"// 16 registers of O^T block (q-block {qb}, d-block DB) -> floats")
+        a(f"template <int DB> __device__ __forceinline__ void read_o{qb}(float (&o)[16]) {{")
+        for db in range(4):
+            a(f"    if constexpr (DB == {db}) {{")
+            for r in range(0, 16, 4):
+                rr = b0 + 16 * db + r
+                a(f'        asm volatile("v_accvgpr_read_b32 %0, a{rr}\\n\\tv_accvgpr_read_b32 %1, a{rr + 1}\\n\\t"'
+                  f' "v_accvgpr_read_b32 %2, a{rr + 2}\\n\\tv_accvgpr_read_b32 %3, a{rr + 3}"'
+                  f' : "=v"(o[{r}]), "=v"(o[{r + 1}]), "=v"(o[{r + 2}]), "=v"(o[{r + 3}]));')
+            a("    }")
+        a("}")
+
+
+def main():
+    helpers = []
+    emit_helpers(helpers)
+    hp = Path(__file__).resolve().parent.parent / "universal-metal-flash-attention_amd" / "csrc" / "fa_fwd16_w64_regs.inc"
+    hp.write_text("\n".join(helpers) + "\n")
+    out = Path(__file__).resolve().parent.parent / "universal-metal-flash-attention_amd" / "csrc" / "fa_fwd16_w64_body.inc"
+    lines = ["// GENERATED by tools/gen_w64_body.py -- do not edit; see that file for the placement rules.",
+             "#if W64_PART == 0  // first tile of a segment: S -> set A"]
+    emit_part(lines, Roles("a", "b"), True, False)
+    lines.append("#elif W64_PART == 1  // steady state, odd tile: S -> set B, P from set A")
+    emit_part(lines, Roles("b", "a"), True, True)
+    lines.append("#elif W64_PART == 2  // steady state, even tile: S -> set A, P from set B")
+    emit_part(lines, Roles("a", "b"), True, True)
+    lines.append("#elif W64_PART == 3  // drain: P of the last tile (set A), then its PV")
+    emit_part(lines, Roles("b", "a"), False, True)
+    lines.append("#elif W64_PART == 4  // drain, last tile in set B")
+    emit_part(lines, Roles("a", "b"), False, True)
+    lines.append("#endif")
+    out.write_text("\n".join(lines) + "\n")
+    print("wrote", out, len(lines), "lines")
+
+
+if __name__ == "__main__":
+    sys.exit(main())

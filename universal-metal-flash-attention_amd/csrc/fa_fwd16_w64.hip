@@ -1,0 +1,134 @@
+// fa_fwd16_w64.hip -- bf16 / fp16 forward at head_dim 128, "one wave per SIMD" structure (no mask, non-causal,
+// Sq % 256 == 0, Skv % 64 == 0); every other case stays on fa_fwd16 (fa_fwd_16.hip).
+//
+// Replaces the same Metal `attention` forward dispatch as fa_fwd_16.hip (MFABridge.swift:2240-2248, 2525-2541).
+//
+// Why a second structure: in fa_fwd16 a wave owns 32 query rows, so every 16 MFMAs it re-reads a whole K and V tile
+// from LDS and its softmax VALU work runs back to back with its MFMAs (measured: time ~ MFMA + VALU, ~45 % MFMA
+// busy).  Here (cdna_hip_programming.md, "4-wave, one-wave-per-SIMD, persistent structure"):
+//   * workgroup = 4 waves = 256 query rows; a wave owns 64 rows (two 32-row q-blocks) and the whole 512-register
+//     file: O^T (64 x 128 fp32), Q^T and the current K tile's fragments live in accumulator registers that only
+//     inline-asm MFMAs / ds_reads touch; the compiler allocates the arch VGPRs (scores, P, V^T fragments).
+//   * per 64-key tile one pass of 64 MFMAs: S(i) = K(i) Q^T, then O^T += V(i-1)^T P(i-1)^T; the softmax of tile
+//     i-1, the transposed V reads, the K fragment reads of tile i+1 and the row max of tile i are placed in the
+//     issue gaps between those MFMAs by tools/gen_w64_body.py (fa_fwd16_w64_body.inc).
+//   * deferred max (T13): the reference max moves only when a row max exceeds it by > 2^6; O (in AGPRs) is then
+//     rescaled by a rare v_accvgpr_read/mul/write pass after the pending tile's PV.
+//   * K/V tiles arrive by LDS-DMA into 2-slot rings (K three tiles ahead, V one), one barrier per tile.
+//   * persistent grid (one workgroup per CU) over the linearised (item, tile) space: every workgroup gets the
+//     same number of tile steps ("stream-K"), so 384 items on 256 CUs (the FLUX shape) cost 1.5 item-times instead
+//     of 2; an item cut by a slice boundary is folded by the last of its parts to arrive, in index order
+//     (bitwise reproducible), through part_buf.
+#include <cstdlib>
+#include <type_traits>
+
+#include "fa_common.h"
+#include "fa_fwd_16_kernel.h"
+#include "kernels.h"
+
+namespace umfa {
+
+struct W64Params {
+    const void* q;
+    const void* k;
+    const void* v;
+    void* o;
+    float* lse;
+    int64_t qs[3], ks[3], vs[3];  // batch, head, seq strides in elements (head_dim contiguous)
+    uint32_t B, H, Sq, Skv;
+    float scale;
+    uint32_t n_items, T;  // items = B*H*(Sq/256) blocks of 256 query rows; T = Skv/64 key tiles per item
+    float* part_buf;      // [2 * grid slots][wave 4][q-block 2][64 O + m + l][lane 64] fp32
+    uint32_t* part_cnt;   // [n_items] arrival tickets, zero between launches (the folding part resets its own)
+};
+
+// ---- asm-owned accumulator registers: helpers with literal register numbers (generated)
+#include "fa_fwd16_w64_regs.inc"
+
+#define W64_T __bf16
+#define W64_MFMA "v_mfma_f32_32x32x16_bf16"
+#define W64_CVT "v_cvt_pk_bf16_f32"
+#define W64_KERNEL fa_fwd16_w64_bf16
+#include "fa_fwd16_w64_kernel.inc"
+#undef W64_T
+#undef W64_MFMA
+#undef W64_CVT
+#undef W64_KERNEL
+
+#define W64_T _Float16
+#define W64_MFMA "v_mfma_f32_32x32x16_f16"
+#define W64_CVT "v_cvt_pk_f16_f32"
+#define W64_KERNEL fa_fwd16_w64_f16
+#include "fa_fwd16_w64_kernel.inc"
+#undef W64_T
+#undef W64_MFMA
+#undef W64_CVT
+#undef W64_KERNEL
+
+static int w64_cu_count() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+bool fwd_w64_supported(const FwdParams& p) {
+    static const bool off = [] { const char* e = getenv("UMFA_NO_W64"); return e && e[0] == '1'; }();
+    if (off || !fwd_16_supported(p)) return false;
+    if (p.D != 128 || p.causal || p.mask_kind != MK_NONE) return false;
+    if (p.Sq == 0 || p.Sq % 256 || p.Skv == 0 || p.Skv % 64) return false;
+    if (p.out_prec != P_FP32 && p.out_prec != p.in_prec) return false;
+    return true;
+}
+
+static uint32_t w64_grid(const FwdParams& p) {
+    const uint64_t total = (uint64_t)p.B * p.H * (p.Sq / 256) * (p.Skv / 64);
+    const uint32_t cus = (uint32_t)w64_cu_count();
+    return total < cus ? (uint32_t)total : cus;
+}
+
+FwdW64Plan fwd_w64_plan(const FwdParams& p) {
+    FwdW64Plan plan;
+    const uint32_t items = p.B * p.H * (p.Sq / 256);
+    plan.cnt_bytes = ((size_t)items * sizeof(uint32_t) + 255) & ~(size_t)255;
+    plan.buf_bytes = (size_t)2 * w64_grid(p) * (4 * 2 * 66 * 64) * sizeof(float);
+    return plan;
+}
+
+template <typename KFN>
+static hipError_t launch_w64_kernel(KFN kfn, const FwdParams& p, const W64Params& wp, hipStream_t stream) {
+    const uint32_t grid = w64_grid(p);
+    const size_t lds = 65536;
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, stream, wp);
+    return hipGetLastError();
+}
+
+// part_cnt must be zero on entry (the runtime zeroes it when it allocates; the kernel leaves it zero).
+hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cnt, hipStream_t stream, const char** name) {
+    if (!fwd_w64_supported(p) || !part_buf || !part_cnt) return hipErrorNotSupported;
+    W64Params wp;
+    wp.q = p.q; wp.k = p.k; wp.v = p.v; wp.o = p.o; wp.lse = p.lse;
+    for (int i = 0; i < 3; ++i) { wp.qs[i] = p.qs[i]; wp.ks[i] = p.ks[i]; wp.vs[i] = p.vs[i]; }
+    wp.B = p.B; wp.H = p.H; wp.Sq = p.Sq; wp.Skv = p.Skv;
+    wp.scale = p.scale;
+    wp.n_items = p.B * p.H * (p.Sq / 256);
+    wp.T = p.Skv / 64;
+    wp.part_buf = part_buf;
+    wp.part_cnt = part_cnt;
+    if (p.in_prec == P_BF16) {
+        *name = "fa_fwd16_w64<bf16,128>";
+        return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64_bf16<float>, p, wp, stream)
+                                    : launch_w64_kernel(fa_fwd16_w64_bf16<__bf16>, p, wp, stream);
+    }
+    *name = "fa_fwd16_w64<fp16,128>";
+    return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64_f16<float>, p, wp, stream)
+                                : launch_w64_kernel(fa_fwd16_w64_f16<_Float16>, p, wp, stream);
+}
+
+}  // namespace umfa

@@ -21,6 +21,15 @@ struct FwdSplitPlan {
 };
 FwdSplitPlan fwd_16_split_plan(const FwdParams& p);
 
+// 64-rows-per-wave persistent forward (fa_fwd16_w64.hip): head_dim 128, no mask, non-causal, Sq % 256 == 0,
+// Skv % 64 == 0.  Needs a zeroed ticket array (cnt_bytes) and a partials buffer (buf_bytes).
+struct FwdW64Plan {
+    size_t buf_bytes, cnt_bytes;
+};
+bool fwd_w64_supported(const FwdParams& p);
+FwdW64Plan fwd_w64_plan(const FwdParams& p);
+hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cnt, hipStream_t stream, const char** name);
+
 // Backward: D = rowsum(dO o O), then dQ and dK/dV.  launch_bwd: fp32-exact (any input type, head_dim <= 128);
 // launch_bwd_16: bf16 / fp16 MFMA (head_dim 128, dO in the input type, no mask).
 hipError_t launch_bwd(const BwdParams& p, hipStream_t stream, const char** name);

@@ -74,7 +74,14 @@ hipError_t dispatch_forward(Context* ctx, const FwdParams& p, int intermediate_p
     const char* name = "none";
     hipError_t e;
     const bool lowp = p.in_prec != P_FP32 && intermediate_prec != P_FP32;
-    if (lowp && fwd_16_supported(p)) {
+    char* w64 = nullptr;
+    if (lowp && fwd_w64_supported(p)) {
+        const FwdW64Plan plan = fwd_w64_plan(p);
+        w64 = (char*)ctx->ensure_w64(plan.cnt_bytes, plan.buf_bytes);
+    }
+    if (w64) {
+        e = launch_fwd_w64(p, (float*)(w64 + ctx->w64_cnt_bytes), (uint32_t*)w64, stream, &name);
+    } else if (lowp && fwd_16_supported(p)) {
         FwdParams pp = p;
         const FwdSplitPlan plan = fwd_16_split_plan(p);
         if (plan.nsplit > 1) {

@@ -52,6 +52,22 @@ struct Context {
         return split_buf;
     }
 
+    // fa_fwd16_w64: zeroed ticket array (kept zero by the kernel) followed by the partials buffer
+    void* w64_buf = nullptr;
+    size_t w64_cnt_bytes = 0, w64_buf_bytes = 0;
+    void* ensure_w64(size_t cnt_bytes, size_t buf_bytes) {
+        if (w64_buf && cnt_bytes <= w64_cnt_bytes && buf_bytes <= w64_buf_bytes) return w64_buf;
+        if (w64_buf) (void)hipFree(w64_buf);
+        w64_buf = nullptr;
+        const size_t c = cnt_bytes > w64_cnt_bytes ? cnt_bytes : w64_cnt_bytes;
+        const size_t b = buf_bytes > w64_buf_bytes ? buf_bytes : w64_buf_bytes;
+        if (hipMalloc(&w64_buf, c + b) != hipSuccess) { w64_cnt_bytes = w64_buf_bytes = 0; return nullptr; }
+        if (hipMemset(w64_buf, 0, c) != hipSuccess) { (void)hipFree(w64_buf); w64_buf = nullptr; w64_cnt_bytes = w64_buf_bytes = 0; return nullptr; }
+        w64_cnt_bytes = c;
+        w64_buf_bytes = b;
+        return w64_buf;
+    }
+
     void* ensure_workspace(size_t bytes) {
         if (bytes <= workspace_bytes) return workspace;
         if (workspace) (void)hipFree(workspace);
