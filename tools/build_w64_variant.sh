@@ -1,0 +1,19 @@
+#!/bin/bash
+# Build a timing-only variant of libMFAFFI.so with some filler kinds of the w64 stream dropped:
+#   tools/build_w64_variant.sh NAME "EXP,ADD" [extra hipcc flags]   ->  tools/lab_bin/libMFAFFI_NAME.so
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+CS=$ROOT/universal-metal-flash-attention_amd/csrc
+NAME=$1; ABL=$2; shift 2
+TMP=$(mktemp -d)
+mkdir -p $ROOT/tools/lab_bin
+cp $CS/*.hip $CS/*.h $CS/*.inc $TMP/
+mkdir -p $TMP/../../include 2>/dev/null || true
+W64_ABL="$ABL" W64_OUT=$TMP/fa_fwd16_w64_body.inc python3 $ROOT/tools/gen_w64_body.py > /dev/null
+# the generator also rewrites the helper include in-tree; it is identical for every variant
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -fno-slp-vectorize -w "$@" -I$CS -c $TMP/fa_fwd16_w64.hip -o $TMP/fa_fwd16_w64.o
+OBJS=""
+for f in runtime runtime_train fa_fwd_exact fa_fwd_16 fa_bwd fa_bwd_16 fa_quant fa_aux; do OBJS="$OBJS $CS/build/$f.o"; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/tools/lab_bin/libMFAFFI_$NAME.so $OBJS $TMP/fa_fwd16_w64.o
+rm -rf $TMP
+echo built tools/lab_bin/libMFAFFI_$NAME.so

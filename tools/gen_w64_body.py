@@ -18,13 +18,18 @@ Sections in the output, selected by W64_PART: 0 = first tile of a segment (no S_
 even tile: the two score sets swap roles), 3 / 4 = drain (no S_new).  The includer defines W64_VOFF, W64_KOFF,
 W64_MFMA, W64_CVT and the variables the statements name (kf, vf, oacc, l4, mx, nm, c2).
 """
+import os
 import sys
 from pathlib import Path
 
-BUDGET = 24          # issue cycles available beside one MFMA
-COST = {"NOP": 32, "EXP": 8, "ADD": 4, "CVT": 4, "VREAD": 8, "KREAD": 4, "MAX": 4, "DEC": 44, "FMA": 4}
+# timing experiments only (results become wrong): W64_ABL=EXP,ADD,... drops those filler kinds, W64_OUT overrides the
+# output path so a variant library can be built beside the real one
+ABL = set(filter(None, os.environ.get("W64_ABL", "").split(",")))
 
-NPRE = 3  # K fragments (kb=0, ks<NPRE) read before the iteration starts
+BUDGET = 24          # issue cycles available beside one MFMA
+COST = {"DMAK": 8, "DMAV": 8, "NOP": 32, "EXP": 8, "ADD": 4, "CVT": 4, "VREAD": 8, "KREAD": 4, "MAX": 4, "DEC": 44, "FMA": 4}
+
+NPRE = 4  # K fragments (kb=0, ks<NPRE) read before the iteration starts (by the includer, after the barrier)
 
 
 # ---- register map.  The kernel is compiled with amdgpu_num_vgpr(128), which on gfx950 confines the COMPILER to
@@ -91,9 +96,18 @@ def op_text(R, op):
     if kind == "MAX":
         _, kb, qb, r, first = op
         v = base(R.new, kb, qb) + r
+        c = (r >> 1) & 1  # two running maxima per q-block: consecutive ops never depend on each other
         if first:
-            return f'asm volatile("v_max_f32 %0, v{v}, v{v + 1}" : "=v"(mx[{qb}]));'
-        return f'asm volatile("v_max3_f32 %0, %0, v{v}, v{v + 1}" : "+v"(mx[{qb}]));'
+            return f'asm volatile("v_max_f32 %0, v{v}, v{v + 1}" : "=v"(mx[{qb}][{c}]));'
+        return f'asm volatile("v_max3_f32 %0, %0, v{v}, v{v + 1}" : "+v"(mx[{qb}][{c}]));'
+    if kind == "DMAK":
+        _, j = op
+        return (f'asm volatile("s_mov_b32 m0, %0\\n\\ts_nop 0\\n\\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_wave + W64_KDST + {j * 1024}), '
+                f'"v"(kdma[{j}]), "s"(k_srd) : "memory"); kdma[{j}] += k_step;')
+    if kind == "DMAV":
+        _, j = op
+        return (f'asm volatile("s_mov_b32 m0, %0\\n\\ts_nop 0\\n\\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_wave + W64_VDST + {j * 1024}), '
+                f'"v"(vdma[{j}]), "s"(v_srd) : "memory"); vdma[{j}] += v_step;')
     if kind == "DEC":
         return "W64_DECIDE();"
     if kind == "NOP":
@@ -130,7 +144,7 @@ def vread_stream():
     for st in range(4):
         for db in range(4):
             use = 32 + st * 8 + db * 2
-            ops.append((("VREAD", st, db), max(0, use - 8), use - 4))
+            ops.append((("VREAD", st, db), max(0, use - 10), use - 6))
     return ops
 
 
@@ -141,7 +155,17 @@ def kread_stream():
             if kb == 0 and ks < NPRE:
                 continue
             use = kb * 16 + ks * 2
-            ops.append((("KREAD", kb, ks), max(0, use - 7), max(0, use - 4)))
+            ops.append((("KREAD", kb, ks), max(0, use - 12), max(0, use - 8)))
+    return ops
+
+
+def dma_stream():
+    """LDS-DMA of K(i+1) and V(i), issued in the first gaps of tile i (their ring slots were released by the barrier
+    that ended tile i-1) so that the VMEM issue overlaps MFMA execution; waited on at the end of tile i."""
+    ops = []
+    for j in range(4):
+        ops.append((("DMAK", j), 1 + 4 * j, 3 + 4 * j))
+        ops.append((("DMAV", j), 3 + 4 * j, 5 + 4 * j))
     return ops
 
 
@@ -155,7 +179,7 @@ def start_stream(have_new, mfma_follows=True):
             ops.append((("NOP",), 32, 63))
         for qb in (0, 1):
             for r in range(0, 16, 2):
-                ops.append((("MAX", kb, qb, r, kb == 0 and r == 0), kb * 16 + 14 + qb + 2, 63))
+                ops.append((("MAX", kb, qb, r, kb == 0 and r < 4), kb * 16 + 14 + qb + 2, 63))
     ops.append((("DEC",), 34, 63))
     for kb in (0, 1):
         for qb in (0, 1):
@@ -226,13 +250,15 @@ def emit_part(lines, R, have_new, have_old):
     if have_new:
         streams.append(start_stream(True, have_old))
         streams.append(kread_stream())
+        streams.append(dma_stream())
     placed = schedule(streams, 64)
     cyc = 0
     for g in range(64):
         if mf[g] is not None:
             lines.append(mf[g])
         for op in placed[g]:
-            lines.append("    " + op_text(R, op))
+            if op[0] not in ABL:
+                lines.append("    " + op_text(R, op))
         fill = sum(COST[o[0]] for o in placed[g])
         cyc += max(32 if mf[g] else 0, (8 if mf[g] else 0) + fill)
         if mf[g] is not None or placed[g]:
@@ -278,6 +304,8 @@ def main():
     hp = Path(__file__).resolve().parent.parent / "universal-metal-flash-attention_amd" / "csrc" / "fa_fwd16_w64_regs.inc"
     hp.write_text("\n".join(helpers) + "\n")
     out = Path(__file__).resolve().parent.parent / "universal-metal-flash-attention_amd" / "csrc" / "fa_fwd16_w64_body.inc"
+    if os.environ.get("W64_OUT"):
+        out = Path(os.environ["W64_OUT"])
     lines = ["// GENERATED by tools/gen_w64_body.py -- do not edit; see that file for the placement rules.",
              "#if W64_PART == 0  // first tile of a segment: S -> set A"]
     emit_part(lines, Roles("a", "b"), True, False)
