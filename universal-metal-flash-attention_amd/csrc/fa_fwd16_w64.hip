@@ -38,7 +38,7 @@ struct W64Params {
     uint32_t B, H, Sq, Skv;
     float scale;
     uint32_t n_items, T;  // items = B*H*(Sq/256) blocks of 256 query rows; T = Skv/64 key tiles per item
-    float* part_buf;      // [2 * grid slots][wave 4][q-block 2][64 O + m + l][lane 64] fp32
+    float* part_buf;      // [2 * grid slots][wave 4][q-block 2][chunk 17][lane 64] x 16 bytes (see the kernel)
     uint32_t* part_cnt;   // [n_items] arrival tickets, zero between launches (the folding part resets its own)
 };
 
@@ -95,7 +95,7 @@ FwdW64Plan fwd_w64_plan(const FwdParams& p) {
     FwdW64Plan plan;
     const uint32_t items = p.B * p.H * (p.Sq / 256);
     plan.cnt_bytes = ((size_t)items * sizeof(uint32_t) + 255) & ~(size_t)255;
-    plan.buf_bytes = (size_t)2 * w64_grid(p) * (4 * 2 * 66 * 64) * sizeof(float);
+    plan.buf_bytes = (size_t)2 * w64_grid(p) * (4 * 2 * 17 * 1024);
     return plan;
 }
 
