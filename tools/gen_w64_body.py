@@ -26,7 +26,8 @@ from pathlib import Path
 # output path so a variant library can be built beside the real one
 ABL = set(filter(None, os.environ.get("W64_ABL", "").split(",")))
 
-BUDGET = 24          # issue cycles available beside one MFMA
+BUDGET = int(os.environ.get("W64_BUDGET", "24"))   # issue cycles available beside one MFMA
+EARLY_MAX = os.environ.get("W64_EARLY_MAX", "1") == "1"  # row max of key-block 0 during the QK of key-block 1, e = s*c - m spread to the end
 COST = {"DMAK": 8, "DMAV": 8, "NOP": 32, "EXP": 8, "ADD": 4, "CVT": 4, "VREAD": 8, "KREAD": 4, "MAX": 4, "DEC": 44, "FMA": 4}
 
 NPRE = 4  # K fragments (kb=0, ks<NPRE) read before the iteration starts (by the includer, after the barrier)
@@ -170,21 +171,27 @@ def dma_stream():
 
 
 def start_stream(have_new, mfma_follows=True):
-    """row max of S_new -> decision -> e = s*c - m in place (sequential stream)."""
+    """row max of S_new -> decision -> e = s*c - m in place (sequential stream).  Four independent max chains
+    (two per q-block) are interleaved so consecutive ops never depend on each other."""
     if not have_new:
         return []
     ops = []
     for kb in (0, 1):
         if kb == 1 and not mfma_follows:
             ops.append((("NOP",), 32, 63))
-        for qb in (0, 1):
-            for r in range(0, 16, 2):
-                ops.append((("MAX", kb, qb, r, kb == 0 and r < 4), kb * 16 + 14 + qb + 2, 63))
-    ops.append((("DEC",), 34, 63))
+        for r in range(0, 16, 2):
+            for qb in (0, 1):
+                earliest = kb * 16 + 14 + qb + 2
+                deadline = (31 if kb == 0 else 42) if (EARLY_MAX and mfma_follows) else 63
+                ops.append((("MAX", kb, qb, r, kb == 0 and r < 4), earliest, deadline))
+    ops.append((("DEC",), 34, 44 if (EARLY_MAX and mfma_follows) else 63))
+    n = 0
     for kb in (0, 1):
         for qb in (0, 1):
             for r in range(16):
-                ops.append((("FMA", kb, qb, r), 36, 63))
+                deadline = 46 + (n * 18) // 64 if (EARLY_MAX and mfma_follows) else 63
+                ops.append((("FMA", kb, qb, r), 36, deadline))
+                n += 1
     return ops
 
 
