@@ -15,10 +15,10 @@
 //   * deferred max (T13): the reference max moves only when a row max exceeds it by > 2^6; O (in AGPRs) is then
 //     rescaled by a rare v_accvgpr_read/mul/write pass after the pending tile's PV.
 //   * K/V tiles arrive by LDS-DMA into 2-slot rings (K three tiles ahead, V one), one barrier per tile.
-//   * persistent grid (one workgroup per CU) over the linearised (item, tile) space: every workgroup gets the
-//     same number of tile steps ("stream-K"), so 384 items on 256 CUs (the FLUX shape) cost 1.5 item-times instead
-//     of 2; an item cut by a slice boundary is folded by the last of its parts to arrive, in index order
-//     (bitwise reproducible), through part_buf.
+//   * persistent grid (one workgroup per CU): whole rounds of items first (lockstep per XCD, K/V read into its L2
+//     once), then the remaining items are shared "stream-K" style, so 384 items on 256 CUs (the FLUX shape) cost
+//     1.5 item-times instead of 2; an item cut by a slice boundary is folded by the last of its parts to arrive,
+//     in index order (bitwise reproducible), through part_buf.
 #include <cstdlib>
 #include <type_traits>
 
@@ -39,7 +39,7 @@ struct W64Params {
     float scale;
     uint32_t n_items, T;  // items = B*H*(Sq/256) blocks of 256 query rows; T = Skv/64 key tiles per item
     float* part_buf;      // [2 * grid slots][wave 4][q-block 2][chunk 17][lane 64] x 16 bytes (see the kernel)
-    uint32_t* part_cnt;   // [n_items] arrival tickets, zero between launches (the folding part resets its own)
+    uint32_t* part_cnt;   // [n_items % grid] arrival tickets, zero between launches (the folding part resets its own)
 };
 
 // ---- asm-owned accumulator registers: helpers with literal register numbers (generated)
@@ -86,15 +86,16 @@ bool fwd_w64_supported(const FwdParams& p) {
 }
 
 static uint32_t w64_grid(const FwdParams& p) {
-    const uint64_t total = (uint64_t)p.B * p.H * (p.Sq / 256) * (p.Skv / 64);
+    const uint64_t total = (uint64_t)p.B * p.H * (p.Sq / 256) * (p.Skv / 64);  // (item, key tile) steps
     const uint32_t cus = (uint32_t)w64_cu_count();
-    return total < cus ? (uint32_t)total : cus;
+    return total < cus ? (uint32_t)total : cus;  // never more workgroups than steps: every slice is non-empty
 }
 
 FwdW64Plan fwd_w64_plan(const FwdParams& p) {
     FwdW64Plan plan;
     const uint32_t items = p.B * p.H * (p.Sq / 256);
-    plan.cnt_bytes = ((size_t)items * sizeof(uint32_t) + 255) & ~(size_t)255;
+    (void)items;
+    plan.cnt_bytes = ((size_t)w64_grid(p) * sizeof(uint32_t) + 255) & ~(size_t)255;  // < grid shared items
     plan.buf_bytes = (size_t)2 * w64_grid(p) * (4 * 2 * 17 * 1024);
     return plan;
 }
