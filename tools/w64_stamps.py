@@ -13,11 +13,15 @@ q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in
 for it in range(4):
     o, lse = umfa_torch.attention_forward(q, k, v, return_lse=True)
 torch.cuda.synchronize()
-raw = lse.cpu().numpy().view(np.uint64)[: 256 * 4].reshape(256, 4)
+raw = lse.cpu().numpy().view(np.uint64)[: 256 * 8].reshape(256, 8)
 ok = (raw[:, 1] > raw[:, 0]) & (raw[:, 1] - raw[:, 0] < 10**8) & (raw[:, 3] > raw[:, 2]) & (raw[:, 3] - raw[:, 2] < 10**10)
 raw = raw[ok]  # stamps of workgroups whose slot a later LSE store overwrote are dropped
 rt = (raw[:, 1] - raw[:, 0]).astype(np.float64) / 100.0  # us
 ck = (raw[:, 3] - raw[:, 2]).astype(np.float64)
 span = (raw[:, 1].max() - raw[:, 0].min()) / 100.0
+clk = np.median(ck / rt)  # MHz = cycles per us
+seg = raw[:, 4:8].astype(np.float64) / clk
+print("   per-WG us (median): prologue %.1f  main loop %.1f  drain %.1f  epilogue+fold %.1f   (max epilogue %.1f)" % (
+    np.median(seg[:, 0]), np.median(seg[:, 1]), np.median(seg[:, 2]), np.median(seg[:, 3]), seg[:, 3].max()))
 print(f"{umfa_torch.last_kernel()} valid {int(ok.sum())}/256 per-WG time us: min {rt.min():.1f} med {np.median(rt):.1f} max {rt.max():.1f}; span {span:.1f} us; "
       f"clock MHz: min {(ck/rt).min():.0f} med {np.median(ck/rt):.0f} max {(ck/rt).max():.0f}; start skew {(raw[:,0].max()-raw[:,0].min())/100.0:.1f} us")

@@ -103,9 +103,13 @@ FwdW64Plan fwd_w64_plan(const FwdParams& p) {
 template <typename KFN>
 static hipError_t launch_w64_kernel(KFN kfn, const FwdParams& p, const W64Params& wp, hipStream_t stream) {
     const uint32_t grid = w64_grid(p);
-    const size_t lds = 65536;
-    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+    const size_t lds = 65536 + 4 * 32 * (512 + 16);  // K/V rings + per-wave output staging
+    static bool attr_set = false;  // one flag per instantiation of this template
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, stream, wp);
     return hipGetLastError();
 }
