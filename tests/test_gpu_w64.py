@@ -111,3 +111,43 @@ def test_w64_deferred_max_rescale_paths():
         assert np.isfinite(o.cpu().numpy()).all()
         assert rel_err(o.cpu().numpy(), ref) < 8e-3, sign
         assert np.abs(lse.cpu().numpy().reshape(rl.shape) - rl).max() < 5e-2
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 256, 256), (1, 2, 512, 512), (2, 3, 768, 768), (1, 2, 1024, 448), (1, 1, 256, 1024),
+                                   (1, 4, 2048, 2048)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_w64_causal_vs_oracle(shape, dt):
+    """causal (top-left aligned, also Sq != Skv): tiles past the diagonal are skipped, diagonal tiles masked"""
+    import umfa_torch
+    B, H, Sq, Skv = shape
+    torch.manual_seed(Sq * 3 + Skv)
+    q = torch.randn(B, H, Sq, 128, device="cuda", dtype=dt)
+    k = torch.randn(B, H, Skv, 128, device="cuda", dtype=dt)
+    v = torch.randn(B, H, Skv, 128, device="cuda", dtype=dt)
+    o, lse = umfa_torch.attention_forward(q, k, v, causal=True, out_dtype=torch.float32, return_lse=True)
+    assert umfa_torch.last_kernel().startswith("fa_fwd16_w64"), umfa_torch.last_kernel()
+    ref, ref_lse = _oracle().sdpa_forward(npy(q), npy(k), npy(v), causal=True, return_lse=True)
+    assert np.isfinite(o.cpu().numpy()).all()
+    assert rel_err(o.cpu().numpy(), ref) < TOL[dt]
+    assert np.abs(lse.cpu().numpy().reshape(ref_lse.shape) - ref_lse).max() < 2e-2
+    assert torch.equal(o, umfa_torch.attention_forward(q, k, v, causal=True, out_dtype=torch.float32))
+    o16 = umfa_torch.attention_forward(q, k, v, causal=True)
+    assert (o16.float() - o).abs().max() <= (2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11) * o.abs().max() * 1.01
+
+
+def test_w64_causal_flux_shape_rows():
+    import umfa_torch
+    torch.manual_seed(1)
+    B, H, S, D = 1, 24, 4096, 128
+    q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    o = umfa_torch.attention_forward(q, k, v, causal=True, out_dtype=torch.float32)
+    assert umfa_torch.last_kernel() == "fa_fwd16_w64<bf16,128>"
+    assert torch.isfinite(o).all()
+    assert torch.equal(o, umfa_torch.attention_forward(q, k, v, causal=True, out_dtype=torch.float32))
+    orc = _oracle()
+    for head in (0, 7, 23):
+        kk, vv = bits(k[0:1, head:head + 1]), bits(v[0:1, head:head + 1])
+        for r in (0, 1, 63, 64, 255, 256, 1000, 2047, 2048, 4095):
+            ref = orc.sdpa_forward(bits(q[0:1, head:head + 1, r:r + 1]), np.ascontiguousarray(kk[:, :, :r + 1]),
+                                   np.ascontiguousarray(vv[:, :, :r + 1]))
+            assert rel_err(o[0, head, r].cpu().numpy(), ref[0, 0, 0]) < 6e-3, (head, r)

@@ -28,7 +28,7 @@ ABL = set(filter(None, os.environ.get("W64_ABL", "").split(",")))
 
 BUDGET = int(os.environ.get("W64_BUDGET", "24"))   # issue cycles available beside one MFMA
 EARLY_MAX = os.environ.get("W64_EARLY_MAX", "1") == "1"  # row max of key-block 0 during the QK of key-block 1, e = s*c - m spread to the end
-COST = {"DMAK": 8, "DMAV": 8, "NOP": 32, "EXP": 8, "ADD": 4, "CVT": 4, "VREAD": 8, "KREAD": 4, "MAX": 4, "DEC": 44, "FMA": 4}
+COST = {"MASK": 8, "DMAK": 8, "DMAV": 8, "NOP": 32, "EXP": 8, "ADD": 4, "CVT": 4, "VREAD": 8, "KREAD": 4, "MAX": 4, "DEC": 44, "FMA": 4}
 
 NPRE = 4  # K fragments (kb=0, ks<NPRE) read before the iteration starts (by the includer, after the barrier)
 
@@ -101,6 +101,13 @@ def op_text(R, op):
         if first:
             return f'asm volatile("v_max_f32 %0, v{v}, v{v + 1}" : "=v"(mx[{qb}][{c}]));'
         return f'asm volatile("v_max3_f32 %0, %0, v{v}, v{v + 1}" : "+v"(mx[{qb}][{c}]));'
+    if kind == "MASK":
+        # causal diagonal tiles: key > row  <=>  dmask + c > 0 with the lane value dmask = 64 t + 4 hi - row0 - ql and the
+        # element constant c = 32 kb - 32 qb + (r & 3) + 8 (r >> 2); masked scores become -inf before the row max
+        _, kb, qb, r = op
+        v = base(R.new, kb, qb) + r
+        c = 32 * kb - 32 * qb + (r & 3) + 8 * (r >> 2)
+        return (f'asm volatile("v_cmp_lt_i32 vcc, {-c}, %0\\n\\tv_cndmask_b32 v{v}, v{v}, %1, vcc" :: "v"(dmask), "v"(neg_inf) : "vcc");')
     if kind == "DMAK":
         _, j = op
         return (f'asm volatile("s_mov_b32 m0, %0\\n\\ts_nop 0\\n\\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_wave + W64_KDST + {j * 1024}), '
@@ -120,24 +127,27 @@ def op_text(R, op):
     raise ValueError(kind)
 
 
-def exp_stream_iter():
-    ops = []
-    pairs = [(kb, qb, r) for kb in (0, 1) for half in (0, 1) for qb in (0, 1) for r in range(8 * half, 8 * half + 8, 2)]
-    prev = None
-    for cur in pairs + [None]:
-        if cur is not None:
-            kb, qb, r = cur
-            dl = 32 + 8 * (2 * kb + (r >> 3)) - 2
-            ops.append((("EXP", kb, qb, r), 0, dl))
-            ops.append((("EXP", kb, qb, r + 1), 0, dl))
-        if prev is not None:
-            kb, qb, r = prev
-            dl = 32 + 8 * (2 * kb + (r >> 3)) - 2
-            ops.append((("ADD", kb, qb, r), 0, dl))
-            ops.append((("ADD", kb, qb, r + 1), 0, dl))
-            ops.append((("CVT", kb, qb, r), 0, dl))
-        prev = cur
-    return ops
+def exp_streams():
+    """exp -> row sum -> pack of S_old, one stream per score block (kb, qb), skewed by one pair so an exp result is
+    not consumed by the next instruction; the 16-key step st = 2 kb + (r >> 3) must be packed before its PV MFMAs."""
+    streams = []
+    for kb in (0, 1):
+        for qb in (0, 1):
+            ops = []
+            prev = None
+            for r in list(range(0, 16, 2)) + [None]:
+                if r is not None:
+                    dl = 32 + 8 * (2 * kb + (r >> 3)) - 2
+                    ops.append((("EXP", kb, qb, r), 0, dl))
+                    ops.append((("EXP", kb, qb, r + 1), 0, dl))
+                if prev is not None:
+                    dl = 32 + 8 * (2 * kb + (prev >> 3)) - 2
+                    ops.append((("ADD", kb, qb, prev), 0, dl))
+                    ops.append((("ADD", kb, qb, prev + 1), 0, dl))
+                    ops.append((("CVT", kb, qb, prev), 0, dl))
+                prev = r
+            streams.append(ops)
+    return streams
 
 
 def vread_stream():
@@ -170,35 +180,72 @@ def dma_stream():
     return ops
 
 
-def start_stream(have_new, mfma_follows=True):
-    """row max of S_new -> decision -> e = s*c - m in place (sequential stream).  Four independent max chains
+def start_streams(have_new, mfma_follows=True, masked=False):
+    """(causal diagonal tiles: mask ->) row max of S_new -> decision -> e = s*c - m in place.
+    Returns several streams (each consumed in order); cross-stream order is enforced by disjoint gap windows:
+    mask(kb) | max(kb) | decision | the four blocks of e = s*c - m in parallel (so that a block whose registers an
+    in-flight PV MFMA shadows - writes_near_mfma - can wait while another proceeds).  Four independent max chains
     (two per q-block) are interleaved so consecutive ops never depend on each other."""
     if not have_new:
         return []
-    ops = []
+    if not mfma_follows:  # first tile of a segment: nothing to hide under, plain order
+        ops = []
+        for kb in (0, 1):
+            ready = kb * 16 + 14 + 2
+            if kb == 1:
+                ops.append((("NOP",), 32, 63))
+            if masked:
+                for qb in (0, 1):
+                    for r in range(16):
+                        ops.append((("MASK", kb, qb, r), ready + qb, 63))
+            for r in range(0, 16, 2):
+                for qb in (0, 1):
+                    ops.append((("MAX", kb, qb, r, kb == 0 and r < 4), ready + qb, 63))
+        ops.append((("DEC",), 34, 63))
+        for kb in (0, 1):
+            for qb in (0, 1):
+                for r in range(16):
+                    ops.append((("FMA", kb, qb, r), 36, 63))
+        return [ops]
+    if masked:
+        w_mask = {0: (16, 30), 1: (32, 44)}
+        w_max = {0: (31, 36), 1: (45, 50)}
+        w_dec, w_fma = (51, 52), (53, 62)
+    else:
+        w_mask = None
+        w_max = {0: (16, 31), 1: (32, 40)}
+        w_dec, w_fma = (41, 43), (44, 61)
+    streams = []
     for kb in (0, 1):
-        if kb == 1 and not mfma_follows:
-            ops.append((("NOP",), 32, 63))
+        ready = kb * 16 + 14 + 2
+        if masked:
+            for qb in (0, 1):
+                streams.append([(("MASK", kb, qb, r), max(w_mask[kb][0], ready + qb), w_mask[kb][1]) for r in range(16)])
+        mx = []
         for r in range(0, 16, 2):
             for qb in (0, 1):
-                earliest = kb * 16 + 14 + qb + 2
-                deadline = (31 if kb == 0 else 42) if (EARLY_MAX and mfma_follows) else 63
-                ops.append((("MAX", kb, qb, r, kb == 0 and r < 4), earliest, deadline))
-    ops.append((("DEC",), 34, 44 if (EARLY_MAX and mfma_follows) else 63))
-    n = 0
+                mx.append((("MAX", kb, qb, r, kb == 0 and r < 4), max(w_max[kb][0], ready + qb), w_max[kb][1]))
+        streams.append(mx)
+    streams.append([(("DEC",), w_dec[0], w_dec[1])])
     for kb in (0, 1):
         for qb in (0, 1):
-            for r in range(16):
-                deadline = 46 + (n * 18) // 64 if (EARLY_MAX and mfma_follows) else 63
-                ops.append((("FMA", kb, qb, r), 36, deadline))
-                n += 1
-    return ops
+            streams.append([(("FMA", kb, qb, r), w_fma[0], w_fma[1]) for r in range(16)])
+    return streams
 
 
 def schedule(streams, gaps):
     """EDF under a per-gap budget.  streams: list of [ (op, earliest, deadline) ... ] each consumed in order."""
     pos = [0] * len(streams)
     out = [[] for _ in range(gaps)]
+    # a stream is consumed in order, so an op inherits the tightest deadline of everything queued behind it
+    tight = []
+    for st_ in streams:
+        t = list(st_)
+        for k in range(len(t) - 2, -1, -1):
+            if t[k + 1][2] < t[k][2]:
+                t[k] = (t[k][0], t[k][1], t[k + 1][2])
+        tight.append(t)
+    streams = tight
     for g in range(gaps):
         used = 0
         while True:
@@ -234,7 +281,58 @@ def schedule(streams, gaps):
     return out
 
 
-def emit_part(lines, R, have_new, have_old):
+def check_part(placed, have_new, have_old, masked):
+    """Data-flow self-check of one scheduled part (gap g = after MFMA g): every consumer sits behind its producer.
+    (A schedule that packed a P fragment one gap late shows up on the GPU as garbage in exactly the O^T blocks whose
+    MFMAs came first - cost a long bisect once.)"""
+    pos = {}
+    for g, ops in enumerate(placed):
+        for k, op in enumerate(ops):
+            pos[op] = (g, k)
+    def before(a, b):
+        return a in pos and b in pos and pos[a] < pos[b]
+    for kb in (0, 1):
+        for qb in (0, 1):
+            if have_old:
+                for r in range(16):
+                    assert before(("EXP", kb, qb, r), ("ADD", kb, qb, r)), ("ADD before EXP", kb, qb, r)
+                for r in range(0, 16, 2):
+                    cv = ("CVT", kb, qb, r)
+                    assert before(("EXP", kb, qb, r), cv) and before(("EXP", kb, qb, r + 1), cv), ("CVT before EXP", cv)
+                    assert before(("ADD", kb, qb, r), cv) and before(("ADD", kb, qb, r + 1), cv), ("CVT before ADD", cv)
+                    # in-place compaction: pair (r, r+1) lands in register 8*(r>>3) + (r&7)/2 of the tile, which must
+                    # already have been consumed as a score (its own ADD and the CVT that read it)
+                    dst = 8 * (r >> 3) + ((r & 7) >> 1)
+                    if dst not in (r, r + 1):
+                        assert before(("ADD", kb, qb, dst), cv), ("CVT overwrites unread score", cv)
+                        assert before(("CVT", kb, qb, dst & ~1), cv), ("CVT overwrites unpacked score", cv)
+                    st = 2 * kb + (r >> 3)
+                    first_use = 32 + 8 * st  # first PV MFMA of this 16-key step (any d-block, any q-block)
+                    assert pos[cv][0] < first_use, ("P fragment packed after its first PV MFMA", cv, pos[cv], first_use)
+            if have_new:
+                last_mfma = kb * 16 + 14 + qb
+                for r in range(0, 16, 2):
+                    mxop = [o for o in pos if o[0] == "MAX" and o[1:4] == (kb, qb, r)][0]
+                    assert pos[mxop][0] > last_mfma, ("row max reads an unfinished score tile", mxop)
+                    if masked:
+                        assert before(("MASK", kb, qb, r), mxop) and before(("MASK", kb, qb, r + 1), mxop), ("MAX before MASK", mxop)
+                    assert before(mxop, ("DEC",)), ("decision before MAX", mxop)
+                for r in range(16):
+                    assert before(("DEC",), ("FMA", kb, qb, r)), ("FMA before decision", kb, qb, r)
+                    if masked:
+                        assert pos[("MASK", kb, qb, r)][0] > last_mfma, ("mask on an unfinished score tile", kb, qb, r)
+    if have_old:
+        for st in range(4):
+            for db in range(4):
+                assert pos[("VREAD", st, db)][0] < 32 + st * 8 + db * 2, ("V fragment read after its MFMA", st, db)
+    if have_new:
+        for kb in (0, 1):
+            for ks in range(8):
+                if ("KREAD", kb, ks) in pos:
+                    assert pos[("KREAD", kb, ks)][0] < kb * 16 + ks * 2, ("K fragment read after its MFMA", kb, ks)
+
+
+def emit_part(lines, R, have_new, have_old, masked=False):
     mf = []
     if have_new:
         for kb in (0, 1):
@@ -252,13 +350,14 @@ def emit_part(lines, R, have_new, have_old):
         mf += [None] * 32
     streams = []
     if have_old:
-        streams.append(exp_stream_iter())
+        streams += exp_streams()
         streams.append(vread_stream())
     if have_new:
-        streams.append(start_stream(True, have_old))
+        streams += start_streams(True, have_old, masked)
         streams.append(kread_stream())
         streams.append(dma_stream())
     placed = schedule(streams, 64)
+    check_part(placed, have_new, have_old, masked)
     cyc = 0
     for g in range(64):
         if mf[g] is not None:
@@ -324,6 +423,12 @@ def main():
     emit_part(lines, Roles("b", "a"), False, True)
     lines.append("#elif W64_PART == 4  // drain, last tile in set B")
     emit_part(lines, Roles("a", "b"), False, True)
+    lines.append("#elif W64_PART == 5  // causal diagonal tile, first tile of a segment")
+    emit_part(lines, Roles("a", "b"), True, False, masked=True)
+    lines.append("#elif W64_PART == 6  // causal diagonal tile, odd")
+    emit_part(lines, Roles("b", "a"), True, True, masked=True)
+    lines.append("#elif W64_PART == 7  // causal diagonal tile, even")
+    emit_part(lines, Roles("a", "b"), True, True, masked=True)
     lines.append("#endif")
     out.write_text("\n".join(lines) + "\n")
     print("wrote", out, len(lines), "lines")

@@ -79,14 +79,15 @@ static int w64_cu_count() {
 bool fwd_w64_supported(const FwdParams& p) {
     static const bool off = [] { const char* e = getenv("UMFA_NO_W64"); return e && e[0] == '1'; }();
     if (off || !fwd_16_supported(p)) return false;
-    if (p.D != 128 || p.causal || p.mask_kind != MK_NONE) return false;
+    if (p.D != 128 || p.mask_kind != MK_NONE) return false;
     if (p.Sq == 0 || p.Sq % 256 || p.Skv == 0 || p.Skv % 64) return false;
     if (p.out_prec != P_FP32 && p.out_prec != p.in_prec) return false;
     return true;
 }
 
 static uint32_t w64_grid(const FwdParams& p) {
-    const uint64_t total = (uint64_t)p.B * p.H * (p.Sq / 256) * (p.Skv / 64);  // (item, key tile) steps
+    uint64_t total = (uint64_t)p.B * p.H * (p.Sq / 256) * (p.Skv / 64);  // (item, key tile) steps
+    if (p.causal) total = (uint64_t)p.B * p.H * ((p.Sq / 256 + 1) / 2);  // jobs = mirrored pairs of q-blocks
     const uint32_t cus = (uint32_t)w64_cu_count();
     return total < cus ? (uint32_t)total : cus;  // never more workgroups than steps: every slice is non-empty
 }
@@ -95,7 +96,7 @@ FwdW64Plan fwd_w64_plan(const FwdParams& p) {
     FwdW64Plan plan;
     const uint32_t items = p.B * p.H * (p.Sq / 256);
     (void)items;
-    plan.cnt_bytes = ((size_t)w64_grid(p) * sizeof(uint32_t) + 255) & ~(size_t)255;  // < grid shared items
+    plan.cnt_bytes = ((size_t)w64_grid(p) * sizeof(uint32_t) + 255) & ~(size_t)255;  // < grid shared items (causal: none)
     plan.buf_bytes = (size_t)2 * w64_grid(p) * (4 * 2 * 17 * 1024);
     return plan;
 }
@@ -128,12 +129,18 @@ hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cn
     wp.part_cnt = part_cnt;
     if (p.in_prec == P_BF16) {
         *name = "fa_fwd16_w64<bf16,128>";
-        return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64_bf16<float>, p, wp, stream)
-                                    : launch_w64_kernel(fa_fwd16_w64_bf16<__bf16>, p, wp, stream);
+        if (p.causal)
+            return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64_bf16<float, true>, p, wp, stream)
+                                        : launch_w64_kernel(fa_fwd16_w64_bf16<__bf16, true>, p, wp, stream);
+        return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64_bf16<float, false>, p, wp, stream)
+                                    : launch_w64_kernel(fa_fwd16_w64_bf16<__bf16, false>, p, wp, stream);
     }
     *name = "fa_fwd16_w64<fp16,128>";
-    return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64_f16<float>, p, wp, stream)
-                                : launch_w64_kernel(fa_fwd16_w64_f16<_Float16>, p, wp, stream);
+    if (p.causal)
+        return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64_f16<float, true>, p, wp, stream)
+                                    : launch_w64_kernel(fa_fwd16_w64_f16<_Float16, true>, p, wp, stream);
+    return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64_f16<float, false>, p, wp, stream)
+                                : launch_w64_kernel(fa_fwd16_w64_f16<_Float16, false>, p, wp, stream);
 }
 
 }  // namespace umfa
