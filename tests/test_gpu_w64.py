@@ -151,3 +151,35 @@ def test_w64_causal_flux_shape_rows():
             ref = orc.sdpa_forward(bits(q[0:1, head:head + 1, r:r + 1]), np.ascontiguousarray(kk[:, :, :r + 1]),
                                    np.ascontiguousarray(vv[:, :, :r + 1]))
             assert rel_err(o[0, head, r].cpu().numpy(), ref[0, 0, 0]) < 6e-3, (head, r)
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 256, 100, False), (1, 2, 512, 1000, False), (2, 2, 1100, 777, False), (1, 3, 1280, 1100, True),
+                                   (1, 2, 1088, 1088, True), (1, 1, 256, 65, True)])
+def test_w64_ragged_shapes(shape):
+    """Sq not a multiple of 256 (rows past the end are computed on zeros and never stored) and Skv not a multiple of 64
+    (the partial last key tile runs the masking variant), with and without the causal mask"""
+    import umfa_torch
+    B, H, Sq, Skv, causal = shape
+    torch.manual_seed(Sq + 7 * Skv)
+    q = torch.randn(B, H, Sq, 128, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(B, H, Skv, 128, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn(B, H, Skv, 128, device="cuda", dtype=torch.bfloat16)
+    # the output tensor sits in the middle of a poisoned allocation: rows past Sq of the last 256-row block, which the
+    # kernel computes but must not store, would land in the guard
+    pool = torch.full((B * H * Sq * 128 + 2 * 65536,), 7.0, device="cuda", dtype=torch.float32)
+    out = pool[65536:65536 + B * H * Sq * 128].view(B, H, Sq, 128)
+    o, lse = umfa_torch.attention_forward(q, k, v, causal=causal, out_dtype=torch.float32, return_lse=True, out=out)
+    assert bool((pool[:65536] == 7.0).all()) and bool((pool[65536 + B * H * Sq * 128:] == 7.0).all())
+    assert umfa_torch.last_kernel().startswith("fa_fwd16_w64"), umfa_torch.last_kernel()
+    ref, ref_lse = _oracle().sdpa_forward(npy(q), npy(k), npy(v), causal=causal, return_lse=True)
+    assert np.isfinite(o.cpu().numpy()).all()
+    assert rel_err(o.cpu().numpy(), ref) < 6e-3
+    assert np.abs(lse.cpu().numpy().reshape(ref_lse.shape) - ref_lse).max() < 2e-2
+    assert torch.equal(o, umfa_torch.attention_forward(q, k, v, causal=causal, out_dtype=torch.float32))
+
+
+def test_w64_small_ragged_sq_stays_on_the_128_row_kernel():
+    import umfa_torch
+    q, k, v = (torch.randn(1, 2, 300, 128, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    umfa_torch.attention_forward(q, k, v)
+    assert umfa_torch.last_kernel() == "fa_fwd16<bf16,128>"

@@ -102,12 +102,13 @@ def op_text(R, op):
             return f'asm volatile("v_max_f32 %0, v{v}, v{v + 1}" : "=v"(mx[{qb}][{c}]));'
         return f'asm volatile("v_max3_f32 %0, %0, v{v}, v{v + 1}" : "+v"(mx[{qb}][{c}]));'
     if kind == "MASK":
-        # causal diagonal tiles: key > row  <=>  dmask + c > 0 with the lane value dmask = 64 t + 4 hi - row0 - ql and the
-        # element constant c = 32 kb - 32 qb + (r & 3) + 8 (r >> 2); masked scores become -inf before the row max
+        # masking tiles: score (kb, qb, r) is masked  <=>  dmask[qb] + c > 0 with the element constant
+        # c = 32 kb - 32 qb + (r & 3) + 8 (r >> 2) and the lane value dmask[qb] = max(causal term 64 t + 4 hi - row0 - ql
+        # [key > row], key-tail term 64 t + 4 hi - Skv + 1 + 32 qb [key >= Skv]); masked scores become -inf before the max
         _, kb, qb, r = op
         v = base(R.new, kb, qb) + r
         c = 32 * kb - 32 * qb + (r & 3) + 8 * (r >> 2)
-        return (f'asm volatile("v_cmp_lt_i32 vcc, {-c}, %0\\n\\tv_cndmask_b32 v{v}, v{v}, %1, vcc" :: "v"(dmask), "v"(neg_inf) : "vcc");')
+        return (f'asm volatile("v_cmp_lt_i32 vcc, {-c}, %0\\n\\tv_cndmask_b32 v{v}, v{v}, %1, vcc" :: "v"(dmask[{qb}]), "v"(neg_inf) : "vcc");')
     if kind == "DMAK":
         _, j = op
         return (f'asm volatile("s_mov_b32 m0, %0\\n\\ts_nop 0\\n\\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_wave + W64_KDST + {j * 1024}), '

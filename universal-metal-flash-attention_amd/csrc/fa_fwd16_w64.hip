@@ -1,5 +1,5 @@
-// fa_fwd16_w64.hip -- bf16 / fp16 forward at head_dim 128, "one wave per SIMD" structure (no mask, non-causal,
-// Sq % 256 == 0, Skv % 64 == 0); every other case stays on fa_fwd16 (fa_fwd_16.hip).
+// fa_fwd16_w64.hip -- bf16 / fp16 forward at head_dim 128, "one wave per SIMD" structure (no mask; causal or not;
+// Sq >= 256, Skv >= 64); every other case stays on fa_fwd16 (fa_fwd_16.hip).
 //
 // Replaces the same Metal `attention` forward dispatch as fa_fwd_16.hip (MFABridge.swift:2240-2248, 2525-2541).
 //
@@ -80,21 +80,23 @@ bool fwd_w64_supported(const FwdParams& p) {
     static const bool off = [] { const char* e = getenv("UMFA_NO_W64"); return e && e[0] == '1'; }();
     if (off || !fwd_16_supported(p)) return false;
     if (p.D != 128 || p.mask_kind != MK_NONE) return false;
-    if (p.Sq == 0 || p.Sq % 256 || p.Skv == 0 || p.Skv % 64) return false;
+    // rows are processed in blocks of 256: a ragged last block wastes its empty waves, so small ragged Sq stay on
+    // the 128-row kernel; any Skv >= 64 works (a partial last key tile runs the masking variant of the tile body)
+    if (p.Skv < 64 || p.Sq < 256 || (p.Sq % 256 != 0 && p.Sq < 1024)) return false;
     if (p.out_prec != P_FP32 && p.out_prec != p.in_prec) return false;
     return true;
 }
 
 static uint32_t w64_grid(const FwdParams& p) {
-    uint64_t total = (uint64_t)p.B * p.H * (p.Sq / 256) * (p.Skv / 64);  // (item, key tile) steps
-    if (p.causal) total = (uint64_t)p.B * p.H * ((p.Sq / 256 + 1) / 2);  // jobs = mirrored pairs of q-blocks
+    uint64_t total = (uint64_t)p.B * p.H * ((p.Sq + 255) / 256) * ((p.Skv + 63) / 64);  // (item, key tile) steps
+    if (p.causal) total = (uint64_t)p.B * p.H * (((p.Sq + 255) / 256 + 1) / 2);  // jobs = mirrored pairs of q-blocks
     const uint32_t cus = (uint32_t)w64_cu_count();
     return total < cus ? (uint32_t)total : cus;  // never more workgroups than steps: every slice is non-empty
 }
 
 FwdW64Plan fwd_w64_plan(const FwdParams& p) {
     FwdW64Plan plan;
-    const uint32_t items = p.B * p.H * (p.Sq / 256);
+    const uint32_t items = p.B * p.H * ((p.Sq + 255) / 256);
     (void)items;
     plan.cnt_bytes = ((size_t)w64_grid(p) * sizeof(uint32_t) + 255) & ~(size_t)255;  // < grid shared items (causal: none)
     plan.buf_bytes = (size_t)2 * w64_grid(p) * (4 * 2 * 17 * 1024);
@@ -123,8 +125,8 @@ hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cn
     for (int i = 0; i < 3; ++i) { wp.qs[i] = p.qs[i]; wp.ks[i] = p.ks[i]; wp.vs[i] = p.vs[i]; }
     wp.B = p.B; wp.H = p.H; wp.Sq = p.Sq; wp.Skv = p.Skv;
     wp.scale = p.scale;
-    wp.n_items = p.B * p.H * (p.Sq / 256);
-    wp.T = p.Skv / 64;
+    wp.n_items = p.B * p.H * ((p.Sq + 255) / 256);
+    wp.T = (p.Skv + 63) / 64;
     wp.part_buf = part_buf;
     wp.part_cnt = part_cnt;
     if (p.in_prec == P_BF16) {
