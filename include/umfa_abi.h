@@ -233,8 +233,12 @@ mfa_error_t mfa_set_scale_arrays(mfa_context_t context, const float* q_scales,
                                  uint32_t k_scales_count, const float* v_scales,
                                  uint32_t v_scales_count); /* [T]:370-375, [B]:807-848 */
 
-/* ---- pre-quantised backward ABI ([H]:480-624).  Out of scope this round:
- * the symbols link and return MFA_ERROR_DEVICE_NOT_SUPPORTED. ---------------- */
+/* ---- pre-quantised backward ABI ([H]:480-624, [B]:1623-2163).  Built: Q, K, V arrive quantised (INT8 / INT4) or in
+ * fp16 / bf16 / fp32 (`*_precision` = mfa_precision_t) with per-tensor scale / zero point or, when `*_block_size` > 0 and
+ * a scale buffer is passed, one fp32 scale (+ optional int32 zero point) per block of `*_block_size` consecutive rows of
+ * a (batch, head) slab, laid out [batch][head][block].  O, dO, LSE, D and the gradients are fp32 dense BHSD; softmax
+ * scale 1/sqrt(head_dim); num_kv_heads may divide num_heads (grouped K/V: dK / dV are summed over the group).  The
+ * query call writes dQ and D, the kv call reads D.  head_dim <= 128; transpose_o must be false. ---------------- */
 #define UMFA_QBWD_TAIL                                                                            \
     float q_scale, int32_t q_zero_point, float k_scale, int32_t k_zero_point, float v_scale,      \
         int32_t v_zero_point, int32_t q_precision, int32_t k_precision, int32_t v_precision,      \

@@ -105,3 +105,93 @@ def test_backward_mfma16_vs_oracle(ctx, shape, dt, causal):
     assert ctx.last_kernel.startswith("fa_bwd_exact")
     for got, ref in [(dq2, rdq), (dk2, rdk), (dv2, rdv)]:
         assert np.abs(got - ref).max() < 5e-5 * max(1.0, np.abs(ref).max())
+
+
+def _prequant_case(bits, grouped, blockwise, causal):
+    """caller-side quantisation (QuantizationTests.swift:72-128 formula), expected gradients from the oracle's fp64
+    backward on the de-quantised operands (K / V broadcast over their group, gradients summed over it)"""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(bits * 100 + grouped * 10 + blockwise)
+    B, H, Hkv, Sq, Skv, D = 2, 4, (2 if grouped else 4), 80, 96, 64
+    qmax = 127 if bits == 8 else 7
+    BS = 32
+
+    def quant(x):
+        if blockwise:  # one scale per 32 consecutive rows of a (batch, head) slab
+            Bq, Hh, S, Dd = x.shape
+            nb = (S + BS - 1) // BS
+            scales = np.zeros((Bq, Hh, nb), np.float32)
+            qv = np.zeros(x.shape, np.int8)
+            for b in range(Bq):
+                for h in range(Hh):
+                    for j in range(nb):
+                        blk = x[b, h, j * BS:(j + 1) * BS]
+                        sc = max(np.abs(blk).max() / qmax, 1e-12)
+                        scales[b, h, j] = sc
+                        qv[b, h, j * BS:(j + 1) * BS] = np.clip(np.round(blk / sc), -qmax - 1, qmax)
+            deq = qv.astype(np.float32) * np.repeat(scales, BS, axis=2)[:, :, :S, None]
+            return qv, 1.0, scales.ravel(), deq
+        sc = np.float32(np.abs(x).max() / qmax)
+        qv = np.clip(np.round(x / sc), -qmax - 1, qmax).astype(np.int8)
+        return qv, float(sc), None, qv.astype(np.float32) * sc
+
+    q = rng.standard_normal((B, H, Sq, D), dtype=np.float32)
+    k = rng.standard_normal((B, Hkv, Skv, D), dtype=np.float32)
+    v = rng.standard_normal((B, Hkv, Skv, D), dtype=np.float32)
+    dout = rng.standard_normal((B, H, Sq, D), dtype=np.float32)
+    (q8, qs, qbs, qd), (k8, ks, kbs, kd), (v8, vs, vbs, vd) = quant(q), quant(k), quant(v)
+    g = H // Hkv
+    kx, vx = np.repeat(kd, g, axis=1), np.repeat(vd, g, axis=1)
+    o, lse = orc.sdpa_forward(qd, kx, vx, causal=causal, return_lse=True)
+    dq, dkx, dvx, dvec = orc.sdpa_backward(dout, qd, kx, vx, o, lse, causal=causal)
+    dk = dkx.reshape(B, Hkv, g, Skv, D).sum(2)
+    dv = dvx.reshape(B, Hkv, g, Skv, D).sum(2)
+    raw = (lambda a: orc.pack_int4(a)) if bits == 4 else (lambda a: a)
+    return dict(q=raw(q8), k=raw(k8), v=raw(v8), out=o, dout=dout, lse=lse.ravel(), q_scale=qs, k_scale=ks, v_scale=vs,
+                q_block_scales=qbs, k_block_scales=kbs, v_block_scales=vbs,
+                q_block_size=BS if blockwise else 0, k_block_size=BS if blockwise else 0, v_block_size=BS if blockwise else 0,
+                q_precision="int8" if bits == 8 else "int4", k_precision="int8" if bits == 8 else "int4",
+                v_precision="int8" if bits == 8 else "int4", causal=causal, num_heads=H, num_kv_heads=Hkv, head_dim=D,
+                seq_len_q=Sq, seq_len_kv=Skv, batch_size=B), (dq, dk, dv, dvec)
+
+
+@pytest.mark.parametrize("bits,grouped,blockwise,causal", [(8, False, False, False), (8, True, True, True), (4, False, True, False),
+                                                           (4, True, False, True)])
+def test_prequantized_backward_abi(ctx, bits, grouped, blockwise, causal):
+    """mfa_attention_backward_{query,kv}_quantized_ex (mfa_ffi.h:542-624): the operands are exactly representable, so the
+    only error is fp32 arithmetic against the oracle's fp64"""
+    import umfa
+    from umfa.core import prequantized_backward
+    kwargs, (dq, dk, dv, dvec) = _prequant_case(bits, grouped, blockwise, causal)
+    gq, gk, gv, gd = prequantized_backward(ctx, **kwargs)
+    assert ctx.last_kernel.startswith("fa_bwd_exact")
+    for got, ref, name in ((gq, dq, "dq"), (gk, dk, "dk"), (gv, dv, "dv"), (gd, dvec.ravel(), "D")):
+        assert np.isfinite(got).all(), name
+        assert np.abs(got - ref).max() < 2e-4 * max(1.0, np.abs(ref).max()), name
+
+
+def test_prequantized_backward_legacy_entries_and_errors(ctx):
+    """the non-_ex entries (mfa_ffi.h:480-540) = per-tensor scales, equal head counts; NULL handles -> error 1"""
+    import umfa
+    from umfa._ffi import _lib
+    from umfa.core import MFABuffer
+    kwargs, (dq, dk, dv, dvec) = _prequant_case(8, False, False, False)
+    B, H, Sq, Skv, D = kwargs["batch_size"], kwargs["num_heads"], kwargs["seq_len_q"], kwargs["seq_len_kv"], kwargs["head_dim"]
+    gq, gk, gv = np.zeros_like(dq), np.zeros_like(dk), np.zeros_like(dv)
+    gd = np.zeros(B * H * Sq, np.float32)
+    arrs = [kwargs["q"], kwargs["k"], kwargs["v"], np.ascontiguousarray(kwargs["out"], np.float32), kwargs["dout"], kwargs["lse"],
+            gq, gk, gv, gd]
+    bufs = [MFABuffer(ctx, np.ascontiguousarray(a)) for a in arrs]
+    bq, bk, bv, bo, bdo, bl, bdq, bdk, bdv, bd = (b.handle for b in bufs)
+    tail = (kwargs["q_scale"], 0, kwargs["k_scale"], 0, kwargs["v_scale"], 0, 3, 3, 3, False, False, False, False, False)
+    try:
+        assert _lib.mfa_attention_backward_query_quantized(ctx.handle, bq, bk, bv, bo, bdo, bl, bdq, bd, B, Sq, Skv, H, D, *tail) == 0
+        assert _lib.mfa_attention_backward_kv_quantized(ctx.handle, bq, bk, bv, bdo, bl, bd, bdk, bdv, B, Sq, Skv, H, D, *tail) == 0
+        assert _lib.mfa_attention_backward_query_quantized(ctx.handle, None, bk, bv, bo, bdo, bl, bdq, bd, B, Sq, Skv, H, D, *tail) == 1
+        bad = tail[:-1] + (True,)  # transpose_o
+        assert _lib.mfa_attention_backward_kv_quantized(ctx.handle, bq, bk, bv, bdo, bl, bd, bdk, bdv, B, Sq, Skv, H, D, *bad) == 1
+    finally:
+        for b in bufs:
+            b.close()
+    assert np.abs(gq - dq).max() < 2e-4 * np.abs(dq).max() and np.abs(gk - dk).max() < 2e-4 * np.abs(dk).max()
+    assert np.abs(gv - dv).max() < 2e-4 * np.abs(dv).max()

@@ -150,4 +150,70 @@ hipError_t launch_hadamard(void* data, uint32_t block_size, uint32_t num_blocks,
     return hipGetLastError();
 }
 
+// ---- de-quantisation of caller-quantised operands (pre-quantised backward ABI, MFABridge.swift:1699-2163) -----------
+// x = (q - zero_point) * scale with one scale per tensor, or one per block of `block_size` consecutive rows of a
+// (batch, head) slab when block scales are given; INT4 = two values per byte, even index in the low nibble, stored
+// value + 8 (QuantizationTests.swift:72-128).  The source may hold fewer heads than the destination (grouped K/V).
+__global__ __launch_bounds__(256) void dequant_kernel(DequantParams p) {
+    const int64_t n = (int64_t)p.B * p.H_dst * p.S * p.D;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const uint32_t d = (uint32_t)(i % p.D);
+        const uint32_t s = (uint32_t)((i / p.D) % p.S);
+        const uint32_t h = (uint32_t)((i / ((int64_t)p.D * p.S)) % p.H_dst);
+        const uint32_t b = (uint32_t)(i / ((int64_t)p.D * p.S * p.H_dst));
+        const uint32_t hs = h / (p.H_dst / p.H_src);
+        const int64_t slab = (int64_t)b * p.H_src + hs;
+        const int64_t e = slab * p.S * p.D + (p.transposed ? (int64_t)d * p.S + s : (int64_t)s * p.D + d);
+        float x;
+        if (p.prec == P_INT8) {
+            x = (float)((const int8_t*)p.src)[e];
+        } else if (p.prec == P_INT4) {
+            const uint8_t byte = ((const uint8_t*)p.src)[e >> 1];
+            x = (float)(int)((e & 1) ? (byte >> 4) : (byte & 15)) - 8.0f;
+        } else {
+            p.dst[i] = load_as_float(p.src, e, p.prec);  // fp16 / bf16 / fp32 operands pass through
+            continue;
+        }
+        float sc = p.scale;
+        int zp = p.zero_point;
+        if (p.block_size && p.block_scales) {
+            const int64_t blk = slab * ((p.S + p.block_size - 1) / p.block_size) + s / p.block_size;
+            sc = p.block_scales[blk];
+            zp = p.block_zero_points ? p.block_zero_points[blk] : 0;
+        }
+        p.dst[i] = (x - (float)zp) * sc;
+    }
+}
+
+// dK / dV of grouped key/value heads: sum the per-query-head gradients of a group
+__global__ __launch_bounds__(256) void group_sum_kernel(const float* src, float* dst, uint32_t B, uint32_t H, uint32_t Hkv,
+                                                        int64_t slab) {
+    const uint32_t g = H / Hkv;
+    const int64_t n = (int64_t)B * Hkv * slab;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t e = i % slab, bh = i / slab;
+        const int64_t b = bh / Hkv, hk = bh % Hkv;
+        float acc = 0.0f;
+        for (uint32_t j = 0; j < g; ++j) acc += src[((b * H + hk * g + j) * slab) + e];
+        dst[i] = acc;
+    }
+}
+
+hipError_t launch_dequant(const DequantParams& p, hipStream_t stream) {
+    if (!p.src || !p.dst || p.H_src == 0 || p.H_dst % p.H_src) return hipErrorInvalidValue;
+    const int64_t n = (int64_t)p.B * p.H_dst * p.S * p.D;
+    if (n == 0) return hipSuccess;
+    const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(dequant_kernel, dim3(grid), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_group_sum(const float* src, float* dst, uint32_t B, uint32_t H, uint32_t Hkv, int64_t slab, hipStream_t stream) {
+    const int64_t n = (int64_t)B * Hkv * slab;
+    if (n == 0) return hipSuccess;
+    const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(group_sum_kernel, dim3(grid), dim3(256), 0, stream, src, dst, B, H, Hkv, slab);
+    return hipGetLastError();
+}
+
 }  // namespace umfa

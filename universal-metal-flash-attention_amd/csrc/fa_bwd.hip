@@ -220,7 +220,8 @@ __global__ __launch_bounds__(256) void bwd_dkdv_kernel(BwdParams p) {
 template <int DP>
 static hipError_t launch_bwd_dp(const BwdParams& p, hipStream_t stream) {
     const int64_t rows = (int64_t)p.B * p.H * p.Sq;
-    hipLaunchKernelGGL(bwd_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, p);
+    const int ph = p.phases ? p.phases : 7;  // the pre-quantised ABI computes dQ (+D) and dK/dV in separate calls
+    if (ph & 1) hipLaunchKernelGGL(bwd_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, p);
     const size_t lds_dq = 2 * 32 * (DP + 1) * sizeof(float);
     const size_t lds_kv = lds_dq + 64 * sizeof(float);
     hipError_t e;
@@ -231,8 +232,8 @@ static hipError_t launch_bwd_dp(const BwdParams& p, hipStream_t stream) {
         if (e != hipSuccess) return e;
     }
     const uint32_t nqb = (p.Sq + 127) / 128, nkb = (p.Skv + 127) / 128;
-    hipLaunchKernelGGL(bwd_dq_kernel<DP>, dim3(nqb * p.B * p.H), dim3(256), lds_dq, stream, p);
-    hipLaunchKernelGGL(bwd_dkdv_kernel<DP>, dim3(nkb * p.B * p.H), dim3(256), lds_kv, stream, p);
+    if (ph & 2) hipLaunchKernelGGL(bwd_dq_kernel<DP>, dim3(nqb * p.B * p.H), dim3(256), lds_dq, stream, p);
+    if (ph & 4) hipLaunchKernelGGL(bwd_dkdv_kernel<DP>, dim3(nkb * p.B * p.H), dim3(256), lds_kv, stream, p);
     return hipGetLastError();
 }
 

@@ -71,6 +71,7 @@ struct BwdParams {
     int causal;
     int in_prec;    // q, k, v
     int dout_prec;  // dO
+    int phases;     // fp32-exact backward only: 0 = everything; else bit 0 = D vector, bit 1 = dQ, bit 2 = dK/dV
 };
 
 __device__ __forceinline__ float bf16_bits_to_float(uint16_t b) {

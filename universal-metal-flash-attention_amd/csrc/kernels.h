@@ -50,6 +50,22 @@ struct RopeParams {
 hipError_t launch_rope(const RopeParams& p, int prec, hipStream_t stream);
 hipError_t launch_hadamard(void* data, uint32_t block_size, uint32_t num_blocks, int prec, hipStream_t stream);
 
+// De-quantisation of caller-quantised operands into fp32 [B, H_dst, S, D] (pre-quantised backward ABI) and the
+// group sum of per-query-head dK / dV for grouped key/value heads.
+struct DequantParams {
+    const void* src;
+    float* dst;
+    const float* block_scales;        // optional, [B * H_src * ceil(S / block_size)]
+    const int32_t* block_zero_points; // optional, same shape
+    uint32_t B, H_src, H_dst, S, D, block_size;
+    float scale;
+    int zero_point;
+    int prec;        // P_INT8 / P_INT4 / P_FP16 / P_BF16 / P_FP32
+    int transposed;  // source slab stored [D, S]
+};
+hipError_t launch_dequant(const DequantParams& p, hipStream_t stream);
+hipError_t launch_group_sum(const float* src, float* dst, uint32_t B, uint32_t H, uint32_t Hkv, int64_t slab, hipStream_t stream);
+
 // Runtime-quantised path (fa_quant.hip): fused symmetric quantiser for Q, K, V + int8-QK^T forward.
 struct QuantViews {
     const int8_t* q8;       // [B*H*Sq][dpq] int8 (rows zero-padded to dpq)

@@ -497,29 +497,6 @@ mfa_error_t mfa_multihead_attention_quantized_direct(
 
 // ============================ not built this round: link, return 3 ============================
 #define NOT_BUILT return MFA_ERROR_DEVICE_NOT_SUPPORTED
-int32_t mfa_attention_backward_query_quantized(mfa_context_t, mfa_buffer_t, mfa_buffer_t, mfa_buffer_t, mfa_buffer_t,
-                                               mfa_buffer_t, mfa_buffer_t, mfa_buffer_t, mfa_buffer_t, uint32_t,
-                                               uint32_t, uint32_t, uint32_t, uint16_t, float, int32_t, float, int32_t,
-                                               float, int32_t, int32_t, int32_t, int32_t, bool, bool, bool, bool,
-                                               bool) { NOT_BUILT; }
-int32_t mfa_attention_backward_kv_quantized(mfa_context_t, mfa_buffer_t, mfa_buffer_t, mfa_buffer_t, mfa_buffer_t,
-                                            mfa_buffer_t, mfa_buffer_t, mfa_buffer_t, mfa_buffer_t, uint32_t, uint32_t,
-                                            uint32_t, uint32_t, uint16_t, float, int32_t, float, int32_t, float,
-                                            int32_t, int32_t, int32_t, int32_t, bool, bool, bool, bool, bool) { NOT_BUILT; }
-int32_t mfa_attention_backward_query_quantized_ex(mfa_context_t, mfa_buffer_t, mfa_buffer_t, mfa_buffer_t,
-                                                  mfa_buffer_t, mfa_buffer_t, mfa_buffer_t, mfa_buffer_t,
-                                                  mfa_buffer_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t,
-                                                  uint16_t, float, int32_t, float, int32_t, float, int32_t, int32_t,
-                                                  int32_t, int32_t, bool, bool, bool, bool, bool, mfa_buffer_t,
-                                                  mfa_buffer_t, mfa_buffer_t, mfa_buffer_t, mfa_buffer_t,
-                                                  mfa_buffer_t, uint32_t, uint32_t, uint32_t, uint32_t) { NOT_BUILT; }
-int32_t mfa_attention_backward_kv_quantized_ex(mfa_context_t, mfa_buffer_t, mfa_buffer_t, mfa_buffer_t, mfa_buffer_t,
-                                               mfa_buffer_t, mfa_buffer_t, mfa_buffer_t, mfa_buffer_t, uint32_t,
-                                               uint32_t, uint32_t, uint32_t, uint32_t, uint16_t, float, int32_t,
-                                               float, int32_t, float, int32_t, int32_t, int32_t, int32_t, bool, bool,
-                                               bool, bool, bool, mfa_buffer_t, mfa_buffer_t, mfa_buffer_t,
-                                               mfa_buffer_t, mfa_buffer_t, mfa_buffer_t, uint32_t, uint32_t, uint32_t,
-                                               uint32_t) { NOT_BUILT; }
 // In-stream rotary rotation (MFABridge.swift:2286-2375): never commits, never waits.
 int mfa_rope_rotate_encode_mtl(void* context, void* command_buffer, void* src_buffer, int64_t src_offset,
                                int64_t src_batch_stride, int64_t src_head_stride, int64_t src_seq_stride,

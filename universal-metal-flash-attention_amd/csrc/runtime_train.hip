@@ -3,6 +3,7 @@
 // mfa_attention_backward           MFABridge.swift:3171-3282
 // mfa_quantized_forward_with_lse   MFABridge+Quantized.swift:227-358
 // mfa_quantized_backward           MFABridge+Quantized.swift:365-533
+// mfa_attention_backward_{query,kv}_quantized[_ex]   MFABridge.swift:1623-2163 (pre-quantised operands)
 #include "runtime_internal.h"
 
 using namespace umfa;
@@ -183,6 +184,224 @@ int32_t mfa_quantized_backward(mfa_context_t context, mfa_buffer_t q, mfa_buffer
     if (hipStreamSynchronize(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
     lat.publish();
     return MFA_SUCCESS;
+}
+
+// ---- pre-quantised backward ABI (MFABridge.swift:1623-2163, mfa_ffi.h:480-624) ----------------------------------------
+// Q, K, V arrive already quantised (or in fp16 / bf16 / fp32: the *_precision arguments are mfa_precision_t values) with
+// per-tensor scale / zero point, or per-block scales when `*_block_size` > 0 and a scale buffer is given.  Block
+// geometry is this library's (the same as its runtime quantiser): `block_size` consecutive rows of one (batch,
+// head) slab, scales laid out [batch][head][block] -- the reference's is not recoverable from its sources (parity
+// unpinned).  O, dO, LSE, D and the gradients are fp32; the softmax scale is 1/sqrt(head_dim) (the
+// ABI carries none); K / V may have fewer heads than Q (grouped), their gradients are summed over the group.
+// Implementation = the reference's contract ("dequantise on load, fp32 math", AGENTS.md:143-152): de-quantise into
+// fp32 copies, then the fp32-exact backward; the query call produces dQ and D, the kv call consumes D.
+namespace {
+
+struct PreQuant {
+    Buffer *q, *k, *v, *qs, *qz, *ks, *kz, *vs, *vz;
+    uint32_t B, Sq, Skv, H, Hkv, D, qbs, kbs, vbs;
+    float q_scale, k_scale, v_scale;
+    int q_zp, k_zp, v_zp, qp, kp, vp;
+    bool tq, tk, tv;
+};
+
+size_t quant_bytes(int prec, size_t n) {
+    switch (prec) {
+    case P_INT8: return n;
+    case P_INT4: return (n + 1) / 2;
+    case P_FP32: return n * 4;
+    default: return n * 2;
+    }
+}
+int raw_prec(int32_t v) { return (v >= 0 && v <= 4) ? (int)v : P_FP16; }  // unknown raw value -> FP16 (:1796)
+
+// validates, uploads and de-quantises Q, K, V into ws = [Q fp32 | K fp32 (H heads) | V fp32 (H heads)]
+mfa_error_t prequant_stage(Context* ctx, const PreQuant& a, float** qf, float** kf, float** vf, size_t extra_bytes,
+                           char** extra, hipStream_t stream) {
+    if (a.D == 0 || a.D > 128 || a.H == 0 || a.Hkv == 0 || a.H % a.Hkv) return MFA_ERROR_INVALID_ARGS;
+    const size_t nq = (size_t)a.B * a.H * a.Sq * a.D, nkv_src = (size_t)a.B * a.Hkv * a.Skv * a.D;
+    const size_t nkv = (size_t)a.B * a.H * a.Skv * a.D;
+    if (!a.q->fits(quant_bytes(a.qp, nq)) || !a.k->fits(quant_bytes(a.kp, nkv_src)) || !a.v->fits(quant_bytes(a.vp, nkv_src)))
+        return MFA_ERROR_INVALID_ARGS;
+    auto blocks_ok = [&](Buffer* s, Buffer* z, uint32_t bs, uint32_t heads, uint32_t S) {
+        if (!bs || !s) return true;
+        const size_t nb = (size_t)a.B * heads * ((S + bs - 1) / bs);
+        return s->fits(nb * 4) && (!z || z->fits(nb * 4));
+    };
+    if (!blocks_ok(a.qs, a.qz, a.qbs, a.H, a.Sq) || !blocks_ok(a.ks, a.kz, a.kbs, a.Hkv, a.Skv) ||
+        !blocks_ok(a.vs, a.vz, a.vbs, a.Hkv, a.Skv))
+        return MFA_ERROR_INVALID_ARGS;
+    const size_t fbytes = ((nq + 2 * nkv) * 4 + 255) & ~(size_t)255;
+    char* ws = (char*)ctx->ensure_workspace(fbytes + extra_bytes + 256);
+    if (!ws) return MFA_ERROR_MEMORY_ALLOCATION;
+    *qf = (float*)ws;
+    *kf = *qf + nq;
+    *vf = *kf + nkv;
+    *extra = ws + fbytes;
+    for (Buffer* b : {a.q, a.k, a.v, a.qs, a.qz, a.ks, a.kz, a.vs, a.vz})
+        if (b && b->upload(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+    auto deq = [&](Buffer* src, float* dst, int prec, uint32_t hs, uint32_t S, float sc, int zp, Buffer* bsc, Buffer* bzp,
+                   uint32_t bs, bool t) {
+        DequantParams d;
+        memset(&d, 0, sizeof(d));
+        d.src = src->dev; d.dst = dst;
+        d.block_scales = (bs && bsc) ? (const float*)bsc->dev : nullptr;
+        d.block_zero_points = (bs && bsc && bzp) ? (const int32_t*)bzp->dev : nullptr;
+        d.B = a.B; d.H_src = hs; d.H_dst = a.H; d.S = S; d.D = a.D; d.block_size = bs;
+        d.scale = sc; d.zero_point = zp; d.prec = prec; d.transposed = t ? 1 : 0;
+        return launch_dequant(d, stream);
+    };
+    if (deq(a.q, *qf, a.qp, a.H, a.Sq, a.q_scale, a.q_zp, a.qs, a.qz, a.qbs, a.tq) != hipSuccess ||
+        deq(a.k, *kf, a.kp, a.Hkv, a.Skv, a.k_scale, a.k_zp, a.ks, a.kz, a.kbs, a.tk) != hipSuccess ||
+        deq(a.v, *vf, a.vp, a.Hkv, a.Skv, a.v_scale, a.v_zp, a.vs, a.vz, a.vbs, a.tv) != hipSuccess)
+        return MFA_ERROR_EXECUTION_FAILED;
+    return MFA_SUCCESS;
+}
+
+}  // namespace
+
+int32_t mfa_attention_backward_query_quantized_ex(
+    mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, mfa_buffer_t v, mfa_buffer_t output, mfa_buffer_t grad_output,
+    mfa_buffer_t logsumexp, mfa_buffer_t grad_query, mfa_buffer_t d_values, uint32_t batch_size, uint32_t seq_len_q,
+    uint32_t seq_len_kv, uint32_t num_heads, uint32_t num_kv_heads, uint16_t head_dim, float q_scale, int32_t q_zero_point,
+    float k_scale, int32_t k_zero_point, float v_scale, int32_t v_zero_point, int32_t q_precision, int32_t k_precision,
+    int32_t v_precision, bool causal, bool transpose_q, bool transpose_k, bool transpose_v, bool transpose_o,
+    mfa_buffer_t q_block_scales, mfa_buffer_t q_block_zero_points, mfa_buffer_t k_block_scales,
+    mfa_buffer_t k_block_zero_points, mfa_buffer_t v_block_scales, mfa_buffer_t v_block_zero_points, uint32_t q_block_size,
+    uint32_t k_block_size, uint32_t v_block_size, uint32_t options) {
+    (void)options;  // ignored by the reference too (MFABridge.swift:1755)
+    Context* ctx = as_ctx(context);
+    Buffer *bo = as_buf(output), *bdo = as_buf(grad_output), *bl = as_buf(logsumexp), *bdq = as_buf(grad_query),
+           *bd = as_buf(d_values);
+    PreQuant a{as_buf(q), as_buf(k), as_buf(v), as_buf(q_block_scales), as_buf(q_block_zero_points), as_buf(k_block_scales),
+               as_buf(k_block_zero_points), as_buf(v_block_scales), as_buf(v_block_zero_points), batch_size, seq_len_q,
+               seq_len_kv, num_heads ? num_heads : 1u, num_kv_heads ? num_kv_heads : (num_heads ? num_heads : 1u), head_dim,
+               q_block_size, k_block_size, v_block_size, q_scale, k_scale, v_scale, q_zero_point, k_zero_point, v_zero_point,
+               raw_prec(q_precision), raw_prec(k_precision), raw_prec(v_precision), transpose_q, transpose_k, transpose_v};
+    if (!ctx || !a.q || !a.k || !a.v || !bo || !bdo || !bl || !bdq || !bd) return MFA_ERROR_INVALID_ARGS;
+    if (transpose_o) return MFA_ERROR_INVALID_ARGS;  // O / dO are read dense (no caller transposes them)
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    hipStream_t stream = nullptr;
+    const size_t nq = (size_t)a.B * a.H * a.Sq * a.D, nr = (size_t)a.B * a.H * a.Sq;
+    if (!bo->fits(nq * 4) || !bdo->fits(nq * 4) || !bl->fits(nr * 4) || !bdq->fits(nq * 4) || !bd->fits(nr * 4))
+        return MFA_ERROR_INVALID_ARGS;
+    if (nq == 0 || a.Skv == 0) return MFA_SUCCESS;
+    float *qf, *kf, *vf;
+    char* extra;
+    LatencyScope lat(ctx, stream);
+    mfa_error_t st = prequant_stage(ctx, a, &qf, &kf, &vf, 0, &extra, stream);
+    if (st != MFA_SUCCESS) return st;
+    for (Buffer* b : {bo, bdo, bl})
+        if (b->upload(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+    BwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.dout = bdo->dev; p.q = qf; p.k = kf; p.v = vf;
+    p.o = (const float*)bo->dev; p.lse = (const float*)bl->dev;
+    p.dq = (float*)bdq->dev; p.dvec = (float*)bd->dev;
+    p.B = a.B; p.H = a.H; p.Sq = a.Sq; p.Skv = a.Skv; p.D = a.D;
+    p.scale = 1.0f / sqrtf((float)a.D); p.causal = causal ? 1 : 0;
+    p.in_prec = P_FP32; p.dout_prec = P_FP32;
+    p.phases = 1 | 2;  // D vector + dQ
+    const char* name = "none";
+    hipError_t e = launch_bwd(p, stream, &name);
+    ctx->last_kernel = name;
+    if (e != hipSuccess) return e == hipErrorInvalidValue ? MFA_ERROR_INVALID_ARGS : MFA_ERROR_EXECUTION_FAILED;
+    lat.stop();
+    if (bdq->download(stream) != hipSuccess || bd->download(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+    if (hipStreamSynchronize(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+    lat.publish();
+    return MFA_SUCCESS;
+}
+
+int32_t mfa_attention_backward_kv_quantized_ex(
+    mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, mfa_buffer_t v, mfa_buffer_t grad_output, mfa_buffer_t logsumexp,
+    mfa_buffer_t d_values, mfa_buffer_t grad_key, mfa_buffer_t grad_value, uint32_t batch_size, uint32_t seq_len_q,
+    uint32_t seq_len_kv, uint32_t num_heads, uint32_t num_kv_heads, uint16_t head_dim, float q_scale, int32_t q_zero_point,
+    float k_scale, int32_t k_zero_point, float v_scale, int32_t v_zero_point, int32_t q_precision, int32_t k_precision,
+    int32_t v_precision, bool causal, bool transpose_q, bool transpose_k, bool transpose_v, bool transpose_o,
+    mfa_buffer_t q_block_scales, mfa_buffer_t q_block_zero_points, mfa_buffer_t k_block_scales,
+    mfa_buffer_t k_block_zero_points, mfa_buffer_t v_block_scales, mfa_buffer_t v_block_zero_points, uint32_t q_block_size,
+    uint32_t k_block_size, uint32_t v_block_size, uint32_t options) {
+    (void)options;
+    Context* ctx = as_ctx(context);
+    Buffer *bdo = as_buf(grad_output), *bl = as_buf(logsumexp), *bd = as_buf(d_values), *bdk = as_buf(grad_key),
+           *bdv = as_buf(grad_value);
+    PreQuant a{as_buf(q), as_buf(k), as_buf(v), as_buf(q_block_scales), as_buf(q_block_zero_points), as_buf(k_block_scales),
+               as_buf(k_block_zero_points), as_buf(v_block_scales), as_buf(v_block_zero_points), batch_size, seq_len_q,
+               seq_len_kv, num_heads ? num_heads : 1u, num_kv_heads ? num_kv_heads : (num_heads ? num_heads : 1u), head_dim,
+               q_block_size, k_block_size, v_block_size, q_scale, k_scale, v_scale, q_zero_point, k_zero_point, v_zero_point,
+               raw_prec(q_precision), raw_prec(k_precision), raw_prec(v_precision), transpose_q, transpose_k, transpose_v};
+    if (!ctx || !a.q || !a.k || !a.v || !bdo || !bl || !bd || !bdk || !bdv) return MFA_ERROR_INVALID_ARGS;
+    if (transpose_o) return MFA_ERROR_INVALID_ARGS;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    hipStream_t stream = nullptr;
+    const size_t nq = (size_t)a.B * a.H * a.Sq * a.D, nr = (size_t)a.B * a.H * a.Sq;
+    const size_t nkv_out = (size_t)a.B * a.Hkv * a.Skv * a.D, nkv = (size_t)a.B * a.H * a.Skv * a.D;
+    if (!bdo->fits(nq * 4) || !bl->fits(nr * 4) || !bd->fits(nr * 4) || !bdk->fits(nkv_out * 4) || !bdv->fits(nkv_out * 4))
+        return MFA_ERROR_INVALID_ARGS;
+    if (nq == 0 || nkv_out == 0) return MFA_SUCCESS;
+    const bool grouped = a.Hkv != a.H;
+    float *qf, *kf, *vf;
+    char* extra;
+    LatencyScope lat(ctx, stream);
+    mfa_error_t st = prequant_stage(ctx, a, &qf, &kf, &vf, grouped ? 2 * nkv * 4 : 0, &extra, stream);
+    if (st != MFA_SUCCESS) return st;
+    for (Buffer* b : {bdo, bl, bd})
+        if (b->upload(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+    BwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.dout = bdo->dev; p.q = qf; p.k = kf; p.v = vf;
+    p.lse = (const float*)bl->dev; p.dvec = (float*)bd->dev;
+    p.dk = grouped ? (float*)extra : (float*)bdk->dev;
+    p.dv = grouped ? (float*)extra + nkv : (float*)bdv->dev;
+    p.B = a.B; p.H = a.H; p.Sq = a.Sq; p.Skv = a.Skv; p.D = a.D;
+    p.scale = 1.0f / sqrtf((float)a.D); p.causal = causal ? 1 : 0;
+    p.in_prec = P_FP32; p.dout_prec = P_FP32;
+    p.phases = 4;  // dK / dV from the caller's D vector
+    const char* name = "none";
+    hipError_t e = launch_bwd(p, stream, &name);
+    ctx->last_kernel = name;
+    if (e != hipSuccess) return e == hipErrorInvalidValue ? MFA_ERROR_INVALID_ARGS : MFA_ERROR_EXECUTION_FAILED;
+    if (grouped) {
+        const int64_t slab = (int64_t)a.Skv * a.D;
+        if (launch_group_sum(p.dk, (float*)bdk->dev, a.B, a.H, a.Hkv, slab, stream) != hipSuccess ||
+            launch_group_sum(p.dv, (float*)bdv->dev, a.B, a.H, a.Hkv, slab, stream) != hipSuccess)
+            return MFA_ERROR_EXECUTION_FAILED;
+    }
+    lat.stop();
+    if (bdk->download(stream) != hipSuccess || bdv->download(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+    if (hipStreamSynchronize(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+    lat.publish();
+    return MFA_SUCCESS;
+}
+
+// the older entries = the _ex ones with equal head counts and no block tables (MFABridge.swift:1623-1697, 1894-1968)
+int32_t mfa_attention_backward_query_quantized(
+    mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, mfa_buffer_t v, mfa_buffer_t output, mfa_buffer_t grad_output,
+    mfa_buffer_t logsumexp, mfa_buffer_t grad_query, mfa_buffer_t d_values, uint32_t batch_size, uint32_t seq_len_q,
+    uint32_t seq_len_kv, uint32_t num_heads, uint16_t head_dim, float q_scale, int32_t q_zero_point, float k_scale,
+    int32_t k_zero_point, float v_scale, int32_t v_zero_point, int32_t q_precision, int32_t k_precision, int32_t v_precision,
+    bool causal, bool transpose_q, bool transpose_k, bool transpose_v, bool transpose_o) {
+    return mfa_attention_backward_query_quantized_ex(
+        context, q, k, v, output, grad_output, logsumexp, grad_query, d_values, batch_size, seq_len_q, seq_len_kv, num_heads,
+        num_heads, head_dim, q_scale, q_zero_point, k_scale, k_zero_point, v_scale, v_zero_point, q_precision, k_precision,
+        v_precision, causal, transpose_q, transpose_k, transpose_v, transpose_o, nullptr, nullptr, nullptr, nullptr, nullptr,
+        nullptr, 0, 0, 0, 0);
+}
+
+int32_t mfa_attention_backward_kv_quantized(
+    mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, mfa_buffer_t v, mfa_buffer_t grad_output, mfa_buffer_t logsumexp,
+    mfa_buffer_t d_values, mfa_buffer_t grad_key, mfa_buffer_t grad_value, uint32_t batch_size, uint32_t seq_len_q,
+    uint32_t seq_len_kv, uint32_t num_heads, uint16_t head_dim, float q_scale, int32_t q_zero_point, float k_scale,
+    int32_t k_zero_point, float v_scale, int32_t v_zero_point, int32_t q_precision, int32_t k_precision, int32_t v_precision,
+    bool causal, bool transpose_q, bool transpose_k, bool transpose_v, bool transpose_o) {
+    return mfa_attention_backward_kv_quantized_ex(
+        context, q, k, v, grad_output, logsumexp, d_values, grad_key, grad_value, batch_size, seq_len_q, seq_len_kv, num_heads,
+        num_heads, head_dim, q_scale, q_zero_point, k_scale, k_zero_point, v_scale, v_zero_point, q_precision, k_precision,
+        v_precision, causal, transpose_q, transpose_k, transpose_v, transpose_o, nullptr, nullptr, nullptr, nullptr, nullptr,
+        nullptr, 0, 0, 0, 0);
 }
 
 }  // extern "C"

@@ -128,6 +128,16 @@ def _load_library() -> ctypes.CDLL:
         _legacy + [mfa_precision_t] * 4 + [_i32, _u32, _u32, _u32, _b, _b] + [_b] * 4)
     sig("mfa_attention_forward_quantized_enhanced", mfa_error_t,
         _legacy + [mfa_precision_t] * 4 + [_i32, _u32, _u32, _u32, _b, _b] + [_b] * 4)
+    # pre-quantised backward (mfa_ffi.h:480-624): 8 buffers, dims, 3 x (scale, zero point), 3 precisions, 5 bools
+    _qb_tail = [_f32, _i32] * 3 + [_i32] * 3 + [_b] * 5
+    _qb_blocks = [mfa_buffer_t] * 6 + [_u32] * 4
+    _u16 = ctypes.c_uint16
+    sig("mfa_attention_backward_query_quantized", _i32, [mfa_context_t] + [mfa_buffer_t] * 8 + [_u32] * 4 + [_u16] + _qb_tail)
+    sig("mfa_attention_backward_kv_quantized", _i32, [mfa_context_t] + [mfa_buffer_t] * 8 + [_u32] * 4 + [_u16] + _qb_tail)
+    sig("mfa_attention_backward_query_quantized_ex", _i32,
+        [mfa_context_t] + [mfa_buffer_t] * 8 + [_u32] * 5 + [_u16] + _qb_tail + _qb_blocks)
+    sig("mfa_attention_backward_kv_quantized_ex", _i32,
+        [mfa_context_t] + [mfa_buffer_t] * 8 + [_u32] * 5 + [_u16] + _qb_tail + _qb_blocks)
     sig("mfa_set_scale_arrays", mfa_error_t,
         [mfa_context_t, ctypes.POINTER(_f32), _u32, ctypes.POINTER(_f32), _u32, ctypes.POINTER(_f32), _u32])
 

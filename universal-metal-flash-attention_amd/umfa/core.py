@@ -332,3 +332,42 @@ def attention_backward(context: MFAContext, dout, q, k, v, out, lse, *, causal: 
         for x in bufs:
             x.close()
     return dq, dk, dv, dvec
+
+
+def prequantized_backward(context: MFAContext, q, k, v, out, dout, lse, *, q_scale=1.0, k_scale=1.0, v_scale=1.0,
+                          q_zero_point=0, k_zero_point=0, v_zero_point=0, q_precision="int8", k_precision="int8",
+                          v_precision="int8", causal: bool = False, num_heads: Optional[int] = None,
+                          num_kv_heads: Optional[int] = None, head_dim: Optional[int] = None, seq_len_q=None,
+                          seq_len_kv=None, batch_size: int = 1, q_block_scales=None, k_block_scales=None,
+                          v_block_scales=None, q_block_size: int = 0, k_block_size: int = 0, v_block_size: int = 0):
+    """dQ, dK, dV (fp32) for caller-quantised operands through mfa_attention_backward_query_quantized_ex + _kv_ (the
+    query call produces D, the kv call consumes it; MFABridge.swift:1699-2163).  q/k/v: raw quantised arrays (int8, or
+    uint8 holding packed int4) laid out [B, H, S, D]; shapes are passed explicitly because packed int4 has none."""
+    prec = {"fp16": 0, "float16": 0, "bf16": 1, "bfloat16": 1, "fp32": 2, "float32": 2, "int8": 3, "int4": 4}
+    B, H, Hkv, Sq, Skv, D = batch_size, num_heads, num_kv_heads or num_heads, seq_len_q, seq_len_kv, head_dim
+    out = np.ascontiguousarray(out, np.float32)
+    dout = np.ascontiguousarray(dout, np.float32)
+    lse = np.ascontiguousarray(lse, np.float32)
+    dq = np.zeros((B, H, Sq, D), np.float32)
+    dk = np.zeros((B, Hkv, Skv, D), np.float32)
+    dv = np.zeros((B, Hkv, Skv, D), np.float32)
+    dvec = np.zeros(B * H * Sq, np.float32)
+
+    def opt(a):
+        return MFABuffer(context, np.ascontiguousarray(a, np.float32)) if a is not None else None
+    bufs = [MFABuffer(context, np.ascontiguousarray(a)) for a in (q, k, v, out, dout, lse, dq, dk, dv, dvec)]
+    blk = [opt(q_block_scales), opt(k_block_scales), opt(v_block_scales)]
+    bq, bk, bv, bo, bdo, bl, bdq, bdk, bdv, bd = (x.handle for x in bufs)
+    hb = [x.handle if x is not None else None for x in blk]
+    tail = (float(q_scale), int(q_zero_point), float(k_scale), int(k_zero_point), float(v_scale), int(v_zero_point),
+            prec[q_precision], prec[k_precision], prec[v_precision], bool(causal), False, False, False, False)
+    blocks = (hb[0], None, hb[1], None, hb[2], None, int(q_block_size), int(k_block_size), int(v_block_size), 0)
+    try:
+        _check_error(_lib.mfa_attention_backward_query_quantized_ex(context.handle, bq, bk, bv, bo, bdo, bl, bdq, bd, B, Sq,
+                                                                     Skv, H, Hkv, D, *tail, *blocks))
+        _check_error(_lib.mfa_attention_backward_kv_quantized_ex(context.handle, bq, bk, bv, bdo, bl, bd, bdk, bdv, B, Sq,
+                                                                  Skv, H, Hkv, D, *tail, *blocks))
+    finally:
+        for x in bufs + [y for y in blk if y is not None]:
+            x.close()
+    return dq, dk, dv, dvec
