@@ -106,7 +106,7 @@ def test_config4_int8_blockwise_S8192_H16_D128():
     q, k, v = (torch.randn(1, 16, 8192, 128, device="cuda", dtype=torch.bfloat16) for _ in range(3))
     k = k + torch.randn(1, 16, 1, 128, device="cuda", dtype=torch.bfloat16) * 2  # per-channel shift
     o8, lse = umfa_torch.quantized_attention_forward(q, k, v, bits=8, quant_mode="blockwise")
-    assert umfa_torch.last_kernel() == "fa_fwd_i8<128>" and torch.isfinite(o8).all()
+    assert umfa_torch.last_kernel() in ("fa_fwd_i8<128>", "fa_fwd_w64_i8<128>") and torch.isfinite(o8).all()
     o8b, _ = umfa_torch.quantized_attention_forward(q, k, v, bits=8, quant_mode="blockwise")
     assert torch.equal(o8, o8b)
     # rows of one head against the oracle's quantised restatement needs the whole slab quantised: compare

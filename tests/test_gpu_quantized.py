@@ -101,3 +101,29 @@ def test_quantized_backward_vs_oracle(ctx):
         assert np.abs(got - ref).max() < 2e-3 * max(1.0, np.abs(ref).max()), (name, np.abs(got - ref).max())
         cos = float((got * ref).sum() / np.sqrt((got ** 2).sum() * (ref ** 2).sum()))
         assert cos > 0.999
+
+
+@pytest.mark.parametrize("shape", [(1, 2, 256, 64), (1, 2, 256, 128), (2, 2, 512, 448), (1, 3, 1280, 1100), (1, 2, 768, 768),
+                                   (2, 24, 1024, 1024)])  # the last one: > 256 x 1 tile steps, i.e. real multi-tile loops
+@pytest.mark.parametrize("bits,mode", [(8, "blockwise"), (8, "tensor"), (4, "blockwise")])
+@pytest.mark.parametrize("causal", [False, True])
+def test_quantized_forward_w64_vs_oracle(ctx, shape, bits, mode, causal):
+    """head_dim 128 shapes that take the 64-rows-per-wave quantised kernel (fa_fwd_w64_i8): one / two / many key tiles,
+    items cut into parts, ragged Sq and Skv, causal; same operands and tolerances as the 128-row kernel above"""
+    import umfa
+    orc = _oracle()
+    B, H, Sq, Skv = shape
+    rng = np.random.default_rng(Sq + Skv + bits)
+    q = rng.standard_normal((B, H, Sq, 128)).astype(np.float32)
+    k = rng.standard_normal((B, H, Skv, 128)).astype(np.float32)
+    v = rng.standard_normal((B, H, Skv, 128)).astype(np.float32)
+    o, lse = umfa.quantized_attention(ctx, q, k, v, causal=causal, precision=f"int{bits}", quant_mode=mode,
+                                      layout="bhsd", return_lse=True)
+    assert ctx.last_kernel.startswith("fa_fwd_w64_i"), ctx.last_kernel
+    ref, rlse = orc.quantized_forward(q, k, v, causal=causal, bits=bits, quant_mode=0 if mode == "tensor" else 2)
+    assert np.isfinite(o).all()
+    assert rel_err(o, ref) < 2e-3, rel_err(o, ref)
+    assert np.abs(lse.reshape(rlse.shape) - rlse).max() < 2e-3
+    o2, _ = umfa.quantized_attention(ctx, q, k, v, causal=causal, precision=f"int{bits}", quant_mode=mode, layout="bhsd",
+                                     return_lse=True)
+    assert np.array_equal(o, o2)  # bitwise reproducible, including the fold of cut items

@@ -28,7 +28,22 @@ ABL = set(filter(None, os.environ.get("W64_ABL", "").split(",")))
 
 BUDGET = int(os.environ.get("W64_BUDGET", "24"))   # issue cycles available beside one MFMA
 EARLY_MAX = os.environ.get("W64_EARLY_MAX", "1") == "1"  # row max of key-block 0 during the QK of key-block 1, e = s*c - m spread to the end
-COST = {"MASK": 8, "DMAK": 8, "DMAV": 8, "NOP": 32, "EXP": 8, "ADD": 4, "CVT": 4, "VREAD": 8, "KREAD": 4, "MAX": 4, "DEC": 44, "FMA": 4}
+class Cfg:
+    """16-bit kernels: S = K Q^T is 32 MFMAs (8 k-steps of 16); int8 kernel (fa_fwd_w64_i8): 16 MFMAs
+    (v_mfma_i32_32x32x32_i8, 4 k-steps of 32), integer scores converted in place (I2F) before mask / max."""
+    def __init__(self, i8):
+        self.i8 = i8
+        self.NQK = 16 if i8 else 32      # MFMAs of the QK^T phase = first gap index of the PV phase
+        self.KS = 4 if i8 else 8         # k-steps per 32-key block
+        self.HALF = self.NQK // 2        # QK^T MFMAs per key block
+        self.NG = self.NQK + 32          # gaps per tile
+        self.KDMA = 2 if i8 else 4       # 1-KiB LDS-DMA pieces of a K tile per wave
+        self.KB_BYTES = 4096 if i8 else 8192  # LDS bytes of one 32-key block of the K tile image
+
+
+C = Cfg(False)
+
+COST = {"I2F": 4, "MASK": 8, "DMAK": 8, "DMAV": 8, "NOP": 32, "EXP": 8, "ADD": 4, "CVT": 4, "VREAD": 8, "KREAD": 4, "MAX": 4, "DEC": 44, "FMA": 4}
 
 NPRE = 4  # K fragments (kb=0, ks<NPRE) read before the iteration starts (by the includer, after the barrier)
 
@@ -64,7 +79,7 @@ class Roles:
 def qk_mfma(R, kb, ks, qb):
     t = tup(R.new, kb, qb)
     c = "0" if ks == 0 else t
-    return f'asm volatile(W64_MFMA " {t}, %0, %1, {c}" :: "v"(kf[{kb}][{ks}]), "a"(qf[{qb}][{ks}]));'
+    return f'asm volatile(W64_MFMA_QK " {t}, %0, %1, {c}" :: "v"(kf[{kb}][{ks}]), "a"(qf[{qb}][{ks}]));'
 
 
 def pv_mfma(R, st, db, qb):
@@ -93,7 +108,7 @@ def op_text(R, op):
         return f"vf[{st}][{db}] = v_frag(W64_VOFF, {db}, {st});"
     if kind == "KREAD":
         _, kb, ks = op
-        return f"kf[{kb}][{ks}] = k_frag(W64_KOFF + {kb * 8192}, {ks});"
+        return f"kf[{kb}][{ks}] = k_frag(W64_KOFF + {kb * C.KB_BYTES}, {ks});"
     if kind == "MAX":
         _, kb, qb, r, first = op
         v = base(R.new, kb, qb) + r
@@ -101,6 +116,10 @@ def op_text(R, op):
         if first:
             return f'asm volatile("v_max_f32 %0, v{v}, v{v + 1}" : "=v"(mx[{qb}][{c}]));'
         return f'asm volatile("v_max3_f32 %0, %0, v{v}, v{v + 1}" : "+v"(mx[{qb}][{c}]));'
+    if kind == "I2F":
+        _, kb, qb, r = op
+        v = base(R.new, kb, qb) + r
+        return f'asm volatile("v_cvt_f32_i32 v{v}, v{v}");'
     if kind == "MASK":
         # masking tiles: score (kb, qb, r) is masked  <=>  dmask[qb] + c > 0 with the element constant
         # c = 32 kb - 32 qb + (r & 3) + 8 (r >> 2) and the lane value dmask[qb] = max(causal term 64 t + 4 hi - row0 - ql
@@ -111,7 +130,7 @@ def op_text(R, op):
         return (f'asm volatile("v_cmp_lt_i32 vcc, {-c}, %0\\n\\tv_cndmask_b32 v{v}, v{v}, %1, vcc" :: "v"(dmask[{qb}]), "v"(neg_inf) : "vcc");')
     if kind == "DMAK":
         _, j = op
-        return (f'asm volatile("s_mov_b32 m0, %0\\n\\ts_nop 0\\n\\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_wave + W64_KDST + {j * 1024}), '
+        return (f'asm volatile("s_mov_b32 m0, %0\\n\\ts_nop 0\\n\\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_wave_k + W64_KDST + {j * 1024}), '
                 f'"v"(kdma[{j}]), "s"(k_srd) : "memory"); kdma[{j}] += k_step;')
     if kind == "DMAV":
         _, j = op
@@ -138,11 +157,11 @@ def exp_streams():
             prev = None
             for r in list(range(0, 16, 2)) + [None]:
                 if r is not None:
-                    dl = 32 + 8 * (2 * kb + (r >> 3)) - 2
+                    dl = C.NQK + 8 * (2 * kb + (r >> 3)) - 2
                     ops.append((("EXP", kb, qb, r), 0, dl))
                     ops.append((("EXP", kb, qb, r + 1), 0, dl))
                 if prev is not None:
-                    dl = 32 + 8 * (2 * kb + (prev >> 3)) - 2
+                    dl = C.NQK + 8 * (2 * kb + (prev >> 3)) - 2
                     ops.append((("ADD", kb, qb, prev), 0, dl))
                     ops.append((("ADD", kb, qb, prev + 1), 0, dl))
                     ops.append((("CVT", kb, qb, prev), 0, dl))
@@ -155,7 +174,7 @@ def vread_stream():
     ops = []
     for st in range(4):
         for db in range(4):
-            use = 32 + st * 8 + db * 2
+            use = C.NQK + st * 8 + db * 2
             ops.append((("VREAD", st, db), max(0, use - 10), use - 6))
     return ops
 
@@ -163,10 +182,10 @@ def vread_stream():
 def kread_stream():
     ops = []
     for kb in (0, 1):
-        for ks in range(8):
-            if kb == 0 and ks < NPRE:
+        for ks in range(C.KS):
+            if kb == 0 and ks < min(NPRE, C.KS):
                 continue
-            use = kb * 16 + ks * 2
+            use = kb * C.HALF + ks * 2
             ops.append((("KREAD", kb, ks), max(0, use - 12), max(0, use - 8)))
     return ops
 
@@ -176,61 +195,78 @@ def dma_stream():
     that ended tile i-1) so that the VMEM issue overlaps MFMA execution; waited on at the end of tile i."""
     ops = []
     for j in range(4):
-        ops.append((("DMAK", j), 1 + 4 * j, 3 + 4 * j))
-        ops.append((("DMAV", j), 3 + 4 * j, 5 + 4 * j))
+        if C.i8:
+            if j < C.KDMA:
+                ops.append((("DMAK", j), 1 + 2 * j, 3 + 2 * j))
+            ops.append((("DMAV", j), 2 + 2 * j, 4 + 2 * j))
+        else:
+            ops.append((("DMAK", j), 1 + 4 * j, 3 + 4 * j))
+            ops.append((("DMAV", j), 3 + 4 * j, 5 + 4 * j))
     return ops
 
 
 def start_streams(have_new, mfma_follows=True, masked=False):
-    """(causal diagonal tiles: mask ->) row max of S_new -> decision -> e = s*c - m in place.
-    Returns several streams (each consumed in order); cross-stream order is enforced by disjoint gap windows:
-    mask(kb) | max(kb) | decision | the four blocks of e = s*c - m in parallel (so that a block whose registers an
-    in-flight PV MFMA shadows - writes_near_mfma - can wait while another proceeds).  Four independent max chains
-    (two per q-block) are interleaved so consecutive ops never depend on each other."""
+    """(int8: convert the integer scores ->) (masking tiles: mask ->) row max of S_new -> decision -> e = s*c - m in
+    place.  Returns several streams (each consumed in order); cross-stream order is enforced by disjoint gap windows:
+    convert(kb) | mask(kb) | max(kb) | decision | the four blocks of e = s*c - m in parallel.  Four independent max
+    chains (two per q-block) are interleaved so consecutive ops never depend on each other."""
     if not have_new:
         return []
+    last = C.NG - 1
+    H = C.HALF
     if not mfma_follows:  # first tile of a segment: nothing to hide under, plain order
         ops = []
         for kb in (0, 1):
-            ready = kb * 16 + 14 + 2
+            ready = kb * H + (H - 2) + 2
             if kb == 1:
-                ops.append((("NOP",), 32, 63))
+                ops.append((("NOP",), C.NQK, last))
+            for qb in (0, 1):
+                for r in range(16):
+                    if C.i8:
+                        ops.append((("I2F", kb, qb, r), ready + qb, last))
             if masked:
                 for qb in (0, 1):
                     for r in range(16):
-                        ops.append((("MASK", kb, qb, r), ready + qb, 63))
+                        ops.append((("MASK", kb, qb, r), ready + qb, last))
             for r in range(0, 16, 2):
                 for qb in (0, 1):
-                    ops.append((("MAX", kb, qb, r, kb == 0 and r < 4), ready + qb, 63))
-        ops.append((("DEC",), 34, 63))
+                    ops.append((("MAX", kb, qb, r, kb == 0 and r < 4), ready + qb, last))
+        ops.append((("DEC",), C.NQK + 2, last))
         for kb in (0, 1):
             for qb in (0, 1):
                 for r in range(16):
-                    ops.append((("FMA", kb, qb, r), 36, 63))
+                    ops.append((("FMA", kb, qb, r), C.NQK + 4, last))
         return [ops]
-    if masked:
-        w_mask = {0: (16, 30), 1: (32, 44)}
-        w_max = {0: (31, 36), 1: (45, 50)}
-        w_dec, w_fma = (51, 52), (53, 62)
+    # gap windows (start, deadline) per stage; kb = 0 scores are complete at gap HALF, kb = 1 at gap NQK
+    if not C.i8:
+        if masked:
+            w = {"mask": {0: (16, 30), 1: (32, 44)}, "max": {0: (31, 36), 1: (45, 50)}, "dec": (51, 52), "fma": (53, 62)}
+        else:
+            w = {"max": {0: (16, 31), 1: (32, 40)}, "dec": (41, 43), "fma": (44, 61)}
     else:
-        w_mask = None
-        w_max = {0: (16, 31), 1: (32, 40)}
-        w_dec, w_fma = (41, 43), (44, 61)
+        if masked:
+            w = {"i2f": {0: (9, 13), 1: (17, 21)}, "mask": {0: (14, 20), 1: (22, 29)}, "max": {0: (21, 24), 1: (30, 33)},
+                 "dec": (34, 35), "fma": (36, 46)}
+        else:
+            w = {"i2f": {0: (9, 14), 1: (17, 22)}, "max": {0: (15, 19), 1: (23, 27)}, "dec": (28, 29), "fma": (30, 45)}
     streams = []
     for kb in (0, 1):
-        ready = kb * 16 + 14 + 2
+        ready = kb * H + (H - 2) + 2
+        if C.i8:
+            for qb in (0, 1):
+                streams.append([(("I2F", kb, qb, r), max(w["i2f"][kb][0], ready + qb), w["i2f"][kb][1]) for r in range(16)])
         if masked:
             for qb in (0, 1):
-                streams.append([(("MASK", kb, qb, r), max(w_mask[kb][0], ready + qb), w_mask[kb][1]) for r in range(16)])
+                streams.append([(("MASK", kb, qb, r), max(w["mask"][kb][0], ready + qb), w["mask"][kb][1]) for r in range(16)])
         mx = []
         for r in range(0, 16, 2):
             for qb in (0, 1):
-                mx.append((("MAX", kb, qb, r, kb == 0 and r < 4), max(w_max[kb][0], ready + qb), w_max[kb][1]))
+                mx.append((("MAX", kb, qb, r, kb == 0 and r < 4), max(w["max"][kb][0], ready + qb), w["max"][kb][1]))
         streams.append(mx)
-    streams.append([(("DEC",), w_dec[0], w_dec[1])])
+    streams.append([(("DEC",), w["dec"][0], w["dec"][1])])
     for kb in (0, 1):
         for qb in (0, 1):
-            streams.append([(("FMA", kb, qb, r), w_fma[0], w_fma[1]) for r in range(16)])
+            streams.append([(("FMA", kb, qb, r), w["fma"][0], w["fma"][1]) for r in range(16)])
     return streams
 
 
@@ -308,13 +344,19 @@ def check_part(placed, have_new, have_old, masked):
                         assert before(("ADD", kb, qb, dst), cv), ("CVT overwrites unread score", cv)
                         assert before(("CVT", kb, qb, dst & ~1), cv), ("CVT overwrites unpacked score", cv)
                     st = 2 * kb + (r >> 3)
-                    first_use = 32 + 8 * st  # first PV MFMA of this 16-key step (any d-block, any q-block)
+                    first_use = C.NQK + 8 * st  # first PV MFMA of this 16-key step (any d-block, any q-block)
                     assert pos[cv][0] < first_use, ("P fragment packed after its first PV MFMA", cv, pos[cv], first_use)
             if have_new:
-                last_mfma = kb * 16 + 14 + qb
+                last_mfma = kb * C.HALF + (C.HALF - 2) + qb
                 for r in range(0, 16, 2):
                     mxop = [o for o in pos if o[0] == "MAX" and o[1:4] == (kb, qb, r)][0]
                     assert pos[mxop][0] > last_mfma, ("row max reads an unfinished score tile", mxop)
+                    if C.i8:
+                        assert before(("I2F", kb, qb, r), mxop) and before(("I2F", kb, qb, r + 1), mxop), ("MAX before I2F", mxop)
+                        assert pos[("I2F", kb, qb, r)][0] > last_mfma, ("convert on an unfinished score tile", kb, qb, r)
+                        if masked:
+                            assert before(("I2F", kb, qb, r), ("MASK", kb, qb, r)), ("MASK before I2F", kb, qb, r)
+                            assert before(("I2F", kb, qb, r + 1), ("MASK", kb, qb, r + 1)), ("MASK before I2F", kb, qb, r + 1)
                     if masked:
                         assert before(("MASK", kb, qb, r), mxop) and before(("MASK", kb, qb, r + 1), mxop), ("MAX before MASK", mxop)
                     assert before(mxop, ("DEC",)), ("decision before MAX", mxop)
@@ -325,23 +367,23 @@ def check_part(placed, have_new, have_old, masked):
     if have_old:
         for st in range(4):
             for db in range(4):
-                assert pos[("VREAD", st, db)][0] < 32 + st * 8 + db * 2, ("V fragment read after its MFMA", st, db)
+                assert pos[("VREAD", st, db)][0] < C.NQK + st * 8 + db * 2, ("V fragment read after its MFMA", st, db)
     if have_new:
         for kb in (0, 1):
-            for ks in range(8):
+            for ks in range(C.KS):
                 if ("KREAD", kb, ks) in pos:
-                    assert pos[("KREAD", kb, ks)][0] < kb * 16 + ks * 2, ("K fragment read after its MFMA", kb, ks)
+                    assert pos[("KREAD", kb, ks)][0] < kb * C.HALF + ks * 2, ("K fragment read after its MFMA", kb, ks)
 
 
 def emit_part(lines, R, have_new, have_old, masked=False):
     mf = []
     if have_new:
         for kb in (0, 1):
-            for ks in range(8):
+            for ks in range(C.KS):
                 for qb in (0, 1):
                     mf.append(qk_mfma(R, kb, ks, qb))
     else:
-        mf += [None] * 32
+        mf += [None] * C.NQK
     if have_old:
         for st in range(4):
             for db in range(4):
@@ -357,10 +399,10 @@ def emit_part(lines, R, have_new, have_old, masked=False):
         streams += start_streams(True, have_old, masked)
         streams.append(kread_stream())
         streams.append(dma_stream())
-    placed = schedule(streams, 64)
+    placed = schedule(streams, C.NG)
     check_part(placed, have_new, have_old, masked)
     cyc = 0
-    for g in range(64):
+    for g in range(C.NG):
         if mf[g] is not None:
             lines.append(mf[g])
         for op in placed[g]:
@@ -405,14 +447,7 @@ def emit_helpers(lines):
         a("}")
 
 
-def main():
-    helpers = []
-    emit_helpers(helpers)
-    hp = Path(__file__).resolve().parent.parent / "universal-metal-flash-attention_amd" / "csrc" / "fa_fwd16_w64_regs.inc"
-    hp.write_text("\n".join(helpers) + "\n")
-    out = Path(__file__).resolve().parent.parent / "universal-metal-flash-attention_amd" / "csrc" / "fa_fwd16_w64_body.inc"
-    if os.environ.get("W64_OUT"):
-        out = Path(os.environ["W64_OUT"])
+def emit_body(out):
     lines = ["// GENERATED by tools/gen_w64_body.py -- do not edit; see that file for the placement rules.",
              "#if W64_PART == 0  // first tile of a segment: S -> set A"]
     emit_part(lines, Roles("a", "b"), True, False)
@@ -424,15 +459,27 @@ def main():
     emit_part(lines, Roles("b", "a"), False, True)
     lines.append("#elif W64_PART == 4  // drain, last tile in set B")
     emit_part(lines, Roles("a", "b"), False, True)
-    lines.append("#elif W64_PART == 5  // causal diagonal tile, first tile of a segment")
+    lines.append("#elif W64_PART == 5  // masking tile (causal diagonal / ragged last key tile), first tile of a segment")
     emit_part(lines, Roles("a", "b"), True, False, masked=True)
-    lines.append("#elif W64_PART == 6  // causal diagonal tile, odd")
+    lines.append("#elif W64_PART == 6  // masking tile, odd")
     emit_part(lines, Roles("b", "a"), True, True, masked=True)
-    lines.append("#elif W64_PART == 7  // causal diagonal tile, even")
+    lines.append("#elif W64_PART == 7  // masking tile, even")
     emit_part(lines, Roles("a", "b"), True, True, masked=True)
     lines.append("#endif")
     out.write_text("\n".join(lines) + "\n")
     print("wrote", out, len(lines), "lines")
+
+
+def main():
+    global C
+    csrc = Path(__file__).resolve().parent.parent / "universal-metal-flash-attention_amd" / "csrc"
+    helpers = []
+    emit_helpers(helpers)
+    (csrc / "fa_fwd16_w64_regs.inc").write_text("\n".join(helpers) + "\n")
+    C = Cfg(False)
+    emit_body(Path(os.environ["W64_OUT"]) if os.environ.get("W64_OUT") else csrc / "fa_fwd16_w64_body.inc")
+    C = Cfg(True)
+    emit_body(Path(os.environ["W64_OUT_I8"]) if os.environ.get("W64_OUT_I8") else csrc / "fa_fwd_w64_i8_body.inc")
 
 
 if __name__ == "__main__":

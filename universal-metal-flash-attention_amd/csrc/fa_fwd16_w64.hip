@@ -45,18 +45,42 @@ struct W64Params {
 // ---- asm-owned accumulator registers: helpers with literal register numbers (generated)
 #include "fa_fwd16_w64_regs.inc"
 
+// int8 K tile image: rows of 128 bytes, 16-byte chunks XOR-swizzled for conflict-free ds_read_b128 (same rule as
+// fa_quant.hip k8_off<128>)
+__device__ __forceinline__ constexpr int k8_off_128(int row, int ch) { return row * 128 + 16 * (ch ^ ((row >> 1) & 7)); }
+
+struct W64I8Params {
+    const int8_t* q8;       // [B*H*Sq][128] int8 (quantiser workspace)
+    const int8_t* k8;       // [B*H*Skv][128]
+    const _Float16* v16;    // [B*H*Skv][128] fp16, de-quantised
+    const float* q_scale;   // [B*H][nqblk], one per 64 rows
+    const float* k_scale;   // [B*H][nkblk]
+    void* o;                // fp32 [B,H,Sq,128]
+    float* lse;
+    uint32_t B, H, Sq, Skv, nqblk, nkblk;
+    float scale;
+    uint32_t n_items, T;
+    float* part_buf;
+    uint32_t* part_cnt;
+};
+
+#define W64_I8 0
+#define W64_BODY_INC "fa_fwd16_w64_body.inc"
 #define W64_T __bf16
 #define W64_MFMA "v_mfma_f32_32x32x16_bf16"
+#define W64_MFMA_QK "v_mfma_f32_32x32x16_bf16"
 #define W64_CVT "v_cvt_pk_bf16_f32"
 #define W64_KERNEL fa_fwd16_w64_bf16
 #include "fa_fwd16_w64_kernel.inc"
 #undef W64_T
 #undef W64_MFMA
+#undef W64_MFMA_QK
 #undef W64_CVT
 #undef W64_KERNEL
 
 #define W64_T _Float16
 #define W64_MFMA "v_mfma_f32_32x32x16_f16"
+#define W64_MFMA_QK "v_mfma_f32_32x32x16_f16"
 #define W64_CVT "v_cvt_pk_f16_f32"
 #define W64_KERNEL fa_fwd16_w64_f16
 #include "fa_fwd16_w64_kernel.inc"
@@ -64,6 +88,27 @@ struct W64Params {
 #undef W64_MFMA
 #undef W64_CVT
 #undef W64_KERNEL
+#undef W64_MFMA_QK
+#undef W64_I8
+#undef W64_BODY_INC
+
+// runtime-quantised variant: int8 QK^T, fp16 PV
+#define W64_I8 1
+#define W64_BODY_INC "fa_fwd_w64_i8_body.inc"
+#define W64_T _Float16
+#define W64_MFMA "v_mfma_f32_32x32x16_f16"
+#define W64_MFMA_QK "v_mfma_i32_32x32x32_i8"
+#define W64_CVT "v_cvt_pk_f16_f32"
+#define W64_KERNEL fa_fwd_w64_i8
+#include "fa_fwd16_w64_kernel.inc"
+#undef W64_T
+#undef W64_MFMA
+#undef W64_MFMA_QK
+#undef W64_CVT
+#undef W64_KERNEL
+#undef W64_I8
+#undef W64_BODY_INC
+
 
 static int w64_cu_count() {
     static int n = 0;
@@ -107,11 +152,16 @@ template <typename KFN>
 static hipError_t launch_w64_kernel(KFN kfn, const FwdParams& p, const W64Params& wp, hipStream_t stream) {
     const uint32_t grid = w64_grid(p);
     const size_t lds = 65536 + 4 * 32 * (512 + 16);  // K/V rings + per-wave output staging
-    static bool attr_set = false;  // one flag per instantiation of this template
-    if (!attr_set) {
+    // (KFN is the same function-pointer type for every kernel here, so a static flag would be shared: keep a small
+    // table of the kernels that already have the attribute)
+    static const void* done[16] = {};
+    bool seen = false;
+    for (const void* d : done) seen |= d == (const void*)kfn;
+    if (!seen) {
         hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        for (const void*& d : done)
+            if (!d) { d = (const void*)kfn; break; }
     }
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, stream, wp);
     return hipGetLastError();
@@ -143,6 +193,40 @@ hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cn
                                     : launch_w64_kernel(fa_fwd16_w64_f16<_Float16, true>, p, wp, stream);
     return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64_f16<float, false>, p, wp, stream)
                                 : launch_w64_kernel(fa_fwd16_w64_f16<_Float16, false>, p, wp, stream);
+}
+
+// ---- runtime-quantised variant ---------------------------------------------------------------------------------
+bool fwd_w64_i8_supported(const FwdParams& p) {
+    static const bool off = [] { const char* e = getenv("UMFA_NO_W64"); return e && e[0] == '1'; }();
+    if (off || p.D != 128 || p.mask_kind != MK_NONE || p.mask) return false;
+    if (!(p.scale > 0.0f)) return false;
+    if (p.Skv < 64 || p.Sq < 256 || (p.Sq % 256 != 0 && p.Sq < 1024)) return false;
+    return true;
+}
+
+hipError_t launch_fwd_w64_i8(const FwdParams& p, const QuantViews& v, float* part_buf, uint32_t* part_cnt, hipStream_t stream) {
+    if (!fwd_w64_i8_supported(p) || !part_buf || !part_cnt || v.dpq != 128) return hipErrorNotSupported;
+    W64I8Params wp;
+    wp.q8 = v.q8; wp.k8 = v.k8; wp.v16 = (const _Float16*)v.v16;
+    wp.q_scale = v.q_scale; wp.k_scale = v.k_scale;
+    wp.o = p.o; wp.lse = p.lse;
+    wp.B = p.B; wp.H = p.H; wp.Sq = p.Sq; wp.Skv = p.Skv; wp.nqblk = v.nqblk; wp.nkblk = v.nkblk;
+    wp.scale = p.scale;
+    wp.n_items = p.B * p.H * ((p.Sq + 255) / 256);
+    wp.T = (p.Skv + 63) / 64;
+    wp.part_buf = part_buf;
+    wp.part_cnt = part_cnt;
+    const uint32_t grid = w64_grid(p);
+    const size_t lds = 65536 + 4 * 32 * (512 + 16);
+    auto kfn = p.causal ? fa_fwd_w64_i8<float, true> : fa_fwd_w64_i8<float, false>;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[p.causal ? 1 : 0]) {
+        hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set[p.causal ? 1 : 0] = true;
+    }
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, stream, wp);
+    return hipGetLastError();
 }
 
 }  // namespace umfa

@@ -535,6 +535,10 @@ hipError_t launch_quantized_fwd(const FwdParams& fp, int bits, int quant_mode, v
     p.nqblk = v.nqblk; p.nkblk = v.nkblk;
     p.scale = fp.scale;
     const uint32_t dp = dp_of(fp.D);
+    if (fp.part_buf && fp.part_cnt && fwd_w64_i8_supported(fp)) {
+        *name = bits == 4 ? "fa_fwd_w64_i4<128>" : "fa_fwd_w64_i8<128>";
+        return launch_fwd_w64_i8(fp, v, fp.part_buf, fp.part_cnt, stream);
+    }
     if (dp == 64) { *name = bits == 4 ? "fa_fwd_i4<64>" : "fa_fwd_i8<64>"; return launch_i8_flags<64>(p, fp.causal, stream); }
     if (dp == 128) { *name = bits == 4 ? "fa_fwd_i4<128>" : "fa_fwd_i8<128>"; return launch_i8_flags<128>(p, fp.causal, stream); }
     *name = bits == 4 ? "fa_fwd_i4<256>" : "fa_fwd_i8<256>";

@@ -87,5 +87,9 @@ hipError_t launch_quantize(const void* q, const void* k, const void* v, int in_p
 // fp.q/k/v: contiguous BHSD in fp.in_prec; fp.o fp32; fp.mask: fp32 additive [B,H,Sq,Skv] or NULL.
 hipError_t launch_quantized_fwd(const FwdParams& fp, int bits, int quant_mode, void* workspace, hipStream_t stream,
                                 const char** name);
+// 64-rows-per-wave variant of the quantised forward (fa_fwd16_w64.hip): head_dim 128, no mask; fp.part_buf / part_cnt as
+// for launch_fwd_w64.  launch_quantized_fwd takes it when fp.part_buf is set and the shape qualifies.
+bool fwd_w64_i8_supported(const FwdParams& p);
+hipError_t launch_fwd_w64_i8(const FwdParams& p, const QuantViews& v, float* part_buf, uint32_t* part_cnt, hipStream_t stream);
 
 }  // namespace umfa

@@ -112,6 +112,13 @@ int32_t mfa_quantized_forward_with_lse(mfa_context_t context, mfa_buffer_t q, mf
     p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv; p.D = D;
     p.scale = softmax_scale; p.causal = causal ? 1 : 0;
     p.in_prec = prec; p.out_prec = P_FP32;
+    if (fwd_w64_i8_supported(p)) {  // scratch of the 64-rows-per-wave kernel (tickets + partials), as for the dense path
+        const FwdW64Plan plan = fwd_w64_plan(p);
+        if (char* w64 = (char*)ctx->ensure_w64(plan.cnt_bytes, plan.buf_bytes)) {
+            p.part_cnt = (uint32_t*)w64;
+            p.part_buf = (float*)(w64 + ctx->w64_cnt_bytes);
+        }
+    }
     LatencyScope lat(ctx, stream);
     const char* name = "none";
     hipError_t e = launch_quantized_fwd(p, bits, mode, ws, stream, &name);
