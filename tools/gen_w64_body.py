@@ -193,15 +193,18 @@ def kread_stream():
 def dma_stream():
     """LDS-DMA of K(i+1) and V(i), issued in the first gaps of tile i (their ring slots were released by the barrier
     that ended tile i-1) so that the VMEM issue overlaps MFMA execution; waited on at the end of tile i."""
-    ops = []
-    for j in range(4):
-        if C.i8:
-            if j < C.KDMA:
-                ops.append((("DMAK", j), 1 + 2 * j, 3 + 2 * j))
-            ops.append((("DMAV", j), 2 + 2 * j, 4 + 2 * j))
-        else:
-            ops.append((("DMAK", j), 1 + 4 * j, 3 + 4 * j))
-            ops.append((("DMAV", j), 3 + 4 * j, 5 + 4 * j))
+    # first gap of each instruction (window of 3 gaps).  Two LDS-DMA instructions in one gap stall the MFMA behind
+    # them: back-to-back placement -7 %, one every 2 gaps baseline, one every 4 gaps +6.5 % (same-box A/B at FLUX);
+    # W64_DMA_K / W64_DMA_V (W64_DMA_K_I8 / _V_I8) override for experiments.
+    sfx = "_I8" if C.i8 else ""
+    kpos = [1, 4] if C.i8 else [1, 9, 17, 25]
+    vpos = [2, 6, 8, 10] if C.i8 else [5, 13, 21, 29]
+    if os.environ.get("W64_DMA_K" + sfx):
+        kpos = [int(x) for x in os.environ["W64_DMA_K" + sfx].split(",")]
+    if os.environ.get("W64_DMA_V" + sfx):
+        vpos = [int(x) for x in os.environ["W64_DMA_V" + sfx].split(",")]
+    ops = [(("DMAK", j), kpos[j], kpos[j] + 2) for j in range(C.KDMA)] + [(("DMAV", j), vpos[j], vpos[j] + 2) for j in range(4)]
+    ops.sort(key=lambda o: o[1])
     return ops
 
 
