@@ -27,6 +27,8 @@ from pathlib import Path
 ABL = set(filter(None, os.environ.get("W64_ABL", "").split(",")))
 
 BUDGET = int(os.environ.get("W64_BUDGET", "24"))   # issue cycles available beside one MFMA
+VR_EARLY, VR_LATE = (int(x) for x in os.environ.get("W64_VREAD", "10,6").split(","))   # V fragment read: gaps before its MFMA
+KR_EARLY, KR_LATE = (int(x) for x in os.environ.get("W64_KREAD", "12,8").split(","))   # K fragment read
 EARLY_MAX = os.environ.get("W64_EARLY_MAX", "1") == "1"  # row max of key-block 0 during the QK of key-block 1, e = s*c - m spread to the end
 class Cfg:
     """16-bit kernels: S = K Q^T is 32 MFMAs (8 k-steps of 16); int8 kernel (fa_fwd_w64_i8): 16 MFMAs
@@ -175,7 +177,7 @@ def vread_stream():
     for st in range(4):
         for db in range(4):
             use = C.NQK + st * 8 + db * 2
-            ops.append((("VREAD", st, db), max(0, use - 10), use - 6))
+            ops.append((("VREAD", st, db), max(0, use - VR_EARLY), use - VR_LATE))
     return ops
 
 
@@ -186,7 +188,7 @@ def kread_stream():
             if kb == 0 and ks < min(NPRE, C.KS):
                 continue
             use = kb * C.HALF + ks * 2
-            ops.append((("KREAD", kb, ks), max(0, use - 12), max(0, use - 8)))
+            ops.append((("KREAD", kb, ks), max(0, use - KR_EARLY), max(0, use - KR_LATE)))
     return ops
 
 
