@@ -1,3 +1,8 @@
-timeout 900 python -m pytest tests/test_gpu_w64.py tests/test_gpu_quantized.py -m gpu -q 2>&1 | tail -3
-python bench.py --steps 100 --warmup 10 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['roofline']['kernel_ms_mean'], d['int8'])"
-for s in "1 16 8192 128" "2 24 4096 128" "4 16 8192 128 causal" "1 24 4096 128 causal"; do python tools/bench_one.py $s; done
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+python3 bench.py --steps 50 --warmup 10 > gpurun_out/bench_r1_final.json 2> gpurun_out/bench_r1_final.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r1_end_stats -- python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-graph > gpurun_out/bench_r1_final_prof.json 2> gpurun_out/bench_r1_final_prof.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/r1_end_pmc_fetch -- python3 tools/run_fwd.py 5 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/r1_end_pmc_write -- python3 tools/run_fwd.py 5 > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU --kernel-trace --output-format csv -d gpurun_out/r1_end_pmc_sq -- python3 tools/run_fwd.py 5 > /dev/null 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d gpurun_out/r1_end_pmc_lds -- python3 tools/run_fwd.py 5 > /dev/null 2>&1
+cat gpurun_out/bench_r1_final.json | cut -c1-1600
