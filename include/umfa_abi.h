@@ -324,6 +324,12 @@ mfa_error_t umfa_attention_forward_stream(
     uint32_t seq_len_kv, uint32_t num_heads, uint16_t head_dim, float softmax_scale, bool causal,
     int32_t input_precision, int32_t intermediate_precision);
 /* Name of the kernel variant the last forward on this context dispatched to (static string). */
+/* MI355X extra: the runtime quantiser alone, on a device tensor [batch_heads, rows, head_dim]; writes the int8 image
+ * (rows padded to *padded_row_bytes = 64 / 128 / 256) and one fp32 scale per 64-row block to device buffers.  Exists so
+ * that the integer half of the quantised path can be compared bit-for-bit with the oracle. */
+int32_t umfa_quantize_rows(mfa_context_t context, void* stream, const void* src, int32_t input_precision,
+                           uint32_t batch_heads, uint32_t rows, uint32_t head_dim, int32_t bits, int32_t quant_mode,
+                           void* q8_out, void* scales_out, uint32_t* padded_row_bytes);
 const char* umfa_last_kernel_name(mfa_context_t context);
 
 #undef UMFA_QUANT_LEGACY_ARGS

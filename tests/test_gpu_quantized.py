@@ -127,3 +127,48 @@ def test_quantized_forward_w64_vs_oracle(ctx, shape, bits, mode, causal):
     o2, _ = umfa.quantized_attention(ctx, q, k, v, causal=causal, precision=f"int{bits}", quant_mode=mode, layout="bhsd",
                                      return_lse=True)
     assert np.array_equal(o, o2)  # bitwise reproducible, including the fold of cut items
+
+
+@pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
+@pytest.mark.parametrize("bits,mode", [(8, 2), (8, 0), (4, 2)])
+def test_quantiser_is_bit_exact_with_the_oracle(dt, bits, mode):
+    """integer work: the int8 / int4 values and the fp32 scales of the runtime quantiser must equal the oracle's
+    (QuantizationTests.swift:72-128: scale = absmax / qmax, q = clamp(round-half-away(x / scale))) bit for bit,
+    including values that sit exactly on or next to a rounding boundary"""
+    import ctypes
+    import umfa_torch
+    from umfa._ffi import _lib, _check_error
+    from umfa_torch import ops
+    orc = _oracle()
+    torch.manual_seed(bits + mode)
+    BH, S, D = 6, 200, 128
+    x = torch.randn(BH, S, D, device="cuda")
+    # plant boundary cases: exact multiples of scale/2 of the first block once its scale is absmax / qmax
+    qmax = 127.0 if bits == 8 else 7.0
+    x[0, 0, 0] = 4.0                                   # becomes the block absmax -> scale = 4 / qmax exactly
+    x[0, 1, :16] = torch.arange(16, device="cuda") * (4.0 / qmax) + (2.0 / qmax)   # k + 0.5 steps: ties
+    x[0, 2, :16] = -x[0, 1, :16]
+    tdt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[dt]
+    xt = x.to(tdt).contiguous()
+    q8 = torch.empty(BH * S * 128, dtype=torch.int8, device="cuda")
+    sc = torch.empty(BH * ((S + 63) // 64), dtype=torch.float32, device="cuda")
+    pad = ctypes.c_uint32(0)
+    stream = torch.cuda.current_stream().cuda_stream
+    _check_error(_lib.umfa_quantize_rows(ops.context(), ctypes.c_void_p(stream), ctypes.c_void_p(xt.data_ptr()),
+                                         {"fp16": 0, "bf16": 1, "fp32": 2}[dt], BH, S, D, bits, mode,
+                                         ctypes.c_void_p(q8.data_ptr()), ctypes.c_void_p(sc.data_ptr()), ctypes.byref(pad)))
+    torch.cuda.synchronize()
+    assert pad.value == 128
+    got_q = q8.cpu().numpy().reshape(BH, S, 128)
+    got_s = sc.cpu().numpy().reshape(BH, -1)
+    xf = xt.float().cpu().numpy()
+    if mode == 2:  # one scale per 64-row block of a (batch, head) slab
+        for bh in range(BH):
+            for b0 in range(0, S, 64):
+                ref_q, ref_s = orc.quantize_symmetric(xf[bh, b0:b0 + 64], bits=bits)
+                assert np.array_equal(got_q[bh, b0:b0 + 64].ravel(), ref_q), (bh, b0)
+                assert got_s[bh, b0 // 64] == ref_s[0]
+    else:          # one scale for the whole tensor
+        ref_q, ref_s = orc.quantize_symmetric(xf, bits=bits)
+        assert np.array_equal(got_q.ravel(), ref_q)
+        assert (got_s == ref_s[0]).all()

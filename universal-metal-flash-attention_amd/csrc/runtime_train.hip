@@ -411,4 +411,29 @@ int32_t mfa_attention_backward_kv_quantized(
         nullptr, 0, 0, 0, 0);
 }
 
+// MI355X extra (not in the reference ABI): run the runtime quantiser on one device tensor [BH, S, D] and hand back its
+// int8 image (rows padded to 64 / 128 / 256 bytes) and the per-64-row-block scales -- the integer half of the quantised
+// path, exposed so that it can be checked bit-for-bit against the oracle (tests/test_gpu_quantized.py).
+int32_t umfa_quantize_rows(mfa_context_t context, void* stream_handle, const void* src, int32_t input_precision,
+                           uint32_t batch_heads, uint32_t rows, uint32_t head_dim, int32_t bits, int32_t quant_mode,
+                           void* q8_out, void* scales_out, uint32_t* padded_row_bytes) {
+    Context* ctx = as_ctx(context);
+    if (!ctx || !src || !q8_out || !scales_out || !quantized_supported(head_dim)) return MFA_ERROR_INVALID_ARGS;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    (void)hipSetDevice(ctx->device);
+    hipStream_t stream = (hipStream_t)stream_handle;
+    void* ws = ctx->ensure_workspace(quant_workspace_bytes(1, batch_heads, rows, rows, head_dim, false));
+    if (!ws) return MFA_ERROR_MEMORY_ALLOCATION;
+    QuantViews v;
+    if (launch_quantize(src, src, src, dense_prec(input_precision), 1, batch_heads, rows, rows, head_dim, bits == 4 ? 4 : 8,
+                        quant_mode == 2 ? 2 : 0, ws, false, &v, stream) != hipSuccess)
+        return MFA_ERROR_EXECUTION_FAILED;
+    if (hipMemcpyAsync(q8_out, v.q8, (size_t)batch_heads * rows * v.dpq, hipMemcpyDeviceToDevice, stream) != hipSuccess ||
+        hipMemcpyAsync(scales_out, v.q_scale, (size_t)batch_heads * v.nqblk * sizeof(float), hipMemcpyDeviceToDevice, stream) !=
+            hipSuccess)
+        return MFA_ERROR_EXECUTION_FAILED;
+    if (padded_row_bytes) *padded_row_bytes = v.dpq;
+    return MFA_SUCCESS;
+}
+
 }  // extern "C"
