@@ -29,6 +29,7 @@ ABL = set(filter(None, os.environ.get("W64_ABL", "").split(",")))
 BUDGET = int(os.environ.get("W64_BUDGET", "24"))   # issue cycles available beside one MFMA
 VR_EARLY, VR_LATE = (int(x) for x in os.environ.get("W64_VREAD", "10,6").split(","))   # V fragment read: gaps before its MFMA
 KR_EARLY, KR_LATE = (int(x) for x in os.environ.get("W64_KREAD", "12,8").split(","))   # K fragment read
+MIDBAR = os.environ.get("W64_MIDBAR", "0") == "1"  # per-tile barrier in the middle of the PV phase (see mid_barrier_streams)
 EARLY_MAX = os.environ.get("W64_EARLY_MAX", "1") == "1"  # row max of key-block 0 during the QK of key-block 1, e = s*c - m spread to the end
 class Cfg:
     """16-bit kernels: S = K Q^T is 32 MFMAs (8 k-steps of 16); int8 kernel (fa_fwd_w64_i8): 16 MFMAs
@@ -45,7 +46,7 @@ class Cfg:
 
 C = Cfg(False)
 
-COST = {"I2F": 4, "MASK": 8, "DMAK": 8, "DMAV": 8, "NOP": 32, "EXP": 8, "ADD": 4, "CVT": 4, "VREAD": 8, "KREAD": 4, "MAX": 4, "DEC": 44, "FMA": 4}
+COST = {"BAR": 16, "KPRE": 4, "I2F": 4, "MASK": 8, "DMAK": 8, "DMAV": 8, "NOP": 32, "EXP": 8, "ADD": 4, "CVT": 4, "VREAD": 8, "KREAD": 4, "MAX": 4, "DEC": 44, "FMA": 4}
 
 NPRE = 4  # K fragments (kb=0, ks<NPRE) read before the iteration starts (by the includer, after the barrier)
 
@@ -118,6 +119,10 @@ def op_text(R, op):
         if first:
             return f'asm volatile("v_max_f32 %0, v{v}, v{v + 1}" : "=v"(mx[{qb}][{c}]));'
         return f'asm volatile("v_max3_f32 %0, %0, v{v}, v{v + 1}" : "+v"(mx[{qb}][{c}]));'
+    if kind == "BAR":
+        return "W64_ITER_BARRIER();"
+    if kind == "KPRE":
+        return f"kf[0][{op[1]}] = k_frag(W64_KNEXT, {op[1]});"
     if kind == "I2F":
         _, kb, qb, r = op
         v = base(R.new, kb, qb) + r
@@ -172,13 +177,34 @@ def exp_streams():
     return streams
 
 
-def vread_stream():
+def bar_gap():
+    return C.NQK + 16  # MIDBAR: behind the PV MFMAs of 16-key steps 0 and 1
+
+
+def vread_stream(have_new=True):
     ops = []
     for st in range(4):
         for db in range(4):
             use = C.NQK + st * 8 + db * 2
-            ops.append((("VREAD", st, db), max(0, use - VR_EARLY), use - VR_LATE))
+            early, late = max(0, use - VR_EARLY), use - VR_LATE
+            if MIDBAR and have_new:  # every V read of the tile sits before the barrier (the slot is refilled behind it)
+                late = min(late, bar_gap() - 2)
+                early = min(early, late - 3)
+            ops.append((("VREAD", st, db), early, late))
     return ops
+
+
+def mid_barrier_streams(have_old):
+    """MIDBAR: the per-tile s_barrier sits in the MIDDLE of the PV phase instead of at the end of the tile.  The MFMAs
+    right behind it (PV of 16-key steps 2, 3) have their operands in registers already, so nothing waits on LDS
+    there, and the first K fragments of the NEXT tile (visible only after this barrier) are read under those MFMAs
+    instead of in front of the next tile's first MFMA.  WAR safety: all V reads of this tile come before the
+    barrier (the V slot is refilled by the next tile's DMA), all K reads are in the first half anyway."""
+    if have_old:
+        g = bar_gap()
+        return [[(("BAR",), g, g)], [(("KPRE", ks), g + 1, g + 10) for ks in range(min(NPRE, C.KS))]]
+    last = C.NG - 1  # first tile of a segment (no PV): barrier + prefetch close the part
+    return [[(("BAR",), last, last)] + [(("KPRE", ks), last, last) for ks in range(min(NPRE, C.KS))]]
 
 
 def kread_stream():
@@ -369,6 +395,13 @@ def check_part(placed, have_new, have_old, masked):
                     assert before(("DEC",), ("FMA", kb, qb, r)), ("FMA before decision", kb, qb, r)
                     if masked:
                         assert pos[("MASK", kb, qb, r)][0] > last_mfma, ("mask on an unfinished score tile", kb, qb, r)
+    if MIDBAR and have_new:
+        bar = pos[("BAR",)]
+        for op, at in pos.items():
+            if op[0] in ("VREAD", "KREAD", "DMAK", "DMAV"):
+                assert at < bar, ("before the barrier", op)
+            if op[0] == "KPRE":
+                assert at > bar, ("next tile's K fragments are visible only behind the barrier", op)
     if have_old:
         for st in range(4):
             for db in range(4):
@@ -399,11 +432,13 @@ def emit_part(lines, R, have_new, have_old, masked=False):
     streams = []
     if have_old:
         streams += exp_streams()
-        streams.append(vread_stream())
+        streams.append(vread_stream(have_new))
     if have_new:
         streams += start_streams(True, have_old, masked)
         streams.append(kread_stream())
         streams.append(dma_stream())
+        if MIDBAR:
+            streams += mid_barrier_streams(have_old)
     placed = schedule(streams, C.NG)
     check_part(placed, have_new, have_old, masked)
     cyc = 0
