@@ -1,0 +1,96 @@
+"""Build-time contracts of the 64-rows-per-wave kernels (fa_fwd16_w64.hip), checked without a GPU:
+
+1. Register ownership.  The kernels address v[128:255] (score tiles) and a[128:255] (O^T) by literal number inside inline
+   asm and rely on `amdgpu_num_vgpr(128)` keeping the COMPILER inside v[0:127] + a[0:127].  The test compiles the file to
+   gfx950 assembly and checks that no instruction outside the asm blocks names a register above 127, that every kernel
+   still gets the full 512-register file, and that nothing is spilled to scratch inside the tile loop.
+2. The committed generated instruction streams (*_body.inc, *_regs.inc) are exactly what tools/gen_w64_body.py emits now
+   (its self-check - every consumer behind its producer - runs as part of the generation)."""
+import os
+import re
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+CSRC = ROOT / "universal-metal-flash-attention_amd" / "csrc"
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def asm(tmp_path_factory):
+    if not Path(HIPCC).exists():
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("w64") / "fa_fwd16_w64.s"
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-w", "--cuda-device-only",
+                           "-S", str(CSRC / "fa_fwd16_w64.hip"), "-o", str(out)], cwd=CSRC)
+    return out.read_text()
+
+
+def _kernels(text):
+    """name -> list of lines of the kernel body"""
+    out, cur, name = {}, None, None
+    for line in text.split("\n"):
+        m = re.match(r"^(_ZN4umfa\w+):", line)
+        if m:
+            name, cur = m.group(1), []
+            out[name] = cur
+        elif cur is not None:
+            cur.append(line)
+            if "s_endpgm" in line:
+                cur = None
+    return out
+
+
+def test_compiler_stays_in_the_lower_register_halves(asm):
+    kernels = _kernels(asm)
+    assert len(kernels) == 10, sorted(kernels)  # bf16 / fp16 x {fp32, 16-bit O} x {causal, not} + int8 x {causal, not}
+    for name, lines in kernels.items():
+        in_asm, vmax, amax, n_mfma, loop_scratch = False, 0, 0, 0, 0
+        mfma_seen = 0
+        total_mfma = sum("v_mfma" in l for l in lines)
+        for l in lines:
+            if "ASMSTART" in l:
+                in_asm = True
+            elif "ASMEND" in l:
+                in_asm = False
+            elif in_asm:
+                mfma_seen += "v_mfma" in l
+            else:
+                for m in re.findall(r"\bv(\d+)\b", l):
+                    vmax = max(vmax, int(m))
+                for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", l):
+                    vmax = max(vmax, int(b))
+                for m in re.findall(r"\ba(\d+)\b", l):
+                    amax = max(amax, int(m))
+                for a, b in re.findall(r"\ba\[(\d+):(\d+)\]", l):
+                    amax = max(amax, int(b))
+                if "scratch_" in l and 0 < mfma_seen < total_mfma:
+                    loop_scratch += 1
+        assert total_mfma >= 250, (name, total_mfma)          # 8 tile-body variants of 48-64 inline-asm MFMAs each
+        assert vmax <= 127 and amax <= 127, (name, vmax, amax)  # the compiler never names our registers
+        assert loop_scratch == 0, (name, loop_scratch)          # no scratch spill between the first and the last MFMA
+
+
+def test_every_kernel_gets_512_registers(asm):
+    nxt = [int(x) for x in re.findall(r"\.amdhsa_next_free_vgpr (\d+)", asm)]
+    acc = [int(x) for x in re.findall(r"\.amdhsa_accum_offset (\d+)", asm)]
+    assert len(nxt) == 10 and all(n == 512 for n in nxt), nxt
+    assert all(a == 256 for a in acc), acc
+
+
+def test_generated_streams_are_current(tmp_path):
+    env = dict(os.environ)
+    for k in list(env):
+        if k.startswith("W64_"):
+            del env[k]
+    env["W64_OUT"] = str(tmp_path / "b16.inc")
+    env["W64_OUT_I8"] = str(tmp_path / "bi8.inc")
+    regs = (CSRC / "fa_fwd16_w64_regs.inc").read_text()
+    subprocess.check_call([sys.executable, str(ROOT / "tools" / "gen_w64_body.py")], env=env, stdout=subprocess.DEVNULL)
+    assert (tmp_path / "b16.inc").read_text() == (CSRC / "fa_fwd16_w64_body.inc").read_text()
+    assert (tmp_path / "bi8.inc").read_text() == (CSRC / "fa_fwd_w64_i8_body.inc").read_text()
+    assert (CSRC / "fa_fwd16_w64_regs.inc").read_text() == regs  # the helper file is rewritten in place: unchanged
