@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
     constexpr int NDB = DP / 32;            // 32-row blocks of O^T
     constexpr int TILE_BYTES = BN * DP * 2;
     constexpr int LPT = BN * NCH / 256;     // 16-byte loads per thread per tile
+    constexpr bool SPLIT_DMA = DMA && (DP == 256 || (DP == 64 && !CAUSAL));
     static_assert(LPT >= 1, "tile too small for 256 threads");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -175,16 +176,22 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
         for (int i = 0; i < 4 * TILE_BYTES / 4096; ++i) *(i32x4*)(smem + i * 4096 + tid * 16) = i32x4{0, 0, 0, 0};
         __syncthreads();
     }
-    auto stage_load = [&](uint32_t t) {
+    // which: 1 = K tile, 2 = V tile, 3 = both.  SPLIT_DMA: the V half is issued behind the QK^T MFMAs instead of back
+    // to back with the K half (LDS-DMA instructions in a row stall the MFMA behind them, profiles/r1/lab_notes.md).
+    // Same-box A/B: head_dim 256 (16 DMA instructions per wave per tile) 1132 -> 1001-1029 us at B2 H24 S4096,
+    // head_dim 64 non-causal +2.5 %, head_dim 128 neutral, the tiny causal head_dim-64 case -3 % (left unsplit).
+    auto stage_load = [&](uint32_t t, int which = 3) {
         if constexpr (DMA) {
             const int ktile = (int)(t * BN) * k_stride_b, vtile = (int)(t * BN) * v_stride_b;
             const unsigned kdst = lds_wave + (t & 1) * TILE_BYTES, vdst = kdst + 2 * TILE_BYTES;
 #pragma unroll
             for (int j = 0; j < IPW; ++j) {
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                             ::"s"(kdst + j * 1024), "v"(kdma[j] + ktile), "s"(k_srd) : "memory");
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                             ::"s"(vdst + j * 1024), "v"(vdma[j] + vtile), "s"(v_srd) : "memory");
+                if (which & 1)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                                 ::"s"(kdst + j * 1024), "v"(kdma[j] + ktile), "s"(k_srd) : "memory");
+                if (which & 2)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                                 ::"s"(vdst + j * 1024), "v"(vdma[j] + vtile), "s"(v_srd) : "memory");
             }
         } else {
             const int ksoff = (int)(t * BN) * k_stride_b, vsoff = (int)(t * BN) * v_stride_b;
@@ -249,15 +256,16 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
 
     for (uint32_t t = t_begin; t < t_end; ++t) {
         const int cur = t & 1;
-#ifndef UMFA_ABL_NO_LOAD
-        stage_load(t + 1);  // next tile in flight under this tile's MFMAs (T14); past the end: all zeros
-#endif
-
         const char* Kt = Kbuf + cur * TILE_BYTES;
         const char* Vt = Vbuf + cur * TILE_BYTES;
         const uint32_t key_base = t * BN;
         // wave-uniform: is any part of this tile visible to this wave's rows?
         const bool active = !CAUSAL || key_base <= wave_q0 + 31;
+#ifndef UMFA_ABL_NO_LOAD
+        // next tile in flight under this tile's MFMAs (T14); past the end: all zeros.  SPLIT_DMA: only the K half
+        // here, the V half behind the QK^T MFMAs of an active tile
+        stage_load(t + 1, (SPLIT_DMA && active) ? 1 : 3);
+#endif
 
         if (active) {
             // ---------------- S^T = K Q^T ----------------
@@ -276,6 +284,13 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
                 }
 #endif
             }
+#ifndef UMFA_ABL_NO_LOAD
+            if constexpr (SPLIT_DMA) {
+                __builtin_amdgcn_sched_barrier(0);
+                stage_load(t + 1, 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
             // first V^T fragments requested before the softmax so their LDS latency hides under it
             V8 va[NST];
 #pragma unroll
