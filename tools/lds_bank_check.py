@@ -60,22 +60,24 @@ for DP in (32, 64, 128, 256):
           f"K write {worst_wk}-way, V write {worst_wv}-way")
 
 
-# ---- dual-use image of csrc/fa_bwd_16.hip: rows of 256 B read both by rows (ds_read_b128) and transposed
-def d_off(row, ch):
-    return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)))
+# ---- dual-use images of csrc/fa_bwd_16.hip: rows of 2*DP bytes read both by rows (ds_read_b128) and transposed
+def d_off(DP, row, ch):
+    f = (((row & 3) << 2) | ((row >> 2) & 3)) if DP == 128 else (((row >> 2) & 3) | (((row >> 1) & 1) << 2))
+    return 2 * DP * row + 16 * (ch ^ f)
 
 
-worst_row = worst_tr = worst_w = 0
-for ks in range(8):
-    for g in B128_GROUPS:
-        worst_row = max(worst_row, ways([d_off(l & 31, 2 * ks + (l >> 5)) for l in g], 16, 64))
-for i, s2, plus8 in itertools.product(range(4), range(2), (0, 8)):
-    for half in (range(0, 32), range(32, 64)):
-        addrs = []
-        for l in half:
-            hi, qq, pp, g1 = l >> 5, (l >> 2) & 3, l & 3, (l >> 4) & 1
-            addrs.append(d_off(16 * s2 + 4 * hi + qq + plus8, 4 * i + 2 * g1 + (pp >> 1)) + 8 * (pp & 1))
-        worst_tr = max(worst_tr, ways(addrs, 8, 64))
-seen = {d_off(r, c) for r in range(32) for c in range(16)}
-assert len(seen) == 512 and max(seen) < 32 * 256
-print(f"dual image (DP=128): row ds_read_b128 {worst_row}-way, transposed ds_read_b64_tr_b16 {worst_tr}-way")
+for DP in (128, 64):
+    worst_row = worst_tr = 0
+    for ks in range(DP // 16):
+        for g in B128_GROUPS:
+            worst_row = max(worst_row, ways([d_off(DP, l & 31, 2 * ks + (l >> 5)) for l in g], 16, 64))
+    for i, s2, plus8 in itertools.product(range(DP // 32), range(2), (0, 8)):
+        for half in (range(0, 32), range(32, 64)):
+            addrs = []
+            for l in half:
+                hi, qq, pp, g1 = l >> 5, (l >> 2) & 3, l & 3, (l >> 4) & 1
+                addrs.append(d_off(DP, 16 * s2 + 4 * hi + qq + plus8, 4 * i + 2 * g1 + (pp >> 1)) + 8 * (pp & 1))
+            worst_tr = max(worst_tr, ways(addrs, 8, 64))
+    seen = {d_off(DP, r, c) for r in range(32) for c in range(DP // 8)}
+    assert len(seen) == 32 * DP // 8 and max(seen) < 32 * 2 * DP
+    print(f"dual image (DP={DP}): row ds_read_b128 {worst_row}-way, transposed ds_read_b64_tr_b16 {worst_tr}-way")

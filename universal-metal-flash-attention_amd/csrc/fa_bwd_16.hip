@@ -1,4 +1,4 @@
-// fa_bwd_16.hip -- bf16 / fp16 MFMA backward for gfx950, head_dim 128 (the FLUX / config-3 shape).
+// fa_bwd_16.hip -- bf16 / fp16 MFMA backward for gfx950, head_dim 128 (the FLUX / config-3 shape) and 64.
 //
 // Same contract as fa_bwd.hip (mfa_attention_backward, MFABridge.swift:3171-3282: D = rowsum(dO o O), dQ, dK, dV in
 // fp32, two dispatches "backward query" then "backward key-value", no atomics) with the five products on
@@ -12,9 +12,10 @@
 //   bwd16_dkdv  workgroup = 4 waves x 32 keys (K, V fragments in registers); sweeps 32-row tiles of Q and dO (LDS).
 //               lane <-> key:     S = Q K^T,  dP = dO V^T,  P, dS as above (row constants from LDS),
 //               dV^T += dO^T P,  dK^T += Q^T dS  (Q^T / dO^T fragments by transposed reads of the same images).
-// All four tile kinds use ONE dual-use LDS image (256-byte rows, 16-byte chunks XOR-swizzled with
-// ((row&3)<<2 | (row>>2)&3)): conflict-free for ds_read_b128 row reads AND ds_read_b64_tr_b16 transposed reads
-// (tools/lds_bank_check.py).  Tiles arrive by LDS-DMA with the swizzle on the source chunk.
+// All four tile kinds use ONE dual-use LDS image (2*D-byte rows, 16-byte chunks XOR-swizzled with
+// ((row&3)<<2 | (row>>2)&3) at D = 128, ((row>>2)&3 | ((row>>1)&1)<<2) at D = 64): conflict-free for ds_read_b128 row
+// reads AND ds_read_b64_tr_b16 transposed reads (tools/lds_bank_check.py).  Tiles arrive by LDS-DMA with the swizzle
+// on the source chunk.
 // P and dS are rounded to the input type before their second product, like P in the forward.
 #include <cstring>
 
@@ -26,11 +27,16 @@ namespace umfa {
 
 namespace {
 
-constexpr int DP = 128, ROW_B = 256, NCH = 16, NKS = 8, NDB = 4;
-constexpr int TILE_ROWS = 32, TILE_BYTES = TILE_ROWS * ROW_B;  // 8 KiB
+// geometry of one head_dim: 16-key MFMA steps, 32-column d-blocks, 32-row tiles of 2*DP-byte rows
+#define BWD16_GEO(DP)                                                                    \
+    constexpr int ROW_B = 2 * DP, NKS = DP / 16, NDB = DP / 32, TILE_BYTES = 32 * ROW_B; \
+    constexpr int TILE_PIECES = TILE_BYTES / 1024
 
+template <int DP>
 __device__ __forceinline__ constexpr int d_off(int row, int ch) {
-    return ROW_B * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+    static_assert(DP == 128 || DP == 64, "swizzles exist for 256- and 128-byte rows");
+    const int f = DP == 128 ? (((row & 3) << 2) | ((row >> 2) & 3)) : (((row >> 2) & 3) | (((row >> 1) & 1) << 2));
+    return 2 * DP * row + 16 * (ch ^ f);
 }
 
 __device__ __forceinline__ i32x4 make_srd(const void* base, uint32_t bytes) {
@@ -43,17 +49,18 @@ __device__ __forceinline__ i32x4 make_srd(const void* base, uint32_t bytes) {
     return d;
 }
 
-// LDS-DMA of `npieces` 1-KiB pieces (4 rows each) of a [rows][256 B] slab image starting at global row `row0`.
+// LDS-DMA of `npieces` 1-KiB pieces (4 or 8 rows each) of a [rows][2*DP B] slab image starting at global row `row0`.
 // Piece n goes to lds_dst + n KiB; wave w issues pieces w, w+4, ...  Rows past the slab are range-checked away.
-template <int NPIECES>
+template <int NPIECES, int DP>
 __device__ __forceinline__ void dma_rows(const i32x4& srd, unsigned lds_dst, uint32_t row0, int uw, int lane) {
-    const int r = lane >> 4, c = lane & 15;
+    constexpr int ROW_B = 2 * DP, NCH = DP / 8, RPP = 1024 / ROW_B;  // chunks per row, rows per piece
+    const int r = lane / NCH, c = lane % NCH;
 #pragma unroll
     for (int n0 = 0; n0 < NPIECES; n0 += 4) {
         const int n = n0 + uw;
         if (n < NPIECES) {
-            const int row = 4 * n + r;
-            const int voff = (int)(row0 + row) * ROW_B + (d_off(row, c) - row * ROW_B);
+            const int row = RPP * n + r;
+            const int voff = (int)(row0 + row) * ROW_B + (d_off<DP>(row, c) - row * ROW_B);
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
                          ::"s"(lds_dst + n * 1024), "v"(voff), "s"(srd) : "memory");
         }
@@ -62,37 +69,42 @@ __device__ __forceinline__ void dma_rows(const i32x4& srd, unsigned lds_dst, uin
 
 // transposed-read fragment: rows (row0 .. +3) and (row0+8 .. +11) x 16 columns of d-block i, as the A operand whose
 // element j is image row 16 s + 8 (j>>2) + 4 hi + (j&3) (the k order of an accumulator used as B operand)
-template <typename M>
+template <typename M, int DP>
 __device__ __forceinline__ typename M::V8 tr_frag(const char* img, int i, int s, int hi, int tr_qq, int tr_pp, int tr_g1) {
     const int ch = 4 * i + 2 * tr_g1 + (tr_pp >> 1);
     const int r0 = 16 * s + 4 * hi + tr_qq;
-    const typename M::V4 lo = M::tr_read(img + d_off(r0, ch) + 8 * (tr_pp & 1));
-    const typename M::V4 hi4 = M::tr_read(img + d_off(r0 + 8, ch) + 8 * (tr_pp & 1));
+    const typename M::V4 lo = M::tr_read(img + d_off<DP>(r0, ch) + 8 * (tr_pp & 1));
+    const typename M::V4 hi4 = M::tr_read(img + d_off<DP>(r0 + 8, ch) + 8 * (tr_pp & 1));
     return __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
 }  // namespace
 
+template <int DP>
 __global__ __launch_bounds__(256) void bwd16_delta_kernel(BwdParams p) {
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= (int64_t)p.B * p.H * p.Sq) return;
-    // 128 columns: two per lane
-    const float a0 = load_as_float(p.dout, row * DP + 2 * lane, p.dout_prec) * p.o[row * DP + 2 * lane];
-    const float a1 = load_as_float(p.dout, row * DP + 2 * lane + 1, p.dout_prec) * p.o[row * DP + 2 * lane + 1];
-    float s = a0 + a1;
+    // DP / 64 columns per lane
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < DP / 64; ++j) {
+        const int64_t at = row * DP + (DP / 64) * lane + j;
+        s += load_as_float(p.dout, at, p.dout_prec) * p.o[at];
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     if (lane == 0) p.dvec[row] = s;
 }
 
 // ------------------------------------------------------------------------------------------------ dQ
-template <typename T, bool CAUSAL>
+template <typename T, bool CAUSAL, int DP>
 __global__ __launch_bounds__(256, 2) void bwd16_dq_kernel(BwdParams p) {
+    BWD16_GEO(DP);
     typedef Mma16<T> M;
     typedef typename M::V8 V8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // [K buf0][K buf1][V buf0][V buf1], 8 KiB each
+    // [K buf0][K buf1][V buf0][V buf1], one 32-key tile (8 KiB at D = 128) each
     const int tid = threadIdx.x, lane = tid & 63, ql = lane & 31, hi = lane >> 5;
     const int wave = tid >> 6, uw = __builtin_amdgcn_readfirstlane(wave);
     const uint32_t nqb = (p.Sq + 127) / 128;
@@ -142,8 +154,8 @@ __global__ __launch_bounds__(256, 2) void bwd16_dq_kernel(BwdParams p) {
     const int tr_qq = (lane >> 2) & 3, tr_pp = lane & 3, tr_g1 = (lane >> 4) & 1;
 
     auto stage = [&](uint32_t t) {
-        dma_rows<8>(k_srd, lds0 + (t & 1) * TILE_BYTES, t * 32, uw, lane);
-        dma_rows<8>(v_srd, lds0 + 2 * TILE_BYTES + (t & 1) * TILE_BYTES, t * 32, uw, lane);
+        dma_rows<TILE_PIECES, DP>(k_srd, lds0 + (t & 1) * TILE_BYTES, t * 32, uw, lane);
+        dma_rows<TILE_PIECES, DP>(v_srd, lds0 + 2 * TILE_BYTES + (t & 1) * TILE_BYTES, t * 32, uw, lane);
     };
     stage(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -160,8 +172,8 @@ __global__ __launch_bounds__(256, 2) void bwd16_dq_kernel(BwdParams p) {
             for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
-                const V8 ak = *(const V8*)(Kt + d_off(ql, 2 * ks + hi));
-                const V8 av = *(const V8*)(Vt + d_off(ql, 2 * ks + hi));
+                const V8 ak = *(const V8*)(Kt + d_off<DP>(ql, 2 * ks + hi));
+                const V8 av = *(const V8*)(Vt + d_off<DP>(ql, 2 * ks + hi));
                 s = M::mma(ak, qf[ks], s);      // S^T[key][q]
                 dp = M::mma(av, dof[ks], dp);   // dP^T[key][q]
             }
@@ -181,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void bwd16_dq_kernel(BwdParams p) {
             for (int i = 0; i < NDB; ++i)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
-                    acc[i] = M::mma(tr_frag<M>(Kt, i, s2, hi, tr_qq, tr_pp, tr_g1), ds[s2], acc[i]);
+                    acc[i] = M::mma(tr_frag<M, DP>(Kt, i, s2, hi, tr_qq, tr_pp, tr_g1), ds[s2], acc[i]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -200,8 +212,9 @@ __global__ __launch_bounds__(256, 2) void bwd16_dq_kernel(BwdParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
-template <typename T, bool CAUSAL>
+template <typename T, bool CAUSAL, int DP>
 __global__ __launch_bounds__(256, 1) void bwd16_dkdv_kernel(BwdParams p) {
+    BWD16_GEO(DP);
     typedef Mma16<T> M;
     typedef typename M::V8 V8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -246,8 +259,8 @@ __global__ __launch_bounds__(256, 1) void bwd16_dkdv_kernel(BwdParams p) {
     const uint32_t ntiles = (p.Sq + QROWS - 1) / QROWS;
     const uint32_t t0 = CAUSAL ? (kb * 128) / QROWS : 0;  // query tiles entirely before this key block see nothing
     auto stage = [&](uint32_t t) {
-        dma_rows<16>(q_srd, lds0 + QT + (t & 1) * QTILE_B, t * QROWS, uw, lane);
-        dma_rows<16>(do_srd, lds0 + DOT + (t & 1) * QTILE_B, t * QROWS, uw, lane);
+        dma_rows<2 * TILE_PIECES, DP>(q_srd, lds0 + QT + (t & 1) * QTILE_B, t * QROWS, uw, lane);
+        dma_rows<2 * TILE_PIECES, DP>(do_srd, lds0 + DOT + (t & 1) * QTILE_B, t * QROWS, uw, lane);
         if (tid < QROWS) {  // row constants of the tile: L2 = LSE * log2e (+inf past Sq -> P = 0) and D
             const uint32_t row = t * QROWS + tid;
             const bool ok = row < p.Sq;
@@ -282,8 +295,8 @@ __global__ __launch_bounds__(256, 1) void bwd16_dkdv_kernel(BwdParams p) {
                 for (int r = 0; r < 16; ++r) { s[u][r] = 0.0f; dp[u][r] = 0.0f; }
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) {
-                    const V8 aq = *(const V8*)(Qt + u * TILE_BYTES + d_off(kl, 2 * ks + hi));  // A: row = query kl of the sub-tile
-                    const V8 ado = *(const V8*)(dOt + u * TILE_BYTES + d_off(kl, 2 * ks + hi));
+                    const V8 aq = *(const V8*)(Qt + u * TILE_BYTES + d_off<DP>(kl, 2 * ks + hi));  // A: row = query kl of the sub-tile
+                    const V8 ado = *(const V8*)(dOt + u * TILE_BYTES + d_off<DP>(kl, 2 * ks + hi));
                     s[u] = M::mma(aq, kf[ks], s[u]);
                     dp[u] = M::mma(ado, vf[ks], dp[u]);
                 }
@@ -312,8 +325,8 @@ __global__ __launch_bounds__(256, 1) void bwd16_dkdv_kernel(BwdParams p) {
                 for (int i = 0; i < NDB; ++i)
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2) {
-                        dv[i] = M::mma(tr_frag<M>(dOt + u * TILE_BYTES, i, s2, hi, tr_qq, tr_pp, tr_g1), pb[s2], dv[i]);
-                        dk[i] = M::mma(tr_frag<M>(Qt + u * TILE_BYTES, i, s2, hi, tr_qq, tr_pp, tr_g1), sb[s2], dk[i]);
+                        dv[i] = M::mma(tr_frag<M, DP>(dOt + u * TILE_BYTES, i, s2, hi, tr_qq, tr_pp, tr_g1), pb[s2], dv[i]);
+                        dk[i] = M::mma(tr_frag<M, DP>(Qt + u * TILE_BYTES, i, s2, hi, tr_qq, tr_pp, tr_g1), sb[s2], dk[i]);
                     }
             }
         }
@@ -338,38 +351,42 @@ __global__ __launch_bounds__(256, 1) void bwd16_dkdv_kernel(BwdParams p) {
 
 bool bwd_16_supported(const BwdParams& p) {
     if (p.in_prec != P_FP16 && p.in_prec != P_BF16) return false;
-    if (p.dout_prec != p.in_prec || p.D != 128 || p.mask) return false;
+    if (p.dout_prec != p.in_prec || (p.D != 128 && p.D != 64) || p.mask) return false;
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     if (!al16(p.q) || !al16(p.k) || !al16(p.v) || !al16(p.dout) || !al16(p.dq) || !al16(p.dk) || !al16(p.dv)) return false;
     // 32-bit buffer offsets inside one (batch, head) slab
     return (uint64_t)p.Sq * 256 < (1ull << 31) && (uint64_t)p.Skv * 256 < (1ull << 31);
 }
 
-template <typename T, bool CAUSAL>
+template <typename T, bool CAUSAL, int DP>
 static hipError_t launch_bwd16_t(const BwdParams& p, hipStream_t stream) {
+    constexpr int TILE_BYTES = 32 * 2 * DP;
     const int64_t rows = (int64_t)p.B * p.H * p.Sq;
-    hipLaunchKernelGGL(bwd16_delta_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(bwd16_delta_kernel<DP>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, p);
     const size_t lds_dq = 4 * TILE_BYTES, lds_kv = 8 * TILE_BYTES + 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)bwd16_dkdv_kernel<T, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+        hipError_t e = hipFuncSetAttribute((const void*)bwd16_dkdv_kernel<T, CAUSAL, DP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const uint32_t nqb = (p.Sq + 127) / 128, nkb = (p.Skv + 127) / 128;
-    hipLaunchKernelGGL((bwd16_dq_kernel<T, CAUSAL>), dim3(nqb * p.B * p.H), dim3(256), lds_dq, stream, p);
-    hipLaunchKernelGGL((bwd16_dkdv_kernel<T, CAUSAL>), dim3(nkb * p.B * p.H), dim3(256), lds_kv, stream, p);
+    hipLaunchKernelGGL((bwd16_dq_kernel<T, CAUSAL, DP>), dim3(nqb * p.B * p.H), dim3(256), lds_dq, stream, p);
+    hipLaunchKernelGGL((bwd16_dkdv_kernel<T, CAUSAL, DP>), dim3(nkb * p.B * p.H), dim3(256), lds_kv, stream, p);
     return hipGetLastError();
 }
 
 hipError_t launch_bwd_16(const BwdParams& p, hipStream_t stream, const char** name) {
     if (!bwd_16_supported(p)) return hipErrorNotSupported;
-    if (p.in_prec == P_BF16) {
-        *name = "fa_bwd16<bf16,128>";
-        return p.causal ? launch_bwd16_t<__bf16, true>(p, stream) : launch_bwd16_t<__bf16, false>(p, stream);
+    const bool bf = p.in_prec == P_BF16;
+    if (p.D == 128) {
+        *name = bf ? "fa_bwd16<bf16,128>" : "fa_bwd16<fp16,128>";
+        if (bf) return p.causal ? launch_bwd16_t<__bf16, true, 128>(p, stream) : launch_bwd16_t<__bf16, false, 128>(p, stream);
+        return p.causal ? launch_bwd16_t<_Float16, true, 128>(p, stream) : launch_bwd16_t<_Float16, false, 128>(p, stream);
     }
-    *name = "fa_bwd16<fp16,128>";
-    return p.causal ? launch_bwd16_t<_Float16, true>(p, stream) : launch_bwd16_t<_Float16, false>(p, stream);
+    *name = bf ? "fa_bwd16<bf16,64>" : "fa_bwd16<fp16,64>";
+    if (bf) return p.causal ? launch_bwd16_t<__bf16, true, 64>(p, stream) : launch_bwd16_t<__bf16, false, 64>(p, stream);
+    return p.causal ? launch_bwd16_t<_Float16, true, 64>(p, stream) : launch_bwd16_t<_Float16, false, 64>(p, stream);
 }
 
 }  // namespace umfa
