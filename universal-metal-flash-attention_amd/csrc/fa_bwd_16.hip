@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void bwd16_dq_kernel(BwdParams p) {
 
 // ------------------------------------------------------------------------------------------------ dK, dV
 template <typename T, bool CAUSAL, int DP>
-__global__ __launch_bounds__(256, 1) void bwd16_dkdv_kernel(BwdParams p) {
+__global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdParams p) {
     BWD16_GEO(DP);
     typedef Mma16<T> M;
     typedef typename M::V8 V8;
