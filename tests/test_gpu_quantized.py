@@ -129,6 +129,29 @@ def test_quantized_forward_w64_vs_oracle(ctx, shape, bits, mode, causal):
     assert np.array_equal(o, o2)  # bitwise reproducible, including the fold of cut items
 
 
+@pytest.mark.parametrize("gain,outlier", [(1.0, 60.0), (3.0, 0.0), (0.05, 0.0)])
+def test_quantized_forward_w64_wide_dynamic_range(ctx, gain, outlier):
+    """The int8 kernel keeps its integer scores in the mantissa of a biased float (no int -> float conversion per score);
+    the bias is cancelled exactly by rounding the per-tile softmax scale to ~22 bits.  Large block scales (outliers,
+    large activations: BIAS * c2 up to ~1e6) and tiny ones must stay inside the same tolerance as N(0,1) data."""
+    import umfa
+    orc = _oracle()
+    rng = np.random.default_rng(int(gain * 100) + int(outlier))
+    B, H, Sq, Skv = 1, 2, 512, 1024
+    q = (rng.standard_normal((B, H, Sq, 128)) * gain).astype(np.float32)
+    k = (rng.standard_normal((B, H, Skv, 128)) * gain).astype(np.float32)
+    v = rng.standard_normal((B, H, Skv, 128)).astype(np.float32)
+    if outlier:
+        q[0, :, ::64, 5] = outlier    # one outlier per quantisation block: block scale x15, ordinary logits
+        k[0, :, 17::128, 9] = -outlier  # every second K block only: neighbouring tiles with very different scales
+    o, lse = umfa.quantized_attention(ctx, q, k, v, precision="int8", quant_mode="blockwise", layout="bhsd", return_lse=True)
+    assert ctx.last_kernel.startswith("fa_fwd_w64_i"), ctx.last_kernel
+    ref, rlse = orc.quantized_forward(q, k, v, bits=8, quant_mode=2)
+    assert np.isfinite(o).all()
+    assert rel_err(o, ref) < 2e-3, rel_err(o, ref)
+    assert np.abs(lse.reshape(rlse.shape) - rlse).max() < 2e-3 * max(1.0, np.abs(rlse).max() / 50)
+
+
 @pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("bits,mode", [(8, 2), (8, 0), (4, 2)])
 def test_quantiser_is_bit_exact_with_the_oracle(dt, bits, mode):

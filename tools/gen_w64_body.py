@@ -33,9 +33,15 @@ MIDBAR = os.environ.get("W64_MIDBAR", "0") == "1"  # per-tile barrier in the mid
 EARLY_MAX = os.environ.get("W64_EARLY_MAX", "1") == "1"  # row max of key-block 0 during the QK of key-block 1, e = s*c - m spread to the end
 class Cfg:
     """16-bit kernels: S = K Q^T is 32 MFMAs (8 k-steps of 16); int8 kernel (fa_fwd_w64_i8): 16 MFMAs
-    (v_mfma_i32_32x32x32_i8, 4 k-steps of 32), integer scores converted in place (I2F) before mask / max."""
+    (v_mfma_i32_32x32x32_i8, 4 k-steps of 32).  The integer scores never pass through v_cvt_f32_i32: the first
+    MFMA of a score block accumulates onto a register tile holding the bits of 1.5 * 2^23 in every element, so the
+    int32 result s + 0x4B400000 IS the float 12582912 + s (|s| <= 127 * 127 * 128 < 2^21 stays inside the mantissa);
+    row max runs on those floats (monotone in s) and the one v_fma_f32 per score that applies scale and reference max
+    takes the bias out with its addend (nmb = -m - 12582912 c).  W64_I8_BIAS=0 (lab, with -DW64_I8_NOBIAS) keeps the
+    explicit in-place conversion (I2F)."""
     def __init__(self, i8):
         self.i8 = i8
+        self.i2f = i8 and os.environ.get("W64_I8_BIAS", "1") == "0"
         self.NQK = 16 if i8 else 32      # MFMAs of the QK^T phase = first gap index of the PV phase
         self.KS = 4 if i8 else 8         # k-steps per 32-key block
         self.HALF = self.NQK // 2        # QK^T MFMAs per key block
@@ -82,6 +88,8 @@ class Roles:
 def qk_mfma(R, kb, ks, qb):
     t = tup(R.new, kb, qb)
     c = "0" if ks == 0 else t
+    if ks == 0 and C.i8 and not C.i2f:
+        return f'asm volatile(W64_MFMA_QK " {t}, %0, %1, %2" :: "v"(kf[{kb}][{ks}]), "a"(qf[{qb}][{ks}]), "v"(bias16));'
     return f'asm volatile(W64_MFMA_QK " {t}, %0, %1, {c}" :: "v"(kf[{kb}][{ks}]), "a"(qf[{qb}][{ks}]));'
 
 
@@ -150,7 +158,8 @@ def op_text(R, op):
     if kind == "FMA":
         _, kb, qb, r = op
         v = base(R.new, kb, qb) + r
-        return f'asm volatile("v_fma_f32 v{v}, v{v}, %0, %1" :: "s"(c2), "v"(nm[{qb}]));'
+        nm = "nmb" if C.i8 and not C.i2f else "nm"
+        return f'asm volatile("v_fma_f32 v{v}, v{v}, %0, %1" :: "s"(c2), "v"({nm}[{qb}]));'
     raise ValueError(kind)
 
 
@@ -253,7 +262,7 @@ def start_streams(have_new, mfma_follows=True, masked=False):
                 ops.append((("NOP",), C.NQK, last))
             for qb in (0, 1):
                 for r in range(16):
-                    if C.i8:
+                    if C.i2f:
                         ops.append((("I2F", kb, qb, r), ready + qb, last))
             if masked:
                 for qb in (0, 1):
@@ -274,16 +283,21 @@ def start_streams(have_new, mfma_follows=True, masked=False):
             w = {"mask": {0: (16, 30), 1: (32, 44)}, "max": {0: (31, 36), 1: (45, 50)}, "dec": (51, 52), "fma": (53, 62)}
         else:
             w = {"max": {0: (16, 31), 1: (32, 40)}, "dec": (41, 43), "fma": (44, 61)}
-    else:
+    elif C.i2f:
         if masked:
             w = {"i2f": {0: (9, 13), 1: (17, 21)}, "mask": {0: (14, 20), 1: (22, 29)}, "max": {0: (21, 24), 1: (30, 33)},
                  "dec": (34, 35), "fma": (36, 46)}
         else:
             w = {"i2f": {0: (9, 14), 1: (17, 22)}, "max": {0: (15, 19), 1: (23, 27)}, "dec": (28, 29), "fma": (30, 45)}
+    else:
+        if masked:
+            w = {"mask": {0: (9, 17), 1: (17, 26)}, "max": {0: (18, 21), 1: (27, 30)}, "dec": (31, 32), "fma": (33, 46)}
+        else:
+            w = {"max": {0: (9, 16), 1: (17, 24)}, "dec": (25, 26), "fma": (27, 45)}
     streams = []
     for kb in (0, 1):
         ready = kb * H + (H - 2) + 2
-        if C.i8:
+        if C.i2f:
             for qb in (0, 1):
                 streams.append([(("I2F", kb, qb, r), max(w["i2f"][kb][0], ready + qb), w["i2f"][kb][1]) for r in range(16)])
         if masked:
@@ -382,7 +396,7 @@ def check_part(placed, have_new, have_old, masked):
                 for r in range(0, 16, 2):
                     mxop = [o for o in pos if o[0] == "MAX" and o[1:4] == (kb, qb, r)][0]
                     assert pos[mxop][0] > last_mfma, ("row max reads an unfinished score tile", mxop)
-                    if C.i8:
+                    if C.i2f:
                         assert before(("I2F", kb, qb, r), mxop) and before(("I2F", kb, qb, r + 1), mxop), ("MAX before I2F", mxop)
                         assert pos[("I2F", kb, qb, r)][0] > last_mfma, ("convert on an unfinished score tile", kb, qb, r)
                         if masked:
