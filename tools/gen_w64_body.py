@@ -52,7 +52,7 @@ class Cfg:
 
 C = Cfg(False)
 
-COST = {"BAR": 16, "KPRE": 4, "I2F": 4, "MASK": 8, "DMAK": 8, "DMAV": 8, "NOP": 32, "EXP": 8, "ADD": 4, "CVT": 4, "VREAD": 8, "KREAD": 4, "MAX": 4, "DEC": 44, "FMA": 4}
+COST = {"UPDK": 4, "UPDV": 4, "BAR": 16, "KPRE": 4, "I2F": 4, "MASK": 8, "DMAK": 8, "DMAV": 8, "NOP": 32, "EXP": 8, "ADD": 4, "CVT": 4, "VREAD": 8, "KREAD": 4, "MAX": 4, "DEC": 44, "FMA": 4}
 
 NPRE = 4  # K fragments (kb=0, ks<NPRE) read before the iteration starts (by the includer, after the barrier)
 
@@ -64,6 +64,11 @@ NPRE = 4  # K fragments (kb=0, ks<NPRE) read before the iteration starts (by the
 #   (in-place compaction by v_cvt_pk);  O^T block (qb, db) at a[128 + 16 (4 qb + db) : +15].
 # The Q^T fragments are compiler values constrained to the accumulator class ("a"): 64 of the compiler's a[0:127].
 S_BASE, O_BASE = 128, 128
+UPD_DELAY = int(os.environ.get("W64_DMA_UPD_DELAY", "4"))  # gaps between a DMA instruction and the update of its offset VGPR
+DMA_MOD = os.environ.get("W64_DMA_MOD", "")  # cache-policy bits of the LDS-DMA loads, e.g. " nt" / " sc0" / " sc1"
+DMASTAMP = os.environ.get("W64_LAB_DMASTAMP") == "1"  # lab: clock stamps around the first K DMA instruction and a control
+NOUPD = os.environ.get("W64_LAB_NOUPD") == "1"  # lab: the DMA source offsets never advance (timing only)
+QF_CLASS = os.environ.get("W64_LAB_QF", "a")  # lab: register class of the Q^T fragments
 
 
 def base(setname, kb, qb):
@@ -89,8 +94,8 @@ def qk_mfma(R, kb, ks, qb):
     t = tup(R.new, kb, qb)
     c = "0" if ks == 0 else t
     if ks == 0 and C.i8 and not C.i2f:
-        return f'asm volatile(W64_MFMA_QK " {t}, %0, %1, %2" :: "v"(kf[{kb}][{ks}]), "a"(qf[{qb}][{ks}]), "v"(bias16));'
-    return f'asm volatile(W64_MFMA_QK " {t}, %0, %1, {c}" :: "v"(kf[{kb}][{ks}]), "a"(qf[{qb}][{ks}]));'
+        return f'asm volatile(W64_MFMA_QK " {t}, %0, %1, %2" :: "v"(kf[{kb}][{ks}]), "{QF_CLASS}"(qf[{qb}][{ks}]), "v"(bias16));'
+    return f'asm volatile(W64_MFMA_QK " {t}, %0, %1, {c}" :: "v"(kf[{kb}][{ks}]), "{QF_CLASS}"(qf[{qb}][{ks}]));'
 
 
 def pv_mfma(R, st, db, qb):
@@ -143,14 +148,27 @@ def op_text(R, op):
         v = base(R.new, kb, qb) + r
         c = 32 * kb - 32 * qb + (r & 3) + 8 * (r >> 2)
         return (f'asm volatile("v_cmp_lt_i32 vcc, {-c}, %0\\n\\tv_cndmask_b32 v{v}, v{v}, %1, vcc" :: "v"(dmask[{qb}]), "v"(neg_inf) : "vcc");')
+    if kind == "DMAK" and DMASTAMP and op[1] == 0:
+        return ('{ asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long d0_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); '
+                'asm volatile("s_mov_b32 m0, %0\\n\\ts_nop 0\\n\\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_wave_k + W64_KDST + 0), "v"(kdma[0]), "s"(k_srd) : "memory"); '
+                'const unsigned long long d1_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st_wait += d1_ - d0_; }')
+    if kind == "UPDK" and DMASTAMP and op[1] == 0:
+        return ('{ asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long d0_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); '
+                'asm volatile("s_mov_b32 m0, %0\\n\\ts_nop 0" ::"s"(lds_wave_k) : "memory"); '
+                'const unsigned long long d1_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st_bar += d1_ - d0_; } kdma[0] += k_step;')
     if kind == "DMAK":
         _, j = op
-        return (f'asm volatile("s_mov_b32 m0, %0\\n\\ts_nop 0\\n\\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_wave_k + W64_KDST + {j * 1024}), '
-                f'"v"(kdma[{j}]), "s"(k_srd) : "memory"); kdma[{j}] += k_step;')
+        return (f'asm volatile("s_mov_b32 m0, %0\\n\\ts_nop 0\\n\\tbuffer_load_dwordx4 %1, %2, 0 offen{DMA_MOD} lds" ::"s"(lds_wave_k + W64_KDST + {j * 1024}), '
+                f'"v"(kdma[{j}]), "s"(k_srd) : "memory");')
     if kind == "DMAV":
         _, j = op
-        return (f'asm volatile("s_mov_b32 m0, %0\\n\\ts_nop 0\\n\\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_wave + W64_VDST + {j * 1024}), '
-                f'"v"(vdma[{j}]), "s"(v_srd) : "memory"); vdma[{j}] += v_step;')
+        return (f'asm volatile("s_mov_b32 m0, %0\\n\\ts_nop 0\\n\\tbuffer_load_dwordx4 %1, %2, 0 offen{DMA_MOD} lds" ::"s"(lds_wave + W64_VDST + {j * 1024}), '
+                f'"v"(vdma[{j}]), "s"(v_srd) : "memory");')
+    if kind == "UPDK":  # the source offset of piece j moves on to the next tile, a few gaps behind its DMA instruction
+        # (a VALU write to a VGPR that an issued VMEM instruction still has to read would wait for it; measured neutral)
+        return "" if NOUPD else f"kdma[{op[1]}] += k_step;"
+    if kind == "UPDV":
+        return "" if NOUPD else f"vdma[{op[1]}] += v_step;"
     if kind == "DEC":
         return "W64_DECIDE();"
     if kind == "NOP":
@@ -243,6 +261,13 @@ def dma_stream():
     ops = [(("DMAK", j), kpos[j], kpos[j] + 2) for j in range(C.KDMA)] + [(("DMAV", j), vpos[j], vpos[j] + 2) for j in range(4)]
     ops.sort(key=lambda o: o[1])
     return ops
+
+
+def dma_update_stream(dma_ops):
+    """offset updates, UPD_DELAY gaps behind the deadline of their DMA instruction"""
+    last = C.NG - 1
+    ups = [(("UPDK" if o[0][0] == "DMAK" else "UPDV", o[0][1]), min(last, o[2] + UPD_DELAY), min(last, o[2] + UPD_DELAY + 3)) for o in dma_ops]
+    return ups
 
 
 def start_streams(have_new, mfma_follows=True, masked=False):
@@ -429,7 +454,12 @@ def check_part(placed, have_new, have_old, masked):
 
 def emit_part(lines, R, have_new, have_old, masked=False):
     mf = []
-    if have_new:
+    if have_new and os.environ.get("W64_LAB_QK_ORDER") == "il":  # lab (timing only): four accumulators round-robin
+        for ks in range(C.KS):
+            for kb in (0, 1):
+                for qb in (0, 1):
+                    mf.append(qk_mfma(R, kb, ks, qb))
+    elif have_new:
         for kb in (0, 1):
             for ks in range(C.KS):
                 for qb in (0, 1):
@@ -450,11 +480,14 @@ def emit_part(lines, R, have_new, have_old, masked=False):
     if have_new:
         streams += start_streams(True, have_old, masked)
         streams.append(kread_stream())
-        streams.append(dma_stream())
+        dmas = dma_stream()
+        streams.append(dmas)
+        streams.append(dma_update_stream(dmas))
         if MIDBAR:
             streams += mid_barrier_streams(have_old)
     placed = schedule(streams, C.NG)
-    check_part(placed, have_new, have_old, masked)
+    if not ABL:
+        check_part(placed, have_new, have_old, masked)
     cyc = 0
     for g in range(C.NG):
         if mf[g] is not None:
