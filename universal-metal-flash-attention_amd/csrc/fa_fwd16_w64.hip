@@ -129,6 +129,21 @@ bool fwd_w64_supported(const FwdParams& p) {
     // the 128-row kernel; any Skv >= 64 works (a partial last key tile runs the masking variant of the tile body)
     if (p.Skv < 64 || p.Sq < 256 || (p.Sq % 256 != 0 && p.Sq < 1024)) return false;
     if (p.out_prec != P_FP32 && p.out_prec != p.in_prec) return false;
+    // Enough parallel work for one workgroup per CU, else the 128-row kernel (2-3 resident workgroups, finer items)
+    // is faster.  Same-box medians, us, w64 / 128-row: causal B4 H16 S1024 (128 jobs) 53 / 46, B1 H16 S2048 (64) 70 / 53,
+    // B1 H8 S4096 (64) 112 / 96, B1 H8 S8192 (128) 213 / 214, B2 H24 S2048 (192) 85 / 98, B8 H16 S1024 (256) 61 / 85;
+    // non-causal B1 H24 S1024 (6 tile steps per CU) 38 / 32, B1 H4 S4096 (16 per CU) 54 / 75.  UMFA_FORCE_W64=1 lifts it
+    // (parity tests on small shapes).
+    const char* force = getenv("UMFA_FORCE_W64");
+    if (!(force && force[0] == '1')) {
+        const uint64_t cus = (uint64_t)w64_cu_count();
+        const uint64_t nqb = (p.Sq + 255) / 256;
+        if (p.causal) {
+            if ((uint64_t)p.B * p.H * ((nqb + 1) / 2) * 4 < cus * 3) return false;
+        } else if ((uint64_t)p.B * p.H * nqb * ((p.Skv + 63) / 64) < cus * 10) {
+            return false;
+        }
+    }
     return true;
 }
 
