@@ -30,7 +30,8 @@ namespace {
 // geometry of one head_dim: 16-key MFMA steps, 32-column d-blocks, 32-row tiles of 2*DP-byte rows
 #define BWD16_GEO(DP)                                                                    \
     constexpr int ROW_B = 2 * DP, NKS = DP / 16, NDB = DP / 32, TILE_BYTES = 32 * ROW_B; \
-    constexpr int TILE_PIECES = TILE_BYTES / 1024
+    constexpr int TILE_PIECES = TILE_BYTES / 1024;                                       \
+    constexpr int PD = DP == 128 ? 4 : 2 /* k-steps of LDS row fragments in flight ahead of their MFMAs */
 
 template <int DP>
 __device__ __forceinline__ constexpr int d_off(int row, int ch) {
@@ -170,12 +171,25 @@ __global__ __launch_bounds__(256, 2) void bwd16_dq_kernel(BwdParams p) {
             f32x16 s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
+            // explicit software pipeline: the row fragments of k-step ks + PD are in flight while the MFMAs of ks
+            // run (left alone, hipcc reuses ONE 4-register buffer: ds_read -> s_waitcnt lgkmcnt(0) -> MFMA, 16 times)
+            V8 ak[NKS], av[NKS];
+#pragma unroll
+            for (int ks = 0; ks < PD; ++ks) {
+                ak[ks] = *(const V8*)(Kt + d_off<DP>(ql, 2 * ks + hi));
+                av[ks] = *(const V8*)(Vt + d_off<DP>(ql, 2 * ks + hi));
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * PD, 0);
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
-                const V8 ak = *(const V8*)(Kt + d_off<DP>(ql, 2 * ks + hi));
-                const V8 av = *(const V8*)(Vt + d_off<DP>(ql, 2 * ks + hi));
-                s = M::mma(ak, qf[ks], s);      // S^T[key][q]
-                dp = M::mma(av, dof[ks], dp);   // dP^T[key][q]
+                if (ks + PD < NKS) {
+                    ak[ks + PD] = *(const V8*)(Kt + d_off<DP>(ql, 2 * (ks + PD) + hi));
+                    av[ks + PD] = *(const V8*)(Vt + d_off<DP>(ql, 2 * (ks + PD) + hi));
+                }
+                s = M::mma(ak[ks], qf[ks], s);      // S^T[key][q]
+                dp = M::mma(av[ks], dof[ks], dp);   // dP^T[key][q]
+                if (ks + PD < NKS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
             }
             const bool edge = (key_base + 32 > p.Skv) || (CAUSAL && key_base + 31 > wave_q0);
             V8 ds[2];
@@ -290,16 +304,26 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
             // S[q][key] = Q K^T, dP[q][key] = dO V^T: rows = queries (registers), columns = keys (lanes)
             f32x16 s[2], dp[2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { s[u][r] = 0.0f; dp[u][r] = 0.0f; }
+            // A operands: row = query kl of sub-tile u, one flat sequence j = u * NKS + ks over both sub-tiles,
+            // software-pipelined like the dq kernel's row fragments (PD k-steps in flight ahead of their MFMAs)
+            V8 aq[2 * NKS], ado[2 * NKS];
+            auto rd = [&](int j) {
+                aq[j] = *(const V8*)(Qt + (j / NKS) * TILE_BYTES + d_off<DP>(kl, 2 * (j % NKS) + hi));
+                ado[j] = *(const V8*)(dOt + (j / NKS) * TILE_BYTES + d_off<DP>(kl, 2 * (j % NKS) + hi));
+            };
 #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) {
-                    const V8 aq = *(const V8*)(Qt + u * TILE_BYTES + d_off<DP>(kl, 2 * ks + hi));  // A: row = query kl of the sub-tile
-                    const V8 ado = *(const V8*)(dOt + u * TILE_BYTES + d_off<DP>(kl, 2 * ks + hi));
-                    s[u] = M::mma(aq, kf[ks], s[u]);
-                    dp[u] = M::mma(ado, vf[ks], dp[u]);
-                }
+            for (int j = 0; j < PD; ++j) rd(j);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * PD, 0);
+#pragma unroll
+            for (int j = 0; j < 2 * NKS; ++j) {
+                if (j + PD < 2 * NKS) rd(j + PD);
+                s[j / NKS] = M::mma(aq[j], kf[j % NKS], s[j / NKS]);
+                dp[j / NKS] = M::mma(ado[j], vf[j % NKS], dp[j / NKS]);
+                if (j + PD < 2 * NKS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
