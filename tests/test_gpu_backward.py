@@ -76,11 +76,12 @@ def test_backward_bitwise_reproducible(ctx):
 
 
 @pytest.mark.parametrize("shape", [(1, 2, 128, 128), (2, 2, 130, 128), (1, 3, 333, 128), (1, 1, 1024, 128),
-                                   (1, 2, 128, 64), (2, 2, 130, 64), (1, 3, 333, 64), (1, 1, 1024, 64), (1, 2, 31, 64)])
+                                   (1, 2, 128, 64), (2, 2, 130, 64), (1, 3, 333, 64), (1, 1, 1024, 64), (1, 2, 31, 64),
+                                   (1, 2, 128, 256), (2, 2, 130, 256), (1, 2, 333, 256), (1, 1, 640, 256)])
 @pytest.mark.parametrize("dt", ["bf16", "fp16"])
 @pytest.mark.parametrize("causal", [False, True])
 def test_backward_mfma16_vs_oracle(ctx, shape, dt, causal):
-    """head_dim 128 / 64 with 16-bit operands takes the bf16/fp16 MFMA backward (P and dS rounded to the input type
+    """head_dim 256 / 128 / 64 with 16-bit operands takes the bf16/fp16 MFMA backward (P and dS rounded to the input type
     before their second product, like P in the forward): relative bound instead of the fp32 one.  The reference's
     own gradient thresholds are far looser (cosine >= 0.7, rel-err <= 30 %, docs/attic/QUANTIZED_TRAINING_BINDINGS.md)."""
     import umfa

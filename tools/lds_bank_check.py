@@ -62,11 +62,11 @@ for DP in (32, 64, 128, 256):
 
 # ---- dual-use images of csrc/fa_bwd_16.hip: rows of 2*DP bytes read both by rows (ds_read_b128) and transposed
 def d_off(DP, row, ch):
-    f = (((row & 3) << 2) | ((row >> 2) & 3)) if DP == 128 else (((row >> 2) & 3) | (((row >> 1) & 1) << 2))
+    f = (((row & 3) << 2) | ((row >> 2) & 3)) if DP >= 128 else (((row >> 2) & 3) | (((row >> 1) & 1) << 2))
     return 2 * DP * row + 16 * (ch ^ f)
 
 
-for DP in (128, 64):
+for DP in (256, 128, 64):
     worst_row = worst_tr = 0
     for ks in range(DP // 16):
         for g in B128_GROUPS:

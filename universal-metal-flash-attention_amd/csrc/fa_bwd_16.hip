@@ -1,4 +1,4 @@
-// fa_bwd_16.hip -- bf16 / fp16 MFMA backward for gfx950, head_dim 128 (the FLUX / config-3 shape) and 64.
+// fa_bwd_16.hip -- bf16 / fp16 MFMA backward for gfx950, head_dim 128 (the FLUX / config-3 shape), 64 and 256.
 //
 // Same contract as fa_bwd.hip (mfa_attention_backward, MFABridge.swift:3171-3282: D = rowsum(dO o O), dQ, dK, dV in
 // fp32, two dispatches "backward query" then "backward key-value", no atomics) with the five products on
@@ -31,12 +31,15 @@ namespace {
 #define BWD16_GEO(DP)                                                                    \
     constexpr int ROW_B = 2 * DP, NKS = DP / 16, NDB = DP / 32, TILE_BYTES = 32 * ROW_B; \
     constexpr int TILE_PIECES = TILE_BYTES / 1024;                                       \
-    constexpr int PD = DP == 128 ? 4 : 2 /* k-steps of LDS row fragments in flight ahead of their MFMAs */
+    constexpr int PD = DP >= 128 ? 4 : 2; /* k-steps of LDS row fragments in flight ahead of their MFMAs */ \
+    constexpr int NH = DP == 256 ? 2 : 1; /* dkdv: passes over the query range, each owning NDB / NH d-blocks of dK, dV */ \
+    [[maybe_unused]] constexpr int NDBH = NDB / NH
 
 template <int DP>
 __device__ __forceinline__ constexpr int d_off(int row, int ch) {
-    static_assert(DP == 128 || DP == 64, "swizzles exist for 256- and 128-byte rows");
-    const int f = DP == 128 ? (((row & 3) << 2) | ((row >> 2) & 3)) : (((row >> 2) & 3) | (((row >> 1) & 1) << 2));
+    static_assert(DP == 256 || DP == 128 || DP == 64, "swizzles exist for 512-, 256- and 128-byte rows");
+    // rows of 256 and 512 bytes all start at bank 0, so they share one swizzle (on the low four chunk-index bits)
+    const int f = DP >= 128 ? (((row & 3) << 2) | ((row >> 2) & 3)) : (((row >> 2) & 3) | (((row >> 1) & 1) << 2));
     return 2 * DP * row + 16 * (ch ^ f);
 }
 
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256) void bwd16_delta_kernel(BwdParams p) {
 
 // ------------------------------------------------------------------------------------------------ dQ
 template <typename T, bool CAUSAL, int DP>
-__global__ __launch_bounds__(256, 2) void bwd16_dq_kernel(BwdParams p) {
+__global__ __launch_bounds__(256, DP == 256 ? 1 : 2) void bwd16_dq_kernel(BwdParams p) {
     BWD16_GEO(DP);
     typedef Mma16<T> M;
     typedef typename M::V8 V8;
@@ -282,12 +285,17 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
             vec[2 * QROWS + (t & 1) * QROWS + tid] = ok ? p.dvec[(int64_t)bh * p.Sq + row] : 0.0f;
         }
     };
-    f32x16 dk[NDB], dv[NDB];
+    const int tr_qq = (lane >> 2) & 3, tr_pp = lane & 3, tr_g1 = (lane >> 4) & 1;
+    // head_dim 256: dK and dV of all 8 d-blocks (256 accumulator registers) do not fit beside the K / V fragments (128),
+    // so the query range is swept NH = 2 times, each pass owning 4 d-blocks (S and dP are recomputed: 6 products
+    // issued for 4 -- against the fp32-exact path this head_dim had to take before, still > 10x)
+#pragma unroll 1
+    for (int hpass = 0; hpass < NH; ++hpass) {
+    f32x16 dk[NDBH], dv[NDBH];
 #pragma unroll
-    for (int i = 0; i < NDB; ++i)
+    for (int i = 0; i < NDBH; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[i][r] = 0.0f; dv[i][r] = 0.0f; }
-    const int tr_qq = (lane >> 2) & 3, tr_pp = lane & 3, tr_g1 = (lane >> 4) & 1;
 
     if (t0 < ntiles) stage(t0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -346,11 +354,11 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
                 }
                 // dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]
 #pragma unroll
-                for (int i = 0; i < NDB; ++i)
+                for (int i = 0; i < NDBH; ++i)
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2) {
-                        dv[i] = M::mma(tr_frag<M, DP>(dOt + u * TILE_BYTES, i, s2, hi, tr_qq, tr_pp, tr_g1), pb[s2], dv[i]);
-                        dk[i] = M::mma(tr_frag<M, DP>(Qt + u * TILE_BYTES, i, s2, hi, tr_qq, tr_pp, tr_g1), sb[s2], dk[i]);
+                        dv[i] = M::mma(tr_frag<M, DP>(dOt + u * TILE_BYTES, i + hpass * NDBH, s2, hi, tr_qq, tr_pp, tr_g1), pb[s2], dv[i]);
+                        dk[i] = M::mma(tr_frag<M, DP>(Qt + u * TILE_BYTES, i + hpass * NDBH, s2, hi, tr_qq, tr_pp, tr_g1), sb[s2], dk[i]);
                     }
             }
         }
@@ -361,25 +369,26 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
         float* okp = p.dk + ((int64_t)bh * p.Skv + key) * DP;
         float* ovp = p.dv + ((int64_t)bh * p.Skv + key) * DP;
 #pragma unroll
-        for (int i = 0; i < NDB; ++i)
+        for (int i = 0; i < NDBH; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int d0 = 32 * i + 8 * g + 4 * hi;
+                const int d0 = 32 * (i + hpass * NDBH) + 8 * g + 4 * hi;
                 f32x4 kv = {dk[i][4 * g] * p.scale, dk[i][4 * g + 1] * p.scale, dk[i][4 * g + 2] * p.scale, dk[i][4 * g + 3] * p.scale};
                 f32x4 vv = {dv[i][4 * g], dv[i][4 * g + 1], dv[i][4 * g + 2], dv[i][4 * g + 3]};
                 *(f32x4*)(okp + d0) = kv;
                 *(f32x4*)(ovp + d0) = vv;
             }
     }
+    }  // hpass
 }
 
 bool bwd_16_supported(const BwdParams& p) {
     if (p.in_prec != P_FP16 && p.in_prec != P_BF16) return false;
-    if (p.dout_prec != p.in_prec || (p.D != 128 && p.D != 64) || p.mask) return false;
+    if (p.dout_prec != p.in_prec || (p.D != 256 && p.D != 128 && p.D != 64) || p.mask) return false;
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     if (!al16(p.q) || !al16(p.k) || !al16(p.v) || !al16(p.dout) || !al16(p.dq) || !al16(p.dk) || !al16(p.dv)) return false;
     // 32-bit buffer offsets inside one (batch, head) slab
-    return (uint64_t)p.Sq * 256 < (1ull << 31) && (uint64_t)p.Skv * 256 < (1ull << 31);
+    return (uint64_t)p.Sq * 2 * p.D < (1ull << 31) && (uint64_t)p.Skv * 2 * p.D < (1ull << 31);
 }
 
 template <typename T, bool CAUSAL, int DP>
@@ -391,6 +400,8 @@ static hipError_t launch_bwd16_t(const BwdParams& p, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)bwd16_dkdv_kernel<T, CAUSAL, DP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)bwd16_dq_kernel<T, CAUSAL, DP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
@@ -407,6 +418,11 @@ hipError_t launch_bwd_16(const BwdParams& p, hipStream_t stream, const char** na
         *name = bf ? "fa_bwd16<bf16,128>" : "fa_bwd16<fp16,128>";
         if (bf) return p.causal ? launch_bwd16_t<__bf16, true, 128>(p, stream) : launch_bwd16_t<__bf16, false, 128>(p, stream);
         return p.causal ? launch_bwd16_t<_Float16, true, 128>(p, stream) : launch_bwd16_t<_Float16, false, 128>(p, stream);
+    }
+    if (p.D == 256) {
+        *name = bf ? "fa_bwd16<bf16,256>" : "fa_bwd16<fp16,256>";
+        if (bf) return p.causal ? launch_bwd16_t<__bf16, true, 256>(p, stream) : launch_bwd16_t<__bf16, false, 256>(p, stream);
+        return p.causal ? launch_bwd16_t<_Float16, true, 256>(p, stream) : launch_bwd16_t<_Float16, false, 256>(p, stream);
     }
     *name = bf ? "fa_bwd16<bf16,64>" : "fa_bwd16<fp16,64>";
     if (bf) return p.causal ? launch_bwd16_t<__bf16, true, 64>(p, stream) : launch_bwd16_t<__bf16, false, 64>(p, stream);

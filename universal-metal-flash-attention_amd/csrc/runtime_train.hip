@@ -49,7 +49,7 @@ mfa_error_t mfa_attention_backward(mfa_context_t context, mfa_buffer_t dout, mfa
         !bl->fits(nr * 4) || !bdq->fits(nq * 4) || !bdk->fits(nkv * 4) || !bdv->fits(nkv * 4) || !bd->fits(nr * 4))
         return MFA_ERROR_INVALID_ARGS;
     if (nq == 0 || nkv == 0) return MFA_SUCCESS;
-    if (D > 128) return MFA_ERROR_INVALID_ARGS;  // backward is built for head_dim <= 128 this round
+    if (D > 256) return MFA_ERROR_INVALID_ARGS;  // like the forward: head_dim <= 256
 
     for (Buffer* b : {bdo, bq, bk, bv, bo, bl})
         if (b->upload(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;

@@ -218,7 +218,7 @@ def scaled_dot_product_attention(query, key, value, attn_mask: Optional[torch.Te
         out = _QuantizedFlashAttentionFn.apply(q, k, v, bool(is_causal), sm_scale, _quant_precision, _quant_mode, mask)
         return out.to(query.dtype)
     if q.requires_grad or k.requires_grad or v.requires_grad:
-        if mask is not None or q.size(3) > 128:
+        if mask is not None or q.size(3) > 256:
             return fallback()  # dense backward takes no mask (:1798-1803)
         _bump("fp32_autograd")
         return _FlashAttentionFn.apply(q, k, v, bool(is_causal), sm_scale)
@@ -344,7 +344,7 @@ def rope_scaled_dot_product_attention(query, key, value, rope_cos, rope_sin, att
         return eager()
     sm_scale = float(scale) if scale is not None else float(D) ** -0.5
     if needs_grad:
-        if attn_mask is not None or Hq != Hkv or D > 128:
+        if attn_mask is not None or Hq != Hkv or D > 256:
             return eager()
         _bump("total")
         _bump("rope_autograd")
