@@ -111,12 +111,12 @@ def test_backward_mfma16_vs_oracle(ctx, shape, dt, causal):
         assert np.abs(got - ref).max() < 5e-5 * max(1.0, np.abs(ref).max())
 
 
-def _prequant_case(bits, grouped, blockwise, causal):
+def _prequant_case(bits, grouped, blockwise, causal, D=64):
     """caller-side quantisation (QuantizationTests.swift:72-128 formula), expected gradients from the oracle's fp64
     backward on the de-quantised operands (K / V broadcast over their group, gradients summed over it)"""
     from oracle import oracle as orc
     rng = np.random.default_rng(bits * 100 + grouped * 10 + blockwise)
-    B, H, Hkv, Sq, Skv, D = 2, 4, (2 if grouped else 4), 80, 96, 64
+    B, H, Hkv, Sq, Skv = 2, 4, (2 if grouped else 4), 80, 96
     qmax = 127 if bits == 8 else 7
     BS = 32
 
@@ -171,6 +171,15 @@ def test_prequantized_backward_abi(ctx, bits, grouped, blockwise, causal):
     assert ctx.last_kernel.startswith("fa_bwd_exact")
     for got, ref, name in ((gq, dq, "dq"), (gk, dk, "dk"), (gv, dv, "dv"), (gd, dvec.ravel(), "D")):
         assert np.isfinite(got).all(), name
+        assert np.abs(got - ref).max() < 2e-4 * max(1.0, np.abs(ref).max()), name
+
+
+def test_prequantized_backward_head_dim_256(ctx):
+    from umfa.core import prequantized_backward
+    kwargs, (dq, dk, dv, dvec) = _prequant_case(8, True, True, True, D=256)
+    gq, gk, gv, gd = prequantized_backward(ctx, **kwargs)
+    assert ctx.last_kernel == "fa_bwd_exact<256>"
+    for got, ref, name in ((gq, dq, "dq"), (gk, dk, "dk"), (gv, dv, "dv"), (gd, dvec.ravel(), "D")):
         assert np.abs(got - ref).max() < 2e-4 * max(1.0, np.abs(ref).max()), name
 
 

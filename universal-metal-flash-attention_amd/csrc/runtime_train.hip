@@ -156,7 +156,7 @@ int32_t mfa_quantized_backward(mfa_context_t context, mfa_buffer_t q, mfa_buffer
         return MFA_ERROR_INVALID_ARGS;
     if (bm && !bm->fits(nr * Skv * 4)) return MFA_ERROR_INVALID_ARGS;
     if (nq == 0 || nkv == 0) return MFA_SUCCESS;
-    if (!quantized_supported(D) || D > 128) return MFA_ERROR_INVALID_ARGS;
+    if (!quantized_supported(D)) return MFA_ERROR_INVALID_ARGS;  // head_dim <= 256, multiple of 8
     const int bits = target_precision == MFA_PRECISION_INT4 ? 4 : 8;
     const int mode = quant_mode == 2 ? 2 : 0;
 
@@ -225,7 +225,7 @@ int raw_prec(int32_t v) { return (v >= 0 && v <= 4) ? (int)v : P_FP16; }  // unk
 // validates, uploads and de-quantises Q, K, V into ws = [Q fp32 | K fp32 (H heads) | V fp32 (H heads)]
 mfa_error_t prequant_stage(Context* ctx, const PreQuant& a, float** qf, float** kf, float** vf, size_t extra_bytes,
                            char** extra, hipStream_t stream) {
-    if (a.D == 0 || a.D > 128 || a.H == 0 || a.Hkv == 0 || a.H % a.Hkv) return MFA_ERROR_INVALID_ARGS;
+    if (a.D == 0 || a.D > 256 || a.H == 0 || a.Hkv == 0 || a.H % a.Hkv) return MFA_ERROR_INVALID_ARGS;
     const size_t nq = (size_t)a.B * a.H * a.Sq * a.D, nkv_src = (size_t)a.B * a.Hkv * a.Skv * a.D;
     const size_t nkv = (size_t)a.B * a.H * a.Skv * a.D;
     if (!a.q->fits(quant_bytes(a.qp, nq)) || !a.k->fits(quant_bytes(a.kp, nkv_src)) || !a.v->fits(quant_bytes(a.vp, nkv_src)))
