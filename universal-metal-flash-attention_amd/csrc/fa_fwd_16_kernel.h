@@ -96,9 +96,25 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
         item = p.n_full + j / nparts;
         part = j % nparts;
     }
-    const uint32_t bh = item / nqb;
+    uint32_t bh = item / nqb;
     uint32_t qb = item % nqb;
-    if (CAUSAL) qb = nqb - 1 - qb;
+    if (CAUSAL) {
+        qb = nqb - 1 - qb;  // longest items first
+#ifndef UMFA_LAB_NO_CAUSAL_PAIRS
+        // Causal items differ in length (q-block j sweeps j + 1 of nqb key ranges), and the workgroups that share a CU
+        // finish together only if their lengths add up alike.  Measured on MI355X (tools/bench_graph.py, variants of the
+        // swap bit): the dispatcher co-locates workgroups that are one CU-count of an XCD (32) apart in XCD-local order,
+        // not consecutive ones.  So consecutive items form a mirrored pair (j, nqb - 1 - j) and the pair 32 items
+        // further on has its long and short member swapped: every CU gets one long and one short item.
+        // B4 H16 S1024 D64 causal (BASELINE config 2) 27.5 -> 22.5 us, D128 44.3 -> 39.8, B2 H16 S4096 D64 120 -> 107.
+        if ((nqb & 1) == 0 && p.n_full == nqb * p.B * p.H) {  // every item whole (no split tail with its own numbering)
+                        const uint32_t pi = item >> 1, second = item & 1, flip = (item >> 5) & 1, h2 = nqb >> 1;
+            const uint32_t j = pi % h2;
+            bh = pi / h2;
+            qb = (second ^ flip) ? j : nqb - 1 - j;
+        }
+#endif
+    }
     const uint32_t b = bh / p.H, h = bh % p.H;
     const uint32_t q_row = qb * BM + wave * 32 + ql;
     const uint32_t wave_q0 = qb * BM + wave * 32;
