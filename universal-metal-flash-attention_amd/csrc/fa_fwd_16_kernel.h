@@ -107,7 +107,12 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
         // not consecutive ones.  So consecutive items form a mirrored pair (j, nqb - 1 - j) and the pair 32 items
         // further on has its long and short member swapped: every CU gets one long and one short item.
         // B4 H16 S1024 D64 causal (BASELINE config 2) 27.5 -> 22.5 us, D128 44.3 -> 39.8, B2 H16 S4096 D64 120 -> 107.
-        if ((nqb & 1) == 0 && p.n_full == nqb * p.B * p.H) {  // every item whole (no split tail with its own numbering)
+        // Only for short launches (the whole grid resident, or a few rounds of short items): beyond that the
+        // dispatcher refills slots as they free up and plain longest-first is the better schedule -- a long item
+        // dispatched late is the tail (B1 H32 S8192 D64: 342 us longest-first vs 369 paired; head_dim 256 runs one
+        // workgroup per CU and has nothing to pair).
+        if ((nqb & 1) == 0 && DP <= 128 && p.n_full == nqb * p.B * p.H  // every item whole (no split tail with its own numbering)
+            && (uint64_t)p.n_full * nqb <= 32768) {
                         const uint32_t pi = item >> 1, second = item & 1, flip = (item >> 5) & 1, h2 = nqb >> 1;
             const uint32_t j = pi % h2;
             bh = pi / h2;
