@@ -53,6 +53,8 @@ class Cfg:
 C = Cfg(False)
 
 COST = {"UPDK": 4, "UPDV": 4, "BAR": 16, "KPRE": 4, "I2F": 4, "MASK": 8, "DMAK": 8, "DMAV": 8, "NOP": 32, "EXP": 8, "ADD": 4, "CVT": 4, "VREAD": 8, "KREAD": 4, "MAX": 4, "DEC": 44, "FMA": 4}
+for _kv in filter(None, os.environ.get("W64_COST", "").split(",")):  # lab: W64_COST=EXP:16,ADD:4 overrides the model
+    COST[_kv.split(":")[0]] = int(_kv.split(":")[1])
 
 NPRE = 4  # K fragments (kb=0, ks<NPRE) read before the iteration starts (by the includer, after the barrier)
 
