@@ -213,9 +213,18 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, ql = lane & 31, hi = lane >> 5;
     const uint32_t nqb = (p.Sq + BM - 1) / BM;
     const uint32_t vid = xcd_remap(blockIdx.x, nqb * p.B * p.H);
-    const uint32_t bh = vid / nqb;
+    uint32_t bh = vid / nqb;
     uint32_t qb = vid % nqb;
-    if (CAUSAL) qb = nqb - 1 - qb;
+    if (CAUSAL) {
+        qb = nqb - 1 - qb;
+        // short causal launches: one long and one short item of a mirrored pair per CU (fa_fwd_16_kernel.h, where
+        // the dispatcher's co-location rule -- XCD-local workgroups 32 apart -- was measured)
+        if ((nqb & 1) == 0 && DP <= 128 && (uint64_t)nqb * nqb * p.B * p.H <= 32768) {
+            const uint32_t pi = vid >> 1, h2 = nqb >> 1, j = pi % h2;
+            bh = pi / h2;
+            qb = (((vid & 1) ^ (vid >> 5)) & 1) ? j : nqb - 1 - j;
+        }
+    }
     const uint32_t q_row = qb * BM + wave * 32 + ql;
     const uint32_t wave_q0 = qb * BM + wave * 32;
     const int D = (int)p.D;
