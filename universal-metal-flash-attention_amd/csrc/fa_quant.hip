@@ -111,9 +111,10 @@ __global__ __launch_bounds__(256) void quantize_kernel(QuantParams p) {
         if (ch < nchunks) {
             const uint32_t r = ch / cpr, d0 = (ch % cpr) * 8;
             // IEEE divide + round-half-away: bit-exact with the oracle (tests/test_gpu_quantized.py checks the integers).
-            // (A reciprocal-multiply fast path with an exact fallback near rounding boundaries measured slower, 49 vs 41 us
-            // at the FLUX shape; a plain multiply -- not bit-exact -- would be 32 us: the divide is ~7 of the ~13 VALU
-            // instructions per element and the boundary test would put 3 of them back.)
+            // (A reciprocal-multiply fast path with an exact fallback near rounding boundaries measured slower twice: per
+            // element 49 vs 41 us at the FLUX shape, per 8-element chunk with a wave ballot 44.5 vs 40.8; a plain
+            // multiply -- not bit-exact -- would be 32 us: the divide is ~7 of the ~13 VALU instructions per element and
+            // the boundary test puts them back.)
             int q[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
