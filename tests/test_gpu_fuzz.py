@@ -17,6 +17,15 @@ GTOL = {torch.bfloat16: 3e-2, torch.float16: 8e-3, torch.float32: 1e-4}  # gradi
 
 
 def _ref(q, k, v, scale, causal, mask):
+    if q.dtype in (torch.float32, torch.float64):  # fp32 operands: the restatement itself in fp64
+        q, k, v = q.double(), k.double(), v.double()
+        s = torch.matmul(q, k.transpose(-1, -2)) * scale
+        Sq, Skv = s.shape[-2:]
+        if causal:
+            s = s.masked_fill(~torch.ones(Sq, Skv, dtype=torch.bool, device=q.device).tril(), float("-inf"))
+        if mask is not None:
+            s = s.masked_fill(~mask, float("-inf")) if mask.dtype == torch.bool else s + mask.double()
+        return torch.matmul(torch.softmax(s, dim=-1), v)
     s = torch.matmul(q.float(), k.float().transpose(-1, -2)) * scale
     Sq, Skv = s.shape[-2:]
     if causal:
@@ -70,7 +79,7 @@ def _mask(kind, B, H, Sq, Skv, g):
     return m
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(96))
 def test_forward_random_case(seed):
     import umfa_torch
     dt, B, H, Sq, Skv, D, causal, mk, strided = _case(seed)
@@ -81,7 +90,7 @@ def test_forward_random_case(seed):
     out, lse = umfa_torch.attention_forward(q, k, v, causal=causal, mask=mask, out_dtype=torch.float32, return_lse=True)
     what = (seed, dt, B, H, Sq, Skv, D, causal, mk, strided, umfa_torch.last_kernel())
     assert torch.isfinite(out).all(), what
-    rel = ((out - ref).abs().max() / ref.abs().max()).item()
+    rel = ((out.to(ref.dtype) - ref).abs().max() / ref.abs().max()).item()
     assert rel < TOL[dt], (rel, what)
     # log-sum-exp (natural log) of the scaled, masked scores
     s = torch.matmul(q.float(), k.float().transpose(-1, -2)) * scale
@@ -93,10 +102,10 @@ def test_forward_random_case(seed):
     # the fused cast-back epilogue agrees with the fp32 output rounded once
     if dt != torch.float32:
         o2 = umfa_torch.attention_forward(q, k, v, causal=causal, mask=mask)
-        assert o2.dtype == dt and ((o2.float() - out).abs().max() / ref.abs().max()).item() < 2 * TOL[dt], what
+        assert o2.dtype == dt and ((o2.float() - out).abs().max() / ref.abs().max().float()).item() < 2 * TOL[dt], what
 
 
-@pytest.mark.parametrize("seed", range(100, 124))
+@pytest.mark.parametrize("seed", range(100, 164))
 def test_backward_random_case(seed):
     import umfa_torch
     dt, B, H, Sq, Skv, D, causal, mk, strided = _case(seed)
@@ -104,8 +113,9 @@ def test_backward_random_case(seed):
     Sq, Skv = min(Sq, 1024), min(Skv, 1024)
     q, k, v, g = _tensors(seed, dt, B, H, Sq, Skv, D, False)
     do = torch.randn(B, H, Sq, D, device="cuda", dtype=dt, generator=g)
-    qr, kr, vr = (t.detach().float().requires_grad_(True) for t in (q, k, v))
-    _ref(qr, kr, vr, D ** -0.5, causal, None).backward(do.float())
+    ref_dt = torch.float64 if dt == torch.float32 else torch.float32
+    qr, kr, vr = (t.detach().to(ref_dt).requires_grad_(True) for t in (q, k, v))
+    _ref(qr, kr, vr, D ** -0.5, causal, None).backward(do.to(ref_dt))
     qg, kg, vg = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
     out = umfa_torch.scaled_dot_product_attention(qg, kg, vg, is_causal=causal)
     out.backward(do)
@@ -114,5 +124,10 @@ def test_backward_random_case(seed):
         assert got is not None and torch.isfinite(got).all(), (name, what)
         # Skv = 1 makes dQ exactly 0 in exact arithmetic (dS = P (dP - D) with P = 1, D = dP): the floor of the
         # denominator keeps the metric meaningful there (operands are N(0,1), ordinary gradients are O(0.1 .. 1))
-        rel = ((got.float() - ref).abs().max() / ref.abs().max().clamp_min(0.05)).item()
+        rel = ((got.to(ref.dtype) - ref).abs().max() / ref.abs().max().clamp_min(0.05)).item()
+        if Skv == 1 and name != "dv":
+            # ... and what is measured there is the cancellation noise of dP - D (both O(10), D from the rounded O the
+            # caller hands back), summed over the queries: bounded absolutely, not against an exact zero
+            assert (got.to(ref.dtype) - ref).abs().max().item() < 1e-6 * Sq + GTOL[dt] * 0.05, (name, what)
+            continue
         assert rel < GTOL[dt], (name, rel, what)
