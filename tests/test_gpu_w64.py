@@ -196,7 +196,8 @@ def test_w64_small_ragged_sq_stays_on_the_128_row_kernel():
 
 @pytest.mark.parametrize("shape,causal,expect_w64", [((1, 24, 4096, 4096), False, True), ((1, 24, 1024, 1024), False, False),
                                                      ((4, 16, 1024, 1024), True, False), ((8, 16, 1024, 1024), True, True),
-                                                     ((1, 4, 4096, 4096), False, True), ((1, 16, 2048, 2048), True, False)])
+                                                     ((1, 4, 4096, 4096), False, True), ((1, 16, 2048, 2048), True, False),
+                                                     ((1, 256, 256, 256), False, True), ((1, 8, 2048, 2048), False, True)])
 def test_w64_dispatch_gate(shape, causal, expect_w64):
     """without UMFA_FORCE_W64: one-workgroup-per-CU kernel only when there is work for (most of) the CUs"""
     import umfa_torch

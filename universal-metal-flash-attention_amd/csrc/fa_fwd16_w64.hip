@@ -140,8 +140,12 @@ bool fwd_w64_supported(const FwdParams& p) {
         const uint64_t nqb = (p.Sq + 255) / 256;
         if (p.causal) {
             if ((uint64_t)p.B * p.H * ((nqb + 1) / 2) * 4 < cus * 3) return false;
-        } else if ((uint64_t)p.B * p.H * nqb * ((p.Skv + 63) / 64) < cus * 10) {
-            return false;
+        } else {
+            // whole rounds (every workgroup one or more complete items, nothing to fold) win at any size: B1 H256 S256
+            // 19 / 22 us, B1 H128 S512 27 / 32; cut items need 10 tile steps per CU, 8 with long key ranges
+            // (B1 H32 S1024: 35 / 33, B1 H8 S2048: 39 / 44, B1 H40 S1024: 44 / 46, B1 H96 S512: 35 / 30)
+            const uint64_t items = (uint64_t)p.B * p.H * nqb, steps = items * ((p.Skv + 63) / 64);
+            if (items % cus != 0 && steps < cus * 10 && !(steps >= cus * 8 && p.Skv >= 2048)) return false;
         }
     }
     return true;
