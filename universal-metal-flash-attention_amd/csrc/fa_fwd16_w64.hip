@@ -139,7 +139,7 @@ bool fwd_w64_supported(const FwdParams& p) {
         const uint64_t cus = (uint64_t)w64_cu_count();
         const uint64_t nqb = (p.Sq + 255) / 256;
         if (p.causal) {
-            if ((uint64_t)p.B * p.H * ((nqb + 1) / 2) * 4 < cus * 3) return false;
+            if ((uint64_t)p.B * p.H * ((nqb + 1) / 2) * 8 < cus * 5) return false;  // 160 jobs: 78 / 85, 126 / 150, 217 / 258 us
         } else {
             // whole rounds (every workgroup one or more complete items, nothing to fold) win at any size: B1 H256 S256
             // 19 / 22 us, B1 H128 S512 27 / 32; cut items need 10 tile steps per CU, 8 with long key ranges
