@@ -94,3 +94,17 @@ def test_generated_streams_are_current(tmp_path):
     assert (tmp_path / "b16.inc").read_text() == (CSRC / "fa_fwd16_w64_body.inc").read_text()
     assert (tmp_path / "bi8.inc").read_text() == (CSRC / "fa_fwd_w64_i8_body.inc").read_text()
     assert (CSRC / "fa_fwd16_w64_regs.inc").read_text() == regs  # the helper file is rewritten in place: unchanged
+
+
+def test_lds_images_are_conflict_free_in_the_bank_model():
+    """tools/lds_bank_check.py models the LDS bank rules for every tile image the kernels use (forward K / V images,
+    the dual-use row + transposed images of the bf16 backward at head_dim 64 / 128 / 256): all must read 1-way."""
+    import subprocess
+    import sys
+    out = subprocess.check_output([sys.executable, str(ROOT / "tools" / "lds_bank_check.py")], text=True)
+    lines = [ln for ln in out.splitlines() if "-way" in ln]
+    assert len(lines) >= 7, out
+    for ln in lines:
+        for tok in ln.replace(",", " ").split():
+            if tok.endswith("-way"):
+                assert tok == "1-way", ln
