@@ -298,3 +298,54 @@ def test_flux_shape_one_head_vs_oracle(ctx):
     c = torch.corrcoef(flat[:, :65536])
     off = c - torch.diag(torch.diag(c))
     assert float(off.abs().max()) < 0.95
+
+
+@pytest.mark.parametrize("kind", ["sliding_bool", "padding_bcast", "blockdiag_float", "random_bool", "causal_plus_window", "odd_skv_bool"])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_mask_tile_early_exit(kind, dt, monkeypatch):
+    """Masks go through a pre-pass that classifies every (32 rows x 64 keys) tile (fa_aux.hip mask_flags_kernel):
+    fully masked tiles are skipped, fully open ones run without reading the mask.  Structured masks (sliding window,
+    key padding, block-diagonal additive -inf) must give the same bits as the per-score path (UMFA_NO_MASK_FLAGS=1)
+    and agree with the fp32 restatement; an unstructured random mask exercises the mixed-tile path."""
+    import umfa_torch
+    torch.manual_seed(11)
+    B, H, Sq, Skv, D = 2, 3, 640, (701 if kind == "odd_skv_bool" else 704), 128
+    q = torch.randn(B, H, Sq, D, device="cuda", dtype=dt)
+    k = torch.randn(B, H, Skv, D, device="cuda", dtype=dt)
+    v = torch.randn(B, H, Skv, D, device="cuda", dtype=dt)
+    i = torch.arange(Sq, device="cuda")[:, None]
+    j = torch.arange(Skv, device="cuda")[None, :]
+    causal = False
+    if kind in ("sliding_bool", "odd_skv_bool"):
+        mask = ((j - i).abs() <= 100)[None, None]                               # [1,1,Sq,Skv] bool, broadcast over b, h
+    elif kind == "padding_bcast":
+        lens = torch.tensor([500, 130], device="cuda")
+        mask = (j[None] < lens[:, None, None])[:, None]                          # [B,1,1,Skv] key padding
+    elif kind == "blockdiag_float":
+        blk = (i // 160 == j // 176)
+        mask = torch.where(blk, 0.0, float("-inf")).to(torch.float32)[None, None].expand(B, H, Sq, Skv).contiguous()
+        mask[:, 1] += 0.25 * torch.randn(Sq, Skv, device="cuda")                 # one head with non-zero finite terms
+        mask = torch.where(blk[None, None], mask, torch.full_like(mask, float("-inf")))
+    elif kind == "random_bool":
+        mask = torch.rand(B, H, Sq, Skv, device="cuda") < 0.7
+        mask[..., 0] = True
+    else:
+        causal = True
+        mask = ((i - j) <= 192)[None, None]                                      # causal AND a look-back window
+
+    def ref():
+        s = torch.matmul(q.float(), k.float().transpose(-1, -2)) * D ** -0.5
+        if causal:
+            s = s.masked_fill(~torch.ones(Sq, Skv, dtype=torch.bool, device="cuda").tril(), float("-inf"))
+        s = s.masked_fill(~mask, float("-inf")) if mask.dtype == torch.bool else s + mask
+        return torch.matmul(torch.softmax(s, dim=-1), v.float())
+
+    out, lse = umfa_torch.attention_forward(q, k, v, causal=causal, mask=mask, out_dtype=torch.float32, return_lse=True)
+    assert umfa_torch.last_kernel().startswith("fa_fwd16<")
+    r = ref()
+    assert torch.isfinite(out).all()
+    assert ((out - r).abs().max() / r.abs().max()).item() < (6e-3 if dt == torch.bfloat16 else 2e-3)
+    monkeypatch.setenv("UMFA_NO_MASK_FLAGS", "1")
+    out2, lse2 = umfa_torch.attention_forward(q, k, v, causal=causal, mask=mask, out_dtype=torch.float32, return_lse=True)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2) and torch.equal(lse, lse2)  # skipping / not reading changes no bit

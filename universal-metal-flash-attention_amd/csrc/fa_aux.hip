@@ -216,4 +216,75 @@ hipError_t launch_group_sum(const float* src, float* dst, uint32_t B, uint32_t H
     return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------ mask tile flags (tile early-exit of fa_fwd16)
+// One wave per (mask batch, mask head, 32-row block, 64-key tile): lane = key of the tile, 32 rows each.  Reads every
+// distinct mask element once (broadcast dims are not expanded).  FwdParams::mask_flags documents the byte.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+template <bool VEC16>
+__global__ __launch_bounds__(256) void mask_flags_kernel(FwdParams p, uint8_t* flags, uint32_t Bm, uint32_t Hm) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wid = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t total = (uint64_t)Bm * Hm * p.mf_nrb * p.mf_ntiles;
+    if (wid >= total) return;
+    const uint32_t tile = (uint32_t)(wid % p.mf_ntiles);
+    const uint32_t rb = (uint32_t)((wid / p.mf_ntiles) % p.mf_nrb);
+    const uint32_t slab = (uint32_t)(wid / ((uint64_t)p.mf_ntiles * p.mf_nrb));
+    const uint32_t hm = slab % Hm, bm = slab / Hm;
+    const uint32_t key = tile * 64 + lane;
+    bool any_open = false, any_term = false;  // an element that attends / an element whose term is not +0
+    if (VEC16) {
+        // byte masks with contiguous, 16-byte aligned rows: a lane owns 16 keys of rows (lane / 4) and (lane / 4) + 16
+        const uint32_t key0 = tile * 64 + (lane & 3) * 16;
+        if (key0 < p.Skv) {  // Skv % 16 == 0 on this path: a segment is all in or all out
+            const uint8_t* base = (const uint8_t*)p.mask + (int64_t)bm * p.ms[0] + (int64_t)hm * p.ms[1] + key0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const uint32_t row = rb * 32 + (lane >> 2) + 16 * i;
+                if (row < p.Sq) {
+                    const u32x4_t w = *(const u32x4_t*)(base + (int64_t)row * p.ms[2]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        // per byte: non-zero attends (term +0), zero is masked (term -inf)
+                        const uint32_t nz = ((w[j] & 0x7f7f7f7fu) + 0x7f7f7f7fu | w[j]) & 0x80808080u;  // 0x80 per non-zero byte
+                        any_open |= nz != 0;
+                        any_term |= nz != 0x80808080u;
+                    }
+                }
+            }
+        }
+    } else if (key < p.Skv) {
+        const int64_t base = (int64_t)bm * p.ms[0] + (int64_t)hm * p.ms[1] + (int64_t)key * p.ms[3];
+        for (uint32_t i = 0; i < 32; ++i) {
+            const uint32_t row = rb * 32 + i;
+            if (row >= p.Sq) break;
+            const float t = mask_term(p.mask, base + (int64_t)row * p.ms[2], p.mask_kind);
+            any_open |= t != -INFINITY;
+            any_term |= t != 0.0f;
+        }
+    }
+    const bool open = __builtin_amdgcn_ballot_w64(any_open) != 0, term = __builtin_amdgcn_ballot_w64(any_term) != 0;
+    if (lane == 0) flags[wid] = !open ? 1 : (!term ? 2 : 0);
+}
+
+hipError_t launch_mask_flags(FwdParams& p, uint8_t* flags, hipStream_t stream) {
+    const uint32_t Bm = p.ms[0] != 0 ? p.B : 1, Hm = p.ms[1] != 0 ? p.H : 1;
+    p.mf_nrb = (p.Sq + 31) / 32;
+    p.mf_ntiles = (p.Skv + 63) / 64;
+    p.mf_bs = p.ms[0] != 0 ? Hm : 0;
+    p.mf_hs = p.ms[1] != 0 ? 1 : 0;
+    const uint64_t total = (uint64_t)Bm * Hm * p.mf_nrb * p.mf_ntiles;
+    const bool vec16 = p.mask_kind == MK_BOOL && p.ms[3] == 1 && p.Skv % 16 == 0 && ((uintptr_t)p.mask & 15) == 0 &&
+                       p.ms[2] % 16 == 0 && p.ms[1] % 16 == 0 && p.ms[0] % 16 == 0;
+    if (vec16) hipLaunchKernelGGL(mask_flags_kernel<true>, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream, p, flags, Bm, Hm);
+    else hipLaunchKernelGGL(mask_flags_kernel<false>, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream, p, flags, Bm, Hm);
+    p.mask_flags = flags;
+    return hipGetLastError();
+}
+
+size_t mask_flags_bytes(const FwdParams& p) {
+    const uint64_t Bm = p.ms[0] != 0 ? p.B : 1, Hm = p.ms[1] != 0 ? p.H : 1;
+    return (size_t)(Bm * Hm * ((p.Sq + 31) / 32) * ((p.Skv + 63) / 64));
+}
+
 }  // namespace umfa

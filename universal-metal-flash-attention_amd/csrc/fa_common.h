@@ -52,6 +52,12 @@ struct FwdParams {
     uint32_t nsplit;     // parts per split item (0/1 = no split)
     float* part_buf;     // [split item][part][wave 4][reg 16*NDB+2][lane 64] fp32
     uint32_t* part_cnt;  // [split item] arrival tickets, zeroed before every launch
+    // mask tile flags (fa_fwd_16, optional): one byte per (mask batch, mask head, 32-row block, 64-key tile) from
+    // mask_flags_kernel -- 0 mixed, 1 every in-range element masked (the tile is skipped), 2 every in-range element
+    // attends with a zero term (the tile runs without reading the mask)
+    const uint8_t* mask_flags;
+    uint32_t mf_bs, mf_hs;         // flag-row strides of batch / head in units of (mf_nrb * mf_ntiles); 0 = broadcast
+    uint32_t mf_nrb, mf_ntiles;    // 32-row blocks, 64-key tiles
 };
 
 struct BwdParams {

@@ -267,6 +267,14 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
     };
 
     const int64_t mrow = HAS_MASK ? ((int64_t)b * p.ms[0] + (int64_t)h * p.ms[1] + (int64_t)q_row * p.ms[2]) : 0;
+    // byte masks with contiguous 4-byte aligned rows: the four keys a lane owns per register group are one dword
+    const bool mvec = HAS_MASK && p.mask_kind == MK_BOOL && p.ms[3] == 1 && (p.Skv & 3) == 0 &&
+                      ((p.ms[0] | p.ms[1] | p.ms[2]) & 3) == 0 && ((uintptr_t)p.mask & 3) == 0;
+    // mask tile flags (FwdParams::mask_flags): this wave's 32 rows are one flag row; 64 tiles per register
+    const uint8_t* mf_row = nullptr;
+    int mf_reg = 0;
+    if (HAS_MASK && p.mask_flags && wave_q0 / 32 < p.mf_nrb)
+        mf_row = p.mask_flags + ((uint64_t)b * p.mf_bs + (uint64_t)h * p.mf_hs) * p.mf_nrb * p.mf_ntiles + (uint64_t)(wave_q0 / 32) * p.mf_ntiles;
 
     stage_load(t_begin);
     stage_write(t_begin & 1);
@@ -281,7 +289,16 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
         const char* Vt = Vbuf + cur * TILE_BYTES;
         const uint32_t key_base = t * BN;
         // wave-uniform: is any part of this tile visible to this wave's rows?
-        const bool active = !CAUSAL || key_base <= wave_q0 + 31;
+        bool active = !CAUSAL || key_base <= wave_q0 + 31;
+        int mflag = 0;  // 1: every element of this wave's tile is masked (skip), 2: none is (no mask reads)
+        if (HAS_MASK && mf_row) {
+            if (t == t_begin || (t & 63) == 0) {
+                const uint32_t t64 = t & ~63u;
+                mf_reg = t64 + lane < p.mf_ntiles ? (int)mf_row[t64 + lane] : 0;
+            }
+            mflag = __builtin_amdgcn_readlane(mf_reg, (int)(t & 63));
+            active = active && mflag != 1;
+        }
 #ifndef UMFA_ABL_NO_LOAD
         // next tile in flight under this tile's MFMAs (T14); past the end: all zeros.  SPLIT_DMA: only the K half
         // here, the V half behind the QK^T MFMAs of an active tile
@@ -320,14 +337,33 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
             // ---------------- online softmax (log2 domain) ----------------
             const bool edge = (key_base + BN > p.Skv) || (CAUSAL && key_base + BN - 1 > wave_q0);
             float mx = -INFINITY;
-            if (HAS_MASK) {
+            if (HAS_MASK && mvec && mflag != 2) {
+                // registers 4g .. 4g+3 of a 32-key block are keys 8g + 4hi + 0..3: one aligned dword of the mask row
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const uint32_t key0 = key_base + 32 * kb + 8 * g + 4 * hi;
+                        uint32_t w = 0;  // keys past Skv / rows past Sq: masked either way below
+                        if (key0 < p.Skv && q_row < p.Sq) w = *(const uint32_t*)((const uint8_t*)p.mask + mrow + key0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = 4 * g + e;
+                            float tv = s[kb][r] * c2;
+                            if (q_row < p.Sq && ((w >> (8 * e)) & 0xffu) == 0) tv = -INFINITY;
+                            if (key0 + e >= p.Skv || (CAUSAL && key0 + e > q_row)) tv = -INFINITY;
+                            s[kb][r] = tv;
+                            mx = fmaxf(mx, tv);
+                        }
+                    }
+            } else if (HAS_MASK) {
 #pragma unroll
                 for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const uint32_t key = key_base + 32 * kb + acc_row(r, hi);
                         float tv = s[kb][r] * c2;
-                        if (key < p.Skv && q_row < p.Sq)
+                        if (mflag != 2 && key < p.Skv && q_row < p.Sq)
                             tv += mask_term(p.mask, mrow + (int64_t)key * p.ms[3], p.mask_kind);
                         if (key >= p.Skv || (CAUSAL && key > q_row)) tv = -INFINITY;
                         s[kb][r] = tv;

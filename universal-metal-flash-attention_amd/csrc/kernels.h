@@ -92,4 +92,8 @@ hipError_t launch_quantized_fwd(const FwdParams& fp, int bits, int quant_mode, v
 bool fwd_w64_i8_supported(const FwdParams& p);
 hipError_t launch_fwd_w64_i8(const FwdParams& p, const QuantViews& v, float* part_buf, uint32_t* part_cnt, hipStream_t stream);
 
+// mask tile flags for fa_fwd16's tile early-exit (fa_aux.hip); launch_mask_flags fills p.mask_flags / mf_*
+size_t mask_flags_bytes(const FwdParams& p);
+hipError_t launch_mask_flags(FwdParams& p, uint8_t* flags, hipStream_t stream);
+
 }  // namespace umfa

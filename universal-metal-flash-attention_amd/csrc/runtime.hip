@@ -94,6 +94,12 @@ hipError_t dispatch_forward(Context* ctx, const FwdParams& p, int intermediate_p
                 pp.part_buf = (float*)(buf + plan.cnt_bytes);
             }
         }
+        if (pp.mask_kind != MK_NONE && !getenv("UMFA_NO_MASK_FLAGS")) {
+            // tile early-exit for masks: one pre-pass over the distinct mask elements classifies every (32 rows x 64
+            // keys) tile; fully masked tiles are skipped, fully open ones run without reading the mask
+            void* fl = ctx->ensure_mask_flags(mask_flags_bytes(pp));
+            if (fl && launch_mask_flags(pp, (uint8_t*)fl, stream) != hipSuccess) pp.mask_flags = nullptr;
+        }
         e = launch_fwd_16(pp, stream, &name);
     } else {
         e = launch_fwd_exact(p, stream, &name);

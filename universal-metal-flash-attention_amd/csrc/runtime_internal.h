@@ -68,6 +68,18 @@ struct Context {
         return w64_buf;
     }
 
+    void* mflag_buf = nullptr;
+    size_t mflag_bytes = 0;
+    void* ensure_mask_flags(size_t bytes) {
+        if (bytes <= mflag_bytes) return mflag_buf;
+        if (mflag_buf) (void)hipFree(mflag_buf);
+        mflag_buf = nullptr;
+        mflag_bytes = 0;
+        if (hipMalloc(&mflag_buf, bytes + 256) != hipSuccess) return nullptr;
+        mflag_bytes = bytes + 256;
+        return mflag_buf;
+    }
+
     void* ensure_workspace(size_t bytes) {
         if (bytes <= workspace_bytes) return workspace;
         if (workspace) (void)hipFree(workspace);
