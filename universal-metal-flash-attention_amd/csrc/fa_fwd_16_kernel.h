@@ -356,6 +356,15 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
                             mx = fmaxf(mx, tv);
                         }
                     }
+            } else if (HAS_MASK && mflag == 2 && !edge) {
+                // fully open interior tile: nothing to read, nothing to compare
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        s[kb][r] *= c2;
+                        mx = fmaxf(mx, s[kb][r]);
+                    }
             } else if (HAS_MASK) {
 #pragma unroll
                 for (int kb = 0; kb < NKB; ++kb)
