@@ -47,7 +47,7 @@ def _case(seed):
     if dt == torch.float32:
         Sq, Skv = min(Sq, 640), min(Skv, 640)
     causal = rng.random() < 0.4
-    mk = rng.choice([None, None, None, "bool", "float", "bcast"]) if not causal else None
+    mk = rng.choice([None, None, None, "bool", "float", "bcast", "strided", "window"]) if not causal else None
     strided = rng.random() < 0.3
     return dt, B, H, Sq, Skv, D, causal, mk, strided
 
@@ -74,6 +74,14 @@ def _mask(kind, B, H, Sq, Skv, g):
         return m
     if kind == "float":
         return torch.randn(B, 1, Sq, Skv, device="cuda", generator=g)
+    if kind == "strided":  # every second column of a wider mask: key stride 2 (no vector reads), per-head
+        m = (torch.rand(B, H, Sq, 2 * Skv, device="cuda", generator=g) < 0.6)[..., ::2]
+        m[..., 0] = True
+        return m
+    if kind == "window":   # band mask: most tiles fully masked or fully open (the tile-flag fast paths)
+        i = torch.arange(Sq, device="cuda")[:, None]
+        j = torch.arange(Skv, device="cuda")[None, :]
+        return ((i * Skv // max(Sq, 1) - j).abs() <= max(8, Skv // 6))[None, None]
     m = torch.rand(1, 1, 1, Skv, device="cuda", generator=g) < 0.7  # key-padding style broadcast mask
     m[..., 0] = True
     return m
