@@ -14,7 +14,10 @@ i = torch.arange(S, device="cuda")[:, None]; j = torch.arange(S, device="cuda")[
 masks = {"sliding window %d, bool [1,1,S,S]" % W: ((i - j).abs() <= W)[None, None].contiguous(),
          "key padding 3000 of 4096, bool [1,1,1,S]": (j < 3000)[None, None].contiguous(),
          "random 80 %% open, bool [1,H,S,S]": torch.rand(1, H, S, S, device="cuda") < 0.8,
-         "all open, bool [1,1,S,S]": torch.ones(1, 1, S, S, dtype=torch.bool, device="cuda")}
+         "all open, bool [1,1,S,S]": torch.ones(1, 1, S, S, dtype=torch.bool, device="cuda"),
+         "additive fp32 bias N(0,1) [1,1,S,S]": torch.randn(1, 1, S, S, device="cuda"),
+         "additive bf16 bias [1,H,S,S]": torch.randn(1, H, S, S, device="cuda", dtype=torch.bfloat16),
+         "sliding window 512 as fp32 0 / -inf [1,1,S,S]": torch.where((i - j).abs() <= W, 0.0, float("-inf"))[None, None].contiguous()}
 out = torch.empty_like(q)
 def timeit(mask):
     for _ in range(3): umfa_torch.attention_forward(q, k, v, mask=mask, out=out)

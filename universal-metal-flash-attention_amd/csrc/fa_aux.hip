@@ -234,21 +234,33 @@ __global__ __launch_bounds__(256) void mask_flags_kernel(FwdParams p, uint8_t* f
     const uint32_t key = tile * 64 + lane;
     bool any_open = false, any_term = false;  // an element that attends / an element whose term is not +0
     if (VEC16) {
-        // byte masks with contiguous, 16-byte aligned rows: a lane owns 16 keys of rows (lane / 4) and (lane / 4) + 16
-        const uint32_t key0 = tile * 64 + (lane & 3) * 16;
-        if (key0 < p.Skv) {  // Skv % 16 == 0 on this path: a segment is all in or all out
-            const uint8_t* base = (const uint8_t*)p.mask + (int64_t)bm * p.ms[0] + (int64_t)hm * p.ms[1] + key0;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const uint32_t row = rb * 32 + (lane >> 2) + 16 * i;
+        // contiguous, 16-byte aligned rows: a lane owns one 16-byte segment (16 / es keys) of a row; a wave-load covers
+        // 16 / es rows of the tile, 2 es loads cover its 32 rows.  Skv % 16 == 0 on this path: a segment is all in or out
+        const int es = p.mask_kind == MK_BOOL ? 1 : (p.mask_kind == MK_F32 ? 4 : 2);
+        const uint32_t spr = 4 * es, rpl = 64 / spr;  // segments per row, rows per wave-load
+        const uint32_t key0 = tile * 64 + (lane % spr) * (16 / es);
+        if (key0 < p.Skv) {
+            const char* base = (const char*)p.mask + ((int64_t)bm * p.ms[0] + (int64_t)hm * p.ms[1] + key0) * es;
+            for (uint32_t i = 0; i < 32 / rpl; ++i) {
+                const uint32_t row = rb * 32 + lane / spr + rpl * i;
                 if (row < p.Sq) {
-                    const u32x4_t w = *(const u32x4_t*)(base + (int64_t)row * p.ms[2]);
+                    const u32x4_t w = *(const u32x4_t*)(base + (int64_t)row * p.ms[2] * es);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        // per byte: non-zero attends (term +0), zero is masked (term -inf)
-                        const uint32_t nz = ((w[j] & 0x7f7f7f7fu) + 0x7f7f7f7fu | w[j]) & 0x80808080u;  // 0x80 per non-zero byte
-                        any_open |= nz != 0;
-                        any_term |= nz != 0x80808080u;
+                        if (p.mask_kind == MK_BOOL) {
+                            // per byte: non-zero attends (term +0), zero is masked (term -inf)
+                            const uint32_t nz = ((w[j] & 0x7f7f7f7fu) + 0x7f7f7f7fu | w[j]) & 0x80808080u;  // 0x80 per non-zero byte
+                            any_open |= nz != 0;
+                            any_term |= nz != 0x80808080u;
+                        } else if (p.mask_kind == MK_F32) {
+                            any_open |= w[j] != 0xff800000u;           // not -inf
+                            any_term |= (w[j] & 0x7fffffffu) != 0;     // not +-0
+                        } else {
+                            const uint32_t ninf = p.mask_kind == MK_F16 ? 0xfc00u : 0xff80u;
+                            const uint32_t lo = w[j] & 0xffffu, hi16 = w[j] >> 16;
+                            any_open |= lo != ninf || hi16 != ninf;
+                            any_term |= (w[j] & 0x7fff7fffu) != 0;
+                        }
                     }
                 }
             }
@@ -274,12 +286,25 @@ hipError_t launch_mask_flags(FwdParams& p, uint8_t* flags, hipStream_t stream) {
     p.mf_bs = p.ms[0] != 0 ? Hm : 0;
     p.mf_hs = p.ms[1] != 0 ? 1 : 0;
     const uint64_t total = (uint64_t)Bm * Hm * p.mf_nrb * p.mf_ntiles;
-    const bool vec16 = p.mask_kind == MK_BOOL && p.ms[3] == 1 && p.Skv % 16 == 0 && ((uintptr_t)p.mask & 15) == 0 &&
-                       p.ms[2] % 16 == 0 && p.ms[1] % 16 == 0 && p.ms[0] % 16 == 0;
+    const int es = p.mask_kind == MK_BOOL ? 1 : (p.mask_kind == MK_F32 ? 4 : 2);
+    const bool vec16 = p.ms[3] == 1 && p.Skv % 16 == 0 && ((uintptr_t)p.mask & 15) == 0 &&
+                       (p.ms[2] * es) % 16 == 0 && (p.ms[1] * es) % 16 == 0 && (p.ms[0] * es) % 16 == 0;
     if (vec16) hipLaunchKernelGGL(mask_flags_kernel<true>, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream, p, flags, Bm, Hm);
     else hipLaunchKernelGGL(mask_flags_kernel<false>, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream, p, flags, Bm, Hm);
     p.mask_flags = flags;
     return hipGetLastError();
+}
+
+// Is the pre-pass worth its read of the mask?  Byte masks: always (at worst +15 % for a dense random per-head mask, 2-4x
+// for banded / padded ones).  Additive float masks are usually dense biases with nothing to skip: only when the distinct
+// mask bytes stay below twice the Q + K + V + O traffic (e.g. one [Sq, Skv] bias shared by the heads).
+bool mask_flags_worthwhile(const FwdParams& p) {
+    if (p.mask_kind == MK_BOOL) return true;
+    const uint64_t Bm = p.ms[0] != 0 ? p.B : 1, Hm = p.ms[1] != 0 ? p.H : 1;
+    const uint64_t es = p.mask_kind == MK_F32 ? 4 : 2, eb = p.in_prec == P_FP32 ? 4 : 2;
+    const uint64_t mask_bytes = Bm * Hm * p.Sq * p.Skv * es;
+    const uint64_t qkvo = (uint64_t)p.B * p.H * p.D * ((uint64_t)p.Sq * (eb + 4) + 2ull * p.Skv * eb);
+    return mask_bytes <= 2 * qkvo;
 }
 
 size_t mask_flags_bytes(const FwdParams& p) {

@@ -267,9 +267,11 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
     };
 
     const int64_t mrow = HAS_MASK ? ((int64_t)b * p.ms[0] + (int64_t)h * p.ms[1] + (int64_t)q_row * p.ms[2]) : 0;
-    // byte masks with contiguous 4-byte aligned rows: the four keys a lane owns per register group are one dword
-    const bool mvec = HAS_MASK && p.mask_kind == MK_BOOL && p.ms[3] == 1 && (p.Skv & 3) == 0 &&
-                      ((p.ms[0] | p.ms[1] | p.ms[2]) & 3) == 0 && ((uintptr_t)p.mask & 3) == 0;
+    // masks with contiguous rows aligned to four elements: the four keys a lane owns per register group are ONE load
+    // (dword for bytes, 8 bytes for fp16 / bf16, 16 bytes for fp32)
+    const int mes = p.mask_kind == MK_BOOL ? 1 : (p.mask_kind == MK_F32 ? 4 : 2);
+    const bool mvec = HAS_MASK && p.ms[3] == 1 && (p.Skv & 3) == 0 && ((p.ms[0] | p.ms[1] | p.ms[2]) & 3) == 0 &&
+                      ((uintptr_t)p.mask & (uintptr_t)(4 * mes - 1)) == 0;
     // mask tile flags (FwdParams::mask_flags): this wave's 32 rows are one flag row; 64 tiles per register
     const uint8_t* mf_row = nullptr;
     int mf_reg = 0;
@@ -344,13 +346,30 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const uint32_t key0 = key_base + 32 * kb + 8 * g + 4 * hi;
-                        uint32_t w = 0;  // keys past Skv / rows past Sq: masked either way below
-                        if (key0 < p.Skv && q_row < p.Sq) w = *(const uint32_t*)((const uint8_t*)p.mask + mrow + key0);
+                        float term[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // keys past Skv / rows past Sq are masked below anyway
+                        if (key0 < p.Skv && q_row < p.Sq) {
+                            const int64_t at = mrow + key0;
+                            if (p.mask_kind == MK_BOOL) {
+                                const uint32_t w = *(const uint32_t*)((const uint8_t*)p.mask + at);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) term[e] = ((w >> (8 * e)) & 0xffu) ? 0.0f : -INFINITY;
+                            } else if (p.mask_kind == MK_F32) {
+                                const f32x4 w = *(const f32x4*)((const float*)p.mask + at);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) term[e] = w[e] * UMFA_LOG2E;
+                            } else {
+                                typedef uint16_t u16x4_t __attribute__((ext_vector_type(4)));
+                                const u16x4_t w = *(const u16x4_t*)((const uint16_t*)p.mask + at);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+                                    term[e] = (p.mask_kind == MK_F16 ? (float)__builtin_bit_cast(_Float16, (uint16_t)w[e])
+                                                                     : bf16_bits_to_float(w[e])) * UMFA_LOG2E;
+                            }
+                        }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int r = 4 * g + e;
-                            float tv = s[kb][r] * c2;
-                            if (q_row < p.Sq && ((w >> (8 * e)) & 0xffu) == 0) tv = -INFINITY;
+                            float tv = s[kb][r] * c2 + term[e];
                             if (key0 + e >= p.Skv || (CAUSAL && key0 + e > q_row)) tv = -INFINITY;
                             s[kb][r] = tv;
                             mx = fmaxf(mx, tv);

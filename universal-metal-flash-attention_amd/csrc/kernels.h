@@ -94,6 +94,7 @@ hipError_t launch_fwd_w64_i8(const FwdParams& p, const QuantViews& v, float* par
 
 // mask tile flags for fa_fwd16's tile early-exit (fa_aux.hip); launch_mask_flags fills p.mask_flags / mf_*
 size_t mask_flags_bytes(const FwdParams& p);
+bool mask_flags_worthwhile(const FwdParams& p);
 hipError_t launch_mask_flags(FwdParams& p, uint8_t* flags, hipStream_t stream);
 
 }  // namespace umfa

@@ -94,7 +94,7 @@ hipError_t dispatch_forward(Context* ctx, const FwdParams& p, int intermediate_p
                 pp.part_buf = (float*)(buf + plan.cnt_bytes);
             }
         }
-        if (pp.mask_kind != MK_NONE && !getenv("UMFA_NO_MASK_FLAGS")) {
+        if (pp.mask_kind != MK_NONE && !getenv("UMFA_NO_MASK_FLAGS") && mask_flags_worthwhile(pp)) {
             // tile early-exit for masks: one pre-pass over the distinct mask elements classifies every (32 rows x 64
             // keys) tile; fully masked tiles are skipped, fully open ones run without reading the mask
             void* fl = ctx->ensure_mask_flags(mask_flags_bytes(pp));
