@@ -168,3 +168,28 @@ def test_rope_sdpa_autograd():
         assert (g.double() - r).abs().max() < 2e-4 * max(1.0, float(r.abs().max()))
     s = umfa_torch.get_dispatch_stats()
     assert s["rope_autograd"] == 1
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 2, 128, 64), (1, 32, 8, 2048, 128), (3, 6, 3, 200, 80)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_gqa_zero_copy_views(shape, dt):
+    """inference GQA: K / V are NOT expanded -- the query heads of a KV head become the heads of a (batch x kv-head)
+    slab with K / V head stride 0 on the in-stream entry; same numbers as the repeat_interleave route"""
+    import umfa_torch
+    from umfa_torch import sdpa
+    B, Hq, Hkv, S, D = shape
+    torch.manual_seed(5)
+    q = torch.randn(B, Hq, S, D, device="cuda", dtype=dt)
+    k = torch.randn(B, Hkv, S, D, device="cuda", dtype=dt)
+    v = torch.randn(B, Hkv, S, D, device="cuda", dtype=dt)
+    g = Hq // Hkv
+    for causal, mask in ((False, None), (True, None), (False, (torch.rand(S, S, device="cuda") < 0.8) | torch.eye(S, dtype=torch.bool, device="cuda"))):
+        assert sdpa._gqa_zero_copy(q, k, v, mask, 0.0, causal, None) is not None
+        out = umfa_torch.scaled_dot_product_attention(q, k, v, attn_mask=mask, is_causal=causal, enable_gqa=True)
+        exp = umfa_torch.scaled_dot_product_attention(q, k.repeat_interleave(g, 1), v.repeat_interleave(g, 1), attn_mask=mask,
+                                                      is_causal=causal)
+        assert out.shape == q.shape and out.dtype == dt
+        assert (out.float() - exp.float()).abs().max().item() < (2e-2 if dt == torch.bfloat16 else 4e-3)
+    # per-head masks and gradients keep the expanding route
+    assert sdpa._gqa_zero_copy(q, k, v, torch.ones(B, Hq, S, S, dtype=torch.bool, device="cuda"), 0.0, False, None) is None
+    assert sdpa._gqa_zero_copy(q.clone().requires_grad_(True), k, v, None, 0.0, False, None) is None

@@ -160,6 +160,35 @@ class _QuantizedFlashAttentionFn(torch.autograd.Function):
         return dq.to(q.dtype), dk.to(q.dtype), dv.to(q.dtype), None, None, None, None, None
 
 
+def _gqa_zero_copy(q, k, v, attn_mask, dropout_p, is_causal, scale):
+    """Inference GQA without materialising repeat_interleave(K), repeat_interleave(V) (the reference's route,
+    metal_sdpa_backend.cpp:1694-1702): the g query heads of a KV head become the heads of a (batch * kv-head) slab whose
+    K / V head stride is 0 -- plain strides on the in-stream entry, K / V are read once per group.  Returns None when
+    the views do not apply (gradients needed, masks with per-head / per-batch extent, non-collapsible strides)."""
+    if (q.dim() != 4 or k.dim() != 4 or v.dim() != 4 or not (q.is_cuda and k.is_cuda and v.is_cuda) or dropout_p > 0.0
+            or q.requires_grad or k.requires_grad or v.requires_grad or _quant_precision != QUANT_NONE
+            or q.dtype not in _SUPPORTED or k.dtype != q.dtype or v.dtype != q.dtype or k.shape != v.shape
+            or q.size(0) != k.size(0) or q.size(3) != k.size(3) or q.size(3) == 0 or q.size(3) > 256):
+        return None
+    B, Hq, Sq, D = q.shape
+    Hkv, Skv = k.size(1), k.size(2)
+    g = Hq // Hkv
+    if attn_mask is not None:
+        m = attn_mask  # right-aligned onto [B, H, Sq, Skv]: only masks shared by every batch element and head
+        if m.dim() > 4 or (m.dim() == 4 and (m.size(0) != 1 or m.size(1) != 1)) or (m.dim() == 3 and m.size(0) != 1):
+            return None  # a per-head or per-batch mask would have to be re-viewed too
+    for t, h in ((q, Hq), (k, Hkv), (v, Hkv)):
+        if t.stride(3) != 1 or (B > 1 and t.stride(0) != h * t.stride(1)):
+            return None
+    qv = q.as_strided((B * Hkv, g, Sq, D), (g * q.stride(1), q.stride(1), q.stride(2), 1), q.storage_offset())
+    kv = k.as_strided((B * Hkv, g, Skv, D), (k.stride(1), 0, k.stride(2), 1), k.storage_offset())
+    vv = v.as_strided((B * Hkv, g, Skv, D), (v.stride(1), 0, v.stride(2), 1), v.storage_offset())
+    sm_scale = float(scale) if scale is not None else float(D) ** -0.5
+    _bump("fp32_instream")
+    out = ops.attention_forward(qv, kv, vv, scale=sm_scale, causal=bool(is_causal), mask=attn_mask, out_dtype=q.dtype)
+    return out.view(B, Hq, Sq, D)
+
+
 def scaled_dot_product_attention(query, key, value, attn_mask: Optional[torch.Tensor] = None, dropout_p: float = 0.0,
                                  is_causal: bool = False, scale: Optional[float] = None, enable_gqa: bool = False):
     if key.dim() != value.dim() or key.dim() < 2 or key.size(-2) != value.size(-2):
@@ -179,6 +208,9 @@ def scaled_dot_product_attention(query, key, value, attn_mask: Optional[torch.Te
     if q.dim() >= 3 and k.dim() >= 3 and q.size(-3) != k.size(-3):
         hq, hkv = q.size(-3), k.size(-3)
         if hq > hkv and hq % hkv == 0:
+            zc = _gqa_zero_copy(q, k, v, attn_mask, dropout_p, is_causal, scale)
+            if zc is not None:
+                return zc
             k = k.repeat_interleave(hq // hkv, -3).contiguous()
             v = v.repeat_interleave(hq // hkv, -3).contiguous()
 
