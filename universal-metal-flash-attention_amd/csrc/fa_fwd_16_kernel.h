@@ -241,8 +241,8 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
         const uint32_t lim = (qb * BM + BM + BN - 1) / BN;
         ntiles = ntiles < lim ? ntiles : lim;
     }
-    const uint32_t t_begin = (uint32_t)(((uint64_t)ntiles * part) / nparts);
-    const uint32_t t_end = (uint32_t)(((uint64_t)ntiles * (part + 1)) / nparts);
+    uint32_t t_begin = (uint32_t)(((uint64_t)ntiles * part) / nparts);
+    uint32_t t_end = (uint32_t)(((uint64_t)ntiles * (part + 1)) / nparts);
 
     f32x16 acc[NDB];
 #pragma unroll
@@ -278,6 +278,42 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
     if (HAS_MASK && p.mask_flags && wave_q0 / 32 < p.mf_nrb)
         mf_row = p.mask_flags + ((uint64_t)b * p.mf_bs + (uint64_t)h * p.mf_hs) * p.mf_nrb * p.mf_ntiles + (uint64_t)(wave_q0 / 32) * p.mf_ntiles;
 
+    if (HAS_MASK && p.mask_flags) {
+        // trim the sweep to [first, last] tile that any of the four waves has to visit: for banded masks most of the
+        // key range is never staged at all (sliding window of +-512 at S = 4096: 18 of 64 tiles per workgroup)
+        uint32_t lo = 0xffffffffu, hi1 = 0;  // first visited tile, one past the last
+        if (mf_row) {
+            for (uint32_t t0 = t_begin & ~63u; t0 < t_end; t0 += 64) {
+                const uint32_t tt = t0 + lane;
+                const bool visit = tt >= t_begin && tt < t_end && mf_row[tt] != 1;
+                const unsigned long long bm = __builtin_amdgcn_ballot_w64(visit);
+                if (bm) {
+                    const uint32_t first = t0 + (uint32_t)__builtin_ctzll(bm), last = t0 + 63u - (uint32_t)__builtin_clzll(bm);
+                    lo = lo < first ? lo : first;
+                    hi1 = hi1 > last + 1 ? hi1 : last + 1;
+                }
+            }
+        }
+        volatile uint32_t* red = (volatile uint32_t*)smem;  // the tile area is not in use yet
+        if (lane == 0) { red[2 * wave] = lo; red[2 * wave + 1] = hi1; }
+        __syncthreads();
+        lo = red[0]; hi1 = red[1];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const uint32_t a = red[2 * w], b2 = red[2 * w + 1];
+            lo = lo < a ? lo : a;
+            hi1 = hi1 > b2 ? hi1 : b2;
+        }
+        __syncthreads();
+        lo = __builtin_amdgcn_readfirstlane(lo);  // workgroup-uniform by construction; tell the compiler
+        hi1 = __builtin_amdgcn_readfirstlane(hi1);
+        if (hi1 <= lo) { t_end = t_begin; }  // nothing to visit: O = 0, LSE = -inf like a fully masked row
+        else { t_begin = lo; t_end = hi1; }
+        if constexpr (DMA) {  // the scratch words sit in the zero-initialised tile area: restore
+            if (tid < 8) ((volatile uint32_t*)smem)[tid] = 0;
+            __syncthreads();
+        }
+    }
     stage_load(t_begin);
     stage_write(t_begin & 1);
     __syncthreads();
