@@ -68,10 +68,14 @@ FwdSplitPlan fwd_16_split_plan(const FwdParams& p) {
     plan.buf_bytes = plan.cnt_bytes = 0;
     const char* env = getenv("UMFA_NO_SPLIT");
     if (p.causal || items == 0 || (env && env[0] == '1')) return plan;  // causal items are uneven already
-    uint32_t k = cus / items;
+    uint32_t k = cus / items, kmax = 8;
+    // One q-block per (batch, head) -- decode-like calls: no two items share K / V, the sweep is bound by how many
+    // tile loads a CU keeps in flight, so aim for two resident workgroups per CU (B8 H32 Sq1 Skv8192: 297 -> 243 us
+    // with 2 parts, B4 H32: 172 -> 133 us with 4; with more items than 2 x CUs splitting only loses)
+    if (nqb == 1) { k = 2 * cus / items; kmax = 16; }
     const char* force = getenv("UMFA_FORCE_SPLIT");  // experiments: split every item k ways
     if (force && force[0] >= '2' && force[0] <= '8') k = (uint32_t)(force[0] - '0');
-    if (k > 8) k = 8;
+    if (k > kmax) k = kmax;
     if (k > ntiles / 4) k = ntiles / 4;  // keep >= 4 key tiles per part
     if (k < 2) return plan;
     plan.n_full = 0;
