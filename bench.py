@@ -13,7 +13,8 @@ One JSON line on rank 0:
              wall time of exactly K steps (max over ranks)
   roofline   bf16 MFMA bound: algorithmic FLOPs per launch / mean kernel duration from HIP events on
              the launch stream, vs the 2.5 PFLOP/s dense peak (MI355X_MICROARCH.md)
-  cpu_baseline  the CPU oracle (oracle/sdpa_ref.c, OpenMP) on a bounded sample of the same workload
+  cpu_baseline  the CPU oracle (oracle/sdpa_ref.c, OpenMP) on a bounded sample of the same workload, plus
+             torch_cpu_sdpa: PyTorch's own CPU SDPA on the full FLUX shape (fp32 and bf16)
   int8       runtime-quantised (block-wise int8) forward of the same shape vs bf16 (when built)
 """
 from __future__ import annotations
@@ -51,8 +52,37 @@ def cpu_baseline(cores: int):
     oracle.sdpa_forward(q, k, v)
     dt = time.perf_counter() - t0
     flops = 4.0 * heads * s_len * s_len * D
-    return {"value": round(flops / dt / 1e12, 5), "unit": "TFLOP/s", "cores": cores, "kind": "port",
-            "sample": f"B=1 H={heads} S={s_len} D={D} bf16 forward, oracle/sdpa_ref.c (fp64 accumulate, OpenMP), {dt:.1f} s"}
+    res = {"value": round(flops / dt / 1e12, 5), "unit": "TFLOP/s", "cores": cores, "kind": "port",
+           "sample": f"B=1 H={heads} S={s_len} D={D} bf16 forward, oracle/sdpa_ref.c (fp64 accumulate, OpenMP), {dt:.1f} s"}
+    try:  # the north-star's other CPU number: PyTorch's own CPU SDPA (the reference's config-1 path) on the FLUX shape
+        res["torch_cpu_sdpa"] = torch_cpu_sdpa()
+    except Exception as exc:
+        res["torch_cpu_sdpa"] = {"error": repr(exc)}
+    return res
+
+
+def torch_cpu_sdpa():
+    """torch.nn.functional.scaled_dot_product_attention on the host cores, full FLUX shape, fp32 and bf16 (best of <= 3
+    runs each, at most ~20 s in all); reported beside the oracle port, never a target."""
+    import torch
+    import torch.nn.functional as F
+    out = {"cores": torch.get_num_threads(), "unit": "TFLOP/s", "sample": f"B={B} H={H} S={S} D={D}, best of <= 3"}
+    budget = time.perf_counter() + 20.0
+    for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        g = torch.Generator().manual_seed(0)
+        q, k, v = (torch.randn(B, H, S, D, generator=g).to(dt) for _ in range(3))
+        best = None
+        for _ in range(3):
+            if time.perf_counter() > budget and best is not None:
+                break
+            t0 = time.perf_counter()
+            F.scaled_dot_product_attention(q, k, v)
+            el = time.perf_counter() - t0
+            best = el if best is None else min(best, el)
+            if time.perf_counter() > budget:
+                break
+        out[name] = round(FLOPS_PER_STEP / best / 1e12, 4)
+    return out
 
 
 def main() -> None:
