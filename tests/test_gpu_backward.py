@@ -208,3 +208,31 @@ def test_prequantized_backward_legacy_entries_and_errors(ctx):
             b.close()
     assert np.abs(gq - dq).max() < 2e-4 * np.abs(dq).max() and np.abs(gk - dk).max() < 2e-4 * np.abs(dk).max()
     assert np.abs(gv - dv).max() < 2e-4 * np.abs(dv).max()
+
+
+@pytest.mark.parametrize("shape,dt", [((1, 2, 256, 128), "bf16"), ((2, 3, 333, 64), "fp16"), ((1, 2, 200, 256), "bf16"),
+                                      ((1, 2, 130, 80), "bf16"), ((1, 2, 96, 64), "fp32")])
+@pytest.mark.parametrize("causal", [False, True])
+def test_backward_stream_entry_matches_blocking_abi(ctx, shape, dt, causal):
+    """umfa_attention_backward_stream (in-stream, raw pointers): fp32 gradients are bit-identical to
+    mfa_attention_backward; with grads_in_input_type they are those values rounded once (MFMA backward only --
+    head_dim 80 and fp32 operands fall back to fp32 gradients + cast inside ops.attention_backward)"""
+    import umfa
+    import umfa_torch
+    from umfa_torch import ops
+    tdt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[dt]
+    torch.manual_seed(21)
+    q, k, v, do = (torch.randn(shape, device="cuda", dtype=tdt) for _ in range(4))
+    o32, lse = umfa_torch.attention_forward(q, k, v, causal=causal, out_dtype=torch.float32, return_lse=True)
+    npy = lambda t: (t.view(torch.int16) if t.dtype == torch.bfloat16 else t).cpu().numpy()  # noqa: E731
+    host = [npy(t).view(np.uint16) if t.dtype == torch.bfloat16 else npy(t) for t in (do, q, k, v)]
+    rdq, rdk, rdv, _ = umfa.attention_backward(ctx, host[0], host[1], host[2], host[3], o32.cpu().numpy(), lse.cpu().numpy(),
+                                               causal=causal, input_precision=dt)
+    scale = shape[-1] ** -0.5
+    g32 = ops.attention_backward(do, q, k, v, o32, lse, scale=scale, causal=causal, grads_in_input_type=False)
+    gty = ops.attention_backward(do, q, k, v, o32, lse, scale=scale, causal=causal, grads_in_input_type=True)
+    torch.cuda.synchronize()
+    for a, b, c in zip(g32, gty, (rdq, rdk, rdv)):
+        ref = torch.from_numpy(np.ascontiguousarray(c)).to(tdt)   # the blocking ABI's fp32 gradients, rounded once
+        assert a.dtype == tdt and b.dtype == tdt
+        assert torch.equal(a.cpu(), ref) and torch.equal(b.cpu(), ref)

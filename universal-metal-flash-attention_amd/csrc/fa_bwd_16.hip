@@ -82,6 +82,17 @@ __device__ __forceinline__ typename M::V8 tr_frag(const char* img, int i, int s,
     return __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// four consecutive gradient elements: fp32 (ABI contract) or rounded once to the input type T
+template <typename T>
+__device__ __forceinline__ void store_grad4(void* base, int64_t elem, f32x4 val, bool in_type) {
+    if (in_type) {
+        typedef T T4 __attribute__((ext_vector_type(4)));
+        *(T4*)((T*)base + elem) = T4{(T)val[0], (T)val[1], (T)val[2], (T)val[3]};
+    } else {
+        *(f32x4*)((float*)base + elem) = val;
+    }
+}
+
 // Causal work items differ in length; with two workgroups per CU they finish together only if the lengths on a CU add
 // up alike.  Same order as the forward (fa_fwd_16_kernel.h, where it was measured): consecutive items are a mirrored
 // pair of blocks, and the pair 32 items (= CUs per XCD) further on has its long and short member swapped.
@@ -229,14 +240,14 @@ __global__ __launch_bounds__(256, DP == 256 ? 1 : 2) void bwd16_dq_kernel(BwdPar
         __syncthreads();
     }
     if (qok) {
-        float* op = p.dq + ((int64_t)bh * p.Sq + q_row) * DP;
+        const int64_t orow = ((int64_t)bh * p.Sq + q_row) * DP;
 #pragma unroll
         for (int i = 0; i < NDB; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 val = {acc[i][4 * g] * p.scale, acc[i][4 * g + 1] * p.scale, acc[i][4 * g + 2] * p.scale,
                              acc[i][4 * g + 3] * p.scale};
-                *(f32x4*)(op + 32 * i + 8 * g + 4 * hi) = val;
+                store_grad4<T>(p.dq, orow + 32 * i + 8 * g + 4 * hi, val, p.grad_in_type != 0);
             }
     }
 }
@@ -380,8 +391,7 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
         __syncthreads();
     }
     if (kok) {
-        float* okp = p.dk + ((int64_t)bh * p.Skv + key) * DP;
-        float* ovp = p.dv + ((int64_t)bh * p.Skv + key) * DP;
+        const int64_t krow = ((int64_t)bh * p.Skv + key) * DP;
 #pragma unroll
         for (int i = 0; i < NDBH; ++i)
 #pragma unroll
@@ -389,8 +399,8 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
                 const int d0 = 32 * (i + hpass * NDBH) + 8 * g + 4 * hi;
                 f32x4 kv = {dk[i][4 * g] * p.scale, dk[i][4 * g + 1] * p.scale, dk[i][4 * g + 2] * p.scale, dk[i][4 * g + 3] * p.scale};
                 f32x4 vv = {dv[i][4 * g], dv[i][4 * g + 1], dv[i][4 * g + 2], dv[i][4 * g + 3]};
-                *(f32x4*)(okp + d0) = kv;
-                *(f32x4*)(ovp + d0) = vv;
+                store_grad4<T>(p.dk, krow + d0, kv, p.grad_in_type != 0);
+                store_grad4<T>(p.dv, krow + d0, vv, p.grad_in_type != 0);
             }
     }
     }  // hpass

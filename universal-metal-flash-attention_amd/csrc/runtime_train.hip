@@ -76,6 +76,37 @@ mfa_error_t mfa_attention_backward(mfa_context_t context, mfa_buffer_t dout, mfa
     return MFA_SUCCESS;
 }
 
+// MI355X extra (not in the reference): the backward of mfa_attention_backward in-stream -- raw device pointers, the
+// caller's stream, no upload / download / synchronise.  grads_in_input_type = true writes dQ, dK, dV rounded once to the
+// operand type from the kernels' epilogues (the torch caller casts the fp32 gradients back immediately otherwise,
+// metal_sdpa_backend.cpp:2799-2802); only the 16-bit MFMA backward offers it (else error 1 and the caller uses fp32).
+mfa_error_t umfa_attention_backward_stream(mfa_context_t context, void* stream, const void* dout, const void* q,
+                                           const void* k, const void* v, const float* out, const float* softmax_lse,
+                                           void* dq, void* dk, void* dv, float* d_buffer, uint32_t batch_size,
+                                           uint32_t seq_len_q, uint32_t seq_len_kv, uint32_t num_heads,
+                                           uint16_t head_dim, float softmax_scale, bool causal, int32_t input_precision,
+                                           int32_t intermediate_precision, bool grads_in_input_type) {
+    Context* ctx = as_ctx(context);
+    if (!ctx || !dout || !q || !k || !v || !out || !softmax_lse || !dq || !dk || !dv || !d_buffer) return MFA_ERROR_INVALID_ARGS;
+    if (head_dim == 0 || head_dim > 256) return MFA_ERROR_INVALID_ARGS;
+    if ((size_t)batch_size * num_heads * seq_len_q * seq_len_kv == 0) return MFA_SUCCESS;
+    BwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.dout = dout; p.q = q; p.k = k; p.v = v; p.o = out; p.lse = softmax_lse;
+    p.dq = (float*)dq; p.dk = (float*)dk; p.dv = (float*)dv; p.dvec = d_buffer;
+    p.B = batch_size; p.H = num_heads; p.Sq = seq_len_q; p.Skv = seq_len_kv; p.D = head_dim;
+    p.scale = softmax_scale; p.causal = causal ? 1 : 0;
+    p.in_prec = dense_prec(input_precision); p.dout_prec = p.in_prec;
+    p.grad_in_type = grads_in_input_type ? 1 : 0;
+    const bool lowp = dense_prec(intermediate_precision) != P_FP32 && !getenv("UMFA_BWD_EXACT");
+    const bool mfma16 = lowp && bwd_16_supported(p);
+    if (grads_in_input_type && !mfma16) return MFA_ERROR_INVALID_ARGS;
+    const char* name = "none";
+    hipError_t e = mfma16 ? launch_bwd_16(p, (hipStream_t)stream, &name) : launch_bwd(p, (hipStream_t)stream, &name);
+    ctx->last_kernel = name;
+    return e == hipSuccess ? MFA_SUCCESS : e == hipErrorInvalidValue ? MFA_ERROR_INVALID_ARGS : MFA_ERROR_EXECUTION_FAILED;
+}
+
 int32_t mfa_quantized_forward_with_lse(mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, mfa_buffer_t v,
                                        mfa_buffer_t out, mfa_buffer_t lse, mfa_buffer_t mask, uint32_t batch_size,
                                        uint32_t seq_len_q, uint32_t seq_len_kv, uint32_t num_heads, uint16_t head_dim,

@@ -158,6 +158,38 @@ def gpu_latency() -> float:
     return float(_lib.mfa_get_gpu_latency(context()))
 
 
+def attention_backward(dout, q, k, v, o32, lse, *, scale: float, causal: bool = False, grads_in_input_type: bool = True,
+                       intermediate_dtype=None):
+    """dQ, dK, dV of the SDPA in-stream (umfa_attention_backward_stream): contiguous BHSD device tensors, O fp32 and LSE
+    from the forward; asynchronous on torch's current stream.  Gradients come back in q.dtype straight from the kernels
+    when the 16-bit MFMA backward serves the call, else fp32 tensors cast afterwards (same values the blocking ABI gives)."""
+    B, H, Sq, D = q.shape
+    Skv = k.shape[2]
+    for t in (dout, q, k, v, o32, lse):
+        assert t.is_cuda and t.is_contiguous()
+    assert o32.dtype == torch.float32 and lse.dtype == torch.float32 and dout.dtype == q.dtype
+    inter = _PREC[intermediate_dtype or q.dtype]
+    dvec = torch.empty((B * H * Sq,), dtype=torch.float32, device=q.device)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream)
+
+    def call(gdt, typed):
+        dq = torch.empty((B, H, Sq, D), dtype=gdt, device=q.device)
+        dk = torch.empty((B, H, Skv, D), dtype=gdt, device=q.device)
+        dv = torch.empty_like(dk)
+        rc = _lib.umfa_attention_backward_stream(
+            context(), stream, *(ctypes.c_void_p(t.data_ptr()) for t in (dout, q, k, v, o32, lse, dq, dk, dv, dvec)),
+            B, Sq, Skv, H, D, float(scale), bool(causal), _PREC[q.dtype], inter, typed)
+        return rc, dq, dk, dv
+
+    if grads_in_input_type and q.dtype != torch.float32:
+        rc, dq, dk, dv = call(q.dtype, True)
+        if rc == 0:
+            return dq, dk, dv
+    rc, dq, dk, dv = call(torch.float32, False)
+    _check_error(rc)
+    return dq.to(q.dtype), dk.to(q.dtype), dv.to(q.dtype)
+
+
 def bench_int8(steps: int = 20, warmup: int = 3):
     """int8 block-quantised forward vs the bf16 forward on the same tensors (quantiser pre-pass included),
     for the FLUX shape and BASELINE config 4 (B1 H16 S8192 D128).  GPU time from the library's hipEvents."""

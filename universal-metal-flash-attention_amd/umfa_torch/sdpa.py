@@ -98,24 +98,10 @@ class _FlashAttentionFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         q, k, v, o32, lse = ctx.saved_tensors
-        B, H, Sq, D = q.shape
-        Skv = k.shape[2]
-        dout = dout.to(q.dtype).contiguous()
-        dq = torch.empty((B, H, Sq, D), dtype=torch.float32, device=q.device)
-        dk = torch.empty((B, H, Skv, D), dtype=torch.float32, device=q.device)
-        dv = torch.empty_like(dk)
-        dvec = torch.empty((B * H * Sq,), dtype=torch.float32, device=q.device)
-        _sync_for_blocking_abi(q)
-        bufs = _dev_bufs(dout, q, k, v, o32, lse, dq, dk, dv, dvec)
-        try:
-            prec = ops._PREC[q.dtype]
-            _check_error(_lib.mfa_attention_backward(ops.context(), *(b.handle for b in bufs), B, Sq, Skv, H, D,
-                                                     float(ctx.scale), bool(ctx.causal), prec, prec,
-                                                     False, False, False, False))
-        finally:
-            for b in bufs:
-                b.close()
-        return dq.to(q.dtype), dk.to(q.dtype), dv.to(q.dtype), None, None
+        # in-stream (no host synchronisation), gradients in the operand type straight from the kernels' epilogues
+        dq, dk, dv = ops.attention_backward(dout.to(q.dtype).contiguous(), q, k, v, o32, lse, scale=float(ctx.scale),
+                                            causal=bool(ctx.causal))
+        return dq, dk, dv, None, None
 
 
 class _QuantizedFlashAttentionFn(torch.autograd.Function):
