@@ -159,7 +159,7 @@ def gpu_latency() -> float:
 
 
 def attention_backward(dout, q, k, v, o32, lse, *, scale: float, causal: bool = False, grads_in_input_type: bool = True,
-                       intermediate_dtype=None):
+                       intermediate_dtype=None, keep_fp32: bool = False):
     """dQ, dK, dV of the SDPA in-stream (umfa_attention_backward_stream): contiguous BHSD device tensors, O fp32 and LSE
     from the forward; asynchronous on torch's current stream.  Gradients come back in q.dtype straight from the kernels
     when the 16-bit MFMA backward serves the call, else fp32 tensors cast afterwards (same values the blocking ABI gives)."""
@@ -181,12 +181,14 @@ def attention_backward(dout, q, k, v, o32, lse, *, scale: float, causal: bool = 
             B, Sq, Skv, H, D, float(scale), bool(causal), _PREC[q.dtype], inter, typed)
         return rc, dq, dk, dv
 
-    if grads_in_input_type and q.dtype != torch.float32:
+    if grads_in_input_type and not keep_fp32 and q.dtype != torch.float32:
         rc, dq, dk, dv = call(q.dtype, True)
         if rc == 0:
             return dq, dk, dv
     rc, dq, dk, dv = call(torch.float32, False)
     _check_error(rc)
+    if keep_fp32:  # the caller post-processes the gradients in fp32 (RoPE inverse rotation)
+        return dq, dk, dv
     return dq.to(q.dtype), dk.to(q.dtype), dv.to(q.dtype)
 
 

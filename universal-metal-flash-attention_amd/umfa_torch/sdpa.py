@@ -310,23 +310,8 @@ class _RopeFlashAttentionFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         q_rot, k_rot, v, o32, lse, cos_t, sin_t = ctx.saved_tensors
-        B, H, Sq, D = q_rot.shape
-        Skv = k_rot.shape[2]
-        dout = dout.to(q_rot.dtype).contiguous()
-        dq = torch.empty((B, H, Sq, D), dtype=torch.float32, device=q_rot.device)
-        dk = torch.empty((B, H, Skv, D), dtype=torch.float32, device=q_rot.device)
-        dv = torch.empty_like(dk)
-        dvec = torch.empty((B * H * Sq,), dtype=torch.float32, device=q_rot.device)
-        _sync_for_blocking_abi(q_rot)
-        bufs = _dev_bufs(dout, q_rot, k_rot, v, o32, lse, dq, dk, dv, dvec)
-        try:
-            prec = ops._PREC[q_rot.dtype]
-            _check_error(_lib.mfa_attention_backward(ops.context(), *(b.handle for b in bufs), B, Sq, Skv, H, D,
-                                                     float(ctx.scale), bool(ctx.causal), prec, prec,
-                                                     False, False, False, False))
-        finally:
-            for b in bufs:
-                b.close()
+        dq, dk, dv = ops.attention_backward(dout.to(q_rot.dtype).contiguous(), q_rot, k_rot, v, o32, lse,
+                                            scale=float(ctx.scale), causal=bool(ctx.causal), keep_fp32=True)
         # RoPE is orthonormal: the gradient w.r.t. the un-rotated tensor is the inverse rotation of the gradient
         dq = ops.rope_rotate(dq, cos_t, sin_t, negate_sin=True)
         dk = ops.rope_rotate(dk, cos_t, sin_t, negate_sin=True)
