@@ -329,13 +329,15 @@ mfa_error_t umfa_attention_forward_stream(
  * that the integer half of the quantised path can be compared bit-for-bit with the oracle. */
 /* MI355X extra: mfa_attention_backward in-stream (raw device pointers, caller's stream, never synchronises).
  * dq / dk / dv are fp32 [B,H,S,D] (the ABI contract) or, with grads_in_input_type, the operand type (16-bit MFMA
- * backward only: head_dim 64 / 128 / 256, 16-bit intermediates; otherwise error 1). d_buffer: fp32 [B*H*Sq] scratch. */
+ * backward only: head_dim 64 / 128 / 256, 16-bit intermediates; otherwise error 1). d_buffer: fp32 [B*H*Sq] scratch.
+ * out: O in fp32 (as for mfa_attention_backward) or, with out_in_input_type, O in the operand type. */
 mfa_error_t umfa_attention_backward_stream(mfa_context_t context, void* stream, const void* dout, const void* q,
-                                           const void* k, const void* v, const float* out, const float* softmax_lse,
+                                           const void* k, const void* v, const void* out, const float* softmax_lse,
                                            void* dq, void* dk, void* dv, float* d_buffer, uint32_t batch_size,
                                            uint32_t seq_len_q, uint32_t seq_len_kv, uint32_t num_heads,
                                            uint16_t head_dim, float softmax_scale, bool causal, int32_t input_precision,
-                                           int32_t intermediate_precision, bool grads_in_input_type);
+                                           int32_t intermediate_precision, bool grads_in_input_type,
+                                           bool out_in_input_type);
 
 int32_t umfa_quantize_rows(mfa_context_t context, void* stream, const void* src, int32_t input_precision,
                            uint32_t batch_heads, uint32_t rows, uint32_t head_dim, int32_t bits, int32_t quant_mode,

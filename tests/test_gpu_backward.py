@@ -236,3 +236,19 @@ def test_backward_stream_entry_matches_blocking_abi(ctx, shape, dt, causal):
         ref = torch.from_numpy(np.ascontiguousarray(c)).to(tdt)   # the blocking ABI's fp32 gradients, rounded once
         assert a.dtype == tdt and b.dtype == tdt
         assert torch.equal(a.cpu(), ref) and torch.equal(b.cpu(), ref)
+
+
+def test_backward_stream_accepts_o_in_operand_type(ctx):
+    """the autograd path keeps O in the operand type (no separate fp32 copy): D = rowsum(dO o O) then comes from the
+    rounded O; gradients stay within the bf16 tolerance of the fp32-O gradients"""
+    import umfa_torch
+    from umfa_torch import ops
+    torch.manual_seed(3)
+    shape = (1, 3, 384, 128)
+    q, k, v, do = (torch.randn(shape, device="cuda", dtype=torch.bfloat16) for _ in range(4))
+    o32, lse = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32, return_lse=True)
+    a = ops.attention_backward(do, q, k, v, o32, lse, scale=128 ** -0.5, keep_fp32=True)
+    b = ops.attention_backward(do, q, k, v, o32.to(torch.bfloat16), lse, scale=128 ** -0.5, keep_fp32=True)
+    for x, y in zip(a, b):
+        assert x.dtype == torch.float32 and y.dtype == torch.float32
+        assert ((x - y).abs().max() / x.abs().max()).item() < 1e-2

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void bwd_delta_kernel(BwdParams p) {
     if (row >= rows) return;
     float s = 0.0f;
     for (uint32_t d = lane; d < p.D; d += 64)
-        s += load_as_float(p.dout, row * p.D + d, p.dout_prec) * p.o[row * p.D + d];
+        s += load_as_float(p.dout, row * p.D + d, p.dout_prec) * (p.o_in_type ? load_as_float(p.o, row * p.D + d, p.in_prec) : p.o[row * p.D + d]);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     if (lane == 0) p.dvec[row] = s;

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void bwd16_delta_kernel(BwdParams p) {
 #pragma unroll
     for (int j = 0; j < DP / 64; ++j) {
         const int64_t at = row * DP + (DP / 64) * lane + j;
-        s += load_as_float(p.dout, at, p.dout_prec) * p.o[at];
+        s += load_as_float(p.dout, at, p.dout_prec) * (p.o_in_type ? load_as_float(p.o, at, p.in_prec) : p.o[at]);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);

@@ -78,6 +78,7 @@ struct BwdParams {
     int in_prec;    // q, k, v
     int dout_prec;  // dO
     int grad_in_type;  // 0: dQ, dK, dV are fp32 (the ABI contract); 1: they are written in the input type (in-stream entry)
+    int o_in_type;     // 0: O is fp32 (the ABI contract); 1: `o` points at O in the input type (in-stream entry)
     int phases;     // fp32-exact backward only: 0 = everything; else bit 0 = D vector, bit 1 = dQ, bit 2 = dK/dV
 };
 

@@ -80,24 +80,28 @@ mfa_error_t mfa_attention_backward(mfa_context_t context, mfa_buffer_t dout, mfa
 // caller's stream, no upload / download / synchronise.  grads_in_input_type = true writes dQ, dK, dV rounded once to the
 // operand type from the kernels' epilogues (the torch caller casts the fp32 gradients back immediately otherwise,
 // metal_sdpa_backend.cpp:2799-2802); only the 16-bit MFMA backward offers it (else error 1 and the caller uses fp32).
+// out_in_input_type = true: `out` is the O tensor in the operand type (what the forward returned to the framework)
+// instead of a separate fp32 copy kept only for D = rowsum(dO o O): halves the activation the autograd graph holds.
 mfa_error_t umfa_attention_backward_stream(mfa_context_t context, void* stream, const void* dout, const void* q,
-                                           const void* k, const void* v, const float* out, const float* softmax_lse,
+                                           const void* k, const void* v, const void* out, const float* softmax_lse,
                                            void* dq, void* dk, void* dv, float* d_buffer, uint32_t batch_size,
                                            uint32_t seq_len_q, uint32_t seq_len_kv, uint32_t num_heads,
                                            uint16_t head_dim, float softmax_scale, bool causal, int32_t input_precision,
-                                           int32_t intermediate_precision, bool grads_in_input_type) {
+                                           int32_t intermediate_precision, bool grads_in_input_type,
+                                           bool out_in_input_type) {
     Context* ctx = as_ctx(context);
     if (!ctx || !dout || !q || !k || !v || !out || !softmax_lse || !dq || !dk || !dv || !d_buffer) return MFA_ERROR_INVALID_ARGS;
     if (head_dim == 0 || head_dim > 256) return MFA_ERROR_INVALID_ARGS;
     if ((size_t)batch_size * num_heads * seq_len_q * seq_len_kv == 0) return MFA_SUCCESS;
     BwdParams p;
     memset(&p, 0, sizeof(p));
-    p.dout = dout; p.q = q; p.k = k; p.v = v; p.o = out; p.lse = softmax_lse;
+    p.dout = dout; p.q = q; p.k = k; p.v = v; p.o = (const float*)out; p.lse = softmax_lse;
     p.dq = (float*)dq; p.dk = (float*)dk; p.dv = (float*)dv; p.dvec = d_buffer;
     p.B = batch_size; p.H = num_heads; p.Sq = seq_len_q; p.Skv = seq_len_kv; p.D = head_dim;
     p.scale = softmax_scale; p.causal = causal ? 1 : 0;
     p.in_prec = dense_prec(input_precision); p.dout_prec = p.in_prec;
     p.grad_in_type = grads_in_input_type ? 1 : 0;
+    p.o_in_type = (out_in_input_type && p.in_prec != P_FP32) ? 1 : 0;  // D = rowsum(dO o O) from the rounded O the caller kept
     const bool lowp = dense_prec(intermediate_precision) != P_FP32 && !getenv("UMFA_BWD_EXACT");
     const bool mfma16 = lowp && bwd_16_supported(p);
     if (grads_in_input_type && !mfma16) return MFA_ERROR_INVALID_ARGS;

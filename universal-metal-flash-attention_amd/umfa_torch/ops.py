@@ -167,7 +167,8 @@ def attention_backward(dout, q, k, v, o32, lse, *, scale: float, causal: bool = 
     Skv = k.shape[2]
     for t in (dout, q, k, v, o32, lse):
         assert t.is_cuda and t.is_contiguous()
-    assert o32.dtype == torch.float32 and lse.dtype == torch.float32 and dout.dtype == q.dtype
+    assert o32.dtype in (torch.float32, q.dtype) and lse.dtype == torch.float32 and dout.dtype == q.dtype
+    o_typed = o32.dtype != torch.float32  # O in the operand type (what the forward returned) instead of an fp32 copy
     inter = _PREC[intermediate_dtype or q.dtype]
     dvec = torch.empty((B * H * Sq,), dtype=torch.float32, device=q.device)
     stream = ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream)
@@ -178,7 +179,7 @@ def attention_backward(dout, q, k, v, o32, lse, *, scale: float, causal: bool = 
         dv = torch.empty_like(dk)
         rc = _lib.umfa_attention_backward_stream(
             context(), stream, *(ctypes.c_void_p(t.data_ptr()) for t in (dout, q, k, v, o32, lse, dq, dk, dv, dvec)),
-            B, Sq, Skv, H, D, float(scale), bool(causal), _PREC[q.dtype], inter, typed)
+            B, Sq, Skv, H, D, float(scale), bool(causal), _PREC[q.dtype], inter, typed, o_typed)
         return rc, dq, dk, dv
 
     if grads_in_input_type and not keep_fp32 and q.dtype != torch.float32:

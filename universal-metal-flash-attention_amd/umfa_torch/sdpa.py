@@ -89,11 +89,12 @@ class _FlashAttentionFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, causal: bool, scale: float):
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
-        o32, lse = ops.attention_forward(q, k, v, scale=scale, causal=causal, out_dtype=torch.float32,
-                                         return_lse=True)
-        ctx.save_for_backward(q, k, v, o32, lse)
+        # O in the operand type from the kernel's epilogue; the SAME tensor serves D = rowsum(dO o O) in the backward
+        # (the reference keeps a separate fp32 O for that, :2672-2870: twice the activation, one more cast)
+        out, lse = ops.attention_forward(q, k, v, scale=scale, causal=causal, out_dtype=q.dtype, return_lse=True)
+        ctx.save_for_backward(q, k, v, out, lse)
         ctx.causal, ctx.scale = causal, scale
-        return o32.to(q.dtype)
+        return out
 
     @staticmethod
     def backward(ctx, dout):
