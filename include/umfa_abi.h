@@ -339,6 +339,14 @@ mfa_error_t umfa_attention_backward_stream(mfa_context_t context, void* stream, 
                                            int32_t intermediate_precision, bool grads_in_input_type,
                                            bool out_in_input_type);
 
+/* MI355X extra: mfa_quantized_forward_with_lse in-stream (dense BHSD device pointers, caller's stream, never
+ * synchronises).  out fp32 [B,H,Sq,D]; lse (fp32 [B*H*Sq]) and mask (fp32 additive [B,H,Sq,Skv]) may be NULL. */
+mfa_error_t umfa_quantized_forward_stream(mfa_context_t context, void* stream, const void* q, const void* k,
+                                          const void* v, float* out, float* lse, const float* mask, uint32_t batch_size,
+                                          uint32_t seq_len_q, uint32_t seq_len_kv, uint32_t num_heads, uint16_t head_dim,
+                                          float softmax_scale, bool causal, int32_t target_precision, int32_t quant_mode,
+                                          int32_t input_precision);
+
 int32_t umfa_quantize_rows(mfa_context_t context, void* stream, const void* src, int32_t input_precision,
                            uint32_t batch_heads, uint32_t rows, uint32_t head_dim, int32_t bits, int32_t quant_mode,
                            void* q8_out, void* scales_out, uint32_t* padded_row_bytes);

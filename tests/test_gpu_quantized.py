@@ -195,3 +195,25 @@ def test_quantiser_is_bit_exact_with_the_oracle(dt, bits, mode):
         ref_q, ref_s = orc.quantize_symmetric(xf, bits=bits)
         assert np.array_equal(got_q.ravel(), ref_q)
         assert (got_s == ref_s[0]).all()
+
+
+@pytest.mark.parametrize("shape,causal,bits,mode", [((1, 24, 1024, 128), False, 8, "blockwise"), ((2, 3, 333, 64), True, 8, "tensor"),
+                                                    ((1, 2, 512, 128), False, 4, "blockwise"), ((1, 2, 200, 256), False, 8, "blockwise")])
+def test_quantized_forward_stream_entry_matches_blocking(shape, causal, bits, mode):
+    """umfa_quantized_forward_stream (asynchronous, caller's stream) gives the bits of mfa_quantized_forward_with_lse"""
+    import umfa_torch
+    torch.manual_seed(8)
+    q, k, v = (torch.randn(shape, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    o1, l1 = umfa_torch.quantized_attention_forward(q, k, v, causal=causal, bits=bits, quant_mode=mode)
+    k1 = umfa_torch.last_kernel()
+    o2, l2 = umfa_torch.quantized_attention_forward_stream(q, k, v, causal=causal, bits=bits, quant_mode=mode, return_lse=True)
+    torch.cuda.synchronize()
+    assert umfa_torch.last_kernel() == k1
+    assert torch.equal(o1, o2) and torch.equal(l1, l2)
+    m = torch.rand(shape[0], shape[1], shape[2], shape[2], device="cuda") < 0.8
+    m[..., 0] = True
+    if not causal:
+        a, _ = umfa_torch.quantized_attention_forward(q, k, v, mask=m, bits=bits, quant_mode=mode)
+        b = umfa_torch.quantized_attention_forward_stream(q, k, v, mask=m, bits=bits, quant_mode=mode)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)

@@ -167,6 +167,43 @@ int32_t mfa_quantized_forward_with_lse(mfa_context_t context, mfa_buffer_t q, mf
     return MFA_SUCCESS;
 }
 
+// MI355X extra (not in the reference): mfa_quantized_forward_with_lse in-stream -- dense BHSD device pointers, the
+// caller's stream, no upload / download / synchronise (the reference's entry blocks; a serving loop should not).
+// O is fp32 [B,H,Sq,D]; lse and mask (fp32 additive [B,H,Sq,Skv]) optional.  One call at a time per context: the
+// quantiser workspace and the split-item scratch belong to the context.
+mfa_error_t umfa_quantized_forward_stream(mfa_context_t context, void* stream, const void* q, const void* k,
+                                          const void* v, float* out, float* lse, const float* mask, uint32_t batch_size,
+                                          uint32_t seq_len_q, uint32_t seq_len_kv, uint32_t num_heads, uint16_t head_dim,
+                                          float softmax_scale, bool causal, int32_t target_precision, int32_t quant_mode,
+                                          int32_t input_precision) {
+    Context* ctx = as_ctx(context);
+    if (!ctx || !q || !k || !v || !out) return MFA_ERROR_INVALID_ARGS;
+    const uint32_t B = batch_size, H = num_heads, Sq = seq_len_q, Skv = seq_len_kv, D = head_dim;
+    if ((size_t)B * H * Sq * Skv == 0) return MFA_SUCCESS;
+    if (!quantized_supported(D) || !(softmax_scale > 0.0f)) return MFA_ERROR_INVALID_ARGS;
+    const int bits = target_precision == MFA_PRECISION_INT4 ? 4 : 8;
+    const int mode = quant_mode == 2 ? 2 : 0;
+    void* ws = ctx->ensure_workspace(quant_workspace_bytes(B, H, Sq, Skv, D, false));
+    if (!ws) return MFA_ERROR_MEMORY_ALLOCATION;
+    FwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.q = q; p.k = k; p.v = v; p.o = out; p.lse = lse; p.mask = mask;
+    p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv; p.D = D;
+    p.scale = softmax_scale; p.causal = causal ? 1 : 0;
+    p.in_prec = dense_prec(input_precision); p.out_prec = P_FP32;
+    if (fwd_w64_i8_supported(p)) {
+        const FwdW64Plan plan = fwd_w64_plan(p);
+        if (char* w64 = (char*)ctx->ensure_w64(plan.cnt_bytes, plan.buf_bytes)) {
+            p.part_cnt = (uint32_t*)w64;
+            p.part_buf = (float*)(w64 + ctx->w64_cnt_bytes);
+        }
+    }
+    const char* name = "none";
+    hipError_t e = launch_quantized_fwd(p, bits, mode, ws, (hipStream_t)stream, &name);
+    ctx->last_kernel = name;
+    return e == hipSuccess ? MFA_SUCCESS : e == hipErrorInvalidValue ? MFA_ERROR_INVALID_ARGS : MFA_ERROR_EXECUTION_FAILED;
+}
+
 // Backward of the quantised forward: re-quantise Q, K, V deterministically (same kernels, same scales as the
 // forward), then the fp32 backward on the de-quantised operands -- the reference's "dequantise-on-load into FP32
 // tiles -> FP32 math" (AGENTS.md:143-152); gradients flow straight through the rounding (STE).

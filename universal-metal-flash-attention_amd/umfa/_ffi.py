@@ -151,6 +151,8 @@ def _load_library() -> ctypes.CDLL:
     sig("mfa_get_quantized_capabilities", None, [_vp])
     sig("umfa_attention_backward_stream", mfa_error_t,
         [mfa_context_t, _vp] + [_vp] * 10 + _DIMS + [_f32, _b, _i32, _i32, _b, _b])
+    sig("umfa_quantized_forward_stream", mfa_error_t,
+        [mfa_context_t, _vp] + [_vp] * 6 + _DIMS + [_f32, _b, _i32, _i32, _i32])
     sig("umfa_last_kernel_name", ctypes.c_char_p, [mfa_context_t])
     sig("umfa_quantize_rows", _i32, [mfa_context_t, _vp, _vp, _i32, _u32, _u32, _u32, _i32, _i32, _vp, _vp,
                                      ctypes.POINTER(_u32)])

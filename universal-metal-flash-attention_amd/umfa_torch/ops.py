@@ -154,6 +154,29 @@ def quantized_attention_forward(q, k, v, *, scale=None, causal=False, mask=None,
     return out, lse
 
 
+def quantized_attention_forward_stream(q, k, v, *, scale=None, causal=False, mask=None, bits: int = 8,
+                                       quant_mode: str = "blockwise", return_lse: bool = False):
+    """quantized_attention_forward without the host round trips: umfa_quantized_forward_stream on torch's current
+    stream (asynchronous).  Same numbers as the blocking entry."""
+    B, H, Sq, D = q.shape
+    Skv = k.shape[2]
+    if scale is None:
+        scale = D ** -0.5
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    out = torch.empty((B, H, Sq, D), dtype=torch.float32, device=q.device)
+    lse = torch.empty((B * H * Sq,), dtype=torch.float32, device=q.device)
+    m32 = None
+    if mask is not None:
+        m32 = torch.zeros((B, H, Sq, Skv), dtype=torch.float32, device=q.device)
+        m32 = (m32.masked_fill(~mask, float("-inf")) if mask.dtype == torch.bool else m32 + mask.float()).contiguous()
+    vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+    _check_error(_lib.umfa_quantized_forward_stream(
+        context(), ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream), vp(q), vp(k), vp(v), vp(out),
+        vp(lse), vp(m32), B, Sq, Skv, H, D, float(scale), bool(causal), 4 if bits == 4 else 3,
+        2 if quant_mode.startswith("block") else 0, _PREC[q.dtype]))
+    return (out, lse) if return_lse else out
+
+
 def gpu_latency() -> float:
     return float(_lib.mfa_get_gpu_latency(context()))
 
