@@ -113,9 +113,11 @@ class _QuantizedFlashAttentionFn(torch.autograd.Function):
         if q.dtype not in (torch.float16, torch.bfloat16):
             q, k, v = q.float(), k.float(), v.float()  # (:3157-3171)
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
-        o32, lse = ops.quantized_attention_forward(q, k, v, scale=scale, causal=causal, mask=mask,
-                                                   bits=4 if precision == QUANT_INT4 else 8,
-                                                   quant_mode="blockwise" if mode == QUANT_BLOCK_WISE else "tensor")
+        # in-stream (the reference's forward blocks on the GPU, :3142-3267; same numbers)
+        o32, lse = ops.quantized_attention_forward_stream(q, k, v, scale=scale, causal=causal, mask=mask,
+                                                          bits=4 if precision == QUANT_INT4 else 8,
+                                                          quant_mode="blockwise" if mode == QUANT_BLOCK_WISE else "tensor",
+                                                          return_lse=True)
         ctx.save_for_backward(q, k, v, o32, lse)
         ctx.mask = mask
         ctx.args = (causal, scale, precision, mode)
