@@ -161,7 +161,32 @@ __global__ __launch_bounds__(256, DP == 256 ? 1 : 2) void bwd16_dq_kernel(BwdPar
     }
     const float c = p.scale * UMFA_LOG2E;
     const float L2 = qok ? p.lse[(int64_t)bh * p.Sq + q_row] * UMFA_LOG2E : INFINITY;  // +inf -> P = 0
-    const float delta = qok ? p.dvec[(int64_t)bh * p.Sq + q_row] : 0.0f;
+    // D[q] = rowsum(dO o O), fused here (the reference zeroes and fills a D scratch in its own pass): this lane already
+    // holds dO[q][16 ks + 8 hi .. +7] for every k-step -- half of the row -- so it reads the same half of O (fp32, or the
+    // operand type on the in-stream entry), multiplies, and the two lanes of a row add their halves.  The dK / dV
+    // kernel, launched behind this one, reads D from the scratch.
+    float delta = 0.0f;
+    if (qok) {
+        const int64_t orow = ((int64_t)bh * p.Sq + q_row) * DP;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int64_t at = orow + 16 * ks + 8 * hi;
+            if (p.o_in_type) {
+                const V8 ov = *(const V8*)((const T*)p.o + at);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) delta = __builtin_fmaf((float)dof[ks][j], (float)ov[j], delta);
+            } else {
+                const f32x4 o0 = *(const f32x4*)(p.o + at), o1 = *(const f32x4*)(p.o + at + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    delta = __builtin_fmaf((float)dof[ks][j], o0[j], delta);
+                    delta = __builtin_fmaf((float)dof[ks][4 + j], o1[j], delta);
+                }
+            }
+        }
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    if (qok && hi == 0) p.dvec[(int64_t)bh * p.Sq + q_row] = delta;
 
     const i32x4 k_srd = make_srd(kp, p.Skv * (uint32_t)ROW_B), v_srd = make_srd(vp, p.Skv * (uint32_t)ROW_B);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((LDS_AS char*)smem));
@@ -419,7 +444,8 @@ template <typename T, bool CAUSAL, int DP>
 static hipError_t launch_bwd16_t(const BwdParams& p, hipStream_t stream) {
     constexpr int TILE_BYTES = 32 * 2 * DP;
     const int64_t rows = (int64_t)p.B * p.H * p.Sq;
-    hipLaunchKernelGGL(bwd16_delta_kernel<DP>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, p);
+    (void)rows;  // D = rowsum(dO o O) is computed inside bwd16_dq (bwd16_delta_kernel stays for reference / lab use)
+    if (getenv("UMFA_LAB_SEPARATE_DELTA")) hipLaunchKernelGGL(bwd16_delta_kernel<DP>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, p);
     const size_t lds_dq = 4 * TILE_BYTES, lds_kv = 8 * TILE_BYTES + 1024;
     static bool attr_set = false;
     if (!attr_set) {
