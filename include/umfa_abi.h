@@ -315,6 +315,10 @@ mfa_error_t mfa_mla_forward(mfa_mla_context_t context, mfa_context_t mfa_context
  * Asynchronous launch of the bf16/fp16 forward with a caller-chosen output
  * element type (0 = fp16, 1 = bf16, 2 = fp32) and optional LSE, so a PyTorch
  * binding can skip the fp32-O round trip (metal_sdpa_backend.cpp:1418-1445). */
+/* umfa_attention_forward_stream only: mask_type value for a sliding window WITHOUT a mask tensor.  mask_shape points at
+ * int64 {left, right}: key attends iff row - left <= key <= row + right; mask / mask_strides / mask_ndim are ignored. */
+#define UMFA_MASK_TYPE_WINDOW 3
+
 mfa_error_t umfa_attention_forward_stream(
     mfa_context_t context, void* stream, const void* q, const int64_t* q_strides, const void* k,
     const int64_t* k_strides, const void* v, const int64_t* v_strides, void* out,

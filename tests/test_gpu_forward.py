@@ -349,3 +349,50 @@ def test_mask_tile_early_exit(kind, dt, monkeypatch):
     out2, lse2 = umfa_torch.attention_forward(q, k, v, causal=causal, mask=mask, out_dtype=torch.float32, return_lse=True)
     torch.cuda.synchronize()
     assert torch.equal(out, out2) and torch.equal(lse, lse2)  # skipping / not reading changes no bit
+
+
+@pytest.mark.parametrize("shape,window,causal", [((1, 3, 640, 704, 128), (100, 100), False), ((2, 2, 1024, 1024, 64), (256, 0), True),
+                                                 ((1, 2, 333, 333, 80), (17, 40), False), ((1, 2, 2048, 2048, 128), (0, 0), False),
+                                                 ((1, 1, 200, 200, 64), (1000, 1000), False)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_native_sliding_window(shape, window, causal, dt):
+    """window=(left, right) on the in-stream entry (no mask tensor): same bits as the equivalent bool band mask through
+    the masked path, and the fp32 restatement's numbers; fp32 operands take the exact kernel with the same window term"""
+    import umfa_torch
+    B, H, Sq, Skv, D = shape
+    torch.manual_seed(13)
+    q = torch.randn(B, H, Sq, D, device="cuda", dtype=dt)
+    k = torch.randn(B, H, Skv, D, device="cuda", dtype=dt)
+    v = torch.randn(B, H, Skv, D, device="cuda", dtype=dt)
+    i = torch.arange(Sq, device="cuda")[:, None]
+    j = torch.arange(Skv, device="cuda")[None, :]
+    band = ((j >= i - window[0]) & (j <= i + window[1]))[None, None]
+    out, lse = umfa_torch.attention_forward(q, k, v, causal=causal, window=window, out_dtype=torch.float32, return_lse=True)
+    ref_o, ref_l = umfa_torch.attention_forward(q, k, v, causal=causal, mask=band, out_dtype=torch.float32, return_lse=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    assert torch.equal(out, ref_o) and torch.equal(lse, ref_l)
+    s = torch.matmul(q.double(), k.double().transpose(-1, -2)) * D ** -0.5
+    keep = band[0, 0] & (torch.ones(Sq, Skv, dtype=torch.bool, device="cuda").tril() if causal else True)
+    r = torch.matmul(torch.softmax(s.masked_fill(~keep, float("-inf")), dim=-1), v.double())
+    assert ((out.double() - r).abs().max() / r.abs().max()).item() < (6e-3 if dt == torch.bfloat16 else 2e-5)
+
+
+def test_native_sliding_window_long_sequence():
+    """S = 16384 with a 512-wide look-back window: no S x S mask exists anywhere; rows equal a dense computation on
+    just their band"""
+    import umfa_torch
+    torch.manual_seed(14)
+    B, H, S, D, W = 1, 4, 16384, 128, 512
+    q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    out = umfa_torch.attention_forward(q, k, v, causal=True, window=(W, 0), out_dtype=torch.float32)
+    for r0 in (0, 5000, 16383 - 64):
+        rows = slice(r0, r0 + 64)
+        lo = max(0, r0 - W)
+        ks = slice(lo, r0 + 64)
+        s = torch.matmul(q[:, :, rows].float(), k[:, :, ks].float().transpose(-1, -2)) * D ** -0.5
+        i = torch.arange(r0, r0 + 64, device="cuda")[:, None]
+        j = torch.arange(lo, r0 + 64, device="cuda")[None, :]
+        s = s.masked_fill(~((j <= i) & (j >= i - W)), float("-inf"))
+        ref = torch.matmul(torch.softmax(s, -1), v[:, :, ks].float())
+        assert ((out[:, :, rows] - ref).abs().max() / ref.abs().max()).item() < 6e-3

@@ -299,6 +299,7 @@ hipError_t launch_mask_flags(FwdParams& p, uint8_t* flags, hipStream_t stream) {
 // for banded / padded ones).  Additive float masks are usually dense biases with nothing to skip: only when the distinct
 // mask bytes stay below twice the Q + K + V + O traffic (e.g. one [Sq, Skv] bias shared by the heads).
 bool mask_flags_worthwhile(const FwdParams& p) {
+    if (p.mask_kind == MK_WINDOW) return false;  // its tile flags are arithmetic, inside the kernel
     if (p.mask_kind == MK_BOOL) return true;
     const uint64_t Bm = p.ms[0] != 0 ? p.B : 1, Hm = p.ms[1] != 0 ? p.H : 1;
     const uint64_t es = p.mask_kind == MK_F32 ? 4 : 2, eb = p.in_prec == P_FP32 ? 4 : 2;

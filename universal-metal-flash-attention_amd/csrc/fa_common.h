@@ -24,7 +24,8 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 enum Prec : int { P_FP16 = 0, P_BF16 = 1, P_FP32 = 2, P_INT8 = 3, P_INT4 = 4 };
 // mask kinds after host-side normalisation (mfa_mask_type_t x mfa_mask_scalar_t)
-enum MaskKind : int { MK_NONE = 0, MK_BOOL = 1, MK_F32 = 2, MK_F16 = 3, MK_BF16 = 4 };
+enum MaskKind : int { MK_NONE = 0, MK_BOOL = 1, MK_F32 = 2, MK_F16 = 3, MK_BF16 = 4,
+                      MK_WINDOW = 5 /* no tensor: key attends iff row - win_left <= key <= row + win_right */ };
 
 #define UMFA_LOG2E 1.4426950408889634f
 #define UMFA_LN2 0.6931471805599453f
@@ -58,6 +59,7 @@ struct FwdParams {
     const uint8_t* mask_flags;
     uint32_t mf_bs, mf_hs;         // flag-row strides of batch / head in units of (mf_nrb * mf_ntiles); 0 = broadcast
     uint32_t mf_nrb, mf_ntiles;    // 32-row blocks, 64-key tiles
+    uint32_t win_left, win_right;  // MK_WINDOW: sliding window (in-stream entry, mask type 3); tile flags are arithmetic
 };
 
 struct BwdParams {
@@ -102,6 +104,11 @@ __device__ __forceinline__ float mask_term(const void* mask, int64_t idx, int ki
     case MK_BF16: return bf16_bits_to_float(((const uint16_t*)mask)[idx]) * UMFA_LOG2E;
     default: return 0.0f;
     }
+}
+
+// MK_WINDOW term of (row, key)
+__device__ __forceinline__ float window_term(uint32_t row, uint32_t key, uint32_t left, uint32_t right) {
+    return (key + left >= row && key <= row + right) ? 0.0f : -INFINITY;
 }
 
 // key index inside a 32-key block held by accumulator register r of lane-half hi

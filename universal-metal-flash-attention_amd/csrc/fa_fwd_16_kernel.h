@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
     // masks with contiguous rows aligned to four elements: the four keys a lane owns per register group are ONE load
     // (dword for bytes, 8 bytes for fp16 / bf16, 16 bytes for fp32)
     const int mes = p.mask_kind == MK_BOOL ? 1 : (p.mask_kind == MK_F32 ? 4 : 2);
-    const bool mvec = HAS_MASK && p.ms[3] == 1 && (p.Skv & 3) == 0 && ((p.ms[0] | p.ms[1] | p.ms[2]) & 3) == 0 &&
+    const bool mvec = HAS_MASK && p.mask_kind != MK_WINDOW && p.ms[3] == 1 && (p.Skv & 3) == 0 && ((p.ms[0] | p.ms[1] | p.ms[2]) & 3) == 0 &&
                       ((uintptr_t)p.mask & (uintptr_t)(4 * mes - 1)) == 0;
     // mask tile flags (FwdParams::mask_flags): this wave's 32 rows are one flag row; 64 tiles per register
     const uint8_t* mf_row = nullptr;
@@ -314,6 +314,15 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
             __syncthreads();
         }
     }
+    if (HAS_MASK && p.mask_kind == MK_WINDOW) {  // the workgroup's 128 rows see keys [row0 - left, row0 + 127 + right] only
+        const uint32_t row0 = qb * BM;
+        const uint32_t lo = row0 > p.win_left ? (row0 - p.win_left) / BN : 0;
+        const uint64_t hik = (uint64_t)row0 + BM - 1 + p.win_right;
+        const uint32_t hi1 = hik / BN + 1 > t_end ? t_end : (uint32_t)(hik / BN + 1);
+        t_begin = lo > t_begin ? lo : t_begin;
+        t_end = hi1 < t_end ? hi1 : t_end;
+        if (t_end < t_begin) t_end = t_begin;
+    }
     stage_load(t_begin);
     stage_write(t_begin & 1);
     __syncthreads();
@@ -335,6 +344,12 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
                 mf_reg = t64 + lane < p.mf_ntiles ? (int)mf_row[t64 + lane] : 0;
             }
             mflag = __builtin_amdgcn_readlane(mf_reg, (int)(t & 63));
+            active = active && mflag != 1;
+        } else if (HAS_MASK && p.mask_kind == MK_WINDOW) {
+            // sliding window: the flags of this wave's 32 rows x this tile's keys are arithmetic
+            const uint32_t k1 = key_base + BN - 1, r1 = wave_q0 + 31;
+            if (k1 + p.win_left < wave_q0 || key_base > r1 + p.win_right) mflag = 1;
+            else if (key_base + p.win_left >= r1 && k1 <= wave_q0 + p.win_right) mflag = 2;
             active = active && mflag != 1;
         }
 #ifndef UMFA_ABL_NO_LOAD
@@ -428,7 +443,8 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
                         const uint32_t key = key_base + 32 * kb + acc_row(r, hi);
                         float tv = s[kb][r] * c2;
                         if (mflag != 2 && key < p.Skv && q_row < p.Sq)
-                            tv += mask_term(p.mask, mrow + (int64_t)key * p.ms[3], p.mask_kind);
+                            tv += p.mask_kind == MK_WINDOW ? window_term(q_row, key, p.win_left, p.win_right)
+                                                           : mask_term(p.mask, mrow + (int64_t)key * p.ms[3], p.mask_kind);
                         if (key >= p.Skv || (CAUSAL && key > q_row)) tv = -INFINITY;
                         s[kb][r] = tv;
                         mx = fmaxf(mx, tv);

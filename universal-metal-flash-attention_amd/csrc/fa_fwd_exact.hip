@@ -85,7 +85,8 @@ __global__ __launch_bounds__(256) void fa_fwd_exact_kernel(FwdParams p) {
             const uint32_t key = t * BN + acc_row(r, hi);
             float tv = s[r] * c;
             if (p.mask_kind != MK_NONE && key < p.Skv && q_row < p.Sq)
-                tv += mask_term(p.mask, mbase + (int64_t)key * p.ms[3], p.mask_kind);
+                tv += p.mask_kind == MK_WINDOW ? window_term(q_row, key, p.win_left, p.win_right)
+                                               : mask_term(p.mask, mbase + (int64_t)key * p.ms[3], p.mask_kind);
             if (key >= p.Skv || (p.causal && key > q_row)) tv = -INFINITY;
             s[r] = tv;
             mx = fmaxf(mx, tv);

@@ -337,7 +337,15 @@ mfa_error_t umfa_attention_forward_stream(mfa_context_t context, void* stream, c
     };
     if (!take(p.qs, q_strides) || !take(p.ks, k_strides) || !take(p.vs, v_strides)) return MFA_ERROR_INVALID_ARGS;
     p.q = q; p.k = k; p.v = v; p.o = out; p.lse = lse;
-    if (mask_type != MFA_MASK_TYPE_NONE) {
+    if ((int)mask_type == UMFA_MASK_TYPE_WINDOW) {
+        // MI355X extra: sliding window without a mask tensor -- mask_shape = {left, right}: key attends iff
+        // row - left <= key <= row + right (combine with `causal` for a look-back window); tiles outside the band are
+        // never staged, tiles inside it run unmasked (fa_fwd_16_kernel.h)
+        if (!mask_shape || mask_shape[0] < 0 || mask_shape[1] < 0) return MFA_ERROR_INVALID_ARGS;
+        p.mask_kind = MK_WINDOW;
+        p.win_left = (uint32_t)(mask_shape[0] > 0x3fffffff ? 0x3fffffff : mask_shape[0]);
+        p.win_right = (uint32_t)(mask_shape[1] > 0x3fffffff ? 0x3fffffff : mask_shape[1]);
+    } else if (mask_type != MFA_MASK_TYPE_NONE) {
         if (!mask || !mask_shape || !mask_strides || mask_ndim == 0 || mask_ndim > 4) return MFA_ERROR_INVALID_ARGS;
         normalise_mask(mask_shape, mask_strides, mask_ndim, mask_type, mask_scalar_type, p);
         p.mask = mask;

@@ -61,8 +61,13 @@ def _mask_args(mask: Optional[torch.Tensor]):
 
 def attention_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, scale: Optional[float] = None,
                       causal: bool = False, mask: Optional[torch.Tensor] = None, out_dtype=None,
-                      return_lse: bool = False, intermediate_dtype=None, out: Optional[torch.Tensor] = None):
+                      return_lse: bool = False, intermediate_dtype=None, out: Optional[torch.Tensor] = None,
+                      window=None):
     """q [B,H,Sq,D], k/v [B,H,Skv,D] device tensors (any BHSD strides with a contiguous last dim).
+
+    window=(left, right): sliding-window attention without a mask tensor -- key j attends to row i iff
+    i - left <= j <= i + right (add causal=True for a look-back-only window); key tiles outside the band are never
+    touched, so the cost follows the band, not Skv.  Exclusive with `mask`.
 
     out_dtype: torch.float32 (the C-ABI contract) or q.dtype (fused cast-back epilogue).
     Asynchronous on torch's current stream.
@@ -79,7 +84,12 @@ def attention_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, scal
     if out is None:
         out = torch.empty((B, H, Sq, D), dtype=out_dtype, device=q.device)
     lse = torch.empty((B * H * Sq,), dtype=torch.float32, device=q.device) if return_lse else None
-    mptr, mshape, mstr, mnd, mt, ms = _mask_args(mask)
+    if window is not None:
+        if mask is not None:
+            raise ValueError("window and mask are exclusive")
+        mptr, mshape, mstr, mnd, mt, ms = None, _i64((int(window[0]), int(window[1]))), None, 0, 3, MFA_MASK_SCALAR_BYTE
+    else:
+        mptr, mshape, mstr, mnd, mt, ms = _mask_args(mask)
     inter = _PREC[intermediate_dtype or q.dtype]
     stream = torch.cuda.current_stream(q.device).cuda_stream
     _check_error(_lib.umfa_attention_forward_stream(
