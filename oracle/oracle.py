@@ -253,3 +253,41 @@ def hadamard(x: np.ndarray, block: int) -> np.ndarray:
     assert v.size % block == 0
     L.ref_hadamard(v.ctypes.data, block, v.size // block)
     return v.reshape(x.shape)
+
+
+def sdpa_forward_rows(q, k, v, rows, scale=None, causal=False, return_lse=False):
+    """The oracle on a subset of query rows against ALL keys: returns O[:, :, rows] (fp32) -- the full-size parity
+    checks use it where the whole tensor would take minutes.  `causal` keeps the absolute row indices (top-left
+    aligned, as ref_sdpa_forward) by way of a bool mask [len(rows), Skv]."""
+    rows = np.asarray(rows, np.int64)
+    qs = np.ascontiguousarray(q[:, :, rows])
+    mask, mt = None, MASK_NONE
+    if causal:
+        mask = np.ascontiguousarray(np.arange(k.shape[2])[None, :] <= rows[:, None])
+        mt = MASK_BOOL
+    return sdpa_forward(qs, k, v, scale=scale, mask=mask, mask_type=mt, return_lse=return_lse)
+
+
+def round_to(x: np.ndarray, kind: str) -> np.ndarray:
+    """fp64/fp32 array rounded to the value set of `kind` ("bf16", "fp16", "fp32"), returned as float64."""
+    if kind == "bf16":
+        return bf16_bits_to_f32(f32_to_bf16_bits(x.astype(np.float32))).astype(np.float64)
+    if kind == "fp16":
+        return x.astype(np.float16).astype(np.float64)
+    return x.astype(np.float32).astype(np.float64)
+
+
+def flash_format_floor(q, k, v, rows, kind: str, scale=None, causal=False):
+    """What an IDEAL flash kernel with `kind` probabilities gives on these rows: exact fp64 scores and exponentials,
+    P rounded once to `kind` (the B operand of the P V MFMA), everything else fp64.  The distance of this from the
+    oracle is the part of a 16-bit kernel's error that the operand FORMAT fixes, whatever the kernel does."""
+    rows = np.asarray(rows, np.int64)
+    qf = to_f32(q).astype(np.float64)[:, :, rows]
+    kf, vf = to_f32(k).astype(np.float64), to_f32(v).astype(np.float64)
+    if scale is None:
+        scale = 1.0 / np.sqrt(q.shape[-1])
+    s = np.einsum("bhid,bhjd->bhij", qf, kf) * scale
+    if causal:
+        s = np.where(np.arange(k.shape[2])[None, :] <= rows[:, None], s, -np.inf)
+    p = np.exp(s - s.max(-1, keepdims=True))
+    return (np.einsum("bhij,bhjd->bhid", round_to(p, kind), vf) / p.sum(-1, keepdims=True)).astype(np.float32)

@@ -118,9 +118,16 @@ int ref_sdpa_forward(const void* q, const void* k, const void* v, float* out, fl
     if (!ks) ks = dk_;
     if (!vs) vs = dk_;
     int failed = 0;
-    /* (batch, head) slabs are independent: one OpenMP task each (threads = OMP_NUM_THREADS). */
+    /* (batch, head) slabs are independent, and so are the rows of a slab: one OpenMP task per (slab, chunk of
+     * ROW_CHUNK rows), so that few-head cases (row-subset checks at the full sizes) still use every host core.
+     * A task converts the slab's K and V to double itself (Skv*D loads against ROW_CHUNK*Skv*D multiply-adds). */
+    enum { ROW_CHUNK = 32 };
+    const int64_t nchunk = ((int64_t)Sq + ROW_CHUNK - 1) / ROW_CHUNK;
 #pragma omp parallel for schedule(dynamic, 1)
-    for (int64_t bh = 0; bh < (int64_t)B * H; ++bh) {
+    for (int64_t task = 0; task < (int64_t)B * H * nchunk; ++task) {
+        const int64_t bh = task / nchunk;
+        const uint32_t i0 = (uint32_t)(task % nchunk) * ROW_CHUNK;
+        const uint32_t i1 = i0 + ROW_CHUNK < Sq ? i0 + ROW_CHUNK : Sq;
         uint32_t b = (uint32_t)(bh / H), h = (uint32_t)(bh % H);
         size_t nkv = (size_t)Skv * D;
         double* kd = (double*)malloc(sizeof(double) * (2 * nkv + Skv + 2 * D + 1));
@@ -131,7 +138,7 @@ int ref_sdpa_forward(const void* q, const void* k, const void* v, float* out, fl
                 kd[(size_t)j * D + d] = load_elem(k, prec, b * ks[0] + h * ks[1] + j * ks[2] + d * ks[3]);
                 vd[(size_t)j * D + d] = load_elem(v, prec, b * vs[0] + h * vs[1] + j * vs[2] + d * vs[3]);
             }
-        for (uint32_t i = 0; i < Sq; ++i) {
+        for (uint32_t i = i0; i < i1; ++i) {
             for (uint32_t d = 0; d < D; ++d)
                 qd[d] = load_elem(q, prec, b * qs[0] + h * qs[1] + i * qs[2] + d * qs[3]);
             double m = -INFINITY;

@@ -22,16 +22,51 @@ def rel_err(a, ref):
     return float(np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-30))
 
 
-def check_rows(q, k, v, o, rows, head, causal, tol):
-    """oracle on selected query rows of one (batch 0, head) slab"""
-    orc = _oracle()
-    kk, vv = bits(k[0:1, head:head + 1].contiguous()), bits(v[0:1, head:head + 1].contiguous())
-    for r in rows:
-        qq = bits(q[0:1, head:head + 1, r:r + 1].contiguous())
-        nk = r + 1 if causal else kk.shape[2]
-        ref = orc.sdpa_forward(qq, np.ascontiguousarray(kk[:, :, :nk]), np.ascontiguousarray(vv[:, :, :nk]))
-        got = o[0, head, r].float().cpu().numpy()
-        assert rel_err(got, ref[0, 0, 0]) < tol, (head, r)
+from tolerances import check_forward, errors, record  # noqa: E402  (measured bounds: tests/tolerances.py)
+
+
+def check_rows(q, k, v, o, rows, causal, kernel, tag, out_dt=None):
+    """The oracle on a subset of query rows of EVERY (batch, head) against all keys; the metric keeps its whole-tensor
+    normalisation (max|O_ref| over the subset), so the bounds of tests/tolerances.py apply as they stand."""
+    rows = np.asarray(rows)
+    ref = _oracle().sdpa_forward_rows(bits(q), bits(k), bits(v), rows, causal=causal)
+    return check_forward(o[:, :, rows].float().cpu().numpy(), ref, q.dtype, kernel, tag, out_dt=out_dt)
+
+
+def test_config1_metal_sdpa_wrapper_B1_H1_S128_D64_fp32():
+    """BASELINE config 1, exact workload and caller: CPU torch tensors through the `MetalSDPA` wrapper
+    (examples/pytorch_sdpa_replacement.py:48-139 semantics) -> umfa.flash_attention_forward -> mfa_attention_forward
+    on host arrays.  Pass = max-abs(O - torch CPU SDPA) < 1e-5 (test_scale_factor_fix.py:66)."""
+    import torch.nn.functional as F
+    import umfa
+    sdpa = umfa.MetalSDPA()
+    try:
+        torch.manual_seed(0)
+        # the reference's 2-D call form ([S, D], one head) and its 4-D umfa form ([B, S, 1, D])
+        q2, k2, v2 = (torch.randn(128, 64) for _ in range(3))
+        for causal in (False, True):
+            o = sdpa(q2, k2, v2, is_causal=causal)
+            assert o.dtype == torch.float32 and o.device.type == "cpu" and o.shape == (128, 64)
+            ref = F.scaled_dot_product_attention(q2[None, None], k2[None, None], v2[None, None], is_causal=causal)[0, 0]
+            d = float((o - ref).abs().max())
+            record("cfg1_metal_sdpa", causal=causal, max_abs=d)
+            assert d < 1e-5, d
+            assert np.abs(o.numpy() - _oracle().sdpa_forward(q2.numpy()[None, None], k2.numpy()[None, None],
+                                                             v2.numpy()[None, None], causal=causal)[0, 0]).max() < 1e-5
+        q4, k4, v4 = (t.view(1, 128, 1, 64) for t in (q2, k2, v2))
+        o4 = sdpa(q4, k4, v4, scale=0.2)
+        ref4 = F.scaled_dot_product_attention(q2[None, None], k2[None, None], v2[None, None], scale=0.2)
+        assert o4.shape == (1, 128, 1, 64) and float((o4.view(128, 64) - ref4[0, 0]).abs().max()) < 1e-5
+        # fp16 stays fp16; any other dtype is computed as fp16 and cast back (reference :110-117)
+        oh = sdpa(q2.half(), k2.half(), v2.half())
+        assert oh.dtype == torch.float16 and float((oh.float() - F.scaled_dot_product_attention(
+            q2.half().float()[None, None], k2.half().float()[None, None], v2.half().float()[None, None])[0, 0]).abs().max()) < 2e-3
+        ob = sdpa(q2.bfloat16(), k2.bfloat16(), v2.bfloat16())
+        assert ob.dtype == torch.bfloat16
+        with pytest.warns(UserWarning):
+            sdpa(q2, k2, v2, attn_mask=torch.ones(128, 128, dtype=torch.bool))
+    finally:
+        sdpa.close()
 
 
 def test_config2_causal_bf16_B4_H16_S1024_D64():
@@ -39,14 +74,15 @@ def test_config2_causal_bf16_B4_H16_S1024_D64():
     torch.manual_seed(0)
     q, k, v = (torch.randn(4, 16, 1024, 64, device="cuda", dtype=torch.bfloat16) for _ in range(3))
     o = umfa_torch.attention_forward(q, k, v, causal=True, out_dtype=torch.float32)
-    assert umfa_torch.last_kernel() == "fa_fwd16<bf16,64>" and torch.isfinite(o).all()
+    kern = umfa_torch.last_kernel()
+    assert kern == "fa_fwd16<bf16,64>" and torch.isfinite(o).all()
     assert torch.equal(o, umfa_torch.attention_forward(q, k, v, causal=True, out_dtype=torch.float32))
-    check_rows(q, k, v, o, [0, 1, 63, 64, 500, 1023], 3, True, 6e-3)
-    # whole heads against the oracle (S=1024 is cheap)
-    orc = _oracle()
-    ref = orc.sdpa_forward(bits(q[1:2, 5:7].contiguous()), bits(k[1:2, 5:7].contiguous()), bits(v[1:2, 5:7].contiguous()),
-                           causal=True)
-    assert rel_err(o[1:2, 5:7].cpu().numpy(), ref) < 6e-3
+    # the WHOLE tensor against the oracle (8.6 GFLOP of fp64: seconds on the box's host cores)
+    ref = _oracle().sdpa_forward(bits(q), bits(k), bits(v), causal=True)
+    mx, _ = check_forward(o.cpu().numpy(), ref, torch.bfloat16, kern, "cfg2_full_fp32O")
+    assert mx < 1.25e-3  # measured 0.94e-3: at this key range bf16 sits at the north-star's 1e-3
+    o16 = umfa_torch.attention_forward(q, k, v, causal=True)
+    check_forward(o16.float().cpu().numpy(), ref, torch.bfloat16, kern, "cfg2_full_bf16O", out_dt=torch.bfloat16)
 
 
 def test_config3_flux_fwd_bwd_bf16():
@@ -57,7 +93,10 @@ def test_config3_flux_fwd_bwd_bf16():
     B, H, S, D = 1, 24, 4096, 128
     q, k, v, do = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(4))
     o32, lse = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32, return_lse=True)
-    check_rows(q, k, v, o32, [0, 777, 4095], 11, False, 6e-3)
+    from oracle import parity
+    check_rows(q, k, v, o32, parity.sample_rows(S), False, umfa_torch.last_kernel(), "cfg3_flux_fp32O")
+    o16 = umfa_torch.attention_forward(q, k, v)
+    check_rows(q, k, v, o16, parity.sample_rows(S), False, umfa_torch.last_kernel(), "cfg3_flux_bf16O", out_dt=torch.bfloat16)
     # LSE of a few rows vs fp64
     orc = _oracle()
     _, l_ref = orc.sdpa_forward(bits(q[0:1, 2:3, 100:101].contiguous()), bits(k[0:1, 2:3].contiguous()),
@@ -109,11 +148,30 @@ def test_config4_int8_blockwise_S8192_H16_D128():
     assert umfa_torch.last_kernel() in ("fa_fwd_i8<128>", "fa_fwd_w64_i8<128>") and torch.isfinite(o8).all()
     o8b, _ = umfa_torch.quantized_attention_forward(q, k, v, bits=8, quant_mode="blockwise")
     assert torch.equal(o8, o8b)
-    # rows of one head against the oracle's quantised restatement needs the whole slab quantised: compare
-    # instead with the bf16 forward (error budget of the format) and with the exact rows
-    o16 = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
-    assert float((o8 - o16).abs().max() / o16.abs().max()) < 0.08
-    check_rows(q, k, v, o8, [5, 4097], 7, False, 0.08)
+    # three heads against the oracle's QUANTISED restatement (oracle.quantized_forward's arithmetic: whole slabs
+    # fake-quantised per 64-row block with the oracle's quantiser, then the fp64 forward) on a row subset with all keys
+    from oracle import parity
+    orc = _oracle()
+    hs, rows, D = [0, 7, 15], parity.sample_rows(8192), 128
+
+    def fake_quant(x):
+        f = orc.to_f32(x).reshape(len(hs), -1)
+        out = np.empty_like(f)
+        for i in range(len(hs)):
+            qi, sc = orc.quantize_symmetric(f[i], group=64 * D, bits=8)
+            out[i] = orc.dequantize(qi, sc, group=64 * D)
+        return out.reshape(1, len(hs), -1, D)
+
+    qs, ks, vs = (bits(t[:, hs].contiguous()) for t in (q, k, v))
+    ref_q = orc.sdpa_forward_rows(fake_quant(qs), fake_quant(ks), fake_quant(vs), rows)
+    ref_x = orc.sdpa_forward_rows(qs, ks, vs, rows)
+    got = o8[:, hs][:, :, rows].cpu().numpy()
+    e_q, _ = errors(got, ref_q)
+    e_x, _ = errors(got, ref_x)
+    e_fmt, _ = errors(ref_q, ref_x)
+    record("cfg4_int8_blockwise", rel_vs_quantized_oracle=e_q, rel_vs_exact=e_x, quantisation_itself=e_fmt)
+    assert e_q < 8e-4, e_q           # the kernel against the reference's arithmetic (measured 3.3e-4: fp16 P, fp32 accumulate)
+    assert e_x < 1.25 * e_fmt + 1e-3  # against exact SDPA: what int8 block quantisation itself costs on this data, no more
 
 
 def test_config5_long_context_one_shard_S32768_D128():
@@ -123,6 +181,10 @@ def test_config5_long_context_one_shard_S32768_D128():
     q, k, v = (torch.randn(1, 4, 32768, 128, device="cuda", dtype=torch.bfloat16) for _ in range(3))
     o = umfa_torch.attention_forward(q, k, v)
     assert o.dtype == torch.bfloat16 and torch.isfinite(o).all()
-    check_rows(q, k, v, o, [0, 16384, 32767], 2, False, 1.2e-2)  # bf16 output rounding on top of the kernel's error
+    from oracle import parity
+    rows = parity.sample_rows(32768, groups=4)
+    check_rows(q, k, v, o, rows, False, umfa_torch.last_kernel(), "cfg5_shard_bf16O", out_dt=torch.bfloat16)
+    o32 = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
+    check_rows(q, k, v, o32, rows, False, umfa_torch.last_kernel(), "cfg5_shard_fp32O")
     oc = umfa_torch.attention_forward(q, k, v, causal=True)
-    check_rows(q, k, v, oc, [31, 20000], 1, True, 1.2e-2)
+    check_rows(q, k, v, oc, rows, True, umfa_torch.last_kernel(), "cfg5_shard_causal_bf16O", out_dt=torch.bfloat16)

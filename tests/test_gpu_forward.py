@@ -1,8 +1,9 @@
 """GPU parity of the HIP forward path, called through the C ABI (ctypes), against the golden vectors
 (torch-CPU SDPA) and the CPU oracle.  Tolerances are the reference's own:
 fp32 max-abs < 1e-5 (test_scale_factor_fix.py:66), fp16 1e-3, bf16 1e-2 (conftest.py:186-199), plus the
-north-star's relative bound for 16-bit inputs: max|O - O_ref| / max|O_ref| <= 1e-3 ... measured against
-fp64 SDPA on the already-rounded inputs."""
+north-star's relative metric for 16-bit inputs, max|O - O_ref| / max|O_ref| against fp64 SDPA on the already-rounded
+inputs, held to the MEASURED bounds of tests/tolerances.py (fp16 inside the north-star's 1e-3 everywhere; bf16 at its
+operand-format floor, 0.8e-3 ... 2e-3 by key range -- DESIGN.md §3.2)."""
 import ctypes
 
 import numpy as np
@@ -155,8 +156,8 @@ def test_relative_error_16bit(ctx, shape, dt, causal):
     ref, ref_lse = orc.sdpa_forward(bits(tq), bits(tk), bits(tv), causal=causal, return_lse=True)
     o = o.cpu().numpy()
     assert np.isfinite(o).all()
-    bound = 1.5e-3 if dt == "fp16" else 6e-3  # P is rounded to the input type before PV
-    assert rel_err(o, ref) < bound, rel_err(o, ref)
+    from tolerances import check_forward  # measured bounds; P is rounded to the input type before PV
+    check_forward(o, ref, dt, umfa_torch.last_kernel(), f"rel16_{shape}_{causal}")
     assert np.abs(lse.cpu().numpy().reshape(ref_lse.shape) - ref_lse).max() < 2e-3
     # fused cast-back epilogue (16-bit out): within half an ulp of the fp32 output (the epilogue multiplies
     # and rounds once -- v_fma_mix -- so exact ties may differ from "round the stored fp32 again")
@@ -293,7 +294,8 @@ def test_flux_shape_one_head_vs_oracle(ctx):
     for h in (0, 23):
         ref = orc.sdpa_forward(bits(q[:, h:h + 1].contiguous()), bits(k[:, h:h + 1].contiguous()),
                                bits(v[:, h:h + 1].contiguous()))
-        assert rel_err(o[:, h:h + 1].cpu().numpy(), ref) < 6e-3
+        from tolerances import check_forward
+        check_forward(o[:, h:h + 1].cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel(), f"flux_head{h}")
     flat = o[0].reshape(24, -1)
     c = torch.corrcoef(flat[:, :65536])
     off = c - torch.diag(torch.diag(c))
@@ -395,4 +397,5 @@ def test_native_sliding_window_long_sequence():
         j = torch.arange(lo, r0 + 64, device="cuda")[None, :]
         s = s.masked_fill(~((j <= i) & (j >= i - W)), float("-inf"))
         ref = torch.matmul(torch.softmax(s, -1), v[:, :, ks].float())
-        assert ((out[:, :, rows] - ref).abs().max() / ref.abs().max()).item() < 6e-3
+        from tolerances import check_forward
+        check_forward(out[:, :, rows].cpu().numpy(), ref.cpu().numpy(), torch.bfloat16, "fa_fwd16", f"window_rows{r0}")

@@ -1,0 +1,124 @@
+"""Asynchronous entries under concurrency and graph capture (csrc/runtime_internal.h "scratch"):
+scratch is per (device, stream), grow-only, never allocated while the stream is capturing."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(autouse=True)
+def _force_w64(monkeypatch):
+    monkeypatch.setenv("UMFA_FORCE_W64", "1")  # small grids: every item of fa_fwd16_w64 is cut into parts and folded
+
+
+def _inputs(seed, B=1, H=5, Sq=768, Skv=448):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return tuple(torch.randn(B, H, s, 128, device="cuda", dtype=torch.bfloat16, generator=g) for s in (Sq, Skv, Skv))
+
+
+def test_two_streams_with_cut_items_equal_serial():
+    """Two streams launch forwards whose items are cut (tickets + partials in scratch) at the same time; each stream has
+    its own ticket words and partial slots, so every result is bit-equal to the serial run."""
+    import umfa_torch
+    cases = [_inputs(s, H=6, Sq=4096, Skv=4096) for s in range(4)]
+    serial = [umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32) for q, k, v in cases]
+    assert umfa_torch.last_kernel().startswith("fa_fwd16_w64")
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = {}
+    for rep in range(6):  # interleaved launches, no synchronisation in between: the two streams overlap on the GPU
+        for i, (q, k, v) in enumerate(cases):
+            with torch.cuda.stream(s1 if i % 2 == 0 else s2):
+                outs[(rep, i)] = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    for (rep, i), o in outs.items():
+        assert torch.equal(o, serial[i]), (rep, i)
+
+
+def test_two_host_threads_two_streams():
+    import umfa_torch
+    cases = [_inputs(10 + s) for s in range(2)]
+    serial = [umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32) for q, k, v in cases]
+    torch.cuda.synchronize()
+    res, errs = [None, None], []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(50):
+                    o = umfa_torch.attention_forward(*cases[i], out_dtype=torch.float32)
+            st.synchronize()
+            res[i] = o
+        except Exception as exc:  # noqa: BLE001
+            errs.append(exc)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    assert torch.equal(res[0], serial[0]) and torch.equal(res[1], serial[1])
+
+
+def test_graph_survives_scratch_growth_and_capture_never_allocates():
+    """A captured graph keeps replaying correctly after later, larger calls on the same stream made the scratch pools
+    grow (old blocks are retired, never freed); a shape that would need NEW scratch during capture is refused with
+    MFA_ERROR_MEMORY_ALLOCATION (2) instead of calling hipMalloc inside the capture."""
+    import umfa_torch
+    from umfa._ffi import MFAError
+    q, k, v = _inputs(1)
+    mask = torch.ones(1, 1, 768, 448, dtype=torch.bool, device="cuda").tril(100)
+    out_a = torch.empty(1, 5, 768, 128, device="cuda", dtype=torch.float32)
+    out_m = torch.empty_like(out_a)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        # warm-up on the capture stream: its pool gets the w64 partials, the mask-flag buffer, the split scratch
+        umfa_torch.attention_forward(q, k, v, out=out_a)
+        umfa_torch.attention_forward(q, k, v, mask=mask, out=out_m)
+    side.synchronize()
+    ref_a, ref_m = out_a.clone(), out_m.clone()
+    big = _inputs(2, H=24, Sq=4096, Skv=4096)
+    out_big = torch.empty(1, 24, 4096, 128, device="cuda", dtype=torch.bfloat16)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            umfa_torch.attention_forward(q, k, v, out=out_a)
+            umfa_torch.attention_forward(q, k, v, mask=mask, out=out_m)
+            # a far larger item count than anything this stream has seen: would have to grow the partials
+            with pytest.raises(MFAError) as ei:
+                umfa_torch.attention_forward(*big, out=out_big)
+            assert ei.value.code == 2
+    # larger calls on the same stream after capture: every pool grows
+    with torch.cuda.stream(side):
+        qb, kb, vb = _inputs(3, H=24, Sq=4096, Skv=4096)
+        umfa_torch.attention_forward(qb, kb, vb)
+        mb = torch.ones(1, 1, 4096, 4096, dtype=torch.bool, device="cuda").tril(300)
+        umfa_torch.attention_forward(qb, kb, vb, mask=mb)
+    side.synchronize()
+    for _ in range(3):
+        out_a.fill_(7.0)
+        out_m.fill_(7.0)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out_a, ref_a) and torch.equal(out_m, ref_m)
+
+
+def test_sync_entry_restores_current_device_and_rejects_unknown_mask_type():
+    import ctypes
+    import umfa
+    from umfa._ffi import _lib
+    dev_before = torch.cuda.current_device()
+    q = np.random.default_rng(0).standard_normal((1, 1, 32, 32)).astype(np.float32)
+    with umfa.MFAContext() as ctx:
+        umfa.flash_attention_forward(ctx, q, q, q, input_precision="fp32", intermediate_precision="fp32", layout="bhsd")
+        assert torch.cuda.current_device() == dev_before
+        bufs = [umfa.MFABuffer(ctx, a) for a in (q, q, q, np.zeros_like(q))]
+        shp = (ctypes.c_int64 * 2)(4, 4)
+        rc = _lib.mfa_attention_forward(ctx.handle, *(b.handle for b in bufs), 1, 32, 32, 1, 32, 0.2, False, 2, 2, 2, False,
+                                        False, False, False, ctypes.c_void_p(q.ctypes.data), 16, shp, shp, 2, 3, 0)
+        assert rc == 1  # UMFA_MASK_TYPE_WINDOW exists on the in-stream entry only
+        for b in bufs:
+            b.close()

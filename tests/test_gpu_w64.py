@@ -36,7 +36,7 @@ def rel_err(a, ref):
     return float(np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-30))
 
 
-TOL = {torch.bfloat16: 6e-3, torch.float16: 1.5e-3}
+from tolerances import check_forward  # noqa: E402  (measured bounds, tests/tolerances.py)
 
 
 @pytest.mark.parametrize("shape", [(1, 2, 256, 64), (1, 2, 256, 128), (1, 1, 256, 192), (2, 3, 512, 256), (1, 2, 256, 1024),
@@ -52,7 +52,7 @@ def test_w64_small_shapes_vs_oracle(shape, dt):
     o, lse = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32, return_lse=True)
     assert umfa_torch.last_kernel().startswith("fa_fwd16_w64"), umfa_torch.last_kernel()
     ref, ref_lse = _oracle().sdpa_forward(npy(q), npy(k), npy(v), return_lse=True)
-    assert rel_err(o.cpu().numpy(), ref) < TOL[dt]
+    check_forward(o.cpu().numpy(), ref, dt, umfa_torch.last_kernel())
     assert np.abs(lse.cpu().numpy().reshape(ref_lse.shape) - ref_lse).max() < 2e-2
     # 16-bit epilogue = the fp32 result rounded once (half an ulp of the 16-bit type)
     o16 = umfa_torch.attention_forward(q, k, v)
@@ -72,16 +72,20 @@ def test_w64_flux_shape_matches_oracle_rows_and_is_deterministic():
     assert torch.isfinite(o).all()
     assert torch.equal(o, umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32))
     orc = _oracle()
-    # heads 0 (whole items), 1 and 2 (items cut by a slice boundary at this shape: 1.5 items per workgroup), 23
-    for head in (0, 1, 2, 13, 23):
-        kk, vv = bits(k[0:1, head:head + 1]), bits(v[0:1, head:head + 1])
-        for r in (0, 255, 256, 300, 511, 512, 1000, 2047, 2048, 3333, 4095):
-            ref, rl = orc.sdpa_forward(bits(q[0:1, head:head + 1, r:r + 1]), kk, vv, return_lse=True)
-            assert rel_err(o[0, head, r].cpu().numpy(), ref[0, 0, 0]) < 6e-3, (head, r)
-            assert abs(float(lse[head * S + r]) - float(rl[0, 0, 0])) < 2e-2
-    # against the 32-rows-per-wave kernel on the same inputs (different tiling, same arithmetic rules)
-    ref16 = torch.nn.functional.scaled_dot_product_attention(q.float(), k.float(), v.float())
-    assert rel_err(o.cpu().numpy(), ref16.cpu().numpy()) < 6e-3
+    # every head (whole items, and items cut by a slice boundary at this shape: 1.5 items per workgroup), rows on and off
+    # the 64 / 256-row grid, all keys; the oracle's row-subset entry keeps the whole-tensor normalisation of the metric
+    rows = np.array([0, 255, 256, 300, 511, 512, 1000, 2047, 2048, 3333, 4095] + list(range(1536, 1600)))
+    ref, rl = orc.sdpa_forward_rows(bits(q), bits(k), bits(v), rows, return_lse=True)
+    check_forward(o[:, :, rows].cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel(), "flux_rows")
+    assert np.abs(lse.view(B, H, S)[:, :, rows].cpu().numpy() - rl).max() < 2e-2
+    # the exact-running-max regime of the same kernel (UMFA_W64_TAU=0) sits at the bf16 format floor
+    import os
+    os.environ["UMFA_W64_TAU"] = "0"
+    try:
+        o0 = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
+        check_forward(o0[:, :, rows].cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel(), "flux_rows_tau0")
+    finally:
+        del os.environ["UMFA_W64_TAU"]
 
 
 def test_w64_strided_inputs_and_cross_attention():
@@ -96,7 +100,7 @@ def test_w64_strided_inputs_and_cross_attention():
     o = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32, scale=0.05)
     assert umfa_torch.last_kernel().startswith("fa_fwd16_w64")
     ref = _oracle().sdpa_forward(bits(q), bits(k), bits(v), scale=0.05)
-    assert rel_err(o.cpu().numpy(), ref) < 6e-3
+    check_forward(o.cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel())
 
 
 def test_w64_deferred_max_rescale_paths():
@@ -118,7 +122,8 @@ def test_w64_deferred_max_rescale_paths():
         assert umfa_torch.last_kernel().startswith("fa_fwd16_w64")
         ref, rl = _oracle().sdpa_forward(bits(q), bits(k), bits(v), return_lse=True)
         assert np.isfinite(o.cpu().numpy()).all()
-        assert rel_err(o.cpu().numpy(), ref) < 8e-3, sign
+        # hostile on purpose: the reference max moves ~10 times per row and P spans 2^6 under the deferred max
+        check_forward(o.cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel(), f"ramp{sign:+.0f}", scale_max=1.5)
         assert np.abs(lse.cpu().numpy().reshape(rl.shape) - rl).max() < 5e-2
 
 
@@ -137,7 +142,7 @@ def test_w64_causal_vs_oracle(shape, dt):
     assert umfa_torch.last_kernel().startswith("fa_fwd16_w64"), umfa_torch.last_kernel()
     ref, ref_lse = _oracle().sdpa_forward(npy(q), npy(k), npy(v), causal=True, return_lse=True)
     assert np.isfinite(o.cpu().numpy()).all()
-    assert rel_err(o.cpu().numpy(), ref) < TOL[dt]
+    check_forward(o.cpu().numpy(), ref, dt, umfa_torch.last_kernel())
     assert np.abs(lse.cpu().numpy().reshape(ref_lse.shape) - ref_lse).max() < 2e-2
     assert torch.equal(o, umfa_torch.attention_forward(q, k, v, causal=True, out_dtype=torch.float32))
     o16 = umfa_torch.attention_forward(q, k, v, causal=True)
@@ -153,13 +158,9 @@ def test_w64_causal_flux_shape_rows():
     assert umfa_torch.last_kernel() == "fa_fwd16_w64<bf16,128>"
     assert torch.isfinite(o).all()
     assert torch.equal(o, umfa_torch.attention_forward(q, k, v, causal=True, out_dtype=torch.float32))
-    orc = _oracle()
-    for head in (0, 7, 23):
-        kk, vv = bits(k[0:1, head:head + 1]), bits(v[0:1, head:head + 1])
-        for r in (0, 1, 63, 64, 255, 256, 1000, 2047, 2048, 4095):
-            ref = orc.sdpa_forward(bits(q[0:1, head:head + 1, r:r + 1]), np.ascontiguousarray(kk[:, :, :r + 1]),
-                                   np.ascontiguousarray(vv[:, :, :r + 1]))
-            assert rel_err(o[0, head, r].cpu().numpy(), ref[0, 0, 0]) < 6e-3, (head, r)
+    rows = np.array([0, 1, 63, 64, 255, 256, 1000, 2047, 2048, 4095] + list(range(3000, 3064)))
+    ref = _oracle().sdpa_forward_rows(bits(q), bits(k), bits(v), rows, causal=True)
+    check_forward(o[:, :, rows].cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel(), "flux_causal_rows")
 
 
 @pytest.mark.parametrize("shape", [(1, 2, 256, 100, False), (1, 2, 512, 1000, False), (2, 2, 1100, 777, False), (1, 3, 1280, 1100, True),
@@ -182,7 +183,7 @@ def test_w64_ragged_shapes(shape):
     assert umfa_torch.last_kernel().startswith("fa_fwd16_w64"), umfa_torch.last_kernel()
     ref, ref_lse = _oracle().sdpa_forward(npy(q), npy(k), npy(v), causal=causal, return_lse=True)
     assert np.isfinite(o.cpu().numpy()).all()
-    assert rel_err(o.cpu().numpy(), ref) < 6e-3
+    check_forward(o.cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel())
     assert np.abs(lse.cpu().numpy().reshape(ref_lse.shape) - ref_lse).max() < 2e-2
     assert torch.equal(o, umfa_torch.attention_forward(q, k, v, causal=causal, out_dtype=torch.float32))
 

@@ -1,0 +1,77 @@
+"""Forward parity bounds of the 16-bit kernels, and the recorder that produced them.
+
+Metric: max = max|O - O_ref| / max|O_ref|, rms = rms(O - O_ref) / rms(O_ref), O_ref = the fp64
+CPU oracle on the already rounded inputs, fp32 O at the ABI.
+
+Where the numbers come from: every bound is the largest value any GPU test measured on MI355X
+(profiles/r2/parity_measured.json, written by running the suite with UMFA_PARITY_RECORD=<file>) plus 25 %.
+What fixes them (tools/err_probe.py, profiles/r2/error_anatomy.md):
+  * fp16: P is rounded to 11 significant bits before P V: max <= 5e-4 -- inside the north-star's 1e-3 at every shape.
+  * bf16: P is rounded to 8 significant bits; an IDEAL flash kernel (exact fp64 everything, P rounded once to bf16:
+    oracle.flash_format_floor) already sits at max 0.8e-3 (S = 256) ... 1.6e-3 (S >= 4096), rms 1.45 ... 1.6e-3.  The
+    kernels whose reference max is the exact running max (fa_fwd16; fa_fwd16_w64 with UMFA_W64_TAU=0) measure AT that
+    floor.  The north-star's 1e-3 is therefore met by bf16 only at short key ranges; the format, not the kernel, decides.
+  * bf16 / fp16 with the deferred max of fa_fwd16_w64 (tau = 6, +38 % speed at the FLUX shape): rms +7...10 %, and a tail
+    in max on rows with one dominant key -- with an exact reference max that key's P is exactly 1.0 and carries no
+    rounding error, with a stale reference it carries the ordinary half-ulp (measured up to 3.5e-3 bf16, 4.1e-4 fp16).
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+
+# (dtype name, deferred max?) -> (max bound, rms bound)
+BOUNDS = {
+    ("fp16", False): (5.0e-4, 2.6e-4),
+    ("fp16", True): (1.0e-3, 2.7e-4),   # north-star bound, asserted as such (measured <= 4.1e-4)
+    ("bf16", False): (2.0e-3, 2.1e-3),
+    ("bf16", True): (4.5e-3, 2.2e-3),
+}
+NORTH_STAR = 1.0e-3
+
+
+def _name(dt) -> str:
+    s = str(dt)
+    return "fp16" if "float16" in s and "bfloat16" not in s or s == "fp16" else "bf16" if "bf" in s else s
+
+
+def errors(o, ref):
+    o = np.asarray(o, np.float64)
+    ref = np.asarray(ref, np.float64)
+    d = o - ref
+    return (float(np.abs(d).max() / max(np.abs(ref).max(), 1e-30)),
+            float(np.sqrt((d * d).mean() / max((ref * ref).mean(), 1e-60))))
+
+
+def record(tag: str, **vals) -> None:
+    path = os.environ.get("UMFA_PARITY_RECORD")
+    if path:
+        with open(path, "a") as f:
+            f.write(json.dumps({"tag": tag, "test": os.environ.get("PYTEST_CURRENT_TEST", ""), **vals}) + "\n")
+
+
+# a 16-bit OUTPUT (fused cast-back epilogue) adds one rounding of O itself: at most half an ulp of the value (2^-8 of it
+# for bf16, 2^-11 for fp16) in max, about 0.41 of that in rms (uniform error, values log-uniform inside a binade)
+OUT_HALF_ULP = {"bf16": 2.0 ** -8, "fp16": 2.0 ** -11}
+
+
+def check_forward(o, ref, dt, kernel: str, tag: str = "", scale_max: float = 1.0, min_elems_for_rms: int = 4096,
+                  out_dt=None):
+    """Assert the forward parity bounds for one output against the oracle.  kernel: umfa_torch.last_kernel() /
+    ctx.last_kernel; scale_max loosens the max bound for deliberately hostile inputs (stated at the call site);
+    out_dt: the element type O was stored in when it is not fp32."""
+    name = _name(dt)
+    deferred = kernel.startswith("fa_fwd16_w64") and float(os.environ.get("UMFA_W64_TAU", "6") or 6) > 0
+    mx, rms = errors(o, ref)
+    bmax, brms = BOUNDS[(name, deferred)]
+    if out_dt is not None and _name(out_dt) in OUT_HALF_ULP:
+        h = OUT_HALF_ULP[_name(out_dt)]
+        bmax, brms = bmax + h, float(np.hypot(brms, 0.45 * h))
+    record(tag or kernel, dtype=name, kernel=kernel, deferred=deferred, out=_name(out_dt) if out_dt is not None else "fp32",
+           max=mx, rms=rms, bound_max=bmax * scale_max, bound_rms=brms * scale_max, n=int(np.asarray(ref).size))
+    assert mx < bmax * scale_max, (tag, kernel, "max", mx, bmax * scale_max)
+    if np.asarray(ref).size >= min_elems_for_rms:
+        assert rms < brms * scale_max, (tag, kernel, "rms", rms, brms * scale_max)
+    return mx, rms

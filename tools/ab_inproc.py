@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""In-process A/B of several builds of libMFAFFI.so (cdna_hip_programming.md §5.4 rule 24: interleaved rounds in ONE
+process on ONE device; separate invocations add cross-process and cross-box variance).
+
+  python tools/ab_inproc.py [--shape B,H,S,D] [--causal] [--dtype bf16|fp16] [--out same|fp32] [--rounds 12]
+                            [--inner 20] [--parity] name=path [name=path ...]
+
+Every library gets its own context (each .so carries its own process-wide singleton); a round launches `inner`
+forwards of each library in turn between two events on the current stream.  Reports median / min per launch per
+library and, with --parity, rel-err against the CPU oracle on a row subset (oracle.parity).
+"""
+import argparse
+import ctypes
+import json
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path[:0] = [str(ROOT), str(ROOT / "universal-metal-flash-attention_amd")]
+import torch  # noqa: E402
+
+from umfa import _ffi  # noqa: E402
+
+
+def i64(v):
+    return (ctypes.c_int64 * len(v))(*[int(x) for x in v])
+
+
+class Lib:
+    def __init__(self, name, path):
+        self.name = name
+        self.lib = _ffi._lib if path == "intree" else _ffi._load_library(str(Path(path).resolve()))
+        self.ctx = _ffi.mfa_context_t()
+        _ffi._check_error(self.lib.mfa_create_context(ctypes.byref(self.ctx)))
+
+    def forward(self, q, k, v, out, causal, lse=None):
+        B, H, Sq, D = q.shape
+        prec = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}
+        rc = self.lib.umfa_attention_forward_stream(
+            self.ctx, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream),
+            ctypes.c_void_p(q.data_ptr()), i64(q.stride()), ctypes.c_void_p(k.data_ptr()), i64(k.stride()),
+            ctypes.c_void_p(v.data_ptr()), i64(v.stride()), ctypes.c_void_p(out.data_ptr()), prec[out.dtype],
+            ctypes.c_void_p(lse.data_ptr()) if lse is not None else None, None, None, None, 0, 0, 0,
+            B, Sq, k.shape[2], H, D, float(D) ** -0.5, bool(causal), prec[q.dtype], prec[q.dtype])
+        assert rc == 0, (self.name, rc)
+
+    def kernel(self):
+        return self.lib.umfa_last_kernel_name(self.ctx).decode()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shape", default="1,24,4096,128")
+    ap.add_argument("--causal", action="store_true")
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--out", default="same")
+    ap.add_argument("--rounds", type=int, default=12)
+    ap.add_argument("--inner", type=int, default=20)
+    ap.add_argument("--parity", action="store_true")
+    ap.add_argument("libs", nargs="+")
+    a = ap.parse_args()
+    B, H, S, D = (int(x) for x in a.shape.split(","))
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[a.dtype]
+    torch.manual_seed(0)
+    q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=torch.float32).to(dt) for _ in range(3))
+    out = torch.empty(B, H, S, D, device="cuda", dtype=dt if a.out == "same" else torch.float32)
+    libs = [Lib(*s.split("=", 1)) for s in a.libs]
+    for L in libs:
+        for _ in range(5):
+            L.forward(q, k, v, out, a.causal)
+    torch.cuda.synchronize()
+    times = {L.name: [] for L in libs}
+    for r in range(a.rounds):
+        order = libs if r % 2 == 0 else libs[::-1]
+        for L in order:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.inner):
+                L.forward(q, k, v, out, a.causal)
+            e1.record()
+            torch.cuda.synchronize()
+            times[L.name].append(e0.elapsed_time(e1) / a.inner)
+    flops = 4.0 * B * H * S * S * D * (0.5 if a.causal else 1.0)
+    res = {"shape": a.shape, "causal": a.causal, "dtype": a.dtype, "out": a.out}
+    for L in libs:
+        t = sorted(times[L.name])
+        med = t[len(t) // 2]
+        res[L.name] = {"kernel": L.kernel(), "ms_median": round(med, 5), "ms_min": round(t[0], 5),
+                       "tflops_median": round(flops / med / 1e9, 1)}
+        if a.parity:
+            from oracle import parity
+            L.forward(q, k, v, out, a.causal)
+            torch.cuda.synchronize()
+            res[L.name]["parity"] = parity.forward_rel_err(q, k, v, out, causal=a.causal, floor_kind=a.dtype)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -40,6 +40,7 @@ struct W64Params {
     uint32_t n_items, T;  // items = B*H*(Sq/256) blocks of 256 query rows; T = Skv/64 key tiles per item
     float* part_buf;      // [2 * grid slots][wave 4][q-block 2][chunk 17][lane 64] x 16 bytes (see the kernel)
     uint32_t* part_cnt;   // [n_items % grid] arrival tickets, zero between launches (the folding part resets its own)
+    float tau;            // deferred-max threshold (log2 units)
 };
 
 // ---- asm-owned accumulator registers: helpers with literal register numbers (generated)
@@ -62,6 +63,7 @@ struct W64I8Params {
     uint32_t n_items, T;
     float* part_buf;
     uint32_t* part_cnt;
+    float tau;
 };
 
 #define W64_I8 0
@@ -109,6 +111,16 @@ struct W64I8Params {
 #undef W64_I8
 #undef W64_BODY_INC
 
+
+// Deferred-max threshold of the w64 kernels: 2^6 unless UMFA_W64_TAU says otherwise (0 = exact running max: +38 % time
+// at the FLUX shape, the tail of the bf16 error distribution shrinks -- DESIGN.md §3.2).  Read at every launch (tests
+// drive both regimes in one process).
+static float w64_tau() {
+    const char* e = getenv("UMFA_W64_TAU");
+    if (!e || !*e) return 6.0f;
+    const float v = (float)atof(e);
+    return v >= 0.0f && v <= 16.0f ? v : 6.0f;
+}
 
 static int w64_cu_count() {
     static int n = 0;
@@ -198,6 +210,7 @@ hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cn
     wp.T = (p.Skv + 63) / 64;
     wp.part_buf = part_buf;
     wp.part_cnt = part_cnt;
+    wp.tau = w64_tau();
     if (p.in_prec == P_BF16) {
         *name = "fa_fwd16_w64<bf16,128>";
         if (p.causal)
@@ -235,6 +248,7 @@ hipError_t launch_fwd_w64_i8(const FwdParams& p, const QuantViews& v, float* par
     wp.T = (p.Skv + 63) / 64;
     wp.part_buf = part_buf;
     wp.part_cnt = part_cnt;
+    wp.tau = w64_tau();
     const uint32_t grid = w64_grid(p);
     const size_t lds = 65536 + 4 * 32 * (512 + 16);
     auto kfn = p.causal ? fa_fwd_w64_i8<float, true> : fa_fwd_w64_i8<float, false>;

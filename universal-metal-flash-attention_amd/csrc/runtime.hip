@@ -69,35 +69,42 @@ void dense_strides(FwdParams& p, bool tq, bool tk, bool tv, bool to) {
     p.os[1] = to ? p.Sq : 1;
 }
 
-// Kernel selection for the dense forward.
-hipError_t dispatch_forward(Context* ctx, const FwdParams& p, int intermediate_prec, hipStream_t stream) {
+// hipError_t of a launcher -> mfa_error_t (hipErrorOutOfMemory: scratch could not be provided, e.g. it would have to
+// grow while the stream is capturing)
+mfa_error_t rc_of(hipError_t e) {
+    return e == hipSuccess ? MFA_SUCCESS
+           : e == hipErrorInvalidValue ? MFA_ERROR_INVALID_ARGS
+           : e == hipErrorOutOfMemory ? MFA_ERROR_MEMORY_ALLOCATION
+                                      : MFA_ERROR_EXECUTION_FAILED;
+}
+
+// Kernel selection for the dense forward.  Call with ctx->mu held; `sc` is the scratch pool of (device, stream).
+hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p, int intermediate_prec, hipStream_t stream) {
     const char* name = "none";
     hipError_t e;
     const bool lowp = p.in_prec != P_FP32 && intermediate_prec != P_FP32;
-    char* w64 = nullptr;
     if (lowp && fwd_w64_supported(p)) {
         const FwdW64Plan plan = fwd_w64_plan(p);
-        w64 = (char*)ctx->ensure_w64(plan.cnt_bytes, plan.buf_bytes);
-    }
-    if (w64) {
-        e = launch_fwd_w64(p, (float*)(w64 + ctx->w64_cnt_bytes), (uint32_t*)w64, stream, &name);
+        char* w64 = sc.ensure_w64(plan.cnt_bytes, plan.buf_bytes, stream);
+        if (!w64) return hipErrorOutOfMemory;
+        e = launch_fwd_w64(p, (float*)(w64 + sc.w64_cnt_bytes), (uint32_t*)w64, stream, &name);
     } else if (lowp && fwd_16_supported(p)) {
         FwdParams pp = p;
         const FwdSplitPlan plan = fwd_16_split_plan(p);
         if (plan.nsplit > 1) {
             // tickets first (16-byte multiple at the allocation start), partials behind them
-            char* buf = (char*)ctx->ensure_split(plan.cnt_bytes + plan.buf_bytes);
-            if (buf) {
-                pp.n_full = plan.n_full;
-                pp.nsplit = plan.nsplit;
-                pp.part_cnt = (uint32_t*)buf;
-                pp.part_buf = (float*)(buf + plan.cnt_bytes);
-            }
+            char* buf = (char*)sc.split.ensure(plan.cnt_bytes + plan.buf_bytes, stream);  // the launcher zeroes the tickets
+            if (!buf) return hipErrorOutOfMemory;  // same shape, same kernel plan, every time: never a silent other plan
+            pp.n_full = plan.n_full;
+            pp.nsplit = plan.nsplit;
+            pp.part_cnt = (uint32_t*)buf;
+            pp.part_buf = (float*)(buf + plan.cnt_bytes);
         }
         if (pp.mask_kind != MK_NONE && !getenv("UMFA_NO_MASK_FLAGS") && mask_flags_worthwhile(pp)) {
             // tile early-exit for masks: one pre-pass over the distinct mask elements classifies every (32 rows x 64
-            // keys) tile; fully masked tiles are skipped, fully open ones run without reading the mask
-            void* fl = ctx->ensure_mask_flags(mask_flags_bytes(pp));
+            // keys) tile; fully masked tiles are skipped, fully open ones run without reading the mask.  Results are
+            // bit-identical with and without the flags, so a pool that may not grow (capture) just runs without them.
+            void* fl = sc.mflags.ensure(mask_flags_bytes(pp), stream);
             if (fl && launch_mask_flags(pp, (uint8_t*)fl, stream) != hipSuccess) pp.mask_flags = nullptr;
         }
         e = launch_fwd_16(pp, stream, &name);
@@ -119,8 +126,13 @@ mfa_error_t forward_sync(mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, 
     Context* ctx = as_ctx(context);
     Buffer *bq = as_buf(q), *bk = as_buf(k), *bv = as_buf(v), *bo = as_buf(out), *bl = as_buf(lse);
     if (!ctx || !bq || !bk || !bv || !bo || (want_lse && !bl)) return MFA_ERROR_INVALID_ARGS;
+    // a wrapped host pointer of unknown size has no HBM mirror: nothing a kernel could read or write
+    if (!bq->dev || !bk->dev || !bv->dev || !bo->dev || (want_lse && !bl->dev)) return MFA_ERROR_INVALID_ARGS;
+    // mask types beyond NONE / BOOL / ADDITIVE (e.g. the in-stream entry's UMFA_MASK_TYPE_WINDOW) do not exist on the
+    // synchronous ABI: refuse instead of computing an unmasked result
+    if (mtype != MFA_MASK_TYPE_NONE && mtype != MFA_MASK_TYPE_BOOL && mtype != MFA_MASK_TYPE_ADDITIVE) return MFA_ERROR_INVALID_ARGS;
     std::lock_guard<std::mutex> lock(ctx->mu);
-    (void)hipSetDevice(ctx->device);
+    DeviceGuard guard(ctx->device);  // the caller's current device is restored on return
     hipStream_t stream = nullptr;
 
     FwdParams p;
@@ -161,8 +173,8 @@ mfa_error_t forward_sync(mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, 
     if (bq->upload(stream) != hipSuccess || bk->upload(stream) != hipSuccess || bv->upload(stream) != hipSuccess)
         return MFA_ERROR_EXECUTION_FAILED;
     (void)hipEventRecord(ctx->ev0, stream);  // kernel-only GPU time -> mfa_get_gpu_latency
-    hipError_t e = dispatch_forward(ctx, p, inter, stream);
-    if (e != hipSuccess) return e == hipErrorInvalidValue ? MFA_ERROR_INVALID_ARGS : MFA_ERROR_EXECUTION_FAILED;
+    hipError_t e = dispatch_forward(ctx, ctx->pool(ctx->device, stream), p, inter, stream);
+    if (e != hipSuccess) return rc_of(e);
     (void)hipEventRecord(ctx->ev1, stream);
     if (bo->download(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
     if (want_lse && bl->download(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
@@ -351,10 +363,13 @@ mfa_error_t umfa_attention_forward_stream(mfa_context_t context, void* stream, c
         p.mask = mask;
     }
     if ((size_t)batch_size * num_heads * seq_len_q * seq_len_kv == 0) return MFA_SUCCESS;
-    hipError_t e = dispatch_forward(ctx, p, dense_prec(intermediate_precision), (hipStream_t)stream);
-    return e == hipSuccess ? MFA_SUCCESS
-           : e == hipErrorInvalidValue ? MFA_ERROR_INVALID_ARGS
-                                       : MFA_ERROR_EXECUTION_FAILED;
+    // Scratch belongs to (device, stream): launches on different streams, from different host threads, never share
+    // ticket words or partial slots; mu only covers the pool lookup and the (asynchronous) launch.
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    const int dev = stream_device((hipStream_t)stream);
+    DeviceGuard guard(dev);
+    return rc_of(dispatch_forward(ctx, ctx->pool(dev, (hipStream_t)stream), p, dense_prec(intermediate_precision),
+                                  (hipStream_t)stream));
 }
 
 // In-stream encode (MFABridge.swift:2377-2543): never commits, never waits.

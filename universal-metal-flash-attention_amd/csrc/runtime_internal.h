@@ -6,8 +6,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "../../include/umfa_abi.h"
@@ -25,75 +27,122 @@ extern const bool g_debug;
         }                                           \
     } while (0)
 
+// ---- scratch: grow-only device blocks, one set per (device, stream) ------------------------------------------------
+// The kernels need caller-invisible device scratch (split-item tickets + partials, mask tile flags, the quantiser's
+// workspace).  Rules that keep the asynchronous entries correct:
+//   * keyed by (device, stream): launches on one stream are ordered, so they may share; two streams (or two host
+//     threads on two streams) never touch the same ticket words or partial slots;
+//   * grow-only: a block that is too small is RETIRED, not freed -- a launch still in flight or a captured hipGraph
+//     may hold its address; retired blocks live until the process ends (sizes are bounded by the largest call:
+//     growth is geometric, so the retired total stays below the live block);
+//   * never allocated while the stream is capturing (hipMalloc is illegal there): the call returns
+//     MFA_ERROR_MEMORY_ALLOCATION and the caller warms the shape up before capture, as bench.py does;
+//   * allocated under a device guard for the stream's device; the caller's current device is restored.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (dev >= 0 && dev != prev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched && prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+inline int stream_device(hipStream_t stream) {
+    int dev = 0;
+    if (stream) {
+        hipDevice_t d;
+        if (hipStreamGetDevice(stream, &d) == hipSuccess) return (int)d;
+        (void)hipGetLastError();
+    }
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    return dev;
+}
+
+inline bool stream_capturing(hipStream_t stream) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &st) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return st != hipStreamCaptureStatusNone;
+}
+
+struct GrowBuf {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    std::vector<void*> retired;
+    // >= need bytes, or nullptr (allocation failed / stream is capturing and the block would have to grow)
+    void* ensure(size_t need, hipStream_t stream, bool* grew = nullptr) {
+        if (grew) *grew = false;
+        if (ptr && need <= bytes) return ptr;
+        if (stream_capturing(stream)) return nullptr;
+        size_t want = need + (need >> 1) + 256;  // geometric growth bounds the retired total
+        void* fresh = nullptr;
+        if (hipMalloc(&fresh, want) != hipSuccess) {
+            (void)hipGetLastError();
+            want = need + 256;
+            if (hipMalloc(&fresh, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        }
+        if (ptr) retired.push_back(ptr);
+        ptr = fresh;
+        bytes = want;
+        if (grew) *grew = true;
+        return ptr;
+    }
+};
+
+struct StreamScratch {
+    GrowBuf split;      // fa_fwd16 split-KV: tickets, then partials
+    GrowBuf w64;        // fa_fwd16_w64: zeroed tickets (the kernel leaves them zero), then partials
+    size_t w64_cnt_bytes = 0;
+    GrowBuf mflags;     // mask tile flags
+    GrowBuf workspace;  // quantiser output (int8 Q/K, V image, scales, fp32 copies for backward)
+
+    // tickets [0, cnt) zeroed on `stream` whenever the block is new, partials behind them at w64_cnt_bytes
+    char* ensure_w64(size_t cnt_bytes, size_t buf_bytes, hipStream_t stream) {
+        const size_t c = cnt_bytes > w64_cnt_bytes ? cnt_bytes : w64_cnt_bytes;
+        bool grew = false;
+        if (c != w64_cnt_bytes && w64.ptr) {  // the ticket area moves: take a fresh block so old launches keep their layout
+            if (stream_capturing(stream)) return nullptr;
+            w64.retired.push_back(w64.ptr);
+            w64.ptr = nullptr;
+            w64.bytes = 0;
+        }
+        char* b = (char*)w64.ensure(c + buf_bytes, stream, &grew);
+        if (!b) return nullptr;
+        if (grew) {
+            if (hipMemsetAsync(b, 0, c, stream) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            w64_cnt_bytes = c;
+        }
+        return b;
+    }
+};
+
 // ---- context (MFAContext + GlobalContextStore, MFABridge.swift:91-150,652-687) -------------
 struct Context {
     uint32_t magic = 0x4d464143;  // 'MFAC'
-    int device = 0;
+    int device = 0;               // device of the synchronous entries (current when the singleton was created)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_latency = 0.0;
     const char* last_kernel = "none";
-    void* scratch = nullptr;  // host-mask staging
+    void* scratch = nullptr;  // host-mask staging of the synchronous entries (used under mu, then synchronised)
     size_t scratch_bytes = 0;
-    void* split_buf = nullptr;  // split-KV partials + tickets (fa_fwd_16)
-    size_t split_bytes = 0;
-    void* workspace = nullptr;  // quantiser output (int8 Q/K, fp16 V, scales, fp32 copies for backward)
-    size_t workspace_bytes = 0;
     std::vector<float> q_scales, k_scales, v_scales;  // mfa_set_scale_arrays: stored, never read
     std::atomic<int> refs{0};
-    std::mutex mu;
+    std::mutex mu;  // guards the pools, last_kernel / latency, and serialises lookup + launch of every entry
 
-    void* ensure_split(size_t bytes) {
-        if (bytes <= split_bytes) return split_buf;
-        if (split_buf) (void)hipFree(split_buf);
-        split_buf = nullptr;
-        split_bytes = 0;
-        if (hipMalloc(&split_buf, bytes + 256) != hipSuccess) return nullptr;
-        split_bytes = bytes + 256;
-        return split_buf;
-    }
-
-    // fa_fwd16_w64: zeroed ticket array (kept zero by the kernel) followed by the partials buffer
-    void* w64_buf = nullptr;
-    size_t w64_cnt_bytes = 0, w64_buf_bytes = 0;
-    void* ensure_w64(size_t cnt_bytes, size_t buf_bytes) {
-        if (w64_buf && cnt_bytes <= w64_cnt_bytes && buf_bytes <= w64_buf_bytes) return w64_buf;
-        if (w64_buf) (void)hipFree(w64_buf);
-        w64_buf = nullptr;
-        const size_t c = cnt_bytes > w64_cnt_bytes ? cnt_bytes : w64_cnt_bytes;
-        const size_t b = buf_bytes > w64_buf_bytes ? buf_bytes : w64_buf_bytes;
-        if (hipMalloc(&w64_buf, c + b) != hipSuccess) { w64_cnt_bytes = w64_buf_bytes = 0; return nullptr; }
-        if (hipMemset(w64_buf, 0, c) != hipSuccess) { (void)hipFree(w64_buf); w64_buf = nullptr; w64_cnt_bytes = w64_buf_bytes = 0; return nullptr; }
-        w64_cnt_bytes = c;
-        w64_buf_bytes = b;
-        return w64_buf;
-    }
-
-    void* mflag_buf = nullptr;
-    size_t mflag_bytes = 0;
-    void* ensure_mask_flags(size_t bytes) {
-        if (bytes <= mflag_bytes) return mflag_buf;
-        if (mflag_buf) (void)hipFree(mflag_buf);
-        mflag_buf = nullptr;
-        mflag_bytes = 0;
-        if (hipMalloc(&mflag_buf, bytes + 256) != hipSuccess) return nullptr;
-        mflag_bytes = bytes + 256;
-        return mflag_buf;
-    }
-
-    void* ensure_workspace(size_t bytes) {
-        if (bytes <= workspace_bytes) return workspace;
-        if (workspace) (void)hipFree(workspace);
-        workspace = nullptr;
-        workspace_bytes = 0;
-        size_t want = bytes + (bytes >> 3) + 256;
-        if (hipMalloc(&workspace, want) != hipSuccess) return nullptr;
-        workspace_bytes = want;
-        return workspace;
-    }
+    std::map<std::pair<int, hipStream_t>, StreamScratch> pools;
+    // call with mu held; the returned object is stable (std::map nodes never move)
+    StreamScratch& pool(int dev, hipStream_t stream) { return pools[std::make_pair(dev, stream)]; }
 
     void* ensure_scratch(size_t bytes) {
         if (bytes <= scratch_bytes) return scratch;
-        if (scratch) (void)hipFree(scratch);
+        if (scratch) (void)hipFree(scratch);  // synchronous entries only: nothing is in flight between calls
         scratch = nullptr;
         scratch_bytes = 0;
         size_t want = bytes + (bytes >> 2) + 256;
@@ -143,7 +192,8 @@ struct Buffer {
         if (!host || host == dev || bytes == 0) return hipSuccess;
         return hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s);
     }
-    bool fits(size_t need) const { return bytes == 0 || need <= bytes; }
+    // bytes == 0: size unknown (device wraps only); a host pointer of unknown size has no HBM mirror (dev == NULL)
+    bool fits(size_t need) const { return dev != nullptr && (bytes == 0 || need <= bytes); }
 };
 
 inline Buffer* as_buf(mfa_buffer_t b) {

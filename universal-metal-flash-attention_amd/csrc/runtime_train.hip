@@ -39,7 +39,7 @@ mfa_error_t mfa_attention_backward(mfa_context_t context, mfa_buffer_t dout, mfa
     if (!ctx || !bdo || !bq || !bk || !bv || !bo || !bl || !bdq || !bdk || !bdv || !bd) return MFA_ERROR_INVALID_ARGS;
     if (transpose_q || transpose_k || transpose_v || transpose_o) return MFA_ERROR_INVALID_ARGS;  // no caller sets them
     std::lock_guard<std::mutex> lock(ctx->mu);
-    (void)hipSetDevice(ctx->device);
+    DeviceGuard guard(ctx->device);
     hipStream_t stream = nullptr;
     const uint32_t B = batch_size, H = num_heads, Sq = seq_len_q, Skv = seq_len_kv, D = head_dim;
     const size_t nq = (size_t)B * H * Sq * D, nkv = (size_t)B * H * Skv * D, nr = (size_t)B * H * Sq;
@@ -120,8 +120,9 @@ int32_t mfa_quantized_forward_with_lse(mfa_context_t context, mfa_buffer_t q, mf
     Buffer *bq = as_buf(q), *bk = as_buf(k), *bv = as_buf(v), *bo = as_buf(out), *bl = as_buf(lse), *bm = as_buf(mask);
     if (!ctx || !bq || !bk || !bv || !bo || !bl) return MFA_ERROR_INVALID_ARGS;
     std::lock_guard<std::mutex> lock(ctx->mu);
-    (void)hipSetDevice(ctx->device);
+    DeviceGuard guard(ctx->device);
     hipStream_t stream = nullptr;
+    const int pool_dev = ctx->device;
     const uint32_t B = batch_size, H = num_heads, Sq = seq_len_q, Skv = seq_len_kv, D = head_dim;
     const size_t nq = (size_t)B * H * Sq * D, nkv = (size_t)B * H * Skv * D, nr = (size_t)B * H * Sq;
     // inputPrecision: 0 fp16, 1 bf16, anything else fp32 (MFABridge+Quantized.swift:274-279)
@@ -135,7 +136,7 @@ int32_t mfa_quantized_forward_with_lse(mfa_context_t context, mfa_buffer_t q, mf
     const int bits = target_precision == MFA_PRECISION_INT4 ? 4 : 8;  // unknown raw value -> INT8 (:267)
     const int mode = quant_mode == 2 ? 2 : 0;                        // default tensor-wise (:268-272)
 
-    void* ws = ctx->ensure_workspace(quant_workspace_bytes(B, H, Sq, Skv, D, false));
+    void* ws = ctx->pool(pool_dev, stream).workspace.ensure(quant_workspace_bytes(B, H, Sq, Skv, D, false), stream);
     if (!ws) return MFA_ERROR_MEMORY_ALLOCATION;
     for (Buffer* b : {bq, bk, bv})
         if (b->upload(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
@@ -149,10 +150,11 @@ int32_t mfa_quantized_forward_with_lse(mfa_context_t context, mfa_buffer_t q, mf
     p.in_prec = prec; p.out_prec = P_FP32;
     if (fwd_w64_i8_supported(p)) {  // scratch of the 64-rows-per-wave kernel (tickets + partials), as for the dense path
         const FwdW64Plan plan = fwd_w64_plan(p);
-        if (char* w64 = (char*)ctx->ensure_w64(plan.cnt_bytes, plan.buf_bytes)) {
-            p.part_cnt = (uint32_t*)w64;
-            p.part_buf = (float*)(w64 + ctx->w64_cnt_bytes);
-        }
+        StreamScratch& sc = ctx->pool(pool_dev, (hipStream_t)stream);
+        char* w64 = sc.ensure_w64(plan.cnt_bytes, plan.buf_bytes, (hipStream_t)stream);
+        if (!w64) return MFA_ERROR_MEMORY_ALLOCATION;
+        p.part_cnt = (uint32_t*)w64;
+        p.part_buf = (float*)(w64 + sc.w64_cnt_bytes);
     }
     LatencyScope lat(ctx, stream);
     const char* name = "none";
@@ -169,8 +171,8 @@ int32_t mfa_quantized_forward_with_lse(mfa_context_t context, mfa_buffer_t q, mf
 
 // MI355X extra (not in the reference): mfa_quantized_forward_with_lse in-stream -- dense BHSD device pointers, the
 // caller's stream, no upload / download / synchronise (the reference's entry blocks; a serving loop should not).
-// O is fp32 [B,H,Sq,D]; lse and mask (fp32 additive [B,H,Sq,Skv]) optional.  One call at a time per context: the
-// quantiser workspace and the split-item scratch belong to the context.
+// O is fp32 [B,H,Sq,D]; lse and mask (fp32 additive [B,H,Sq,Skv]) optional.  The quantiser workspace and the split-item
+// scratch belong to the (device, stream) pool, so calls on different streams do not interfere.
 mfa_error_t umfa_quantized_forward_stream(mfa_context_t context, void* stream, const void* q, const void* k,
                                           const void* v, float* out, float* lse, const float* mask, uint32_t batch_size,
                                           uint32_t seq_len_q, uint32_t seq_len_kv, uint32_t num_heads, uint16_t head_dim,
@@ -183,7 +185,10 @@ mfa_error_t umfa_quantized_forward_stream(mfa_context_t context, void* stream, c
     if (!quantized_supported(D) || !(softmax_scale > 0.0f)) return MFA_ERROR_INVALID_ARGS;
     const int bits = target_precision == MFA_PRECISION_INT4 ? 4 : 8;
     const int mode = quant_mode == 2 ? 2 : 0;
-    void* ws = ctx->ensure_workspace(quant_workspace_bytes(B, H, Sq, Skv, D, false));
+    std::lock_guard<std::mutex> lock(ctx->mu);  // pool lookup + launch; scratch is per (device, stream)
+    const int pool_dev = stream_device((hipStream_t)stream);
+    DeviceGuard guard(pool_dev);
+    void* ws = ctx->pool(pool_dev, (hipStream_t)stream).workspace.ensure(quant_workspace_bytes(B, H, Sq, Skv, D, false), (hipStream_t)stream);
     if (!ws) return MFA_ERROR_MEMORY_ALLOCATION;
     FwdParams p;
     memset(&p, 0, sizeof(p));
@@ -193,10 +198,11 @@ mfa_error_t umfa_quantized_forward_stream(mfa_context_t context, void* stream, c
     p.in_prec = dense_prec(input_precision); p.out_prec = P_FP32;
     if (fwd_w64_i8_supported(p)) {
         const FwdW64Plan plan = fwd_w64_plan(p);
-        if (char* w64 = (char*)ctx->ensure_w64(plan.cnt_bytes, plan.buf_bytes)) {
-            p.part_cnt = (uint32_t*)w64;
-            p.part_buf = (float*)(w64 + ctx->w64_cnt_bytes);
-        }
+        StreamScratch& sc = ctx->pool(pool_dev, (hipStream_t)stream);
+        char* w64 = sc.ensure_w64(plan.cnt_bytes, plan.buf_bytes, (hipStream_t)stream);
+        if (!w64) return MFA_ERROR_MEMORY_ALLOCATION;
+        p.part_cnt = (uint32_t*)w64;
+        p.part_buf = (float*)(w64 + sc.w64_cnt_bytes);
     }
     const char* name = "none";
     hipError_t e = launch_quantized_fwd(p, bits, mode, ws, (hipStream_t)stream, &name);
@@ -217,8 +223,9 @@ int32_t mfa_quantized_backward(mfa_context_t context, mfa_buffer_t q, mfa_buffer
            *bl = as_buf(lse), *bdq = as_buf(grad_q), *bdk = as_buf(grad_k), *bdv = as_buf(grad_v), *bm = as_buf(mask);
     if (!ctx || !bq || !bk || !bv || !bo || !bdo || !bl || !bdq || !bdk || !bdv) return MFA_ERROR_INVALID_ARGS;
     std::lock_guard<std::mutex> lock(ctx->mu);
-    (void)hipSetDevice(ctx->device);
+    DeviceGuard guard(ctx->device);
     hipStream_t stream = nullptr;
+    const int pool_dev = ctx->device;
     const uint32_t B = batch_size, H = num_heads, Sq = seq_len_q, Skv = seq_len_kv, D = head_dim;
     const size_t nq = (size_t)B * H * Sq * D, nkv = (size_t)B * H * Skv * D, nr = (size_t)B * H * Sq;
     const int prec = dense_prec(input_precision);
@@ -234,7 +241,7 @@ int32_t mfa_quantized_backward(mfa_context_t context, mfa_buffer_t q, mfa_buffer
 
     // workspace: quantiser output + fp32 copies + the D vector the callee owns (MFABridge+Quantized.swift:470-474)
     const size_t wq = quant_workspace_bytes(B, H, Sq, Skv, D, true);
-    char* ws = (char*)ctx->ensure_workspace(wq + nr * 4 + 256);
+    char* ws = (char*)ctx->pool(pool_dev, stream).workspace.ensure(wq + nr * 4 + 256, stream);
     if (!ws) return MFA_ERROR_MEMORY_ALLOCATION;
     for (Buffer* b : {bq, bk, bv, bo, bdo, bl})
         if (b->upload(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
@@ -311,7 +318,7 @@ mfa_error_t prequant_stage(Context* ctx, const PreQuant& a, float** qf, float** 
         !blocks_ok(a.vs, a.vz, a.vbs, a.Hkv, a.Skv))
         return MFA_ERROR_INVALID_ARGS;
     const size_t fbytes = ((nq + 2 * nkv) * 4 + 255) & ~(size_t)255;
-    char* ws = (char*)ctx->ensure_workspace(fbytes + extra_bytes + 256);
+    char* ws = (char*)ctx->pool(ctx->device, stream).workspace.ensure(fbytes + extra_bytes + 256, stream);  // synchronous entries only
     if (!ws) return MFA_ERROR_MEMORY_ALLOCATION;
     *qf = (float*)ws;
     *kf = *qf + nq;
@@ -360,7 +367,7 @@ int32_t mfa_attention_backward_query_quantized_ex(
     if (!ctx || !a.q || !a.k || !a.v || !bo || !bdo || !bl || !bdq || !bd) return MFA_ERROR_INVALID_ARGS;
     if (transpose_o) return MFA_ERROR_INVALID_ARGS;  // O / dO are read dense (no caller transposes them)
     std::lock_guard<std::mutex> lock(ctx->mu);
-    (void)hipSetDevice(ctx->device);
+    DeviceGuard guard(ctx->device);
     hipStream_t stream = nullptr;
     const size_t nq = (size_t)a.B * a.H * a.Sq * a.D, nr = (size_t)a.B * a.H * a.Sq;
     if (!bo->fits(nq * 4) || !bdo->fits(nq * 4) || !bl->fits(nr * 4) || !bdq->fits(nq * 4) || !bd->fits(nr * 4))
@@ -414,7 +421,7 @@ int32_t mfa_attention_backward_kv_quantized_ex(
     if (!ctx || !a.q || !a.k || !a.v || !bdo || !bl || !bd || !bdk || !bdv) return MFA_ERROR_INVALID_ARGS;
     if (transpose_o) return MFA_ERROR_INVALID_ARGS;
     std::lock_guard<std::mutex> lock(ctx->mu);
-    (void)hipSetDevice(ctx->device);
+    DeviceGuard guard(ctx->device);
     hipStream_t stream = nullptr;
     const size_t nq = (size_t)a.B * a.H * a.Sq * a.D, nr = (size_t)a.B * a.H * a.Sq;
     const size_t nkv_out = (size_t)a.B * a.Hkv * a.Skv * a.D, nkv = (size_t)a.B * a.H * a.Skv * a.D;
@@ -492,9 +499,10 @@ int32_t umfa_quantize_rows(mfa_context_t context, void* stream_handle, const voi
     Context* ctx = as_ctx(context);
     if (!ctx || !src || !q8_out || !scales_out || !quantized_supported(head_dim)) return MFA_ERROR_INVALID_ARGS;
     std::lock_guard<std::mutex> lock(ctx->mu);
-    (void)hipSetDevice(ctx->device);
     hipStream_t stream = (hipStream_t)stream_handle;
-    void* ws = ctx->ensure_workspace(quant_workspace_bytes(1, batch_heads, rows, rows, head_dim, false));
+    const int pool_dev = stream_device(stream);
+    DeviceGuard guard(pool_dev);
+    void* ws = ctx->pool(pool_dev, stream).workspace.ensure(quant_workspace_bytes(1, batch_heads, rows, rows, head_dim, false), stream);
     if (!ws) return MFA_ERROR_MEMORY_ALLOCATION;
     QuantViews v;
     if (launch_quantize(src, src, src, dense_prec(input_precision), 1, batch_heads, rows, rows, head_dim, bits == 4 ? 4 : 8,

@@ -73,7 +73,8 @@ _DIMS = [_u32, _u32, _u32, _u32, _u16]  # batch, seq_q, seq_kv, heads, head_dim
 _MASK_HOST = [_vp, _sz, _i64p, _i64p, _u32, _i32, _i32]
 
 
-def _load_library() -> ctypes.CDLL:
+def _load_library(path: str | None = None) -> ctypes.CDLL:
+    """path: an explicit library file (tools/ab_inproc.py loads variant builds side by side); default = the search."""
     # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so, so when torch is
     # installed load it first and let libMFAFFI.so bind to that copy (same SONAME).  Two runtimes
     # in one process cannot share streams or device pointers (and the second one sees no device).
@@ -81,7 +82,7 @@ def _load_library() -> ctypes.CDLL:
         import torch  # noqa: F401
     except Exception:  # pure-numpy callers: the system ROCm runtime is used
         pass
-    lib = ctypes.CDLL(_find_library())
+    lib = ctypes.CDLL(path or _find_library())
 
     def sig(name, restype, argtypes):
         fn = getattr(lib, name)

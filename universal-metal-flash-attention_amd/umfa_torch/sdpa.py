@@ -193,6 +193,26 @@ def scaled_dot_product_attention(query, key, value, attn_mask: Optional[torch.Te
         return out
     _bump("total")
     q, k, v = query, key, value
+
+    def fallback():
+        _bump("pytorch_fallback")
+        m = attn_mask
+        if m is not None and m.dtype in (torch.float16, torch.bfloat16):
+            m = m.float()
+        return _native_sdpa(query, key, value, attn_mask=m, dropout_p=dropout_p, is_causal=is_causal, scale=scale,
+                            enable_gqa=enable_gqa)
+
+    # masks the kernels cannot read (dtype, rank) or that do not broadcast onto [B, H, Sq, Skv] go to torch, which
+    # raises its own error for a mis-shaped one -- the kernels trust shape and strides, so nothing unchecked reaches them
+    if attn_mask is not None and q.dim() == 4:
+        if attn_mask.dtype not in (torch.bool, torch.float32, torch.float16, torch.bfloat16) or attn_mask.dim() > 4:
+            return fallback()
+        try:
+            if torch.broadcast_shapes(tuple(attn_mask.shape), (q.size(0), q.size(1), q.size(2), k.size(2))) != \
+                    (q.size(0), q.size(1), q.size(2), k.size(2)):
+                return fallback()
+        except RuntimeError:
+            return fallback()
     # (iii) GQA
     if q.dim() >= 3 and k.dim() >= 3 and q.size(-3) != k.size(-3):
         hq, hkv = q.size(-3), k.size(-3)
@@ -202,14 +222,6 @@ def scaled_dot_product_attention(query, key, value, attn_mask: Optional[torch.Te
                 return zc
             k = k.repeat_interleave(hq // hkv, -3).contiguous()
             v = v.repeat_interleave(hq // hkv, -3).contiguous()
-
-    def fallback():
-        _bump("pytorch_fallback")
-        m = attn_mask
-        if m is not None and m.dtype in (torch.float16, torch.bfloat16):
-            m = m.float()
-        return _native_sdpa(query, key, value, attn_mask=m, dropout_p=dropout_p, is_causal=is_causal, scale=scale,
-                            enable_gqa=enable_gqa)
 
     unsupported = (not (q.is_cuda and k.is_cuda and v.is_cuda) or q.dim() != 4 or k.dim() != 4 or v.dim() != 4
                    or q.size(0) != k.size(0) or q.size(0) != v.size(0) or q.size(1) != k.size(1)
