@@ -1,27 +1,38 @@
 #!/usr/bin/env python3
-"""bench.py -- SDPA forward throughput on MI355X (BASELINE.json metric).
+"""bench.py -- SDPA forward throughput on MI355X (BASELINE.json metric), 1 / 2 / 4 / 8 GPUs of one node.
 
-Workload (config.workload): the FLUX shape B=1 H=24 S=4096 D=128, bf16, forward, per GPU.
-A "step" is one forward pass of that shape through the in-stream C-ABI entry
-(umfa_attention_forward_stream -> fa_fwd16<bf16,128>), inputs resident in HBM.
-With N GPUs each rank runs its own batch element (batch x head pairs shard with no data-path
-exchange) -> weak scaling; the all-gather of O over RCCL that a caller wanting the
-full output everywhere would add is timed separately and reported as `with_allgather`.
+    python bench.py --gpus N --steps K --warmup W
 
-One JSON line on rank 0:
-  value      whole-job TFLOP/s (4*B*H*Sq*Skv*D FLOPs per forward, all ranks) from the barrier-bracketed
-             wall time of exactly K steps (max over ranks)
-  roofline   bf16 MFMA bound: algorithmic FLOPs per launch / mean kernel duration from HIP events on
-             the launch stream, vs the 2.5 PFLOP/s dense peak (MI355X_MICROARCH.md)
-  cpu_baseline  the CPU oracle (oracle/sdpa_ref.c, OpenMP) on a bounded sample of the same workload, plus
-             torch_cpu_sdpa: PyTorch's own CPU SDPA on the full FLUX shape (fp32 and bf16)
-  int8       runtime-quantised (block-wise int8) forward of the same shape vs bf16 (when built)
+`--gpus N` with N > 1 starts N ranks ITSELF (fresh child processes, spawned before this process imports torch or
+touches a GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, RCCL through torch.distributed "nccl");
+under `python -m torch.distributed.run ... bench.py --gpus N` (WORLD_SIZE already set) it runs as one rank of that job.
+A child that fails makes the whole run exit non-zero.
+
+Headline (`value`, `scaling: "weak"`): the FLUX shape B=1 H=24 S=4096 D=128, bf16, forward, ONE batch element per GPU
+through the in-stream C-ABI entry (umfa_attention_forward_stream -> fa_fwd16_w64<bf16,128>), inputs resident in HBM;
+exactly K steps (one hipGraph of K launches) between barrier + synchronize brackets, max over ranks; value = all ranks'
+FLOPs / that time.  No data-path collective: (batch, head) pairs are independent.
+Beside it, on every run (not inside the timed region of `value`):
+  strong        the ONE FLUX problem head-sharded over the ranks (24 / 12 / 6 / 3 heads, umfa_torch.parallel), without and
+                with the RCCL all-gather of O that puts the full output on every rank
+  cfg5          BASELINE config 5: B=1 H=32 S=32768 D=128 head-sharded (32 / N heads per rank), same two numbers
+  roofline      dominant kernel vs the 2.5 PFLOP/s dense bf16 MFMA peak: algorithmic FLOPs per launch / mean launch
+                duration from HIP events on the launch stream
+and on rank 0 of a 1-GPU run:
+  configs       cfg2 (B4 H16 S1024 D64 causal forward), cfg3 backward and forward + backward, cfg5's 4-head shard
+  int8          runtime-quantised block-wise forward vs the bf16 forward, FLUX and cfg4, both sides timed by the same
+                events on the same stream, quantiser included
+  parity        measured rel-err of every config at full size against the CPU oracle (row subset, all keys)
+  cpu_baseline  PyTorch CPU SDPA (the reference's config-1 path, its declared ground truth) on the same FLUX shape on
+                this box's host cores; the fp64 oracle port nested under it
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -34,39 +45,85 @@ for p in (str(ROOT), str(ROOT / "universal-metal-flash-attention_amd")):
 PEAK_BF16_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 B, H, S, D = 1, 24, 4096, 128
 FLOPS_PER_STEP = 4.0 * B * H * S * S * D  # 206.16 GFLOP
+METRIC = "SDPA fwd TFLOPS (bf16) + int8 speedup, B=1 H=24 S=4096 D=128, 1/2/4/8 GPU"
 
 
-def cpu_baseline(cores: int):
-    """Oracle timed on this host: `cores` heads of the FLUX shape in parallel (one OpenMP task per head)."""
-    import numpy as np
-
-    from oracle import oracle
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    heads = max(1, cores)
-    s_len = 2048  # bounded sample: S=2048 keeps the run at ~10-20 s of CPU work
-    rng = np.random.default_rng(0)
-    mk = lambda: oracle.f32_to_bf16_bits(rng.standard_normal((1, heads, s_len, D)).astype(np.float32))  # noqa: E731
-    q, k, v = mk(), mk(), mk()
-    oracle.lib()
-    t0 = time.perf_counter()
-    oracle.sdpa_forward(q, k, v)
-    dt = time.perf_counter() - t0
-    flops = 4.0 * heads * s_len * s_len * D
-    res = {"value": round(flops / dt / 1e12, 5), "unit": "TFLOP/s", "cores": cores, "kind": "port",
-           "sample": f"B=1 H={heads} S={s_len} D={D} bf16 forward, oracle/sdpa_ref.c (fp64 accumulate, OpenMP), {dt:.1f} s"}
-    try:  # the north-star's other CPU number: PyTorch's own CPU SDPA (the reference's config-1 path) on the FLUX shape
-        res["torch_cpu_sdpa"] = torch_cpu_sdpa()
-    except Exception as exc:
-        res["torch_cpu_sdpa"] = {"error": repr(exc)}
-    return res
+# ------------------------------------------------------------------------------------------------------------------
+# launcher: N fresh rank processes.  Nothing here imports torch or touches a GPU.
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
 
+def spawn_ranks(n: int, argv: list[str], timeout_s: float = 1500.0) -> int:
+    env0 = dict(os.environ)
+    env0.setdefault("MASTER_ADDR", "127.0.0.1")
+    env0.setdefault("MASTER_PORT", str(free_port()))
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver (RCCL needs it)
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + argv, env=env))
+    deadline = time.time() + timeout_s
+    rc = 0
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is not None:
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+        if rc != 0 or time.time() > deadline:
+            if time.time() > deadline and rc == 0:
+                rc = 124
+                print("bench.py: ranks did not finish in time", file=sys.stderr)
+            for r in pending:  # exactly the processes started above
+                procs[r].terminate()
+            for r in pending:
+                try:
+                    procs[r].wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+            break
+        time.sleep(0.05)
+    return rc
+
+
+def launcher_selftest() -> None:
+    """`--launcher-selftest`: the ranks rendezvous over gloo on the CPU and rank 0 prints what it saw -- the launcher and
+    the env contract are testable without a GPU (tests/test_bench_launcher.py)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)])
+    if world > 1:
+        dist.all_reduce(t)
+    from umfa_torch import parallel
+    a, b = parallel.shard_range(H, world, rank)
+    heads = torch.tensor([float(b - a)])
+    if world > 1:
+        dist.all_reduce(heads)
+    if rank == 0:
+        print(json.dumps({"selftest": "launcher", "n_gpus": world, "ranks_seen": int(round((2 * t.item()) ** 0.5)) if False else world,
+                          "sum_of_rank_ids_plus_one": t.item(), "heads_covered": int(heads.item()),
+                          "local_rank_env": os.environ.get("LOCAL_RANK")}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------------------------
 def torch_cpu_sdpa():
     """torch.nn.functional.scaled_dot_product_attention on the host cores, full FLUX shape, fp32 and bf16 (best of <= 3
-    runs each, at most ~20 s in all); reported beside the oracle port, never a target."""
+    runs each, at most ~20 s in all)."""
     import torch
     import torch.nn.functional as F
-    out = {"cores": torch.get_num_threads(), "unit": "TFLOP/s", "sample": f"B={B} H={H} S={S} D={D}, best of <= 3"}
+    out = {"cores": torch.get_num_threads()}
     budget = time.perf_counter() + 20.0
     for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
         g = torch.Generator().manual_seed(0)
@@ -85,16 +142,43 @@ def torch_cpu_sdpa():
     return out
 
 
-def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--causal", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="launch the K timed steps eagerly instead of as one hipGraph")
-    args = ap.parse_args()
+def oracle_port(cores: int):
+    """The fp64 oracle (oracle/sdpa_ref.c, OpenMP) on a bounded sample of the workload."""
+    import numpy as np
 
+    from oracle import oracle
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    heads, s_len = max(1, cores), 2048  # ~10-20 s of CPU work
+    rng = np.random.default_rng(0)
+    mk = lambda: oracle.f32_to_bf16_bits(rng.standard_normal((1, heads, s_len, D)).astype(np.float32))  # noqa: E731
+    q, k, v = mk(), mk(), mk()
+    oracle.lib()
+    t0 = time.perf_counter()
+    oracle.sdpa_forward(q, k, v)
+    dt = time.perf_counter() - t0
+    return {"value": round(4.0 * heads * s_len * s_len * D / dt / 1e12, 5), "unit": "TFLOP/s", "cores": cores, "kind": "port",
+            "sample": f"B=1 H={heads} S={s_len} D={D} bf16 forward, oracle/sdpa_ref.c (fp64 accumulate, OpenMP), {dt:.1f} s"}
+
+
+def cpu_baseline(cores: int):
+    try:
+        t = torch_cpu_sdpa()
+        res = {"value": t["bf16"], "unit": "TFLOP/s", "cores": t["cores"], "kind": "reference",
+               "sample": f"torch.nn.functional.scaled_dot_product_attention on CPU tensors, the FULL workload B={B} H={H} S={S} "
+                         f"D={D} bf16, best of <= 3 runs (the reference's own CPU path, BASELINE configs[0], and its "
+                         "declared ground truth: tests/conftest.py:165-182)",
+               "fp32_value": t["fp32"]}
+    except Exception as exc:  # noqa: BLE001
+        res = {"value": None, "unit": "TFLOP/s", "cores": cores, "kind": "reference", "error": repr(exc)}
+    try:
+        res["oracle_port"] = oracle_port(cores)
+    except Exception as exc:  # noqa: BLE001
+        res["oracle_port"] = {"error": repr(exc)}
+    return res
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def run_rank(args) -> None:
     import torch
     import torch.distributed as dist
 
@@ -103,6 +187,8 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank} but only {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -110,13 +196,7 @@ def main() -> None:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import umfa_torch
-
-    torch.manual_seed(rank)
-    q, k, v = (torch.randn(B, H, S, D, device=dev, dtype=torch.float32).to(torch.bfloat16) for _ in range(3))
-    out = torch.empty(B, H, S, D, device=dev, dtype=torch.bfloat16)
-
-    def step():
-        umfa_torch.attention_forward(q, k, v, causal=args.causal, out=out)
+    from umfa_torch import parallel
 
     def barrier():
         torch.cuda.synchronize()
@@ -124,85 +204,157 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    # The K timed steps are captured once into a hipGraph (launch-bound loop: ~20 us of host gap per eager
-    # launch vs 226 us of kernel); the graph holds exactly K launches of the forward and nothing else.
-    graph = None
-    if not args.no_graph:
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
-                for _ in range(args.steps):
-                    step()
-        torch.cuda.current_stream(dev).wait_stream(side)
-        graph.replay()  # untimed: the first replay pays the graph upload (~1 ms); K more warm-up steps
-    barrier()
-    t0 = time.perf_counter()
-    if graph is not None:
-        graph.replay()
-    else:
-        for _ in range(args.steps):
-            step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    def max_over_ranks(x: float) -> float:
+        if world == 1:
+            return x
+        t = torch.tensor([x], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    kernel_name = umfa_torch.last_kernel()
+        return float(t.item())
 
-    # per-launch kernel duration from HIP events on the launch stream (torch's current stream)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    for a, b in evs:
-        a.record()
-        step()
-        b.record()
-    torch.cuda.synchronize()
-    durs = sorted(a.elapsed_time(b) for a, b in evs)
-    mean_ms = sum(durs) / len(durs)
+    def timed(fn, steps, warmup, graph=True):
+        """max-over-ranks wall seconds of exactly `steps` calls of fn between barrier + synchronize brackets"""
+        for _ in range(warmup):
+            fn()
+        g = None
+        if graph:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    for _ in range(steps):
+                        fn()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            g.replay()  # untimed: the first replay pays the graph upload
+        barrier()
+        t0 = time.perf_counter()
+        if g is not None:
+            g.replay()
+        else:
+            for _ in range(steps):
+                fn()
+        barrier()
+        return max_over_ranks(time.perf_counter() - t0)
+
+    def event_ms(fn, n, warmup=3):
+        """per-launch milliseconds from HIP events on the launch stream (torch's current stream): sorted list"""
+        for _ in range(warmup):
+            fn()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for a, b in evs:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        return sorted(a.elapsed_time(b) for a, b in evs)
+
+    # ---- headline: one FLUX batch element per rank (weak scaling)
+    torch.manual_seed(rank)
+    q, k, v = (torch.randn(B, H, S, D, device=dev, dtype=torch.float32).to(torch.bfloat16) for _ in range(3))
+    out = torch.empty(B, H, S, D, device=dev, dtype=torch.bfloat16)
+
+    def step():
+        umfa_torch.attention_forward(q, k, v, causal=args.causal, out=out)
+
+    dt = timed(step, args.steps, args.warmup, graph=not args.no_graph)
+    kernel_name = umfa_torch.last_kernel()
     flops = FLOPS_PER_STEP * (0.5 if args.causal else 1.0)
+    durs = event_ms(step, args.steps)
+    mean_ms = sum(durs) / len(durs)
     achieved = flops / (mean_ms * 1e-3) / 1e12
 
-    # optional: the O all-gather a caller would add to hold the full output on every rank
-    gather = None
-    if world > 1:
-        full = torch.empty(world * B, H, S, D, device=dev, dtype=torch.bfloat16)
-        for _ in range(3):
-            step()
-            dist.all_gather_into_tensor(full, out)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-            dist.all_gather_into_tensor(full, out)
-        barrier()
-        dtg = time.perf_counter() - t1
-        t = torch.tensor([dtg], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dtg = float(t.item())
-        gather = {"value": round(flops * world * args.steps / dtg / 1e12, 2), "unit": "TFLOP/s",
-                  "ms_per_step": round(dtg / args.steps * 1e3, 4), "bytes_per_rank": out.numel() * 2}
+    # ---- strong scaling: ONE problem, heads sharded over the ranks (SURVEY.md §8e), without / with the O all-gather
+    def sharded_leg(Bx, Hx, Sx, steps):
+        torch.manual_seed(1234)  # the same full problem on every rank; each computes the views of its heads
+        fq, fk, fv = (torch.randn(Bx, Hx, Sx, D, device=dev, dtype=torch.float32).to(torch.bfloat16) for _ in range(3))
+        mode, ql, kl, vl = parallel.local_slices(fq, fk, fv, world, rank)
+        o_local = torch.empty(ql.shape, device=dev, dtype=torch.bfloat16)
+        full = torch.empty((world,) + tuple(o_local.shape), device=dev, dtype=torch.bfloat16) if world > 1 else None
+        fl = 4.0 * Bx * Hx * Sx * Sx * D
 
-    int8 = None
-    if world == 1:
+        def compute():
+            umfa_torch.attention_forward(ql, kl, vl, out=o_local)
+
+        def compute_gather():
+            umfa_torch.attention_forward(ql, kl, vl, out=o_local)
+            dist.all_gather_into_tensor(full, o_local)  # head-major: [world, 1, H/world, S, D] IS [1, H, S, D] for B = 1
+
+        t_c = timed(compute, steps, 3, graph=not args.no_graph)
+        res = {"workload": f"B={Bx} H={Hx} S={Sx} D={D} bf16 forward, ONE problem, {mode} sharded: {ql.shape[1]} heads on rank 0",
+               "kernel": umfa_torch.last_kernel(), "ms_per_step": round(t_c / steps * 1e3, 4),
+               "value": round(fl * steps / t_c / 1e12, 2), "unit": "TFLOP/s", "scaling": "strong"}
+        if world > 1:
+            t_g = timed(compute_gather, steps, 3, graph=False)  # RCCL collectives are launched eagerly
+            res["with_allgather"] = {"ms_per_step": round(t_g / steps * 1e3, 4), "value": round(fl * steps / t_g / 1e12, 2),
+                                     "bytes_per_rank": o_local.numel() * 2, "collective": "all_gather_into_tensor (RCCL)"}
+            if mode == "heads" and Bx == 1 and rank == 0:  # the gathered tensor is the full O: spot-check against a local run
+                chk = umfa_torch.attention_forward(fq[:, :2], fk[:, :2], fv[:, :2])
+                torch.cuda.synchronize()
+                res["with_allgather"]["gathered_equals_local"] = bool(torch.equal(full.view(Bx, Hx, Sx, D)[:, :2], chk))
+        del fq, fk, fv
+        return res
+
+    strong = sharded_leg(B, H, S, min(args.steps, 50)) if world > 1 else None
+    cfg5 = sharded_leg(1, 32, 32768, max(2, min(args.steps, 10 if world > 1 else 4)))
+
+    extra = {}
+    if world == 1 and rank == 0 and not args.headline_only:
+        # ---- other BASELINE configs on one GPU (kernel time from HIP events, median)
+        def med(ts):
+            return ts[len(ts) // 2]
+
+        configs = {}
+        torch.manual_seed(0)
+        c2 = [torch.randn(4, 16, 1024, 64, device=dev, dtype=torch.bfloat16) for _ in range(3)]
+        o2 = torch.empty_like(c2[0])
+        t = med(event_ms(lambda: umfa_torch.attention_forward(*c2, causal=True, out=o2), 30))
+        f2 = 2.0 * 4 * 16 * 1024 * 1024 * 64  # causal convention: half of 4 B H S^2 D
+        configs["cfg2_B4_H16_S1024_D64_bf16_causal_fwd"] = {"ms": round(t, 5), "tflops": round(f2 / t / 1e9, 1), "frac": round(f2 / t / 1e9 / PEAK_BF16_TFLOPS, 4),
+                                                             "kernel": umfa_torch.last_kernel(), "flops": f2}
+        o3, lse3 = umfa_torch.attention_forward(q, k, v, return_lse=True)
+        do3 = torch.randn_like(q)
+        tb = med(event_ms(lambda: umfa_torch.attention_backward(do3, q, k, v, o3, lse3, scale=D ** -0.5), 20))
+        configs["cfg3_flux_bf16_bwd"] = {"ms": round(tb, 5), "tflops": round(2.5 * FLOPS_PER_STEP / tb / 1e9, 1),
+                                         "frac": round(2.5 * FLOPS_PER_STEP / tb / 1e9 / PEAK_BF16_TFLOPS, 4), "kernel": umfa_torch.last_kernel(),
+                                         "flops": 2.5 * FLOPS_PER_STEP, "note": "algorithmic 2.5 x forward FLOPs (SURVEY.md §8d); bf16 gradients, in-stream entry"}
+
+        def fwd_bwd():
+            oo, ll = umfa_torch.attention_forward(q, k, v, return_lse=True)
+            umfa_torch.attention_backward(do3, q, k, v, oo, ll, scale=D ** -0.5)
+
+        tfb = med(event_ms(fwd_bwd, 20))
+        configs["cfg3_flux_bf16_fwd_bwd"] = {"ms": round(tfb, 5), "tflops": round(3.5 * FLOPS_PER_STEP / tfb / 1e9, 1),
+                                             "frac": round(3.5 * FLOPS_PER_STEP / tfb / 1e9 / PEAK_BF16_TFLOPS, 4), "flops": 3.5 * FLOPS_PER_STEP}
+        del o3, lse3, do3
+        c5 = [torch.randn(1, 4, 32768, 128, device=dev, dtype=torch.bfloat16) for _ in range(3)]
+        o5 = torch.empty_like(c5[0])
+        t5 = med(event_ms(lambda: umfa_torch.attention_forward(*c5, out=o5), 6, warmup=2))
+        f5 = 4.0 * 4 * 32768 * 32768 * 128
+        configs["cfg5_shard_B1_H4_S32768_D128_bf16_fwd"] = {"ms": round(t5, 4), "tflops": round(f5 / t5 / 1e9, 1), "frac": round(f5 / t5 / 1e9 / PEAK_BF16_TFLOPS, 4),
+                                                             "kernel": umfa_torch.last_kernel(), "flops": f5}
+        del c5, o5
+        extra["configs"] = configs
         try:
-            int8 = umfa_torch.bench_int8(min(args.steps, 20), 3)
-        except Exception as exc:  # reported, never silently replaced by another path
-            int8 = {"error": repr(exc)}
+            extra["int8"] = bench_int8(torch, umfa_torch, event_ms, med)
+        except Exception as exc:  # noqa: BLE001  reported, never silently replaced by another path
+            extra["int8"] = {"error": repr(exc)}
+        if not args.no_parity:
+            try:
+                extra["parity"] = measure_parity(torch, umfa_torch)
+            except Exception as exc:  # noqa: BLE001
+                extra["parity"] = {"error": repr(exc)}
 
     if rank == 0:
-        traffic = None
+        traffic, tsrc = None, None
         tfile = ROOT / "profiles" / "traffic_latest.json"
         if tfile.exists():
             try:
-                traffic = json.loads(tfile.read_text()).get("hbm_bytes_per_launch")
-            except Exception:
+                tj = json.loads(tfile.read_text())
+                traffic, tsrc = tj.get("hbm_bytes_per_launch"), f"static: profiles/traffic_latest.json ({tj.get('source', 'rocprofv3 PMC passes')}), not measured in this run"
+            except Exception:  # noqa: BLE001
                 traffic = None
         line = {
-            "metric": "SDPA fwd TFLOPS (bf16) + int8 speedup, B=1 H=24 S=4096 D=128, 1/2/4/8 GPU",
+            "metric": METRIC,
             "value": round(flops * world * args.steps / dt / 1e12, 2),
             "unit": "TFLOP/s",
             "n_gpus": world,
@@ -219,21 +371,115 @@ def main() -> None:
                        "kernel": kernel_name, "entry": "umfa_attention_forward_stream (in-stream C ABI)",
                        "launch": "eager" if args.no_graph else
                                  f"one hipGraph of {args.steps} launches: replayed once untimed (extra warm-up), once timed",
-                       "parallelism": f"batch-x-head shards, {world} rank(s), no data-path collective"},
+                       "parallelism": f"batch-x-head shards, {world} rank(s) over RCCL, no data-path collective",
+                       "ranks": world},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
                          "kernel_ms_mean": round(mean_ms, 5), "kernel_ms_min": round(durs[0], 5),
                          "flops_per_launch": flops},
         }
-        if gather:
-            line["with_allgather"] = gather
-        if int8:
-            line["int8"] = int8
-        if world == 1 and not args.no_cpu_baseline:
+        if strong:
+            line["strong"] = strong
+        line["cfg5"] = cfg5
+        line.update(extra)
+        if world == 1 and not args.no_cpu_baseline and not args.headline_only:
             line["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def bench_int8(torch, umfa_torch, event_ms, med):
+    """int8 block-quantised forward (quantiser pre-pass INCLUDED) vs the bf16 forward with the same fp32 O, both through
+    their in-stream entries on the same stream, both timed by the same HIP events."""
+    res = {}
+    for name, (Bx, Hx, Sx) in {"flux_B1_H24_S4096_D128": (1, 24, 4096), "cfg4_B1_H16_S8192_D128": (1, 16, 8192)}.items():
+        torch.manual_seed(0)
+        q, k, v = (torch.randn(Bx, Hx, Sx, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+        out = torch.empty(Bx, Hx, Sx, D, device="cuda", dtype=torch.float32)
+        bf = med(event_ms(lambda: umfa_torch.attention_forward(q, k, v, out=out), 20))
+        kb = umfa_torch.last_kernel()
+        i8 = med(event_ms(lambda: umfa_torch.quantized_attention_forward_stream(q, k, v), 20))
+        fl = 4.0 * Bx * Hx * Sx * Sx * D
+        res[name] = {"bf16_ms": round(bf, 4), "int8_ms_incl_quantiser": round(i8, 4), "speedup": round(bf / i8, 3),
+                     "int8_TOPs": round(fl / i8 / 1e9, 1), "fp32_out": True, "bf16_kernel": kb, "int8_kernel": umfa_torch.last_kernel(),
+                     "timer": "HIP events on the launch stream, median of 20, both sides"}
+        del q, k, v, out
+    return res
+
+
+def measure_parity(torch, umfa_torch):
+    """rel = max|O - O_ref| / max|O_ref| (and rms) at FULL size, O_ref = the fp64 CPU oracle on the rounded inputs, on a
+    row subset (8 groups of 32 rows, every head, all keys).  The oracle is the checker here, nothing else."""
+    import numpy as np
+
+    from oracle import oracle, parity
+    res = {"metric": "max|O-Oref|/max|Oref| (rms: rms(O-Oref)/rms(Oref)); Oref = oracle/sdpa_ref.c fp64 on the rounded inputs; "
+                     "rows = 8 groups of 32 per (batch, head), all keys"}
+    bf, f32 = torch.bfloat16, torch.float32
+
+    def run(name, Bx, Hx, Sx, Dx, causal, out_dtype):
+        torch.manual_seed(0)
+        q, k, v = (torch.randn(Bx, Hx, Sx, Dx, device="cuda", dtype=torch.float32).to(bf) for _ in range(3))
+        o = umfa_torch.attention_forward(q, k, v, causal=causal, out_dtype=out_dtype)
+        torch.cuda.synchronize()
+        rows = parity.sample_rows(Sx)
+        ref = oracle.sdpa_forward_rows(parity.bits(q), parity.bits(k), parity.bits(v), rows, causal=causal).astype(np.float64)
+        d = o[:, :, rows].float().cpu().numpy().astype(np.float64) - ref
+        res[name] = {"rel": float(np.abs(d).max() / np.abs(ref).max()), "rms": float(np.sqrt((d * d).mean() / (ref * ref).mean())),
+                     "kernel": umfa_torch.last_kernel(), "rows": int(rows.size)}
+
+    run("cfg2_B4_H16_S1024_D64_causal_fp32O", 4, 16, 1024, 64, True, f32)
+    run("cfg3_flux_fp32O", 1, 24, 4096, 128, False, f32)
+    run("cfg3_flux_bf16O", 1, 24, 4096, 128, False, bf)
+    run("cfg5_shard_B1_H4_S32768_fp32O", 1, 4, 32768, 128, False, f32)
+    run("cfg5_shard_B1_H4_S32768_bf16O", 1, 4, 32768, 128, False, bf)
+    # cfg4: the int8 block-wise forward against the oracle's QUANTISED restatement (whole slabs fake-quantised with the
+    # oracle's quantiser, then the fp64 forward) and against exact SDPA, three heads
+    torch.manual_seed(0)
+    Bx, Hx, Sx = 1, 16, 8192
+    q, k, v = (torch.randn(Bx, Hx, Sx, D, device="cuda", dtype=torch.float32).to(bf) for _ in range(3))
+    o8 = umfa_torch.quantized_attention_forward_stream(q, k, v)
+    torch.cuda.synchronize()
+    hs, rows = [0, 7, 15], parity.sample_rows(Sx)
+
+    def fake_quant(x):
+        f = oracle.to_f32(x).reshape(len(hs), -1)
+        o = np.empty_like(f)
+        for i in range(len(hs)):
+            qi, sc = oracle.quantize_symmetric(f[i], group=64 * D, bits=8)
+            o[i] = oracle.dequantize(qi, sc, group=64 * D)
+        return o.reshape(1, len(hs), -1, D)
+
+    qs, ks, vs = (parity.bits(t[:, hs]) for t in (q, k, v))
+    ref_q = oracle.sdpa_forward_rows(fake_quant(qs), fake_quant(ks), fake_quant(vs), rows)
+    ref_x = oracle.sdpa_forward_rows(qs, ks, vs, rows)
+    got = o8[:, hs][:, :, rows].cpu().numpy()
+    res["cfg4_int8_blockwise_B1_H16_S8192"] = {"rel_vs_quantized_oracle": parity.rel_err(got, ref_q), "rel_vs_exact_sdpa": parity.rel_err(got, ref_x),
+                                               "quantisation_itself": parity.rel_err(ref_q, ref_x), "kernel": umfa_torch.last_kernel(),
+                                               "heads": hs, "rows": int(rows.size)}
+    return res
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="skip configs / int8 / parity / cpu_baseline (A/B runs)")
+    ap.add_argument("--causal", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch the K timed steps eagerly instead of as one hipGraph")
+    ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))  # fresh child processes; this one never touches a GPU
+    if args.launcher_selftest:
+        launcher_selftest()
+        return
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -23,11 +23,11 @@ import os
 import numpy as np
 
 # (dtype name, deferred max?) -> (max bound, rms bound)
-BOUNDS = {
-    ("fp16", False): (5.0e-4, 2.6e-4),
-    ("fp16", True): (1.0e-3, 2.7e-4),   # north-star bound, asserted as such (measured <= 4.1e-4)
-    ("bf16", False): (2.0e-3, 2.1e-3),
-    ("bf16", True): (4.5e-3, 2.2e-3),
+BOUNDS = {                          # largest measured (suite + tools/err_probe.py)  -> + 25 %
+    ("fp16", False): (2.2e-4, 2.3e-4),  # 1.69e-4 / 1.79e-4
+    ("fp16", True): (5.2e-4, 2.6e-4),   # 4.1e-4 (B1 H256 S256 whole tensor) / 2.06e-4
+    ("bf16", False): (2.15e-3, 1.95e-3),  # 1.70e-3 / 1.54e-3
+    ("bf16", True): (4.4e-3, 2.1e-3),   # 3.5e-3 (B1 H64 S1024 whole tensor) / 1.67e-3
 }
 NORTH_STAR = 1.0e-3
 
@@ -67,11 +67,13 @@ def check_forward(o, ref, dt, kernel: str, tag: str = "", scale_max: float = 1.0
     mx, rms = errors(o, ref)
     bmax, brms = BOUNDS[(name, deferred)]
     if out_dt is not None and _name(out_dt) in OUT_HALF_ULP:
-        h = OUT_HALF_ULP[_name(out_dt)]
-        bmax, brms = bmax + h, float(np.hypot(brms, 0.45 * h))
+        h = OUT_HALF_ULP[_name(out_dt)]  # measured with bf16 O: max 2.07e-3 (exact max) / 3.34e-3 (deferred), rms 2.0e-3 / 2.35e-3
+        bmax, brms = float(np.hypot(bmax, 0.5 * h)), float(np.hypot(brms, 0.5 * h))
     record(tag or kernel, dtype=name, kernel=kernel, deferred=deferred, out=_name(out_dt) if out_dt is not None else "fp32",
            max=mx, rms=rms, bound_max=bmax * scale_max, bound_rms=brms * scale_max, n=int(np.asarray(ref).size))
     assert mx < bmax * scale_max, (tag, kernel, "max", mx, bmax * scale_max)
+    if name == "fp16" and scale_max == 1.0:
+        assert mx <= NORTH_STAR, (tag, kernel, "north-star 1e-3", mx)  # fp16 meets the stated tolerance everywhere
     if np.asarray(ref).size >= min_elems_for_rms:
         assert rms < brms * scale_max, (tag, kernel, "rms", rms, brms * scale_max)
     return mx, rms
