@@ -110,9 +110,8 @@ def launcher_selftest() -> None:
     if world > 1:
         dist.all_reduce(heads)
     if rank == 0:
-        print(json.dumps({"selftest": "launcher", "n_gpus": world, "ranks_seen": int(round((2 * t.item()) ** 0.5)) if False else world,
-                          "sum_of_rank_ids_plus_one": t.item(), "heads_covered": int(heads.item()),
-                          "local_rank_env": os.environ.get("LOCAL_RANK")}), flush=True)
+        print(json.dumps({"selftest": "launcher", "n_gpus": world, "sum_of_rank_ids_plus_one": t.item(),
+                          "heads_covered": int(heads.item()), "local_rank_env": os.environ.get("LOCAL_RANK")}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -213,19 +212,25 @@ def run_rank(args) -> None:
 
     def timed(fn, steps, warmup, graph=True):
         """max-over-ranks wall seconds of exactly `steps` calls of fn between barrier + synchronize brackets"""
-        for _ in range(warmup):
-            fn()
         g = None
         if graph:
+            # warm-up AND capture on the same side stream: scratch pools are per (device, stream) and never grow while
+            # a stream is capturing (runtime_internal.h), so the capture stream must have seen the shape first
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
+                for _ in range(max(1, warmup)):
+                    fn()
+                side.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=side):
                     for _ in range(steps):
                         fn()
             torch.cuda.current_stream(dev).wait_stream(side)
             g.replay()  # untimed: the first replay pays the graph upload
+        else:
+            for _ in range(warmup):
+                fn()
         barrier()
         t0 = time.perf_counter()
         if g is not None:

@@ -127,6 +127,24 @@ def test_w64_deferred_max_rescale_paths():
         assert np.abs(lse.cpu().numpy().reshape(rl.shape) - rl).max() < 5e-2
 
 
+def test_w64_deferred_max_tail_vs_exact_running_max(monkeypatch):
+    """The shape on which the deferred max shows its tail (profiles/r2/error_anatomy.md: B1 H64 S1024, whole tensor
+    against the oracle): tau = 6 stays inside the measured deferred-max bounds, and the same kernel with
+    UMFA_W64_TAU=0 (exact running max) sits at the bf16 operand-format floor -- same rows, same inputs."""
+    import umfa_torch
+    torch.manual_seed(0)
+    q, k, v = (torch.randn(1, 64, 1024, 128, device="cuda", dtype=torch.float32).to(torch.bfloat16) for _ in range(3))
+    ref = _oracle().sdpa_forward(bits(q), bits(k), bits(v))
+    o6 = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
+    assert umfa_torch.last_kernel().startswith("fa_fwd16_w64")
+    m6, r6 = check_forward(o6.cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel(), "tail_tau6")
+    monkeypatch.setenv("UMFA_W64_TAU", "0")
+    o0 = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
+    m0, r0 = check_forward(o0.cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel(), "tail_tau0")
+    assert m0 < 1.6e-3 and r0 < r6  # measured: 0.9e-3 ... 1.2e-3 max, rms 7 ... 10 % under the deferred regime
+    assert not torch.equal(o0, o6)
+
+
 @pytest.mark.parametrize("shape", [(1, 2, 256, 256), (1, 2, 512, 512), (2, 3, 768, 768), (1, 2, 1024, 448), (1, 1, 256, 1024),
                                    (1, 4, 2048, 2048)])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
