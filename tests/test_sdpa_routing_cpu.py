@@ -73,3 +73,24 @@ def test_counter_names_match_reference():
     assert set(umfa_torch.get_dispatch_stats()) == {
         "total", "quantized_autograd", "fp32_autograd", "fp32_direct", "fp32_instream", "rope_instream",
         "rope_autograd", "pytorch_fallback", "mask_all_true_skipped"}
+
+
+def test_custom_op_traces_as_one_node_with_fake_tensors():
+    """umfa::sdpa_forward has a fake implementation: a trace over fake ROCm tensors (what torch.compile does) keeps it
+    as one opaque node with the right output metadata -- no GPU needed to check that."""
+    import torch
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from torch.fx.experimental.proxy_tensor import make_fx
+
+    import umfa_torch
+    with FakeTensorMode() as mode:
+        q = torch.empty(2, 4, 256, 128, device="cuda", dtype=torch.bfloat16)
+        gm = make_fx(lambda a, b, c: umfa_torch.library.sdpa(a, b, c, is_causal=True), tracing_mode="fake")(q, q, q)
+    targets = [n.target for n in gm.graph.nodes if n.op == "call_function"]
+    assert torch.ops.umfa.sdpa_forward.default in targets, targets
+    assert not any("scaled_dot_product" in str(t) for t in targets)
+    # dropout is not ours: the same entry point traces to torch's own kernels instead
+    with FakeTensorMode():
+        q = torch.empty(2, 4, 256, 128, device="cuda", dtype=torch.bfloat16)
+        assert not umfa_torch.library.op_supports(q, q, q, None, 0.1, False)
+        assert not umfa_torch.library.op_supports(q, q, q, torch.empty(3, 256, dtype=torch.bool, device="cuda"), 0.0, False)

@@ -180,6 +180,11 @@ def _gqa_zero_copy(q, k, v, attn_mask, dropout_p, is_causal, scale):
 
 def scaled_dot_product_attention(query, key, value, attn_mask: Optional[torch.Tensor] = None, dropout_p: float = 0.0,
                                  is_causal: bool = False, scale: Optional[float] = None, enable_gqa: bool = False):
+    if torch.compiler.is_compiling():
+        # being traced (torch.compile): ctypes launches, locks and counters cannot be traced -- hand over to the opaque
+        # custom op umfa::sdpa_forward (library.py), which runs the same kernels at run time of the compiled graph
+        from . import library
+        return library.sdpa(query, key, value, attn_mask, dropout_p, is_causal, scale, enable_gqa)
     if key.dim() != value.dim() or key.dim() < 2 or key.size(-2) != value.size(-2):
         raise RuntimeError("UMFA SDPA: key and value must have matching sequence lengths")
     # (ii) promote 2-D / 3-D
@@ -199,8 +204,9 @@ def scaled_dot_product_attention(query, key, value, attn_mask: Optional[torch.Te
         m = attn_mask
         if m is not None and m.dtype in (torch.float16, torch.bfloat16):
             m = m.float()
-        return _native_sdpa(query, key, value, attn_mask=m, dropout_p=dropout_p, is_causal=is_causal, scale=scale,
-                            enable_gqa=enable_gqa)
+        from . import library  # torch's own SDPA; past our aten override when that is installed
+        return library.native_sdpa(query, key, value, attn_mask=m, dropout_p=dropout_p, is_causal=is_causal, scale=scale,
+                                   enable_gqa=enable_gqa)
 
     # masks the kernels cannot read (dtype, rank) or that do not broadcast onto [B, H, Sq, Skv] go to torch, which
     # raises its own error for a mis-shaped one -- the kernels trust shape and strides, so nothing unchecked reaches them
