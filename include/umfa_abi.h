@@ -181,7 +181,12 @@ mfa_error_t mfa_attention_backward(
 
 /* ---- runtime-quantised forward / backward, [T]:498-531, [Q]:227-533.
  * target_precision 3 = INT8, 4 = INT4; quant_mode 0 = per tensor, 2 = block-wise;
- * mask: fp32 additive [B,H,Sq,Skv] buffer or NULL. */
+ * mask: fp32 additive [B,H,Sq,Skv] buffer or NULL.
+ * MI355X extra value (additive; the reference reads every value other than 2 as per-tensor):
+ *   quant_mode 3 = UMFA_QUANT_BLOCKWISE_FP8PV: block-wise int8 Q K^T as mode 2, P and V in fp8 e4m3 (V with one
+ *   power-of-two scale per 64-key tile), P V on the 2x-rate fp8 MFMA -- SageAttention2's arithmetic, coarser than the
+ *   reference's int8-storage / fp32-math; served for head_dim 128 without mask, anything else runs mode 2. */
+#define UMFA_QUANT_BLOCKWISE_FP8PV 3
 int32_t mfa_quantized_forward_with_lse(
     mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, mfa_buffer_t v, mfa_buffer_t out,
     mfa_buffer_t lse, mfa_buffer_t mask, uint32_t batch_size, uint32_t seq_len_q,

@@ -291,3 +291,60 @@ def flash_format_floor(q, k, v, rows, kind: str, scale=None, causal=False):
         s = np.where(np.arange(k.shape[2])[None, :] <= rows[:, None], s, -np.inf)
     p = np.exp(s - s.max(-1, keepdims=True))
     return (np.einsum("bhij,bhjd->bhid", round_to(p, kind), vf) / p.sum(-1, keepdims=True)).astype(np.float32)
+
+
+def round_e4m3(x: np.ndarray) -> np.ndarray:
+    """float array rounded to the OCP fp8 e4m3fn value set (round to nearest even; 3 mantissa bits, normals from 2^-6,
+    subnormal step 2^-9, largest finite 448), returned as float64.  |x| must be <= 448 (the kernels guarantee it)."""
+    x = np.asarray(x, np.float64)
+    a = np.abs(x)
+    e = np.clip(np.floor(np.log2(np.maximum(a, 2.0 ** -30))), -6, 8)
+    q = 2.0 ** (e - 3)
+    return np.sign(x) * np.minimum(np.round(a / q) * q, 448.0)
+
+
+def fp8_v_tiles(v: np.ndarray, tile: int = 64):
+    """The fp8 P V mode's V quantiser restated (fa_quant.hip, quant_mode 3): per (batch, head, 64-key tile) the smallest
+    power of two 2^e with absmax / 2^e <= 448, V / 2^e rounded to e4m3.  Returns (de-quantised V as float64, exponents)."""
+    vf = to_f32(v).astype(np.float64)
+    B, H, S, D = vf.shape
+    T = (S + tile - 1) // tile
+    pad = np.zeros((B, H, T * tile, D))
+    pad[:, :, :S] = vf
+    t = pad.reshape(B, H, T, tile, D)
+    am = np.abs(t).max(axis=(3, 4))
+    e = np.where(am > 0, np.ceil(np.log2(np.maximum(am, 1e-300) / 448.0)), 0.0)
+    # frexp convention of the kernel: amax / 448 = f 2^e with f in [0.5, 1): exact powers of two land one exponent higher
+    e = np.where((am > 0) & (np.log2(np.maximum(am, 1e-300) / 448.0) == e), e + 1, e)
+    sc = 2.0 ** e[..., None, None]
+    return (round_e4m3(t / sc) * sc).reshape(B, H, T * tile, D)[:, :, :S], e
+
+
+def quantized_forward_fp8pv(q, k, v, rows=None, scale=None, causal=False, p_fp8: bool = False, seed=None):
+    """quant_mode 3 restated: Q, K fake-quantised block-wise to int8 exactly as quantized_forward does, V through
+    fp8_v_tiles, then fp64 SDPA.  p_fp8=False keeps P exact: the reference point the kernel is held against (its own P
+    rounding to fp8, whose pattern depends on the deferred reference max, is bounded separately by the test);
+    p_fp8=True rounds P (relative to the exact row max) to e4m3 and normalises by the rounded sum -- the statistical
+    model of what the kernel adds.  rows: subset of query rows (all keys)."""
+    B, H, Sq, D = q.shape
+    if scale is None:
+        scale = 1.0 / np.sqrt(D)
+
+    def fq(x):
+        f = to_f32(x).reshape(B * H, -1)
+        out = np.empty_like(f)
+        for i in range(B * H):
+            qi, sc = quantize_symmetric(f[i], group=64 * D, bits=8)
+            out[i] = dequantize(qi, sc, group=64 * D)
+        return out.reshape(x.shape).astype(np.float64)
+
+    qf, kf = fq(q), fq(k)
+    vf, _ = fp8_v_tiles(v)
+    rows = np.arange(Sq) if rows is None else np.asarray(rows)
+    s = np.einsum("bhid,bhjd->bhij", qf[:, :, rows], kf) * scale
+    if causal:
+        s = np.where(np.arange(k.shape[2])[None, :] <= rows[:, None], s, -np.inf)
+    p = np.exp(s - s.max(-1, keepdims=True))
+    if p_fp8:
+        p = round_e4m3(p)
+    return (np.einsum("bhij,bhjd->bhid", p, vf) / p.sum(-1, keepdims=True)).astype(np.float32)

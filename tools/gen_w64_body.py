@@ -39,22 +39,30 @@ class Cfg:
     row max runs on those floats (monotone in s) and the one v_fma_f32 per score that applies scale and reference max
     takes the bias out with its addend (nmb = -m - 12582912 c).  W64_I8_BIAS=0 (lab, with -DW64_I8_NOBIAS) keeps the
     explicit in-place conversion (I2F)."""
-    def __init__(self, i8):
+    def __init__(self, i8, f8=False):
         self.i8 = i8
+        self.f8 = f8                     # fp8 (e4m3) P and V: O^T += V^T P^T on v_mfma_scale_f32_32x32x64_f8f6f4 (see Cfg8 notes)
         self.i2f = i8 and os.environ.get("W64_I8_BIAS", "1") == "0"
         self.NQK = 16 if i8 else 32      # MFMAs of the QK^T phase = first gap index of the PV phase
         self.KS = 4 if i8 else 8         # k-steps per 32-key block
         self.HALF = self.NQK // 2        # QK^T MFMAs per key block
-        self.NG = self.NQK + 32          # gaps per tile
+        self.NPV = 20 if f8 else 32      # gap slots of the PV phase (a 64-cycle fp8 MFMA takes two 32-cycle slots)
+        self.NG = self.NQK + self.NPV    # gaps per tile
         self.KDMA = 2 if i8 else 4       # 1-KiB LDS-DMA pieces of a K tile per wave
+        self.VDMA = 2 if f8 else 4       # ... of a V tile
         self.KB_BYTES = 4096 if i8 else 8192  # LDS bytes of one 32-key block of the K tile image
+        self.budget = int(os.environ.get("W64_BUDGET_F8", "40")) if f8 else BUDGET
+
+    def pv_gap(self, qb, db):
+        """gap slot of the fp8 PV MFMA of (q-block, d-block); db = 4: the row-sum MFMA of the q-block"""
+        return self.NQK + 10 * qb + 2 * db
 
 
-C = Cfg(False)
-
-COST = {"UPDK": 4, "UPDV": 4, "BAR": 16, "KPRE": 4, "I2F": 4, "MASK": 8, "DMAK": 8, "DMAV": 8, "NOP": 32, "EXP": 8, "ADD": 4, "CVT": 4, "VREAD": 8, "KREAD": 4, "MAX": 4, "DEC": 44, "FMA": 4}
+COST = {"CVT8": 4, "VREAD8": 8, "UPDK": 4, "UPDV": 4, "BAR": 16, "KPRE": 4, "I2F": 4, "MASK": 8, "DMAK": 8, "DMAV": 8, "NOP": 32, "EXP": 8, "ADD": 4, "CVT": 4, "VREAD": 8, "KREAD": 4, "MAX": 4, "DEC": 44, "FMA": 4}
 for _kv in filter(None, os.environ.get("W64_COST", "").split(",")):  # lab: W64_COST=EXP:16,ADD:4 overrides the model
     COST[_kv.split(":")[0]] = int(_kv.split(":")[1])
+
+C = Cfg(False)
 
 NPRE = 4  # K fragments (kb=0, ks<NPRE) read before the iteration starts (by the includer, after the barrier)
 
@@ -95,9 +103,46 @@ class Roles:
 def qk_mfma(R, kb, ks, qb):
     t = tup(R.new, kb, qb)
     c = "0" if ks == 0 else t
+    if ks == 0 and C.f8:
+        return f'asm volatile(W64_MFMA_QK " {t}, %0, %1, v[{F8_BIAS}:{F8_BIAS + 15}]" :: "v"(kf[{kb}][{ks}]), "{QF_CLASS}"(qf[{qb}][{ks}]));'
     if ks == 0 and C.i8 and not C.i2f:
         return f'asm volatile(W64_MFMA_QK " {t}, %0, %1, %2" :: "v"(kf[{kb}][{ks}]), "{QF_CLASS}"(qf[{qb}][{ks}]), "v"(bias16));'
     return f'asm volatile(W64_MFMA_QK " {t}, %0, %1, {c}" :: "v"(kf[{kb}][{ks}]), "{QF_CLASS}"(qf[{qb}][{ks}]));'
+
+
+# ---- fp8 variant (Cfg.f8): SageAttention2-style P V.  Per 64-key tile and q-block the WHOLE key range is ONE MFMA k-range
+# (v_mfma_scale_f32_32x32x64_f8f6f4: 64 cycles, twice the bf16 rate per flop; operand maps measured by
+# tools/lab/f8_probe.hip: lane l holds row/col l % 32 and k-slots 32 (l / 32) + byte).  The B operand P^T is the score
+# accumulator packed in place: byte j = 4 m + b of lane half h is the score of key b + 8 (m & 3) + 4 h + 32 (m >> 2), i.e.
+# register m of the packed fragment holds scores 4 m' .. 4 m' + 3 (m' = m & 3) of key block m >> 2 -- two v_cvt_pk_fp8_f32
+# per register -- and the eight packed registers of a q-block sit in the first eight registers of its key-block-0 tile.
+# The A operand V^T comes from the quantiser already in that k order (fa_quant.hip v8 image), two ds_read_b128 per
+# d-block, shared by both q-blocks; its per-tile power-of-two scale rides in the instruction's scale_a operand.
+# The row sum l = sum_k P is a ninth MFMA per q-block against an all-ones A operand (the MFMA pipe is half idle in
+# this variant, the VALU is not): it sums exactly the rounded P that P V uses and removes 64 v_add per tile.
+# Register ownership of the fp8 kernel: it is compiled with amdgpu_num_vgpr(96), so v[96:127] and a[96:127] are ours too.
+# The row-sum accumulators MUST be literal registers: as compiler values ("+a") hipcc copied them between basic blocks
+# right behind the asm statement, i.e. before the 64-cycle MFMA had written them (it pads nothing for inline asm) -- rows
+# lost whole tiles of their sum (measured: O = 1.0 ... 1.33 for V = 1).
+F8_BIAS = 96     # v[96:111]  the int8 score bias tile (1.5 * 2^23 in every element)
+F8_ONES = 112    # v[112:119] fp8 1.0 in every k-slot: A operand of the row-sum MFMA
+F8_SONE = 120    # v120       E8M0 scale bytes of 1.0
+F8_VSC = 121     # v121       E8M0 scale bytes of the V tile in use (set per tile by the includer)
+F8_L = 96        # a[96:111] / a[112:127]: row-sum accumulators of q-block 0 / 1
+
+
+def pv8_mfma(R, db, qb):
+    b = base(R.old, 0, qb)
+    o = oreg(qb, db)
+    return (f'asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 {o}, %0, v[{b}:{b + 7}], {o}, v{F8_VSC}, v{F8_SONE} op_sel_hi:[0,0,0]" '
+            f':: "v"(vf8[{db}]));')
+
+
+def l8_mfma(R, qb):
+    b = base(R.old, 0, qb)
+    la = f"a[{F8_L + 16 * qb}:{F8_L + 16 * qb + 15}]"
+    return (f'asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 {la}, v[{F8_ONES}:{F8_ONES + 7}], v[{b}:{b + 7}], {la}, '
+            f'v{F8_SONE}, v{F8_SONE} op_sel_hi:[0,0,0]");')
 
 
 def pv_mfma(R, st, db, qb):
@@ -121,6 +166,14 @@ def op_text(R, op):
         b = base(R.old, kb, qb)
         d = b + 8 * (r >> 3) + ((r & 7) >> 1)
         return f'asm volatile(W64_CVT " v{d}, v{b + r}, v{b + r + 1}");'
+    if kind == "CVT8":
+        _, kb, qb, m, hi = op
+        src = base(R.old, kb, qb) + 4 * m + (2 if hi else 0)
+        d = base(R.old, 0, qb) + 4 * kb + m
+        sel = " op_sel:[0,0,1]" if hi else ""
+        return f'asm volatile("v_cvt_pk_fp8_f32 v{d}, v{src}, v{src + 1}{sel}");'
+    if kind == "VREAD8":
+        return f"vf8[{op[1]}] = v8_frag(W64_VOFF, {op[1]});"
     if kind == "VREAD":
         _, st, db = op
         return f"vf[{st}][{db}] = v_frag(W64_VOFF, {db}, {st});"
@@ -206,6 +259,30 @@ def exp_streams():
     return streams
 
 
+def exp8_streams():
+    """fp8 variant: exp and pack of S_old, ONE ordered stream per q-block (key block 0 first: key block 1 packs into
+    registers 4..7 of the key-block-0 tile, which must have been consumed); the pack of a 4-score group trails the
+    exponentials of the next group; everything of a q-block before its first P V MFMA."""
+    streams = []
+    for qb in (0, 1):
+        dl = C.pv_gap(qb, 0) - 1
+        ops, pend = [], None
+        for kb in (0, 1):
+            for m in range(4):
+                for r in range(4 * m, 4 * m + 4):
+                    ops.append((("EXP", kb, qb, r), 0, dl))
+                if pend is not None:
+                    ops += [(("CVT8",) + pend + (0,), 0, dl), (("CVT8",) + pend + (1,), 0, dl)]
+                pend = (kb, qb, m)
+        ops += [(("CVT8",) + pend + (0,), 0, dl), (("CVT8",) + pend + (1,), 0, dl)]
+        streams.append(ops)
+    return streams
+
+
+def vread8_stream():
+    return [(("VREAD8", db), max(0, C.pv_gap(0, db) - 12), C.pv_gap(0, db) - 4) for db in range(4)]
+
+
 def bar_gap():
     return C.NQK + 16  # MIDBAR: behind the PV MFMAs of 16-key steps 0 and 1
 
@@ -256,11 +333,13 @@ def dma_stream():
     sfx = "_I8" if C.i8 else ""
     kpos = [1, 4] if C.i8 else [1, 9, 17, 25]
     vpos = [2, 6, 8, 10] if C.i8 else [5, 13, 21, 29]
+    if C.f8:
+        sfx, kpos, vpos = "_F8", [1, 5], [9, 13]
     if os.environ.get("W64_DMA_K" + sfx):
         kpos = [int(x) for x in os.environ["W64_DMA_K" + sfx].split(",")]
     if os.environ.get("W64_DMA_V" + sfx):
         vpos = [int(x) for x in os.environ["W64_DMA_V" + sfx].split(",")]
-    ops = [(("DMAK", j), kpos[j], kpos[j] + 2) for j in range(C.KDMA)] + [(("DMAV", j), vpos[j], vpos[j] + 2) for j in range(4)]
+    ops = [(("DMAK", j), kpos[j], kpos[j] + 2) for j in range(C.KDMA)] + [(("DMAV", j), vpos[j], vpos[j] + 2) for j in range(C.VDMA)]
     ops.sort(key=lambda o: o[1])
     return ops
 
@@ -316,6 +395,11 @@ def start_streams(have_new, mfma_follows=True, masked=False):
                  "dec": (34, 35), "fma": (36, 46)}
         else:
             w = {"i2f": {0: (9, 14), 1: (17, 22)}, "max": {0: (15, 19), 1: (23, 27)}, "dec": (28, 29), "fma": (30, 45)}
+    elif C.f8:
+        if masked:
+            w = {"mask": {0: (9, 14), 1: (17, 21)}, "max": {0: (15, 17), 1: (22, 24)}, "dec": (25, 26), "fma": (27, 35)}
+        else:
+            w = {"max": {0: (9, 16), 1: (17, 24)}, "dec": (25, 26), "fma": (27, 35)}
     else:
         if masked:
             w = {"mask": {0: (9, 17), 1: (17, 26)}, "max": {0: (18, 21), 1: (27, 30)}, "dec": (31, 32), "fma": (33, 46)}
@@ -344,6 +428,7 @@ def start_streams(have_new, mfma_follows=True, masked=False):
 
 def schedule(streams, gaps):
     """EDF under a per-gap budget.  streams: list of [ (op, earliest, deadline) ... ] each consumed in order."""
+    BUDGET = C.budget
     pos = [0] * len(streams)
     out = [[] for _ in range(gaps)]
     # a stream is consumed in order, so an op inherits the tightest deadline of everything queued behind it
@@ -400,9 +485,27 @@ def check_part(placed, have_new, have_old, masked):
             pos[op] = (g, k)
     def before(a, b):
         return a in pos and b in pos and pos[a] < pos[b]
+    if have_old and C.f8:
+        for qb in (0, 1):
+            first_use = C.pv_gap(qb, 0)
+            for kb in (0, 1):
+                for m in range(4):
+                    lo, hi = ("CVT8", kb, qb, m, 0), ("CVT8", kb, qb, m, 1)
+                    for r in range(4 * m, 4 * m + 4):
+                        assert before(("EXP", kb, qb, r), lo if r < 4 * m + 2 else hi), ("pack before EXP", kb, qb, r)
+                    assert before(lo, hi), ("high word packed before the low word (which rewrites the register's low half only)", lo)
+                    assert pos[hi][0] < first_use, ("P fragment packed after its first PV MFMA", hi, pos[hi], first_use)
+                    # in-place compaction: destination register 4 kb + m of the key-block-0 tile must already have been
+                    # consumed as a score: it is score 4 kb + m of key block 0, packed by group (4 kb + m) >> 2
+                    dst = 4 * kb + m
+                    if not (kb == 0 and m == 0):
+                        g = dst >> 2
+                        assert before(("CVT8", 0, qb, g, 1 if dst & 2 else 0), lo), ("pack overwrites an unpacked score", lo)
+        for db in range(4):
+            assert pos[("VREAD8", db)][0] < C.pv_gap(0, db), ("V fragment read after its MFMA", db)
     for kb in (0, 1):
         for qb in (0, 1):
-            if have_old:
+            if have_old and not C.f8:
                 for r in range(16):
                     assert before(("EXP", kb, qb, r), ("ADD", kb, qb, r)), ("ADD before EXP", kb, qb, r)
                 for r in range(0, 16, 2):
@@ -443,7 +546,7 @@ def check_part(placed, have_new, have_old, masked):
                 assert at < bar, ("before the barrier", op)
             if op[0] == "KPRE":
                 assert at > bar, ("next tile's K fragments are visible only behind the barrier", op)
-    if have_old:
+    if have_old and not C.f8:
         for st in range(4):
             for db in range(4):
                 assert pos[("VREAD", st, db)][0] < C.NQK + st * 8 + db * 2, ("V fragment read after its MFMA", st, db)
@@ -468,15 +571,23 @@ def emit_part(lines, R, have_new, have_old, masked=False):
                     mf.append(qk_mfma(R, kb, ks, qb))
     else:
         mf += [None] * C.NQK
-    if have_old:
+    if have_old and C.f8:
+        for qb in (0, 1):
+            for db in range(4):
+                mf += [pv8_mfma(R, db, qb), None]   # 64-cycle instruction: two gap slots
+            mf += [l8_mfma(R, qb), None]
+    elif have_old:
         for st in range(4):
             for db in range(4):
                 for qb in (0, 1):
                     mf.append(pv_mfma(R, st, db, qb))
     else:
-        mf += [None] * 32
+        mf += [None] * C.NPV
     streams = []
-    if have_old:
+    if have_old and C.f8:
+        streams += exp8_streams()
+        streams.append(vread8_stream())
+    elif have_old:
         streams += exp_streams()
         streams.append(vread_stream(have_new))
     if have_new:
@@ -498,7 +609,8 @@ def emit_part(lines, R, have_new, have_old, masked=False):
             if op[0] not in ABL:
                 lines.append("    " + op_text(R, op))
         fill = sum(COST[o[0]] for o in placed[g])
-        cyc += max(32 if mf[g] else 0, (8 if mf[g] else 0) + fill)
+        busy = mf[g] is not None or (C.f8 and g >= C.NQK and g > 0 and mf[g - 1] is not None)  # second slot of a 64-cycle MFMA
+        cyc += max(32 if busy else 0, (8 if mf[g] else 0) + fill)
         if mf[g] is not None or placed[g]:
             lines.append(f"__builtin_amdgcn_sched_barrier(0);  // gap {g}: filler issue {fill} cyc")
     lines.append(f"// modelled issue time of this part: {cyc} cycles")
@@ -536,6 +648,38 @@ def emit_helpers(lines):
         a("}")
 
 
+def emit_helpers_f8(lines):
+    """Helpers of the fp8 kernel (compiled with amdgpu_num_vgpr(96)): its literal v[96:127] / a[96:127]."""
+    a = lines.append
+    a("// GENERATED by tools/gen_w64_body.py -- literal registers of fa_fwd_w64_i8f8 (see F8_* there).")
+    a("__device__ __forceinline__ void f8_init_consts() {")
+    a("    asm volatile(" + " ".join(f'"v_mov_b32 v{F8_BIAS + r}, 0x4b400000\\n\\t"' for r in range(16)) +
+      " " + " ".join(f'"v_mov_b32 v{F8_ONES + r}, 0x38383838\\n\\t"' for r in range(8)) +
+      f' "v_mov_b32 v{F8_SONE}, 0x7f7f7f7f\\n\\tv_mov_b32 v{F8_VSC}, 0x7f7f7f7f\\n\\ts_nop 1" ::: "memory");')
+    a("}")
+    a("__device__ __forceinline__ void f8_set_vscale(unsigned e8) {")
+    a(f'    asm volatile("v_mov_b32 v{F8_VSC}, %0\\n\\ts_nop 1" :: "s"(e8) : "memory");')
+    a("}")
+    a("__device__ __forceinline__ void f8_zero_l() {")
+    a("    asm volatile(" + " ".join(f'"v_accvgpr_write_b32 a{F8_L + r}, 0\\n\\t"' for r in range(32)) + ' "s_nop 0" ::: "memory");')
+    a("}")
+    a("// row sums *= alpha (rare path of the deferred max); only register 0 of each accumulator is ever read back, but all")
+    a("// sixteen keep accumulating, so all are scaled")
+    a("__device__ __forceinline__ void f8_scale_l(float a0, float a1) {")
+    a("    float t0, t1, t2, t3;")
+    for qb in (0, 1):
+        for r in range(F8_L + 16 * qb, F8_L + 16 * qb + 16, 4):
+            a(f'    asm volatile("v_accvgpr_read_b32 %0, a{r}\\n\\tv_accvgpr_read_b32 %1, a{r + 1}\\n\\tv_accvgpr_read_b32 %2, a{r + 2}\\n\\t"'
+              f' "v_accvgpr_read_b32 %3, a{r + 3}\\n\\ts_nop 1\\n\\tv_mul_f32 %0, %0, %4\\n\\tv_mul_f32 %1, %1, %4\\n\\tv_mul_f32 %2, %2, %4\\n\\t"'
+              f' "v_mul_f32 %3, %3, %4\\n\\ts_nop 1\\n\\tv_accvgpr_write_b32 a{r}, %0\\n\\tv_accvgpr_write_b32 a{r + 1}, %1\\n\\t"'
+              f' "v_accvgpr_write_b32 a{r + 2}, %2\\n\\tv_accvgpr_write_b32 a{r + 3}, %3"'
+              f' : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3) : "v"(a{qb}));')
+    a("}")
+    a("__device__ __forceinline__ void f8_read_l(float& l0, float& l1) {")
+    a(f'    asm volatile("v_accvgpr_read_b32 %0, a{F8_L}\\n\\tv_accvgpr_read_b32 %1, a{F8_L + 16}" : "=v"(l0), "=v"(l1));')
+    a("}")
+
+
 def emit_body(out):
     lines = ["// GENERATED by tools/gen_w64_body.py -- do not edit; see that file for the placement rules.",
              "#if W64_PART == 0  // first tile of a segment: S -> set A"]
@@ -564,11 +708,14 @@ def main():
     csrc = Path(__file__).resolve().parent.parent / "universal-metal-flash-attention_amd" / "csrc"
     helpers = []
     emit_helpers(helpers)
+    emit_helpers_f8(helpers)
     (csrc / "fa_fwd16_w64_regs.inc").write_text("\n".join(helpers) + "\n")
     C = Cfg(False)
     emit_body(Path(os.environ["W64_OUT"]) if os.environ.get("W64_OUT") else csrc / "fa_fwd16_w64_body.inc")
     C = Cfg(True)
     emit_body(Path(os.environ["W64_OUT_I8"]) if os.environ.get("W64_OUT_I8") else csrc / "fa_fwd_w64_i8_body.inc")
+    C = Cfg(True, f8=True)
+    emit_body(Path(os.environ["W64_OUT_I8F8"]) if os.environ.get("W64_OUT_I8F8") else csrc / "fa_fwd_w64_i8f8_body.inc")
 
 
 if __name__ == "__main__":

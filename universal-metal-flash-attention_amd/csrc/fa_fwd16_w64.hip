@@ -54,6 +54,8 @@ struct W64I8Params {
     const int8_t* q8;       // [B*H*Sq][128] int8 (quantiser workspace)
     const int8_t* k8;       // [B*H*Skv][128]
     const _Float16* v16;    // [B*H*Skv][128] fp16, de-quantised
+    const uint8_t* v8;      // fp8 variant: [B*H][tile][8192] e4m3 in MFMA operand order (fa_quant.hip)
+    const uint32_t* v_e8;   // fp8 variant: [B*H][nkblk] E8M0 scale byte of the tile, replicated in the four bytes
     const float* q_scale;   // [B*H][nqblk], one per 64 rows
     const float* k_scale;   // [B*H][nkblk]
     void* o;                // fp32 [B,H,Sq,128]
@@ -108,6 +110,24 @@ struct W64I8Params {
 #undef W64_MFMA_QK
 #undef W64_CVT
 #undef W64_KERNEL
+#undef W64_BODY_INC
+
+// runtime-quantised, fp8 P V (opt-in fast mode, quant_mode 3): int8 QK^T, fp8 e4m3 P and V
+#undef W64_F8
+#define W64_F8 1
+#define W64_BODY_INC "fa_fwd_w64_i8f8_body.inc"
+#define W64_T _Float16
+#define W64_MFMA "v_mfma_f32_32x32x16_f16"
+#define W64_MFMA_QK "v_mfma_i32_32x32x32_i8"
+#define W64_CVT "v_cvt_pk_f16_f32"
+#define W64_KERNEL fa_fwd_w64_i8f8
+#include "fa_fwd16_w64_kernel.inc"
+#undef W64_T
+#undef W64_MFMA
+#undef W64_MFMA_QK
+#undef W64_CVT
+#undef W64_KERNEL
+#undef W64_F8
 #undef W64_I8
 #undef W64_BODY_INC
 
@@ -240,6 +260,7 @@ hipError_t launch_fwd_w64_i8(const FwdParams& p, const QuantViews& v, float* par
     if (!fwd_w64_i8_supported(p) || !part_buf || !part_cnt || v.dpq != 128) return hipErrorNotSupported;
     W64I8Params wp;
     wp.q8 = v.q8; wp.k8 = v.k8; wp.v16 = (const _Float16*)v.v16;
+    wp.v8 = v.v8; wp.v_e8 = v.v_e8;
     wp.q_scale = v.q_scale; wp.k_scale = v.k_scale;
     wp.o = p.o; wp.lse = p.lse;
     wp.B = p.B; wp.H = p.H; wp.Sq = p.Sq; wp.Skv = p.Skv; wp.nqblk = v.nqblk; wp.nkblk = v.nkblk;
@@ -251,12 +272,15 @@ hipError_t launch_fwd_w64_i8(const FwdParams& p, const QuantViews& v, float* par
     wp.tau = w64_tau();
     const uint32_t grid = w64_grid(p);
     const size_t lds = 65536 + 4 * 32 * (512 + 16);
-    auto kfn = p.causal ? fa_fwd_w64_i8<float, true> : fa_fwd_w64_i8<float, false>;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[p.causal ? 1 : 0]) {
+    const bool f8 = v.v8 != nullptr;
+    auto kfn = f8 ? (p.causal ? fa_fwd_w64_i8f8<float, true> : fa_fwd_w64_i8f8<float, false>)
+                  : (p.causal ? fa_fwd_w64_i8<float, true> : fa_fwd_w64_i8<float, false>);
+    static bool attr_set[4] = {false, false, false, false};
+    const int ai = (f8 ? 2 : 0) + (p.causal ? 1 : 0);
+    if (!attr_set[ai]) {
         hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set[p.causal ? 1 : 0] = true;
+        attr_set[ai] = true;
     }
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, stream, wp);
     return hipGetLastError();

@@ -33,6 +33,8 @@ struct QuantParams {
     int8_t* q8;           // [B*H*Sq][DPQ]
     int8_t* k8;           // [B*H*Skv][DPQ]
     _Float16* v16;        // [B*H*Skv][DPQ] (rows zero-padded like Q/K)
+    uint8_t* v8;          // fp8 P V mode (quant_mode 3, D = 128): V as e4m3 [B*H][tile][8192] in MFMA operand order, else NULL
+    uint32_t* v_e8;       // ... and the tile's power-of-two scale as an E8M0 byte replicated four times
     float* f32[3];        // optional fake-quantised fp32 copies (backward), [rows][D]
     float* scale[3];      // per (bh, block)
     uint32_t rows[3];     // Sq, Skv, Skv
@@ -48,9 +50,19 @@ struct QuantParams {
 // 16-byte loads into registers (8 elements per chunk, <= 8 chunks per thread), reduced to its absmax through
 // wave shuffles + 4 LDS words, then quantised from the registers and written with 8-byte (int8 Q/K) or
 // 16-byte (fp16 V) stores -- HBM-bound: every input byte is read once (twice in tensor-wise mode).
+// fp8 V image (fa_fwd_w64_i8f8, tools/gen_w64_body.py "fp8 variant"): byte offset inside the 8-KiB image of a 64-key tile of
+// element (key kk < 64, d < 128).  A-operand order of v_mfma_scale_f32_32x32x64_f8f6f4 matched to the packed P^T:
+// k-slot 32 h + j of lane (d % 32, h) is key (j & 3) + 8 ((j >> 2) & 3) + 4 h + 32 (j >> 4); the two 16-byte halves of a
+// lane's 32 bytes are stored 1 KiB apart so that each ds_read_b128 of a wave is one contiguous KiB.
+__device__ __forceinline__ int v8_off(int kk, int d) {
+    const int k32 = kk & 31, h = (k32 >> 2) & 1, b = (k32 & 3) + 4 * (k32 >> 3);
+    return (d >> 5) * 2048 + (kk >> 5) * 1024 + (32 * h + (d & 31)) * 16 + b;
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void quantize_kernel(QuantParams p) {
     __shared__ float red[4];
+    __shared__ __attribute__((aligned(16))) unsigned char v8img[8192];
     constexpr int MAXC = 8;  // chunks per thread: 64 rows * (256 / 8) chunks / 256 threads
     uint32_t id = blockIdx.x;
     int t = 0;
@@ -103,6 +115,42 @@ __global__ __launch_bounds__(256) void quantize_kernel(QuantParams p) {
         if (tid == 0) p.scale[t][bh * p.nblk[t] + blk] = sc;
     } else {
         sc = p.scale[t][bh * p.nblk[t] + blk];
+    }
+    if (MODE == 2 && t == 2 && p.v8) {
+        // fp8 P V mode: V / 2^e as e4m3 (round to nearest even), 2^e the smallest power of two with absmax / 2^e <= 448
+        // -- a power-of-two scale costs a floating-point format nothing and rides in the MFMA's E8M0 scale operand
+        int e = 0;
+        if (amax > 0.0f) {
+            (void)frexpf(amax * (1.0f / 448.0f), &e);   // amax / 448 = f * 2^e, f in [0.5, 1)  =>  2^e >= amax / 448
+            e = e < -126 ? -126 : e;
+        }
+        const float inv = __builtin_amdgcn_ldexpf(1.0f, -e);
+        if (tid == 0) {
+            const uint32_t byte = (uint32_t)(e + 127) & 0xffu;
+            p.v_e8[bh * p.nblk[2] + blk] = byte * 0x01010101u;
+            p.scale[2][bh * p.nblk[2] + blk] = __builtin_amdgcn_ldexpf(1.0f, e);
+        }
+        *(i32x4*)(v8img + tid * 32) = i32x4{0, 0, 0, 0};        // rows past Skv stay fp8 zero: 0 * P, never NaN * 0
+        *(i32x4*)(v8img + tid * 32 + 16) = i32x4{0, 0, 0, 0};
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const uint32_t ch = tid + 256 * c;
+            if (ch < nchunks) {
+                const int r = (int)(ch / cpr), d0 = (int)(ch % cpr) * 8;
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    const unsigned w = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(x[c][j] * inv, x[c][j + 1] * inv, 0, false);
+                    v8img[v8_off(r, d0 + j)] = (unsigned char)(w & 0xff);
+                    v8img[v8_off(r, d0 + j + 1)] = (unsigned char)((w >> 8) & 0xff);
+                }
+            }
+        }
+        __syncthreads();
+        uint8_t* dst = p.v8 + ((int64_t)bh * p.nblk[2] + blk) * 8192;
+        *(i32x4*)(dst + tid * 16) = *(const i32x4*)(v8img + tid * 16);
+        *(i32x4*)(dst + 4096 + tid * 16) = *(const i32x4*)(v8img + 4096 + tid * 16);
+        return;
     }
     const int64_t orow0 = (int64_t)bh * p.rows[t] + row0;
 #pragma unroll
@@ -448,6 +496,7 @@ static WsLayout ws_layout(uint32_t B, uint32_t H, uint32_t Sq, uint32_t Skv, uin
     w.sq = off; off = align256(off + BH * nqb * 4);
     w.sk = off; off = align256(off + BH * nkb * 4);
     w.sv = off; off = align256(off + BH * nkb * 4);
+    off = align256(off + BH * nkb * 4);  // fp8 P V mode: the V tiles' E8M0 scale words behind the fp32 scales
     w.f32q = w.f32k = w.f32v = 0;
     if (want_f32) {
         w.f32q = off; off = align256(off + BH * Sq * D * 4);
@@ -491,6 +540,12 @@ hipError_t launch_quantize(const void* q, const void* k, const void* v, int in_p
     qp.qlo = bits == 4 ? -8 : -128;
     qp.qhi = bits == 4 ? 7 : 127;
     const uint32_t grid = qp.BH * (qp.nblk[0] + qp.nblk[1] + qp.nblk[2]);
+    const bool f8v = quant_mode == 3 && D == 128 && bits == 8 && !want_f32;  // fp8 P V mode: block-wise Q / K + the fp8 V image
+    if (f8v) {
+        qp.v8 = (uint8_t*)(ws + w.v16);       // the fp16 V region holds the (half as large) fp8 image instead
+        qp.v_e8 = (uint32_t*)(ws + w.sv + (size_t)align256(qp.BH * qp.nblk[2] * 4));
+    }
+    if (quant_mode == 3) quant_mode = 2;
     if (quant_mode == 2) {
         hipLaunchKernelGGL(quantize_kernel<2>, dim3(grid), dim3(256), 0, stream, qp);
     } else {
@@ -501,6 +556,7 @@ hipError_t launch_quantize(const void* q, const void* k, const void* v, int in_p
     }
     if (views) {
         views->q8 = qp.q8; views->k8 = qp.k8; views->v16 = qp.v16;
+        views->v8 = qp.v8; views->v_e8 = qp.v_e8;
         views->q_scale = qp.scale[0]; views->k_scale = qp.scale[1]; views->v_scale = qp.scale[2];
         views->qf = qp.f32[0]; views->kf = qp.f32[1]; views->vf = qp.f32[2];
         views->nqblk = qp.nblk[0]; views->nkblk = qp.nblk[1]; views->dpq = qp.DPQ;
@@ -535,6 +591,9 @@ static hipError_t launch_i8_flags(const I8FwdParams& p, bool causal, hipStream_t
 hipError_t launch_quantized_fwd(const FwdParams& fp, int bits, int quant_mode, void* workspace, hipStream_t stream,
                                 const char** name) {
     if (!quantized_supported(fp.D)) return hipErrorInvalidValue;
+    // quant_mode 3 (fp8 P V, opt-in): only the 64-rows-per-wave kernel implements it; every other case runs the
+    // block-wise int8 path (mode 2), which is the more accurate of the two
+    if (quant_mode == 3 && !(bits == 8 && fp.part_buf && fp.part_cnt && fwd_w64_i8_supported(fp))) quant_mode = 2;
     QuantViews v;
     hipError_t e = launch_quantize(fp.q, fp.k, fp.v, fp.in_prec, fp.B, fp.H, fp.Sq, fp.Skv, fp.D, bits, quant_mode,
                                    workspace, false, &v, stream);
@@ -550,7 +609,7 @@ hipError_t launch_quantized_fwd(const FwdParams& fp, int bits, int quant_mode, v
     p.scale = fp.scale;
     const uint32_t dp = dp_of(fp.D);
     if (fp.part_buf && fp.part_cnt && fwd_w64_i8_supported(fp)) {
-        *name = bits == 4 ? "fa_fwd_w64_i4<128>" : "fa_fwd_w64_i8<128>";
+        *name = v.v8 ? "fa_fwd_w64_i8f8<128>" : bits == 4 ? "fa_fwd_w64_i4<128>" : "fa_fwd_w64_i8<128>";
         return launch_fwd_w64_i8(fp, v, fp.part_buf, fp.part_cnt, stream);
     }
     if (dp == 64) { *name = bits == 4 ? "fa_fwd_i4<64>" : "fa_fwd_i8<64>"; return launch_i8_flags<64>(p, fp.causal, stream); }

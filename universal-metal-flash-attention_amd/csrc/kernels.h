@@ -71,6 +71,8 @@ struct QuantViews {
     const int8_t* q8;       // [B*H*Sq][dpq] int8 (rows zero-padded to dpq)
     const int8_t* k8;       // [B*H*Skv][dpq]
     const void* v16;        // [B*H*Skv][D] fp16, de-quantised (q_v * s_v)
+    const uint8_t* v8;      // quant_mode 3 only: V as fp8 e4m3 [B*H][tile][8192] in MFMA operand order, else NULL
+    const uint32_t* v_e8;   // quant_mode 3 only: per-tile power-of-two scale (E8M0 byte x 4)
     const float* q_scale;   // [B*H][nqblk]
     const float* k_scale;   // [B*H][nkblk]
     const float* v_scale;

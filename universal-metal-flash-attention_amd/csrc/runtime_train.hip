@@ -134,7 +134,8 @@ int32_t mfa_quantized_forward_with_lse(mfa_context_t context, mfa_buffer_t q, mf
     if (nq == 0 || nkv == 0) return MFA_SUCCESS;
     if (!quantized_supported(D) || !(softmax_scale > 0.0f)) return MFA_ERROR_INVALID_ARGS;
     const int bits = target_precision == MFA_PRECISION_INT4 ? 4 : 8;  // unknown raw value -> INT8 (:267)
-    const int mode = quant_mode == 2 ? 2 : 0;                        // default tensor-wise (:268-272)
+    // default tensor-wise (:268-272); 3 = UMFA_QUANT_BLOCKWISE_FP8PV (additive, include/umfa_abi.h): block-wise int8 Q / K, fp8 P V
+    const int mode = quant_mode == 2 ? 2 : quant_mode == 3 ? 3 : 0;
 
     void* ws = ctx->pool(pool_dev, stream).workspace.ensure(quant_workspace_bytes(B, H, Sq, Skv, D, false), stream);
     if (!ws) return MFA_ERROR_MEMORY_ALLOCATION;
@@ -184,7 +185,7 @@ mfa_error_t umfa_quantized_forward_stream(mfa_context_t context, void* stream, c
     if ((size_t)B * H * Sq * Skv == 0) return MFA_SUCCESS;
     if (!quantized_supported(D) || !(softmax_scale > 0.0f)) return MFA_ERROR_INVALID_ARGS;
     const int bits = target_precision == MFA_PRECISION_INT4 ? 4 : 8;
-    const int mode = quant_mode == 2 ? 2 : 0;
+    const int mode = quant_mode == 2 ? 2 : quant_mode == 3 ? 3 : 0;
     std::lock_guard<std::mutex> lock(ctx->mu);  // pool lookup + launch; scratch is per (device, stream)
     const int pool_dev = stream_device((hipStream_t)stream);
     DeviceGuard guard(pool_dev);

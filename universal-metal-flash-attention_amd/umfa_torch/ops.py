@@ -59,6 +59,13 @@ def _mask_args(mask: Optional[torch.Tensor]):
     return (ctypes.c_void_p(mask.data_ptr()), _i64(mask.shape), _i64(mask.stride()), mask.dim(), mt, ms)
 
 
+def _quant_mode(name: str) -> int:
+    """"tensor" -> 0, "blockwise" -> 2 (the reference's two modes, MFABridge+Quantized.swift:268-272), "blockwise_fp8pv" -> 3:
+    UMFA_QUANT_BLOCKWISE_FP8PV, the MI355X fast mode (block-wise int8 Q K^T, fp8 e4m3 P and V on the 2x-rate MFMA)."""
+    n = name.lower()
+    return 3 if "fp8" in n else 2 if n.startswith("block") else 0
+
+
 def attention_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, scale: Optional[float] = None,
                       causal: bool = False, mask: Optional[torch.Tensor] = None, out_dtype=None,
                       return_lse: bool = False, intermediate_dtype=None, out: Optional[torch.Tensor] = None,
@@ -157,7 +164,7 @@ def quantized_attention_forward(q, k, v, *, scale=None, causal=False, mask=None,
     try:
         _check_error(_lib.mfa_quantized_forward_with_lse(
             context(), *(b.handle for b in bufs), B, Sq, Skv, H, D, float(scale), bool(causal),
-            4 if bits == 4 else 3, 2 if quant_mode.startswith("block") else 0, _PREC[q.dtype]))
+            4 if bits == 4 else 3, _quant_mode(quant_mode), _PREC[q.dtype]))
     finally:
         for b in bufs:
             b.close()
@@ -183,7 +190,7 @@ def quantized_attention_forward_stream(q, k, v, *, scale=None, causal=False, mas
     _check_error(_lib.umfa_quantized_forward_stream(
         context(), ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream), vp(q), vp(k), vp(v), vp(out),
         vp(lse), vp(m32), B, Sq, Skv, H, D, float(scale), bool(causal), 4 if bits == 4 else 3,
-        2 if quant_mode.startswith("block") else 0, _PREC[q.dtype]))
+        _quant_mode(quant_mode), _PREC[q.dtype]))
     return (out, lse) if return_lse else out
 
 
