@@ -405,10 +405,15 @@ def bench_int8(torch, umfa_torch, event_ms, med):
         bf = med(event_ms(lambda: umfa_torch.attention_forward(q, k, v, out=out), 20))
         kb = umfa_torch.last_kernel()
         i8 = med(event_ms(lambda: umfa_torch.quantized_attention_forward_stream(q, k, v), 20))
+        k8 = umfa_torch.last_kernel()
+        f8 = med(event_ms(lambda: umfa_torch.quantized_attention_forward_stream(q, k, v, quant_mode="blockwise_fp8pv"), 20))
         fl = 4.0 * Bx * Hx * Sx * Sx * D
         res[name] = {"bf16_ms": round(bf, 4), "int8_ms_incl_quantiser": round(i8, 4), "speedup": round(bf / i8, 3),
-                     "int8_TOPs": round(fl / i8 / 1e9, 1), "fp32_out": True, "bf16_kernel": kb, "int8_kernel": umfa_torch.last_kernel(),
-                     "timer": "HIP events on the launch stream, median of 20, both sides"}
+                     "int8_TOPs": round(fl / i8 / 1e9, 1), "fp32_out": True, "bf16_kernel": kb, "int8_kernel": k8,
+                     "fp8pv_ms_incl_quantiser": round(f8, 4), "fp8pv_speedup": round(bf / f8, 3), "fp8pv_kernel": umfa_torch.last_kernel(),
+                     "modes": "int8 = quant_mode 2, the reference's arithmetic (int8 Q K V block-wise, P and P V in fp16); fp8pv = quant_mode 3 "
+                              "(opt-in: int8 Q K^T, fp8 e4m3 P and V on the 2x-rate MFMA; rel-err in parity.cfg4_fp8pv)",
+                     "timer": "HIP events on the launch stream, median of 20, every side"}
         del q, k, v, out
     return res
 
@@ -460,6 +465,12 @@ def measure_parity(torch, umfa_torch):
     ref_q = oracle.sdpa_forward_rows(fake_quant(qs), fake_quant(ks), fake_quant(vs), rows)
     ref_x = oracle.sdpa_forward_rows(qs, ks, vs, rows)
     got = o8[:, hs][:, :, rows].cpu().numpy()
+    o3 = umfa_torch.quantized_attention_forward_stream(q, k, v, quant_mode="blockwise_fp8pv")
+    torch.cuda.synchronize()
+    got3 = o3[:, hs][:, :, rows].cpu().numpy()
+    ref3 = oracle.quantized_forward_fp8pv(qs, ks, vs, rows=rows)
+    res["cfg4_fp8pv_B1_H16_S8192"] = {"rel_vs_its_restatement_exact_P": parity.rel_err(got3, ref3), "rel_vs_exact_sdpa": parity.rel_err(got3, ref_x),
+                                      "rel_vs_int8_oracle": parity.rel_err(got3, ref_q), "kernel": umfa_torch.last_kernel(), "heads": hs, "rows": int(rows.size)}
     res["cfg4_int8_blockwise_B1_H16_S8192"] = {"rel_vs_quantized_oracle": parity.rel_err(got, ref_q), "rel_vs_exact_sdpa": parity.rel_err(got, ref_x),
                                                "quantisation_itself": parity.rel_err(ref_q, ref_x), "kernel": umfa_torch.last_kernel(),
                                                "heads": hs, "rows": int(rows.size)}

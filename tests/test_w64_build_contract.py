@@ -52,8 +52,12 @@ def test_compiler_stays_in_the_lower_register_halves(asm):
     for name, lines in kernels.items():
         in_asm, vmax, amax, n_mfma, loop_scratch = False, 0, 0, 0, 0
         mfma_seen = 0
+        depth = 0  # loop depth of the current basic block, from the label comments ("in Loop: Header=... Depth=N")
         total_mfma = sum("v_mfma" in l for l in lines)
         for l in lines:
+            if re.match(r"^\.LBB\d+_\d+:", l):
+                m = re.search(r"Depth=(\d+)", l)
+                depth = int(m.group(1)) if m else 0
             if "ASMSTART" in l:
                 in_asm = True
             elif "ASMEND" in l:
@@ -69,12 +73,13 @@ def test_compiler_stays_in_the_lower_register_halves(asm):
                     amax = max(amax, int(m))
                 for a, b in re.findall(r"\ba\[(\d+):(\d+)\]", l):
                     amax = max(amax, int(b))
-                if "scratch_" in l and 0 < mfma_seen < total_mfma:
+                # the tile loop is the depth-2 loop (depth 1 = the workgroup's segments: prologue, drain, output, fold)
+                if "scratch_" in l and depth >= 2:
                     loop_scratch += 1
         assert total_mfma >= 150, (name, total_mfma)          # 8 tile-body variants of 16-64 inline-asm MFMAs each
         lim = 95 if "i8f8" in name else 127  # the fp8 kernel also owns v[96:127] / a[96:127] (amdgpu_num_vgpr(96))
         assert vmax <= lim and amax <= lim, (name, vmax, amax)  # the compiler never names our registers
-        assert loop_scratch == 0, (name, loop_scratch)          # no scratch spill between the first and the last MFMA
+        assert loop_scratch == 0, (name, loop_scratch)          # no scratch traffic inside the tile loop
 
 
 def test_every_kernel_gets_512_registers(asm):

@@ -44,6 +44,15 @@ class Lib:
             B, Sq, k.shape[2], H, D, float(D) ** -0.5, bool(causal), prec[q.dtype], prec[q.dtype])
         assert rc == 0, (self.name, rc)
 
+    def qforward(self, q, k, v, out, causal, mode):
+        B, H, Sq, D = q.shape
+        prec = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}
+        rc = self.lib.umfa_quantized_forward_stream(
+            self.ctx, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), ctypes.c_void_p(q.data_ptr()),
+            ctypes.c_void_p(k.data_ptr()), ctypes.c_void_p(v.data_ptr()), ctypes.c_void_p(out.data_ptr()), None, None,
+            B, Sq, k.shape[2], H, D, float(D) ** -0.5, bool(causal), 3, mode, prec[q.dtype])
+        assert rc == 0, (self.name, rc)
+
     def kernel(self):
         return self.lib.umfa_last_kernel_name(self.ctx).decode()
 
@@ -57,6 +66,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=12)
     ap.add_argument("--inner", type=int, default=20)
     ap.add_argument("--parity", action="store_true")
+    ap.add_argument("--quant", type=int, default=0, help="2 / 3: time umfa_quantized_forward_stream with that quant_mode (fp32 O)")
     ap.add_argument("libs", nargs="+")
     a = ap.parse_args()
     B, H, S, D = (int(x) for x in a.shape.split(","))
@@ -65,6 +75,10 @@ def main():
     q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=torch.float32).to(dt) for _ in range(3))
     out = torch.empty(B, H, S, D, device="cuda", dtype=dt if a.out == "same" else torch.float32)
     libs = [Lib(*s.split("=", 1)) for s in a.libs]
+    if a.quant:
+        out = torch.empty(B, H, S, D, device="cuda", dtype=torch.float32)
+        for L in libs:
+            L.forward = (lambda q_, k_, v_, o_, c_, L=L: L.qforward(q_, k_, v_, o_, c_, a.quant))
     for L in libs:
         for _ in range(5):
             L.forward(q, k, v, out, a.causal)

@@ -26,10 +26,16 @@ from pathlib import Path
 # output path so a variant library can be built beside the real one
 ABL = set(filter(None, os.environ.get("W64_ABL", "").split(",")))
 
-BUDGET = int(os.environ.get("W64_BUDGET", "24"))   # issue cycles available beside one MFMA
+BUDGET = int(os.environ.get("W64_BUDGET", "28"))   # issue cycles available beside one MFMA
 VR_EARLY, VR_LATE = (int(x) for x in os.environ.get("W64_VREAD", "10,6").split(","))   # V fragment read: gaps before its MFMA
 KR_EARLY, KR_LATE = (int(x) for x in os.environ.get("W64_KREAD", "12,8").split(","))   # K fragment read
 MIDBAR = os.environ.get("W64_MIDBAR", "0") == "1"  # per-tile barrier in the middle of the PV phase (see mid_barrier_streams)
+# issue cycles of fillers placed BEFORE the first MFMA of a tile body: that MFMA waits for K fragments read right behind
+# the tile's barrier (LDS latency, ~150 cycles); softmax work of the previous tile runs in that shadow instead of behind it
+PRE = {"16": int(os.environ.get("W64_PRE", "0")), "i8": int(os.environ.get("W64_PRE_I8", "0")), "f8": int(os.environ.get("W64_PRE_F8", "0"))}
+ROTATE = int(os.environ.get("W64_LAB_ROTATE", "0"))  # lab, TIMING ONLY (results wrong): steady-state bodies start with their last ROTATE gaps
+GAPSTAMP = [int(x) for x in os.environ.get("W64_LAB_GAPSTAMP", "").split(",") if x]  # lab: clock stamps in front of these gaps (steady-state parts)
+SPEC = os.environ.get("W64_SPEC", "1") == "1"  # steady-state tiles: e = s*c - m against the CURRENT reference first, row max of e, cheap decision (spec_streams)
 EARLY_MAX = os.environ.get("W64_EARLY_MAX", "1") == "1"  # row max of key-block 0 during the QK of key-block 1, e = s*c - m spread to the end
 class Cfg:
     """16-bit kernels: S = K Q^T is 32 MFMAs (8 k-steps of 16); int8 kernel (fa_fwd_w64_i8): 16 MFMAs
@@ -51,14 +57,17 @@ class Cfg:
         self.KDMA = 2 if i8 else 4       # 1-KiB LDS-DMA pieces of a K tile per wave
         self.VDMA = 2 if f8 else 4       # ... of a V tile
         self.KB_BYTES = 4096 if i8 else 8192  # LDS bytes of one 32-key block of the K tile image
-        self.budget = int(os.environ.get("W64_BUDGET_F8", "40")) if f8 else BUDGET
+        # per-gap filler budget (cost-model cycles).  The tile's filler work must FIT: what does not is forced into its deadline
+        # gap, and the int8 body had 248 cycles piled into gap 45, the bf16 body 128 into gap 61 -- right in front of the
+        # tile's barrier, where nothing overlaps them (gap stamps, profiles/r2/lab_notes.md).  Defaults = total / gaps, rounded up.
+        self.budget = int(os.environ.get("W64_BUDGET_F8", "40")) if f8 else int(os.environ.get("W64_BUDGET_I8", "36")) if i8 else BUDGET
 
     def pv_gap(self, qb, db):
         """gap slot of the fp8 PV MFMA of (q-block, d-block); db = 4: the row-sum MFMA of the q-block"""
         return self.NQK + 10 * qb + 2 * db
 
 
-COST = {"CVT8": 4, "VREAD8": 8, "UPDK": 4, "UPDV": 4, "BAR": 16, "KPRE": 4, "I2F": 4, "MASK": 8, "DMAK": 8, "DMAV": 8, "NOP": 32, "EXP": 8, "ADD": 4, "CVT": 4, "VREAD": 8, "KREAD": 4, "MAX": 4, "DEC": 44, "FMA": 4}
+COST = {"DEC2": 20, "MXINIT": 8, "MAXE": 4, "CVT8": 4, "VREAD8": 8, "UPDK": 4, "UPDV": 4, "BAR": 16, "KPRE": 4, "I2F": 4, "MASK": 8, "DMAK": 8, "DMAV": 8, "NOP": 32, "EXP": 8, "ADD": 4, "CVT": 4, "VREAD": 8, "KREAD": 4, "MAX": 4, "DEC": 44, "FMA": 4}
 for _kv in filter(None, os.environ.get("W64_COST", "").split(",")):  # lab: W64_COST=EXP:16,ADD:4 overrides the model
     COST[_kv.split(":")[0]] = int(_kv.split(":")[1])
 
@@ -226,6 +235,14 @@ def op_text(R, op):
         return "" if NOUPD else f"vdma[{op[1]}] += v_step;"
     if kind == "DEC":
         return "W64_DECIDE();"
+    if kind == "DEC2":
+        return "W64_DECIDE2();"
+    if kind == "MXINIT":
+        return "mx[0][0] = mx[0][1] = mx[1][0] = mx[1][1] = neg_inf;"
+    if kind == "MAXE":  # row max of e = s*c - m (after the FMA): always the accumulating form, mx starts at -inf
+        _, kb, qb, r = op
+        v = base(R.new, kb, qb) + r
+        return f'asm volatile("v_max3_f32 %0, %0, v{v}, v{v + 1}" : "+v"(mx[{qb}][{(r >> 1) & 1}]));'
     if kind == "NOP":
         return 'asm volatile("s_nop 15\\n\\ts_nop 15");  // MFMA result -> VALU read distance when no MFMA follows'
     if kind == "FMA":
@@ -426,11 +443,44 @@ def start_streams(have_new, mfma_follows=True, masked=False):
     return streams
 
 
-def schedule(streams, gaps):
-    """EDF under a per-gap budget.  streams: list of [ (op, earliest, deadline) ... ] each consumed in order."""
+def spec_streams(masked):
+    """Steady-state tiles, speculative order: the reference max m of the PREVIOUS tiles is known when the tile starts, so
+    e = s*c - m is applied to a score block as soon as its MFMAs are done (no wait for this tile's row max), the row max
+    is taken of e (monotone in s), and the per-tile decision shrinks to "any e above tau?" (W64_DECIDE2).  Only when it
+    fires (rare) the includer moves the reference and shifts the stored e by the difference (fix_e_*).  The old order
+    (max of the raw scores -> full decision -> fma) put a ~25-instruction dependent chain plus all 64 fmas behind the
+    last score MFMA: 40-56 us of 356-432 at B1 H16 S8192 in the int8 kernels (timing-only ablations, lab notes r2).
+    One ordered stream per score block: (int8 convert ->) (mask ->) fma of a register pair, its max one pair later."""
+    last = C.NG - 1
+    dec_at = last - 1
+    streams = [[(("MXINIT",), 0, max(1, C.HALF - 2))]]
+    for kb in (0, 1):
+        ready = kb * C.HALF + C.HALF
+        for qb in (0, 1):
+            st, dl = ready + qb, dec_at - 1
+            ops = []
+            if C.i2f:
+                ops += [(("I2F", kb, qb, r), st, dl) for r in range(16)]
+            if masked:
+                ops += [(("MASK", kb, qb, r), st, dl) for r in range(16)]
+            pend = None
+            for r in range(0, 16, 2):
+                ops += [(("FMA", kb, qb, r), st, dl), (("FMA", kb, qb, r + 1), st, dl)]
+                if pend is not None:
+                    ops.append((("MAXE", kb, qb, pend), st, dl))
+                pend = r
+            ops.append((("MAXE", kb, qb, pend), st, dl))
+            streams.append(ops)
+    streams.append([(("DEC2",), dec_at, dec_at)])
+    return streams
+
+
+def schedule(streams, gaps, pre_budget=0):
+    """EDF under a per-gap budget.  streams: list of [ (op, earliest, deadline) ... ] each consumed in order.
+    Returns gaps + 1 lists: the first is the pre-slot (fillers ahead of MFMA 0, budget pre_budget, ops runnable at gap 0)."""
     BUDGET = C.budget
     pos = [0] * len(streams)
-    out = [[] for _ in range(gaps)]
+    out = [[] for _ in range(gaps + 1)]
     # a stream is consumed in order, so an op inherits the tightest deadline of everything queued behind it
     tight = []
     for st_ in streams:
@@ -440,7 +490,11 @@ def schedule(streams, gaps):
                 t[k] = (t[k][0], t[k][1], t[k + 1][2])
         tight.append(t)
     streams = tight
-    for g in range(gaps):
+    for slot in range(gaps + 1):
+        g = max(0, slot - 1)          # slot 0 = the pre-slot: what may run at gap 0, nothing forced
+        BUDGET = pre_budget if slot == 0 else C.budget
+        if slot == 0 and pre_budget <= 0:
+            continue
         used = 0
         while True:
             best = None
@@ -448,13 +502,13 @@ def schedule(streams, gaps):
                 if pos[si] >= len(s):
                     continue
                 op, earliest, deadline = s[pos[si]]
-                if earliest > g:
+                if earliest > g or (slot == 0 and op[0] not in ("EXP", "CVT", "CVT8", "ADD", "MXINIT")):
                     continue
                 remaining = sum(COST[o[0][0]] for o in s[pos[si]:])
                 # how far this stream is behind an even spread up to its last deadline
                 last_dl = min(gaps - 1, max(d for _, _, d in s[pos[si]:]))
                 need_rate = remaining / max(1, (last_dl - g + 1))
-                forced = deadline <= g
+                forced = deadline <= g and slot > 0
                 key = (0 if forced else 1, -need_rate)
                 if best is None or key < best[0]:
                     best = (key, si, forced)
@@ -467,7 +521,7 @@ def schedule(streams, gaps):
                 break
             if not forced and used >= BUDGET:
                 break
-            out[g].append(op)
+            out[slot].append(op)
             used += c
             pos[si] += 1
     for si, s in enumerate(streams):
@@ -475,11 +529,13 @@ def schedule(streams, gaps):
     return out
 
 
-def check_part(placed, have_new, have_old, masked):
+def check_part(placed, have_new, have_old, masked, pre=()):
     """Data-flow self-check of one scheduled part (gap g = after MFMA g): every consumer sits behind its producer.
     (A schedule that packed a P fragment one gap late shows up on the GPU as garbage in exactly the O^T blocks whose
     MFMAs came first - cost a long bisect once.)"""
     pos = {}
+    for k, op in enumerate(pre):
+        pos[op] = (-1, k)
     for g, ops in enumerate(placed):
         for k, op in enumerate(ops):
             pos[op] = (g, k)
@@ -521,7 +577,19 @@ def check_part(placed, have_new, have_old, masked):
                     st = 2 * kb + (r >> 3)
                     first_use = C.NQK + 8 * st  # first PV MFMA of this 16-key step (any d-block, any q-block)
                     assert pos[cv][0] < first_use, ("P fragment packed after its first PV MFMA", cv, pos[cv], first_use)
-            if have_new:
+            if have_new and ("DEC2",) in pos:
+                last_mfma = kb * C.HALF + (C.HALF - 2) + qb
+                for r in range(16):
+                    f = ("FMA", kb, qb, r)
+                    assert pos[f][0] > last_mfma, ("fma on an unfinished score tile", f)
+                    assert before(("MXINIT",), ("MAXE", kb, qb, r & ~1)), ("row max before its -inf start", kb, qb, r)
+                    assert before(f, ("MAXE", kb, qb, r & ~1)), ("row max of e before the fma", f)
+                    assert before(("MAXE", kb, qb, r & ~1), ("DEC2",)), ("decision before the row max", kb, qb, r)
+                    if masked:
+                        assert before(("MASK", kb, qb, r), f) and pos[("MASK", kb, qb, r)][0] > last_mfma, ("mask order", kb, qb, r)
+                    if C.i2f:
+                        assert before(("I2F", kb, qb, r), f) and pos[("I2F", kb, qb, r)][0] > last_mfma, ("convert order", kb, qb, r)
+            elif have_new:
                 last_mfma = kb * C.HALF + (C.HALF - 2) + qb
                 for r in range(0, 16, 2):
                     mxop = [o for o in pos if o[0] == "MAX" and o[1:4] == (kb, qb, r)][0]
@@ -591,18 +659,30 @@ def emit_part(lines, R, have_new, have_old, masked=False):
         streams += exp_streams()
         streams.append(vread_stream(have_new))
     if have_new:
-        streams += start_streams(True, have_old, masked)
+        streams += spec_streams(masked) if (SPEC and have_old) else start_streams(True, have_old, masked)
         streams.append(kread_stream())
         dmas = dma_stream()
         streams.append(dmas)
         streams.append(dma_update_stream(dmas))
         if MIDBAR:
             streams += mid_barrier_streams(have_old)
-    placed = schedule(streams, C.NG)
+    pre_budget = PRE["f8" if C.f8 else "i8" if C.i8 else "16"] if (have_new and have_old) else 0
+    slots = schedule(streams, C.NG, pre_budget)
+    pre, placed = slots[0], slots[1:]
     if not ABL:
-        check_part(placed, have_new, have_old, masked)
+        check_part(placed, have_new, have_old, masked, pre)
+    for op in pre:
+        if op[0] not in ABL:
+            lines.append("    " + op_text(R, op))
+    if pre:
+        lines.append(f"__builtin_amdgcn_sched_barrier(0);  // pre-slot: {sum(COST[o[0]] for o in pre)} cyc of fillers ahead of the first MFMA")
     cyc = 0
-    for g in range(C.NG):
+    order = list(range(C.NG))
+    if ROTATE and have_new and have_old:
+        order = order[C.NG - ROTATE:] + order[:C.NG - ROTATE]
+    for g in order:
+        if GAPSTAMP and have_new and have_old and g in GAPSTAMP:
+            lines.append(f"W64_GSTAMP({GAPSTAMP.index(g)});")
         if mf[g] is not None:
             lines.append(mf[g])
         for op in placed[g]:
@@ -645,6 +725,18 @@ def emit_helpers(lines):
                   f' "v_accvgpr_read_b32 %2, a{rr + 2}\\n\\tv_accvgpr_read_b32 %3, a{rr + 3}"'
                   f' : "=v"(o[{r}]), "=v"(o[{r + 1}]), "=v"(o[{r + 2}]), "=v"(o[{r + 3}]));')
             a("    }")
+        a("}")
+
+
+def emit_helpers_fix(lines):
+    """Rare path of the speculative order: the reference max moved, shift the stored e = s*c - m of the NEW score set."""
+    a = lines.append
+    for setname in ("a", "b"):
+        a(f"// e += d (d = old reference - new reference <= 0) on every score register of set {setname.upper()}: q-block 0 with d0, 1 with d1")
+        a(f"__device__ __forceinline__ void fix_e_{setname}(float d0, float d1) {{")
+        for qb in (0, 1):
+            txt = " ".join(f'"v_add_f32 v{base(setname, kb, qb) + r}, v{base(setname, kb, qb) + r}, %0\\n\\t"' for kb in (0, 1) for r in range(16))
+            a(f'    asm volatile({txt} "s_nop 0" :: "v"(d{qb}));')
         a("}")
 
 
@@ -708,6 +800,7 @@ def main():
     csrc = Path(__file__).resolve().parent.parent / "universal-metal-flash-attention_amd" / "csrc"
     helpers = []
     emit_helpers(helpers)
+    emit_helpers_fix(helpers)
     emit_helpers_f8(helpers)
     (csrc / "fa_fwd16_w64_regs.inc").write_text("\n".join(helpers) + "\n")
     C = Cfg(False)

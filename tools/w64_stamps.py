@@ -8,10 +8,14 @@ import numpy as np
 import torch
 import umfa_torch
 B, H, S, D = (int(x) for x in sys.argv[1:5])
+MODE = sys.argv[5] if len(sys.argv) > 5 else "bf16"   # bf16 | blockwise | blockwise_fp8pv
 torch.manual_seed(0)
 q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
 for it in range(4):
-    o, lse = umfa_torch.attention_forward(q, k, v, return_lse=True)
+    if MODE == "bf16":
+        o, lse = umfa_torch.attention_forward(q, k, v, return_lse=True)
+    else:
+        o, lse = umfa_torch.quantized_attention_forward_stream(q, k, v, quant_mode=MODE, return_lse=True)
 torch.cuda.synchronize()
 raw = lse.cpu().numpy().view(np.uint64)[: 256 * 8].reshape(256, 8)
 ok = (raw[:, 1] > raw[:, 0]) & (raw[:, 1] - raw[:, 0] < 10**8) & (raw[:, 3] > raw[:, 2]) & (raw[:, 3] - raw[:, 2] < 10**10)
