@@ -212,6 +212,11 @@ __global__ __launch_bounds__(256, DP == 256 ? 1 : 2) void bwd16_dq_kernel(BwdPar
     };
     stage(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ... and once more as a builtin, for hipcc's own scoreboard: Q / dO fragments (loaded above, first used inside the
+    // loop) otherwise keep "s_waitcnt vmcnt(1) / vmcnt(0)" in front of the first MFMAs of EVERY tile -- right behind
+    // stage(t + 1), whose LDS-DMA loads the compiler does not see, so each tile waited for its successor's prefetch
+    // (tools/trace_waits.py; same mechanism as in fa_fwd16_w64)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
 
     for (uint32_t t = 0; t < ntiles; ++t) {
@@ -328,12 +333,22 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
     auto stage = [&](uint32_t t) {
         dma_rows<2 * TILE_PIECES, DP>(q_srd, lds0 + QT + (t & 1) * QTILE_B, t * QROWS, uw, lane);
         dma_rows<2 * TILE_PIECES, DP>(do_srd, lds0 + DOT + (t & 1) * QTILE_B, t * QROWS, uw, lane);
-        if (tid < QROWS) {  // row constants of the tile: L2 = LSE * log2e (+inf past Sq -> P = 0) and D
-            const uint32_t row = t * QROWS + tid;
-            const bool ok = row < p.Sq;
-            vec[(t & 1) * QROWS + tid] = ok ? p.lse[(int64_t)bh * p.Sq + row] * UMFA_LOG2E : INFINITY;
-            vec[2 * QROWS + (t & 1) * QROWS + tid] = ok ? p.dvec[(int64_t)bh * p.Sq + row] : 0.0f;
-        }
+    };
+    // Row constants of a tile (LSE and D of its 64 rows) ride with the tile: one LDS-DMA dword load each (wave 0: LSE,
+    // wave 1: D), waited for by the tile's own "s_waitcnt vmcnt(0)" + barrier.  As compiler-visible loads hipcc put
+    // "s_waitcnt vmcnt(0)" in front of their ds_write -- right behind the LDS-DMA issue, which it cannot see -- so wave 0
+    // waited for the whole prefetch at the top of every tile and the other waves for wave 0 at the barrier.
+    // Rows past Sq read 0 (descriptor range check): their Q and dO rows are zero too, so S = dP = 0, P = 1, dS = 0 and
+    // nothing reaches dK or dV.  LSE arrives in natural-log units; the factor log2(e) is applied where it is used.
+    const i32x4 lse_srd = make_srd(p.lse + (int64_t)bh * p.Sq, p.Sq * 4u), dv_srd = make_srd(p.dvec + (int64_t)bh * p.Sq, p.Sq * 4u);
+    auto stage_consts = [&](uint32_t t) {
+        const int voff = (int)(t * QROWS + (uint32_t)lane) * 4;
+        if (uw == 0)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
+                         ::"s"(lds0 + VEC + (t & 1) * QROWS * 4), "v"(voff), "s"(lse_srd) : "memory");
+        else if (uw == 1)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
+                         ::"s"(lds0 + VEC + 2 * QROWS * 4 + (t & 1) * QROWS * 4), "v"(voff), "s"(dv_srd) : "memory");
     };
     const int tr_qq = (lane >> 2) & 3, tr_pp = lane & 3, tr_g1 = (lane >> 4) & 1;
     // head_dim 256: dK and dV of all 8 d-blocks (256 accumulator registers) do not fit beside the K / V fragments (128),
@@ -347,12 +362,14 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[i][r] = 0.0f; dv[i][r] = 0.0f; }
 
-    if (t0 < ntiles) stage(t0);
+    if (t0 < ntiles) { stage(t0); stage_consts(t0); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // for the compiler's scoreboard too (K / V fragments are first used in the loop)
     __syncthreads();
 
     for (uint32_t t = t0; t < ntiles; ++t) {
         stage(t + 1);
+        stage_consts(t + 1);
         const char* Qt = smem + QT + (t & 1) * QTILE_B;
         const char* dOt = smem + DOT + (t & 1) * QTILE_B;
         const float* L2v = vec + (t & 1) * QROWS;
@@ -396,7 +413,7 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int r = 4 * g + e;
-                        float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], c, -l2[e]));
+                        float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], c, -l2[e] * UMFA_LOG2E));
                         if (edge && key > qb0 + 8 * g + 4 * hi + e) pr = 0.0f;
                         pb[r >> 3][r & 7] = (T)pr;
                         sb[r >> 3][r & 7] = (T)(pr * (dp[u][r] - dl[e]));
