@@ -227,6 +227,11 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
     auto stage_write = [&](int buf) {
         if constexpr (DMA) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA has landed (then the barrier)
+            // the same wait as a builtin keeps hipcc's scoreboard empty too: it cannot see the LDS-DMA loads, and with
+            // the Q fragment loads (issued before the loop, first used inside it) still "pending" in its model it put
+            // s_waitcnt vmcnt(3) ... vmcnt(0) in front of the first MFMAs of every tile -- right behind the issue of
+            // the next tile's LDS-DMA, i.e. every tile waited for its successor's prefetch (tools/trace_waits.py)
+            __builtin_amdgcn_s_waitcnt(0x0F70);
         } else {
 #pragma unroll
             for (int i = 0; i < LPT; ++i) {

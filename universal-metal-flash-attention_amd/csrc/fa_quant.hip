@@ -335,7 +335,8 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
             }
         }
     };
-    auto stage_write = [&](int) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+    // (the builtin repeats the wait for hipcc's scoreboard: see fa_fwd_16_kernel.h stage_write)
+    auto stage_write = [&](int) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_waitcnt(0x0F70); };
 
     uint32_t ntiles = (p.Skv + BN - 1) / BN;
     if (CAUSAL) {
