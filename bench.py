@@ -299,8 +299,8 @@ def run_rank(args) -> None:
         del fq, fk, fv
         return res
 
-    strong = sharded_leg(B, H, S, min(args.steps, 50)) if world > 1 else None
-    cfg5 = sharded_leg(1, 32, 32768, max(2, min(args.steps, 10 if world > 1 else 4)))
+    strong = sharded_leg(B, H, S, min(args.steps, 50)) if world > 1 and not args.headline_only else None
+    cfg5 = None if args.headline_only else sharded_leg(1, 32, 32768, max(2, min(args.steps, 10 if world > 1 else 4)))
 
     extra = {}
     if world == 1 and rank == 0 and not args.headline_only:
@@ -385,7 +385,8 @@ def run_rank(args) -> None:
         }
         if strong:
             line["strong"] = strong
-        line["cfg5"] = cfg5
+        if cfg5:
+            line["cfg5"] = cfg5
         line.update(extra)
         if world == 1 and not args.no_cpu_baseline and not args.headline_only:
             line["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
@@ -484,7 +485,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--headline-only", action="store_true", help="skip configs / int8 / parity / cpu_baseline (A/B runs)")
+    ap.add_argument("--headline-only", action="store_true", help="only the headline workload: no strong / cfg5 legs, no configs / int8 / parity / cpu_baseline (A/B and rocprof runs: "
+                         "every fa_fwd16_w64 dispatch of the process is then a FLUX launch)")
     ap.add_argument("--causal", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch the K timed steps eagerly instead of as one hipGraph")
     ap.add_argument("--launcher-selftest", action="store_true", help=argparse.SUPPRESS)
