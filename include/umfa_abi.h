@@ -332,6 +332,18 @@ mfa_error_t umfa_attention_forward_stream(
     mfa_mask_scalar_t mask_scalar_type, uint32_t batch_size, uint32_t seq_len_q,
     uint32_t seq_len_kv, uint32_t num_heads, uint16_t head_dim, float softmax_scale, bool causal,
     int32_t input_precision, int32_t intermediate_precision);
+
+/* MI355X extra: RoPE + SDPA in one in-stream call.  Replaces the reference's sequence of two rotary launches into dense
+ * Q_rot / K_rot copies and the attention encode after them (metal_sdpa_backend.cpp:1472-1641): K is rotated once into the
+ * stream's workspace, Q is rotated in registers behind the attention kernel's Q fragment load.  Bit-identical to the
+ * unfused sequence (rotate q, rotate k, attend).  cos / sin: fp32 [S, D] (table_batch_stride 0) or [B, S, D]
+ * (table_batch_stride S * D), pair-duplicated; seq_len_q == seq_len_kv, head_dim even; no mask. */
+mfa_error_t umfa_rope_attention_forward_stream(
+    mfa_context_t context, void* stream, const void* q, const int64_t* q_strides, const void* k,
+    const int64_t* k_strides, const void* v, const int64_t* v_strides, void* out, int32_t out_precision, float* lse,
+    const float* cos_table, const float* sin_table, int64_t table_batch_stride, uint32_t batch_size, uint32_t seq_len_q,
+    uint32_t seq_len_kv, uint32_t num_heads, uint16_t head_dim, float softmax_scale, bool causal,
+    int32_t input_precision, int32_t intermediate_precision);
 /* Name of the kernel variant the last forward on this context dispatched to (static string). */
 /* MI355X extra: the runtime quantiser alone, on a device tensor [batch_heads, rows, head_dim]; writes the int8 image
  * (rows padded to *padded_row_bytes = 64 / 128 / 256) and one fp32 scale per 64-row block to device buffers.  Exists so

@@ -43,17 +43,8 @@ __global__ __launch_bounds__(256) void rope_rotate_kernel(RopeParams p) {
         }
         const f32x4 c0 = *(const f32x4*)(p.cos_table + t), c1 = *(const f32x4*)(p.cos_table + t + 4);
         const f32x4 s0 = *(const f32x4*)(p.sin_table + t), s1 = *(const f32x4*)(p.sin_table + t + 4);
-        const float cs[4] = {c0[0], c0[2], c1[0], c1[2]};  // even entries only (MFABridge.swift:264-266)
-        float sn[4] = {s0[0], s0[2], s1[0], s1[2]};
         float y[8];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (p.negate_sin) sn[k] = -sn[k];
-            // no fma contraction: the reference computes x0*c - x1*sn with separately rounded products only if
-            // its compiler does not fuse either; either form is within 1 ulp of the fp64 value (tests allow 2 ulp)
-            y[2 * k] = x[2 * k] * cs[k] - x[2 * k + 1] * sn[k];
-            y[2 * k + 1] = x[2 * k + 1] * cs[k] + x[2 * k] * sn[k];
-        }
+        rope_rotate8(x, c0, c1, s0, s1, p.negate_sin != 0, y);  // shared with the fused Q load (fa_common.h)
         if constexpr (sizeof(T) == 2) {
             typedef T T8 __attribute__((ext_vector_type(8)));
             T8 o;

@@ -60,7 +60,47 @@ struct FwdParams {
     uint32_t mf_bs, mf_hs;         // flag-row strides of batch / head in units of (mf_nrb * mf_ntiles); 0 = broadcast
     uint32_t mf_nrb, mf_ntiles;    // 32-row blocks, 64-key tiles
     uint32_t win_left, win_right;  // MK_WINDOW: sliding window (in-stream entry, mask type 3); tile flags are arithmetic
+    // fused rotary embedding of Q (umfa_rope_attention_forward_stream): fp32 tables [Sq, D] (or [B, Sq, D] with
+    // rope_tb = Sq * D), pair-duplicated, applied to the Q fragments right after their load; K arrives already rotated
+    const float* rope_cos;
+    const float* rope_sin;
+    int64_t rope_tb;
 };
+
+// Interleaved-pair rotary rotation of 8 consecutive elements (4 pairs) given the 8 table entries of their columns
+// (only the even ones are read, MFABridge.swift:264-266).  ONE definition for the stand-alone rotate kernel (fa_aux.hip)
+// and for the fused Q load of the forward kernels: both then round identically (the fused path is checked bit-for-bit
+// against rotate-then-attend).  Products and sums are pinned (no contraction choice left to the compiler).
+__device__ __forceinline__ void rope_rotate8(const float (&x)[8], const f32x4& c0, const f32x4& c1, const f32x4& s0,
+                                             const f32x4& s1, bool negate_sin, float (&y)[8]) {
+    const float cs[4] = {c0[0], c0[2], c1[0], c1[2]};
+    float sn[4] = {s0[0], s0[2], s1[0], s1[2]};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (negate_sin) sn[k] = -sn[k];
+        y[2 * k] = __builtin_fmaf(x[2 * k], cs[k], -__fmul_rn(x[2 * k + 1], sn[k]));
+        y[2 * k + 1] = __builtin_fmaf(x[2 * k + 1], cs[k], __fmul_rn(x[2 * k], sn[k]));
+    }
+    // the fp32 results are final here: without this the fp16 instantiations fold the last FMA and the conversion into
+    // v_fma_mix{lo,hi}_f16 in one caller and not in the other (seen: ~1e-4 of the elements one fp16 ulp apart)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(y[j]));
+}
+
+// Q^T fragment (8 consecutive head-dim elements of one query row, 16-bit type T) rotated in registers
+template <typename T, typename V8>
+__device__ __forceinline__ V8 rope_fragment(V8 v, const float* __restrict__ cos_t, const float* __restrict__ sin_t, int64_t at) {
+    float x[8], y[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = (float)v[j];
+    const f32x4 c0 = *(const f32x4*)(cos_t + at), c1 = *(const f32x4*)(cos_t + at + 4);
+    const f32x4 s0 = *(const f32x4*)(sin_t + at), s1 = *(const f32x4*)(sin_t + at + 4);
+    rope_rotate8(x, c0, c1, s0, s1, false, y);
+    V8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (T)y[j];
+    return o;
+}
 
 struct BwdParams {
     const void* dout;

@@ -41,6 +41,9 @@ struct W64Params {
     float* part_buf;      // [2 * grid slots][wave 4][q-block 2][chunk 17][lane 64] x 16 bytes (see the kernel)
     uint32_t* part_cnt;   // [n_items % grid] arrival tickets, zero between launches (the folding part resets its own)
     float tau;            // deferred-max threshold (log2 units)
+    const float* rope_cos;  // fused rotary embedding of Q (FwdParams::rope_*), NULL = none
+    const float* rope_sin;
+    int64_t rope_tb;
 };
 
 // ---- asm-owned accumulator registers: helpers with literal register numbers (generated)
@@ -231,6 +234,18 @@ hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cn
     wp.part_buf = part_buf;
     wp.part_cnt = part_cnt;
     wp.tau = w64_tau();
+    wp.rope_cos = p.rope_cos; wp.rope_sin = p.rope_sin; wp.rope_tb = p.rope_tb;
+    if (p.rope_cos) {  // fused-RoPE instantiations exist for O in the operand type only (runtime.hip asks first)
+        if (p.out_prec != p.in_prec) return hipErrorNotSupported;
+        if (p.in_prec == P_BF16) {
+            *name = "fa_fwd16_w64<bf16,128,rope>";
+            return p.causal ? launch_w64_kernel(fa_fwd16_w64_bf16<__bf16, true, true>, p, wp, stream)
+                            : launch_w64_kernel(fa_fwd16_w64_bf16<__bf16, false, true>, p, wp, stream);
+        }
+        *name = "fa_fwd16_w64<fp16,128,rope>";
+        return p.causal ? launch_w64_kernel(fa_fwd16_w64_f16<_Float16, true, true>, p, wp, stream)
+                        : launch_w64_kernel(fa_fwd16_w64_f16<_Float16, false, true>, p, wp, stream);
+    }
     if (p.in_prec == P_BF16) {
         *name = "fa_fwd16_w64<bf16,128>";
         if (p.causal)

@@ -88,6 +88,8 @@ hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p,
         char* w64 = sc.ensure_w64(plan.cnt_bytes, plan.buf_bytes, stream);
         if (!w64) return hipErrorOutOfMemory;
         e = launch_fwd_w64(p, (float*)(w64 + sc.w64_cnt_bytes), (uint32_t*)w64, stream, &name);
+    } else if (p.rope_cos) {
+        return hipErrorNotSupported;  // only the 256-row kernel rotates Q in registers (the entry asks before it sets this)
     } else if (lowp && fwd_16_supported(p)) {
         FwdParams pp = p;
         const FwdSplitPlan plan = fwd_16_split_plan(p);
@@ -370,6 +372,76 @@ mfa_error_t umfa_attention_forward_stream(mfa_context_t context, void* stream, c
     DeviceGuard guard(dev);
     return rc_of(dispatch_forward(ctx, ctx->pool(dev, (hipStream_t)stream), p, dense_prec(intermediate_precision),
                                   (hipStream_t)stream));
+}
+
+// MI355X extra: RoPE + SDPA in one call (the reference's rope_scaled_dot_product_attention rotates Q and K into dense
+// copies with mfa_rope_rotate_encode_mtl and then attends, metal_sdpa_backend.cpp:1472-1641).  Here K is rotated ONCE
+// by the rotate kernel into the stream's workspace (every query block re-reads it: it must exist rotated), and Q is
+// rotated in registers right after the Q fragment load of the attention kernel -- the dense Q_rot round trip (one read
+// + one write of Q) and its launch are gone.  Bit-identical to rotate-then-attend (one shared rotation routine).
+// cos / sin: fp32 [S, D] (table_batch_stride = 0) or [B, S, D] (= S * D), pair-duplicated; Sq == Skv; no mask.
+mfa_error_t umfa_rope_attention_forward_stream(mfa_context_t context, void* stream, const void* q, const int64_t* q_strides,
+                                               const void* k, const int64_t* k_strides, const void* v,
+                                               const int64_t* v_strides, void* out, int32_t out_precision, float* lse,
+                                               const float* cos_table, const float* sin_table, int64_t table_batch_stride,
+                                               uint32_t batch_size, uint32_t seq_len_q, uint32_t seq_len_kv,
+                                               uint32_t num_heads, uint16_t head_dim, float softmax_scale, bool causal,
+                                               int32_t input_precision, int32_t intermediate_precision) {
+    Context* ctx = as_ctx(context);
+    if (!ctx || !q || !k || !v || !out || !cos_table || !sin_table) return MFA_ERROR_INVALID_ARGS;
+    if (head_dim == 0 || head_dim > 256 || (head_dim & 1) || seq_len_q != seq_len_kv) return MFA_ERROR_INVALID_ARGS;
+    FwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.B = batch_size; p.H = num_heads; p.Sq = seq_len_q; p.Skv = seq_len_kv; p.D = head_dim;
+    p.scale = softmax_scale;
+    p.causal = causal ? 1 : 0;
+    p.in_prec = dense_prec(input_precision);
+    p.out_prec = dense_prec(out_precision);
+    dense_strides(p, false, false, false, false);
+    auto take = [](int64_t* dst, const int64_t* src) -> bool {
+        if (!src) return true;
+        for (int i = 0; i < 4; ++i) dst[i] = src[i];
+        return src[3] == 1 && src[0] >= 0 && src[1] >= 0 && src[2] >= 0;
+    };
+    int64_t ks_in[4];
+    for (int i = 0; i < 4; ++i) ks_in[i] = p.ks[i];
+    if (!take(p.qs, q_strides) || !take(ks_in, k_strides) || !take(p.vs, v_strides)) return MFA_ERROR_INVALID_ARGS;
+    p.q = q; p.v = v; p.o = out; p.lse = lse;
+    const size_t nelem = (size_t)batch_size * num_heads * seq_len_kv * head_dim;
+    if (nelem == 0 || seq_len_q == 0) return MFA_SUCCESS;
+    hipStream_t st = (hipStream_t)stream;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    const int dev = stream_device(st);
+    DeviceGuard guard(dev);
+    StreamScratch& sc = ctx->pool(dev, st);
+    const size_t eb = elem_bytes(p.in_prec);
+    const bool lowp = p.in_prec != P_FP32 && dense_prec(intermediate_precision) != P_FP32;
+    FwdParams probe = p;  // dense K for the kernel-selection predicates
+    probe.k = k;
+    // in-kernel Q rotation: the 256-row kernel only, O in the operand type (fa_fwd16_w64.hip); everything else takes Q
+    // through the rotate kernel too (same result, one more pass)
+    const bool fuse_q = lowp && p.out_prec == p.in_prec && fwd_w64_supported(probe);
+    char* ws = (char*)sc.workspace.ensure((fuse_q ? 1 : 2) * nelem * eb + 512, st);
+    if (!ws) return MFA_ERROR_MEMORY_ALLOCATION;
+    RopeParams r;
+    memset(&r, 0, sizeof(r));
+    r.cos_table = cos_table; r.sin_table = sin_table; r.table_batch_stride = table_batch_stride;
+    r.B = batch_size; r.H = num_heads; r.S = seq_len_kv; r.D = head_dim;
+    r.src = k; r.dst = ws;
+    r.src_batch_stride = ks_in[0]; r.src_head_stride = ks_in[1]; r.src_seq_stride = ks_in[2];
+    if (launch_rope(r, p.in_prec, st) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+    p.k = ws;  // dense BHSD (dense_strides above)
+    if (fuse_q) {
+        p.rope_cos = cos_table; p.rope_sin = sin_table; p.rope_tb = table_batch_stride;
+    } else {  // fp32 / exact kernels take Q through the rotate kernel as well
+        char* qrot = ws + ((nelem * eb + 255) & ~(size_t)255);
+        r.src = q; r.dst = qrot; r.S = seq_len_q;
+        r.src_batch_stride = p.qs[0]; r.src_head_stride = p.qs[1]; r.src_seq_stride = p.qs[2];
+        if (launch_rope(r, p.in_prec, st) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+        p.q = qrot;
+        p.qs[0] = (int64_t)num_heads * seq_len_q * head_dim; p.qs[1] = (int64_t)seq_len_q * head_dim; p.qs[2] = head_dim; p.qs[3] = 1;
+    }
+    return rc_of(dispatch_forward(ctx, sc, p, dense_prec(intermediate_precision), st));
 }
 
 // In-stream encode (MFABridge.swift:2377-2543): never commits, never waits.

@@ -113,6 +113,9 @@ def _load_library(path: str | None = None) -> ctypes.CDLL:
     sig("umfa_attention_forward_stream", mfa_error_t,
         [mfa_context_t, _vp, _vp, _i64p, _vp, _i64p, _vp, _i64p, _vp, _i32, _vp,
          _vp, _i64p, _i64p, _u32, _i32, _i32] + _DIMS + [_f32, _b, _i32, _i32])
+    sig("umfa_rope_attention_forward_stream", mfa_error_t,
+        [mfa_context_t, _vp, _vp, _i64p, _vp, _i64p, _vp, _i64p, _vp, _i32, _vp, _vp, _vp, ctypes.c_int64] + _DIMS +
+        [_f32, _b, _i32, _i32])
     sig("mfa_attention_forward_with_lse", _i32,
         [mfa_context_t] + [mfa_buffer_t] * 5 + _DIMS + [_f32, _b, _i32, _i32] + [_b] * 4)
     sig("mfa_attention_backward", mfa_error_t,

@@ -288,6 +288,38 @@ def rope_rotate(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, *, negate
     return out
 
 
+def rope_attention_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, *,
+                           scale: Optional[float] = None, causal: bool = False, out_dtype=None,
+                           return_lse: bool = False):
+    """softmax(rope(q) rope(k)^T * scale) v in ONE in-stream call (umfa_rope_attention_forward_stream): K is rotated
+    once into the stream's workspace, Q inside the attention kernel behind its fragment load.  Bit-identical to
+    rope_rotate(q), rope_rotate(k), attention_forward (the reference's sequence, metal_sdpa_backend.cpp:1472-1641).
+    q, k, v [B,H,S,D] (same S), contiguous last dim; cos / sin fp32 [S,D] or [B,S,D], pair-duplicated."""
+    assert q.is_cuda and k.is_cuda and v.is_cuda, "device tensors required"
+    B, H, Sq, D = q.shape
+    Skv = k.shape[2]
+    for t in (q, k, v):
+        if t.stride(-1) != 1:
+            raise ValueError("last dimension must be contiguous")
+    if cos.dtype != torch.float32 or sin.dtype != torch.float32 or cos.shape != sin.shape or cos.shape[-2:] != (Sq, D):
+        raise ValueError("cos / sin must be fp32 [S, D] or [B, S, D]")
+    cos, sin = cos.contiguous(), sin.contiguous()
+    tb = Sq * D if cos.dim() == 3 else 0
+    if scale is None:
+        scale = D ** -0.5
+    out = torch.empty((B, H, Sq, D), dtype=out_dtype or q.dtype, device=q.device)
+    lse = torch.empty((B * H * Sq,), dtype=torch.float32, device=q.device) if return_lse else None
+    stream = torch.cuda.current_stream(q.device).cuda_stream
+    _check_error(_lib.umfa_rope_attention_forward_stream(
+        context(), ctypes.c_void_p(stream),
+        ctypes.c_void_p(q.data_ptr()), _i64(q.stride()), ctypes.c_void_p(k.data_ptr()), _i64(k.stride()),
+        ctypes.c_void_p(v.data_ptr()), _i64(v.stride()), ctypes.c_void_p(out.data_ptr()), _PREC[out.dtype],
+        ctypes.c_void_p(lse.data_ptr()) if lse is not None else None,
+        ctypes.c_void_p(cos.data_ptr()), ctypes.c_void_p(sin.data_ptr()), tb, B, Sq, Skv, H, D, float(scale),
+        bool(causal), _PREC[q.dtype], _PREC[q.dtype]))
+    return (out, lse) if return_lse else out
+
+
 def hadamard_rotate(t: torch.Tensor, block_size: int) -> torch.Tensor:
     """In-place group-wise Hadamard rotation of a contiguous fp32 / fp16 tensor (reference: hadamard_rotate_inplace,
     metal_sdpa_backend.cpp:3400-3418).  Applying it twice is the identity."""

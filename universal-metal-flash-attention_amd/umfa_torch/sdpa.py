@@ -376,6 +376,13 @@ def rope_scaled_dot_product_attention(query, key, value, rope_cos, rope_sin, att
         return _RopeFlashAttentionFn.apply(query, key, value, cos_t, sin_t, bool(is_causal), sm_scale)
     q_src = query if query.stride(-1) == 1 else query.contiguous()
     k_src = key if key.stride(-1) == 1 else key.contiguous()
+    if attn_mask is None and Hq == Hkv:
+        # one call: K rotated once into the stream's workspace, Q rotated inside the attention kernel
+        v_src = value if value.stride(-1) == 1 else value.contiguous()
+        _bump("total")
+        _bump("fp32_instream")   # the same nine counters as the unfused sequence bumps
+        _bump("rope_instream")
+        return ops.rope_attention_forward(q_src, k_src, v_src, cos_t, sin_t, scale=sm_scale, causal=bool(is_causal))
     q_rot = ops.rope_rotate(q_src, cos_t, sin_t)
     k_rot = ops.rope_rotate(k_src, cos_t, sin_t)
     _bump("rope_instream")
