@@ -34,6 +34,7 @@ MIDBAR = os.environ.get("W64_MIDBAR", "0") == "1"  # per-tile barrier in the mid
 # the tile's barrier (LDS latency, ~150 cycles); softmax work of the previous tile runs in that shadow instead of behind it
 PRE = {"16": int(os.environ.get("W64_PRE", "0")), "i8": int(os.environ.get("W64_PRE_I8", "0")), "f8": int(os.environ.get("W64_PRE_F8", "0"))}
 ROTATE = int(os.environ.get("W64_LAB_ROTATE", "0"))  # lab, TIMING ONLY (results wrong): steady-state bodies start with their last ROTATE gaps
+FSTAMP = [int(x) for x in os.environ.get("W64_LAB_FSTAMP", "").split(",") if x]  # lab: up to 8 wait-free s_memtime stamps in front of these gaps
 GAPSTAMP = [int(x) for x in os.environ.get("W64_LAB_GAPSTAMP", "").split(",") if x]  # lab: clock stamps in front of these gaps (steady-state parts)
 SPEC = os.environ.get("W64_SPEC", "1") == "1"  # steady-state tiles: e = s*c - m against the CURRENT reference first, row max of e, cheap decision (spec_streams)
 EARLY_MAX = os.environ.get("W64_EARLY_MAX", "1") == "1"  # row max of key-block 0 during the QK of key-block 1, e = s*c - m spread to the end
@@ -683,6 +684,8 @@ def emit_part(lines, R, have_new, have_old, masked=False):
     for g in order:
         if GAPSTAMP and have_new and have_old and g in GAPSTAMP:
             lines.append(f"W64_GSTAMP({GAPSTAMP.index(g)});")
+        if FSTAMP and have_new and have_old and not masked and g in FSTAMP:
+            lines.append(f"W64_FSTAMP({FSTAMP.index(g)});")
         if mf[g] is not None:
             lines.append(mf[g])
         for op in placed[g]:
@@ -693,6 +696,8 @@ def emit_part(lines, R, have_new, have_old, masked=False):
         cyc += max(32 if busy else 0, (8 if mf[g] else 0) + fill)
         if mf[g] is not None or placed[g]:
             lines.append(f"__builtin_amdgcn_sched_barrier(0);  // gap {g}: filler issue {fill} cyc")
+    if FSTAMP and have_new and have_old and not masked:
+        lines.append(f"W64_FSTAMP_END({len(FSTAMP)});")
     lines.append(f"// modelled issue time of this part: {cyc} cycles")
 
 

@@ -35,6 +35,12 @@
 #define M_MIX MFMA "v_fma_f32 v100, v100, s4, v117\n v_exp_f32 v101, v101\n v_add_f32 v102, v102, v118\n v_cvt_pk_bf16_f32 v103, v120, v121\n"
 #define M_MIX5 M_MIX "v_max3_f32 v104, v104, v122, v123\n"
 
+#define PKFMA8 "v_pk_fma_f32 v[100:101], v[100:101], v[116:117], v[118:119]\n v_pk_fma_f32 v[102:103], v[102:103], v[118:119], v[120:121]\n v_pk_fma_f32 v[104:105], v[104:105], v[120:121], v[122:123]\n v_pk_fma_f32 v[106:107], v[106:107], v[122:123], v[116:117]\n v_pk_fma_f32 v[108:109], v[108:109], v[116:117], v[118:119]\n v_pk_fma_f32 v[110:111], v[110:111], v[118:119], v[120:121]\n v_pk_fma_f32 v[112:113], v[112:113], v[120:121], v[122:123]\n v_pk_fma_f32 v[114:115], v[114:115], v[122:123], v[116:117]\n "
+#define PKFMAB8 "v_pk_fma_f32 v[100:101], v[100:101], v[116:117], v[118:119] op_sel_hi:[1,0,0]\n v_pk_fma_f32 v[102:103], v[102:103], v[118:119], v[120:121] op_sel_hi:[1,0,0]\n v_pk_fma_f32 v[104:105], v[104:105], v[120:121], v[122:123] op_sel_hi:[1,0,0]\n v_pk_fma_f32 v[106:107], v[106:107], v[122:123], v[116:117] op_sel_hi:[1,0,0]\n v_pk_fma_f32 v[108:109], v[108:109], v[116:117], v[118:119] op_sel_hi:[1,0,0]\n v_pk_fma_f32 v[110:111], v[110:111], v[118:119], v[120:121] op_sel_hi:[1,0,0]\n v_pk_fma_f32 v[112:113], v[112:113], v[120:121], v[122:123] op_sel_hi:[1,0,0]\n v_pk_fma_f32 v[114:115], v[114:115], v[122:123], v[116:117] op_sel_hi:[1,0,0]\n "
+#define PKADD8 "v_pk_add_f32 v[100:101], v[100:101], v[116:117]\n v_pk_add_f32 v[102:103], v[102:103], v[118:119]\n v_pk_add_f32 v[104:105], v[104:105], v[120:121]\n v_pk_add_f32 v[106:107], v[106:107], v[122:123]\n v_pk_add_f32 v[108:109], v[108:109], v[116:117]\n v_pk_add_f32 v[110:111], v[110:111], v[118:119]\n v_pk_add_f32 v[112:113], v[112:113], v[120:121]\n v_pk_add_f32 v[114:115], v[114:115], v[122:123]\n "
+#define PKMUL8 "v_pk_mul_f32 v[100:101], v[100:101], v[116:117]\n v_pk_mul_f32 v[102:103], v[102:103], v[118:119]\n v_pk_mul_f32 v[104:105], v[104:105], v[120:121]\n v_pk_mul_f32 v[106:107], v[106:107], v[122:123]\n v_pk_mul_f32 v[108:109], v[108:109], v[116:117]\n v_pk_mul_f32 v[110:111], v[110:111], v[118:119]\n v_pk_mul_f32 v[112:113], v[112:113], v[120:121]\n v_pk_mul_f32 v[114:115], v[114:115], v[122:123]\n "
+#define M_PK MFMA "v_pk_fma_f32 v[100:101], v[100:101], v[116:117], v[118:119] op_sel_hi:[1,0,0]\n v_exp_f32 v102, v102\n v_exp_f32 v103, v103\n v_pk_add_f32 v[104:105], v[104:105], v[120:121]\n v_cvt_pk_bf16_f32 v106, v120, v121\n"
+#define M_PK6 M_PK "v_max3_f32 v107, v107, v122, v123\n"
 template <int V>
 __global__ void probe(unsigned long long* cyc, int n) {
     asm volatile("v_mov_b32 v116, 1.0\n v_mov_b32 v117, 0\n v_mov_b32 v118, 1.0\n v_mov_b32 v119, 0\n v_mov_b32 v120, 1.0\n v_mov_b32 v121, 0\n v_mov_b32 v122, 1.0\n v_mov_b32 v123, 0\n s_mov_b32 s4, 1.0" ::: CLOB, "s4");
@@ -56,6 +62,12 @@ __global__ void probe(unsigned long long* cyc, int n) {
         if constexpr (V == 10) asm volatile(R8(M_MIX M_MIX) ::: CLOB, "s4");
         if constexpr (V == 11) asm volatile(R8(M_MIX5 M_MIX5) ::: CLOB, "s4");
         if constexpr (V == 12) asm volatile(R8(MFMA MFMA) ::: CLOB);
+        if constexpr (V == 13) asm volatile(R8(PKFMA8 PKFMA8) ::: CLOB);
+        if constexpr (V == 14) asm volatile(R8(PKFMAB8 PKFMAB8) ::: CLOB);
+        if constexpr (V == 15) asm volatile(R8(PKADD8 PKADD8) ::: CLOB);
+        if constexpr (V == 16) asm volatile(R8(PKMUL8 PKMUL8) ::: CLOB);
+        if constexpr (V == 17) asm volatile(R8(M_PK M_PK) ::: CLOB);
+        if constexpr (V == 18) asm volatile(R8(M_PK6 M_PK6) ::: CLOB);
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
@@ -78,7 +90,13 @@ int main() {
     run<3>("v_fma_f32 v, v, s, v", 128, cyc);
     run<4>("v_cvt_pk_bf16_f32", 128, cyc);
     run<5>("v_max3_f32", 128, cyc);
+    run<13>("v_pk_fma_f32", 128, cyc);
+    run<14>("v_pk_fma_f32 op_sel_hi:[1,0,0] (broadcast low of src1)", 128, cyc);
+    run<15>("v_pk_add_f32", 128, cyc);
+    run<16>("v_pk_mul_f32", 128, cyc);
     run<12>("mfma only", 16, cyc);
+    run<17>("mfma + pk_fma exp exp pk_add cvt (2 scores)", 16, cyc);
+    run<18>("mfma + pk_fma exp exp pk_add cvt max3", 16, cyc);
     run<6>("mfma + 4 v_fma (3 VGPR)", 16, cyc);
     run<7>("mfma + 4 v_add", 16, cyc);
     run<8>("mfma + 5 v_add", 16, cyc);

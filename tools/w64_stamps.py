@@ -29,3 +29,14 @@ print("   per-WG us (median): prologue %.1f  main loop %.1f  drain %.1f  epilogu
     np.median(seg[:, 0]), np.median(seg[:, 1]), np.median(seg[:, 2]), np.median(seg[:, 3]), seg[:, 3].max()))
 print(f"{umfa_torch.last_kernel()} valid {int(ok.sum())}/256 per-WG time us: min {rt.min():.1f} med {np.median(rt):.1f} max {rt.max():.1f}; span {span:.1f} us; "
       f"clock MHz: min {(ck/rt).min():.0f} med {np.median(ck/rt):.0f} max {(ck/rt).max():.0f}; start skew {(raw[:,0].max()-raw[:,0].min())/100.0:.1f} us")
+if len(sys.argv) > 6 and sys.argv[6] == "fs":
+    # W64_LAB_FSTAMP build: dbg[4..7] = 8 x uint32 accumulated cycle deltas; argv[7] = comma list of the stamped gaps, argv[8] = steady tiles per WG
+    gaps = [int(x) for x in sys.argv[7].split(",")]
+    acc = raw[:, 4:8].copy().view(np.uint32).reshape(len(raw), 8).astype(np.float64)
+    tot = acc[:, :len(gaps)].sum(1)
+    med = np.median(acc, 0)
+    names = [f"{gaps[-1]}->next {gaps[0]}"] + [f"{gaps[i-1]}->{gaps[i]}" for i in range(1, len(gaps))]
+    share = med[:len(gaps)] / med[:len(gaps)].sum()
+    print("   fine stamps (median over WGs, share of the steady tile):")
+    for n, m, sh in zip(names, med, share):
+        print(f"      {n:>14}: {sh * 100:5.1f} %")
