@@ -324,6 +324,12 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
         }
     }
 
+    if constexpr (DP == 128) {
+        // home these 64 registers in the accumulator half of the file: the S / dP MFMAs of the pinned pipeline below take
+        // them as AGPR B operands (Mma16::mma_v); left in VGPRs, hipcc copies each one to a scratch AGPR before every use
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+a"(kf[ks]), "+a"(vf[ks]));
+    }
     const float c = p.scale * UMFA_LOG2E;
     // query tiles of 64 rows = two 32-row sub-tiles per barrier: both S/dP products are issued before the first
     // sub-tile's exp/convert work, so the wave has matrix work in flight while its VALU runs
@@ -367,7 +373,21 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
     __builtin_amdgcn_s_waitcnt(0x0F70);  // for the compiler's scoreboard too (K / V fragments are first used in the loop)
     __syncthreads();
 
-    for (uint32_t t = t0; t < ntiles; ++t) {
+    // Causal: the tiles whose queries all lie before this wave's keys (at most one per wave: wave_k0 - 63 <= q_base from
+    // tile wave_k0 / 64 on) only keep the staging and the barriers going, in a loop of their own -- as a branch around
+    // the tile body inside ONE loop, hipcc merged the 128 dK / dV accumulators of the two paths with ~330
+    // v_accvgpr_read / _write copies per tile.
+    uint32_t t = t0;
+    if (CAUSAL) {
+        const uint32_t t_act = __builtin_amdgcn_readfirstlane((kb * 128 + (uint32_t)uw * 32) / QROWS);  // wave-uniform for the compiler too
+        for (; t < ntiles && t < t_act; ++t) {
+            stage(t + 1);
+            stage_consts(t + 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    for (; t < ntiles; ++t) {
         stage(t + 1);
         stage_consts(t + 1);
         const char* Qt = smem + QT + (t & 1) * QTILE_B;
@@ -375,58 +395,139 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
         const float* L2v = vec + (t & 1) * QROWS;
         const float* Dv = vec + 2 * QROWS + (t & 1) * QROWS;
         const uint32_t q_base = t * QROWS;
-        if (!CAUSAL || q_base + QROWS - 1 >= wave_k0) {  // some query of the tile sees some key of this wave
-            // S[q][key] = Q K^T, dP[q][key] = dO V^T: rows = queries (registers), columns = keys (lanes)
-            f32x16 s[2], dp[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { s[u][r] = 0.0f; dp[u][r] = 0.0f; }
-            // A operands: row = query kl of sub-tile u, one flat sequence j = u * NKS + ks over both sub-tiles,
-            // software-pipelined like the dq kernel's row fragments (PD k-steps in flight ahead of their MFMAs)
-            V8 aq[2 * NKS], ado[2 * NKS];
-            auto rd = [&](int j) {
-                aq[j] = *(const V8*)(Qt + (j / NKS) * TILE_BYTES + d_off<DP>(kl, 2 * (j % NKS) + hi));
-                ado[j] = *(const V8*)(dOt + (j / NKS) * TILE_BYTES + d_off<DP>(kl, 2 * (j % NKS) + hi));
-            };
-#pragma unroll
-            for (int j = 0; j < PD; ++j) rd(j);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * PD, 0);
-#pragma unroll
-            for (int j = 0; j < 2 * NKS; ++j) {
-                if (j + PD < 2 * NKS) rd(j + PD);
-                s[j / NKS] = M::mma(aq[j], kf[j % NKS], s[j / NKS]);
-                dp[j / NKS] = M::mma(ado[j], vf[j % NKS], dp[j / NKS]);
-                if (j + PD < 2 * NKS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const uint32_t qb0 = q_base + 32 * u;
-                const bool edge = CAUSAL && qb0 < wave_k0 + 31;  // sub-tile straddles the diagonal of this wave's keys
-                V8 pb[2], sb[2];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    // registers 4g .. 4g+3 are queries 8g + 4hi + 0..3 of the sub-tile
-                    const f32x4 l2 = *(const f32x4*)(L2v + 32 * u + 8 * g + 4 * hi);
-                    const f32x4 dl = *(const f32x4*)(Dv + 32 * u + 8 * g + 4 * hi);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = 4 * g + e;
-                        float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], c, -l2[e] * UMFA_LOG2E));
+        {
+            if constexpr (DP == 128) {
+                // One tile = 64 MFMAs in four phases of 16 (at D = 128), every phase's MFMAs back to back and the vector work
+                // of the NEXT phase's operands placed between them, in source order pinned by sched_barrier(0):
+                //   P1a  S, dP of sub-tile 0                    (row fragments of Q, dO: PD k-steps in flight)
+                //   P1b  S, dP of sub-tile 1        | P, dS of sub-tile 0 (exp2, products, rounding to T)
+                //   P2a  dV, dK += sub-tile 0       | P, dS of sub-tile 1
+                //   P2b  dV, dK += sub-tile 1
+                // Left to hipcc the second half was "2 x ds_read_b64_tr_b16 -> s_waitcnt lgkmcnt(0) -> MFMA" 32 times per
+                // tile with the exponentials in front of it, nothing overlapped (tools/trace_waits.py; PMC: 38 % of the
+                // wave cycles in waits, MFMA pipe 36 % busy).
+                // S[q][key] = Q K^T, dP[q][key] = dO V^T: rows = queries (registers), columns = keys (lanes)
+                f32x16 s[2], dp[2];
+                V8 aq[2 * NKS], ado[2 * NKS];
+                auto rd = [&](int j) {
+                    aq[j] = *(const V8*)(Qt + (j / NKS) * TILE_BYTES + d_off<DP>(kl, 2 * (j % NKS) + hi));
+                    ado[j] = *(const V8*)(dOt + (j / NKS) * TILE_BYTES + d_off<DP>(kl, 2 * (j % NKS) + hi));
+                };
+                // row constants of sub-tile u: registers 4g .. 4g+3 are queries 8g + 4hi + 0..3
+                f32x4 l2c[2][4], dlc[2][4];
+                auto rd_consts = [&](int u) {
+    #pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        l2c[u][g] = *(const f32x4*)(L2v + 32 * u + 8 * g + 4 * hi);
+                        dlc[u][g] = *(const f32x4*)(Dv + 32 * u + 8 * g + 4 * hi);
+                    }
+                };
+                V8 pb[2][2], sb[2][2];
+                // P and dS of scores r0, r0 + 1 of sub-tile u (one packed conversion each)
+                auto softmax_pair = [&](int u, int r0) {
+                    const uint32_t qb0 = q_base + 32 * u;
+                    const bool edge = CAUSAL && qb0 < wave_k0 + 31;  // sub-tile straddles the diagonal of this wave's keys
+    #pragma unroll
+                    for (int r = r0; r < r0 + 2; ++r) {
+                        const int g = r >> 2, e = r & 3;
+                        float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], c, -l2c[u][g][e] * UMFA_LOG2E));
                         if (edge && key > qb0 + 8 * g + 4 * hi + e) pr = 0.0f;
-                        pb[r >> 3][r & 7] = (T)pr;
-                        sb[r >> 3][r & 7] = (T)(pr * (dp[u][r] - dl[e]));
+                        pb[u][r >> 3][r & 7] = (T)pr;
+                        sb[u][r >> 3][r & 7] = (T)(pr * (dp[u][r] - dlc[u][g][e]));
                     }
+                };
+                constexpr int NF = 4 * NDBH, PT = 4;  // dV / dK MFMAs of one sub-tile; transposed fragments in flight
+                V8 tf[2 * NF];
+                auto trd = [&](int j) {
+                    const int u = j / NF, r = j % NF, i = r >> 2, s2 = (r >> 1) & 1;
+                    tf[j] = tr_frag<M, DP>(((r & 1) ? Qt : dOt) + u * TILE_BYTES, i + hpass * NDBH, s2, hi, tr_qq, tr_pp, tr_g1);
+                };
+    #pragma unroll
+                for (int j = 0; j < PD; ++j) rd(j);
+                rd_consts(0);
+                __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                for (int j = 0; j < 2 * NKS; ++j) {
+                    if (j + PD < 2 * NKS) rd(j + PD);
+                    if (j == 2 * NKS - 3) rd_consts(1);  // late: needed from the second step of P2a on, 32 registers
+                    if (j >= 2 * NKS - PT / 2) { trd(2 * (j - (2 * NKS - PT / 2))); trd(2 * (j - (2 * NKS - PT / 2)) + 1); }
+                    // VGPR-destination MFMAs (Mma16::mma_v: the vector unit reads S and dP; as AGPR accumulators they cost
+                    // 128 v_accvgpr_read per tile); first k-step of a sub-tile: C = 0 as the inline constant
+                    if (j % NKS) { M::mma_v(s[j / NKS], aq[j], kf[j % NKS]); M::mma_v(dp[j / NKS], ado[j], vf[j % NKS]); }
+                    else { M::mma_v_first(s[j / NKS], aq[j], kf[j % NKS]); M::mma_v_first(dp[j / NKS], ado[j], vf[j % NKS]); }
+                    if (j >= NKS) {  // P1b: the 8 score pairs of sub-tile 0 spread over the NKS steps
+    #pragma unroll
+                        for (int cch = 0; cch < 8; ++cch)
+                            if (cch * NKS / 8 == j - NKS) softmax_pair(0, 2 * cch);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                // dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]
-#pragma unroll
-                for (int i = 0; i < NDBH; ++i)
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        dv[i] = M::mma(tr_frag<M, DP>(dOt + u * TILE_BYTES, i + hpass * NDBH, s2, hi, tr_qq, tr_pp, tr_g1), pb[s2], dv[i]);
-                        dk[i] = M::mma(tr_frag<M, DP>(Qt + u * TILE_BYTES, i + hpass * NDBH, s2, hi, tr_qq, tr_pp, tr_g1), sb[s2], dk[i]);
+    #pragma unroll
+                for (int j = 0; j < 2 * NF; ++j) {
+                    const int u = j / NF, r = j % NF, i = r >> 2, s2 = (r >> 1) & 1;
+                    if (j + PT < 2 * NF) trd(j + PT);
+                    if (r & 1) dk[i] = M::mma(tf[j], sb[u][s2], dk[i]);
+                    else dv[i] = M::mma(tf[j], pb[u][s2], dv[i]);
+                    if (j < NF) {  // P2a: the 8 score pairs of sub-tile 1 spread over the NF steps
+    #pragma unroll
+                        for (int cch = 0; cch < 8; ++cch)
+                            if (cch * NF / 8 + 1 == j) softmax_pair(1, 2 * cch);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {  // head_dim 64 (two workgroups per CU, 256 registers) and 256 (two passes): hipcc's own order
+                // S[q][key] = Q K^T, dP[q][key] = dO V^T: rows = queries (registers), columns = keys (lanes)
+                f32x16 s[2], dp[2];
+    #pragma unroll
+                for (int u = 0; u < 2; ++u)
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) { s[u][r] = 0.0f; dp[u][r] = 0.0f; }
+                // A operands: row = query kl of sub-tile u, one flat sequence j = u * NKS + ks over both sub-tiles,
+                // software-pipelined like the dq kernel's row fragments (PD k-steps in flight ahead of their MFMAs)
+                V8 aq[2 * NKS], ado[2 * NKS];
+                auto rd = [&](int j) {
+                    aq[j] = *(const V8*)(Qt + (j / NKS) * TILE_BYTES + d_off<DP>(kl, 2 * (j % NKS) + hi));
+                    ado[j] = *(const V8*)(dOt + (j / NKS) * TILE_BYTES + d_off<DP>(kl, 2 * (j % NKS) + hi));
+                };
+    #pragma unroll
+                for (int j = 0; j < PD; ++j) rd(j);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * PD, 0);
+    #pragma unroll
+                for (int j = 0; j < 2 * NKS; ++j) {
+                    if (j + PD < 2 * NKS) rd(j + PD);
+                    s[j / NKS] = M::mma(aq[j], kf[j % NKS], s[j / NKS]);
+                    dp[j / NKS] = M::mma(ado[j], vf[j % NKS], dp[j / NKS]);
+                    if (j + PD < 2 * NKS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                }
+    #pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const uint32_t qb0 = q_base + 32 * u;
+                    const bool edge = CAUSAL && qb0 < wave_k0 + 31;  // sub-tile straddles the diagonal of this wave's keys
+                    V8 pb[2], sb[2];
+    #pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        // registers 4g .. 4g+3 are queries 8g + 4hi + 0..3 of the sub-tile
+                        const f32x4 l2 = *(const f32x4*)(L2v + 32 * u + 8 * g + 4 * hi);
+                        const f32x4 dl = *(const f32x4*)(Dv + 32 * u + 8 * g + 4 * hi);
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int r = 4 * g + e;
+                            float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], c, -l2[e] * UMFA_LOG2E));
+                            if (edge && key > qb0 + 8 * g + 4 * hi + e) pr = 0.0f;
+                            pb[r >> 3][r & 7] = (T)pr;
+                            sb[r >> 3][r & 7] = (T)(pr * (dp[u][r] - dl[e]));
+                        }
+                    }
+                    // dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]
+    #pragma unroll
+                    for (int i = 0; i < NDBH; ++i)
+    #pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            dv[i] = M::mma(tr_frag<M, DP>(dOt + u * TILE_BYTES, i + hpass * NDBH, s2, hi, tr_qq, tr_pp, tr_g1), pb[s2], dv[i]);
+                            dk[i] = M::mma(tr_frag<M, DP>(Qt + u * TILE_BYTES, i + hpass * NDBH, s2, hi, tr_qq, tr_pp, tr_g1), sb[s2], dk[i]);
+                        }
+                }
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -484,6 +585,12 @@ hipError_t launch_bwd_16(const BwdParams& p, hipStream_t stream, const char** na
     if (p.D == 128) {
         *name = bf ? "fa_bwd16<bf16,128>" : "fa_bwd16<fp16,128>";
         if (bf) return p.causal ? launch_bwd16_t<__bf16, true, 128>(p, stream) : launch_bwd16_t<__bf16, false, 128>(p, stream);
+#ifdef BWD16_LAB_ONLY128  // lab builds (fast asm inspection): bf16 head_dim 128 only
+        return hipErrorNotSupported;
+    }
+    return hipErrorNotSupported;
+}
+#else
         return p.causal ? launch_bwd16_t<_Float16, true, 128>(p, stream) : launch_bwd16_t<_Float16, false, 128>(p, stream);
     }
     if (p.D == 256) {
@@ -495,5 +602,6 @@ hipError_t launch_bwd_16(const BwdParams& p, hipStream_t stream, const char** na
     if (bf) return p.causal ? launch_bwd16_t<__bf16, true, 64>(p, stream) : launch_bwd16_t<__bf16, false, 64>(p, stream);
     return p.causal ? launch_bwd16_t<_Float16, true, 64>(p, stream) : launch_bwd16_t<_Float16, false, 64>(p, stream);
 }
+#endif
 
 }  // namespace umfa

@@ -19,6 +19,17 @@ template <> struct Mma16<__bf16> {
     static __device__ __forceinline__ V4 tr_read(const char* lds) {
         return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((V4 LDS_AS*)(lds));
     }
+    // The same MFMA with a VGPR destination and an AGPR-resident B operand, for accumulators the vector unit reads right
+    // after (S, dP of the backward).  In a kernel that needs AGPRs at all hipcc selects the AGPR-destination form for EVERY
+    // builtin MFMA, and each such value then costs a v_accvgpr_read per register before a VALU instruction can touch it.
+    // Inline asm: hipcc pads nothing after it -- the CALLER keeps >= 2 MFMA issues between the last write of an
+    // accumulator and its first vector read (XDL write -> VALU read: 18 wait states at 16 passes).
+    static __device__ __forceinline__ void mma_v_first(f32x16& c, V8 a, V8 b) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "a"(b));
+    }
+    static __device__ __forceinline__ void mma_v(f32x16& c, V8 a, V8 b) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
+    }
 };
 template <> struct Mma16<_Float16> {
     typedef f16x8 V8;
@@ -28,6 +39,12 @@ template <> struct Mma16<_Float16> {
     }
     static __device__ __forceinline__ V4 tr_read(const char* lds) {
         return __builtin_bit_cast(V4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 LDS_AS*)(lds)));
+    }
+    static __device__ __forceinline__ void mma_v_first(f32x16& c, V8 a, V8 b) {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "a"(b));
+    }
+    static __device__ __forceinline__ void mma_v(f32x16& c, V8 a, V8 b) {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
     }
 };
 
