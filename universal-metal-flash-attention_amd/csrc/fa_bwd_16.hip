@@ -18,6 +18,7 @@
 // on the source chunk.
 // P and dS are rounded to the input type before their second product, like P in the forward.
 #include <cstring>
+#include <type_traits>
 
 #include "fa_common.h"
 #include "fa_fwd_16_kernel.h"  // Mma16<T>, xcd_remap
@@ -219,53 +220,86 @@ __global__ __launch_bounds__(256, DP == 256 ? 1 : 2) void bwd16_dq_kernel(BwdPar
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
 
-    for (uint32_t t = 0; t < ntiles; ++t) {
-        stage(t + 1);  // other buffer: its last readers passed the previous barrier
-        const char* Kt = smem + (t & 1) * TILE_BYTES;
-        const char* Vt = smem + 2 * TILE_BYTES + (t & 1) * TILE_BYTES;
+    // One 32-key tile.  EDGE: the tile crosses the end of the key range or this wave's causal diagonal, scores get a
+    // per-key test; every other tile runs without it (as a run-time flag inside ONE body the test became 16 v_cmp + 32
+    // v_cndmask on every tile of every launch, in a loop that is VALU-issue bound: two waves per SIMD, ~170 vector
+    // instructions per 24 MFMAs).
+    // PAR: which half of the double buffer, as a compile-time constant in the steady-state loop (unrolled by two): every
+    // LDS address is then a loop-invariant lane register + an immediate, where a run-time (t & 1) cost ~40 address adds
+    // per tile; -1 = run-time parity (the few edge tiles).
+    auto tile_body = [&](uint32_t t, auto EDGE_C, auto PAR_C) {
+        constexpr bool EDGE = decltype(EDGE_C)::value;
+        constexpr int PAR = decltype(PAR_C)::value;
+        const int par = PAR >= 0 ? PAR : (int)(t & 1);
+        const char* Kt = smem + par * TILE_BYTES;
+        const char* Vt = smem + 2 * TILE_BYTES + par * TILE_BYTES;
         const uint32_t key_base = t * 32;
-        if (!CAUSAL || key_base <= wave_q0 + 31) {
-            f32x16 s, dp;
+        f32x16 s, dp;
+        // explicit software pipeline: the row fragments of k-step ks + PD are in flight while the MFMAs of ks
+        // run (left alone, hipcc reuses ONE 4-register buffer: ds_read -> s_waitcnt lgkmcnt(0) -> MFMA, 16 times)
+        V8 ak[NKS], av[NKS];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.0f; dp[r] = 0.0f; }
-            // explicit software pipeline: the row fragments of k-step ks + PD are in flight while the MFMAs of ks
-            // run (left alone, hipcc reuses ONE 4-register buffer: ds_read -> s_waitcnt lgkmcnt(0) -> MFMA, 16 times)
-            V8 ak[NKS], av[NKS];
-#pragma unroll
-            for (int ks = 0; ks < PD; ++ks) {
-                ak[ks] = *(const V8*)(Kt + d_off<DP>(ql, 2 * ks + hi));
-                av[ks] = *(const V8*)(Vt + d_off<DP>(ql, 2 * ks + hi));
-            }
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * PD, 0);
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                if (ks + PD < NKS) {
-                    ak[ks + PD] = *(const V8*)(Kt + d_off<DP>(ql, 2 * (ks + PD) + hi));
-                    av[ks + PD] = *(const V8*)(Vt + d_off<DP>(ql, 2 * (ks + PD) + hi));
-                }
-                s = M::mma(ak[ks], qf[ks], s);      // S^T[key][q]
-                dp = M::mma(av[ks], dof[ks], dp);   // dP^T[key][q]
-                if (ks + PD < NKS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            }
-            const bool edge = (key_base + 32 > p.Skv) || (CAUSAL && key_base + 31 > wave_q0);
-            V8 ds[2];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -L2));
-                if (edge) {
-                    const uint32_t key = key_base + acc_row(r, hi);
-                    if (key >= p.Skv || (CAUSAL && key > q_row)) pr = 0.0f;
-                }
-                ds[r >> 3][r & 7] = (T)(pr * (dp[r] - delta));
-            }
-            // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
-#pragma unroll
-            for (int i = 0; i < NDB; ++i)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-                    acc[i] = M::mma(tr_frag<M, DP>(Kt, i, s2, hi, tr_qq, tr_pp, tr_g1), ds[s2], acc[i]);
+        for (int ks = 0; ks < PD; ++ks) {
+            ak[ks] = *(const V8*)(Kt + d_off<DP>(ql, 2 * ks + hi));
+            av[ks] = *(const V8*)(Vt + d_off<DP>(ql, 2 * ks + hi));
         }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * PD, 0);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (ks + PD < NKS) {
+                ak[ks + PD] = *(const V8*)(Kt + d_off<DP>(ql, 2 * (ks + PD) + hi));
+                av[ks + PD] = *(const V8*)(Vt + d_off<DP>(ql, 2 * (ks + PD) + hi));
+            }
+            s = M::mma(ak[ks], qf[ks], ks ? s : f32x16{});      // S^T[key][q]   (first k-step: C = 0 inline)
+            dp = M::mma(av[ks], dof[ks], ks ? dp : f32x16{});   // dP^T[key][q]
+            if (ks + PD < NKS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        }
+        V8 ds[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c, -L2));
+            if constexpr (EDGE) {
+                const uint32_t key = key_base + acc_row(r, hi);
+                if (key >= p.Skv || (CAUSAL && key > q_row)) pr = 0.0f;
+            }
+            ds[r >> 3][r & 7] = (T)(pr * (dp[r] - delta));
+        }
+        // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+#pragma unroll
+        for (int i = 0; i < NDB; ++i)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+                acc[i] = M::mma(tr_frag<M, DP>(Kt, i, s2, hi, tr_qq, tr_pp, tr_g1), ds[s2], acc[i]);
+    };
+    // tile ranges of this wave (wave-uniform): [0, t1) plain, [t1, t2) edge, [t2, ntiles) nothing to do but keep the
+    // staging and the barriers of the workgroup going
+    const uint32_t wq0 = __builtin_amdgcn_readfirstlane(qb * 128 + (uint32_t)uw * 32);
+    uint32_t t2 = ntiles, t1 = p.Skv / 32;
+    if (CAUSAL) {
+        t2 = wq0 / 32 + 1 < ntiles ? wq0 / 32 + 1 : ntiles;  // key_base <= wave_q0 + 31
+        t1 = wq0 / 32 < t1 ? wq0 / 32 : t1;                  // key_base + 31 <= wave_q0
+    }
+    t1 = t1 < t2 ? t1 : t2;
+    uint32_t t = 0;
+    for (; t + 1 < t1; t += 2) {  // t even
+        stage(t + 1);  // other buffer: its last readers passed the previous barrier
+        tile_body(t, std::false_type{}, std::integral_constant<int, 0>{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        stage(t + 2);
+        tile_body(t + 1, std::false_type{}, std::integral_constant<int, 1>{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    for (; t < t2; ++t) {  // an odd plain tile (computed with the test: same values) and the edge tiles
+        stage(t + 1);
+        tile_body(t, std::true_type{}, std::integral_constant<int, -1>{});
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    for (; t < ntiles; ++t) {
+        stage(t + 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -387,13 +421,17 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
             __syncthreads();
         }
     }
-    for (; t < ntiles; ++t) {
-        stage(t + 1);
-        stage_consts(t + 1);
-        const char* Qt = smem + QT + (t & 1) * QTILE_B;
-        const char* dOt = smem + DOT + (t & 1) * QTILE_B;
-        const float* L2v = vec + (t & 1) * QROWS;
-        const float* Dv = vec + 2 * QROWS + (t & 1) * QROWS;
+    // EDGE: some query of the tile lies before some key of this wave (causal diagonal): scores get a per-key test.
+    // PAR: half of the double buffer as a compile-time constant (steady loop, unrolled by two: LDS addresses are then lane
+    // registers + immediates; a run-time (t & 1) cost ~46 address adds per tile), -1 = run-time parity.
+    auto tile_body = [&](uint32_t t, auto EDGE_C, auto PAR_C) {
+        constexpr bool EDGE = decltype(EDGE_C)::value;
+        constexpr int PAR = decltype(PAR_C)::value;
+        const int par = PAR >= 0 ? PAR : (int)(t & 1);
+        const char* Qt = smem + QT + par * QTILE_B;
+        const char* dOt = smem + DOT + par * QTILE_B;
+        const float* L2v = vec + par * QROWS;
+        const float* Dv = vec + 2 * QROWS + par * QROWS;
         const uint32_t q_base = t * QROWS;
         {
             if constexpr (DP == 128) {
@@ -426,7 +464,7 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
                 // P and dS of scores r0, r0 + 1 of sub-tile u (one packed conversion each)
                 auto softmax_pair = [&](int u, int r0) {
                     const uint32_t qb0 = q_base + 32 * u;
-                    const bool edge = CAUSAL && qb0 < wave_k0 + 31;  // sub-tile straddles the diagonal of this wave's keys
+                    const bool edge = EDGE && CAUSAL && qb0 < wave_k0 + 31;  // sub-tile straddles the diagonal of this wave's keys
     #pragma unroll
                     for (int r = r0; r < r0 + 2; ++r) {
                         const int g = r >> 2, e = r & 3;
@@ -503,7 +541,7 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
     #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const uint32_t qb0 = q_base + 32 * u;
-                    const bool edge = CAUSAL && qb0 < wave_k0 + 31;  // sub-tile straddles the diagonal of this wave's keys
+                    const bool edge = EDGE && CAUSAL && qb0 < wave_k0 + 31;  // sub-tile straddles the diagonal of this wave's keys
                     V8 pb[2], sb[2];
     #pragma unroll
                     for (int g = 0; g < 4; ++g) {
@@ -530,9 +568,28 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
                 }
             }
         }
+    };
+    auto step = [&](uint32_t tt, auto EDGE_C, auto PAR_C) {
+        stage(tt + 1);
+        stage_consts(tt + 1);
+        tile_body(tt, EDGE_C, PAR_C);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+    };
+    // [t, t_ne): tiles on the diagonal (and one more when that leaves an odd start), run-time parity; then pairs
+    uint32_t t_ne = t;
+    if (CAUSAL) {
+        t_ne = __builtin_amdgcn_readfirstlane((kb * 128 + (uint32_t)uw * 32 + 31 + QROWS - 1) / QROWS);  // q_base >= wave_k0 + 31
+        t_ne = t_ne > t ? t_ne : t;
     }
+    t_ne += t_ne & 1;
+    t_ne = t_ne < ntiles ? t_ne : ntiles;
+    for (; t < t_ne; ++t) step(t, std::true_type{}, std::integral_constant<int, -1>{});
+    for (; t + 1 < ntiles; t += 2) {
+        step(t, std::false_type{}, std::integral_constant<int, 0>{});
+        step(t + 1, std::false_type{}, std::integral_constant<int, 1>{});
+    }
+    for (; t < ntiles; ++t) step(t, std::true_type{}, std::integral_constant<int, -1>{});
     if (kok) {
         const int64_t krow = ((int64_t)bh * p.Skv + key) * DP;
 #pragma unroll
