@@ -23,7 +23,7 @@ for name in ("randn", "zeros"):
     if MODE == "bwd":
         o_, lse_ = ops.attention_forward(q, k, v, return_lse=True)
         do_ = torch.randn_like(q) if name == "randn" else torch.zeros_like(q)
-        step = lambda: ops.attention_backward(do_, q, k, v, o_, lse_)
+        step = lambda: ops.attention_backward(do_, q, k, v, o_, lse_, scale=D ** -0.5)
         per = 40
     elif MODE in ("fp8pv", "int8"):
         step = lambda: umfa_torch.quantized_attention_forward_stream(q, k, v, quant_mode="blockwise_fp8pv" if MODE == "fp8pv" else "blockwise")
