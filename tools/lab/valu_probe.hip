@@ -41,6 +41,9 @@
 #define PKMUL8 "v_pk_mul_f32 v[100:101], v[100:101], v[116:117]\n v_pk_mul_f32 v[102:103], v[102:103], v[118:119]\n v_pk_mul_f32 v[104:105], v[104:105], v[120:121]\n v_pk_mul_f32 v[106:107], v[106:107], v[122:123]\n v_pk_mul_f32 v[108:109], v[108:109], v[116:117]\n v_pk_mul_f32 v[110:111], v[110:111], v[118:119]\n v_pk_mul_f32 v[112:113], v[112:113], v[120:121]\n v_pk_mul_f32 v[114:115], v[114:115], v[122:123]\n "
 #define M_PK MFMA "v_pk_fma_f32 v[100:101], v[100:101], v[116:117], v[118:119] op_sel_hi:[1,0,0]\n v_exp_f32 v102, v102\n v_exp_f32 v103, v103\n v_pk_add_f32 v[104:105], v[104:105], v[120:121]\n v_cvt_pk_bf16_f32 v106, v120, v121\n"
 #define M_PK6 M_PK "v_max3_f32 v107, v107, v122, v123\n"
+#define DOT16 "v_dot2_f32_bf16 v100, v116, v119, v100\n v_dot2_f32_bf16 v101, v117, v120, v101\n v_dot2_f32_bf16 v102, v118, v121, v102\n v_dot2_f32_bf16 v103, v119, v122, v103\n v_dot2_f32_bf16 v104, v120, v123, v104\n v_dot2_f32_bf16 v105, v121, v116, v105\n v_dot2_f32_bf16 v106, v122, v117, v106\n v_dot2_f32_bf16 v107, v123, v118, v107\n v_dot2_f32_bf16 v108, v116, v119, v108\n v_dot2_f32_bf16 v109, v117, v120, v109\n v_dot2_f32_bf16 v110, v118, v121, v110\n v_dot2_f32_bf16 v111, v119, v122, v111\n v_dot2_f32_bf16 v112, v120, v123, v112\n v_dot2_f32_bf16 v113, v121, v116, v113\n v_dot2_f32_bf16 v114, v122, v117, v114\n v_dot2_f32_bf16 v115, v123, v118, v115\n "
+#define DOTC16 "v_dot2c_f32_bf16 v100, v116, v119\n v_dot2c_f32_bf16 v101, v117, v120\n v_dot2c_f32_bf16 v102, v118, v121\n v_dot2c_f32_bf16 v103, v119, v122\n v_dot2c_f32_bf16 v104, v120, v123\n v_dot2c_f32_bf16 v105, v121, v116\n v_dot2c_f32_bf16 v106, v122, v117\n v_dot2c_f32_bf16 v107, v123, v118\n v_dot2c_f32_bf16 v108, v116, v119\n v_dot2c_f32_bf16 v109, v117, v120\n v_dot2c_f32_bf16 v110, v118, v121\n v_dot2c_f32_bf16 v111, v119, v122\n v_dot2c_f32_bf16 v112, v120, v123\n v_dot2c_f32_bf16 v113, v121, v116\n v_dot2c_f32_bf16 v114, v122, v117\n v_dot2c_f32_bf16 v115, v123, v118\n "
+#define M_DOT MFMA "v_fma_f32 v100, v100, s4, v117\n v_exp_f32 v101, v101\n v_dot2_f32_bf16 v102, v118, v119, v102\n v_cvt_pk_bf16_f32 v103, v120, v121\n v_dot2c_f32_bf16 v104, v120, v121\n"
 template <int V>
 __global__ void probe(unsigned long long* cyc, int n) {
     asm volatile("v_mov_b32 v116, 1.0\n v_mov_b32 v117, 0\n v_mov_b32 v118, 1.0\n v_mov_b32 v119, 0\n v_mov_b32 v120, 1.0\n v_mov_b32 v121, 0\n v_mov_b32 v122, 1.0\n v_mov_b32 v123, 0\n s_mov_b32 s4, 1.0" ::: CLOB, "s4");
@@ -66,6 +69,9 @@ __global__ void probe(unsigned long long* cyc, int n) {
         if constexpr (V == 14) asm volatile(R8(PKFMAB8 PKFMAB8) ::: CLOB);
         if constexpr (V == 15) asm volatile(R8(PKADD8 PKADD8) ::: CLOB);
         if constexpr (V == 16) asm volatile(R8(PKMUL8 PKMUL8) ::: CLOB);
+        if constexpr (V == 19) asm volatile(R8(DOT16) ::: CLOB);
+        if constexpr (V == 20) asm volatile(R8(DOTC16) ::: CLOB);
+        if constexpr (V == 21) asm volatile(R8(M_DOT M_DOT) ::: CLOB, "s4");
         if constexpr (V == 17) asm volatile(R8(M_PK M_PK) ::: CLOB);
         if constexpr (V == 18) asm volatile(R8(M_PK6 M_PK6) ::: CLOB);
     }
@@ -94,7 +100,10 @@ int main() {
     run<14>("v_pk_fma_f32 op_sel_hi:[1,0,0] (broadcast low of src1)", 128, cyc);
     run<15>("v_pk_add_f32", 128, cyc);
     run<16>("v_pk_mul_f32", 128, cyc);
+    run<19>("v_dot2_f32_bf16", 128, cyc);
+    run<20>("v_dot2c_f32_bf16", 128, cyc);
     run<12>("mfma only", 16, cyc);
+    run<21>("mfma + fma(s) exp dot2 cvt dot2c", 16, cyc);
     run<17>("mfma + pk_fma exp exp pk_add cvt (2 scores)", 16, cyc);
     run<18>("mfma + pk_fma exp exp pk_add cvt max3", 16, cyc);
     run<6>("mfma + 4 v_fma (3 VGPR)", 16, cyc);
