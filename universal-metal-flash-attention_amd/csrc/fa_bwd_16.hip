@@ -187,7 +187,15 @@ __global__ __launch_bounds__(256, DP == 256 ? 1 : 2) void bwd16_dq_kernel(BwdPar
         }
     }
     delta += __shfl_xor(delta, 32, 64);
-    if (qok && hi == 0) p.dvec[(int64_t)bh * p.Sq + q_row] = delta;
+    if (qok && hi == 0) {
+        const int64_t ri = (int64_t)bh * p.Sq + q_row;
+        p.dvec[ri] = delta;
+        // ... and, for bwd16_dkdv, the two row constants in the form it consumes them: the addend of the exponent FMA and
+        // the initial value of the dP accumulator (dP - D comes out of the MFMA chain) -- 64 vector instructions per tile
+        // (32 multiplies, 32 subtractions) that its loop no longer issues
+        p.rowc[ri] = -L2;
+        p.rowc[(int64_t)p.B * p.H * p.Sq + ri] = -delta;
+    }
 
     const i32x4 k_srd = make_srd(kp, p.Skv * (uint32_t)ROW_B), v_srd = make_srd(vp, p.Skv * (uint32_t)ROW_B);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((LDS_AS char*)smem));
@@ -380,7 +388,7 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
     // waited for the whole prefetch at the top of every tile and the other waves for wave 0 at the barrier.
     // Rows past Sq read 0 (descriptor range check): their Q and dO rows are zero too, so S = dP = 0, P = 1, dS = 0 and
     // nothing reaches dK or dV.  LSE arrives in natural-log units; the factor log2(e) is applied where it is used.
-    const i32x4 lse_srd = make_srd(p.lse + (int64_t)bh * p.Sq, p.Sq * 4u), dv_srd = make_srd(p.dvec + (int64_t)bh * p.Sq, p.Sq * 4u);
+    const i32x4 lse_srd = make_srd(p.rowc + (int64_t)bh * p.Sq, p.Sq * 4u), dv_srd = make_srd(p.rowc + ((int64_t)p.B * p.H + bh) * p.Sq, p.Sq * 4u);
     auto stage_consts = [&](uint32_t t) {
         const int voff = (int)(t * QROWS + (uint32_t)lane) * 4;
         if (uw == 0)
@@ -446,18 +454,23 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
                 // wave cycles in waits, MFMA pipe 36 % busy).
                 // S[q][key] = Q K^T, dP[q][key] = dO V^T: rows = queries (registers), columns = keys (lanes)
                 f32x16 s[2], dp[2];
-                V8 aq[2 * NKS], ado[2 * NKS];
-                auto rd = [&](int j) {
-                    aq[j] = *(const V8*)(Qt + (j / NKS) * TILE_BYTES + d_off<DP>(kl, 2 * (j % NKS) + hi));
-                    ado[j] = *(const V8*)(dOt + (j / NKS) * TILE_BYTES + d_off<DP>(kl, 2 * (j % NKS) + hi));
+                // row fragments as ONE flat sequence f: sub-tile u = f / 2NKS, then the NKS fragments of Q (S = Q K^T), then the
+                // NKS of dO (dP = dO V^T) -- all S MFMAs of a sub-tile before its dP MFMAs, so the dP accumulator can start
+                // at -D (row constants read from LDS while the S MFMAs run): dP - D comes out of the MFMA chain
+                V8 rf[4 * NKS];
+                auto rd = [&](int f) {
+                    const int u = f / (2 * NKS), ks = f % NKS;
+                    rf[f] = *(const V8*)((((f / NKS) & 1) ? dOt : Qt) + u * TILE_BYTES + d_off<DP>(kl, 2 * ks + hi));
                 };
                 // row constants of sub-tile u: registers 4g .. 4g+3 are queries 8g + 4hi + 0..3
-                f32x4 l2c[2][4], dlc[2][4];
+                f32x4 l2c[2][4];
                 auto rd_consts = [&](int u) {
     #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        l2c[u][g] = *(const f32x4*)(L2v + 32 * u + 8 * g + 4 * hi);
-                        dlc[u][g] = *(const f32x4*)(Dv + 32 * u + 8 * g + 4 * hi);
+                        l2c[u][g] = *(const f32x4*)(L2v + 32 * u + 8 * g + 4 * hi);   // -LSE log2(e)
+                        const f32x4 nd = *(const f32x4*)(Dv + 32 * u + 8 * g + 4 * hi);  // -D
+    #pragma unroll
+                        for (int e = 0; e < 4; ++e) dp[u][4 * g + e] = nd[e];
                     }
                 };
                 V8 pb[2][2], sb[2][2];
@@ -468,10 +481,10 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
     #pragma unroll
                     for (int r = r0; r < r0 + 2; ++r) {
                         const int g = r >> 2, e = r & 3;
-                        float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], c, -l2c[u][g][e] * UMFA_LOG2E));
+                        float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], c, l2c[u][g][e]));  // l2c = -LSE log2(e)
                         if (edge && key > qb0 + 8 * g + 4 * hi + e) pr = 0.0f;
                         pb[u][r >> 3][r & 7] = (T)pr;
-                        sb[u][r >> 3][r & 7] = (T)(pr * (dp[u][r] - dlc[u][g][e]));
+                        sb[u][r >> 3][r & 7] = (T)(pr * dp[u][r]);                                      // dp = dP - D (accumulator started at -D)
                     }
                 };
                 constexpr int NF = 4 * NDBH, PT = 4;  // dV / dK MFMAs of one sub-tile; transposed fragments in flight
@@ -480,23 +493,26 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
                     const int u = j / NF, r = j % NF, i = r >> 2, s2 = (r >> 1) & 1;
                     tf[j] = tr_frag<M, DP>(((r & 1) ? Qt : dOt) + u * TILE_BYTES, i + hpass * NDBH, s2, hi, tr_qq, tr_pp, tr_g1);
                 };
+                constexpr int PF = 2 * PD;  // row fragments in flight
     #pragma unroll
-                for (int j = 0; j < PD; ++j) rd(j);
+                for (int f = 0; f < PF; ++f) rd(f);
                 rd_consts(0);
                 __builtin_amdgcn_sched_barrier(0);
     #pragma unroll
-                for (int j = 0; j < 2 * NKS; ++j) {
-                    if (j + PD < 2 * NKS) rd(j + PD);
-                    if (j == 2 * NKS - 3) rd_consts(1);  // late: needed from the second step of P2a on, 32 registers
-                    if (j >= 2 * NKS - PT / 2) { trd(2 * (j - (2 * NKS - PT / 2))); trd(2 * (j - (2 * NKS - PT / 2)) + 1); }
+                for (int f = 0; f < 4 * NKS; ++f) {
+                    const int u = f / (2 * NKS), ks = f % NKS;
+                    if (f + PF < 4 * NKS) rd(f + PF);
+                    if (f == 2 * NKS + 2) rd_consts(1);  // needed from f = 3 NKS on (dP of sub-tile 1 starts at -D)
+                    if (f >= 4 * NKS - PT) trd(f - (4 * NKS - PT));
                     // VGPR-destination MFMAs (Mma16::mma_v: the vector unit reads S and dP; as AGPR accumulators they cost
-                    // 128 v_accvgpr_read per tile); first k-step of a sub-tile: C = 0 as the inline constant
-                    if (j % NKS) { M::mma_v(s[j / NKS], aq[j], kf[j % NKS]); M::mma_v(dp[j / NKS], ado[j], vf[j % NKS]); }
-                    else { M::mma_v_first(s[j / NKS], aq[j], kf[j % NKS]); M::mma_v_first(dp[j / NKS], ado[j], vf[j % NKS]); }
-                    if (j >= NKS) {  // P1b: the 8 score pairs of sub-tile 0 spread over the NKS steps
+                    // 128 v_accvgpr_read per tile); first k-step of S: C = 0 as the inline constant
+                    if ((f / NKS) & 1) M::mma_v(dp[u], rf[f], vf[ks]);
+                    else if (ks) M::mma_v(s[u], rf[f], kf[ks]);
+                    else M::mma_v_first(s[u], rf[f], kf[ks]);
+                    if (f >= 2 * NKS + 1) {  // P1b: the 8 score pairs of sub-tile 0 behind every second MFMA (>= 2 issues after dP's last)
     #pragma unroll
                         for (int cch = 0; cch < 8; ++cch)
-                            if (cch * NKS / 8 == j - NKS) softmax_pair(0, 2 * cch);
+                            if (2 * NKS + 1 + cch * (2 * NKS) / 8 == f) softmax_pair(0, 2 * cch);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -551,10 +567,10 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
     #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int r = 4 * g + e;
-                            float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], c, -l2[e] * UMFA_LOG2E));
+                            float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], c, l2[e]));  // l2 = -LSE log2(e), dl = -D (p.rowc)
                             if (edge && key > qb0 + 8 * g + 4 * hi + e) pr = 0.0f;
                             pb[r >> 3][r & 7] = (T)pr;
-                            sb[r >> 3][r & 7] = (T)(pr * (dp[u][r] - dl[e]));
+                            sb[r >> 3][r & 7] = (T)(pr * (dp[u][r] + dl[e]));
                         }
                     }
                     // dV^T[d][key] += dO^T[d][q] P[q][key];  dK^T[d][key] += Q^T[d][q] dS[q][key]

@@ -113,6 +113,7 @@ struct BwdParams {
     float* dk;
     float* dv;
     float* dvec;
+    float* rowc;    // bwd16 only, internal scratch [2][B*H*Sq]: -LSE * log2(e), then -D (written by bwd16_dq, read by bwd16_dkdv)
     const float* mask;  // optional fp32 additive [B,H,Sq,Skv] (quantised backward only)
     uint32_t B, H, Sq, Skv, D;
     float scale;

@@ -102,6 +102,7 @@ struct StreamScratch {
     size_t w64_cnt_bytes = 0;
     GrowBuf mflags;     // mask tile flags
     GrowBuf workspace;  // quantiser output (int8 Q/K, V image, scales, fp32 copies for backward)
+    GrowBuf rowc;       // bwd16: row constants [2][B*H*Sq] fp32 (-LSE log2 e, -D) from bwd16_dq for bwd16_dkdv
 
     // tickets [0, cnt) zeroed on `stream` whenever the block is new, partials behind them at w64_cnt_bytes
     char* ensure_w64(size_t cnt_bytes, size_t buf_bytes, hipStream_t stream) {

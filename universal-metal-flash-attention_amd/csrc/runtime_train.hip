@@ -65,7 +65,12 @@ mfa_error_t mfa_attention_backward(mfa_context_t context, mfa_buffer_t dout, mfa
     const char* name = "none";
     // 16-bit operands with 16-bit intermediates -> MFMA backward; everything else -> fp32-exact backward
     const bool lowp = dense_prec(intermediate_precision) != P_FP32 && !getenv("UMFA_BWD_EXACT");
-    hipError_t e = (lowp && bwd_16_supported(p)) ? launch_bwd_16(p, stream, &name) : launch_bwd(p, stream, &name);
+    const bool mfma16 = lowp && bwd_16_supported(p);
+    if (mfma16) {
+        p.rowc = (float*)ctx->pool(ctx->device, stream).rowc.ensure(2 * nr * sizeof(float), stream);
+        if (!p.rowc) return MFA_ERROR_MEMORY_ALLOCATION;
+    }
+    hipError_t e = mfma16 ? launch_bwd_16(p, stream, &name) : launch_bwd(p, stream, &name);
     ctx->last_kernel = name;
     if (e != hipSuccess) return e == hipErrorInvalidValue ? MFA_ERROR_INVALID_ARGS : MFA_ERROR_EXECUTION_FAILED;
     lat.stop();
@@ -106,6 +111,13 @@ mfa_error_t umfa_attention_backward_stream(mfa_context_t context, void* stream, 
     const bool mfma16 = lowp && bwd_16_supported(p);
     if (grads_in_input_type && !mfma16) return MFA_ERROR_INVALID_ARGS;
     const char* name = "none";
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    const int dev = stream_device((hipStream_t)stream);
+    DeviceGuard guard(dev);
+    if (mfma16) {  // row constants of the second kernel, from the scratch pool of this (device, stream)
+        p.rowc = (float*)ctx->pool(dev, (hipStream_t)stream).rowc.ensure((size_t)2 * batch_size * num_heads * seq_len_q * sizeof(float), (hipStream_t)stream);
+        if (!p.rowc) return MFA_ERROR_MEMORY_ALLOCATION;
+    }
     hipError_t e = mfma16 ? launch_bwd_16(p, (hipStream_t)stream, &name) : launch_bwd(p, (hipStream_t)stream, &name);
     ctx->last_kernel = name;
     return e == hipSuccess ? MFA_SUCCESS : e == hipErrorInvalidValue ? MFA_ERROR_INVALID_ARGS : MFA_ERROR_EXECUTION_FAILED;
