@@ -589,8 +589,12 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
         stage(tt + 1);
         stage_consts(tt + 1);
         tile_body(tt, EDGE_C, PAR_C);
+#ifdef BWD16_LAB_NOBAR      // lab, timing only (results are wrong): what the end-of-tile wait + barrier cost
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#endif
     };
     // [t, t_ne): tiles on the diagonal (and one more when that leaves an odd start), run-time parity; then pairs
     uint32_t t_ne = t;
