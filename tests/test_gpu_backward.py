@@ -252,3 +252,24 @@ def test_backward_stream_accepts_o_in_operand_type(ctx):
     for x, y in zip(a, b):
         assert x.dtype == torch.float32 and y.dtype == torch.float32
         assert ((x - y).abs().max() / x.abs().max()).item() < 1e-2
+
+
+@pytest.mark.parametrize("which", ["1", "2"])
+@pytest.mark.parametrize("causal", [False, True])
+def test_backward_both_dq_kernels_head_dim_128(ctx, which, causal, monkeypatch):
+    """head_dim 128 has two dQ kernels (two workgroups per CU with 32-key tiles; one per CU with 64-key tiles and the pinned
+    four-phase pipeline); the launcher picks by causality.  UMFA_BWD_DQ forces one: both must meet the oracle on both kinds
+    of launch, ragged sizes included."""
+    import umfa
+    orc = _oracle()
+    monkeypatch.setenv("UMFA_BWD_DQ", which)
+    for shape in [(1, 2, 256, 128), (2, 1, 333, 128), (1, 1, 1024, 128)]:
+        rng = np.random.default_rng(21)
+        q, k, v, do = (orc.f32_to_bf16_bits(rng.standard_normal(shape).astype(np.float32)).reshape(shape) for _ in range(4))
+        o, lse = orc.sdpa_forward(q, k, v, causal=causal, return_lse=True)
+        rdq, rdk, rdv, _ = orc.sdpa_backward(do, q, k, v, o, lse, causal=causal)
+        dq, dk, dv, _ = umfa.attention_backward(ctx, do, q, k, v, o, lse.ravel(), causal=causal, input_precision="bf16")
+        assert ctx.last_kernel.startswith("fa_bwd16")
+        for got, ref, name in [(dq, rdq, "dq"), (dk, rdk, "dk"), (dv, rdv, "dv")]:
+            rel = np.abs(got - ref).max() / np.abs(ref).max()
+            assert np.isfinite(got).all() and rel < 2e-2, (which, causal, shape, name, rel)

@@ -5,7 +5,7 @@ import numpy as np
 import umfa
 from oracle import oracle as orc
 ctx = umfa.MFAContext() if hasattr(umfa, "MFAContext") else umfa.create_context()
-for shape, causal in [((1, 2, 128, 256), True), ((1, 2, 128, 256), False), ((1, 2, 333, 256), True), ((1, 2, 128, 128), True)]:
+for shape, causal in [((1, 2, 128, 128), True), ((1, 2, 256, 128), True), ((1, 1, 1024, 128), True), ((1, 2, 130, 128), True), ((1, 2, 128, 128), False)]:
     rng = np.random.default_rng(9)
     f = [rng.standard_normal(shape).astype(np.float32) for _ in range(4)]
     q, k, v, do = (orc.f32_to_bf16_bits(a).reshape(shape) for a in f)

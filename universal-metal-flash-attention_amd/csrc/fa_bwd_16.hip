@@ -324,6 +324,210 @@ __global__ __launch_bounds__(256, DP == 256 ? 1 : 2) void bwd16_dq_kernel(BwdPar
     }
 }
 
+// ------------------------------------------------------------------------------------------------ dQ, head_dim 128, v2
+// The same products as bwd16_dq with the structure bwd16_dkdv got in round 2: ONE workgroup per CU (one wave per SIMD, the
+// whole register file: FLUX = 768 workgroups = 3 full rounds, where two-per-CU left every CU's third workgroup running
+// alone at a third of the matrix pipe), 64-key tiles = two 32-key sub-tiles per barrier, and the tile as four phases of
+// back-to-back MFMAs with the vector work of the next phase's operands between them (source order pinned):
+//   P1a  S^T, dP^T of sub-tile 0 (K / V row fragments PF ahead)      P1b  S^T, dP^T of sub-tile 1 | P, dS of sub-tile 0
+//   P2a  dQ^T += K0^T dS0 (transposed fragments PT ahead)            | P, dS of sub-tile 1          P2b  dQ^T += K1^T dS1
+// S^T / dP^T are VGPR-destination MFMAs (Mma16::mma_v) with the Q / dO fragments homed in AGPRs.
+template <typename T, bool CAUSAL>
+__global__ __launch_bounds__(256, 1) void bwd16_dq2_kernel(BwdParams p) {
+    constexpr int DP = 128;
+    BWD16_GEO(DP);
+    typedef Mma16<T> M;
+    typedef typename M::V8 V8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // [K buf0 16 KiB][K buf1][V buf0][V buf1]: 64-key tiles = two 32-row sub-images each
+    constexpr int KROWS = 64, KTILE_B = KROWS * ROW_B, KT = 0, VT = 2 * KTILE_B;
+    const int tid = threadIdx.x, lane = tid & 63, ql = lane & 31, hi = lane >> 5;
+    const int wave = tid >> 6, uw = __builtin_amdgcn_readfirstlane(wave);
+    const uint32_t nqb = (p.Sq + 127) / 128;
+    const uint32_t vid = xcd_remap(blockIdx.x, nqb * p.B * p.H);
+    uint32_t bh = vid / nqb;
+    uint32_t qb = vid % nqb;
+    if (CAUSAL) { bh = vid / nqb; qb = nqb - 1 - vid % nqb; }  // longest first (one workgroup per CU: slots refill as they free up)
+    const uint32_t q_row = qb * 128 + wave * 32 + ql;
+    const bool qok = q_row < p.Sq;
+    const T* qp = (const T*)p.q + (int64_t)bh * p.Sq * DP;
+    const T* dop = (const T*)p.dout + (int64_t)bh * p.Sq * DP;
+    const T* kp = (const T*)p.k + (int64_t)bh * p.Skv * DP;
+    const T* vp = (const T*)p.v + (int64_t)bh * p.Skv * DP;
+
+    // B operands: lane (q, hi) holds Q[q][16 ks + 8 hi ..], dO[q][...]
+    V8 qf[NKS], dof[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        if (qok) {
+            qf[ks] = *(const V8*)(qp + (int64_t)q_row * DP + 16 * ks + 8 * hi);
+            dof[ks] = *(const V8*)(dop + (int64_t)q_row * DP + 16 * ks + 8 * hi);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { qf[ks][j] = (T)0.0f; dof[ks][j] = (T)0.0f; }
+        }
+    }
+    const float c = p.scale * UMFA_LOG2E;
+    const float L2 = qok ? p.lse[(int64_t)bh * p.Sq + q_row] * UMFA_LOG2E : INFINITY;  // +inf -> P = 0
+    // D[q] = rowsum(dO o O), fused here as in bwd16_dq (see there)
+    float delta = 0.0f;
+    if (qok) {
+        const int64_t orow = ((int64_t)bh * p.Sq + q_row) * DP;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int64_t at = orow + 16 * ks + 8 * hi;
+            if (p.o_in_type) {
+                const V8 ov = *(const V8*)((const T*)p.o + at);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) delta = __builtin_fmaf((float)dof[ks][j], (float)ov[j], delta);
+            } else {
+                const f32x4 o0 = *(const f32x4*)(p.o + at), o1 = *(const f32x4*)(p.o + at + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    delta = __builtin_fmaf((float)dof[ks][j], o0[j], delta);
+                    delta = __builtin_fmaf((float)dof[ks][4 + j], o1[j], delta);
+                }
+            }
+        }
+    }
+    delta += __shfl_xor(delta, 32, 64);
+    if (qok && hi == 0) {
+        const int64_t ri = (int64_t)bh * p.Sq + q_row;
+        p.dvec[ri] = delta;
+        p.rowc[ri] = -L2;                                        // row constants for bwd16_dkdv (see bwd16_dq)
+        p.rowc[(int64_t)p.B * p.H * p.Sq + ri] = -delta;
+    }
+    // home the B operands in the accumulator half of the register file (Mma16::mma_v takes them from there)
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+a"(qf[ks]), "+a"(dof[ks]));
+
+    const i32x4 k_srd = make_srd(kp, p.Skv * (uint32_t)ROW_B), v_srd = make_srd(vp, p.Skv * (uint32_t)ROW_B);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((LDS_AS char*)smem));
+#pragma unroll
+    for (int i = 0; i < 4 * KTILE_B / 4096; ++i) *(i32x4*)(smem + i * 4096 + tid * 16) = i32x4{0, 0, 0, 0};
+    __syncthreads();
+
+    uint32_t ntiles = (p.Skv + KROWS - 1) / KROWS;
+    if (CAUSAL) {
+        const uint32_t lim = (qb * 128 + 128 + KROWS - 1) / KROWS;
+        ntiles = ntiles < lim ? ntiles : lim;
+    }
+    f32x16 acc[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    const int tr_qq = (lane >> 2) & 3, tr_pp = lane & 3, tr_g1 = (lane >> 4) & 1;
+
+    auto stage = [&](uint32_t t) {
+        dma_rows<2 * TILE_PIECES, DP>(k_srd, lds0 + KT + (t & 1) * KTILE_B, t * KROWS, uw, lane);
+        dma_rows<2 * TILE_PIECES, DP>(v_srd, lds0 + VT + (t & 1) * KTILE_B, t * KROWS, uw, lane);
+    };
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // and for hipcc's scoreboard (Q / dO fragment loads; see bwd16_dq)
+    __syncthreads();
+
+    auto tile_body = [&](uint32_t t, auto EDGE_C, auto PAR_C) {
+        constexpr bool EDGE = decltype(EDGE_C)::value;
+        constexpr int PAR = decltype(PAR_C)::value;
+        const int par = PAR >= 0 ? PAR : (int)(t & 1);
+        const char* Kt = smem + KT + par * KTILE_B;
+        const char* Vt = smem + VT + par * KTILE_B;
+        const uint32_t key_base = t * KROWS;
+        f32x16 s[2], dp[2];
+        // row fragments as one flat sequence f: sub-tile u = f / 2NKS, NKS of K (S^T = K Q^T), then NKS of V (dP^T = V dO^T)
+        // (alternating the two chains k-step by k-step measured slower, same box: the hardware chains back-to-back MFMAs
+        // onto one accumulator without a bubble)
+        V8 rf[4 * NKS];
+        auto rd = [&](int f) {
+            const int u = f / (2 * NKS), ks = f % NKS;
+            rf[f] = *(const V8*)((((f / NKS) & 1) ? Vt : Kt) + u * TILE_BYTES + d_off<DP>(ql, 2 * ks + hi));
+        };
+        V8 ds[2][2];
+        auto softmax_pair = [&](int u, int r0) {  // dS of scores r0, r0 + 1 of sub-tile u
+#pragma unroll
+            for (int r = r0; r < r0 + 2; ++r) {
+                float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], c, -L2));
+                if constexpr (EDGE) {
+                    const uint32_t key = key_base + 32 * u + acc_row(r, hi);
+                    if (key >= p.Skv || (CAUSAL && key > q_row)) pr = 0.0f;
+                }
+                ds[u][r >> 3][r & 7] = (T)(pr * (dp[u][r] - delta));
+            }
+        };
+        constexpr int NF = 2 * NDB, PT = 4, PF = 8;  // dQ MFMAs of one sub-tile; transposed / row fragments in flight
+        V8 tf[2 * NF];
+        auto trd = [&](int j) {
+            const int u = j / NF, r = j % NF, i = r >> 1, s2 = r & 1;
+            tf[j] = tr_frag<M, DP>(Kt + u * TILE_BYTES, i, s2, hi, tr_qq, tr_pp, tr_g1);
+        };
+#pragma unroll
+        for (int f = 0; f < PF; ++f) rd(f);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < 4 * NKS; ++f) {
+            const int u = f / (2 * NKS), ks = f % NKS;
+            if (f + PF < 4 * NKS) rd(f + PF);
+            if (f >= 4 * NKS - PT) trd(f - (4 * NKS - PT));
+            if ((f / NKS) & 1) { if (ks) M::mma_v(dp[u], rf[f], dof[ks]); else M::mma_v_first(dp[u], rf[f], dof[ks]); }
+            else { if (ks) M::mma_v(s[u], rf[f], qf[ks]); else M::mma_v_first(s[u], rf[f], qf[ks]); }
+            __builtin_amdgcn_sched_barrier(0);  // the vector work below must not move ahead of this MFMA (see Mma16::mma_v)
+            // P1b: the 8 score pairs of sub-tile 0 behind every second MFMA (>= 2 issues after dP's last); ONE call site
+            // per step: eight guarded copies per step put the loop over hipcc's pragma-unroll cost threshold, the loop
+            // then stayed rolled, the accumulators went through scratch and were copied right behind the asm MFMAs
+            if (f >= 2 * NKS + 1 && (f - (2 * NKS + 1)) % 2 == 0) softmax_pair(0, f - (2 * NKS + 1));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+#pragma unroll
+        for (int j = 0; j < 2 * NF; ++j) {
+            const int u = j / NF, r = j % NF, i = r >> 1, s2 = r & 1;
+            if (j + PT < 2 * NF) trd(j + PT);
+            acc[i] = M::mma(tf[j], ds[u][s2], acc[i]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (j >= 1 && j < 1 + 8) softmax_pair(1, 2 * (j - 1));  // P2a: one score pair of sub-tile 1 behind each MFMA (first: 2 issues after dP's last)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto step = [&](uint32_t tt, auto EDGE_C, auto PAR_C) {
+        stage(tt + 1);  // other buffer: its last readers passed the previous barrier
+        tile_body(tt, EDGE_C, PAR_C);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    // tile ranges of this wave (wave-uniform): [0, t1) plain, [t1, t2) with the per-key test, [t2, ntiles) idle
+    const uint32_t wq0 = __builtin_amdgcn_readfirstlane(qb * 128 + (uint32_t)uw * 32);
+    uint32_t t2 = ntiles, t1 = p.Skv / KROWS;
+    if (CAUSAL) {
+        t2 = (wq0 + 31) / KROWS + 1 < ntiles ? (wq0 + 31) / KROWS + 1 : ntiles;  // key_base <= wave_q0 + 31
+        t1 = (wq0 + 1) / KROWS < t1 ? (wq0 + 1) / KROWS : t1;                    // key_base + 63 <= wave_q0
+    }
+    t1 = t1 < t2 ? t1 : t2;
+    uint32_t t = 0;
+    for (; t + 1 < t1; t += 2) {
+        step(t, std::false_type{}, std::integral_constant<int, 0>{});
+        step(t + 1, std::false_type{}, std::integral_constant<int, 1>{});
+    }
+    for (; t < t2; ++t) step(t, std::true_type{}, std::integral_constant<int, -1>{});
+    for (; t < ntiles; ++t) {
+        stage(t + 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (qok) {
+        const int64_t orow = ((int64_t)bh * p.Sq + q_row) * DP;
+#pragma unroll
+        for (int i = 0; i < NDB; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 val = {acc[i][4 * g] * p.scale, acc[i][4 * g + 1] * p.scale, acc[i][4 * g + 2] * p.scale,
+                             acc[i][4 * g + 3] * p.scale};
+                store_grad4<T>(p.dq, orow + 32 * i + 8 * g + 4 * hi, val, p.grad_in_type != 0);
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ dK, dV
 template <typename T, bool CAUSAL, int DP>
 __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdParams p) {
@@ -509,11 +713,10 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
                     if ((f / NKS) & 1) M::mma_v(dp[u], rf[f], vf[ks]);
                     else if (ks) M::mma_v(s[u], rf[f], kf[ks]);
                     else M::mma_v_first(s[u], rf[f], kf[ks]);
-                    if (f >= 2 * NKS + 1) {  // P1b: the 8 score pairs of sub-tile 0 behind every second MFMA (>= 2 issues after dP's last)
-    #pragma unroll
-                        for (int cch = 0; cch < 8; ++cch)
-                            if (2 * NKS + 1 + cch * (2 * NKS) / 8 == f) softmax_pair(0, 2 * cch);
-                    }
+                    __builtin_amdgcn_sched_barrier(0);  // the vector work below must not move ahead of this MFMA (see Mma16::mma_v)
+                    // P1b: the 8 score pairs of sub-tile 0 behind every second MFMA (>= 2 issues after dP's last); one call site
+                    // per step (see bwd16_dq2: guarded copies per step can push the loop over the pragma-unroll threshold)
+                    if (f >= 2 * NKS + 1 && (f - (2 * NKS + 1)) % 2 == 0) softmax_pair(0, f - (2 * NKS + 1));
                     __builtin_amdgcn_sched_barrier(0);
                 }
     #pragma unroll
@@ -522,11 +725,9 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
                     if (j + PT < 2 * NF) trd(j + PT);
                     if (r & 1) dk[i] = M::mma(tf[j], sb[u][s2], dk[i]);
                     else dv[i] = M::mma(tf[j], pb[u][s2], dv[i]);
-                    if (j < NF) {  // P2a: the 8 score pairs of sub-tile 1 spread over the NF steps
-    #pragma unroll
-                        for (int cch = 0; cch < 8; ++cch)
-                            if (cch * NF / 8 + 1 == j) softmax_pair(1, 2 * cch);
-                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    // P2a: the 8 score pairs of sub-tile 1 behind every second MFMA, from the second one on
+                    if (j < NF && j % 2 == 1) softmax_pair(1, j - 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {  // head_dim 64 (two workgroups per CU, 256 registers) and 256 (two passes): hipcc's own order
@@ -651,7 +852,28 @@ static hipError_t launch_bwd16_t(const BwdParams& p, hipStream_t stream) {
         attr_set = true;
     }
     const uint32_t nqb = (p.Sq + 127) / 128, nkb = (p.Skv + 127) / 128;
-    hipLaunchKernelGGL((bwd16_dq_kernel<T, CAUSAL, DP>), dim3(nqb * p.B * p.H), dim3(256), lds_dq, stream, p);
+    if constexpr (DP == 128) {
+        // one-workgroup-per-CU kernel for non-causal launches (same box, ms per backward, v2 / two-per-CU: FLUX 0.678 / 0.693,
+        // B2 H8 S2048 0.145 / 0.159, B8 H16 S1024 0.304 / 0.299); causal launches keep the two-per-CU kernel (FLUX causal
+        // 0.477 / 0.464, B4 H16 S8192 causal 3.46 / 3.45: unequal items balance better over two slots per CU).
+        // UMFA_BWD_DQ=1 / 2 forces one of them (A/B).
+        const char* fe = getenv("UMFA_BWD_DQ");  // read per launch: tests drive both kernels in one process
+        const int force = fe ? atoi(fe) : 0;
+        if (force == 2 || (force == 0 && !CAUSAL)) {
+            const size_t lds_dq2 = 4 * 64 * 2 * DP;
+            static bool attr2 = false;
+            if (!attr2) {
+                hipError_t e2 = hipFuncSetAttribute((const void*)bwd16_dq2_kernel<T, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq2);
+                if (e2 != hipSuccess) return e2;
+                attr2 = true;
+            }
+            hipLaunchKernelGGL((bwd16_dq2_kernel<T, CAUSAL>), dim3(nqb * p.B * p.H), dim3(256), lds_dq2, stream, p);
+        } else {
+            hipLaunchKernelGGL((bwd16_dq_kernel<T, CAUSAL, DP>), dim3(nqb * p.B * p.H), dim3(256), lds_dq, stream, p);
+        }
+    } else {
+        hipLaunchKernelGGL((bwd16_dq_kernel<T, CAUSAL, DP>), dim3(nqb * p.B * p.H), dim3(256), lds_dq, stream, p);
+    }
     hipLaunchKernelGGL((bwd16_dkdv_kernel<T, CAUSAL, DP>), dim3(nkb * p.B * p.H), dim3(256), lds_kv, stream, p);
     return hipGetLastError();
 }
