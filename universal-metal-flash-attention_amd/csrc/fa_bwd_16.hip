@@ -72,6 +72,40 @@ __device__ __forceinline__ void dma_rows(const i32x4& srd, unsigned lds_dst, uin
     }
 }
 
+// The same with the lane-dependent part of every piece's source offset computed ONCE (dma_lane_offsets, before the tile
+// loop): per tile one scalar multiply and one vector add per piece are left.  As dma_rows inside the loop the row / chunk /
+// swizzle arithmetic of all pieces was redone for every tile: ~540 of ~3600 cycles per tile of bwd16_dkdv (phase stamps,
+// tools/lab/bwd_stamps.py).
+template <int NPIECES, int DP>
+__device__ __forceinline__ void dma_lane_offsets(int (&off)[(NPIECES + 3) / 4], int uw, int lane) {
+    constexpr int NCH = DP / 8, RPP = 1024 / (2 * DP);
+    const int r = lane / NCH, c = lane % NCH;
+#pragma unroll
+    for (int i = 0; i < (NPIECES + 3) / 4; ++i) {
+        const int row = RPP * (4 * i + uw) + r;
+        off[i] = d_off<DP>(row, c);  // = row * ROW_B + 16 * (c ^ swizzle(row))
+    }
+}
+template <int NPIECES, int DP>
+__device__ __forceinline__ void dma_rows_pre(const i32x4& srd, unsigned lds_dst, uint32_t row0, int uw, const int (&off)[(NPIECES + 3) / 4]) {
+    constexpr int ROW_B = 2 * DP;
+    const int base = (int)row0 * ROW_B;
+#pragma unroll
+    for (int i = 0; i < (NPIECES + 3) / 4; ++i) {
+        const int n = 4 * i + uw;
+        if (n < NPIECES) {
+            const int voff = base + off[i];
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                         ::"s"(lds_dst + n * 1024), "v"(voff), "s"(srd) : "memory");
+        }
+    }
+}
+
+// one 1-KiB piece of an LDS-DMA tile (see dma_rows_pre)
+__device__ __forceinline__ void dma_piece(const i32x4& srd, unsigned lds_dst, int voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_dst), "v"(voff), "s"(srd) : "memory");
+}
+
 // transposed-read fragment: rows (row0 .. +3) and (row0+8 .. +11) x 16 columns of d-block i, as the A operand whose
 // element j is image row 16 s + 8 (j>>2) + 4 hi + (j&3) (the k order of an accumulator used as B operand)
 template <typename M, int DP>
@@ -215,7 +249,7 @@ __global__ __launch_bounds__(256, DP == 256 ? 1 : 2) void bwd16_dq_kernel(BwdPar
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
     const int tr_qq = (lane >> 2) & 3, tr_pp = lane & 3, tr_g1 = (lane >> 4) & 1;
 
-    auto stage = [&](uint32_t t) {
+    auto stage = [&](uint32_t t) __attribute__((always_inline)) {
         dma_rows<TILE_PIECES, DP>(k_srd, lds0 + (t & 1) * TILE_BYTES, t * 32, uw, lane);
         dma_rows<TILE_PIECES, DP>(v_srd, lds0 + 2 * TILE_BYTES + (t & 1) * TILE_BYTES, t * 32, uw, lane);
     };
@@ -235,7 +269,7 @@ __global__ __launch_bounds__(256, DP == 256 ? 1 : 2) void bwd16_dq_kernel(BwdPar
     // PAR: which half of the double buffer, as a compile-time constant in the steady-state loop (unrolled by two): every
     // LDS address is then a loop-invariant lane register + an immediate, where a run-time (t & 1) cost ~40 address adds
     // per tile; -1 = run-time parity (the few edge tiles).
-    auto tile_body = [&](uint32_t t, auto EDGE_C, auto PAR_C) {
+    auto tile_body = [&](uint32_t t, auto EDGE_C, auto PAR_C) __attribute__((always_inline)) {
         constexpr bool EDGE = decltype(EDGE_C)::value;
         constexpr int PAR = decltype(PAR_C)::value;
         const int par = PAR >= 0 ? PAR : (int)(t & 1);
@@ -419,16 +453,24 @@ __global__ __launch_bounds__(256, 1) void bwd16_dq2_kernel(BwdParams p) {
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
     const int tr_qq = (lane >> 2) & 3, tr_pp = lane & 3, tr_g1 = (lane >> 4) & 1;
 
-    auto stage = [&](uint32_t t) {
-        dma_rows<2 * TILE_PIECES, DP>(k_srd, lds0 + KT + (t & 1) * KTILE_B, t * KROWS, uw, lane);
-        dma_rows<2 * TILE_PIECES, DP>(v_srd, lds0 + VT + (t & 1) * KTILE_B, t * KROWS, uw, lane);
+    int dma_off[(2 * TILE_PIECES + 3) / 4];
+    dma_lane_offsets<2 * TILE_PIECES, DP>(dma_off, uw, lane);
+    auto stage = [&](uint32_t t) __attribute__((always_inline)) {
+        dma_rows_pre<2 * TILE_PIECES, DP>(k_srd, lds0 + KT + (t & 1) * KTILE_B, t * KROWS, uw, dma_off);
+        dma_rows_pre<2 * TILE_PIECES, DP>(v_srd, lds0 + VT + (t & 1) * KTILE_B, t * KROWS, uw, dma_off);
+    };
+    constexpr int NPW = (2 * TILE_PIECES + 3) / 4;
+    auto stage_piece = [&](uint32_t t, int i) __attribute__((always_inline)) {  // one piece at a time from inside the pinned MFMA stream (see bwd16_dkdv)
+        const int j = i % NPW, n = 4 * j + uw;
+        const int voff = (int)(t * KROWS) * ROW_B + dma_off[j];
+        dma_piece(i < NPW ? k_srd : v_srd, lds0 + (i < NPW ? KT : VT) + (t & 1) * KTILE_B + n * 1024, voff);
     };
     stage(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_waitcnt(0x0F70);  // and for hipcc's scoreboard (Q / dO fragment loads; see bwd16_dq)
     __syncthreads();
 
-    auto tile_body = [&](uint32_t t, auto EDGE_C, auto PAR_C) {
+    auto tile_body = [&](uint32_t t, auto EDGE_C, auto PAR_C) __attribute__((always_inline)) {
         constexpr bool EDGE = decltype(EDGE_C)::value;
         constexpr int PAR = decltype(PAR_C)::value;
         const int par = PAR >= 0 ? PAR : (int)(t & 1);
@@ -468,6 +510,7 @@ __global__ __launch_bounds__(256, 1) void bwd16_dq2_kernel(BwdParams p) {
 #pragma unroll
         for (int f = 0; f < 4 * NKS; ++f) {
             const int u = f / (2 * NKS), ks = f % NKS;
+            if (f % 4 == 1 && f / 4 < 2 * NPW) stage_piece(t + 1, f / 4);
             if (f + PF < 4 * NKS) rd(f + PF);
             if (f >= 4 * NKS - PT) trd(f - (4 * NKS - PT));
             if ((f / NKS) & 1) { if (ks) M::mma_v(dp[u], rf[f], dof[ks]); else M::mma_v_first(dp[u], rf[f], dof[ks]); }
@@ -490,9 +533,8 @@ __global__ __launch_bounds__(256, 1) void bwd16_dq2_kernel(BwdParams p) {
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    auto step = [&](uint32_t tt, auto EDGE_C, auto PAR_C) {
-        stage(tt + 1);  // other buffer: its last readers passed the previous barrier
-        tile_body(tt, EDGE_C, PAR_C);
+    auto step = [&](uint32_t tt, auto EDGE_C, auto PAR_C) __attribute__((always_inline)) {
+        tile_body(tt, EDGE_C, PAR_C);  // issues the next tile's LDS-DMA pieces itself (other buffer: its last readers passed the previous barrier)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
@@ -582,9 +624,25 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
     constexpr int QROWS = 64, QTILE_B = QROWS * ROW_B;
     const uint32_t ntiles = (p.Sq + QROWS - 1) / QROWS;
     const uint32_t t0 = CAUSAL ? (kb * 128) / QROWS : 0;  // query tiles entirely before this key block see nothing
-    auto stage = [&](uint32_t t) {
-        dma_rows<2 * TILE_PIECES, DP>(q_srd, lds0 + QT + (t & 1) * QTILE_B, t * QROWS, uw, lane);
-        dma_rows<2 * TILE_PIECES, DP>(do_srd, lds0 + DOT + (t & 1) * QTILE_B, t * QROWS, uw, lane);
+    constexpr int NPW = DP == 128 ? (2 * TILE_PIECES + 3) / 4 : 1;  // pieces per wave and tile image (hoisted offsets: head_dim 128 only)
+    int dma_off[NPW];
+    if constexpr (DP == 128) dma_lane_offsets<2 * TILE_PIECES, DP>(dma_off, uw, lane);
+    auto stage = [&](uint32_t t) __attribute__((always_inline)) {
+        if constexpr (DP == 128) {
+            dma_rows_pre<2 * TILE_PIECES, DP>(q_srd, lds0 + QT + (t & 1) * QTILE_B, t * QROWS, uw, dma_off);
+            dma_rows_pre<2 * TILE_PIECES, DP>(do_srd, lds0 + DOT + (t & 1) * QTILE_B, t * QROWS, uw, dma_off);
+        } else {
+            dma_rows<2 * TILE_PIECES, DP>(q_srd, lds0 + QT + (t & 1) * QTILE_B, t * QROWS, uw, lane);
+            dma_rows<2 * TILE_PIECES, DP>(do_srd, lds0 + DOT + (t & 1) * QTILE_B, t * QROWS, uw, lane);
+        }
+    };
+    // head_dim 128: the next tile's eight pieces one at a time from inside the pinned MFMA stream (a wave that issues them
+    // back to back sits ~520 cycles in the issue of these nine instructions: phase stamps, tools/lab/bwd_stamps.py --
+    // the same finding as in fa_fwd16_w64, where one LDS-DMA per four MFMA gaps was +6.5 %)
+    auto stage_piece = [&](uint32_t t, int i) __attribute__((always_inline)) {  // i = 0 .. 2 NPW - 1: Q pieces, then dO pieces
+        const int j = i % NPW, n = 4 * j + uw;
+        const int voff = (int)(t * QROWS) * ROW_B + dma_off[j];
+        dma_piece(i < NPW ? q_srd : do_srd, lds0 + (i < NPW ? QT : DOT) + (t & 1) * QTILE_B + n * 1024, voff);
     };
     // Row constants of a tile (LSE and D of its 64 rows) ride with the tile: one LDS-DMA dword load each (wave 0: LSE,
     // wave 1: D), waited for by the tile's own "s_waitcnt vmcnt(0)" + barrier.  As compiler-visible loads hipcc put
@@ -593,7 +651,7 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
     // Rows past Sq read 0 (descriptor range check): their Q and dO rows are zero too, so S = dP = 0, P = 1, dS = 0 and
     // nothing reaches dK or dV.  LSE arrives in natural-log units; the factor log2(e) is applied where it is used.
     const i32x4 lse_srd = make_srd(p.rowc + (int64_t)bh * p.Sq, p.Sq * 4u), dv_srd = make_srd(p.rowc + ((int64_t)p.B * p.H + bh) * p.Sq, p.Sq * 4u);
-    auto stage_consts = [&](uint32_t t) {
+    auto stage_consts = [&](uint32_t t) __attribute__((always_inline)) {
         const int voff = (int)(t * QROWS + (uint32_t)lane) * 4;
         if (uw == 0)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
@@ -633,10 +691,17 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
             __syncthreads();
         }
     }
+#ifdef BWD16_LAB_STAMP  // lab: wait-free clock stamps at the phase boundaries of the pinned tile, summed per workgroup
+    unsigned long long lst[7] = {0, 0, 0, 0, 0, 0, 0};
+    uint32_t lacc[6] = {0, 0, 0, 0, 0, 0};
+#define BWD_STAMP(k) asm volatile("s_memtime %0" : "=s"(lst[k]))
+#else
+#define BWD_STAMP(k) do { } while (0)
+#endif
     // EDGE: some query of the tile lies before some key of this wave (causal diagonal): scores get a per-key test.
     // PAR: half of the double buffer as a compile-time constant (steady loop, unrolled by two: LDS addresses are then lane
     // registers + immediates; a run-time (t & 1) cost ~46 address adds per tile), -1 = run-time parity.
-    auto tile_body = [&](uint32_t t, auto EDGE_C, auto PAR_C) {
+    auto tile_body = [&](uint32_t t, auto EDGE_C, auto PAR_C) __attribute__((always_inline)) {
         constexpr bool EDGE = decltype(EDGE_C)::value;
         constexpr int PAR = decltype(PAR_C)::value;
         const int par = PAR >= 0 ? PAR : (int)(t & 1);
@@ -698,6 +763,7 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
                     tf[j] = tr_frag<M, DP>(((r & 1) ? Qt : dOt) + u * TILE_BYTES, i + hpass * NDBH, s2, hi, tr_qq, tr_pp, tr_g1);
                 };
                 constexpr int PF = 2 * PD;  // row fragments in flight
+                BWD_STAMP(1);
     #pragma unroll
                 for (int f = 0; f < PF; ++f) rd(f);
                 rd_consts(0);
@@ -705,6 +771,9 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
     #pragma unroll
                 for (int f = 0; f < 4 * NKS; ++f) {
                     const int u = f / (2 * NKS), ks = f % NKS;
+                    if (f == 2 * NKS) BWD_STAMP(2);
+                    if (f % 4 == 1 && f / 4 < 2 * NPW) stage_piece(t + 1, f / 4);
+                    if (f == 3) stage_consts(t + 1);
                     if (f + PF < 4 * NKS) rd(f + PF);
                     if (f == 2 * NKS + 2) rd_consts(1);  // needed from f = 3 NKS on (dP of sub-tile 1 starts at -D)
                     if (f >= 4 * NKS - PT) trd(f - (4 * NKS - PT));
@@ -722,6 +791,8 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
     #pragma unroll
                 for (int j = 0; j < 2 * NF; ++j) {
                     const int u = j / NF, r = j % NF, i = r >> 2, s2 = (r >> 1) & 1;
+                    if (j == 0) BWD_STAMP(3);
+                    if (j == NF) BWD_STAMP(4);
                     if (j + PT < 2 * NF) trd(j + PT);
                     if (r & 1) dk[i] = M::mma(tf[j], sb[u][s2], dk[i]);
                     else dv[i] = M::mma(tf[j], pb[u][s2], dv[i]);
@@ -786,15 +857,25 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
             }
         }
     };
-    auto step = [&](uint32_t tt, auto EDGE_C, auto PAR_C) {
-        stage(tt + 1);
-        stage_consts(tt + 1);
+    auto step = [&](uint32_t tt, auto EDGE_C, auto PAR_C) __attribute__((always_inline)) {
+        BWD_STAMP(0);
+        if constexpr (DP != 128) {  // (head_dim 128 issues them piece by piece inside the tile body)
+            stage(tt + 1);
+            stage_consts(tt + 1);
+        }
         tile_body(tt, EDGE_C, PAR_C);
+        BWD_STAMP(5);
 #ifdef BWD16_LAB_NOBAR      // lab, timing only (results are wrong): what the end-of-tile wait + barrier cost
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 #else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#endif
+#ifdef BWD16_LAB_STAMP
+        BWD_STAMP(6);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k_ = 0; k_ < 6; ++k_) lacc[k_] += (uint32_t)lst[k_ + 1] - (uint32_t)lst[k_];
 #endif
     };
     // [t, t_ne): tiles on the diagonal (and one more when that leaves an odd start), run-time parity; then pairs
@@ -824,6 +905,12 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
                 store_grad4<T>(p.dv, krow + d0, vv, p.grad_in_type != 0);
             }
     }
+#ifdef BWD16_LAB_STAMP
+    if (tid == 0) {  // lab only: overwrites the head of the LSE input (dkdv reads p.rowc, not p.lse)
+        uint32_t* dbg = (uint32_t*)p.lse + (size_t)blockIdx.x * 8;
+        for (int k_ = 0; k_ < 6; ++k_) dbg[k_] = lacc[k_];
+    }
+#endif
     }  // hpass
 }
 
