@@ -583,7 +583,12 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
     const int tid = threadIdx.x, lane = tid & 63, kl = lane & 31, hi = lane >> 5;
     const int wave = tid >> 6, uw = __builtin_amdgcn_readfirstlane(wave);
     const uint32_t nkb = (p.Skv + 127) / 128;
-    const uint32_t vid = xcd_remap(blockIdx.x, nkb * p.B * p.H);
+    // Non-causal launches may come as a PERSISTENT grid (one workgroup per CU looping over its key blocks, item += gridDim.x:
+    // no dispatch latency and no LDS clearing between the ~3 blocks a CU gets at the FLUX shape); with gridDim.x = number
+    // of items the loop runs once.  Causal launches keep one workgroup per item (unequal items: dynamic dispatch balances).
+    const uint32_t n_items = nkb * p.B * p.H;
+    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const uint32_t vid = xcd_remap(item, n_items);
     uint32_t bh = vid / nkb, kb = vid % nkb;
     if (CAUSAL) kb = causal_rank(vid, nkb, bh, DP == 64);  // the first key block is seen by the most queries
     const uint32_t key = kb * 128 + wave * 32 + kl, wave_k0 = kb * 128 + wave * 32;
@@ -596,9 +601,11 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((LDS_AS char*)smem));
     float* const vec = (float*)(smem + VEC);
 
+    if (item == blockIdx.x) {
 #pragma unroll
-    for (int i = 0; i < VEC / 4096; ++i) *(i32x4*)(smem + i * 4096 + tid * 16) = i32x4{0, 0, 0, 0};
-    __syncthreads();
+        for (int i = 0; i < VEC / 4096; ++i) *(i32x4*)(smem + i * 4096 + tid * 16) = i32x4{0, 0, 0, 0};
+        __syncthreads();
+    }
     // B operands of S = Q K^T and dP = dO V^T: lane (key, hi) holds K[key][16 ks + 8 hi ..], V[key][...]
     V8 kf[NKS], vf[NKS];
 #pragma unroll
@@ -912,6 +919,7 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
     }
 #endif
     }  // hpass
+    }  // item
 }
 
 bool bwd_16_supported(const BwdParams& p) {
@@ -961,7 +969,13 @@ static hipError_t launch_bwd16_t(const BwdParams& p, hipStream_t stream) {
     } else {
         hipLaunchKernelGGL((bwd16_dq_kernel<T, CAUSAL, DP>), dim3(nqb * p.B * p.H), dim3(256), lds_dq, stream, p);
     }
-    hipLaunchKernelGGL((bwd16_dkdv_kernel<T, CAUSAL, DP>), dim3(nkb * p.B * p.H), dim3(256), lds_kv, stream, p);
+    uint32_t kv_grid = nkb * p.B * p.H;
+    // measured equal to one workgroup per item (FLUX 0.654-0.657 vs 0.656-0.680 ms, B1 H16 S8192 1.625 vs 1.631): off unless asked for
+    if (!CAUSAL && DP == 128 && getenv("UMFA_BWD_PERSIST")) {  // persistent: one workgroup per CU (see the kernel)
+        static const uint32_t n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return (uint32_t)n; }();
+        if (kv_grid > n_cu) kv_grid = n_cu;
+    }
+    hipLaunchKernelGGL((bwd16_dkdv_kernel<T, CAUSAL, DP>), dim3(kv_grid), dim3(256), lds_kv, stream, p);
     return hipGetLastError();
 }
 
