@@ -190,6 +190,18 @@ static uint32_t w64_grid(const FwdParams& p) {
     uint64_t total = (uint64_t)p.B * p.H * ((p.Sq + 255) / 256) * ((p.Skv + 63) / 64);  // (item, key tile) steps
     if (p.causal) total = (uint64_t)p.B * p.H * (((p.Sq + 255) / 256 + 1) / 2);  // jobs = mirrored pairs of q-blocks
     const uint32_t cus = (uint32_t)w64_cu_count();
+    if (const char* e = getenv("UMFA_W64_GRID")) {  // lab: force the number of workgroups
+        const uint32_t g = (uint32_t)atoi(e);
+        if (g > 0 && g <= cus && g <= total) return g;
+    }
+    if (!p.causal) {
+        // few items (the strong-scaling shards of a problem: B1 H3 S4096 = 48 items): a whole number of EQUAL parts per item
+        // (grid = items x floor(CUs / items): the slices total * w / G then start and end on part boundaries, every
+        // workgroup has one segment and one prologue) instead of CUs ragged slices.  Graph-replayed us, aligned / ragged:
+        // H3 47.3 / 51.7, H6 71.5 / 72.7, H12 (one part: whole items) 109.1 / 110.0.
+        const uint64_t items = (uint64_t)p.B * p.H * ((p.Sq + 255) / 256);
+        if (items < cus && cus / items >= 2 && items * (cus / items) <= total) return (uint32_t)(items * (cus / items));
+    }
     return total < cus ? (uint32_t)total : cus;  // never more workgroups than steps: every slice is non-empty
 }
 
