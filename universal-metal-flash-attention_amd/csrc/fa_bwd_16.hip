@@ -388,6 +388,18 @@ __global__ __launch_bounds__(256, 1) void bwd16_dq2_kernel(BwdParams p) {
     const T* dop = (const T*)p.dout + (int64_t)bh * p.Sq * DP;
     const T* kp = (const T*)p.k + (int64_t)bh * p.Skv * DP;
     const T* vp = (const T*)p.v + (int64_t)bh * p.Skv * DP;
+    const i32x4 k_srd = make_srd(kp, p.Skv * (uint32_t)ROW_B), v_srd = make_srd(vp, p.Skv * (uint32_t)ROW_B);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((LDS_AS char*)smem));
+#pragma unroll
+    for (int i = 0; i < 4 * KTILE_B / 4096; ++i) *(i32x4*)(smem + i * 4096 + tid * 16) = i32x4{0, 0, 0, 0};
+    __syncthreads();
+    int dma_off[(2 * TILE_PIECES + 3) / 4];
+    dma_lane_offsets<2 * TILE_PIECES, DP>(dma_off, uw, lane);
+    auto stage = [&](uint32_t t) __attribute__((always_inline)) {
+        dma_rows_pre<2 * TILE_PIECES, DP>(k_srd, lds0 + KT + (t & 1) * KTILE_B, t * KROWS, uw, dma_off);
+        dma_rows_pre<2 * TILE_PIECES, DP>(v_srd, lds0 + VT + (t & 1) * KTILE_B, t * KROWS, uw, dma_off);
+    };
+    stage(0);  // first: its latency runs under the Q / dO / O loads and the D row sums below
 
     // B operands: lane (q, hi) holds Q[q][16 ks + 8 hi ..], dO[q][...]
     V8 qf[NKS], dof[NKS];
@@ -435,11 +447,6 @@ __global__ __launch_bounds__(256, 1) void bwd16_dq2_kernel(BwdParams p) {
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+a"(qf[ks]), "+a"(dof[ks]));
 
-    const i32x4 k_srd = make_srd(kp, p.Skv * (uint32_t)ROW_B), v_srd = make_srd(vp, p.Skv * (uint32_t)ROW_B);
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((LDS_AS char*)smem));
-#pragma unroll
-    for (int i = 0; i < 4 * KTILE_B / 4096; ++i) *(i32x4*)(smem + i * 4096 + tid * 16) = i32x4{0, 0, 0, 0};
-    __syncthreads();
 
     uint32_t ntiles = (p.Skv + KROWS - 1) / KROWS;
     if (CAUSAL) {
@@ -453,20 +460,14 @@ __global__ __launch_bounds__(256, 1) void bwd16_dq2_kernel(BwdParams p) {
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
     const int tr_qq = (lane >> 2) & 3, tr_pp = lane & 3, tr_g1 = (lane >> 4) & 1;
 
-    int dma_off[(2 * TILE_PIECES + 3) / 4];
-    dma_lane_offsets<2 * TILE_PIECES, DP>(dma_off, uw, lane);
-    auto stage = [&](uint32_t t) __attribute__((always_inline)) {
-        dma_rows_pre<2 * TILE_PIECES, DP>(k_srd, lds0 + KT + (t & 1) * KTILE_B, t * KROWS, uw, dma_off);
-        dma_rows_pre<2 * TILE_PIECES, DP>(v_srd, lds0 + VT + (t & 1) * KTILE_B, t * KROWS, uw, dma_off);
-    };
+
     constexpr int NPW = (2 * TILE_PIECES + 3) / 4;
     auto stage_piece = [&](uint32_t t, int i) __attribute__((always_inline)) {  // one piece at a time from inside the pinned MFMA stream (see bwd16_dkdv)
         const int j = i % NPW, n = 4 * j + uw;
         const int voff = (int)(t * KROWS) * ROW_B + dma_off[j];
         dma_piece(i < NPW ? k_srd : v_srd, lds0 + (i < NPW ? KT : VT) + (t & 1) * KTILE_B + n * 1024, voff);
     };
-    stage(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tile 0 (issued at the top of the kernel) and everything loaded since
     __builtin_amdgcn_s_waitcnt(0x0F70);  // and for hipcc's scoreboard (Q / dO fragment loads; see bwd16_dq)
     __syncthreads();
 
@@ -500,8 +501,10 @@ __global__ __launch_bounds__(256, 1) void bwd16_dq2_kernel(BwdParams p) {
         };
         constexpr int NF = 2 * NDB, PT = 4, PF = 8;  // dQ MFMAs of one sub-tile; transposed / row fragments in flight
         V8 tf[2 * NF];
+        // dQ MFMA j: sub-tile u = j / NF; sub-tile 0 d-block-major, sub-tile 1 k-step-major (its first four MFMAs need only
+        // the first half of dS(1): the second half of that softmax runs under them)
         auto trd = [&](int j) {
-            const int u = j / NF, r = j % NF, i = r >> 1, s2 = r & 1;
+            const int u = j / NF, r = j % NF, i = u ? (r & 3) : (r >> 1), s2 = u ? (r >> 2) : (r & 1);
             tf[j] = tr_frag<M, DP>(Kt + u * TILE_BYTES, i, s2, hi, tr_qq, tr_pp, tr_g1);
         };
 #pragma unroll
@@ -525,11 +528,14 @@ __global__ __launch_bounds__(256, 1) void bwd16_dq2_kernel(BwdParams p) {
         // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
 #pragma unroll
         for (int j = 0; j < 2 * NF; ++j) {
-            const int u = j / NF, r = j % NF, i = r >> 1, s2 = r & 1;
+            const int u = j / NF, r = j % NF, i = u ? (r & 3) : (r >> 1), s2 = u ? (r >> 2) : (r & 1);
             if (j + PT < 2 * NF) trd(j + PT);
             acc[i] = M::mma(tf[j], ds[u][s2], acc[i]);
             __builtin_amdgcn_sched_barrier(0);
-            if (j >= 1 && j < 1 + 8) softmax_pair(1, 2 * (j - 1));  // P2a: one score pair of sub-tile 1 behind each MFMA (first: 2 issues after dP's last)
+            // the score pairs of sub-tile 1: 0..3 (dS(1)[0]) behind MFMAs 1, 3, 5, 7 of P2a (first: 2 issues after dP's last),
+            // 4..7 (dS(1)[1]) behind MFMAs 8..11 = the k-step-0 MFMAs of P2b
+            if (j < NF && (j & 1)) softmax_pair(1, j - 1);
+            if (j >= NF && j < NF + 4) softmax_pair(1, 8 + 2 * (j - NF));
             __builtin_amdgcn_sched_barrier(0);
         }
     };
