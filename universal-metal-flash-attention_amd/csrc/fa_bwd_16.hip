@@ -580,6 +580,10 @@ __global__ __launch_bounds__(256, 1) void bwd16_dq2_kernel(BwdParams p) {
 template <typename T, bool CAUSAL, int DP>
 __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdParams p) {
     BWD16_GEO(DP);
+#ifdef BWD16_LAB_STAMP
+    const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime();
+    unsigned long long rt_loop0 = 0, rt_loop1 = 0;
+#endif
     typedef Mma16<T> M;
     typedef typename M::V8 V8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -891,6 +895,9 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
         for (int k_ = 0; k_ < 6; ++k_) lacc[k_] += (uint32_t)lst[k_ + 1] - (uint32_t)lst[k_];
 #endif
     };
+#ifdef BWD16_LAB_STAMP
+    rt_loop0 = __builtin_amdgcn_s_memrealtime();
+#endif
     // [t, t_ne): tiles on the diagonal (and one more when that leaves an odd start), run-time parity; then pairs
     uint32_t t_ne = t;
     if (CAUSAL) {
@@ -905,6 +912,9 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
         step(t + 1, std::false_type{}, std::integral_constant<int, 1>{});
     }
     for (; t < ntiles; ++t) step(t, std::true_type{}, std::integral_constant<int, -1>{});
+#ifdef BWD16_LAB_STAMP
+    rt_loop1 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (kok) {
         const int64_t krow = ((int64_t)bh * p.Skv + key) * DP;
 #pragma unroll
@@ -920,8 +930,12 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
     }
 #ifdef BWD16_LAB_STAMP
     if (tid == 0) {  // lab only: overwrites the head of the LSE input (dkdv reads p.rowc, not p.lse)
-        uint32_t* dbg = (uint32_t*)p.lse + (size_t)blockIdx.x * 8;
+        uint32_t* dbg = (uint32_t*)p.lse + (size_t)blockIdx.x * 16;
         for (int k_ = 0; k_ < 6; ++k_) dbg[k_] = lacc[k_];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long rt_exit = __builtin_amdgcn_s_memrealtime();
+        dbg[6] = (uint32_t)(rt_loop0 - rt_entry); dbg[7] = (uint32_t)(rt_loop1 - rt_loop0); dbg[8] = (uint32_t)(rt_exit - rt_loop1);
+        dbg[9] = (uint32_t)rt_entry; dbg[10] = (uint32_t)rt_exit;
     }
 #endif
     }  // hpass
