@@ -783,12 +783,12 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
                 BWD_STAMP(1);
     #pragma unroll
                 for (int f = 0; f < PF; ++f) rd(f);
-                rd_consts(0);
                 __builtin_amdgcn_sched_barrier(0);
     #pragma unroll
                 for (int f = 0; f < 4 * NKS; ++f) {
                     const int u = f / (2 * NKS), ks = f % NKS;
                     if (f == 2 * NKS) BWD_STAMP(2);
+                    if (f == 1) rd_consts(0);  // behind the tile's first MFMA, not in front of it; needed at f = NKS
                     if (f % 4 == 1 && f / 4 < 2 * NPW) stage_piece(t + 1, f / 4);
                     if (f == 3) stage_consts(t + 1);
                     if (f + PF < 4 * NKS) rd(f + PF);
