@@ -915,7 +915,40 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
 #ifdef BWD16_LAB_STAMP
     rt_loop1 = __builtin_amdgcn_s_memrealtime();
 #endif
-    if (kok) {
+    if (DP == 128 && p.grad_in_type) {
+        // Gradients in the operand type (in-stream entry), head_dim 128: a lane holds 4 consecutive d of ONE key per register
+        // group, so direct stores touch 32 rows x 8 bytes per instruction (64 scattered store instructions per wave and
+        // tensor pair, ~5.8 us per workgroup); instead each wave writes its 32 x 128 block into its own 8 KiB of the (idle)
+        // tile buffers -- 16-byte chunks XOR-swizzled with the row -- and streams it out as whole 256-byte rows, 16 bytes
+        // per lane, 4 rows per instruction (the forward's T21).  dK first, then dV through the same 8 KiB.
+        char* stg = smem + wave * 8192;
+        typedef T T4 __attribute__((ext_vector_type(4)));
+        auto flush = [&](void* base, auto&& val) {
+#pragma unroll
+            for (int i = 0; i < NDBH; ++i)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 x = val(i, g);
+                    const int ch = (4 * i + g) ^ (kl & 15);  // 16-byte chunk holding d = 32 i + 8 g + {0..7}
+                    *(T4*)(stg + kl * 256 + 16 * ch + 8 * hi) = T4{(T)x[0], (T)x[1], (T)x[2], (T)x[3]};
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            T* out = (T*)base + ((int64_t)bh * p.Skv + wave_k0) * DP;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int r = 4 * it + (lane >> 4), c = lane & 15;
+                const i32x4 v16 = *(const i32x4*)(stg + r * 256 + 16 * (c ^ (r & 15)));
+                if (wave_k0 + r < p.Skv) *(i32x4*)(out + r * DP + 8 * c) = v16;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+        flush(p.dk, [&](int i, int g) { return f32x4{dk[i][4 * g] * p.scale, dk[i][4 * g + 1] * p.scale, dk[i][4 * g + 2] * p.scale, dk[i][4 * g + 3] * p.scale}; });
+        flush(p.dv, [&](int i, int g) { return f32x4{dv[i][4 * g], dv[i][4 * g + 1], dv[i][4 * g + 2], dv[i][4 * g + 3]}; });
+    } else if (kok) {
         const int64_t krow = ((int64_t)bh * p.Skv + key) * DP;
 #pragma unroll
         for (int i = 0; i < NDBH; ++i)
@@ -939,6 +972,7 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
     }
 #endif
     }  // hpass
+    if (item + gridDim.x < n_items) __syncthreads();  // persistent grid: the epilogue staged through the tile buffers the next item's DMA writes
     }  // item
 }
 
