@@ -563,7 +563,29 @@ __global__ __launch_bounds__(256, 1) void bwd16_dq2_kernel(BwdParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    if (qok) {
+    if (p.grad_in_type) {  // operand-type dQ: through per-wave LDS rows, whole 256-byte rows out (see bwd16_dkdv's epilogue)
+        char* stg = smem + wave * 8192;
+        typedef T T4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int i = 0; i < NDB; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch = (4 * i + g) ^ (ql & 15);
+                *(T4*)(stg + ql * 256 + 16 * ch + 8 * hi) = T4{(T)(acc[i][4 * g] * p.scale), (T)(acc[i][4 * g + 1] * p.scale),
+                                                                (T)(acc[i][4 * g + 2] * p.scale), (T)(acc[i][4 * g + 3] * p.scale)};
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t wave_q0 = qb * 128 + wave * 32;
+        T* out = (T*)p.dq + ((int64_t)bh * p.Sq + wave_q0) * DP;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int r = 4 * it + (lane >> 4), c = lane & 15;
+            const i32x4 v16 = *(const i32x4*)(stg + r * 256 + 16 * (c ^ (r & 15)));
+            if (wave_q0 + r < p.Sq) *(i32x4*)(out + r * DP + 8 * c) = v16;
+        }
+    } else if (qok) {
         const int64_t orow = ((int64_t)bh * p.Sq + q_row) * DP;
 #pragma unroll
         for (int i = 0; i < NDB; ++i)
@@ -571,7 +593,7 @@ __global__ __launch_bounds__(256, 1) void bwd16_dq2_kernel(BwdParams p) {
             for (int g = 0; g < 4; ++g) {
                 f32x4 val = {acc[i][4 * g] * p.scale, acc[i][4 * g + 1] * p.scale, acc[i][4 * g + 2] * p.scale,
                              acc[i][4 * g + 3] * p.scale};
-                store_grad4<T>(p.dq, orow + 32 * i + 8 * g + 4 * hi, val, p.grad_in_type != 0);
+                store_grad4<T>(p.dq, orow + 32 * i + 8 * g + 4 * hi, val, false);
             }
     }
 }
