@@ -188,3 +188,21 @@ def test_config5_long_context_one_shard_S32768_D128():
     check_rows(q, k, v, o32, rows, False, umfa_torch.last_kernel(), "cfg5_shard_fp32O")
     oc = umfa_torch.attention_forward(q, k, v, causal=True)
     check_rows(q, k, v, oc, rows, True, umfa_torch.last_kernel(), "cfg5_shard_causal_bf16O", out_dt=torch.bfloat16)
+
+
+@pytest.mark.parametrize("heads", [3, 6, 12])
+def test_flux_strong_scaling_shards(heads):
+    """The per-rank shards of the strong-scaling leg (bench.py `strong`): the FLUX problem's 24 heads over 8 / 4 / 2 ranks.
+    Few items per launch: fa_fwd16_w64 cuts every item into a whole number of equal parts (grid = items x floor(CUs / items))
+    and folds them; the result must meet the same bounds as the uncut launch, and two launches must agree bit for bit."""
+    import umfa_torch
+    torch.manual_seed(heads)
+    q, k, v = (torch.randn(1, heads, 4096, 128, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    o = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
+    kern = umfa_torch.last_kernel()
+    assert kern.startswith("fa_fwd16_w64"), kern
+    from oracle import parity
+    rows = parity.sample_rows(4096, groups=4)
+    check_rows(q, k, v, o, rows, False, kern, f"strong_shard_H{heads}")
+    o2 = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
+    assert torch.equal(o, o2)
