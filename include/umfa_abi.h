@@ -373,6 +373,20 @@ int32_t umfa_quantize_rows(mfa_context_t context, void* stream, const void* src,
                            void* q8_out, void* scales_out, uint32_t* padded_row_bytes);
 const char* umfa_last_kernel_name(mfa_context_t context);
 
+/* MI355X extra: launcher switches, context-wide (the context is a process-wide singleton, MFABridge.swift:652-687).
+ * They replace environment variables read on the launch path: the environment (UMFA_<NAME>) only gives the initial
+ * value when the library is first used.  name / value (strings):
+ *   "softmax_reference"  "default" | "exact" | "deferred" | "lazy" -- reference of the online softmax in the
+ *                        64-rows-per-wave forward kernels: exact running max (every P <= 1); deferred max (the reference
+ *                        moves when a row max exceeds it by 2^softmax_tau); lazy (bf16 only: no row max after a
+ *                        segment's first tile, exact power-of-two rebase read off the matrix-pipe row sums).
+ *                        default = lazy for bf16, deferred for fp16 and the int8 kernels.
+ *   "softmax_tau"        "0" ... "16" (log2 units, default 6)
+ *   "force_w64" "no_w64" "w64_grid" "no_mask_flags" "bwd_exact" "bwd_dq" "bwd_persist" "no_split" "force_split"
+ *   "no_dma" "bn64"      kernel-selection overrides used by tests and A/B benches ("0" / "1" or a number)
+ * Returns MFA_ERROR_INVALID_ARGS for an unknown name or a value out of range.  Thread-safe; affects later launches. */
+mfa_error_t umfa_set_option(mfa_context_t context, const char* name, const char* value);
+
 #undef UMFA_QUANT_LEGACY_ARGS
 #undef UMFA_QBWD_TAIL
 #undef UMFA_QBWD_BLOCKS

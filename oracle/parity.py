@@ -40,10 +40,13 @@ def forward_rel_err(q, k, v, o, *, causal=False, scale=None, rows=None, floor_ki
     qb, kb, vb = bits(q), bits(k), bits(v)
     ref = oracle.sdpa_forward_rows(qb, kb, vb, rows, scale=scale, causal=causal)
     got = o.detach().float().cpu().numpy()[:, :, rows]
-    res = {"rel": rel_err(got, ref), "rows": int(rows.size)}
+    d = got.astype(np.float64) - ref.astype(np.float64)
+    res = {"rel": rel_err(got, ref), "rms": float(np.sqrt((d * d).mean() / (ref.astype(np.float64) ** 2).mean())), "rows": int(rows.size)}
     if floor_kind:
         sub = rows[:: max(1, rows.size // 64)]  # the emulation holds [B,H,rows,Skv] in fp64: keep it small
         pos = np.searchsorted(rows, sub)
         fl = oracle.flash_format_floor(qb, kb, vb, sub, floor_kind, scale=scale, causal=causal)
         res["format_floor"] = rel_err(fl, ref[:, :, pos])
+        df = fl.astype(np.float64) - ref[:, :, pos].astype(np.float64)
+        res["format_floor_rms"] = float(np.sqrt((df * df).mean() / (ref[:, :, pos].astype(np.float64) ** 2).mean()))
     return res

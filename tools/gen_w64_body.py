@@ -50,6 +50,10 @@ class Cfg:
         self.i8 = i8
         self.f8 = f8                     # fp8 (e4m3) P and V: O^T += V^T P^T on v_mfma_scale_f32_32x32x64_f8f6f4 (see Cfg8 notes)
         self.i2f = i8 and os.environ.get("W64_I8_BIAS", "1") == "0"
+        # row sums on the matrix pipe (16-bit P kernels): l += sum of the ROUNDED P fragment by v_mfma_f32_4x4x4_16b against an
+        # all-ones operand (a lane-local sum: block b = lane / 4, column j = lane % 4 -> the lane's own four values; 8-cycle
+        # instruction).  16 of them per tile replace 64 v_add_f32, and l is the sum of exactly the values P V consumes.
+        self.msum = (not f8) and os.environ.get("W64_MSUM", "1") == "1"
         self.NQK = 16 if i8 else 32      # MFMAs of the QK^T phase = first gap index of the PV phase
         self.KS = 4 if i8 else 8         # k-steps per 32-key block
         self.HALF = self.NQK // 2        # QK^T MFMAs per key block
@@ -68,7 +72,7 @@ class Cfg:
         return self.NQK + 10 * qb + 2 * db
 
 
-COST = {"DEC2": 20, "MXINIT": 8, "MAXE": 4, "CVT8": 4, "VREAD8": 8, "UPDK": 4, "UPDV": 4, "BAR": 16, "KPRE": 4, "I2F": 4, "MASK": 8, "DMAK": 8, "DMAV": 8, "NOP": 32, "EXP": 8, "ADD": 4, "CVT": 4, "VREAD": 8, "KREAD": 4, "MAX": 4, "DEC": 44, "FMA": 4}
+COST = {"MSUM": 8, "LCHK": 12, "DEC2": 20, "MXINIT": 8, "MAXE": 4, "CVT8": 4, "VREAD8": 8, "UPDK": 4, "UPDV": 4, "BAR": 16, "KPRE": 4, "I2F": 4, "MASK": 8, "DMAK": 8, "DMAV": 8, "NOP": 32, "EXP": 8, "ADD": 4, "CVT": 4, "VREAD": 8, "KREAD": 4, "MAX": 4, "DEC": 44, "FMA": 4}
 for _kv in filter(None, os.environ.get("W64_COST", "").split(",")):  # lab: W64_COST=EXP:16,ADD:4 overrides the model
     COST[_kv.split(":")[0]] = int(_kv.split(":")[1])
 
@@ -134,6 +138,9 @@ def qk_mfma(R, kb, ks, qb):
 # The row-sum accumulators MUST be literal registers: as compiler values ("+a") hipcc copied them between basic blocks
 # right behind the asm statement, i.e. before the 64-cycle MFMA had written them (it pads nothing for inline asm) -- rows
 # lost whole tiles of their sum (measured: O = 1.0 ... 1.33 for V = 1).
+# msum kernels are compiled with amdgpu_num_vgpr(118): v[118:127] are asm-owned as well
+MS_L = 118       # v[118:121] / v[122:125]: row-sum accumulators of q-block 0 / 1 (four identical columns each)
+MS_ONES = 126    # v[126:127]: 1.0 in all four 16-bit k-slots, the A operand of the row-sum MFMA
 F8_BIAS = 96     # v[96:111]  the int8 score bias tile (1.5 * 2^23 in every element)
 F8_ONES = 112    # v[112:119] fp8 1.0 in every k-slot: A operand of the row-sum MFMA
 F8_SONE = 120    # v120       E8M0 scale bytes of 1.0
@@ -176,6 +183,11 @@ def op_text(R, op):
         b = base(R.old, kb, qb)
         d = b + 8 * (r >> 3) + ((r & 7) >> 1)
         return f'asm volatile(W64_CVT " v{d}, v{b + r}, v{b + r + 1}");'
+    if kind == "MSUM":
+        _, st, qb, h = op
+        b = base(R.old, st >> 1, qb) + 8 * (st & 1) + 2 * h
+        la = f"v[{MS_L + 4 * qb}:{MS_L + 4 * qb + 3}]"
+        return f'asm volatile(W64_MSUM " {la}, v[{MS_ONES}:{MS_ONES + 1}], v[{b}:{b + 1}], {la}");'
     if kind == "CVT8":
         _, kb, qb, m, hi = op
         src = base(R.old, kb, qb) + 4 * m + (2 if hi else 0)
@@ -269,12 +281,26 @@ def exp_streams():
                     ops.append((("EXP", kb, qb, r + 1), 0, dl))
                 if prev is not None:
                     dl = C.NQK + 8 * (2 * kb + (prev >> 3)) - 2
-                    ops.append((("ADD", kb, qb, prev), 0, dl))
-                    ops.append((("ADD", kb, qb, prev + 1), 0, dl))
+                    if not C.msum:
+                        ops.append((("ADD", kb, qb, prev), 0, dl))
+                        ops.append((("ADD", kb, qb, prev + 1), 0, dl))
                     ops.append((("CVT", kb, qb, prev), 0, dl))
                 prev = r
             streams.append(ops)
     return streams
+
+
+def msum_stream():
+    """row-sum MFMAs of the packed P fragments: two per (16-key step, q-block) (a 4x4x4 B operand is two registers = four
+    values); a fragment is complete one gap before its first P V MFMA (exp_streams deadline), and the set is overwritten
+    by the next tile's scores, so everything sits inside the P V phase.  The last one keeps >= 3 MFMA issues to the end
+    of the body: the includer's reads of l (v_cmp in the lazy check, the segment's final read) need the result landed."""
+    ops = []
+    for st in range(4):
+        for h in (0, 1):
+            for qb in (0, 1):  # consecutive ones go to different accumulators; the scheduler puts at most one in a gap
+                ops.append((("MSUM", st, qb, h), C.NQK + 8 * st, C.NG - 4))
+    return ops
 
 
 def exp8_streams():
@@ -444,6 +470,26 @@ def start_streams(have_new, mfma_follows=True, masked=False):
     return streams
 
 
+def lazy_streams(masked):
+    """Steady-state tiles of the LAZY reference mode (bf16 P only): no row max at all.  e = s*c - m against the reference
+    of the previous tiles as soon as a score block's MFMAs are done; whether the reference has to move is read off the
+    row sums the matrix pipe delivers anyway (includer: W64_LAZY_CHECK on l after the body -- bf16 P and the fp32
+    accumulators have fp32's exponent range, so a stale reference costs no accuracy until l nears 2^100; the includer
+    rebases by an exact power of two long before, and a segment that still overflows is re-run with the max chain)."""
+    last = C.NG - 1
+    streams = []
+    for kb in (0, 1):
+        ready = kb * C.HALF + C.HALF
+        for qb in (0, 1):
+            st, dl = ready + qb, last
+            ops = []
+            if masked:
+                ops += [(("MASK", kb, qb, r), st, dl) for r in range(16)]
+            ops += [(("FMA", kb, qb, r), st, dl) for r in range(16)]
+            streams.append(ops)
+    return streams
+
+
 def spec_streams(masked):
     """Steady-state tiles, speculative order: the reference max m of the PREVIOUS tiles is known when the tile starts, so
     e = s*c - m is applied to a score block as soon as its MFMAs are done (no wait for this tile's row max), the row max
@@ -476,10 +522,14 @@ def spec_streams(masked):
     return streams
 
 
-def schedule(streams, gaps, pre_budget=0):
+GAP_CAP = {"MSUM": 1}  # at most this many ops of a kind in one gap (a second row-sum MFMA would queue behind the first in the matrix pipe)
+
+
+def schedule(streams, gaps, pre_budget=0, budget=None):
     """EDF under a per-gap budget.  streams: list of [ (op, earliest, deadline) ... ] each consumed in order.
     Returns gaps + 1 lists: the first is the pre-slot (fillers ahead of MFMA 0, budget pre_budget, ops runnable at gap 0)."""
-    BUDGET = C.budget
+    gap_budget = budget if budget is not None else C.budget
+    BUDGET = gap_budget
     pos = [0] * len(streams)
     out = [[] for _ in range(gaps + 1)]
     # a stream is consumed in order, so an op inherits the tightest deadline of everything queued behind it
@@ -493,10 +543,11 @@ def schedule(streams, gaps, pre_budget=0):
     streams = tight
     for slot in range(gaps + 1):
         g = max(0, slot - 1)          # slot 0 = the pre-slot: what may run at gap 0, nothing forced
-        BUDGET = pre_budget if slot == 0 else C.budget
+        BUDGET = pre_budget if slot == 0 else gap_budget
         if slot == 0 and pre_budget <= 0:
             continue
         used = 0
+        kinds = {}
         while True:
             best = None
             for si, s in enumerate(streams):
@@ -504,6 +555,8 @@ def schedule(streams, gaps, pre_budget=0):
                     continue
                 op, earliest, deadline = s[pos[si]]
                 if earliest > g or (slot == 0 and op[0] not in ("EXP", "CVT", "CVT8", "ADD", "MXINIT")):
+                    continue
+                if kinds.get(op[0], 0) >= GAP_CAP.get(op[0], 1 << 30) and not (deadline <= g and slot > 0):
                     continue
                 remaining = sum(COST[o[0][0]] for o in s[pos[si]:])
                 # how far this stream is behind an even spread up to its last deadline
@@ -524,13 +577,14 @@ def schedule(streams, gaps, pre_budget=0):
                 break
             out[slot].append(op)
             used += c
+            kinds[op[0]] = kinds.get(op[0], 0) + 1
             pos[si] += 1
     for si, s in enumerate(streams):
         assert pos[si] == len(s), f"stream {si} not fully placed ({pos[si]}/{len(s)})"
     return out
 
 
-def check_part(placed, have_new, have_old, masked, pre=()):
+def check_part(placed, have_new, have_old, masked, pre=(), lazy=False):
     """Data-flow self-check of one scheduled part (gap g = after MFMA g): every consumer sits behind its producer.
     (A schedule that packed a P fragment one gap late shows up on the GPU as garbage in exactly the O^T blocks whose
     MFMAs came first - cost a long bisect once.)"""
@@ -564,21 +618,35 @@ def check_part(placed, have_new, have_old, masked, pre=()):
         for qb in (0, 1):
             if have_old and not C.f8:
                 for r in range(16):
-                    assert before(("EXP", kb, qb, r), ("ADD", kb, qb, r)), ("ADD before EXP", kb, qb, r)
+                    if not C.msum:
+                        assert before(("EXP", kb, qb, r), ("ADD", kb, qb, r)), ("ADD before EXP", kb, qb, r)
                 for r in range(0, 16, 2):
                     cv = ("CVT", kb, qb, r)
                     assert before(("EXP", kb, qb, r), cv) and before(("EXP", kb, qb, r + 1), cv), ("CVT before EXP", cv)
-                    assert before(("ADD", kb, qb, r), cv) and before(("ADD", kb, qb, r + 1), cv), ("CVT before ADD", cv)
+                    if not C.msum:
+                        assert before(("ADD", kb, qb, r), cv) and before(("ADD", kb, qb, r + 1), cv), ("CVT before ADD", cv)
+                    else:  # the row-sum MFMA of this packed pair: a later gap than the pack (a big MFMA issues in between), >= 3 MFMA issues before the body ends
+                        ms = ("MSUM", 2 * kb + (r >> 3), qb, (r & 7) >> 2)
+                        assert pos[cv][0] < pos[ms][0] <= C.NG - 4, ("row-sum MFMA placement", ms, pos[cv], pos[ms])
                     # in-place compaction: pair (r, r+1) lands in register 8*(r>>3) + (r&7)/2 of the tile, which must
                     # already have been consumed as a score (its own ADD and the CVT that read it)
                     dst = 8 * (r >> 3) + ((r & 7) >> 1)
                     if dst not in (r, r + 1):
-                        assert before(("ADD", kb, qb, dst), cv), ("CVT overwrites unread score", cv)
+                        if not C.msum:
+                            assert before(("ADD", kb, qb, dst), cv), ("CVT overwrites unread score", cv)
                         assert before(("CVT", kb, qb, dst & ~1), cv), ("CVT overwrites unpacked score", cv)
                     st = 2 * kb + (r >> 3)
                     first_use = C.NQK + 8 * st  # first PV MFMA of this 16-key step (any d-block, any q-block)
                     assert pos[cv][0] < first_use, ("P fragment packed after its first PV MFMA", cv, pos[cv], first_use)
-            if have_new and ("DEC2",) in pos:
+            if have_new and lazy:
+                last_mfma = kb * C.HALF + (C.HALF - 2) + qb
+                for r in range(16):
+                    f = ("FMA", kb, qb, r)
+                    assert pos[f][0] > last_mfma, ("fma on an unfinished score tile", f)
+                    if masked:
+                        assert before(("MASK", kb, qb, r), f) and pos[("MASK", kb, qb, r)][0] > last_mfma, ("mask order", kb, qb, r)
+                assert not any(o[0] in ("MAX", "MAXE", "DEC", "DEC2", "MXINIT") for o in pos), "lazy body carries a max chain"
+            elif have_new and ("DEC2",) in pos:
                 last_mfma = kb * C.HALF + (C.HALF - 2) + qb
                 for r in range(16):
                     f = ("FMA", kb, qb, r)
@@ -626,7 +694,7 @@ def check_part(placed, have_new, have_old, masked, pre=()):
                     assert pos[("KREAD", kb, ks)][0] < kb * C.HALF + ks * 2, ("K fragment read after its MFMA", kb, ks)
 
 
-def emit_part(lines, R, have_new, have_old, masked=False):
+def emit_part(lines, R, have_new, have_old, masked=False, lazy=False):
     mf = []
     if have_new and os.environ.get("W64_LAB_QK_ORDER") == "il":  # lab (timing only): four accumulators round-robin
         for ks in range(C.KS):
@@ -659,8 +727,14 @@ def emit_part(lines, R, have_new, have_old, masked=False):
     elif have_old:
         streams += exp_streams()
         streams.append(vread_stream(have_new))
+        if C.msum:
+            streams.append(msum_stream())
     if have_new:
-        streams += spec_streams(masked) if (SPEC and have_old) else start_streams(True, have_old, masked)
+        if lazy:
+            assert have_old and not C.f8
+            streams += lazy_streams(masked)
+        else:
+            streams += spec_streams(masked) if (SPEC and have_old) else start_streams(True, have_old, masked)
         streams.append(kread_stream())
         dmas = dma_stream()
         streams.append(dmas)
@@ -668,10 +742,17 @@ def emit_part(lines, R, have_new, have_old, masked=False):
         if MIDBAR:
             streams += mid_barrier_streams(have_old)
     pre_budget = PRE["f8" if C.f8 else "i8" if C.i8 else "16"] if (have_new and have_old) else 0
-    slots = schedule(streams, C.NG, pre_budget)
+    budget = None
+    if (C.msum or lazy) and have_new and have_old:
+        # the filler work of an msum / lazy body is 15-30 % below the budget the other bodies were tuned with: spread it evenly
+        # (total / gaps, rounded up to a whole 4-cycle issue slot) instead of front-loading the tile
+        total = sum(COST[o[0][0]] for st_ in streams for o in st_)
+        budget = 4 * (-(-total // (4 * C.NG)))
+        budget = int(os.environ.get("W64_BUDGET_LAZY" if lazy else "W64_BUDGET_MSUM", budget))
+    slots = schedule(streams, C.NG, pre_budget, budget)
     pre, placed = slots[0], slots[1:]
     if not ABL:
-        check_part(placed, have_new, have_old, masked, pre)
+        check_part(placed, have_new, have_old, masked, pre, lazy)
     for op in pre:
         if op[0] not in ABL:
             lines.append("    " + op_text(R, op))
@@ -706,7 +787,24 @@ def emit_helpers(lines):
     a = lines.append
     a("// GENERATED by tools/gen_w64_body.py -- helpers that address the asm-owned O^T registers a[128:255].")
     a("__device__ __forceinline__ void zero_o() {")
-    a("    asm volatile(" + " ".join(f'"v_accvgpr_write_b32 a{O_BASE + r}, 0\\n\\t"' for r in range(128)) + ' "s_nop 0" ::: "memory", "v255", "a255");')
+    a("    asm volatile(" + " ".join(f'"v_accvgpr_write_b32 a{O_BASE + r}, 0\\n\\t"' for r in range(128)) + ' "s_nop 0" ::: "memory", "v254", "a254");')
+    a("}")
+    a("// (the clobbers make the kernel descriptor allocate the whole register file: next_free = 255 rounds up to 256 + 256;")
+    a("// v255 / a255 themselves are names hipcc reserves, and naming them in a clobber list draws a warning)")
+    a("// ---- matrix-pipe row sums (tools/gen_w64_body.py MS_*): literal v[118:127], kernels compiled with amdgpu_num_vgpr(118)")
+    a("__device__ __forceinline__ void ms_init_ones(unsigned bits) {")
+    a(f'    asm volatile("v_mov_b32 v{MS_ONES}, %0\\n\\tv_mov_b32 v{MS_ONES + 1}, %0\\n\\ts_nop 1" :: "s"(bits) : "memory");')
+    a("}")
+    a("__device__ __forceinline__ void ms_zero_l() {")
+    a("    asm volatile(" + " ".join(f'"v_mov_b32 v{MS_L + r}, 0\\n\\t"' for r in range(8)) + ' "s_nop 1" ::: "memory");')
+    a("}")
+    a("// row sums *= alpha (rare paths: deferred max moved / lazy rebase); the four columns of an accumulator are identical and")
+    a("// keep accumulating independently, so all are scaled.  Callers sit behind the s_nops that follow the tile's last MFMA.")
+    a("__device__ __forceinline__ void ms_scale_l(float a0, float a1) {")
+    a("    asm volatile(" + " ".join(f'"v_mul_f32 v{MS_L + r}, v{MS_L + r}, %{r >> 2}\\n\\t"' for r in range(8)) + ' "s_nop 1" :: "v"(a0), "v"(a1) : "memory");')
+    a("}")
+    a("__device__ __forceinline__ void ms_read_l(float& l0, float& l1) {")
+    a(f'    asm volatile("v_mov_b32 %0, v{MS_L}\\n\\tv_mov_b32 %1, v{MS_L + 4}" : "=v"(l0), "=v"(l1));')
     a("}")
     for qb in (0, 1):
         b0 = O_BASE + qb * 64
@@ -795,6 +893,15 @@ def emit_body(out):
     emit_part(lines, Roles("b", "a"), True, True, masked=True)
     lines.append("#elif W64_PART == 7  // masking tile, even")
     emit_part(lines, Roles("a", "b"), True, True, masked=True)
+    if not C.i8:
+        lines.append("#elif W64_PART == 8  // LAZY reference (no row max), steady state, odd tile")
+        emit_part(lines, Roles("b", "a"), True, True, lazy=True)
+        lines.append("#elif W64_PART == 9  // LAZY, even tile")
+        emit_part(lines, Roles("a", "b"), True, True, lazy=True)
+        lines.append("#elif W64_PART == 10  // LAZY, masking tile, odd")
+        emit_part(lines, Roles("b", "a"), True, True, masked=True, lazy=True)
+        lines.append("#elif W64_PART == 11  // LAZY, masking tile, even")
+        emit_part(lines, Roles("a", "b"), True, True, masked=True, lazy=True)
     lines.append("#endif")
     out.write_text("\n".join(lines) + "\n")
     print("wrote", out, len(lines), "lines")

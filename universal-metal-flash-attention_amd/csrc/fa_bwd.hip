@@ -225,12 +225,10 @@ static hipError_t launch_bwd_dp(const BwdParams& p, hipStream_t stream) {
     const size_t lds_dq = 2 * 32 * (DP + 1) * sizeof(float);
     const size_t lds_kv = lds_dq + 64 * sizeof(float);
     hipError_t e;
-    if (lds_kv > 48 * 1024) {
-        e = hipFuncSetAttribute((const void*)bwd_dq_kernel<DP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)bwd_dkdv_kernel<DP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
-        if (e != hipSuccess) return e;
-    }
+    e = ensure_dynamic_lds((const void*)bwd_dq_kernel<DP>, lds_dq);
+    if (e != hipSuccess) return e;
+    e = ensure_dynamic_lds((const void*)bwd_dkdv_kernel<DP>, lds_kv);
+    if (e != hipSuccess) return e;
     const uint32_t nqb = (p.Sq + 127) / 128, nkb = (p.Skv + 127) / 128;
     if (ph & 2) hipLaunchKernelGGL(bwd_dq_kernel<DP>, dim3(nqb * p.B * p.H), dim3(256), lds_dq, stream, p);
     if (ph & 4) hipLaunchKernelGGL(bwd_dkdv_kernel<DP>, dim3(nkb * p.B * p.H), dim3(256), lds_kv, stream, p);

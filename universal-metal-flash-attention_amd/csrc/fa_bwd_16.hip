@@ -1012,32 +1012,20 @@ static hipError_t launch_bwd16_t(const BwdParams& p, hipStream_t stream) {
     constexpr int TILE_BYTES = 32 * 2 * DP;
     const int64_t rows = (int64_t)p.B * p.H * p.Sq;
     (void)rows;  // D = rowsum(dO o O) is computed inside bwd16_dq (bwd16_delta_kernel stays for reference / lab use)
-    if (getenv("UMFA_LAB_SEPARATE_DELTA")) hipLaunchKernelGGL(bwd16_delta_kernel<DP>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, p);
+    if (tuning().bwd_separate_delta.load(std::memory_order_relaxed)) hipLaunchKernelGGL(bwd16_delta_kernel<DP>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, p);
     const size_t lds_dq = 4 * TILE_BYTES, lds_kv = 8 * TILE_BYTES + 1024;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)bwd16_dkdv_kernel<T, CAUSAL, DP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)bwd16_dq_kernel<T, CAUSAL, DP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds((const void*)bwd16_dkdv_kernel<T, CAUSAL, DP>, lds_kv); e != hipSuccess) return e;
+    if (hipError_t e = ensure_dynamic_lds((const void*)bwd16_dq_kernel<T, CAUSAL, DP>, lds_dq); e != hipSuccess) return e;
     const uint32_t nqb = (p.Sq + 127) / 128, nkb = (p.Skv + 127) / 128;
     if constexpr (DP == 128) {
         // one-workgroup-per-CU kernel for non-causal launches (same box, ms per backward, v2 / two-per-CU: FLUX 0.678 / 0.693,
         // B2 H8 S2048 0.145 / 0.159, B8 H16 S1024 0.304 / 0.299); causal launches keep the two-per-CU kernel (FLUX causal
         // 0.477 / 0.464, B4 H16 S8192 causal 3.46 / 3.45: unequal items balance better over two slots per CU).
         // UMFA_BWD_DQ=1 / 2 forces one of them (A/B).
-        const char* fe = getenv("UMFA_BWD_DQ");  // read per launch: tests drive both kernels in one process
-        const int force = fe ? atoi(fe) : 0;
+        const int force = tuning().bwd_dq.load(std::memory_order_relaxed);  // umfa_set_option("bwd_dq", ...): tests drive both kernels in one process
         if (force == 2 || (force == 0 && !CAUSAL)) {
             const size_t lds_dq2 = 4 * 64 * 2 * DP;
-            static bool attr2 = false;
-            if (!attr2) {
-                hipError_t e2 = hipFuncSetAttribute((const void*)bwd16_dq2_kernel<T, CAUSAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dq2);
-                if (e2 != hipSuccess) return e2;
-                attr2 = true;
-            }
+            if (hipError_t e2 = ensure_dynamic_lds((const void*)bwd16_dq2_kernel<T, CAUSAL>, lds_dq2); e2 != hipSuccess) return e2;
             hipLaunchKernelGGL((bwd16_dq2_kernel<T, CAUSAL>), dim3(nqb * p.B * p.H), dim3(256), lds_dq2, stream, p);
         } else {
             hipLaunchKernelGGL((bwd16_dq_kernel<T, CAUSAL, DP>), dim3(nqb * p.B * p.H), dim3(256), lds_dq, stream, p);
@@ -1047,8 +1035,8 @@ static hipError_t launch_bwd16_t(const BwdParams& p, hipStream_t stream) {
     }
     uint32_t kv_grid = nkb * p.B * p.H;
     // measured equal to one workgroup per item (FLUX 0.654-0.657 vs 0.656-0.680 ms, B1 H16 S8192 1.625 vs 1.631): off unless asked for
-    if (!CAUSAL && DP == 128 && getenv("UMFA_BWD_PERSIST")) {  // persistent: one workgroup per CU (see the kernel)
-        static const uint32_t n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return (uint32_t)n; }();
+    if (!CAUSAL && DP == 128 && tuning().bwd_persist.load(std::memory_order_relaxed)) {  // persistent: one workgroup per CU (see the kernel)
+        const uint32_t n_cu = (uint32_t)device_cu_count();
         if (kv_grid > n_cu) kv_grid = n_cu;
     }
     hipLaunchKernelGGL((bwd16_dkdv_kernel<T, CAUSAL, DP>), dim3(kv_grid), dim3(256), lds_kv, stream, p);

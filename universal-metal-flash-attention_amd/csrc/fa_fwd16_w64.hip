@@ -41,6 +41,7 @@ struct W64Params {
     float* part_buf;      // [2 * grid slots][wave 4][q-block 2][chunk 17][lane 64] x 16 bytes (see the kernel)
     uint32_t* part_cnt;   // [n_items % grid] arrival tickets, zero between launches (the folding part resets its own)
     float tau;            // deferred-max threshold (log2 units)
+    uint32_t lazy;        // bf16 kernels: lazy reference mode (no row max after a segment's first tile; see the kernel)
     const float* rope_cos;  // fused rotary embedding of Q (FwdParams::rope_*), NULL = none
     const float* rope_sin;
     int64_t rope_tb;
@@ -76,18 +77,27 @@ struct W64I8Params {
 #define W64_T __bf16
 #define W64_MFMA "v_mfma_f32_32x32x16_bf16"
 #define W64_MFMA_QK "v_mfma_f32_32x32x16_bf16"
+#define W64_MSUM "v_mfma_f32_4x4x4_16b_bf16"   /* row sums: lane-local sum of four P values against an all-ones operand */
+#define W64_ONES_BITS 0x3f803f80u              /* bf16 1.0 twice */
+#define W64_LAZY_PARTS 1                        /* bf16 P has fp32's exponent range: the lazy reference mode exists here only */
 #define W64_CVT "v_cvt_pk_bf16_f32"
 #define W64_KERNEL fa_fwd16_w64_bf16
 #include "fa_fwd16_w64_kernel.inc"
 #undef W64_T
 #undef W64_MFMA
 #undef W64_MFMA_QK
+#undef W64_MSUM
+#undef W64_ONES_BITS
+#undef W64_LAZY_PARTS
 #undef W64_CVT
 #undef W64_KERNEL
 
 #define W64_T _Float16
 #define W64_MFMA "v_mfma_f32_32x32x16_f16"
 #define W64_MFMA_QK "v_mfma_f32_32x32x16_f16"
+#define W64_MSUM "v_mfma_f32_4x4x4_16b_f16"
+#define W64_ONES_BITS 0x3c003c00u              /* fp16 1.0 twice */
+#define W64_LAZY_PARTS 0
 #define W64_CVT "v_cvt_pk_f16_f32"
 #define W64_KERNEL fa_fwd16_w64_f16
 #include "fa_fwd16_w64_kernel.inc"
@@ -98,6 +108,7 @@ struct W64I8Params {
 #undef W64_MFMA_QK
 #undef W64_I8
 #undef W64_BODY_INC
+// (W64_MSUM / W64_ONES_BITS / W64_LAZY_PARTS of the fp16 family stay defined for the int8 kernels below: fp16 P there too)
 
 // runtime-quantised variant: int8 QK^T, fp16 PV
 #define W64_I8 1
@@ -135,30 +146,19 @@ struct W64I8Params {
 #undef W64_BODY_INC
 
 
-// Deferred-max threshold of the w64 kernels: 2^6 unless UMFA_W64_TAU says otherwise (0 = exact running max: +38 % time
-// at the FLUX shape, the tail of the bf16 error distribution shrinks -- DESIGN.md §3.2).  Read at every launch (tests
-// drive both regimes in one process).
-static float w64_tau() {
-    const char* e = getenv("UMFA_W64_TAU");
-    if (!e || !*e) return 6.0f;
-    const float v = (float)atof(e);
-    return v >= 0.0f && v <= 16.0f ? v : 6.0f;
+// Softmax reference policy of a launch (kernels.h SoftmaxRef, set by umfa_set_option): tau of the max-chain tile bodies and
+// whether the bf16 kernels run their lazy bodies.  Measured accuracy / time of the regimes: DESIGN.md §3.2.
+static void w64_softmax_policy(int in_prec, float* tau, uint32_t* lazy) {
+    const int mode = tuning().sm_mode.load(std::memory_order_relaxed);
+    const float t = tuning().sm_tau.load(std::memory_order_relaxed);
+    *tau = mode == SM_EXACT ? 0.0f : t;
+    *lazy = (in_prec == P_BF16 && (mode == SM_DEFAULT || mode == SM_LAZY)) ? 1u : 0u;
 }
 
-static int w64_cu_count() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
+static int w64_cu_count() { return device_cu_count(); }
 
 bool fwd_w64_supported(const FwdParams& p) {
-    static const bool off = [] { const char* e = getenv("UMFA_NO_W64"); return e && e[0] == '1'; }();
-    if (off || !fwd_16_supported(p)) return false;
+    if (tuning().no_w64.load(std::memory_order_relaxed) || !fwd_16_supported(p)) return false;
     if (p.D != 128 || p.mask_kind != MK_NONE) return false;
     // rows are processed in blocks of 256: a ragged last block wastes its empty waves, so small ragged Sq stay on
     // the 128-row kernel; any Skv >= 64 works (a partial last key tile runs the masking variant of the tile body)
@@ -169,8 +169,7 @@ bool fwd_w64_supported(const FwdParams& p) {
     // B1 H8 S4096 (64) 112 / 96, B1 H8 S8192 (128) 213 / 214, B2 H24 S2048 (192) 85 / 98, B8 H16 S1024 (256) 61 / 85;
     // non-causal B1 H24 S1024 (6 tile steps per CU) 38 / 32, B1 H4 S4096 (16 per CU) 54 / 75.  UMFA_FORCE_W64=1 lifts it
     // (parity tests on small shapes).
-    const char* force = getenv("UMFA_FORCE_W64");
-    if (!(force && force[0] == '1')) {
+    if (!tuning().force_w64.load(std::memory_order_relaxed)) {
         const uint64_t cus = (uint64_t)w64_cu_count();
         const uint64_t nqb = (p.Sq + 255) / 256;
         if (p.causal) {
@@ -190,9 +189,9 @@ static uint32_t w64_grid(const FwdParams& p) {
     uint64_t total = (uint64_t)p.B * p.H * ((p.Sq + 255) / 256) * ((p.Skv + 63) / 64);  // (item, key tile) steps
     if (p.causal) total = (uint64_t)p.B * p.H * (((p.Sq + 255) / 256 + 1) / 2);  // jobs = mirrored pairs of q-blocks
     const uint32_t cus = (uint32_t)w64_cu_count();
-    if (const char* e = getenv("UMFA_W64_GRID")) {  // lab: force the number of workgroups
-        const uint32_t g = (uint32_t)atoi(e);
-        if (g > 0 && g <= cus && g <= total) return g;
+    if (const int gi = tuning().w64_grid.load(std::memory_order_relaxed)) {  // lab: force the number of workgroups
+        const uint32_t g = (uint32_t)gi;
+        if (gi > 0 && g <= cus && g <= total) return g;
     }
     if (!p.causal) {
         // few items (the strong-scaling shards of a problem: B1 H3 S4096 = 48 items): a whole number of EQUAL parts per item
@@ -217,18 +216,8 @@ FwdW64Plan fwd_w64_plan(const FwdParams& p) {
 template <typename KFN>
 static hipError_t launch_w64_kernel(KFN kfn, const FwdParams& p, const W64Params& wp, hipStream_t stream) {
     const uint32_t grid = w64_grid(p);
-    const size_t lds = 65536 + 4 * 32 * (512 + 16);  // K/V rings + per-wave output staging
-    // (KFN is the same function-pointer type for every kernel here, so a static flag would be shared: keep a small
-    // table of the kernels that already have the attribute)
-    static const void* done[16] = {};
-    bool seen = false;
-    for (const void* d : done) seen |= d == (const void*)kfn;
-    if (!seen) {
-        hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        for (const void*& d : done)
-            if (!d) { d = (const void*)kfn; break; }
-    }
+    const size_t lds = 65536 + 4 * 32 * (512 + 16) + 16;  // K/V rings + per-wave output staging + the lazy mode's overflow flag
+    if (hipError_t e = ensure_dynamic_lds((const void*)kfn, lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, stream, wp);
     return hipGetLastError();
 }
@@ -245,7 +234,7 @@ hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cn
     wp.T = (p.Skv + 63) / 64;
     wp.part_buf = part_buf;
     wp.part_cnt = part_cnt;
-    wp.tau = w64_tau();
+    w64_softmax_policy(p.in_prec, &wp.tau, &wp.lazy);
     wp.rope_cos = p.rope_cos; wp.rope_sin = p.rope_sin; wp.rope_tb = p.rope_tb;
     if (p.rope_cos) {  // fused-RoPE instantiations exist for O in the operand type only (runtime.hip asks first)
         if (p.out_prec != p.in_prec) return hipErrorNotSupported;
@@ -276,8 +265,7 @@ hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cn
 
 // ---- runtime-quantised variant ---------------------------------------------------------------------------------
 bool fwd_w64_i8_supported(const FwdParams& p) {
-    static const bool off = [] { const char* e = getenv("UMFA_NO_W64"); return e && e[0] == '1'; }();
-    if (off || p.D != 128 || p.mask_kind != MK_NONE || p.mask) return false;
+    if (tuning().no_w64.load(std::memory_order_relaxed) || p.D != 128 || p.mask_kind != MK_NONE || p.mask) return false;
     if (!(p.scale > 0.0f)) return false;
     if (p.Skv < 64 || p.Sq < 256 || (p.Sq % 256 != 0 && p.Sq < 1024)) return false;
     return true;
@@ -296,19 +284,14 @@ hipError_t launch_fwd_w64_i8(const FwdParams& p, const QuantViews& v, float* par
     wp.T = (p.Skv + 63) / 64;
     wp.part_buf = part_buf;
     wp.part_cnt = part_cnt;
-    wp.tau = w64_tau();
+    uint32_t lazy_unused = 0;
+    w64_softmax_policy(P_FP16, &wp.tau, &lazy_unused);  // fp16 P: deferred / exact max only
     const uint32_t grid = w64_grid(p);
-    const size_t lds = 65536 + 4 * 32 * (512 + 16);
+    const size_t lds = 65536 + 4 * 32 * (512 + 16) + 16;
     const bool f8 = v.v8 != nullptr;
     auto kfn = f8 ? (p.causal ? fa_fwd_w64_i8f8<float, true> : fa_fwd_w64_i8f8<float, false>)
                   : (p.causal ? fa_fwd_w64_i8<float, true> : fa_fwd_w64_i8<float, false>);
-    static bool attr_set[4] = {false, false, false, false};
-    const int ai = (f8 ? 2 : 0) + (p.causal ? 1 : 0);
-    if (!attr_set[ai]) {
-        hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set[ai] = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds((const void*)kfn, lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, stream, wp);
     return hipGetLastError();
 }

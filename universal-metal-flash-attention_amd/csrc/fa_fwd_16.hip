@@ -40,16 +40,7 @@ bool fwd_16_supported(const FwdParams& p) {
     return true;
 }
 
-static int cu_count() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
+static int cu_count() { return device_cu_count(); }
 
 static inline uint32_t dp16_of(uint32_t D) { return D <= 32 ? 32 : D <= 64 ? 64 : D <= 128 ? 128 : 256; }
 
@@ -66,15 +57,14 @@ FwdSplitPlan fwd_16_split_plan(const FwdParams& p) {
     plan.n_full = items;
     plan.nsplit = 1;
     plan.buf_bytes = plan.cnt_bytes = 0;
-    const char* env = getenv("UMFA_NO_SPLIT");
-    if (p.causal || items == 0 || (env && env[0] == '1')) return plan;  // causal items are uneven already
+    if (p.causal || items == 0 || tuning().no_split.load(std::memory_order_relaxed)) return plan;  // causal items are uneven already
     uint32_t k = cus / items, kmax = 8;
     // One q-block per (batch, head) -- decode-like calls: no two items share K / V, the sweep is bound by how many
     // tile loads a CU keeps in flight, so aim for two resident workgroups per CU (B8 H32 Sq1 Skv8192: 297 -> 243 us
     // with 2 parts, B4 H32: 172 -> 133 us with 4; with more items than 2 x CUs splitting only loses)
     if (nqb == 1) { k = 2 * cus / items; kmax = 16; }
-    const char* force = getenv("UMFA_FORCE_SPLIT");  // experiments: split every item k ways
-    if (force && force[0] >= '2' && force[0] <= '8') k = (uint32_t)(force[0] - '0');
+    const int force = tuning().force_split.load(std::memory_order_relaxed);  // experiments: split every item k ways
+    if (force >= 2 && force <= 8) k = (uint32_t)force;
     if (k > kmax) k = kmax;
     if (k > ntiles / 4) k = ntiles / 4;  // keep >= 4 key tiles per part
     if (k < 2) return plan;
@@ -98,23 +88,12 @@ static hipError_t launch_dma(const FwdParams& pin, hipStream_t stream) {
     }
     const size_t lds = 4 * BN * DP * 2;
     auto kfn = fa_fwd16_kernel<T, DP, CAUSAL, HAS_MASK, OUT, DMA, BN>;
-    static bool attr_set = false;  // per instantiation
-    if (lds > 48 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds((const void*)kfn, lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, stream, p);
     return hipGetLastError();
 }
 
-static bool dma_enabled() {
-    static const bool on = [] {
-        const char* e = getenv("UMFA_NO_DMA");
-        return !(e && e[0] == '1');
-    }();
-    return on;
-}
+static bool dma_enabled() { return !tuning().no_dma.load(std::memory_order_relaxed); }
 
 // LDS-DMA staging when head_dim fills the padded row exactly; register staging otherwise.
 template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT>
@@ -124,8 +103,7 @@ static hipError_t launch_one(const FwdParams& p, hipStream_t stream) {
         // (lab, same box: FLUX 768 items 264 -> 242 us; 3072 items 895 -> 870 us; never slower)
         // (causal launches lose with it: 184 vs 146 us at the FLUX shape, so they keep 64-key tiles)
         if constexpr (DP == 128 && !HAS_MASK && !CAUSAL) {
-            static const bool bn32 = [] { const char* e = getenv("UMFA_BN64"); return !(e && e[0] == '1'); }();
-            if (bn32) return launch_dma<T, DP, CAUSAL, HAS_MASK, OUT, true, 32>(p, stream);
+            if (!tuning().bn64.load(std::memory_order_relaxed)) return launch_dma<T, DP, CAUSAL, HAS_MASK, OUT, true, 32>(p, stream);
         }
         return launch_dma<T, DP, CAUSAL, HAS_MASK, OUT, true, 64>(p, stream);
     }

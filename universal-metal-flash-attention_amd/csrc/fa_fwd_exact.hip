@@ -143,11 +143,7 @@ template <int DP>
 static hipError_t launch_exact(const FwdParams& p, hipStream_t stream) {
     const uint32_t nqb = (p.Sq + 127) / 128;
     const size_t lds = 2 * 32 * (DP + 1) * sizeof(float);
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)fa_fwd_exact_kernel<DP>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
+    if (hipError_t e = ensure_dynamic_lds((const void*)fa_fwd_exact_kernel<DP>, lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(fa_fwd_exact_kernel<DP>, dim3(nqb * p.B * p.H), dim3(256), lds, stream, p);
     return hipGetLastError();
 }

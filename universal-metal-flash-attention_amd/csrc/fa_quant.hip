@@ -572,12 +572,7 @@ static hipError_t launch_i8_one(const I8FwdParams& p, hipStream_t stream) {
     const uint32_t nqb = (p.Sq + 127) / 128;
     const size_t lds = 2 * BN * DP + 2 * BN * DP * 2;
     auto kfn = fa_fwd_i8_kernel<DP, CAUSAL, HAS_MASK, BN>;
-    static bool attr_set = false;
-    if (lds > 48 * 1024 && !attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    if (hipError_t e = ensure_dynamic_lds((const void*)kfn, lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(kfn, dim3(nqb * p.B * p.H), dim3(256), lds, stream, p);
     return hipGetLastError();
 }

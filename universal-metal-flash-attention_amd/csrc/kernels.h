@@ -2,9 +2,31 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "fa_common.h"
 
 namespace umfa {
+
+// Process-wide launcher switches (tuning.hip): initial values from the environment once, then umfa_set_option only.
+enum SoftmaxRef : int {
+    SM_DEFAULT = 0,   // bf16: lazy; fp16 / int8 kernels: deferred max with threshold 2^sm_tau
+    SM_EXACT = 1,     // the reference max is the exact running max (every P <= 1)
+    SM_DEFERRED = 2,  // deferred max: the reference moves when a row max exceeds it by 2^sm_tau (T13)
+    SM_LAZY = 3,      // bf16 only: no row max after a segment's first tile, rebase by exact powers of two off the row sums
+};
+struct Tuning {
+    std::atomic<int> sm_mode{SM_DEFAULT};
+    std::atomic<float> sm_tau{6.0f};
+    std::atomic<int> force_w64{0}, no_w64{0}, w64_grid{0}, no_mask_flags{0}, bwd_exact{0}, bwd_dq{0}, bwd_persist{0},
+        bwd_separate_delta{0}, no_split{0}, force_split{0}, no_dma{0}, bn64{0};
+};
+Tuning& tuning();
+bool set_tuning(const char* name, const char* value);  // false: unknown name or value out of range
+// per-device launch state (tuning.hip): CU count of the CURRENT device; MaxDynamicSharedMemorySize of `kernel` on the
+// current device raised to >= bytes (once per device and kernel)
+int device_cu_count();
+hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes);
 
 // fp32-exact forward (any input type, any D <= 256, masks, causal, LSE).
 hipError_t launch_fwd_exact(const FwdParams& p, hipStream_t stream, const char** name);

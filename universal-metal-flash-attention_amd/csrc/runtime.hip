@@ -102,7 +102,7 @@ hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p,
             pp.part_cnt = (uint32_t*)buf;
             pp.part_buf = (float*)(buf + plan.cnt_bytes);
         }
-        if (pp.mask_kind != MK_NONE && !getenv("UMFA_NO_MASK_FLAGS") && mask_flags_worthwhile(pp)) {
+        if (pp.mask_kind != MK_NONE && !tuning().no_mask_flags.load(std::memory_order_relaxed) && mask_flags_worthwhile(pp)) {
             // tile early-exit for masks: one pre-pass over the distinct mask elements classifies every (32 rows x 64
             // keys) tile; fully masked tiles are skipped, fully open ones run without reading the mask.  Results are
             // bit-identical with and without the flags, so a pool that may not grow (capture) just runs without them.
@@ -502,6 +502,11 @@ int32_t mfa_has_native_bfloat_msl32(void) { return device_usable(nullptr) ? 1 : 
 const char* umfa_last_kernel_name(mfa_context_t context) {
     Context* c = as_ctx(context);
     return c ? c->last_kernel : "none";
+}
+
+mfa_error_t umfa_set_option(mfa_context_t context, const char* name, const char* value) {
+    if (!as_ctx(context)) return MFA_ERROR_INVALID_ARGS;
+    return set_tuning(name, value) ? MFA_SUCCESS : MFA_ERROR_INVALID_ARGS;
 }
 
 mfa_error_t mfa_set_scale_arrays(mfa_context_t context, const float* q_scales, uint32_t q_scales_count,

@@ -64,7 +64,7 @@ mfa_error_t mfa_attention_backward(mfa_context_t context, mfa_buffer_t dout, mfa
     LatencyScope lat(ctx, stream);
     const char* name = "none";
     // 16-bit operands with 16-bit intermediates -> MFMA backward; everything else -> fp32-exact backward
-    const bool lowp = dense_prec(intermediate_precision) != P_FP32 && !getenv("UMFA_BWD_EXACT");
+    const bool lowp = dense_prec(intermediate_precision) != P_FP32 && !tuning().bwd_exact.load(std::memory_order_relaxed);
     const bool mfma16 = lowp && bwd_16_supported(p);
     if (mfma16) {
         p.rowc = (float*)ctx->pool(ctx->device, stream).rowc.ensure(2 * nr * sizeof(float), stream);
@@ -107,7 +107,7 @@ mfa_error_t umfa_attention_backward_stream(mfa_context_t context, void* stream, 
     p.in_prec = dense_prec(input_precision); p.dout_prec = p.in_prec;
     p.grad_in_type = grads_in_input_type ? 1 : 0;
     p.o_in_type = (out_in_input_type && p.in_prec != P_FP32) ? 1 : 0;  // D = rowsum(dO o O) from the rounded O the caller kept
-    const bool lowp = dense_prec(intermediate_precision) != P_FP32 && !getenv("UMFA_BWD_EXACT");
+    const bool lowp = dense_prec(intermediate_precision) != P_FP32 && !tuning().bwd_exact.load(std::memory_order_relaxed);
     const bool mfma16 = lowp && bwd_16_supported(p);
     if (grads_in_input_type && !mfma16) return MFA_ERROR_INVALID_ARGS;
     const char* name = "none";

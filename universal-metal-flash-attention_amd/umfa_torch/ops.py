@@ -37,6 +37,39 @@ def last_kernel() -> str:
     return _lib.umfa_last_kernel_name(context()).decode()
 
 
+# launcher switches (include/umfa_abi.h umfa_set_option); the library's defaults, for options() to restore
+_OPTION_DEFAULTS = {"softmax_reference": "default", "softmax_tau": "6", "force_w64": "0", "no_w64": "0", "w64_grid": "0",
+                    "no_mask_flags": "0", "bwd_exact": "0", "bwd_dq": "0", "bwd_persist": "0", "no_split": "0",
+                    "force_split": "0", "no_dma": "0", "bn64": "0"}
+_option_state = {}
+
+
+def set_option(name: str, value) -> None:
+    """Context-wide launcher switch, e.g. set_option("softmax_reference", "exact") -- see umfa_set_option in the header."""
+    _check_error(_lib.umfa_set_option(context(), name.encode(), str(value).encode()))
+    _option_state[name] = str(value)
+
+
+class options:
+    """with umfa_torch.options(softmax_reference="exact", force_w64=1): ...  -- sets the switches, restores the previous
+    values (the library defaults for switches never set through this module) on exit."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+        self.prev = {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            self.prev[k] = _option_state.get(k, _OPTION_DEFAULTS[k])
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.prev.items():
+            set_option(k, v)
+        return False
+
+
 def _i64(vals):
     return (ctypes.c_int64 * len(vals))(*[int(v) for v in vals])
 
