@@ -26,3 +26,20 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture
+def umfa_opts():
+    """set launcher switches (umfa_set_option) for one test: umfa_opts(force_w64=1, softmax_reference="exact"); the
+    previous values come back at teardown.  (The environment only seeds these switches when the library is first used.)"""
+    import umfa_torch
+    stack = []
+
+    def setter(**kw):
+        ctx = umfa_torch.options(**kw)
+        ctx.__enter__()
+        stack.append(ctx)
+
+    yield setter
+    while stack:
+        stack.pop().__exit__(None, None, None)

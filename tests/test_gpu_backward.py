@@ -256,13 +256,13 @@ def test_backward_stream_accepts_o_in_operand_type(ctx):
 
 @pytest.mark.parametrize("which", ["1", "2"])
 @pytest.mark.parametrize("causal", [False, True])
-def test_backward_both_dq_kernels_head_dim_128(ctx, which, causal, monkeypatch):
+def test_backward_both_dq_kernels_head_dim_128(ctx, which, causal, umfa_opts):
     """head_dim 128 has two dQ kernels (two workgroups per CU with 32-key tiles; one per CU with 64-key tiles and the pinned
     four-phase pipeline); the launcher picks by causality.  UMFA_BWD_DQ forces one: both must meet the oracle on both kinds
     of launch, ragged sizes included."""
     import umfa
     orc = _oracle()
-    monkeypatch.setenv("UMFA_BWD_DQ", which)
+    umfa_opts(bwd_dq=which)
     for shape in [(1, 2, 256, 128), (2, 1, 333, 128), (1, 1, 1024, 128)]:
         rng = np.random.default_rng(21)
         q, k, v, do = (orc.f32_to_bf16_bits(rng.standard_normal(shape).astype(np.float32)).reshape(shape) for _ in range(4))

@@ -30,7 +30,8 @@ def check_rows(q, k, v, o, rows, causal, kernel, tag, out_dt=None):
     normalisation (max|O_ref| over the subset), so the bounds of tests/tolerances.py apply as they stand."""
     rows = np.asarray(rows)
     ref = _oracle().sdpa_forward_rows(bits(q), bits(k), bits(v), rows, causal=causal)
-    return check_forward(o[:, :, rows].float().cpu().numpy(), ref, q.dtype, kernel, tag, out_dt=out_dt)
+    return check_forward(o[:, :, rows].float().cpu().numpy(), ref, q.dtype, kernel, tag, out_dt=out_dt,
+                         inputs=(bits(q), bits(k), bits(v)), rows=rows, causal=causal)
 
 
 def test_config1_metal_sdpa_wrapper_B1_H1_S128_D64_fp32():

@@ -157,7 +157,7 @@ def test_relative_error_16bit(ctx, shape, dt, causal):
     o = o.cpu().numpy()
     assert np.isfinite(o).all()
     from tolerances import check_forward  # measured bounds; P is rounded to the input type before PV
-    check_forward(o, ref, dt, umfa_torch.last_kernel(), f"rel16_{shape}_{causal}")
+    check_forward(o, ref, dt, umfa_torch.last_kernel(), f"rel16_{shape}_{causal}", inputs=(bits(tq), bits(tk), bits(tv)), causal=causal)
     assert np.abs(lse.cpu().numpy().reshape(ref_lse.shape) - ref_lse).max() < 2e-3
     # fused cast-back epilogue (16-bit out): within half an ulp of the fp32 output (the epilogue multiplies
     # and rounds once -- v_fma_mix -- so exact ties may differ from "round the stored fp32 again")
@@ -295,7 +295,8 @@ def test_flux_shape_one_head_vs_oracle(ctx):
         ref = orc.sdpa_forward(bits(q[:, h:h + 1].contiguous()), bits(k[:, h:h + 1].contiguous()),
                                bits(v[:, h:h + 1].contiguous()))
         from tolerances import check_forward
-        check_forward(o[:, h:h + 1].cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel(), f"flux_head{h}")
+        check_forward(o[:, h:h + 1].cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel(), f"flux_head{h}",
+                      inputs=(bits(q[:, h:h + 1].contiguous()), bits(k[:, h:h + 1].contiguous()), bits(v[:, h:h + 1].contiguous())))
     flat = o[0].reshape(24, -1)
     c = torch.corrcoef(flat[:, :65536])
     off = c - torch.diag(torch.diag(c))
@@ -304,7 +305,7 @@ def test_flux_shape_one_head_vs_oracle(ctx):
 
 @pytest.mark.parametrize("kind", ["sliding_bool", "padding_bcast", "blockdiag_float", "random_bool", "causal_plus_window", "odd_skv_bool"])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
-def test_mask_tile_early_exit(kind, dt, monkeypatch):
+def test_mask_tile_early_exit(kind, dt, umfa_opts):
     """Masks go through a pre-pass that classifies every (32 rows x 64 keys) tile (fa_aux.hip mask_flags_kernel):
     fully masked tiles are skipped, fully open ones run without reading the mask.  Structured masks (sliding window,
     key padding, block-diagonal additive -inf) must give the same bits as the per-score path (UMFA_NO_MASK_FLAGS=1)
@@ -347,7 +348,7 @@ def test_mask_tile_early_exit(kind, dt, monkeypatch):
     r = ref()
     assert torch.isfinite(out).all()
     assert ((out - r).abs().max() / r.abs().max()).item() < (6e-3 if dt == torch.bfloat16 else 2e-3)
-    monkeypatch.setenv("UMFA_NO_MASK_FLAGS", "1")
+    umfa_opts(no_mask_flags=1)
     out2, lse2 = umfa_torch.attention_forward(q, k, v, causal=causal, mask=mask, out_dtype=torch.float32, return_lse=True)
     torch.cuda.synchronize()
     assert torch.equal(out, out2) and torch.equal(lse, lse2)  # skipping / not reading changes no bit

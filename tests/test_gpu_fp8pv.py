@@ -19,8 +19,8 @@ def bits(t):
 
 
 @pytest.fixture(autouse=True)
-def _force_w64(monkeypatch):
-    monkeypatch.setenv("UMFA_FORCE_W64", "1")
+def _force_w64(umfa_opts):
+    umfa_opts(force_w64=1)
 
 
 @pytest.mark.parametrize("shape,causal", [((1, 2, 256, 256), False), ((1, 3, 512, 448), False), ((2, 2, 768, 768), True),

@@ -35,11 +35,11 @@ CASES = [  # (B, H, S, D), dtype, causal, batched tables, force the 256-row kern
 
 
 @pytest.mark.parametrize("shape,dt,causal,batched,force", CASES)
-def test_fused_equals_rotate_then_attend(shape, dt, causal, batched, force, monkeypatch):
+def test_fused_equals_rotate_then_attend(shape, dt, causal, batched, force, umfa_opts):
     import umfa_torch
     from umfa_torch import ops
     if force:
-        monkeypatch.setenv("UMFA_FORCE_W64", "1")
+        umfa_opts(force_w64=1)
     B, H, S, D = shape
     torch.manual_seed(11)
     q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=dt) for _ in range(3))
@@ -54,11 +54,11 @@ def test_fused_equals_rotate_then_attend(shape, dt, causal, batched, force, monk
     assert np.array_equal(_raw(lse), _raw(lse_ref))
 
 
-def test_fused_strided_operands_and_routing(monkeypatch):
+def test_fused_strided_operands_and_routing(umfa_opts):
     """BSHD-permuted views (contiguous last dim only) through the public routing function."""
     import umfa_torch
     from umfa_torch import ops
-    monkeypatch.setenv("UMFA_FORCE_W64", "1")
+    umfa_opts(force_w64=1)
     B, H, S, D = 1, 4, 512, 128
     torch.manual_seed(12)
     q, k, v = (torch.randn(B, S, H, D, device="cuda", dtype=torch.bfloat16).permute(0, 2, 1, 3) for _ in range(3))
@@ -73,12 +73,12 @@ def test_fused_strided_operands_and_routing(monkeypatch):
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
-def test_fused_vs_oracle(dt, monkeypatch):
+def test_fused_vs_oracle(dt, umfa_opts):
     import umfa_torch  # noqa: F401
     from umfa_torch import ops
     from oracle import oracle
     from tolerances import check_forward
-    monkeypatch.setenv("UMFA_FORCE_W64", "1")
+    umfa_opts(force_w64=1)
     B, H, S, D = 1, 2, 512, 128
     torch.manual_seed(13)
     q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=dt) for _ in range(3))

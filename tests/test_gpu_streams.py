@@ -10,8 +10,8 @@ torch = pytest.importorskip("torch")
 
 
 @pytest.fixture(autouse=True)
-def _force_w64(monkeypatch):
-    monkeypatch.setenv("UMFA_FORCE_W64", "1")  # small grids: every item of fa_fwd16_w64 is cut into parts and folded
+def _force_w64(umfa_opts):
+    umfa_opts(force_w64=1)  # small grids: every item of fa_fwd16_w64 is cut into parts and folded
 
 
 def _inputs(seed, B=1, H=5, Sq=768, Skv=448):

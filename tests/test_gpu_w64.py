@@ -16,12 +16,12 @@ def _oracle():
 
 
 @pytest.fixture(autouse=True)
-def _force_w64(request, monkeypatch):
+def _force_w64(request, umfa_opts):
     """The dispatcher sends shapes with too little parallel work for one workgroup per CU to the 128-row kernel
-    (fa_fwd16_w64.hip: fwd_w64_supported); the parity cases here are small on purpose, so lift that gate.
-    (read per call by the library)"""
+    (fa_fwd16_w64.hip: fwd_w64_supported); the parity cases here are small on purpose, so lift that gate
+    (umfa_set_option, restored after the test)."""
     if "dispatch_gate" not in request.node.name:
-        monkeypatch.setenv("UMFA_FORCE_W64", "1")
+        umfa_opts(force_w64=1)
 
 
 def bits(t):
@@ -52,7 +52,7 @@ def test_w64_small_shapes_vs_oracle(shape, dt):
     o, lse = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32, return_lse=True)
     assert umfa_torch.last_kernel().startswith("fa_fwd16_w64"), umfa_torch.last_kernel()
     ref, ref_lse = _oracle().sdpa_forward(npy(q), npy(k), npy(v), return_lse=True)
-    check_forward(o.cpu().numpy(), ref, dt, umfa_torch.last_kernel())
+    check_forward(o.cpu().numpy(), ref, dt, umfa_torch.last_kernel(), inputs=(npy(q), npy(k), npy(v)))
     assert np.abs(lse.cpu().numpy().reshape(ref_lse.shape) - ref_lse).max() < 2e-2
     # 16-bit epilogue = the fp32 result rounded once (half an ulp of the 16-bit type)
     o16 = umfa_torch.attention_forward(q, k, v)
@@ -76,16 +76,15 @@ def test_w64_flux_shape_matches_oracle_rows_and_is_deterministic():
     # the 64 / 256-row grid, all keys; the oracle's row-subset entry keeps the whole-tensor normalisation of the metric
     rows = np.array([0, 255, 256, 300, 511, 512, 1000, 2047, 2048, 3333, 4095] + list(range(1536, 1600)))
     ref, rl = orc.sdpa_forward_rows(bits(q), bits(k), bits(v), rows, return_lse=True)
-    check_forward(o[:, :, rows].cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel(), "flux_rows")
+    inp = (bits(q), bits(k), bits(v))
+    check_forward(o[:, :, rows].cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel(), "flux_rows", inputs=inp, rows=rows)
     assert np.abs(lse.view(B, H, S)[:, :, rows].cpu().numpy() - rl).max() < 2e-2
-    # the exact-running-max regime of the same kernel (UMFA_W64_TAU=0) sits at the bf16 format floor
-    import os
-    os.environ["UMFA_W64_TAU"] = "0"
-    try:
-        o0 = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
-        check_forward(o0[:, :, rows].cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel(), "flux_rows_tau0")
-    finally:
-        del os.environ["UMFA_W64_TAU"]
+    # the other regimes of the same kernel: exact running max (sits at the bf16 format floor) and the deferred max
+    for regime in ({"softmax_reference": "exact"}, {"softmax_reference": "deferred", "softmax_tau": 6}):
+        with umfa_torch.options(**regime):
+            o0 = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
+            check_forward(o0[:, :, rows].cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel(),
+                          "flux_rows_" + regime["softmax_reference"], inputs=inp, rows=rows)
 
 
 def test_w64_strided_inputs_and_cross_attention():
@@ -100,7 +99,7 @@ def test_w64_strided_inputs_and_cross_attention():
     o = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32, scale=0.05)
     assert umfa_torch.last_kernel().startswith("fa_fwd16_w64")
     ref = _oracle().sdpa_forward(bits(q), bits(k), bits(v), scale=0.05)
-    check_forward(o.cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel())
+    check_forward(o.cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel(), inputs=(bits(q), bits(k), bits(v)), scale=0.05)
 
 
 def test_w64_deferred_max_rescale_paths():
@@ -122,27 +121,66 @@ def test_w64_deferred_max_rescale_paths():
         assert umfa_torch.last_kernel().startswith("fa_fwd16_w64")
         ref, rl = _oracle().sdpa_forward(bits(q), bits(k), bits(v), return_lse=True)
         assert np.isfinite(o.cpu().numpy()).all()
-        # hostile on purpose: the reference max moves ~10 times per row and P spans 2^6 under the deferred max
+        # hostile on purpose: the reference moves many times per row (lazy: power-of-two rebases off the row sums)
         check_forward(o.cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel(), f"ramp{sign:+.0f}", scale_max=1.5)
+        with umfa_torch.options(softmax_reference="deferred", softmax_tau=6):  # the max-chain bodies: O rescale on every 2^6 rise
+            o6 = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
+            check_forward(o6.cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel(), f"ramp{sign:+.0f}_tau6", scale_max=1.5)
         assert np.abs(lse.cpu().numpy().reshape(rl.shape) - rl).max() < 5e-2
 
 
-def test_w64_deferred_max_tail_vs_exact_running_max(monkeypatch):
-    """The shape on which the deferred max shows its tail (profiles/r2/error_anatomy.md: B1 H64 S1024, whole tensor
-    against the oracle): tau = 6 stays inside the measured deferred-max bounds, and the same kernel with
-    UMFA_W64_TAU=0 (exact running max) sits at the bf16 operand-format floor -- same rows, same inputs."""
+def test_w64_stale_reference_tail_vs_exact_running_max():
+    """The shape on which a stale softmax reference shows its tail (profiles/r2/error_anatomy.md: B1 H64 S1024 against the
+    oracle): the default (lazy) and deferred regimes stay inside the stale-reference multiples of the format floor, and
+    the same kernel with softmax_reference = exact sits AT the floor -- same rows, same inputs."""
     import umfa_torch
     torch.manual_seed(0)
     q, k, v = (torch.randn(1, 64, 1024, 128, device="cuda", dtype=torch.float32).to(torch.bfloat16) for _ in range(3))
-    ref = _oracle().sdpa_forward(bits(q), bits(k), bits(v))
-    o6 = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
+    rows = np.arange(0, 1024, 4)
+    inp = (bits(q), bits(k), bits(v))
+    ref = _oracle().sdpa_forward_rows(*inp, rows)
+    ol = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
     assert umfa_torch.last_kernel().startswith("fa_fwd16_w64")
-    m6, r6 = check_forward(o6.cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel(), "tail_tau6")
-    monkeypatch.setenv("UMFA_W64_TAU", "0")
-    o0 = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
-    m0, r0 = check_forward(o0.cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel(), "tail_tau0")
-    assert m0 < 1.6e-3 and r0 < r6  # measured: 0.9e-3 ... 1.2e-3 max, rms 7 ... 10 % under the deferred regime
-    assert not torch.equal(o0, o6)
+    ml, rl = check_forward(ol[:, :, rows].cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel(), "tail_lazy", inputs=inp, rows=rows)
+    with umfa_torch.options(softmax_reference="deferred", softmax_tau=6):
+        o6 = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
+        check_forward(o6[:, :, rows].cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel(), "tail_tau6", inputs=inp, rows=rows)
+    with umfa_torch.options(softmax_reference="exact"):
+        o0 = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
+        m0, r0 = check_forward(o0[:, :, rows].cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel(), "tail_exact", inputs=inp, rows=rows)
+    assert r0 < rl and m0 < ml  # the exact reference is the better one: measured 1.05e-3 vs 3.5e-3 max, rms 7 ... 10 % lower
+    assert not torch.equal(o0, ol)
+
+
+def test_w64_lazy_overflow_restarts_the_segment_with_the_max_chain():
+    """The lazy mode's escape hatch: scores that jump by far more than 2^100 between two key tiles overflow the stale
+    reference (P = inf); the workgroup must notice, re-run the segment with the max chain, and still meet the oracle --
+    for the rows that jump AND for the ordinary rows that share their workgroup."""
+    import umfa_torch
+    torch.manual_seed(5)
+    B, H, Sq, Skv, D = 1, 3, 512, 768, 128
+    q = torch.randn(B, H, Sq, D, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(B, H, Skv, D, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn(B, H, Skv, D, device="cuda", dtype=torch.bfloat16)
+    # head 1: keys 300 ... 767 carry a huge component along the mean query direction: scores rise by ~400 nats at key 300
+    d = q[:, 1].float().mean(dim=1, keepdim=True)
+    d = d / d.norm(dim=-1, keepdim=True)
+    kk = k.float()
+    kk[:, 1, 300:] += 4000.0 * d
+    k = kk.to(torch.bfloat16)
+    o, lse = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32, return_lse=True)
+    assert umfa_torch.last_kernel().startswith("fa_fwd16_w64")
+    ref, rl = _oracle().sdpa_forward(bits(q), bits(k), bits(v), return_lse=True)
+    on = o.cpu().numpy()
+    assert np.isfinite(on).all()
+    check_forward(on, ref, torch.bfloat16, umfa_torch.last_kernel(), "lazy_overflow", scale_max=1.5)
+    finite = np.isfinite(rl)
+    assert np.abs(lse.cpu().numpy().reshape(rl.shape) - rl)[finite].max() < 5e-2 * max(1.0, np.abs(rl[finite]).max() / 50)
+    with umfa_torch.options(softmax_reference="exact"):
+        oe = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
+    # rows of head 1 went through the restart; their neighbours in heads 0 and 2 never left the lazy bodies
+    assert float((o[:, 1] - oe[:, 1]).abs().max()) <= 8e-3 * float(oe[:, 1].abs().max())
+    assert torch.equal(o, umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32))  # bitwise repeatable
 
 
 @pytest.mark.parametrize("shape", [(1, 2, 256, 256), (1, 2, 512, 512), (2, 3, 768, 768), (1, 2, 1024, 448), (1, 1, 256, 1024),
@@ -160,7 +198,7 @@ def test_w64_causal_vs_oracle(shape, dt):
     assert umfa_torch.last_kernel().startswith("fa_fwd16_w64"), umfa_torch.last_kernel()
     ref, ref_lse = _oracle().sdpa_forward(npy(q), npy(k), npy(v), causal=True, return_lse=True)
     assert np.isfinite(o.cpu().numpy()).all()
-    check_forward(o.cpu().numpy(), ref, dt, umfa_torch.last_kernel())
+    check_forward(o.cpu().numpy(), ref, dt, umfa_torch.last_kernel(), inputs=(npy(q), npy(k), npy(v)), causal=True)
     assert np.abs(lse.cpu().numpy().reshape(ref_lse.shape) - ref_lse).max() < 2e-2
     assert torch.equal(o, umfa_torch.attention_forward(q, k, v, causal=True, out_dtype=torch.float32))
     o16 = umfa_torch.attention_forward(q, k, v, causal=True)
@@ -178,7 +216,8 @@ def test_w64_causal_flux_shape_rows():
     assert torch.equal(o, umfa_torch.attention_forward(q, k, v, causal=True, out_dtype=torch.float32))
     rows = np.array([0, 1, 63, 64, 255, 256, 1000, 2047, 2048, 4095] + list(range(3000, 3064)))
     ref = _oracle().sdpa_forward_rows(bits(q), bits(k), bits(v), rows, causal=True)
-    check_forward(o[:, :, rows].cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel(), "flux_causal_rows")
+    check_forward(o[:, :, rows].cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel(), "flux_causal_rows",
+                  inputs=(bits(q), bits(k), bits(v)), rows=rows, causal=True)
 
 
 @pytest.mark.parametrize("shape", [(1, 2, 256, 100, False), (1, 2, 512, 1000, False), (2, 2, 1100, 777, False), (1, 3, 1280, 1100, True),
@@ -201,7 +240,7 @@ def test_w64_ragged_shapes(shape):
     assert umfa_torch.last_kernel().startswith("fa_fwd16_w64"), umfa_torch.last_kernel()
     ref, ref_lse = _oracle().sdpa_forward(npy(q), npy(k), npy(v), causal=causal, return_lse=True)
     assert np.isfinite(o.cpu().numpy()).all()
-    check_forward(o.cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel())
+    check_forward(o.cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel(), inputs=(npy(q), npy(k), npy(v)), causal=causal)
     assert np.abs(lse.cpu().numpy().reshape(ref_lse.shape) - ref_lse).max() < 2e-2
     assert torch.equal(o, umfa_torch.attention_forward(q, k, v, causal=causal, out_dtype=torch.float32))
 

@@ -1,19 +1,25 @@
-"""Forward parity bounds of the 16-bit kernels, and the recorder that produced them.
+"""Forward parity bounds of the 16-bit kernels -- derived from the operand FORMAT, not fitted to a kernel.
 
 Metric: max = max|O - O_ref| / max|O_ref|, rms = rms(O - O_ref) / rms(O_ref), O_ref = the fp64
 CPU oracle on the already rounded inputs, fp32 O at the ABI.
 
-Where the numbers come from: every bound is the largest value any GPU test measured on MI355X
-(profiles/r2/parity_measured.json, written by running the suite with UMFA_PARITY_RECORD=<file>) plus 25 %.
-What fixes them (tools/err_probe.py, profiles/r2/error_anatomy.md):
-  * fp16: P is rounded to 11 significant bits before P V: max <= 5e-4 -- inside the north-star's 1e-3 at every shape.
-  * bf16: P is rounded to 8 significant bits; an IDEAL flash kernel (exact fp64 everything, P rounded once to bf16:
-    oracle.flash_format_floor) already sits at max 0.8e-3 (S = 256) ... 1.6e-3 (S >= 4096), rms 1.45 ... 1.6e-3.  The
-    kernels whose reference max is the exact running max (fa_fwd16; fa_fwd16_w64 with UMFA_W64_TAU=0) measure AT that
-    floor.  The north-star's 1e-3 is therefore met by bf16 only at short key ranges; the format, not the kernel, decides.
-  * bf16 / fp16 with the deferred max of fa_fwd16_w64 (tau = 6, +38 % speed at the FLUX shape): rms +7...10 %, and a tail
-    in max on rows with one dominant key -- with an exact reference max that key's P is exactly 1.0 and carries no
-    rounding error, with a stale reference it carries the ordinary half-ulp (measured up to 3.5e-3 bf16, 4.1e-4 fp16).
+Two assertions, both independent of what any kernel measured last week:
+
+1. FLOOR-RELATIVE (whenever the call site hands over the inputs).  `oracle.flash_format_floor` is what an IDEAL flash
+   kernel gives on the same rows: exact fp64 scores, exponentials and sums, P rounded ONCE to the operand type because
+   the P V MFMA takes nothing wider.  Its distance from the oracle is the part of the error the format fixes
+   (profiles/r2/error_anatomy.md: bf16 0.8e-3 (S = 256) ... 1.6e-3 (S >= 4096) max, ~1.5e-3 rms; fp16 8x smaller).
+   A kernel is held to a multiple of THAT, on the same rows:
+     exact running max (fa_fwd16; fa_fwd16_w64 with softmax_reference = exact)      max <= 1.15 x floor, rms <= 1.05 x floor
+     stale reference (fa_fwd16_w64 lazy / deferred max: a row's largest P is no      max <= 2.5 x floor,  rms <= 1.15 x floor
+       longer exactly 1.0, so the dominant key takes the ordinary half-ulp too)
+   The rms bound is the sharp one: a kernel that got 15 % worse everywhere fails it in every regime.
+2. FORMAT CEILING (every call, also without inputs: masks, windows, fuzz shapes): max <= one ulp of P at 1.0
+   (2^-8 bf16, 2^-11 fp16), rms <= half of it.  The reference's own tolerances are 1e-2 (bf16) / 1e-3 (fp16)
+   (examples/pytorch-custom-op-ffi/tests/conftest.py:186-199).
+
+fp16 additionally meets the north-star's 1e-3 everywhere (asserted); bf16 cannot -- its floor is above 1e-3 from
+S ~ 1024 on -- and is held to the floor instead.
 """
 from __future__ import annotations
 
@@ -22,14 +28,14 @@ import os
 
 import numpy as np
 
-# (dtype name, deferred max?) -> (max bound, rms bound)
-BOUNDS = {                          # largest measured (suite + tools/err_probe.py)  -> + 25 %
-    ("fp16", False): (2.2e-4, 2.3e-4),  # 1.69e-4 / 1.79e-4
-    ("fp16", True): (5.2e-4, 2.6e-4),   # 4.1e-4 (B1 H256 S256 whole tensor) / 2.06e-4
-    ("bf16", False): (2.15e-3, 1.95e-3),  # 1.70e-3 / 1.54e-3
-    ("bf16", True): (4.4e-3, 2.1e-3),   # 3.5e-3 (B1 H64 S1024 whole tensor) / 1.67e-3
-}
+ULP_AT_ONE = {"bf16": 2.0 ** -8, "fp16": 2.0 ** -11}
+# regime -> (multiple of the floor's max, multiple of the floor's rms)
+FLOOR_MULT = {"exact": (1.15, 1.05), "stale": (2.5, 1.15)}  # measured worst (profiles/r3/parity_record.jsonl): 1.00 / 1.00 and 1.38 / 1.09
 NORTH_STAR = 1.0e-3
+MAX_FLOOR_ROWS = 64  # the floor emulation holds [B, H, rows, Skv] in fp64
+# the MAX of a few thousand elements is a noisy statistic (kernel and ideal kernel round different P at the binade
+# edges); below this many compared elements the max multiple is widened by SMALL_SAMPLE_SLACK, the rms multiple is not
+SMALL_SAMPLE, SMALL_SAMPLE_SLACK = 1 << 17, 1.25  # measured worst small-sample max ratio: 1.08 (exact), 1.19 (stale)
 
 
 def _name(dt) -> str:
@@ -52,28 +58,66 @@ def record(tag: str, **vals) -> None:
             f.write(json.dumps({"tag": tag, "test": os.environ.get("PYTEST_CURRENT_TEST", ""), **vals}) + "\n")
 
 
+def regime_of(kernel: str) -> str:
+    """"exact": the kernel's softmax reference is the exact running max; "stale": fa_fwd16_w64 in its lazy / deferred modes."""
+    if not kernel.startswith("fa_fwd16_w64"):
+        return "exact"
+    try:
+        from umfa_torch import ops
+        mode = ops._option_state.get("softmax_reference", "default")
+        tau = float(ops._option_state.get("softmax_tau", "6"))
+    except Exception:  # noqa: BLE001  (callers that only use the ctypes package: library defaults)
+        mode, tau = "default", 6.0
+    return "exact" if mode == "exact" or (mode == "deferred" and tau == 0.0) else "stale"
+
+
 # a 16-bit OUTPUT (fused cast-back epilogue) adds one rounding of O itself: at most half an ulp of the value (2^-8 of it
 # for bf16, 2^-11 for fp16) in max, about 0.41 of that in rms (uniform error, values log-uniform inside a binade)
 OUT_HALF_ULP = {"bf16": 2.0 ** -8, "fp16": 2.0 ** -11}
 
 
 def check_forward(o, ref, dt, kernel: str, tag: str = "", scale_max: float = 1.0, min_elems_for_rms: int = 4096,
-                  out_dt=None):
-    """Assert the forward parity bounds for one output against the oracle.  kernel: umfa_torch.last_kernel() /
-    ctx.last_kernel; scale_max loosens the max bound for deliberately hostile inputs (stated at the call site);
-    out_dt: the element type O was stored in when it is not fp32."""
+                  out_dt=None, inputs=None, rows=None, causal: bool = False, scale=None):
+    """Assert the forward parity bounds for one output against the oracle.
+
+    o, ref: [B, H, R, D] (R = all query rows, or the subset `rows` of them).  kernel: umfa_torch.last_kernel() /
+    ctx.last_kernel.  inputs = (q, k, v) as the oracle takes them (bf16 as uint16 bits): enables the floor-relative
+    assertion on (a spread of <= 64 of) the same rows; rows / causal / scale describe them.  scale_max loosens the max
+    bounds for deliberately hostile inputs (stated at the call site); out_dt: the element type O was stored in when it is
+    not fp32."""
     name = _name(dt)
-    deferred = kernel.startswith("fa_fwd16_w64") and float(os.environ.get("UMFA_W64_TAU", "6") or 6) > 0
+    regime = regime_of(kernel)
     mx, rms = errors(o, ref)
-    bmax, brms = BOUNDS[(name, deferred)]
+    cmax, crms = ULP_AT_ONE[name], 0.5 * ULP_AT_ONE[name]
     if out_dt is not None and _name(out_dt) in OUT_HALF_ULP:
-        h = OUT_HALF_ULP[_name(out_dt)]  # measured with bf16 O: max 2.07e-3 (exact max) / 3.34e-3 (deferred), rms 2.0e-3 / 2.35e-3
-        bmax, brms = float(np.hypot(bmax, 0.5 * h)), float(np.hypot(brms, 0.5 * h))
-    record(tag or kernel, dtype=name, kernel=kernel, deferred=deferred, out=_name(out_dt) if out_dt is not None else "fp32",
-           max=mx, rms=rms, bound_max=bmax * scale_max, bound_rms=brms * scale_max, n=int(np.asarray(ref).size))
-    assert mx < bmax * scale_max, (tag, kernel, "max", mx, bmax * scale_max)
+        h = OUT_HALF_ULP[_name(out_dt)]
+        cmax, crms = float(np.hypot(cmax, 0.5 * h)), float(np.hypot(crms, 0.5 * h))
+    rec = dict(dtype=name, kernel=kernel, regime=regime, out=_name(out_dt) if out_dt is not None else "fp32", max=mx, rms=rms,
+               ceiling_max=cmax * scale_max, ceiling_rms=crms * scale_max, n=int(np.asarray(ref).size))
+    fl = None
+    if inputs is not None and out_dt is None:
+        from oracle import oracle
+        qb, kb, vb = inputs
+        R = np.asarray(ref).shape[2]
+        grows = np.arange(R) if rows is None else np.asarray(rows)
+        pos = np.unique(np.linspace(0, R - 1, min(R, MAX_FLOOR_ROWS)).astype(np.int64))
+        floor_o = oracle.flash_format_floor(qb, kb, vb, grows[pos], name, scale=scale, causal=causal)
+        fmax, frms = errors(floor_o, np.asarray(ref)[:, :, pos])
+        kmax, krms = errors(np.asarray(o)[:, :, pos], np.asarray(ref)[:, :, pos])
+        fl = (fmax, frms, kmax, krms)
+        rec.update(floor_max=fmax, floor_rms=frms, max_on_floor_rows=kmax, rms_on_floor_rows=krms)
+    record(tag or kernel, **rec)
+    assert mx < cmax * scale_max, (tag, kernel, "format ceiling, max", mx, cmax * scale_max)
     if name == "fp16" and scale_max == 1.0:
         assert mx <= NORTH_STAR, (tag, kernel, "north-star 1e-3", mx)  # fp16 meets the stated tolerance everywhere
     if np.asarray(ref).size >= min_elems_for_rms:
-        assert rms < brms * scale_max, (tag, kernel, "rms", rms, brms * scale_max)
+        assert rms < crms * scale_max, (tag, kernel, "format ceiling, rms", rms, crms * scale_max)
+    if fl is not None:
+        fmax, frms, kmax, krms = fl
+        mmax, mrms = FLOOR_MULT[regime]
+        if np.asarray(ref)[:, :, :MAX_FLOOR_ROWS].size < SMALL_SAMPLE:
+            mmax *= SMALL_SAMPLE_SLACK
+        assert kmax <= mmax * scale_max * fmax, (tag, kernel, regime, "max vs format floor", kmax, fmax, mmax * scale_max)
+        if np.asarray(ref)[:, :, :MAX_FLOOR_ROWS].size >= min_elems_for_rms:
+            assert krms <= mrms * scale_max * frms, (tag, kernel, regime, "rms vs format floor", krms, frms, mrms * scale_max)
     return mx, rms

@@ -53,7 +53,10 @@ class Cfg:
         # row sums on the matrix pipe (16-bit P kernels): l += sum of the ROUNDED P fragment by v_mfma_f32_4x4x4_16b against an
         # all-ones operand (a lane-local sum: block b = lane / 4, column j = lane % 4 -> the lane's own four values; 8-cycle
         # instruction).  16 of them per tile replace 64 v_add_f32, and l is the sum of exactly the values P V consumes.
-        self.msum = (not f8) and os.environ.get("W64_MSUM", "1") == "1"
+        # OFF by default (lab option W64_MSUM=1 with -DW64_MSUM_ON=1): same-box A/B, every shape slower than the v_add form
+        # (FLUX -3.5 %, B4 H16 S8192 causal -3.8 %, int8 -1 %): alternating with 32x32x16 MFMAs a 4x4x4 costs the matrix
+        # pipe 16 cycles, 256 per tile, and the loop is not VALU-issue bound enough to win them back (profiles/r3/lab_notes.md).
+        self.msum = (not f8) and os.environ.get("W64_MSUM", "0") == "1"
         self.NQK = 16 if i8 else 32      # MFMAs of the QK^T phase = first gap index of the PV phase
         self.KS = 4 if i8 else 8         # k-steps per 32-key block
         self.HALF = self.NQK // 2        # QK^T MFMAs per key block

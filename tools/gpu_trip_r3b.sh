@@ -13,5 +13,5 @@ $AB --shape 1,16,8192,128 $LIBS > $O/ab_s8192.json 2>>$O/ab_err.txt
 $AB --shape 4,16,8192,128 --causal --rounds 6 --inner 5 $LIBS > $O/ab_causal.json 2>>$O/ab_err.txt
 $AB --causal $LIBS > $O/ab_flux_causal.json 2>>$O/ab_err.txt
 cat $O/ab_*.json
-timeout 600 python tools/lab/settle_probe.py > $O/settle.json 2>$O/settle_err.txt
-cat $O/settle.json
+true
+

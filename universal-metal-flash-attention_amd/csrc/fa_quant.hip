@@ -59,6 +59,20 @@ __device__ __forceinline__ int v8_off(int kk, int d) {
     return (d >> 5) * 2048 + (kk >> 5) * 1024 + (32 * h + (d & 31)) * 16 + b;
 }
 
+// a / b for a divisor b whose refined reciprocal r1 = fma(fma(-b, rcp(b), 1), rcp(b), rcp(b)) the caller holds: the
+// numerator half of the AMDGPU fp32 division (LLVM LowerFDIV32: div_scale, rcp, fma x2 | mul, fma x3, div_fmas, div_fixup)
+// with the scale steps left out.  Those steps are the identity when b is in [2^-60, 2^60] and |a| >= 2^-103 (then no
+// operand or quotient is near the denormal range and the exponents are < 96 apart: v_div_scale passes a and b through,
+// v_div_fmas is a plain fma, v_div_fixup returns its first operand), so the quotient is bit-identical to `a / b`.  Smaller
+// |a| give |a / b| < 2^-43 in either form: the same integer 0 after rounding, which is all the quantiser keeps.
+__device__ __forceinline__ float div_by_block_scale(float a, float b, float r1) {
+    const float q0 = a * r1;
+    const float e1 = __builtin_fmaf(-b, q0, a);
+    const float q1 = __builtin_fmaf(e1, r1, q0);
+    const float e2 = __builtin_fmaf(-b, q1, a);
+    return __builtin_fmaf(e2, r1, q1);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256) void quantize_kernel(QuantParams p) {
     __shared__ float red[4];
@@ -153,20 +167,23 @@ __global__ __launch_bounds__(256) void quantize_kernel(QuantParams p) {
         return;
     }
     const int64_t orow0 = (int64_t)bh * p.rows[t] + row0;
+    // x / sc with ONE divisor for the whole block: the divisor's half of the IEEE division (reciprocal + one Newton step)
+    // is taken once, each element pays the numerator's half only (div_by_block_scale): the same operations in the same
+    // order as hipcc's correctly rounded fp32 divide, so the integers stay bit-exact with the oracle
+    // (tests/test_gpu_quantized.py checks them).  Outside the exponent range where that divide would not rescale its
+    // operands the plain divide runs (uniform per block).
+    const float rcp0 = __builtin_amdgcn_rcpf(sc);
+    const float rcp1 = __builtin_fmaf(__builtin_fmaf(-sc, rcp0, 1.0f), rcp0, rcp0);
+    const bool fast_div = sc >= 0x1p-60f && sc <= 0x1p60f;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
         const uint32_t ch = tid + 256 * c;
         if (ch < nchunks) {
             const uint32_t r = ch / cpr, d0 = (ch % cpr) * 8;
-            // IEEE divide + round-half-away: bit-exact with the oracle (tests/test_gpu_quantized.py checks the integers).
-            // (A reciprocal-multiply fast path with an exact fallback near rounding boundaries measured slower twice: per
-            // element 49 vs 41 us at the FLUX shape, per 8-element chunk with a wave ballot 44.5 vs 40.8; a plain
-            // multiply -- not bit-exact -- would be 32 us: the divide is ~7 of the ~13 VALU instructions per element and
-            // the boundary test puts them back.)
             int q[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                int qv = (int)roundf(x[c][j] / sc);
+                int qv = (int)roundf(fast_div ? div_by_block_scale(x[c][j], sc, rcp1) : x[c][j] / sc);
                 q[j] = qv < p.qlo ? p.qlo : (qv > p.qhi ? p.qhi : qv);
             }
             if (t < 2) {
