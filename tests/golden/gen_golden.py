@@ -162,5 +162,53 @@ def main() -> None:
     print(f"wrote {len(list(HERE.glob('*.npz')))} fixture files, {total/1e6:.2f} MB")
 
 
+def rotations() -> None:
+    """Fixtures of the two rotations beside the attention path.
+
+    RoPE: the reference's executable eager spec, `apply_rope_eager_bhsd`
+    (examples/pytorch-custom-op-ffi/src/metal_sdpa_backend.cpp:1451-1468), restated here line by line in torch: fp32 math,
+    interleaved pairs, out = x * cos + stack(-x_imag, x_real) * sin, cast back to x's dtype; pair-duplicated tables,
+    [S, D] and [B, S, D].
+    Hadamard: the contract of `mfa_hadamard_rotate` is "group-wise FWHT, normalised by 1/sqrt(N), double application =
+    identity" (Sources/MFABridge/MFABridge.swift:3433-3459, AGENTS.md:161-170); the matrix itself lives in the absent
+    submodule.  The fixture is y = H_N x / sqrt(N) with H_N from `scipy.linalg.hadamard` -- an INDEPENDENT Sylvester
+    (natural-order) construction, explicit matrix product in fp64 -- so the oracle's butterfly and the HIP kernel are pinned
+    to something neither of them computed.  (Natural vs sequency ordering cannot be recovered from the reference; natural
+    is the ordering a plain FWHT butterfly produces and the one this fixture fixes.)"""
+    import scipy.linalg
+    out = {}
+    for dt, name in [(torch.float32, "fp32"), (torch.float16, "fp16"), (torch.bfloat16, "bf16")]:
+        for batched in (False, True):
+            torch.manual_seed(123)
+            b, h, s, d = 2, 3, 37, 64
+            x = torch.randn(b, h, s, d).to(dt)
+            ang = torch.rand((b, s, d // 2) if batched else (s, d // 2)) * 6.2831853
+            cos_t = torch.repeat_interleave(torch.cos(ang), 2, dim=-1)
+            sin_t = torch.repeat_interleave(torch.sin(ang), 2, dim=-1)
+            cos_b = (cos_t.unsqueeze(0) if cos_t.dim() == 2 else cos_t).unsqueeze(1)
+            sin_b = (sin_t.unsqueeze(0) if sin_t.dim() == 2 else sin_t).unsqueeze(1)
+            xf = x.float()
+            pairs = xf.reshape(b, h, s, d // 2, 2)
+            rotated = torch.stack((-pairs[..., 1], pairs[..., 0]), -1).reshape(b, h, s, d)
+            y = (xf * cos_b + rotated * sin_b).to(dt)
+            tag = f"{name}_{'bsd' if batched else 'sd'}"
+            out[f"x_{tag}"], out[f"cos_{tag}"], out[f"sin_{tag}"], out[f"y_{tag}"] = store_bits(x), cos_t.numpy(), sin_t.numpy(), store_bits(y)
+            out[f"y32_{tag}"] = (xf * cos_b + rotated * sin_b).numpy()  # before the cast back
+    np.savez_compressed(HERE / "rope.npz", **out)
+    out = {}
+    rng = np.random.default_rng(2024)
+    for n in (2, 16, 64, 256):
+        x = rng.standard_normal(3 * n).astype(np.float32)
+        hm = scipy.linalg.hadamard(n).astype(np.float64) / np.sqrt(n)
+        out[f"x_{n}"] = x
+        out[f"y_{n}"] = (x.astype(np.float64).reshape(3, n) @ hm.T).reshape(-1)
+    np.savez_compressed(HERE / "hadamard.npz", **out)
+    print("wrote rope.npz, hadamard.npz")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "rotations":
+        rotations()  # (only the two files above: the SDPA fixtures stay byte-identical)
+    else:
+        main()
+        rotations()

@@ -66,3 +66,32 @@ def test_hadamard_matches_oracle_and_is_involution(dt, block):
     assert abs(float(y.float().norm()) / float(x.float().norm()) - 1.0) < 2e-3
     with pytest.raises(RuntimeError):
         umfa_torch.hadamard_rotate(torch.zeros(10, device="cuda"), 4)
+
+
+@pytest.mark.parametrize("name", ["fp32", "fp16", "bf16"])
+@pytest.mark.parametrize("lay", ["sd", "bsd"])
+def test_rope_kernel_matches_the_reference_eager_spec_fixture(golden_dir, name, lay):
+    """the HIP rotation against tests/golden/rope.npz (the reference's eager spec, metal_sdpa_backend.cpp:1451-1468)"""
+    import umfa_torch
+    g = np.load(golden_dir / "rope.npz")
+    tag = f"{name}_{lay}"
+    dt = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[name]
+    xb = g[f"x_{tag}"]
+    x = (torch.from_numpy(xb.view(np.int16)).view(torch.bfloat16) if name == "bf16" else torch.from_numpy(xb)).cuda()
+    cos, sin = torch.from_numpy(g[f"cos_{tag}"]).cuda(), torch.from_numpy(g[f"sin_{tag}"]).cuda()
+    y = umfa_torch.rope_rotate(x, cos, sin)
+    assert y.dtype == dt
+    wb = g[f"y_{tag}"]
+    want = torch.from_numpy(wb.view(np.int16)).view(torch.bfloat16) if name == "bf16" else torch.from_numpy(wb)
+    diff = (y.float().cpu() - want.float()).abs()
+    tol = {"fp32": 2e-6, "fp16": 2e-3, "bf16": 1.6e-2}[name]  # one ulp of the type at the largest value (ties may round either way)
+    assert float(diff.max()) <= tol * max(1.0, float(want.float().abs().max()))
+    assert float((diff > 0).float().mean()) < 2e-3  # and almost every element is the spec's exact bits
+
+
+@pytest.mark.parametrize("n", [16, 64, 256])
+def test_hadamard_kernel_matches_the_sylvester_fixture(golden_dir, n):
+    import umfa_torch
+    g = np.load(golden_dir / "hadamard.npz")
+    y = umfa_torch.hadamard_rotate(torch.from_numpy(g[f"x_{n}"]).cuda(), n)
+    assert np.abs(y.cpu().numpy() - g[f"y_{n}"]).max() < 2e-5

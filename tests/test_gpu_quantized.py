@@ -87,6 +87,7 @@ def test_quantized_backward_vs_oracle(ctx):
     for b in bufs:
         b.close()
     assert rc == 0
+    assert ctx.last_kernel.startswith("fa_bwd16<fp16"), ctx.last_kernel  # the 16-bit MFMA backward on fp16 de-quantised operands
     # oracle: de-quantise with the same formula, then the fp64 backward
     def fake(x):
         out = np.empty_like(x)

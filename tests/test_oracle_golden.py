@@ -151,3 +151,35 @@ def test_rope_and_hadamard_oracle_identities():
     assert np.allclose(h, [0.5, 0.5, 0.5, 0.5])
     v = rng.standard_normal(64).astype(np.float32)
     assert np.abs(oracle.hadamard(oracle.hadamard(v, 16).astype(np.float32), 16) - v).max() < 1e-6
+
+
+def test_rope_oracle_matches_the_reference_eager_spec(golden_dir):
+    """oracle.rope_rotate against fixtures computed by the reference's executable eager spec restated in torch
+    (metal_sdpa_backend.cpp:1451-1468; tests/golden/gen_golden.py rotations): fp32 image within fp32 rounding of the
+    spec's fp32 value, and -- rounded to the tensor's type -- the spec's own output bits for all but rounding ties."""
+    g = np.load(golden_dir / "rope.npz")
+    for name in ("fp32", "fp16", "bf16"):
+        for lay in ("sd", "bsd"):
+            tag = f"{name}_{lay}"
+            x, cos, sin = g[f"x_{tag}"], g[f"cos_{tag}"], g[f"sin_{tag}"]
+            y = oracle.rope_rotate(x, cos, sin)
+            assert np.abs(y - g[f"y32_{tag}"]).max() < 2e-6 * max(1.0, np.abs(g[f"y32_{tag}"]).max()), tag
+            if name == "fp16":
+                got = y.astype(np.float16)
+                want = g[f"y_{tag}"]
+                assert (got != want).mean() < 1e-3 and np.abs(got.astype(np.float32) - want.astype(np.float32)).max() < 4e-3
+            elif name == "bf16":
+                got = oracle.f32_to_bf16_bits(y)
+                assert (got != g[f"y_{tag}"]).mean() < 1e-3
+            # inverse rotation (negate_sin): the gradient path of the reference's autograd wrapper
+            back = oracle.rope_rotate(y.astype(np.float32), cos, sin, negate_sin=True)
+            assert np.abs(back - oracle.to_f32(x)).max() < 1e-5 * max(1.0, np.abs(oracle.to_f32(x)).max())
+
+
+def test_hadamard_oracle_matches_an_independent_sylvester_matrix(golden_dir):
+    """oracle.hadamard (a butterfly) against y = H x / sqrt(N) with H from scipy.linalg.hadamard, computed as an explicit
+    matrix product when the fixture was made: ordering (natural) and normalisation pinned by something the oracle did not compute"""
+    g = np.load(golden_dir / "hadamard.npz")
+    for n in (2, 16, 64, 256):
+        y = oracle.hadamard(g[f"x_{n}"], n)
+        assert np.abs(y - g[f"y_{n}"]).max() < 1e-6, n

@@ -123,7 +123,9 @@ def qk_mfma(R, kb, ks, qb):
     if ks == 0 and C.f8:
         return f'asm volatile(W64_MFMA_QK " {t}, %0, %1, v[{F8_BIAS}:{F8_BIAS + 15}]" :: "v"(kf[{kb}][{ks}]), "{QF_CLASS}"(qf[{qb}][{ks}]));'
     if ks == 0 and C.i8 and not C.i2f:
-        return f'asm volatile(W64_MFMA_QK " {t}, %0, %1, %2" :: "v"(kf[{kb}][{ks}]), "{QF_CLASS}"(qf[{qb}][{ks}]), "v"(bias16));'
+        # literal bias tile (the kernel is compiled with amdgpu_num_vgpr(112)): as a compiler value hipcc parks it in AGPRs
+        # and copies it back with 16 v_accvgpr_read in front of EVERY tile as soon as anything else in the kernel changes
+        return f'asm volatile(W64_MFMA_QK " {t}, %0, %1, v[{I8_BIAS}:{I8_BIAS + 15}]" :: "v"(kf[{kb}][{ks}]), "{QF_CLASS}"(qf[{qb}][{ks}]));'
     return f'asm volatile(W64_MFMA_QK " {t}, %0, %1, {c}" :: "v"(kf[{kb}][{ks}]), "{QF_CLASS}"(qf[{qb}][{ks}]));'
 
 
@@ -144,6 +146,7 @@ def qk_mfma(R, kb, ks, qb):
 # msum kernels are compiled with amdgpu_num_vgpr(118): v[118:127] are asm-owned as well
 MS_L = 118       # v[118:121] / v[122:125]: row-sum accumulators of q-block 0 / 1 (four identical columns each)
 MS_ONES = 126    # v[126:127]: 1.0 in all four 16-bit k-slots, the A operand of the row-sum MFMA
+I8_BIAS = 112    # v[112:127] of fa_fwd_w64_i8 (amdgpu_num_vgpr(112)): the int8 score bias tile (1.5 * 2^23 in every element)
 F8_BIAS = 96     # v[96:111]  the int8 score bias tile (1.5 * 2^23 in every element)
 F8_ONES = 112    # v[112:119] fp8 1.0 in every k-slot: A operand of the row-sum MFMA
 F8_SONE = 120    # v120       E8M0 scale bytes of 1.0
@@ -854,6 +857,10 @@ def emit_helpers_f8(lines):
     a("    asm volatile(" + " ".join(f'"v_mov_b32 v{F8_BIAS + r}, 0x4b400000\\n\\t"' for r in range(16)) +
       " " + " ".join(f'"v_mov_b32 v{F8_ONES + r}, 0x38383838\\n\\t"' for r in range(8)) +
       f' "v_mov_b32 v{F8_SONE}, 0x7f7f7f7f\\n\\tv_mov_b32 v{F8_VSC}, 0x7f7f7f7f\\n\\ts_nop 1" ::: "memory");')
+    a("}")
+    a("// fa_fwd_w64_i8 (compiled with amdgpu_num_vgpr(112)): its literal bias tile")
+    a("__device__ __forceinline__ void i8_init_bias() {")
+    a("    asm volatile(" + " ".join(f'"v_mov_b32 v{I8_BIAS + r}, 0x4b400000\\n\\t"' for r in range(16)) + ' "s_nop 1" ::: "memory");')
     a("}")
     a("__device__ __forceinline__ void f8_set_vscale(unsigned e8) {")
     a(f'    asm volatile("v_mov_b32 v{F8_VSC}, %0\\n\\ts_nop 1" :: "s"(e8) : "memory");')

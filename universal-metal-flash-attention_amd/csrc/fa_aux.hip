@@ -145,8 +145,20 @@ hipError_t launch_hadamard(void* data, uint32_t block_size, uint32_t num_blocks,
 // x = (q - zero_point) * scale with one scale per tensor, or one per block of `block_size` consecutive rows of a
 // (batch, head) slab when block scales are given; INT4 = two values per byte, even index in the low nibble, stored
 // value + 8 (QuantizationTests.swift:72-128).  The source may hold fewer heads than the destination (grouped K/V).
+// dst16 != NULL: the result goes out as fp16 (operands of the 16-bit MFMA backward) and a value outside fp16's range raises
+// *overflow (the caller then repeats the call on the fp32 path)
+__device__ __forceinline__ void dequant_store(const DequantParams& p, int64_t i, float x, bool& ovf) {
+    if (p.dst16) {
+        ovf |= !(fabsf(x) <= 65504.0f);
+        ((_Float16*)p.dst16)[i] = (_Float16)x;
+    } else {
+        p.dst[i] = x;
+    }
+}
+
 __global__ __launch_bounds__(256) void dequant_kernel(DequantParams p) {
     const int64_t n = (int64_t)p.B * p.H_dst * p.S * p.D;
+    bool ovf = false;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const uint32_t d = (uint32_t)(i % p.D);
         const uint32_t s = (uint32_t)((i / p.D) % p.S);
@@ -162,7 +174,7 @@ __global__ __launch_bounds__(256) void dequant_kernel(DequantParams p) {
             const uint8_t byte = ((const uint8_t*)p.src)[e >> 1];
             x = (float)(int)((e & 1) ? (byte >> 4) : (byte & 15)) - 8.0f;
         } else {
-            p.dst[i] = load_as_float(p.src, e, p.prec);  // fp16 / bf16 / fp32 operands pass through
+            dequant_store(p, i, load_as_float(p.src, e, p.prec), ovf);  // fp16 / bf16 / fp32 operands pass through
             continue;
         }
         float sc = p.scale;
@@ -172,7 +184,41 @@ __global__ __launch_bounds__(256) void dequant_kernel(DequantParams p) {
             sc = p.block_scales[blk];
             zp = p.block_zero_points ? p.block_zero_points[blk] : 0;
         }
-        p.dst[i] = (x - (float)zp) * sc;
+        dequant_store(p, i, (x - (float)zp) * sc, ovf);
+    }
+    if (ovf && p.overflow) atomicOr(p.overflow, 1u);
+}
+
+// dense cast to fp16 (dO of the quantised backward entries: fp32 / bf16 at the ABI, fp16 for the MFMA backward)
+__global__ __launch_bounds__(256) void cast_f16_kernel(const void* src, int prec, _Float16* dst, int64_t n8, uint32_t* overflow) {
+    bool ovf = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        float x[8];
+        if (prec == P_FP32) {
+            const f32x4 lo = ((const f32x4*)src)[2 * i], hi = ((const f32x4*)src)[2 * i + 1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { x[j] = lo[j]; x[4 + j] = hi[j]; }
+        } else {
+            const s16x8 raw = ((const s16x8*)src)[i];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = bf16_bits_to_float((uint16_t)raw[j]);
+        }
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            ovf |= !(fabsf(x[j]) <= 65504.0f);
+            o[j] = (_Float16)x[j];
+        }
+        ((f16x8*)dst)[i] = o;
+    }
+    if (ovf && overflow) atomicOr(overflow, 1u);
+}
+
+// row constants of bwd16_dkdv from (LSE, D) when the dQ kernel that normally writes them ran in another call
+__global__ __launch_bounds__(256) void bwd16_rowc_kernel(const float* lse, const float* dvec, float* rowc, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        rowc[i] = -lse[i] * UMFA_LOG2E;
+        rowc[n + i] = -dvec[i];
     }
 }
 
@@ -190,8 +236,24 @@ __global__ __launch_bounds__(256) void group_sum_kernel(const float* src, float*
     }
 }
 
+hipError_t launch_cast_f16(const void* src, int prec, void* dst, int64_t n, uint32_t* overflow, hipStream_t stream) {
+    if (!src || !dst || (n & 7) || (prec != P_FP32 && prec != P_BF16)) return hipErrorInvalidValue;
+    if (n == 0) return hipSuccess;
+    const int64_t n8 = n / 8;
+    const unsigned grid = (unsigned)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(cast_f16_kernel, dim3(grid), dim3(256), 0, stream, src, prec, (_Float16*)dst, n8, overflow);
+    return hipGetLastError();
+}
+
+hipError_t launch_bwd16_rowc(const float* lse, const float* dvec, float* rowc, int64_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(bwd16_rowc_kernel, dim3(grid), dim3(256), 0, stream, lse, dvec, rowc, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_dequant(const DequantParams& p, hipStream_t stream) {
-    if (!p.src || !p.dst || p.H_src == 0 || p.H_dst % p.H_src) return hipErrorInvalidValue;
+    if (!p.src || (!p.dst && !p.dst16) || p.H_src == 0 || p.H_dst % p.H_src) return hipErrorInvalidValue;
     const int64_t n = (int64_t)p.B * p.H_dst * p.S * p.D;
     if (n == 0) return hipSuccess;
     const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);

@@ -1017,6 +1017,13 @@ static hipError_t launch_bwd16_t(const BwdParams& p, hipStream_t stream) {
     if (hipError_t e = ensure_dynamic_lds((const void*)bwd16_dkdv_kernel<T, CAUSAL, DP>, lds_kv); e != hipSuccess) return e;
     if (hipError_t e = ensure_dynamic_lds((const void*)bwd16_dq_kernel<T, CAUSAL, DP>, lds_dq); e != hipSuccess) return e;
     const uint32_t nqb = (p.Sq + 127) / 128, nkb = (p.Skv + 127) / 128;
+    // phases (the pre-quantised backward ABI computes dQ (+ D) and dK / dV in separate calls): bit 0 | bit 1 = the dQ kernel
+    // (it also writes D and the row constants), bit 2 = dK / dV -- alone, the row constants are rebuilt from the caller's
+    // (LSE, D) first
+    const int ph = p.phases ? p.phases : 7;
+    if (!(ph & 3)) {
+        if (hipError_t e = launch_bwd16_rowc(p.lse, p.dvec, p.rowc, rows, stream); e != hipSuccess) return e;
+    } else
     if constexpr (DP == 128) {
         // one-workgroup-per-CU kernel for non-causal launches (same box, ms per backward, v2 / two-per-CU: FLUX 0.678 / 0.693,
         // B2 H8 S2048 0.145 / 0.159, B8 H16 S1024 0.304 / 0.299); causal launches keep the two-per-CU kernel (FLUX causal
@@ -1033,6 +1040,7 @@ static hipError_t launch_bwd16_t(const BwdParams& p, hipStream_t stream) {
     } else {
         hipLaunchKernelGGL((bwd16_dq_kernel<T, CAUSAL, DP>), dim3(nqb * p.B * p.H), dim3(256), lds_dq, stream, p);
     }
+    if (!(ph & 4)) return hipGetLastError();
     uint32_t kv_grid = nkb * p.B * p.H;
     // measured equal to one workgroup per item (FLUX 0.654-0.657 vs 0.656-0.680 ms, B1 H16 S8192 1.625 vs 1.631): off unless asked for
     if (!CAUSAL && DP == 128 && tuning().bwd_persist.load(std::memory_order_relaxed)) {  // persistent: one workgroup per CU (see the kernel)

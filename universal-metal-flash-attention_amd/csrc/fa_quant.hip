@@ -36,6 +36,8 @@ struct QuantParams {
     uint8_t* v8;          // fp8 P V mode (quant_mode 3, D = 128): V as e4m3 [B*H][tile][8192] in MFMA operand order, else NULL
     uint32_t* v_e8;       // ... and the tile's power-of-two scale as an E8M0 byte replicated four times
     float* f32[3];        // optional fake-quantised fp32 copies (backward), [rows][D]
+    _Float16* f16[3];     // optional fake-quantised fp16 copies (MFMA backward), [rows][D]
+    uint32_t* overflow;   // with f16: set when q * scale does not fit fp16
     float* scale[3];      // per (bh, block)
     uint32_t rows[3];     // Sq, Skv, Skv
     uint32_t nblk[3];     // blocks per (b,h)
@@ -175,6 +177,7 @@ __global__ __launch_bounds__(256) void quantize_kernel(QuantParams p) {
     const float rcp0 = __builtin_amdgcn_rcpf(sc);
     const float rcp1 = __builtin_fmaf(__builtin_fmaf(-sc, rcp0, 1.0f), rcp0, rcp0);
     const bool fast_div = sc >= 0x1p-60f && sc <= 0x1p60f;
+    bool f16_ovf = false;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
         const uint32_t ch = tid + 256 * c;
@@ -201,6 +204,16 @@ __global__ __launch_bounds__(256) void quantize_kernel(QuantParams p) {
                 for (int j = 0; j < 8; ++j) hv[j] = (_Float16)((float)q[j] * sc);
                 *(f16x8*)(p.v16 + (orow0 + r) * p.DPQ + d0) = hv;
             }
+            if (p.f16[t]) {
+                f16x8 hv;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float y = (float)q[j] * sc;
+                    f16_ovf |= !(fabsf(y) <= 65504.0f);
+                    hv[j] = (_Float16)y;
+                }
+                *(f16x8*)(p.f16[t] + (orow0 + r) * p.D + d0) = hv;
+            }
             if (p.f32[t]) {
                 float* f = p.f32[t] + (orow0 + r) * p.D + d0;
                 *(f32x4*)f = f32x4{(float)q[0] * sc, (float)q[1] * sc, (float)q[2] * sc, (float)q[3] * sc};
@@ -208,6 +221,7 @@ __global__ __launch_bounds__(256) void quantize_kernel(QuantParams p) {
             }
         }
     }
+    if (f16_ovf && p.overflow) atomicOr(p.overflow, 1u);
     // zero the row padding of the images (head_dim below the padded 64 / 128 / 256)
     if (p.DPQ > p.D) {
         const uint32_t padc = (p.DPQ - p.D) / 8;
@@ -533,7 +547,8 @@ bool quantized_supported(uint32_t D) { return D >= 8 && D % 8 == 0 && D <= 256; 
 
 hipError_t launch_quantize(const void* q, const void* k, const void* v, int in_prec, uint32_t B, uint32_t H,
                            uint32_t Sq, uint32_t Skv, uint32_t D, int bits, int quant_mode, void* workspace,
-                           bool want_f32, QuantViews* views, hipStream_t stream) {
+                           int copies, QuantViews* views, hipStream_t stream, uint32_t* overflow) {
+    const bool want_f32 = copies != 0;  // the fp16 copies live in the (twice as large) fp32 regions
     const WsLayout w = ws_layout(B, H, Sq, Skv, D, want_f32);
     char* ws = (char*)workspace;
     QuantParams qp;
@@ -545,10 +560,15 @@ hipError_t launch_quantize(const void* q, const void* k, const void* v, int in_p
     qp.scale[0] = (float*)(ws + w.sq);
     qp.scale[1] = (float*)(ws + w.sk);
     qp.scale[2] = (float*)(ws + w.sv);
-    if (want_f32) {
+    if (copies == 1) {
         qp.f32[0] = (float*)(ws + w.f32q);
         qp.f32[1] = (float*)(ws + w.f32k);
         qp.f32[2] = (float*)(ws + w.f32v);
+    } else if (copies == 2) {
+        qp.f16[0] = (_Float16*)(ws + w.f32q);
+        qp.f16[1] = (_Float16*)(ws + w.f32k);
+        qp.f16[2] = (_Float16*)(ws + w.f32v);
+        qp.overflow = overflow;
     }
     qp.rows[0] = Sq; qp.rows[1] = Skv; qp.rows[2] = Skv;
     for (int t = 0; t < 3; ++t) qp.nblk[t] = (qp.rows[t] + QBLK - 1) / QBLK;
@@ -577,6 +597,7 @@ hipError_t launch_quantize(const void* q, const void* k, const void* v, int in_p
         views->v8 = qp.v8; views->v_e8 = qp.v_e8;
         views->q_scale = qp.scale[0]; views->k_scale = qp.scale[1]; views->v_scale = qp.scale[2];
         views->qf = qp.f32[0]; views->kf = qp.f32[1]; views->vf = qp.f32[2];
+        views->qh = qp.f16[0]; views->kh = qp.f16[1]; views->vh = qp.f16[2];
         views->nqblk = qp.nblk[0]; views->nkblk = qp.nblk[1]; views->dpq = qp.DPQ;
     }
     return hipGetLastError();
@@ -609,7 +630,7 @@ hipError_t launch_quantized_fwd(const FwdParams& fp, int bits, int quant_mode, v
     if (quant_mode == 3 && !(bits == 8 && fp.part_buf && fp.part_cnt && fwd_w64_i8_supported(fp))) quant_mode = 2;
     QuantViews v;
     hipError_t e = launch_quantize(fp.q, fp.k, fp.v, fp.in_prec, fp.B, fp.H, fp.Sq, fp.Skv, fp.D, bits, quant_mode,
-                                   workspace, false, &v, stream);
+                                   workspace, 0, &v, stream);
     if (e != hipSuccess) return e;
     I8FwdParams p;
     memset(&p, 0, sizeof(p));

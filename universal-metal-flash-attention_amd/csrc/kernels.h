@@ -77,6 +77,8 @@ hipError_t launch_hadamard(void* data, uint32_t block_size, uint32_t num_blocks,
 struct DequantParams {
     const void* src;
     float* dst;
+    void* dst16;                      // optional: fp16 output instead of dst (operands of the 16-bit MFMA backward)
+    uint32_t* overflow;               // with dst16: set to 1 when a value does not fit fp16
     const float* block_scales;        // optional, [B * H_src * ceil(S / block_size)]
     const int32_t* block_zero_points; // optional, same shape
     uint32_t B, H_src, H_dst, S, D, block_size;
@@ -86,6 +88,10 @@ struct DequantParams {
     int transposed;  // source slab stored [D, S]
 };
 hipError_t launch_dequant(const DequantParams& p, hipStream_t stream);
+// dense fp32 / bf16 -> fp16 (n % 8 == 0, 16-byte aligned); *overflow |= 1 when a value does not fit
+hipError_t launch_cast_f16(const void* src, int prec, void* dst, int64_t n, uint32_t* overflow, hipStream_t stream);
+// rowc[0 .. n) = -lse * log2 e, rowc[n .. 2n) = -dvec: what bwd16_dq leaves for bwd16_dkdv, for a dK / dV-only call
+hipError_t launch_bwd16_rowc(const float* lse, const float* dvec, float* rowc, int64_t n, hipStream_t stream);
 hipError_t launch_group_sum(const float* src, float* dst, uint32_t B, uint32_t H, uint32_t Hkv, int64_t slab, hipStream_t stream);
 
 // Runtime-quantised path (fa_quant.hip): fused symmetric quantiser for Q, K, V + int8-QK^T forward.
@@ -98,16 +104,21 @@ struct QuantViews {
     const float* q_scale;   // [B*H][nqblk]
     const float* k_scale;   // [B*H][nkblk]
     const float* v_scale;
-    const float* qf;        // optional fake-quantised fp32 copies [rows][D] (backward)
+    const float* qf;        // optional fake-quantised fp32 copies [rows][D] (backward, copies = 1)
     const float* kf;
     const float* vf;
+    const void* qh;         // optional fake-quantised fp16 copies [rows][D] (MFMA backward, copies = 2)
+    const void* kh;
+    const void* vh;
     uint32_t nqblk, nkblk, dpq;
 };
 bool quantized_supported(uint32_t D);
 size_t quant_workspace_bytes(uint32_t B, uint32_t H, uint32_t Sq, uint32_t Skv, uint32_t D, bool want_f32);
+// copies: 0 none, 1 fake-quantised fp32 copies (fp32-exact backward), 2 fp16 copies in the same workspace region (16-bit
+// MFMA backward; *overflow |= 1 when q * scale does not fit fp16)
 hipError_t launch_quantize(const void* q, const void* k, const void* v, int in_prec, uint32_t B, uint32_t H,
                            uint32_t Sq, uint32_t Skv, uint32_t D, int bits, int quant_mode, void* workspace,
-                           bool want_f32, QuantViews* views, hipStream_t stream);
+                           int copies, QuantViews* views, hipStream_t stream, uint32_t* overflow = nullptr);
 // fp.q/k/v: contiguous BHSD in fp.in_prec; fp.o fp32; fp.mask: fp32 additive [B,H,Sq,Skv] or NULL.
 hipError_t launch_quantized_fwd(const FwdParams& fp, int bits, int quant_mode, void* workspace, hipStream_t stream,
                                 const char** name);

@@ -223,6 +223,11 @@ mfa_error_t umfa_quantized_forward_stream(mfa_context_t context, void* stream, c
     return e == hipSuccess ? MFA_SUCCESS : e == hipErrorInvalidValue ? MFA_ERROR_INVALID_ARGS : MFA_ERROR_EXECUTION_FAILED;
 }
 
+// The 16-bit MFMA backward as the engine of the quantised backward entries: head_dim 64 / 128 / 256, no mask, not forced off
+static bool bwd16_shape_ok(uint32_t D, bool has_mask) {
+    return !has_mask && (D == 64 || D == 128 || D == 256) && !tuning().bwd_exact.load(std::memory_order_relaxed);
+}
+
 // Backward of the quantised forward: re-quantise Q, K, V deterministically (same kernels, same scales as the
 // forward), then the fp32 backward on the de-quantised operands -- the reference's "dequantise-on-load into FP32
 // tiles -> FP32 math" (AGENTS.md:143-152); gradients flow straight through the rounding (STE).
@@ -252,36 +257,67 @@ int32_t mfa_quantized_backward(mfa_context_t context, mfa_buffer_t q, mfa_buffer
     const int bits = target_precision == MFA_PRECISION_INT4 ? 4 : 8;
     const int mode = quant_mode == 2 ? 2 : 0;
 
-    // workspace: quantiser output + fp32 copies + the D vector the callee owns (MFABridge+Quantized.swift:470-474)
-    const size_t wq = quant_workspace_bytes(B, H, Sq, Skv, D, true);
-    char* ws = (char*)ctx->pool(pool_dev, stream).workspace.ensure(wq + nr * 4 + 256, stream);
-    if (!ws) return MFA_ERROR_MEMORY_ALLOCATION;
     for (Buffer* b : {bq, bk, bv, bo, bdo, bl})
         if (b->upload(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
     if (bm && bm->upload(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
-    LatencyScope lat(ctx, stream);
-    QuantViews views;
-    hipError_t e = launch_quantize(bq->dev, bk->dev, bv->dev, prec, B, H, Sq, Skv, D, bits, mode, ws, true, &views, stream);
-    if (e != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
-    BwdParams p;
-    memset(&p, 0, sizeof(p));
-    p.dout = bdo->dev; p.q = views.qf; p.k = views.kf; p.v = views.vf;
-    p.o = (const float*)bo->dev; p.lse = (const float*)bl->dev;
-    p.dq = (float*)bdq->dev; p.dk = (float*)bdk->dev; p.dv = (float*)bdv->dev;
-    p.dvec = (float*)(ws + ((wq + 255) & ~(size_t)255));
-    p.mask = bm ? (const float*)bm->dev : nullptr;
-    p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv; p.D = D;
-    p.scale = softmax_scale; p.causal = causal ? 1 : 0;
-    p.in_prec = P_FP32; p.dout_prec = prec;
-    const char* name = "none";
-    e = launch_bwd(p, stream, &name);
-    ctx->last_kernel = name;
-    if (e != hipSuccess) return e == hipErrorInvalidValue ? MFA_ERROR_INVALID_ARGS : MFA_ERROR_EXECUTION_FAILED;
-    lat.stop();
-    for (Buffer* b : {bdq, bdk, bdv})
-        if (b->download(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
-    if (hipStreamSynchronize(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
-    lat.publish();
+    // Two ways to run it.  FAST (head_dim 64 / 128 / 256, no mask): the de-quantised operands q * s go out of the quantiser
+    // as fp16 (a 7-bit integer times a scale: fp16 holds it to 2^-12; the forward's V image is the same thing), dO is cast
+    // to fp16, and the 16-bit MFMA backward runs (MFABridge+Quantized.swift:365-533 dispatches two kernels on quantised
+    // operands as well).  A value outside fp16's range raises a device flag, read after the call's synchronise: the call is
+    // then repeated on the EXACT path (fp32 copies -> fp32-exact backward), which is also what masks and other head dims take.
+    const bool try_fast = bwd16_shape_ok(D, bm != nullptr);
+    for (int attempt = try_fast ? 0 : 1; attempt < 2; ++attempt) {
+        const bool fast = attempt == 0;
+        // workspace: quantiser output + copies | D vector the callee owns (MFABridge+Quantized.swift:470-474) | fast: dO fp16, row constants, flag
+        const size_t wq = (quant_workspace_bytes(B, H, Sq, Skv, D, true) + 255) & ~(size_t)255;
+        const size_t o_dvec = wq, o_do16 = o_dvec + ((nr * 4 + 255) & ~(size_t)255), o_rowc = o_do16 + ((nq * 2 + 255) & ~(size_t)255),
+                     o_flag = o_rowc + ((2 * nr * 4 + 255) & ~(size_t)255);
+        char* ws = (char*)ctx->pool(pool_dev, stream).workspace.ensure((fast ? o_flag + 256 : o_do16) + 256, stream);
+        if (!ws) return MFA_ERROR_MEMORY_ALLOCATION;
+        uint32_t* flag = (uint32_t*)(ws + o_flag);
+        if (fast && hipMemsetAsync(flag, 0, 4, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+        LatencyScope lat(ctx, stream);
+        QuantViews views;
+        hipError_t e = launch_quantize(bq->dev, bk->dev, bv->dev, prec, B, H, Sq, Skv, D, bits, mode, ws, fast ? 2 : 1, &views, stream,
+                                       fast ? flag : nullptr);
+        if (e != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+        BwdParams p;
+        memset(&p, 0, sizeof(p));
+        p.o = (const float*)bo->dev; p.lse = (const float*)bl->dev;
+        p.dq = (float*)bdq->dev; p.dk = (float*)bdk->dev; p.dv = (float*)bdv->dev;
+        p.dvec = (float*)(ws + o_dvec);
+        p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv; p.D = D;
+        p.scale = softmax_scale; p.causal = causal ? 1 : 0;
+        const char* name = "none";
+        if (fast) {
+            p.q = views.qh; p.k = views.kh; p.v = views.vh;
+            p.in_prec = P_FP16; p.dout_prec = P_FP16;
+            p.dout = bdo->dev;
+            if (prec != P_FP16) {
+                if (launch_cast_f16(bdo->dev, prec, ws + o_do16, (int64_t)nq, flag, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+                p.dout = ws + o_do16;
+            }
+            p.rowc = (float*)(ws + o_rowc);
+            e = bwd_16_supported(p) ? launch_bwd_16(p, stream, &name) : hipErrorNotSupported;
+            if (e == hipErrorNotSupported) continue;  // (alignment of a wrapped caller buffer): the exact path
+        } else {
+            p.dout = bdo->dev; p.q = views.qf; p.k = views.kf; p.v = views.vf;
+            p.mask = bm ? (const float*)bm->dev : nullptr;
+            p.in_prec = P_FP32; p.dout_prec = prec;
+            e = launch_bwd(p, stream, &name);
+        }
+        ctx->last_kernel = name;
+        if (e != hipSuccess) return e == hipErrorInvalidValue ? MFA_ERROR_INVALID_ARGS : MFA_ERROR_EXECUTION_FAILED;
+        lat.stop();
+        uint32_t overflow = 0;
+        if (fast && hipMemcpyAsync(&overflow, flag, 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+        for (Buffer* b : {bdq, bdk, bdv})
+            if (b->download(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+        if (hipStreamSynchronize(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+        lat.publish();
+        if (!fast || !overflow) break;
+        DBG("quantised backward: an operand left fp16's range, repeating on the fp32-exact path");
+    }
     return MFA_SUCCESS;
 }
 
@@ -314,9 +350,10 @@ size_t quant_bytes(int prec, size_t n) {
 }
 int raw_prec(int32_t v) { return (v >= 0 && v <= 4) ? (int)v : P_FP16; }  // unknown raw value -> FP16 (:1796)
 
-// validates, uploads and de-quantises Q, K, V into ws = [Q fp32 | K fp32 (H heads) | V fp32 (H heads)]
+// validates, uploads and de-quantises Q, K, V into ws = [Q | K (H heads) | V (H heads)], fp32 -- or, `half` (operands of the
+// 16-bit MFMA backward), fp16 in the same slots with *overflow raised by values outside fp16's range
 mfa_error_t prequant_stage(Context* ctx, const PreQuant& a, float** qf, float** kf, float** vf, size_t extra_bytes,
-                           char** extra, hipStream_t stream) {
+                           char** extra, hipStream_t stream, bool half = false, size_t overflow_off = 0) {
     if (a.D == 0 || a.D > 256 || a.H == 0 || a.Hkv == 0 || a.H % a.Hkv) return MFA_ERROR_INVALID_ARGS;
     const size_t nq = (size_t)a.B * a.H * a.Sq * a.D, nkv_src = (size_t)a.B * a.Hkv * a.Skv * a.D;
     const size_t nkv = (size_t)a.B * a.H * a.Skv * a.D;
@@ -333,17 +370,21 @@ mfa_error_t prequant_stage(Context* ctx, const PreQuant& a, float** qf, float** 
     const size_t fbytes = ((nq + 2 * nkv) * 4 + 255) & ~(size_t)255;
     char* ws = (char*)ctx->pool(ctx->device, stream).workspace.ensure(fbytes + extra_bytes + 256, stream);  // synchronous entries only
     if (!ws) return MFA_ERROR_MEMORY_ALLOCATION;
+    const size_t esz = half ? 2 : 4;  // the slots keep their fp32 size: one workspace plan for both attempts
     *qf = (float*)ws;
-    *kf = *qf + nq;
-    *vf = *kf + nkv;
+    *kf = (float*)(ws + nq * esz);
+    *vf = (float*)(ws + (nq + nkv) * esz);
     *extra = ws + fbytes;
     for (Buffer* b : {a.q, a.k, a.v, a.qs, a.qz, a.ks, a.kz, a.vs, a.vz})
         if (b && b->upload(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+    if (half && hipMemsetAsync(*extra + overflow_off, 0, 4, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;  // the kernels below OR into it
     auto deq = [&](Buffer* src, float* dst, int prec, uint32_t hs, uint32_t S, float sc, int zp, Buffer* bsc, Buffer* bzp,
                    uint32_t bs, bool t) {
         DequantParams d;
         memset(&d, 0, sizeof(d));
-        d.src = src->dev; d.dst = dst;
+        d.src = src->dev; d.dst = half ? nullptr : dst;
+        d.dst16 = half ? (void*)dst : nullptr;
+        d.overflow = half ? (uint32_t*)(*extra + overflow_off) : nullptr;  // a word inside the caller's extra region
         d.block_scales = (bs && bsc) ? (const float*)bsc->dev : nullptr;
         d.block_zero_points = (bs && bsc && bzp) ? (const int32_t*)bzp->dev : nullptr;
         d.B = a.B; d.H_src = hs; d.H_dst = a.H; d.S = S; d.D = a.D; d.block_size = bs;
@@ -386,30 +427,52 @@ int32_t mfa_attention_backward_query_quantized_ex(
     if (!bo->fits(nq * 4) || !bdo->fits(nq * 4) || !bl->fits(nr * 4) || !bdq->fits(nq * 4) || !bd->fits(nr * 4))
         return MFA_ERROR_INVALID_ARGS;
     if (nq == 0 || a.Skv == 0) return MFA_SUCCESS;
-    float *qf, *kf, *vf;
-    char* extra;
-    LatencyScope lat(ctx, stream);
-    mfa_error_t st = prequant_stage(ctx, a, &qf, &kf, &vf, 0, &extra, stream);
-    if (st != MFA_SUCCESS) return st;
     for (Buffer* b : {bo, bdo, bl})
         if (b->upload(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
-    BwdParams p;
-    memset(&p, 0, sizeof(p));
-    p.dout = bdo->dev; p.q = qf; p.k = kf; p.v = vf;
-    p.o = (const float*)bo->dev; p.lse = (const float*)bl->dev;
-    p.dq = (float*)bdq->dev; p.dvec = (float*)bd->dev;
-    p.B = a.B; p.H = a.H; p.Sq = a.Sq; p.Skv = a.Skv; p.D = a.D;
-    p.scale = 1.0f / sqrtf((float)a.D); p.causal = causal ? 1 : 0;
-    p.in_prec = P_FP32; p.dout_prec = P_FP32;
-    p.phases = 1 | 2;  // D vector + dQ
-    const char* name = "none";
-    hipError_t e = launch_bwd(p, stream, &name);
-    ctx->last_kernel = name;
-    if (e != hipSuccess) return e == hipErrorInvalidValue ? MFA_ERROR_INVALID_ARGS : MFA_ERROR_EXECUTION_FAILED;
-    lat.stop();
-    if (bdq->download(stream) != hipSuccess || bd->download(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
-    if (hipStreamSynchronize(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
-    lat.publish();
+    // FAST: operands de-quantised to fp16, dO cast to fp16, the dQ kernel of the 16-bit MFMA backward (it also leaves D);
+    // a value outside fp16's range -> the flag -> the call is repeated on the EXACT (fp32) path.  See mfa_quantized_backward.
+    const bool try_fast = bwd16_shape_ok(a.D, false);
+    for (int attempt = try_fast ? 0 : 1; attempt < 2; ++attempt) {
+        const bool fast = attempt == 0;
+        const size_t o_do16 = 0, o_rowc = (nq * 2 + 255) & ~(size_t)255, o_flag = o_rowc + ((2 * nr * 4 + 255) & ~(size_t)255);
+        float *qf, *kf, *vf;
+        char* extra;
+        LatencyScope lat(ctx, stream);
+        mfa_error_t st = prequant_stage(ctx, a, &qf, &kf, &vf, fast ? o_flag + 256 : 0, &extra, stream, fast, o_flag);
+        if (st != MFA_SUCCESS) return st;
+        uint32_t* flag = (uint32_t*)(extra + o_flag);
+        BwdParams p;
+        memset(&p, 0, sizeof(p));
+        p.dout = bdo->dev; p.q = qf; p.k = kf; p.v = vf;
+        p.o = (const float*)bo->dev; p.lse = (const float*)bl->dev;
+        p.dq = (float*)bdq->dev; p.dvec = (float*)bd->dev;
+        p.B = a.B; p.H = a.H; p.Sq = a.Sq; p.Skv = a.Skv; p.D = a.D;
+        p.scale = 1.0f / sqrtf((float)a.D); p.causal = causal ? 1 : 0;
+        p.in_prec = P_FP32; p.dout_prec = P_FP32;
+        p.phases = 1 | 2;  // D vector + dQ
+        const char* name = "none";
+        hipError_t e;
+        if (fast) {
+            p.in_prec = P_FP16; p.dout_prec = P_FP16;
+            if (launch_cast_f16(bdo->dev, P_FP32, extra + o_do16, (int64_t)nq, flag, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+            p.dout = extra + o_do16;
+            p.rowc = (float*)(extra + o_rowc);
+            e = bwd_16_supported(p) ? launch_bwd_16(p, stream, &name) : hipErrorNotSupported;
+            if (e == hipErrorNotSupported) continue;
+        } else {
+            e = launch_bwd(p, stream, &name);
+        }
+        ctx->last_kernel = name;
+        if (e != hipSuccess) return e == hipErrorInvalidValue ? MFA_ERROR_INVALID_ARGS : MFA_ERROR_EXECUTION_FAILED;
+        lat.stop();
+        uint32_t overflow = 0;
+        if (fast && hipMemcpyAsync(&overflow, flag, 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+        if (bdq->download(stream) != hipSuccess || bd->download(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+        if (hipStreamSynchronize(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+        lat.publish();
+        if (!fast || !overflow) break;
+        DBG("pre-quantised backward (query): an operand left fp16's range, repeating on the fp32-exact path");
+    }
     return MFA_SUCCESS;
 }
 
@@ -442,37 +505,58 @@ int32_t mfa_attention_backward_kv_quantized_ex(
         return MFA_ERROR_INVALID_ARGS;
     if (nq == 0 || nkv_out == 0) return MFA_SUCCESS;
     const bool grouped = a.Hkv != a.H;
-    float *qf, *kf, *vf;
-    char* extra;
-    LatencyScope lat(ctx, stream);
-    mfa_error_t st = prequant_stage(ctx, a, &qf, &kf, &vf, grouped ? 2 * nkv * 4 : 0, &extra, stream);
-    if (st != MFA_SUCCESS) return st;
     for (Buffer* b : {bdo, bl, bd})
         if (b->upload(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
-    BwdParams p;
-    memset(&p, 0, sizeof(p));
-    p.dout = bdo->dev; p.q = qf; p.k = kf; p.v = vf;
-    p.lse = (const float*)bl->dev; p.dvec = (float*)bd->dev;
-    p.dk = grouped ? (float*)extra : (float*)bdk->dev;
-    p.dv = grouped ? (float*)extra + nkv : (float*)bdv->dev;
-    p.B = a.B; p.H = a.H; p.Sq = a.Sq; p.Skv = a.Skv; p.D = a.D;
-    p.scale = 1.0f / sqrtf((float)a.D); p.causal = causal ? 1 : 0;
-    p.in_prec = P_FP32; p.dout_prec = P_FP32;
-    p.phases = 4;  // dK / dV from the caller's D vector
-    const char* name = "none";
-    hipError_t e = launch_bwd(p, stream, &name);
-    ctx->last_kernel = name;
-    if (e != hipSuccess) return e == hipErrorInvalidValue ? MFA_ERROR_INVALID_ARGS : MFA_ERROR_EXECUTION_FAILED;
-    if (grouped) {
-        const int64_t slab = (int64_t)a.Skv * a.D;
-        if (launch_group_sum(p.dk, (float*)bdk->dev, a.B, a.H, a.Hkv, slab, stream) != hipSuccess ||
-            launch_group_sum(p.dv, (float*)bdv->dev, a.B, a.H, a.Hkv, slab, stream) != hipSuccess)
-            return MFA_ERROR_EXECUTION_FAILED;
+    const bool try_fast = bwd16_shape_ok(a.D, false);  // FAST / EXACT as in the query entry; the row constants come from (LSE, D)
+    for (int attempt = try_fast ? 0 : 1; attempt < 2; ++attempt) {
+        const bool fast = attempt == 0;
+        const size_t o_grp = 0, o_do16 = grouped ? ((2 * nkv * 4 + 255) & ~(size_t)255) : 0, o_rowc = o_do16 + ((nq * 2 + 255) & ~(size_t)255),
+                     o_flag = o_rowc + ((2 * nr * 4 + 255) & ~(size_t)255);
+        float *qf, *kf, *vf;
+        char* extra;
+        LatencyScope lat(ctx, stream);
+        mfa_error_t st = prequant_stage(ctx, a, &qf, &kf, &vf, fast ? o_flag + 256 : o_do16, &extra, stream, fast, o_flag);
+        if (st != MFA_SUCCESS) return st;
+        uint32_t* flag = (uint32_t*)(extra + o_flag);
+        BwdParams p;
+        memset(&p, 0, sizeof(p));
+        p.dout = bdo->dev; p.q = qf; p.k = kf; p.v = vf;
+        p.lse = (const float*)bl->dev; p.dvec = (float*)bd->dev;
+        p.dk = grouped ? (float*)(extra + o_grp) : (float*)bdk->dev;
+        p.dv = grouped ? (float*)(extra + o_grp) + nkv : (float*)bdv->dev;
+        p.B = a.B; p.H = a.H; p.Sq = a.Sq; p.Skv = a.Skv; p.D = a.D;
+        p.scale = 1.0f / sqrtf((float)a.D); p.causal = causal ? 1 : 0;
+        p.in_prec = P_FP32; p.dout_prec = P_FP32;
+        p.phases = 4;  // dK / dV from the caller's D vector
+        const char* name = "none";
+        hipError_t e;
+        if (fast) {
+            p.in_prec = P_FP16; p.dout_prec = P_FP16;
+            if (launch_cast_f16(bdo->dev, P_FP32, extra + o_do16, (int64_t)nq, flag, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+            p.dout = extra + o_do16;
+            p.rowc = (float*)(extra + o_rowc);
+            e = bwd_16_supported(p) ? launch_bwd_16(p, stream, &name) : hipErrorNotSupported;
+            if (e == hipErrorNotSupported) continue;
+        } else {
+            e = launch_bwd(p, stream, &name);
+        }
+        ctx->last_kernel = name;
+        if (e != hipSuccess) return e == hipErrorInvalidValue ? MFA_ERROR_INVALID_ARGS : MFA_ERROR_EXECUTION_FAILED;
+        if (grouped) {
+            const int64_t slab = (int64_t)a.Skv * a.D;
+            if (launch_group_sum(p.dk, (float*)bdk->dev, a.B, a.H, a.Hkv, slab, stream) != hipSuccess ||
+                launch_group_sum(p.dv, (float*)bdv->dev, a.B, a.H, a.Hkv, slab, stream) != hipSuccess)
+                return MFA_ERROR_EXECUTION_FAILED;
+        }
+        lat.stop();
+        uint32_t overflow = 0;
+        if (fast && hipMemcpyAsync(&overflow, flag, 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+        if (bdk->download(stream) != hipSuccess || bdv->download(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+        if (hipStreamSynchronize(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+        lat.publish();
+        if (!fast || !overflow) break;
+        DBG("pre-quantised backward (kv): an operand left fp16's range, repeating on the fp32-exact path");
     }
-    lat.stop();
-    if (bdk->download(stream) != hipSuccess || bdv->download(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
-    if (hipStreamSynchronize(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
-    lat.publish();
     return MFA_SUCCESS;
 }
 
