@@ -399,7 +399,6 @@ def run_rank(args) -> None:
                                                              "kernel": umfa_torch.last_kernel(), "flops": f2, "timer": GT}
         # the headline shape in the two regimes that meet / sit on the stated tolerance, beside the headline's (lazy reference):
         # exact running max (bf16 at its operand-format floor) and fp16 (inside 1e-3)
-        from oracle import oracle as _orc
         from oracle import parity as _par
 
         def _flux_regime(name, dt_, **opts):
@@ -443,6 +442,18 @@ def run_rank(args) -> None:
         configs["cfg5_shard_B1_H4_S32768_D128_bf16_fwd"] = {"ms": round(t5, 4), "tflops": round(f5 / t5 / 1e9, 1), "frac": round(f5 / t5 / 1e9 / PEAK_BF16_TFLOPS, 4),
                                                              "kernel": umfa_torch.last_kernel(), "flops": f5}
         del c5, o5
+        # config 4's quantised backward: quantiser + cast + the two 16-bit MFMA backward kernels on fp16 de-quantised operands
+        try:
+            q4, k4, v4, do4 = (torch.randn(1, 16, 8192, D, device=dev, dtype=torch.bfloat16) for _ in range(4))
+            o4, l4 = umfa_torch.quantized_attention_forward_stream(q4, k4, v4, return_lse=True)
+            tq = graph_ms(lambda: umfa_torch.quantized_attention_backward_stream(do4, q4, k4, v4, o4, l4), 10, warmup=2)
+            f4 = 2.5 * 4.0 * 16 * 8192 * 8192 * D
+            configs["cfg4_int8_bwd"] = {"ms": round(tq, 4), "tflops": round(f4 / tq / 1e9, 1), "frac": round(f4 / tq / 1e9 / PEAK_BF16_TFLOPS, 4),
+                                        "kernel": umfa_torch.last_kernel(), "flops": f4,
+                                        "note": "umfa_quantized_backward_stream, quantiser and dO cast inside; algorithmic 2.5 x forward FLOPs; round 2 ran this on the fp32-exact engine (42.5 ms)"}
+            del q4, k4, v4, do4, o4, l4
+        except Exception as exc:  # noqa: BLE001
+            configs["cfg4_int8_bwd"] = {"error": repr(exc)}
         extra["configs"] = configs
         try:
             extra["int8"] = bench_int8(torch, umfa_torch, event_ms, med)

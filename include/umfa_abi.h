@@ -368,6 +368,16 @@ mfa_error_t umfa_quantized_forward_stream(mfa_context_t context, void* stream, c
                                           float softmax_scale, bool causal, int32_t target_precision, int32_t quant_mode,
                                           int32_t input_precision);
 
+/* MI355X extra: mfa_quantized_backward in-stream (dense BHSD device pointers, caller's stream, never synchronises).
+ * Same engines as the blocking entry (16-bit MFMA backward on fp16 de-quantised operands at head_dim 64 / 128 / 256,
+ * else fp32-exact).  status: optional device uint32, zeroed on the stream and set to 1 when an operand left fp16's range
+ * (the gradients are then invalid: repeat through mfa_quantized_backward, which falls back by itself). */
+mfa_error_t umfa_quantized_backward_stream(mfa_context_t context, void* stream, const void* q, const void* k,
+                                           const void* v, const float* out, const void* dout, const float* lse, float* dq,
+                                           float* dk, float* dv, uint32_t* status, uint32_t batch_size, uint32_t seq_len_q,
+                                           uint32_t seq_len_kv, uint32_t num_heads, uint16_t head_dim, float softmax_scale,
+                                           bool causal, int32_t target_precision, int32_t quant_mode, int32_t input_precision);
+
 int32_t umfa_quantize_rows(mfa_context_t context, void* stream, const void* src, int32_t input_precision,
                            uint32_t batch_heads, uint32_t rows, uint32_t head_dim, int32_t bits, int32_t quant_mode,
                            void* q8_out, void* scales_out, uint32_t* padded_row_bytes);

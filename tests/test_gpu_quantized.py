@@ -218,3 +218,46 @@ def test_quantized_forward_stream_entry_matches_blocking(shape, causal, bits, mo
         b = umfa_torch.quantized_attention_forward_stream(q, k, v, mask=m, bits=bits, quant_mode=mode)
         torch.cuda.synchronize()
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("D,dt", [(128, "bf16"), (64, "fp16"), (80, "bf16")])
+def test_quantized_backward_stream_entry_matches_the_blocking_entry(ctx, D, dt):
+    """umfa_quantized_backward_stream (in-stream, raw device pointers) = mfa_quantized_backward's numbers: the 16-bit MFMA
+    engine at head_dim 64 / 128 (status stays 0), the fp32-exact engine at head_dim 80; and a V beyond fp16's range raises
+    the status word instead of returning wrong gradients silently."""
+    import ctypes
+    import torch
+    import umfa_torch
+    from umfa._ffi import _lib
+    from umfa_torch import ops
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float16
+    torch.manual_seed(13)
+    B, H, S = 1, 2, 256
+    q, k, v, do = (torch.randn(B, H, S, D, device="cuda", dtype=tdt) for _ in range(4))
+    o, lse = umfa_torch.quantized_attention_forward_stream(q, k, v, return_lse=True)
+    dq, dk, dv, status = umfa_torch.quantized_attention_backward_stream(do, q, k, v, o, lse)
+    torch.cuda.synchronize()
+    kern = umfa_torch.last_kernel()
+    assert kern.startswith("fa_bwd16<fp16") if D != 80 else kern.startswith("fa_bwd_exact"), kern
+    assert int(status.item()) == 0
+    # the blocking entry on the same device tensors (zero-copy wraps)
+    gq, gk, gv = (torch.zeros_like(t) for t in (dq, dk, dv))
+
+    def wrap(t):
+        from umfa import _ffi
+        h = _ffi.mfa_buffer_t()
+        _ffi._check_error(_lib.mfa_buffer_from_mtl_buffer(ops.context(), ctypes.c_void_p(t.data_ptr()), t.numel() * t.element_size(), ctypes.byref(h)))
+        return h
+    hs = [wrap(t) for t in (q, k, v, o, do, lse, gq, gk, gv)]
+    rc = _lib.mfa_quantized_backward(ops.context(), *hs, None, B, S, S, H, D, float(D) ** -0.5, False, 3, 2, ops._PREC[tdt])
+    assert rc == 0
+    for h in hs:
+        _lib.mfa_destroy_buffer(h)
+    for a, b in ((dq, gq), (dk, gk), (dv, gv)):
+        assert torch.equal(a, b)
+    if D != 80:
+        big = (v.float() * 3.0e5).to(tdt) if dt == "bf16" else None
+        if big is not None:  # bf16 V beyond 65504
+            _, _, _, st = umfa_torch.quantized_attention_backward_stream(do, q, k, big, o, lse)
+            torch.cuda.synchronize()
+            assert int(st.item()) == 1

@@ -321,6 +321,69 @@ int32_t mfa_quantized_backward(mfa_context_t context, mfa_buffer_t q, mfa_buffer
     return MFA_SUCCESS;
 }
 
+// MI355X extra (not in the reference): mfa_quantized_backward in-stream -- dense BHSD device pointers, the caller's stream,
+// never synchronises.  Engine as in the blocking entry: the 16-bit MFMA backward on fp16 de-quantised operands where the
+// shape allows (head_dim 64 / 128 / 256), else the fp32-exact one.  An in-stream call cannot repeat itself, so a value
+// outside fp16's range is REPORTED instead: `status` (device, one uint32, may be NULL) is zeroed on the stream and ORed
+// with 1 by the kernels that saw one -- the gradients are then not valid and the caller uses the blocking entry (or sets
+// the option "bwd_exact").  out / gradients fp32, dout in the input precision, lse fp32 [B*H*Sq].
+mfa_error_t umfa_quantized_backward_stream(mfa_context_t context, void* stream_handle, const void* q, const void* k,
+                                           const void* v, const float* out, const void* dout, const float* lse, float* dq,
+                                           float* dk, float* dv, uint32_t* status, uint32_t batch_size, uint32_t seq_len_q,
+                                           uint32_t seq_len_kv, uint32_t num_heads, uint16_t head_dim, float softmax_scale,
+                                           bool causal, int32_t target_precision, int32_t quant_mode, int32_t input_precision) {
+    Context* ctx = as_ctx(context);
+    if (!ctx || !q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv) return MFA_ERROR_INVALID_ARGS;
+    const uint32_t B = batch_size, H = num_heads, Sq = seq_len_q, Skv = seq_len_kv, D = head_dim;
+    const size_t nq = (size_t)B * H * Sq * D, nr = (size_t)B * H * Sq;
+    if (nq == 0 || (size_t)B * H * Skv * D == 0) return MFA_SUCCESS;
+    if (!quantized_supported(D)) return MFA_ERROR_INVALID_ARGS;
+    const int prec = dense_prec(input_precision);
+    const int bits = target_precision == MFA_PRECISION_INT4 ? 4 : 8;
+    const int mode = quant_mode == 2 ? 2 : 0;
+    hipStream_t stream = (hipStream_t)stream_handle;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    const int dev = stream_device(stream);
+    DeviceGuard guard(dev);
+    const bool fast = bwd16_shape_ok(D, false);
+    const size_t wq = (quant_workspace_bytes(B, H, Sq, Skv, D, true) + 255) & ~(size_t)255;
+    const size_t o_dvec = wq, o_do16 = o_dvec + ((nr * 4 + 255) & ~(size_t)255), o_rowc = o_do16 + ((nq * 2 + 255) & ~(size_t)255),
+                 o_flag = o_rowc + ((2 * nr * 4 + 255) & ~(size_t)255);
+    char* ws = (char*)ctx->pool(dev, stream).workspace.ensure((fast ? o_flag + 256 : o_do16) + 256, stream);
+    if (!ws) return MFA_ERROR_MEMORY_ALLOCATION;
+    uint32_t* flag = status ? status : (uint32_t*)(ws + o_flag);
+    if ((fast || status) && hipMemsetAsync(flag, 0, 4, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+    QuantViews views;
+    if (launch_quantize(q, k, v, prec, B, H, Sq, Skv, D, bits, mode, ws, fast ? 2 : 1, &views, stream, fast ? flag : nullptr) != hipSuccess)
+        return MFA_ERROR_EXECUTION_FAILED;
+    BwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.o = out; p.lse = lse; p.dq = dq; p.dk = dk; p.dv = dv;
+    p.dvec = (float*)(ws + o_dvec);
+    p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv; p.D = D;
+    p.scale = softmax_scale; p.causal = causal ? 1 : 0;
+    const char* name = "none";
+    hipError_t e;
+    if (fast) {
+        p.q = views.qh; p.k = views.kh; p.v = views.vh;
+        p.in_prec = P_FP16; p.dout_prec = P_FP16;
+        p.dout = dout;
+        if (prec != P_FP16) {
+            if (launch_cast_f16(dout, prec, ws + o_do16, (int64_t)nq, flag, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+            p.dout = ws + o_do16;
+        }
+        p.rowc = (float*)(ws + o_rowc);
+        if (!bwd_16_supported(p)) return MFA_ERROR_INVALID_ARGS;  // 16-byte alignment of the caller's tensors
+        e = launch_bwd_16(p, stream, &name);
+    } else {
+        p.dout = dout; p.q = views.qf; p.k = views.kf; p.v = views.vf;
+        p.in_prec = P_FP32; p.dout_prec = prec;
+        e = launch_bwd(p, stream, &name);
+    }
+    ctx->last_kernel = name;
+    return e == hipSuccess ? MFA_SUCCESS : e == hipErrorInvalidValue ? MFA_ERROR_INVALID_ARGS : MFA_ERROR_EXECUTION_FAILED;
+}
+
 // ---- pre-quantised backward ABI (MFABridge.swift:1623-2163, mfa_ffi.h:480-624) ----------------------------------------
 // Q, K, V arrive already quantised (or in fp16 / bf16 / fp32: the *_precision arguments are mfa_precision_t values) with
 // per-tensor scale / zero point, or per-block scales when `*_block_size` > 0 and a scale buffer is given.  Block

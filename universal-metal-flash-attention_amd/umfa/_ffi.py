@@ -157,6 +157,10 @@ def _load_library(path: str | None = None) -> ctypes.CDLL:
         [mfa_context_t, _vp] + [_vp] * 10 + _DIMS + [_f32, _b, _i32, _i32, _b, _b])
     sig("umfa_quantized_forward_stream", mfa_error_t,
         [mfa_context_t, _vp] + [_vp] * 6 + _DIMS + [_f32, _b, _i32, _i32, _i32])
+    if path is None or hasattr(lib, "umfa_quantized_backward_stream"):
+        sig("umfa_quantized_backward_stream", mfa_error_t,
+            [mfa_context_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, ctypes.c_uint16,
+             ctypes.c_float, ctypes.c_bool, _i32, _i32, _i32])
     sig("umfa_last_kernel_name", ctypes.c_char_p, [mfa_context_t])
     if path is None or hasattr(lib, "umfa_set_option"):  # (tools/ab_inproc.py also loads older builds by explicit path)
         sig("umfa_set_option", _i32, [mfa_context_t, ctypes.c_char_p, ctypes.c_char_p])

@@ -227,6 +227,31 @@ def quantized_attention_forward_stream(q, k, v, *, scale=None, causal=False, mas
     return (out, lse) if return_lse else out
 
 
+def quantized_attention_backward_stream(dout, q, k, v, o32, lse, *, scale=None, causal=False, bits: int = 8,
+                                        quant_mode: str = "blockwise"):
+    """Backward of quantized_attention_forward_stream, in-stream (umfa_quantized_backward_stream): contiguous BHSD device
+    tensors, O fp32 and LSE from the quantised forward.  Returns (dq, dk, dv, status): fp32 gradients and a device
+    uint32 that is non-zero when an operand left fp16's range on the 16-bit MFMA engine (then use the blocking
+    mfa_quantized_backward -- umfa_torch's autograd Function does -- or the option bwd_exact)."""
+    B, H, Sq, D = q.shape
+    Skv = k.shape[2]
+    if scale is None:
+        scale = D ** -0.5
+    for t in (dout, q, k, v, o32, lse):
+        assert t.is_cuda and t.is_contiguous()
+    assert o32.dtype == torch.float32 and lse.dtype == torch.float32 and dout.dtype == q.dtype
+    dq = torch.empty((B, H, Sq, D), dtype=torch.float32, device=q.device)
+    dk = torch.empty((B, H, Skv, D), dtype=torch.float32, device=q.device)
+    dv = torch.empty_like(dk)
+    status = torch.zeros(1, dtype=torch.int32, device=q.device)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    _check_error(_lib.umfa_quantized_backward_stream(
+        context(), ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream), vp(q), vp(k), vp(v), vp(o32), vp(dout),
+        vp(lse), vp(dq), vp(dk), vp(dv), vp(status), B, Sq, Skv, H, D, float(scale), bool(causal), 4 if bits == 4 else 3,
+        _quant_mode(quant_mode), _PREC[q.dtype]))
+    return dq, dk, dv, status
+
+
 def gpu_latency() -> float:
     return float(_lib.mfa_get_gpu_latency(context()))
 
