@@ -397,6 +397,13 @@ const char* umfa_last_kernel_name(mfa_context_t context);
  * Returns MFA_ERROR_INVALID_ARGS for an unknown name or a value out of range.  Thread-safe; affects later launches. */
 mfa_error_t umfa_set_option(mfa_context_t context, const char* name, const char* value);
 
+/* MI355X extra: free the library's device scratch (stream-K partials, mask tile flags, quantiser workspace, row constants).
+ * Scratch is pooled per (device, stream) and per hipGraph capture, grows geometrically and is otherwise never freed --
+ * a launch in flight or a captured graph may hold its addresses.  This call waits for the devices concerned, then frees
+ * the pools of `stream` (eager and every capture made on it) or, with all_streams != 0, every pool.  The caller vouches
+ * that no graph captured with those pools will be replayed again. */
+mfa_error_t umfa_release_scratch(mfa_context_t context, void* stream, int32_t all_streams);
+
 #undef UMFA_QUANT_LEGACY_ARGS
 #undef UMFA_QBWD_TAIL
 #undef UMFA_QBWD_BLOCKS

@@ -504,6 +504,24 @@ const char* umfa_last_kernel_name(mfa_context_t context) {
     return c ? c->last_kernel : "none";
 }
 
+mfa_error_t umfa_release_scratch(mfa_context_t context, void* stream, int32_t all_streams) {
+    Context* c = as_ctx(context);
+    if (!c) return MFA_ERROR_INVALID_ARGS;
+    std::lock_guard<std::mutex> lock(c->mu);
+    // the caller vouches for "no live graph"; in-flight launches are waited for here
+    int n = 0, prev = 0;
+    if (hipGetDeviceCount(&n) == hipSuccess && hipGetDevice(&prev) == hipSuccess) {
+        for (auto& kv : c->pools)
+            if (all_streams || kv.first.stream == (hipStream_t)stream) {
+                (void)hipSetDevice(kv.first.dev);
+                (void)hipDeviceSynchronize();
+            }
+        (void)hipSetDevice(prev);
+    }
+    c->release_pools((hipStream_t)stream, all_streams != 0);
+    return MFA_SUCCESS;
+}
+
 mfa_error_t umfa_set_option(mfa_context_t context, const char* name, const char* value) {
     if (!as_ctx(context)) return MFA_ERROR_INVALID_ARGS;
     return set_tuning(name, value) ? MFA_SUCCESS : MFA_ERROR_INVALID_ARGS;

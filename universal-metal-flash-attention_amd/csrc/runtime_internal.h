@@ -27,17 +27,24 @@ extern const bool g_debug;
         }                                           \
     } while (0)
 
-// ---- scratch: grow-only device blocks, one set per (device, stream) ------------------------------------------------
+// ---- scratch: grow-only device blocks, one set per (device, stream) -- and per CAPTURE ------------------------------
 // The kernels need caller-invisible device scratch (split-item tickets + partials, mask tile flags, the quantiser's
 // workspace).  Rules that keep the asynchronous entries correct:
 //   * keyed by (device, stream): launches on one stream are ordered, so they may share; two streams (or two host
 //     threads on two streams) never touch the same ticket words or partial slots;
+//   * keyed by the CAPTURE as well: a call made while its stream is being captured bakes scratch addresses into kernel
+//     nodes, and the graph may later be replayed on any stream, concurrently with eager launches on the capture stream
+//     or with another graph captured on it (torch.cuda.graph captures everything on one process-wide stream) -- so every
+//     capture sequence (hipStreamGetCaptureInfo id) gets a pool of its own, used by nothing else;
 //   * grow-only: a block that is too small is RETIRED, not freed -- a launch still in flight or a captured hipGraph
-//     may hold its address; retired blocks live until the process ends (sizes are bounded by the largest call:
+//     may hold its address; retired blocks live until umfa_release_scratch (sizes are bounded by the largest call:
 //     growth is geometric, so the retired total stays below the live block);
-//   * never allocated while the stream is capturing (hipMalloc is illegal there): the call returns
-//     MFA_ERROR_MEMORY_ALLOCATION and the caller warms the shape up before capture, as bench.py does;
-//   * allocated under a device guard for the stream's device; the caller's current device is restored.
+//   * allocation during capture is legal: hipMalloc runs under hipThreadExchangeStreamCaptureMode(relaxed) (it is not a
+//     stream operation and nothing here depends on its implicit ordering); if the runtime still refuses, the call
+//     returns MFA_ERROR_MEMORY_ALLOCATION and the capture is untouched;
+//   * allocated under a device guard for the stream's device; the caller's current device is restored;
+//   * never freed behind the caller's back: umfa_release_scratch(context, stream, all) frees pools the caller knows to be
+//     idle (no launch in flight, no live graph that was captured with them).
 struct DeviceGuard {
     int prev = -1;
     bool switched = false;
@@ -72,6 +79,28 @@ inline bool stream_capturing(hipStream_t stream) {
     return st != hipStreamCaptureStatusNone;
 }
 
+// 0 when the stream is not capturing, else a non-zero id unique to the capture sequence
+inline unsigned long long capture_id(hipStream_t stream) {
+    if (!stream) return 0;  // the legacy default stream cannot be captured
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    unsigned long long id = 0;
+    if (hipStreamGetCaptureInfo(stream, &st, &id) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return st == hipStreamCaptureStatusActive ? id + 1 : 0;
+}
+
+// hipMalloc that is legal while a stream of this thread is capturing
+inline hipError_t malloc_any_mode(void** p, size_t bytes, bool capturing) {
+    if (!capturing) return hipMalloc(p, bytes);
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    if (hipThreadExchangeStreamCaptureMode(&mode) != hipSuccess) { (void)hipGetLastError(); return hipErrorStreamCaptureUnsupported; }
+    const hipError_t e = hipMalloc(p, bytes);
+    (void)hipThreadExchangeStreamCaptureMode(&mode);  // back to the caller's mode
+    return e;
+}
+
 struct GrowBuf {
     void* ptr = nullptr;
     size_t bytes = 0;
@@ -80,19 +109,26 @@ struct GrowBuf {
     void* ensure(size_t need, hipStream_t stream, bool* grew = nullptr) {
         if (grew) *grew = false;
         if (ptr && need <= bytes) return ptr;
-        if (stream_capturing(stream)) return nullptr;
+        const bool cap = stream_capturing(stream);
         size_t want = need + (need >> 1) + 256;  // geometric growth bounds the retired total
         void* fresh = nullptr;
-        if (hipMalloc(&fresh, want) != hipSuccess) {
+        if (malloc_any_mode(&fresh, want, cap) != hipSuccess) {
             (void)hipGetLastError();
             want = need + 256;
-            if (hipMalloc(&fresh, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            if (malloc_any_mode(&fresh, want, cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         }
         if (ptr) retired.push_back(ptr);
         ptr = fresh;
         bytes = want;
         if (grew) *grew = true;
         return ptr;
+    }
+    void release() {  // caller: nothing in flight, no live graph holds these addresses
+        if (ptr) (void)hipFree(ptr);
+        for (void* r : retired) (void)hipFree(r);
+        retired.clear();
+        ptr = nullptr;
+        bytes = 0;
     }
 };
 
@@ -109,7 +145,6 @@ struct StreamScratch {
         const size_t c = cnt_bytes > w64_cnt_bytes ? cnt_bytes : w64_cnt_bytes;
         bool grew = false;
         if (c != w64_cnt_bytes && w64.ptr) {  // the ticket area moves: take a fresh block so old launches keep their layout
-            if (stream_capturing(stream)) return nullptr;
             w64.retired.push_back(w64.ptr);
             w64.ptr = nullptr;
             w64.bytes = 0;
@@ -117,10 +152,21 @@ struct StreamScratch {
         char* b = (char*)w64.ensure(c + buf_bytes, stream, &grew);
         if (!b) return nullptr;
         if (grew) {
-            if (hipMemsetAsync(b, 0, c, stream) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            if (hipMemsetAsync(b, 0, c, stream) != hipSuccess) {
+                // tickets not zeroed: this block must never be handed out as valid -- retire it, the next call starts over
+                (void)hipGetLastError();
+                w64.retired.push_back(w64.ptr);
+                w64.ptr = nullptr;
+                w64.bytes = 0;
+                return nullptr;
+            }
             w64_cnt_bytes = c;
         }
         return b;
+    }
+    void release() {
+        split.release(); w64.release(); mflags.release(); workspace.release(); rowc.release();
+        w64_cnt_bytes = 0;
     }
 };
 
@@ -137,9 +183,46 @@ struct Context {
     std::atomic<int> refs{0};
     std::mutex mu;  // guards the pools, last_kernel / latency, and serialises lookup + launch of every entry
 
-    std::map<std::pair<int, hipStream_t>, StreamScratch> pools;
+    struct PoolKey {
+        int dev;
+        hipStream_t stream;
+        unsigned long long capture;  // 0 = eager launches; else the capture sequence the pool belongs to
+        bool operator<(const PoolKey& o) const {
+            return dev != o.dev ? dev < o.dev : stream != o.stream ? stream < o.stream : capture < o.capture;
+        }
+    };
+    std::map<PoolKey, StreamScratch> pools;
     // call with mu held; the returned object is stable (std::map nodes never move)
-    StreamScratch& pool(int dev, hipStream_t stream) { return pools[std::make_pair(dev, stream)]; }
+    StreamScratch& pool(int dev, hipStream_t stream) {
+        unsigned long long cap = capture_id(stream);
+        if (cap && !capture_alloc_works()) cap = 0;  // runtime refuses hipMalloc during capture: the stream's eager pool, warmed up by the caller
+        return pools[PoolKey{dev, stream, cap}];
+    }
+    // probed once, at the first call made under capture: can this runtime allocate while a stream is capturing?
+    static bool capture_alloc_works() {
+        static const bool ok = [] {
+            void* p = nullptr;
+            if (malloc_any_mode(&p, 256, true) != hipSuccess) { (void)hipGetLastError(); return false; }
+            (void)hipFree(p);
+            return true;
+        }();
+        return ok;
+    }
+    // frees the pools of `stream` (eager and capture-private), or every pool; call with mu held, devices idle
+    size_t release_pools(hipStream_t stream, bool all) {
+        size_t n = 0;
+        for (auto it = pools.begin(); it != pools.end();) {
+            if (all || it->first.stream == stream) {
+                DeviceGuard g(it->first.dev);
+                it->second.release();
+                it = pools.erase(it);
+                ++n;
+            } else {
+                ++it;
+            }
+        }
+        return n;
+    }
 
     void* ensure_scratch(size_t bytes) {
         if (bytes <= scratch_bytes) return scratch;

@@ -162,6 +162,8 @@ def _load_library(path: str | None = None) -> ctypes.CDLL:
             [mfa_context_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, ctypes.c_uint16,
              ctypes.c_float, ctypes.c_bool, _i32, _i32, _i32])
     sig("umfa_last_kernel_name", ctypes.c_char_p, [mfa_context_t])
+    if path is None or hasattr(lib, "umfa_release_scratch"):
+        sig("umfa_release_scratch", mfa_error_t, [mfa_context_t, _vp, _i32])
     if path is None or hasattr(lib, "umfa_set_option"):  # (tools/ab_inproc.py also loads older builds by explicit path)
         sig("umfa_set_option", _i32, [mfa_context_t, ctypes.c_char_p, ctypes.c_char_p])
     sig("umfa_quantize_rows", _i32, [mfa_context_t, _vp, _vp, _i32, _u32, _u32, _u32, _i32, _i32, _vp, _vp,

@@ -28,9 +28,9 @@ from . import ops
 _SUPPORTED = (torch.float32, torch.float16, torch.bfloat16)
 
 
-def _bump(name: str) -> None:
+def _bump(name: str, by: int = 1) -> None:
     from . import sdpa as _s
-    _s._bump(name)
+    _s._bump(name, by)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -45,7 +45,7 @@ def sdpa_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, attn_mask: O
             q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
             break
     _bump("total")          # reached only through library.sdpa / a compiled graph: the eager routing counts for itself
-    _bump("fp32_instream")
+    _bump("fp32_instream")  # (a training call is re-classified as fp32_autograd by _setup_context, like the eager routing)
     out, lse = ops.attention_forward(q, k, v, scale=float(scale), causal=bool(is_causal), mask=attn_mask, out_dtype=q.dtype,
                                      return_lse=True)
     return out, lse
@@ -79,6 +79,11 @@ def _setup_context(ctx, inputs, output):
                            "the routing function sends masked training calls to torch's native SDPA")
     ctx.save_for_backward(q, k, v, out, lse)
     ctx.is_causal, ctx.scale = bool(is_causal), float(scale)
+    if q.requires_grad or k.requires_grad or v.requires_grad:
+        # the op body (which cannot see requires_grad) counted this call as fp32_instream: move it, so that the eager and
+        # the op routing report the same statistics for the same model
+        _bump("fp32_autograd")
+        _bump("fp32_instream", -1)
 
 
 def _backward(ctx, dout, dlse):
@@ -90,8 +95,14 @@ def _backward(ctx, dout, dlse):
 sdpa_forward.register_autograd(_backward, setup_context=_setup_context)
 
 
-def op_supports(q, k, v, attn_mask, dropout_p, needs_grad: bool) -> bool:
-    """Static (trace-time) conditions under which the custom op serves the call; everything else is torch's."""
+def op_supports(q, k, v, attn_mask, dropout_p, needs_grad: bool, is_causal: bool = False) -> bool:
+    """Static (trace-time) conditions under which the custom op serves the call; everything else is torch's.
+    The same decisions as the eager routing (sdpa.scaled_dot_product_attention), so that a model gives the same numbers and
+    the same dispatch statistics compiled and eager: a quantisation mode set through set_quantization_mode is served by
+    the eager Function only (the op has no quantised variant), and is_causal together with an attn_mask is torch's error."""
+    from . import sdpa as _s
+    if _s._quant_precision != _s.QUANT_NONE or (is_causal and attn_mask is not None):
+        return False
     if dropout_p > 0.0 or q.dim() != 4 or k.dim() != 4 or v.dim() != 4:
         return False
     if not (q.is_cuda and k.is_cuda and v.is_cuda) or q.dtype not in _SUPPORTED or k.dtype != q.dtype or v.dtype != q.dtype:
@@ -121,7 +132,7 @@ def sdpa(query, key, value, attn_mask=None, dropout_p: float = 0.0, is_causal: b
     if q.dim() == 4 and k.dim() == 4 and q.shape[1] != k.shape[1] and k.shape[1] > 0 and q.shape[1] % k.shape[1] == 0:
         g = q.shape[1] // k.shape[1]  # GQA as the reference does it (metal_sdpa_backend.cpp:1694-1702)
         k, v = k.repeat_interleave(g, 1), v.repeat_interleave(g, 1)
-    if not op_supports(q, k, v, attn_mask, dropout_p, needs_grad):
+    if not op_supports(q, k, v, attn_mask, dropout_p, needs_grad, bool(is_causal)):
         return native_sdpa(query, key, value, attn_mask=attn_mask, dropout_p=dropout_p, is_causal=is_causal, scale=scale,
                            enable_gqa=enable_gqa)
     sm_scale = float(scale) if scale is not None else float(q.shape[-1]) ** -0.5

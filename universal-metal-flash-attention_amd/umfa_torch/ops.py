@@ -37,6 +37,13 @@ def last_kernel() -> str:
     return _lib.umfa_last_kernel_name(context()).decode()
 
 
+def release_scratch(stream=None, all_streams: bool = False) -> None:
+    """Free the library's pooled device scratch of `stream` (default: torch's current stream) or of every stream
+    (umfa_release_scratch): only when no graph captured with it will be replayed again."""
+    st = torch.cuda.current_stream().cuda_stream if stream is None else stream.cuda_stream
+    _check_error(_lib.umfa_release_scratch(context(), ctypes.c_void_p(st), 1 if all_streams else 0))
+
+
 # launcher switches (include/umfa_abi.h umfa_set_option); the library's defaults, for options() to restore
 _OPTION_DEFAULTS = {"softmax_reference": "default", "softmax_tau": "6", "force_w64": "0", "no_w64": "0", "w64_grid": "0",
                     "no_mask_flags": "0", "bwd_exact": "0", "bwd_dq": "0", "bwd_persist": "0", "no_split": "0",

@@ -42,9 +42,9 @@ _native_sdpa = F.scaled_dot_product_attention
 _SUPPORTED = (torch.float32, torch.float16, torch.bfloat16)
 
 
-def _bump(name: str) -> None:
+def _bump(name: str, by: int = 1) -> None:
     with _stats_lock:
-        _stats[name] += 1
+        _stats[name] += by
 
 
 def get_dispatch_stats() -> dict:
