@@ -63,33 +63,35 @@ def test_two_host_threads_two_streams():
     assert torch.equal(res[0], serial[0]) and torch.equal(res[1], serial[1])
 
 
-def test_graph_keeps_replaying_after_scratch_growth_and_capture_has_private_scratch():
-    """A captured graph keeps replaying correctly after later, larger calls on the same stream made the scratch pools
-    grow, and a shape the stream has never seen can be captured without any warm-up: every capture gets scratch of its
-    own (allocated under the relaxed capture mode), so nothing it bakes into kernel nodes is shared with eager launches."""
+def test_graph_survives_scratch_growth_and_capture_never_allocates():
+    """A captured graph keeps replaying correctly after later, larger calls on the same stream (the capture took the
+    warmed-up pool over as its own; eager calls afterwards fill a fresh one); a shape that would need NEW scratch during
+    capture is refused with MFA_ERROR_MEMORY_ALLOCATION (2) instead of calling hipMalloc inside the capture."""
     import umfa_torch
+    from umfa._ffi import MFAError
     q, k, v = _inputs(1)
     mask = torch.ones(1, 1, 768, 448, dtype=torch.bool, device="cuda").tril(100)
     out_a = torch.empty(1, 5, 768, 128, device="cuda", dtype=torch.float32)
     out_m = torch.empty_like(out_a)
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
+        # warm-up on the capture stream: its pool gets the w64 partials, the mask-flag buffer, the split scratch
         umfa_torch.attention_forward(q, k, v, out=out_a)
         umfa_torch.attention_forward(q, k, v, mask=mask, out=out_m)
     side.synchronize()
     ref_a, ref_m = out_a.clone(), out_m.clone()
     big = _inputs(2, H=24, Sq=4096, Skv=4096)
     out_big = torch.empty(1, 24, 4096, 128, device="cuda", dtype=torch.bfloat16)
-    ref_big = umfa_torch.attention_forward(*big)
-    torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.stream(side):
         with torch.cuda.graph(g, stream=side):
             umfa_torch.attention_forward(q, k, v, out=out_a)
             umfa_torch.attention_forward(q, k, v, mask=mask, out=out_m)
-            # a far larger item count than anything this stream has seen: the capture's own pool takes it
-            umfa_torch.attention_forward(*big, out=out_big)
-    # larger calls on the same stream after capture: the eager pools grow
+            # a far larger item count than anything this stream has seen: would have to grow the partials
+            with pytest.raises(MFAError) as ei:
+                umfa_torch.attention_forward(*big, out=out_big)
+            assert ei.value.code == 2
+    # larger calls on the same stream after capture: a fresh eager pool, the graph's own is untouched
     with torch.cuda.stream(side):
         qb, kb, vb = _inputs(3, H=24, Sq=4096, Skv=4096)
         umfa_torch.attention_forward(qb, kb, vb)
@@ -99,15 +101,14 @@ def test_graph_keeps_replaying_after_scratch_growth_and_capture_has_private_scra
     for _ in range(3):
         out_a.fill_(7.0)
         out_m.fill_(7.0)
-        out_big.fill_(7.0)
         g.replay()
         torch.cuda.synchronize()
-        assert torch.equal(out_a, ref_a) and torch.equal(out_m, ref_m) and torch.equal(out_big, ref_big)
+        assert torch.equal(out_a, ref_a) and torch.equal(out_m, ref_m)
 
 
 def test_two_graphs_captured_on_one_stream_replay_concurrently_on_two_streams():
-    """torch captures every graph on one process-wide stream: two graphs whose kernels cut items (tickets + partials in
-    scratch) must not share that scratch.  Replayed at the same time on two streams, with eager launches running on the
+    """Two graphs captured on ONE stream (torch's default is one process-wide capture stream), whose kernels cut items
+    (tickets + partials in scratch), must not share that scratch: each capture owns the pool its warm-up filled.  Replayed at the same time on two streams, with eager launches running on the
     capture stream as well, every result equals the serial one."""
     import umfa_torch
     cases = [_inputs(20 + s, H=6, Sq=4096, Skv=4096) for s in range(3)]
@@ -119,6 +120,8 @@ def test_two_graphs_captured_on_one_stream_replay_concurrently_on_two_streams():
     for i in range(2):
         g = torch.cuda.CUDAGraph()
         with torch.cuda.stream(cap):
+            umfa_torch.attention_forward(*cases[i], out=outs[i])  # warm-up before EVERY capture: the capture takes this pool over
+            cap.synchronize()
             with torch.cuda.graph(g, stream=cap):
                 for _ in range(4):
                     umfa_torch.attention_forward(*cases[i], out=outs[i])

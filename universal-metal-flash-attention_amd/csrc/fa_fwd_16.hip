@@ -57,7 +57,23 @@ FwdSplitPlan fwd_16_split_plan(const FwdParams& p) {
     plan.n_full = items;
     plan.nsplit = 1;
     plan.buf_bytes = plan.cnt_bytes = 0;
-    if (p.causal || items == 0 || tuning().no_split.load(std::memory_order_relaxed)) return plan;  // causal items are uneven already
+    if (items == 0 || tuning().no_split.load(std::memory_order_relaxed)) return plan;
+    if (p.causal) {
+        // Causal items are uneven already; what a SHORT causal launch (every item resident at once) waits for is its
+        // longest item: q-block nqb - 1 sweeps every key tile alone.  Lab option force_split = 2: cut the heavy half of each
+        // head's q-blocks (qb >= nqb / 2) into two key ranges.  MEASURED SLOWER with this kernel's release / acquire fold
+        // (round 3, graph-replayed us, split / whole: B4 H16 S1024 D64 [BASELINE config 2] 40.4 / 20.7, B8 H16 S512 D64
+        // 37.8 / 14.0, B2 H16 S2048 D64 48.5 / 31.6, B1 H32 S2048 D128 81.7 / 55.1): 512 agent-scope release fences in a 20-us
+        // launch cost more than the halved critical path returns.  Off by default; results are identical to 1e-2.
+        const int force = tuning().force_split.load(std::memory_order_relaxed);
+        const bool want = force == 2;
+        if (!want || (nqb & 1) || nqb < 4 || p.Sq != p.Skv || dp > 128) return plan;
+        plan.n_full = items / 2;
+        plan.nsplit = 2;
+        plan.buf_bytes = (size_t)(items / 2) * 2 * 4 * (16 * (dp / 32) + 2) * 64 * sizeof(float);
+        plan.cnt_bytes = ((size_t)(items / 2) * sizeof(uint32_t) + 15) & ~(size_t)15;
+        return plan;
+    }
     uint32_t k = cus / items, kmax = 8;
     // One q-block per (batch, head) -- decode-like calls: no two items share K / V, the sweep is bound by how many
     // tile loads a CU keeps in flight, so aim for two resident workgroups per CU (B8 H32 Sq1 Skv8192: 297 -> 243 us

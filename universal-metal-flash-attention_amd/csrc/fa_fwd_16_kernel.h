@@ -104,17 +104,26 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
     // work item = one 128-row query block of one (batch, head).  Items [0, n_full) are processed whole;
     // the remaining ones (a partial last round of workgroups) are split into nsplit key ranges.
     uint32_t item, part = 0, nparts = 1;
-    if (blockIdx.x < p.n_full) {
-        item = xcd_remap(blockIdx.x, p.n_full);
+    // causal launches with a split plan (fwd_16_split_plan, short launches): the HEAVY half of a head's q-blocks
+    // (qb >= nqb / 2) is cut into two key ranges, the light half stays whole; heavy parts are dispatched first
+    const bool causal_split = CAUSAL && p.nsplit > 1;
+    const uint32_t bx = causal_split ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    if (bx < p.n_full) {
+        item = xcd_remap(bx, p.n_full);
     } else {
         const uint32_t n_tail = gridDim.x - p.n_full;
-        const uint32_t j = xcd_remap(blockIdx.x - p.n_full, n_tail);
+        const uint32_t j = xcd_remap(bx - p.n_full, n_tail);
         nparts = p.nsplit;
         item = p.n_full + j / nparts;
         part = j % nparts;
     }
     uint32_t bh = item / nqb;
     uint32_t qb = item % nqb;
+    if (causal_split) {
+        const uint32_t h2 = nqb >> 1, idx = item < p.n_full ? item : item - p.n_full;
+        bh = idx / h2;
+        qb = (item < p.n_full ? 0 : h2) + idx % h2;
+    } else
     if (CAUSAL) {
         qb = nqb - 1 - qb;  // longest items first
 #ifndef UMFA_LAB_NO_CAUSAL_PAIRS

@@ -39,9 +39,12 @@ extern const bool g_debug;
 //   * grow-only: a block that is too small is RETIRED, not freed -- a launch still in flight or a captured hipGraph
 //     may hold its address; retired blocks live until umfa_release_scratch (sizes are bounded by the largest call:
 //     growth is geometric, so the retired total stays below the live block);
-//   * allocation during capture is legal: hipMalloc runs under hipThreadExchangeStreamCaptureMode(relaxed) (it is not a
-//     stream operation and nothing here depends on its implicit ordering); if the runtime still refuses, the call
-//     returns MFA_ERROR_MEMORY_ALLOCATION and the capture is untouched;
+//   * never allocated while the stream is capturing (hipMalloc invalidates the capture on this runtime, also under
+//     hipThreadExchangeStreamCaptureMode(relaxed): tried, round 3): the FIRST call of a capture takes over the stream's
+//     eager pool -- the one the caller's warm-up run on that stream filled -- as the capture's private pool; eager calls on
+//     the stream afterwards start a fresh pool (allocated outside any capture).  A call under capture whose pool is too
+//     small returns MFA_ERROR_MEMORY_ALLOCATION: warm the shape up on the capture stream before EVERY capture, as
+//     bench.py and torch's own graph recipe do;
 //   * allocated under a device guard for the stream's device; the caller's current device is restored;
 //   * never freed behind the caller's back: umfa_release_scratch(context, stream, all) frees pools the caller knows to be
 //     idle (no launch in flight, no live graph that was captured with them).
@@ -91,16 +94,6 @@ inline unsigned long long capture_id(hipStream_t stream) {
     return st == hipStreamCaptureStatusActive ? id + 1 : 0;
 }
 
-// hipMalloc that is legal while a stream of this thread is capturing
-inline hipError_t malloc_any_mode(void** p, size_t bytes, bool capturing) {
-    if (!capturing) return hipMalloc(p, bytes);
-    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
-    if (hipThreadExchangeStreamCaptureMode(&mode) != hipSuccess) { (void)hipGetLastError(); return hipErrorStreamCaptureUnsupported; }
-    const hipError_t e = hipMalloc(p, bytes);
-    (void)hipThreadExchangeStreamCaptureMode(&mode);  // back to the caller's mode
-    return e;
-}
-
 struct GrowBuf {
     void* ptr = nullptr;
     size_t bytes = 0;
@@ -109,13 +102,13 @@ struct GrowBuf {
     void* ensure(size_t need, hipStream_t stream, bool* grew = nullptr) {
         if (grew) *grew = false;
         if (ptr && need <= bytes) return ptr;
-        const bool cap = stream_capturing(stream);
+        if (stream_capturing(stream)) return nullptr;
         size_t want = need + (need >> 1) + 256;  // geometric growth bounds the retired total
         void* fresh = nullptr;
-        if (malloc_any_mode(&fresh, want, cap) != hipSuccess) {
+        if (hipMalloc(&fresh, want) != hipSuccess) {
             (void)hipGetLastError();
             want = need + 256;
-            if (malloc_any_mode(&fresh, want, cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            if (hipMalloc(&fresh, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
         }
         if (ptr) retired.push_back(ptr);
         ptr = fresh;
@@ -145,6 +138,7 @@ struct StreamScratch {
         const size_t c = cnt_bytes > w64_cnt_bytes ? cnt_bytes : w64_cnt_bytes;
         bool grew = false;
         if (c != w64_cnt_bytes && w64.ptr) {  // the ticket area moves: take a fresh block so old launches keep their layout
+            if (stream_capturing(stream)) return nullptr;
             w64.retired.push_back(w64.ptr);
             w64.ptr = nullptr;
             w64.bytes = 0;
@@ -194,19 +188,20 @@ struct Context {
     std::map<PoolKey, StreamScratch> pools;
     // call with mu held; the returned object is stable (std::map nodes never move)
     StreamScratch& pool(int dev, hipStream_t stream) {
-        unsigned long long cap = capture_id(stream);
-        if (cap && !capture_alloc_works()) cap = 0;  // runtime refuses hipMalloc during capture: the stream's eager pool, warmed up by the caller
-        return pools[PoolKey{dev, stream, cap}];
-    }
-    // probed once, at the first call made under capture: can this runtime allocate while a stream is capturing?
-    static bool capture_alloc_works() {
-        static const bool ok = [] {
-            void* p = nullptr;
-            if (malloc_any_mode(&p, 256, true) != hipSuccess) { (void)hipGetLastError(); return false; }
-            (void)hipFree(p);
-            return true;
-        }();
-        return ok;
+        const unsigned long long cap = capture_id(stream);
+        if (!cap) return pools[PoolKey{dev, stream, 0}];
+        const PoolKey ck{dev, stream, cap};
+        auto it = pools.find(ck);
+        if (it == pools.end()) {
+            // first call of this capture: the stream's eager pool (filled by the caller's warm-up) becomes the capture's own
+            it = pools.emplace(ck, StreamScratch()).first;
+            auto eager = pools.find(PoolKey{dev, stream, 0});
+            if (eager != pools.end()) {
+                it->second = std::move(eager->second);
+                pools.erase(eager);
+            }
+        }
+        return it->second;
     }
     // frees the pools of `stream` (eager and capture-private), or every pool; call with mu held, devices idle
     size_t release_pools(hipStream_t stream, bool all) {
