@@ -192,13 +192,21 @@ def run_rank(args) -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # UMFA_BENCH_ONE_DEVICE=1 (code-path rehearsal on a 1-GPU box, never a measurement): every rank uses cuda:0 and the
+    # process group is gloo (RCCL refuses two ranks on one device); the JSON line is marked `rehearsal`
+    rehearsal = os.environ.get("UMFA_BENCH_ONE_DEVICE") == "1"
+    if rehearsal:
+        local_rank = 0
     if local_rank >= torch.cuda.device_count():
         raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank} but only {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import umfa_torch
     from umfa_torch import parallel
@@ -212,7 +220,7 @@ def run_rank(args) -> None:
     def max_over_ranks(x: float) -> float:
         if world == 1:
             return x
-        t = torch.tensor([x], device=dev, dtype=torch.float64)
+        t = torch.tensor([x], device="cpu" if rehearsal else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -324,10 +332,15 @@ def run_rank(args) -> None:
     dt, settle = timed(step, args.steps, args.warmup, graph=(world == 1 and not args.no_graph))
     kernel_name = umfa_torch.last_kernel()
     gathered_ok = None
-    if strong_ok and rank == 0:  # the assembled tensor is the full O: spot-check two heads against a local run
-        chk = umfa_torch.attention_forward(q[:, :2], k[:, :2], v[:, :2], causal=args.causal)
-        torch.cuda.synchronize()
-        gathered_ok = bool(torch.equal(out[:, :2], chk))
+    if strong_ok and rank == 0:
+        # the assembled tensor is the full O: rank 0 recomputes its own first chunk and the first chunk of the LAST rank with
+        # launches of the same shape (same work decomposition => the kernels are bitwise repeatable) and compares bit for bit
+        gathered_ok = True
+        for r_ in (0, world - 1):
+            a_, b_, _, _ = parallel.owned_heads(H, world, r_)[0]
+            chk = umfa_torch.attention_forward(q[:, a_:b_], k[:, a_:b_], v[:, a_:b_], causal=args.causal)
+            torch.cuda.synchronize()
+            gathered_ok = gathered_ok and bool(torch.equal(out[:, a_:b_], chk))
 
     # dominant kernel: this rank's launch(es) of one step, HIP events on the launch stream
     if strong_ok:
@@ -499,6 +512,7 @@ def run_rank(args) -> None:
                        "gathered_equals_local": gathered_ok,
                        "ranks": world},
             "settle": settle,
+            **({"rehearsal": "UMFA_BENCH_ONE_DEVICE=1: all ranks on cuda:0 over gloo -- a code-path check, not a measurement"} if rehearsal else {}),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
                          "kernel_ms_mean": round(mean_ms, 5), "kernel_ms_min": round(durs[0], 5),

@@ -360,6 +360,17 @@ mfa_error_t umfa_attention_backward_stream(mfa_context_t context, void* stream, 
                                            int32_t intermediate_precision, bool grads_in_input_type,
                                            bool out_in_input_type);
 
+/* MI355X extra: umfa_attention_backward_stream for grouped-query attention without expanded K / V copies (the reference
+ * expands them with repeat_interleave before both passes, metal_sdpa_backend.cpp:1694-1702).  k, v, dk, dv:
+ * [B, num_kv_heads, Skv, D]; everything else as umfa_attention_backward_stream.  16-bit MFMA backward only (16-bit
+ * operands, head_dim 64 / 128 / 256): otherwise MFA_ERROR_INVALID_ARGS and the caller expands K / V itself. */
+mfa_error_t umfa_attention_backward_gqa_stream(mfa_context_t context, void* stream, const void* dout, const void* q,
+                                               const void* k, const void* v, const void* out, const float* softmax_lse,
+                                               void* dq, void* dk, void* dv, float* d_buffer, uint32_t batch_size,
+                                               uint32_t seq_len_q, uint32_t seq_len_kv, uint32_t num_heads,
+                                               uint32_t num_kv_heads, uint16_t head_dim, float softmax_scale, bool causal,
+                                               int32_t input_precision, bool grads_in_input_type, bool out_in_input_type);
+
 /* MI355X extra: mfa_quantized_forward_with_lse in-stream (dense BHSD device pointers, caller's stream, never
  * synchronises).  out fp32 [B,H,Sq,D]; lse (fp32 [B*H*Sq]) and mask (fp32 additive [B,H,Sq,Skv]) may be NULL. */
 mfa_error_t umfa_quantized_forward_stream(mfa_context_t context, void* stream, const void* q, const void* k,

@@ -193,3 +193,36 @@ def test_gqa_zero_copy_views(shape, dt):
     # per-head masks and gradients keep the expanding route
     assert sdpa._gqa_zero_copy(q, k, v, torch.ones(B, Hq, S, S, dtype=torch.bool, device="cuda"), 0.0, False, None) is None
     assert sdpa._gqa_zero_copy(q.clone().requires_grad_(True), k, v, None, 0.0, False, None) is None
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 2, 256, 64), (1, 32, 8, 1024, 128), (1, 4, 1, 320, 128), (1, 6, 3, 200, 80)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("causal", [False, True])
+def test_gqa_training_reads_k_v_in_place(shape, dt, causal):
+    """training GQA: no repeat_interleave copies in forward or backward (umfa_attention_backward_gqa_stream); O and the
+    gradients equal the expanding route's -- dQ bit for bit (same kernels, same operands), dK / dV up to the order of
+    the group sum (fp32 sum in the library vs torch's sum of rounded per-head gradients)"""
+    import umfa_torch
+    B, Hq, Hkv, S, D = shape
+    g = Hq // Hkv
+    torch.manual_seed(9)
+    q = torch.randn(B, Hq, S, D, device="cuda", dtype=dt, requires_grad=True)
+    k = torch.randn(B, Hkv, S, D, device="cuda", dtype=dt, requires_grad=True)
+    v = torch.randn(B, Hkv, S, D, device="cuda", dtype=dt, requires_grad=True)
+    do = torch.randn(B, Hq, S, D, device="cuda", dtype=dt)
+    out = umfa_torch.scaled_dot_product_attention(q, k, v, is_causal=causal, enable_gqa=True)
+    out.backward(do)
+    kern = umfa_torch.last_kernel()
+    gq, gk, gv = q.grad.clone(), k.grad.clone(), v.grad.clone()
+    q2, k2, v2 = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
+    ke, ve = k2.repeat_interleave(g, 1), v2.repeat_interleave(g, 1)
+    exp = umfa_torch.scaled_dot_product_attention(q2, ke, ve, is_causal=causal)
+    exp.backward(do)
+    tol = 2e-2 if dt == torch.bfloat16 else 4e-3
+    assert (out.float() - exp.float()).abs().max().item() < tol
+    if D in (64, 128, 256):
+        assert kern.startswith("fa_bwd16"), kern
+        assert torch.equal(gq, q2.grad)
+    for a, b_ in ((gq, q2.grad), (gk, k2.grad), (gv, v2.grad)):
+        assert a.shape == b_.shape
+        assert (a.float() - b_.float()).abs().max().item() <= tol * max(1.0, b_.float().abs().max().item())

@@ -222,17 +222,26 @@ __global__ __launch_bounds__(256) void bwd16_rowc_kernel(const float* lse, const
     }
 }
 
-// dK / dV of grouped key/value heads: sum the per-query-head gradients of a group
-__global__ __launch_bounds__(256) void group_sum_kernel(const float* src, float* dst, uint32_t B, uint32_t H, uint32_t Hkv,
-                                                        int64_t slab) {
+// dK / dV of grouped key/value heads: sum the per-query-head gradients of a group (fp32, fixed order), four elements per
+// lane (16-byte loads; slab = Skv * D is a multiple of 8)
+__global__ __launch_bounds__(256) void group_sum_kernel(const float* src, void* dst, uint32_t B, uint32_t H, uint32_t Hkv,
+                                                        int64_t slab, int out_prec) {
     const uint32_t g = H / Hkv;
-    const int64_t n = (int64_t)B * Hkv * slab;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const int64_t e = i % slab, bh = i / slab;
+    const int64_t slab4 = slab / 4, n4 = (int64_t)B * Hkv * slab4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int64_t e = i % slab4, bh = i / slab4;
         const int64_t b = bh / Hkv, hk = bh % Hkv;
-        float acc = 0.0f;
-        for (uint32_t j = 0; j < g; ++j) acc += src[((b * H + hk * g + j) * slab) + e];
-        dst[i] = acc;
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (uint32_t j = 0; j < g; ++j) acc += ((const f32x4*)(src + (b * H + hk * g + j) * slab))[e];
+        if (out_prec == P_FP16) {
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            ((h4*)dst)[i] = h4{(_Float16)acc[0], (_Float16)acc[1], (_Float16)acc[2], (_Float16)acc[3]};
+        } else if (out_prec == P_BF16) {
+            typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+            ((b4*)dst)[i] = b4{(__bf16)acc[0], (__bf16)acc[1], (__bf16)acc[2], (__bf16)acc[3]};
+        } else {
+            ((f32x4*)dst)[i] = acc;
+        }
     }
 }
 
@@ -261,11 +270,13 @@ hipError_t launch_dequant(const DequantParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_group_sum(const float* src, float* dst, uint32_t B, uint32_t H, uint32_t Hkv, int64_t slab, hipStream_t stream) {
+hipError_t launch_group_sum(const float* src, void* dst, uint32_t B, uint32_t H, uint32_t Hkv, int64_t slab, hipStream_t stream,
+                            int out_prec) {
     const int64_t n = (int64_t)B * Hkv * slab;
     if (n == 0) return hipSuccess;
-    const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(group_sum_kernel, dim3(grid), dim3(256), 0, stream, src, dst, B, H, Hkv, slab);
+    if (slab % 4 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)((n / 4 + 255) / 256 < 8192 ? (n / 4 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(group_sum_kernel, dim3(grid), dim3(256), 0, stream, src, dst, B, H, Hkv, slab, out_prec);
     return hipGetLastError();
 }
 

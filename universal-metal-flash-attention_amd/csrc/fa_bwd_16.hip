@@ -161,6 +161,12 @@ __global__ __launch_bounds__(256) void bwd16_delta_kernel(BwdParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------ dQ
+// (batch, key/value head) slab that query head `bh` attends to: grouped-query attention without expanded K / V copies
+__device__ __forceinline__ uint32_t bwd16_kv_slab(const BwdParams& p, uint32_t bh) {
+    if (p.Hkv == 0 || p.Hkv == p.H) return bh;
+    return (bh / p.H) * p.Hkv + (bh % p.H) / (p.H / p.Hkv);
+}
+
 template <typename T, bool CAUSAL, int DP>
 __global__ __launch_bounds__(256, DP == 256 ? 1 : 2) void bwd16_dq_kernel(BwdParams p) {
     BWD16_GEO(DP);
@@ -179,8 +185,9 @@ __global__ __launch_bounds__(256, DP == 256 ? 1 : 2) void bwd16_dq_kernel(BwdPar
     const bool qok = q_row < p.Sq;
     const T* qp = (const T*)p.q + (int64_t)bh * p.Sq * DP;
     const T* dop = (const T*)p.dout + (int64_t)bh * p.Sq * DP;
-    const T* kp = (const T*)p.k + (int64_t)bh * p.Skv * DP;
-    const T* vp = (const T*)p.v + (int64_t)bh * p.Skv * DP;
+    const uint32_t kvbh = bwd16_kv_slab(p, bh);  // grouped K / V heads are read in place
+    const T* kp = (const T*)p.k + (int64_t)kvbh * p.Skv * DP;
+    const T* vp = (const T*)p.v + (int64_t)kvbh * p.Skv * DP;
 
     // B operands: lane (q, hi) holds Q[q][16 ks + 8 hi ..], dO[q][...]
     V8 qf[NKS], dof[NKS];
@@ -386,8 +393,9 @@ __global__ __launch_bounds__(256, 1) void bwd16_dq2_kernel(BwdParams p) {
     const bool qok = q_row < p.Sq;
     const T* qp = (const T*)p.q + (int64_t)bh * p.Sq * DP;
     const T* dop = (const T*)p.dout + (int64_t)bh * p.Sq * DP;
-    const T* kp = (const T*)p.k + (int64_t)bh * p.Skv * DP;
-    const T* vp = (const T*)p.v + (int64_t)bh * p.Skv * DP;
+    const uint32_t kvbh = bwd16_kv_slab(p, bh);  // grouped K / V heads are read in place
+    const T* kp = (const T*)p.k + (int64_t)kvbh * p.Skv * DP;
+    const T* vp = (const T*)p.v + (int64_t)kvbh * p.Skv * DP;
     const i32x4 k_srd = make_srd(kp, p.Skv * (uint32_t)ROW_B), v_srd = make_srd(vp, p.Skv * (uint32_t)ROW_B);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((LDS_AS char*)smem));
 #pragma unroll
@@ -627,8 +635,9 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
     const bool kok = key < p.Skv;
     const T* qp = (const T*)p.q + (int64_t)bh * p.Sq * DP;
     const T* dop = (const T*)p.dout + (int64_t)bh * p.Sq * DP;
-    const T* kp = (const T*)p.k + (int64_t)bh * p.Skv * DP;
-    const T* vp = (const T*)p.v + (int64_t)bh * p.Skv * DP;
+    const uint32_t kvbh = bwd16_kv_slab(p, bh);  // grouped K / V heads are read in place
+    const T* kp = (const T*)p.k + (int64_t)kvbh * p.Skv * DP;
+    const T* vp = (const T*)p.v + (int64_t)kvbh * p.Skv * DP;
     const i32x4 q_srd = make_srd(qp, p.Sq * (uint32_t)ROW_B), do_srd = make_srd(dop, p.Sq * (uint32_t)ROW_B);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((LDS_AS char*)smem));
     float* const vec = (float*)(smem + VEC);
@@ -937,7 +946,7 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
 #ifdef BWD16_LAB_STAMP
     rt_loop1 = __builtin_amdgcn_s_memrealtime();
 #endif
-    if (DP == 128 && p.grad_in_type) {
+    if (DP == 128 && p.grad_in_type && !p.dkdv_fp32) {
         // Gradients in the operand type (in-stream entry), head_dim 128: a lane holds 4 consecutive d of ONE key per register
         // group, so direct stores touch 32 rows x 8 bytes per instruction (64 scattered store instructions per wave and
         // tensor pair, ~5.8 us per workgroup); instead each wave writes its 32 x 128 block into its own 8 KiB of the (idle)
@@ -979,8 +988,8 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
                 const int d0 = 32 * (i + hpass * NDBH) + 8 * g + 4 * hi;
                 f32x4 kv = {dk[i][4 * g] * p.scale, dk[i][4 * g + 1] * p.scale, dk[i][4 * g + 2] * p.scale, dk[i][4 * g + 3] * p.scale};
                 f32x4 vv = {dv[i][4 * g], dv[i][4 * g + 1], dv[i][4 * g + 2], dv[i][4 * g + 3]};
-                store_grad4<T>(p.dk, krow + d0, kv, p.grad_in_type != 0);
-                store_grad4<T>(p.dv, krow + d0, vv, p.grad_in_type != 0);
+                store_grad4<T>(p.dk, krow + d0, kv, p.grad_in_type != 0 && !p.dkdv_fp32);
+                store_grad4<T>(p.dv, krow + d0, vv, p.grad_in_type != 0 && !p.dkdv_fp32);
             }
     }
 #ifdef BWD16_LAB_STAMP
@@ -1001,6 +1010,7 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
 bool bwd_16_supported(const BwdParams& p) {
     if (p.in_prec != P_FP16 && p.in_prec != P_BF16) return false;
     if (p.dout_prec != p.in_prec || (p.D != 256 && p.D != 128 && p.D != 64) || p.mask) return false;
+    if (p.Hkv && (p.Hkv > p.H || p.H % p.Hkv)) return false;
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     if (!al16(p.q) || !al16(p.k) || !al16(p.v) || !al16(p.dout) || !al16(p.dq) || !al16(p.dk) || !al16(p.dv)) return false;
     // 32-bit buffer offsets inside one (batch, head) slab

@@ -122,7 +122,10 @@ struct BwdParams {
     int dout_prec;  // dO
     int grad_in_type;  // 0: dQ, dK, dV are fp32 (the ABI contract); 1: they are written in the input type (in-stream entry)
     int o_in_type;     // 0: O is fp32 (the ABI contract); 1: `o` points at O in the input type (in-stream entry)
-    int phases;     // fp32-exact backward only: 0 = everything; else bit 0 = D vector, bit 1 = dQ, bit 2 = dK/dV
+    int phases;     // 0 = everything; else bit 0 = D vector, bit 1 = dQ, bit 2 = dK/dV (the pre-quantised ABI's two calls)
+    uint32_t Hkv;   // bwd16 only: K / V hold Hkv heads (grouped-query attention, H % Hkv == 0; 0 = H): query head h reads K / V head
+                    // h / (H / Hkv) in place (no expanded copies); dK / dV still come out per QUERY head, the caller sums the groups
+    int dkdv_fp32;  // bwd16 only: dK / dV in fp32 even when grad_in_type asks for operand-type dQ (they are summed over a group next)
 };
 
 __device__ __forceinline__ float bf16_bits_to_float(uint16_t b) {

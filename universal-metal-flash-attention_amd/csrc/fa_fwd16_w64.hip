@@ -42,6 +42,7 @@ struct W64Params {
     uint32_t* part_cnt;   // [n_items % grid] arrival tickets, zero between launches (the folding part resets its own)
     float tau;            // deferred-max threshold (log2 units)
     uint32_t lazy;        // bf16 kernels: lazy reference mode (no row max after a segment's first tile; see the kernel)
+    uint32_t skew;        // tiles moved from the folding part of a two-way cut item to the publishing part (see the kernel)
     const float* rope_cos;  // fused rotary embedding of Q (FwdParams::rope_*), NULL = none
     const float* rope_sin;
     int64_t rope_tb;
@@ -70,6 +71,7 @@ struct W64I8Params {
     float* part_buf;
     uint32_t* part_cnt;
     float tau;
+    uint32_t skew;
 };
 
 #define W64_I8 0
@@ -235,6 +237,7 @@ hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cn
     wp.part_buf = part_buf;
     wp.part_cnt = part_cnt;
     w64_softmax_policy(p.in_prec, &wp.tau, &wp.lazy);
+    wp.skew = (uint32_t)tuning().w64_skew.load(std::memory_order_relaxed);
     wp.rope_cos = p.rope_cos; wp.rope_sin = p.rope_sin; wp.rope_tb = p.rope_tb;
     if (p.rope_cos) {  // fused-RoPE instantiations exist for O in the operand type only (runtime.hip asks first)
         if (p.out_prec != p.in_prec) return hipErrorNotSupported;
@@ -286,6 +289,7 @@ hipError_t launch_fwd_w64_i8(const FwdParams& p, const QuantViews& v, float* par
     wp.part_cnt = part_cnt;
     uint32_t lazy_unused = 0;
     w64_softmax_policy(P_FP16, &wp.tau, &lazy_unused);  // fp16 P: deferred / exact max only
+    wp.skew = (uint32_t)tuning().w64_skew.load(std::memory_order_relaxed);
     const uint32_t grid = w64_grid(p);
     const size_t lds = 65536 + 4 * 32 * (512 + 16) + 16;
     const bool f8 = v.v8 != nullptr;

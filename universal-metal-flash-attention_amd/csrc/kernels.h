@@ -18,7 +18,7 @@ enum SoftmaxRef : int {
 struct Tuning {
     std::atomic<int> sm_mode{SM_DEFAULT};
     std::atomic<float> sm_tau{6.0f};
-    std::atomic<int> force_w64{0}, no_w64{0}, w64_grid{0}, no_mask_flags{0}, bwd_exact{0}, bwd_dq{0}, bwd_persist{0},
+    std::atomic<int> force_w64{0}, no_w64{0}, w64_grid{0}, w64_skew{0}, no_mask_flags{0}, bwd_exact{0}, bwd_dq{0}, bwd_persist{0},
         bwd_separate_delta{0}, no_split{0}, force_split{0}, no_dma{0}, bn64{0};
 };
 Tuning& tuning();
@@ -92,7 +92,9 @@ hipError_t launch_dequant(const DequantParams& p, hipStream_t stream);
 hipError_t launch_cast_f16(const void* src, int prec, void* dst, int64_t n, uint32_t* overflow, hipStream_t stream);
 // rowc[0 .. n) = -lse * log2 e, rowc[n .. 2n) = -dvec: what bwd16_dq leaves for bwd16_dkdv, for a dK / dV-only call
 hipError_t launch_bwd16_rowc(const float* lse, const float* dvec, float* rowc, int64_t n, hipStream_t stream);
-hipError_t launch_group_sum(const float* src, float* dst, uint32_t B, uint32_t H, uint32_t Hkv, int64_t slab, hipStream_t stream);
+// dst: [B, Hkv, slab] in out_prec (fp32 default; fp16 / bf16: rounded once after the fp32 sum)
+hipError_t launch_group_sum(const float* src, void* dst, uint32_t B, uint32_t H, uint32_t Hkv, int64_t slab, hipStream_t stream,
+                            int out_prec = P_FP32);
 
 // Runtime-quantised path (fa_quant.hip): fused symmetric quantiser for Q, K, V + int8-QK^T forward.
 struct QuantViews {

@@ -123,6 +123,61 @@ mfa_error_t umfa_attention_backward_stream(mfa_context_t context, void* stream, 
     return e == hipSuccess ? MFA_SUCCESS : e == hipErrorInvalidValue ? MFA_ERROR_INVALID_ARGS : MFA_ERROR_EXECUTION_FAILED;
 }
 
+// MI355X extra: the in-stream backward for grouped-query attention WITHOUT expanded K / V (the reference's route is
+// repeat_interleave of K and V before both passes, metal_sdpa_backend.cpp:1694-1702): k, v are [B, Hkv, Skv, D]; query head
+// h reads K / V head h / (Hq / Hkv) in place; dK / dV are produced per query head in fp32 scratch and summed over each
+// group (deterministic order) into [B, Hkv, Skv, D] in the operand type or fp32.  16-bit MFMA backward only (head_dim
+// 64 / 128 / 256, 16-bit operands): other calls return MFA_ERROR_INVALID_ARGS and the caller expands K / V itself.
+mfa_error_t umfa_attention_backward_gqa_stream(mfa_context_t context, void* stream, const void* dout, const void* q,
+                                               const void* k, const void* v, const void* out, const float* softmax_lse,
+                                               void* dq, void* dk, void* dv, float* d_buffer, uint32_t batch_size,
+                                               uint32_t seq_len_q, uint32_t seq_len_kv, uint32_t num_heads,
+                                               uint32_t num_kv_heads, uint16_t head_dim, float softmax_scale, bool causal,
+                                               int32_t input_precision, bool grads_in_input_type, bool out_in_input_type) {
+    Context* ctx = as_ctx(context);
+    if (!ctx || !dout || !q || !k || !v || !out || !softmax_lse || !dq || !dk || !dv || !d_buffer) return MFA_ERROR_INVALID_ARGS;
+    if (num_kv_heads == 0 || num_kv_heads > num_heads || num_heads % num_kv_heads) return MFA_ERROR_INVALID_ARGS;
+    if ((size_t)batch_size * num_heads * seq_len_q * seq_len_kv == 0) return MFA_SUCCESS;
+    BwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.dout = dout; p.q = q; p.k = k; p.v = v; p.o = (const float*)out; p.lse = softmax_lse;
+    p.dq = (float*)dq; p.dvec = d_buffer;
+    p.B = batch_size; p.H = num_heads; p.Hkv = num_kv_heads; p.Sq = seq_len_q; p.Skv = seq_len_kv; p.D = head_dim;
+    p.scale = softmax_scale; p.causal = causal ? 1 : 0;
+    p.in_prec = dense_prec(input_precision); p.dout_prec = p.in_prec;
+    p.grad_in_type = grads_in_input_type ? 1 : 0;
+    p.o_in_type = (out_in_input_type && p.in_prec != P_FP32) ? 1 : 0;
+    const bool grouped = num_kv_heads != num_heads;
+    p.dkdv_fp32 = grouped ? 1 : 0;
+    p.dk = (float*)dk; p.dv = (float*)dv;  // (alignment check below; replaced by scratch when grouped)
+    if (tuning().bwd_exact.load(std::memory_order_relaxed) || !bwd_16_supported(p)) return MFA_ERROR_INVALID_ARGS;
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    const int dev = stream_device((hipStream_t)stream);
+    DeviceGuard guard(dev);
+    StreamScratch& sc = ctx->pool(dev, (hipStream_t)stream);
+    const size_t nr = (size_t)batch_size * num_heads * seq_len_q, nkvq = (size_t)batch_size * num_heads * seq_len_kv * head_dim;
+    p.rowc = (float*)sc.rowc.ensure(2 * nr * sizeof(float), (hipStream_t)stream);
+    if (!p.rowc) return MFA_ERROR_MEMORY_ALLOCATION;
+    if (grouped) {
+        float* tmp = (float*)sc.workspace.ensure(2 * nkvq * sizeof(float) + 256, (hipStream_t)stream);
+        if (!tmp) return MFA_ERROR_MEMORY_ALLOCATION;
+        p.dk = tmp;
+        p.dv = tmp + nkvq;
+    }
+    const char* name = "none";
+    hipError_t e = launch_bwd_16(p, (hipStream_t)stream, &name);
+    ctx->last_kernel = name;
+    if (e != hipSuccess) return e == hipErrorInvalidValue ? MFA_ERROR_INVALID_ARGS : MFA_ERROR_EXECUTION_FAILED;
+    if (grouped) {
+        const int oprec = grads_in_input_type ? p.in_prec : P_FP32;
+        const int64_t slab = (int64_t)seq_len_kv * head_dim;
+        if (launch_group_sum(p.dk, dk, batch_size, num_heads, num_kv_heads, slab, (hipStream_t)stream, oprec) != hipSuccess ||
+            launch_group_sum(p.dv, dv, batch_size, num_heads, num_kv_heads, slab, (hipStream_t)stream, oprec) != hipSuccess)
+            return MFA_ERROR_EXECUTION_FAILED;
+    }
+    return MFA_SUCCESS;
+}
+
 int32_t mfa_quantized_forward_with_lse(mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, mfa_buffer_t v,
                                        mfa_buffer_t out, mfa_buffer_t lse, mfa_buffer_t mask, uint32_t batch_size,
                                        uint32_t seq_len_q, uint32_t seq_len_kv, uint32_t num_heads, uint16_t head_dim,

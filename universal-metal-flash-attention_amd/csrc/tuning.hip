@@ -43,6 +43,7 @@ Tuning& tuning() {
         x->force_w64.store(env_flag("UMFA_FORCE_W64"));
         x->no_w64.store(env_flag("UMFA_NO_W64"));
         x->w64_grid.store(env_int("UMFA_W64_GRID", 0));
+        x->w64_skew.store(env_int("UMFA_W64_SKEW", 0));
         x->no_mask_flags.store(getenv("UMFA_NO_MASK_FLAGS") != nullptr);
         x->bwd_exact.store(getenv("UMFA_BWD_EXACT") != nullptr);
         x->bwd_dq.store(env_int("UMFA_BWD_DQ", 0));
@@ -78,7 +79,7 @@ bool set_tuning(const char* name, const char* value) {
         return true;
     }
     struct { const char* n; std::atomic<int>* v; bool flag; } tab[] = {
-        {"force_w64", &t.force_w64, true}, {"no_w64", &t.no_w64, true}, {"w64_grid", &t.w64_grid, false},
+        {"force_w64", &t.force_w64, true}, {"no_w64", &t.no_w64, true}, {"w64_grid", &t.w64_grid, false}, {"w64_skew", &t.w64_skew, false},
         {"no_mask_flags", &t.no_mask_flags, true}, {"bwd_exact", &t.bwd_exact, true}, {"bwd_dq", &t.bwd_dq, false},
         {"bwd_persist", &t.bwd_persist, true}, {"bwd_separate_delta", &t.bwd_separate_delta, true},
         {"no_split", &t.no_split, true}, {"force_split", &t.force_split, false}, {"no_dma", &t.no_dma, true},

@@ -45,7 +45,7 @@ def release_scratch(stream=None, all_streams: bool = False) -> None:
 
 
 # launcher switches (include/umfa_abi.h umfa_set_option); the library's defaults, for options() to restore
-_OPTION_DEFAULTS = {"softmax_reference": "default", "softmax_tau": "6", "force_w64": "0", "no_w64": "0", "w64_grid": "0",
+_OPTION_DEFAULTS = {"softmax_reference": "default", "softmax_tau": "6", "force_w64": "0", "no_w64": "0", "w64_grid": "0", "w64_skew": "0",
                     "no_mask_flags": "0", "bwd_exact": "0", "bwd_dq": "0", "bwd_persist": "0", "no_split": "0",
                     "force_split": "0", "no_dma": "0", "bn64": "0"}
 _option_state = {}
@@ -257,6 +257,30 @@ def quantized_attention_backward_stream(dout, q, k, v, o32, lse, *, scale=None, 
         vp(lse), vp(dq), vp(dk), vp(dv), vp(status), B, Sq, Skv, H, D, float(scale), bool(causal), 4 if bits == 4 else 3,
         _quant_mode(quant_mode), _PREC[q.dtype]))
     return dq, dk, dv, status
+
+
+def attention_backward_gqa(dout, q, k, v, o, lse, *, scale: float, causal: bool = False):
+    """dQ [B,Hq,Sq,D], dK, dV [B,Hkv,Skv,D] of grouped-query attention with K / V read IN PLACE (no repeat_interleave
+    copies): umfa_attention_backward_gqa_stream, in-stream, gradients in q.dtype.  Returns None when the 16-bit MFMA
+    backward cannot serve the call (fp32 operands, head_dim other than 64 / 128 / 256): the caller then expands K / V."""
+    B, Hq, Sq, D = q.shape
+    Hkv, Skv = k.shape[1], k.shape[2]
+    for t in (dout, q, k, v, o, lse):
+        assert t.is_cuda and t.is_contiguous()
+    if q.dtype == torch.float32 or D not in (64, 128, 256) or Hq % Hkv:
+        return None
+    assert o.dtype in (torch.float32, q.dtype) and lse.dtype == torch.float32 and dout.dtype == q.dtype
+    dq = torch.empty_like(q)
+    dk, dv = torch.empty_like(k), torch.empty_like(v)
+    dvec = torch.empty((B * Hq * Sq,), dtype=torch.float32, device=q.device)
+    rc = _lib.umfa_attention_backward_gqa_stream(
+        context(), ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream),
+        *(ctypes.c_void_p(t.data_ptr()) for t in (dout, q, k, v, o, lse, dq, dk, dv, dvec)),
+        B, Sq, Skv, Hq, Hkv, D, float(scale), bool(causal), _PREC[q.dtype], True, o.dtype != torch.float32)
+    if rc == 1:
+        return None
+    _check_error(rc)
+    return dq, dk, dv
 
 
 def gpu_latency() -> float:

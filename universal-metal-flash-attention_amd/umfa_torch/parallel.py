@@ -66,7 +66,12 @@ def all_gather_output(o_local: torch.Tensor, mode: str, full_shape, group=None) 
     sizes = [shard_range(n, world, r)[1] - shard_range(n, world, r)[0] for r in range(world)]
     if min(sizes) == max(sizes):
         buf = o_local.new_empty((world,) + tuple(o_local.shape))
-        dist.all_gather_into_tensor(buf.view(-1), o_local.contiguous().view(-1), group=group)  # flat: the form every backend takes
+        if o_local.is_cuda and dist.get_backend(group) == "gloo":  # one-device rehearsal: gloo gathers on the host
+            host = torch.empty(buf.shape, dtype=buf.dtype)
+            dist.all_gather_into_tensor(host.view(-1), o_local.contiguous().view(-1).cpu(), group=group)
+            buf.copy_(host)
+        else:
+            dist.all_gather_into_tensor(buf.view(-1), o_local.contiguous().view(-1), group=group)  # flat: the form every backend takes
         full = buf.movedim(0, axis)  # [.., world, shard, ..]: adjacent to the sharded axis
         shp = list(o_local.shape)
         shp[axis] *= world
@@ -166,7 +171,12 @@ def overlapped_sharded_sdpa(q, k, v, out_full: torch.Tensor, *, attention_fn: Ca
             ev.record(torch.cuda.current_stream(out_full.device))
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(ev)
-                dist.all_gather_into_tensor(grp, mine, group=group)
+                if dist.get_backend(group) != "gloo":
+                    dist.all_gather_into_tensor(grp, mine, group=group)  # RCCL: sendbuff = recvbuff + rank * count is its in-place form
+                else:  # code-path rehearsal on one device (bench.py UMFA_BENCH_ONE_DEVICE): gloo gathers on the host
+                    host = torch.empty(grp.shape, dtype=grp.dtype)
+                    dist.all_gather_into_tensor(host, mine.cpu(), group=group)
+                    grp.copy_(host)
         else:
             dist.all_gather_into_tensor(grp, mine.clone(), group=group)  # gloo (CPU tests) has no in-place form
     if on_gpu and world > 1:

@@ -105,6 +105,41 @@ class _FlashAttentionFn(torch.autograd.Function):
         return dq, dk, dv, None, None
 
 
+class _GqaFlashAttentionFn(torch.autograd.Function):
+    """Training with grouped K / V heads WITHOUT the reference's repeat_interleave copies (metal_sdpa_backend.cpp:1694-1702):
+    the forward reads K / V through head-stride-0 views (the g query heads of a KV head become the heads of a
+    (batch x kv-head) slab), the backward reads them in place (umfa_attention_backward_gqa_stream) and sums dK / dV over
+    each group inside the library.  Saves the expanded K and V (2 x Hq / Hkv x their size) in the autograd graph."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, causal: bool, scale: float):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        B, Hq, Sq, D = q.shape
+        Hkv, Skv = k.shape[1], k.shape[2]
+        g = Hq // Hkv
+        qv = q.view(B * Hkv, g, Sq, D)
+        kv = k.view(B * Hkv, 1, Skv, D).expand(B * Hkv, g, Skv, D)
+        vv = v.view(B * Hkv, 1, Skv, D).expand(B * Hkv, g, Skv, D)
+        out, lse = ops.attention_forward(qv, kv, vv, scale=scale, causal=causal, out_dtype=q.dtype, return_lse=True)
+        out = out.view(B, Hq, Sq, D)
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.causal, ctx.scale = causal, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        res = ops.attention_backward_gqa(dout.to(q.dtype).contiguous(), q, k, v, out, lse, scale=float(ctx.scale), causal=bool(ctx.causal))
+        if res is None:  # shapes the MFMA backward does not serve: the reference's route, here only in the backward
+            g = q.shape[1] // k.shape[1]
+            dq, dke, dve = ops.attention_backward(dout.to(q.dtype).contiguous(), q, k.repeat_interleave(g, 1).contiguous(),
+                                                  v.repeat_interleave(g, 1).contiguous(), out, lse, scale=float(ctx.scale),
+                                                  causal=bool(ctx.causal))
+            B, Hkv, Skv, D = k.shape
+            res = dq, dke.view(B, Hkv, g, Skv, D).sum(2).to(k.dtype), dve.view(B, Hkv, g, Skv, D).sum(2).to(v.dtype)
+        return res[0], res[1], res[2], None, None
+
+
 class _QuantizedFlashAttentionFn(torch.autograd.Function):
     """MetalQuantizedFlashAttentionFn (:3139-3397): runtime quantisation of Q, K, V; STE backward."""
 
@@ -226,6 +261,14 @@ def scaled_dot_product_attention(query, key, value, attn_mask: Optional[torch.Te
             zc = _gqa_zero_copy(q, k, v, attn_mask, dropout_p, is_causal, scale)
             if zc is not None:
                 return zc
+            if (q.dim() == 4 and k.dim() == 4 and v.dim() == 4 and attn_mask is None and dropout_p == 0.0 and _quant_precision == QUANT_NONE
+                    and q.is_cuda and k.is_cuda and v.is_cuda and q.dtype in (torch.float16, torch.bfloat16) and k.dtype == q.dtype
+                    and v.dtype == q.dtype and k.shape == v.shape and q.size(0) == k.size(0) and q.size(3) == k.size(3)
+                    and q.size(3) in (64, 128, 256) and (q.requires_grad or k.requires_grad or v.requires_grad)):
+                # training: no expanded K / V anywhere (forward through stride-0 views, backward in place)
+                _bump("fp32_autograd")
+                sm = float(scale) if scale is not None else float(q.size(-1)) ** -0.5
+                return _GqaFlashAttentionFn.apply(q, k, v, bool(is_causal), sm)
             k = k.repeat_interleave(hq // hkv, -3).contiguous()
             v = v.repeat_interleave(hq // hkv, -3).contiguous()
 
