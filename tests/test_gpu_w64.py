@@ -1,4 +1,4 @@
-"""GPU parity of the 64-rows-per-wave persistent forward (fa_fwd16_w64, head_dim 128, no mask, non-causal,
+"""GPU parity of the 64-rows-per-wave persistent forward (fa_fwd16_w64, head_dim 128 and 64, no mask, non-causal,
 Sq % 256 == 0, Skv % 64 == 0) against the CPU oracle, through the in-stream C ABI.  The shapes are chosen to
 cover: one-tile and odd/even tile counts (the two score sets swap roles), items cut into many parts by the
 slice boundaries (small grids: every workgroup gets one tile), whole items, the mix of both (FLUX), strided
@@ -245,6 +245,79 @@ def test_w64_ragged_shapes(shape):
     assert torch.equal(o, umfa_torch.attention_forward(q, k, v, causal=causal, out_dtype=torch.float32))
 
 
+@pytest.mark.parametrize("shape", [(1, 2, 256, 64, False), (1, 2, 256, 192, False), (2, 3, 512, 256, False), (1, 5, 768, 448, False),
+                                   (1, 2, 256, 1024, False), (1, 2, 512, 512, True), (2, 3, 768, 768, True), (1, 2, 1024, 448, True),
+                                   (1, 4, 2048, 2048, True), (1, 2, 512, 1000, False), (2, 2, 1100, 777, False),
+                                   (1, 3, 1280, 1100, True), (1, 1, 256, 65, True)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_w64_head_dim_64_vs_oracle(shape, dt):
+    """head_dim 64 on the same structure (fa_fwd16_w64d64_*: 32 MFMAs per key tile, 128-byte rows in the tile images):
+    whole and cut items, causal, ragged Sq / Skv, LSE, both output types, bitwise repeatable"""
+    import umfa_torch
+    B, H, Sq, Skv, causal = shape
+    torch.manual_seed(Sq + 5 * Skv + 64)
+    q = torch.randn(B, H, Sq, 64, device="cuda", dtype=dt)
+    k = torch.randn(B, H, Skv, 64, device="cuda", dtype=dt)
+    v = torch.randn(B, H, Skv, 64, device="cuda", dtype=dt)
+    pool = torch.full((B * H * Sq * 64 + 2 * 65536,), 7.0, device="cuda", dtype=torch.float32)
+    out = pool[65536:65536 + B * H * Sq * 64].view(B, H, Sq, 64)
+    o, lse = umfa_torch.attention_forward(q, k, v, causal=causal, out_dtype=torch.float32, return_lse=True, out=out)
+    kern = umfa_torch.last_kernel()
+    assert kern == ("fa_fwd16_w64<bf16,64>" if dt == torch.bfloat16 else "fa_fwd16_w64<fp16,64>"), kern
+    assert bool((pool[:65536] == 7.0).all()) and bool((pool[65536 + B * H * Sq * 64:] == 7.0).all())
+    ref, ref_lse = _oracle().sdpa_forward(npy(q), npy(k), npy(v), causal=causal, return_lse=True)
+    assert np.isfinite(o.cpu().numpy()).all()
+    check_forward(o.cpu().numpy(), ref, dt, kern, "w64_d64", inputs=(npy(q), npy(k), npy(v)), causal=causal)
+    assert np.abs(lse.cpu().numpy().reshape(ref_lse.shape) - ref_lse).max() < 2e-2
+    assert torch.equal(o, umfa_torch.attention_forward(q, k, v, causal=causal, out_dtype=torch.float32))
+    o16 = umfa_torch.attention_forward(q, k, v, causal=causal)
+    assert o16.dtype == dt
+    assert (o16.float() - o).abs().max() <= (2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11) * o.abs().max() * 1.01
+    # the same call on the 128-row kernel (exact running max): two independent kernels, one answer
+    with umfa_torch.options(no_w64=1):
+        o128 = umfa_torch.attention_forward(q, k, v, causal=causal, out_dtype=torch.float32)
+        assert umfa_torch.last_kernel().startswith("fa_fwd16<")
+    assert float((o - o128).abs().max()) <= (2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10) * float(o128.abs().max())
+
+
+@pytest.mark.parametrize("mode", ["exact", "deferred", "lazy"])
+def test_w64_head_dim_64_softmax_references_and_strides(mode):
+    """every softmax-reference policy of the head_dim 64 kernel, on strided [B, S, H, D] storage, 8 key tiles per item"""
+    import umfa_torch
+    torch.manual_seed(11)
+    B, H, S, D = 2, 4, 512, 64
+    qs, ks, vs = (torch.randn(B, S, H, D, device="cuda", dtype=torch.bfloat16) * 2.0 for _ in range(3))
+    q, k, v = (t.transpose(1, 2) for t in (qs, ks, vs))
+    with umfa_torch.options(softmax_reference=mode):
+        o = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
+        kern = umfa_torch.last_kernel()
+        assert kern == "fa_fwd16_w64<bf16,64>"
+        ref = _oracle().sdpa_forward(bits(q), bits(k), bits(v))
+        check_forward(o.cpu().numpy(), ref, torch.bfloat16, kern, "w64_d64_" + mode, inputs=(bits(q), bits(k), bits(v)))
+
+
+def test_w64_head_dim_64_lazy_overflow_restart():
+    import umfa_torch
+    torch.manual_seed(6)
+    B, H, Sq, Skv, D = 1, 3, 512, 768, 64
+    q = torch.randn(B, H, Sq, D, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(B, H, Skv, D, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn(B, H, Skv, D, device="cuda", dtype=torch.bfloat16)
+    d = q[:, 1].float().mean(dim=1, keepdim=True)
+    d = d / d.norm(dim=-1, keepdim=True)
+    kk = k.float()
+    kk[:, 1, 300:] += 4000.0 * d
+    k = kk.to(torch.bfloat16)
+    o = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
+    assert umfa_torch.last_kernel() == "fa_fwd16_w64<bf16,64>"
+    ref = _oracle().sdpa_forward(bits(q), bits(k), bits(v))
+    assert torch.isfinite(o).all()
+    check_forward(o.cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel(), "w64_d64_lazy_overflow", scale_max=1.5)
+    with umfa_torch.options(softmax_reference="exact"):
+        oe = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
+    assert float((o[:, 1] - oe[:, 1]).abs().max()) <= 8e-3 * float(oe[:, 1].abs().max())
+
+
 def test_w64_small_ragged_sq_stays_on_the_128_row_kernel():
     import umfa_torch
     q, k, v = (torch.randn(1, 2, 300, 128, device="cuda", dtype=torch.bfloat16) for _ in range(3))
@@ -265,3 +338,18 @@ def test_w64_dispatch_gate(shape, causal, expect_w64):
     umfa_torch.attention_forward(q, k, k, causal=causal)
     torch.cuda.synchronize()
     assert umfa_torch.last_kernel().startswith("fa_fwd16_w64") == expect_w64, umfa_torch.last_kernel()
+
+
+@pytest.mark.parametrize("shape,causal,expect_w64", [((1, 24, 4096, 4096), False, True), ((8, 16, 1024, 1024), False, True),
+                                                     ((1, 40, 1024, 1024), False, False), ((4, 16, 1024, 1024), True, False),
+                                                     ((5, 16, 1024, 1024), True, False), ((8, 16, 1024, 1024), True, True),
+                                                     ((4, 16, 4096, 4096), True, True)])
+def test_w64_dispatch_gate_head_dim_64(shape, causal, expect_w64):
+    """head_dim 64: half the MFMA time per tile step, so the gate sits higher (BASELINE config 2 stays on the 128-row kernel)"""
+    import umfa_torch
+    B, H, Sq, Skv = shape
+    q = torch.randn(B, H, Sq, 64, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(B, H, Skv, 64, device="cuda", dtype=torch.bfloat16)
+    umfa_torch.attention_forward(q, k, k, causal=causal)
+    torch.cuda.synchronize()
+    assert umfa_torch.last_kernel() == ("fa_fwd16_w64<bf16,64>" if expect_w64 else "fa_fwd16<bf16,64>"), umfa_torch.last_kernel()

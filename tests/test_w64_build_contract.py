@@ -50,7 +50,8 @@ def test_compiler_stays_in_the_lower_register_halves(asm):
     kernels = _kernels(asm)
     # bf16 / fp16 x {fp32, 16-bit O} x {causal, not} + bf16 / fp16 x {causal, not} with the fused Q rotation (16-bit O)
     # + int8 x {causal, not} + int8-fp8 x {causal, not}
-    assert len(kernels) == 16, sorted(kernels)
+    # + the head_dim 64 family: bf16 / fp16 x {fp32, 16-bit O} x {causal, not}
+    assert len(kernels) == 24, sorted(kernels)
     for name, lines in kernels.items():
         in_asm, vmax, amax, n_mfma, loop_scratch = False, 0, 0, 0, 0
         mfma_seen = 0
@@ -90,7 +91,7 @@ def test_every_kernel_gets_512_registers(asm):
     nxt = [int(x) for x in re.findall(r"\.amdhsa_next_free_vgpr (\d+)", asm)]
     acc = [int(x) for x in re.findall(r"\.amdhsa_accum_offset (\d+)", asm)]
     # the hardware allocates in granules of 8 registers: 511 (clobbers name v254 / a254, the highest names hipcc does not reserve) is 512
-    assert len(nxt) == 16 and all((n + 7) // 8 * 8 == 512 for n in nxt), nxt
+    assert len(nxt) == 24 and all((n + 7) // 8 * 8 == 512 for n in nxt), nxt
     assert all(a == 256 for a in acc), acc
 
 
@@ -102,9 +103,11 @@ def test_generated_streams_are_current(tmp_path):
     env["W64_OUT"] = str(tmp_path / "b16.inc")
     env["W64_OUT_I8"] = str(tmp_path / "bi8.inc")
     env["W64_OUT_I8F8"] = str(tmp_path / "bi8f8.inc")
+    env["W64_OUT_D64"] = str(tmp_path / "bd64.inc")
     regs = (CSRC / "fa_fwd16_w64_regs.inc").read_text()
     subprocess.check_call([sys.executable, str(ROOT / "tools" / "gen_w64_body.py")], env=env, stdout=subprocess.DEVNULL)
     assert (tmp_path / "b16.inc").read_text() == (CSRC / "fa_fwd16_w64_body.inc").read_text()
+    assert (tmp_path / "bd64.inc").read_text() == (CSRC / "fa_fwd16_w64d64_body.inc").read_text()
     assert (tmp_path / "bi8.inc").read_text() == (CSRC / "fa_fwd_w64_i8_body.inc").read_text()
     assert (tmp_path / "bi8f8.inc").read_text() == (CSRC / "fa_fwd_w64_i8f8_body.inc").read_text()
     assert (CSRC / "fa_fwd16_w64_regs.inc").read_text() == regs  # the helper file is rewritten in place: unchanged

@@ -46,9 +46,14 @@ class Cfg:
     row max runs on those floats (monotone in s) and the one v_fma_f32 per score that applies scale and reference max
     takes the bias out with its addend (nmb = -m - 12582912 c).  W64_I8_BIAS=0 (lab, with -DW64_I8_NOBIAS) keeps the
     explicit in-place conversion (I2F)."""
-    def __init__(self, i8, f8=False):
+    def __init__(self, i8, f8=False, d64=False):
         self.i8 = i8
         self.f8 = f8                     # fp8 (e4m3) P and V: O^T += V^T P^T on v_mfma_scale_f32_32x32x64_f8f6f4 (see Cfg8 notes)
+        # head_dim 64 (16-bit kernels only, fa_fwd16_w64d64): half the k-steps of S = K Q^T and two d-blocks of O^T instead of
+        # four -- 32 MFMAs per 64-key tile for the same softmax work, rows of 128 bytes in the K / V tile images (the int8
+        # kernels' K geometry).  The O^T register map is head_dim 128's with d-blocks 0 and 1 of each q-block in use.
+        self.d64 = d64
+        assert not (d64 and (i8 or f8))
         self.i2f = i8 and os.environ.get("W64_I8_BIAS", "1") == "0"
         # row sums on the matrix pipe (16-bit P kernels): l += sum of the ROUNDED P fragment by v_mfma_f32_4x4x4_16b against an
         # all-ones operand (a lane-local sum: block b = lane / 4, column j = lane % 4 -> the lane's own four values; 8-cycle
@@ -57,18 +62,21 @@ class Cfg:
         # (FLUX -3.5 %, B4 H16 S8192 causal -3.8 %, int8 -1 %): alternating with 32x32x16 MFMAs a 4x4x4 costs the matrix
         # pipe 16 cycles, 256 per tile, and the loop is not VALU-issue bound enough to win them back (profiles/r3/lab_notes.md).
         self.msum = (not f8) and os.environ.get("W64_MSUM", "0") == "1"
-        self.NQK = 16 if i8 else 32      # MFMAs of the QK^T phase = first gap index of the PV phase
-        self.KS = 4 if i8 else 8         # k-steps per 32-key block
+        self.NQK = 16 if (i8 or d64) else 32      # MFMAs of the QK^T phase = first gap index of the PV phase
+        self.KS = 4 if (i8 or d64) else 8         # k-steps per 32-key block
         self.HALF = self.NQK // 2        # QK^T MFMAs per key block
-        self.NPV = 20 if f8 else 32      # gap slots of the PV phase (a 64-cycle fp8 MFMA takes two 32-cycle slots)
+        self.NDB = 2 if d64 else 4       # 32-row d-blocks of O^T
+        self.PVS = 2 * self.NDB          # PV MFMAs per 16-key step (d-blocks x two q-blocks)
+        self.NPV = 20 if f8 else 4 * self.PVS  # gap slots of the PV phase (a 64-cycle fp8 MFMA takes two 32-cycle slots)
         self.NG = self.NQK + self.NPV    # gaps per tile
-        self.KDMA = 2 if i8 else 4       # 1-KiB LDS-DMA pieces of a K tile per wave
-        self.VDMA = 2 if f8 else 4       # ... of a V tile
-        self.KB_BYTES = 4096 if i8 else 8192  # LDS bytes of one 32-key block of the K tile image
+        self.KDMA = 2 if (i8 or d64) else 4       # 1-KiB LDS-DMA pieces of a K tile per wave
+        self.VDMA = 2 if (f8 or d64) else 4       # ... of a V tile
+        self.KB_BYTES = 4096 if (i8 or d64) else 8192  # LDS bytes of one 32-key block of the K tile image
         # per-gap filler budget (cost-model cycles).  The tile's filler work must FIT: what does not is forced into its deadline
         # gap, and the int8 body had 248 cycles piled into gap 45, the bf16 body 128 into gap 61 -- right in front of the
         # tile's barrier, where nothing overlaps them (gap stamps, profiles/r2/lab_notes.md).  Defaults = total / gaps, rounded up.
-        self.budget = int(os.environ.get("W64_BUDGET_F8", "40")) if f8 else int(os.environ.get("W64_BUDGET_I8", "36")) if i8 else BUDGET
+        self.budget = int(os.environ.get("W64_BUDGET_F8", "40")) if f8 else int(os.environ.get("W64_BUDGET_I8", "36")) if i8 else \
+            int(os.environ.get("W64_BUDGET_D64", "48")) if d64 else BUDGET
 
     def pv_gap(self, qb, db):
         """gap slot of the fp8 PV MFMA of (q-block, d-block); db = 4: the row-sum MFMA of the q-block"""
@@ -117,9 +125,21 @@ class Roles:
         self.new, self.old = new, old
 
 
+LAB_SHAPE16 = os.environ.get("W64_LAB_SHAPE16") == "1"  # lab, TIMING ONLY (results are garbage of the right distribution): every
+# 32x32x16 MFMA becomes two 16x16x32 on the same operand registers, each accumulator quarter fed by every other k-step -- the
+# same FLOPs, LDS reads, vector work and operand statistics; measures what the MFMA shape is worth at the power cap
+
+
 def qk_mfma(R, kb, ks, qb):
     t = tup(R.new, kb, qb)
     c = "0" if ks == 0 else t
+    if LAB_SHAPE16 and not C.i8:
+        b = base(R.new, kb, qb)
+        out = []
+        for q in (2 * (ks & 1), 2 * (ks & 1) + 1):
+            tq = f"v[{b + 4 * q}:{b + 4 * q + 3}]"
+            out.append(f'asm volatile(W64_MFMA16 " {tq}, %0, %1, {"0" if ks < 2 else tq}" :: "v"(kf[{kb}][{ks}]), "{QF_CLASS}"(qf[{qb}][{ks}]));')
+        return " ".join(out)
     if ks == 0 and C.f8:
         return f'asm volatile(W64_MFMA_QK " {t}, %0, %1, v[{F8_BIAS}:{F8_BIAS + 15}]" :: "v"(kf[{kb}][{ks}]), "{QF_CLASS}"(qf[{qb}][{ks}]));'
     if ks == 0 and C.i8 and not C.i2f:
@@ -171,6 +191,13 @@ def l8_mfma(R, qb):
 def pv_mfma(R, st, db, qb):
     b = base(R.old, st >> 1, qb) + 8 * (st & 1)
     o = oreg(qb, db)
+    if LAB_SHAPE16:
+        r = O_BASE + 16 * (4 * qb + db)
+        out = []
+        for q in (2 * (st & 1), 2 * (st & 1) + 1):
+            oq = f"a[{r + 4 * q}:{r + 4 * q + 3}]"
+            out.append(f'asm volatile(W64_MFMA16 " {oq}, %0, v[{b}:{b + 3}], {oq}" :: "v"(vf[{st}][{db}]));')
+        return " ".join(out)
     return f'asm volatile(W64_MFMA " {o}, %0, v[{b}:{b + 3}], {o}" :: "v"(vf[{st}][{db}]));'
 
 
@@ -282,11 +309,11 @@ def exp_streams():
             prev = None
             for r in list(range(0, 16, 2)) + [None]:
                 if r is not None:
-                    dl = C.NQK + 8 * (2 * kb + (r >> 3)) - 2
+                    dl = C.NQK + C.PVS * (2 * kb + (r >> 3)) - 2
                     ops.append((("EXP", kb, qb, r), 0, dl))
                     ops.append((("EXP", kb, qb, r + 1), 0, dl))
                 if prev is not None:
-                    dl = C.NQK + 8 * (2 * kb + (prev >> 3)) - 2
+                    dl = C.NQK + C.PVS * (2 * kb + (prev >> 3)) - 2
                     if not C.msum:
                         ops.append((("ADD", kb, qb, prev), 0, dl))
                         ops.append((("ADD", kb, qb, prev + 1), 0, dl))
@@ -305,7 +332,7 @@ def msum_stream():
     for st in range(4):
         for h in (0, 1):
             for qb in (0, 1):  # consecutive ones go to different accumulators; the scheduler puts at most one in a gap
-                ops.append((("MSUM", st, qb, h), C.NQK + 8 * st, C.NG - 4))
+                ops.append((("MSUM", st, qb, h), C.NQK + C.PVS * st, C.NG - 4))
     return ops
 
 
@@ -340,8 +367,8 @@ def bar_gap():
 def vread_stream(have_new=True):
     ops = []
     for st in range(4):
-        for db in range(4):
-            use = C.NQK + st * 8 + db * 2
+        for db in range(C.NDB):
+            use = C.NQK + st * C.PVS + db * 2
             early, late = max(0, use - VR_EARLY), use - VR_LATE
             if MIDBAR and have_new:  # every V read of the tile sits before the barrier (the slot is refilled behind it)
                 late = min(late, bar_gap() - 2)
@@ -385,6 +412,8 @@ def dma_stream():
     vpos = [2, 6, 8, 10] if C.i8 else [5, 13, 21, 29]
     if C.f8:
         sfx, kpos, vpos = "_F8", [1, 5], [9, 13]
+    if C.d64:
+        sfx, kpos, vpos = "_D64", [1, 9], [5, 13]
     if os.environ.get("W64_DMA_K" + sfx):
         kpos = [int(x) for x in os.environ["W64_DMA_K" + sfx].split(",")]
     if os.environ.get("W64_DMA_V" + sfx):
@@ -642,7 +671,7 @@ def check_part(placed, have_new, have_old, masked, pre=(), lazy=False):
                             assert before(("ADD", kb, qb, dst), cv), ("CVT overwrites unread score", cv)
                         assert before(("CVT", kb, qb, dst & ~1), cv), ("CVT overwrites unpacked score", cv)
                     st = 2 * kb + (r >> 3)
-                    first_use = C.NQK + 8 * st  # first PV MFMA of this 16-key step (any d-block, any q-block)
+                    first_use = C.NQK + C.PVS * st  # first PV MFMA of this 16-key step (any d-block, any q-block)
                     assert pos[cv][0] < first_use, ("P fragment packed after its first PV MFMA", cv, pos[cv], first_use)
             if have_new and lazy:
                 last_mfma = kb * C.HALF + (C.HALF - 2) + qb
@@ -691,8 +720,8 @@ def check_part(placed, have_new, have_old, masked, pre=(), lazy=False):
                 assert at > bar, ("next tile's K fragments are visible only behind the barrier", op)
     if have_old and not C.f8:
         for st in range(4):
-            for db in range(4):
-                assert pos[("VREAD", st, db)][0] < C.NQK + st * 8 + db * 2, ("V fragment read after its MFMA", st, db)
+            for db in range(C.NDB):
+                assert pos[("VREAD", st, db)][0] < C.NQK + st * C.PVS + db * 2, ("V fragment read after its MFMA", st, db)
     if have_new:
         for kb in (0, 1):
             for ks in range(C.KS):
@@ -721,7 +750,7 @@ def emit_part(lines, R, have_new, have_old, masked=False, lazy=False):
             mf += [l8_mfma(R, qb), None]
     elif have_old:
         for st in range(4):
-            for db in range(4):
+            for db in range(C.NDB):
                 for qb in (0, 1):
                     mf.append(pv_mfma(R, st, db, qb))
     else:
@@ -931,6 +960,8 @@ def main():
     emit_body(Path(os.environ["W64_OUT_I8"]) if os.environ.get("W64_OUT_I8") else csrc / "fa_fwd_w64_i8_body.inc")
     C = Cfg(True, f8=True)
     emit_body(Path(os.environ["W64_OUT_I8F8"]) if os.environ.get("W64_OUT_I8F8") else csrc / "fa_fwd_w64_i8f8_body.inc")
+    C = Cfg(False, d64=True)
+    emit_body(Path(os.environ["W64_OUT_D64"]) if os.environ.get("W64_OUT_D64") else csrc / "fa_fwd16_w64d64_body.inc")
 
 
 if __name__ == "__main__":

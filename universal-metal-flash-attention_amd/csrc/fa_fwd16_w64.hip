@@ -108,8 +108,49 @@ struct W64I8Params {
 #undef W64_CVT
 #undef W64_KERNEL
 #undef W64_MFMA_QK
-#undef W64_I8
 #undef W64_BODY_INC
+
+// head_dim 64: the same structure (tools/gen_w64_body.py Cfg(d64=True)): 32 MFMAs per 64-key tile, rows of 128 bytes in the
+// tile images, d-blocks 0 and 1 of head_dim 128's O^T register map
+#define W64_DP 64
+#define W64_BODY_INC "fa_fwd16_w64d64_body.inc"
+#undef W64_MSUM
+#undef W64_ONES_BITS
+#undef W64_LAZY_PARTS
+#define W64_T __bf16
+#define W64_MFMA "v_mfma_f32_32x32x16_bf16"
+#define W64_MFMA_QK "v_mfma_f32_32x32x16_bf16"
+#define W64_MSUM "v_mfma_f32_4x4x4_16b_bf16"
+#define W64_ONES_BITS 0x3f803f80u
+#define W64_LAZY_PARTS 1
+#define W64_CVT "v_cvt_pk_bf16_f32"
+#define W64_KERNEL fa_fwd16_w64d64_bf16
+#include "fa_fwd16_w64_kernel.inc"
+#undef W64_T
+#undef W64_MFMA
+#undef W64_MFMA_QK
+#undef W64_MSUM
+#undef W64_ONES_BITS
+#undef W64_LAZY_PARTS
+#undef W64_CVT
+#undef W64_KERNEL
+#define W64_T _Float16
+#define W64_MFMA "v_mfma_f32_32x32x16_f16"
+#define W64_MFMA_QK "v_mfma_f32_32x32x16_f16"
+#define W64_MSUM "v_mfma_f32_4x4x4_16b_f16"
+#define W64_ONES_BITS 0x3c003c00u
+#define W64_LAZY_PARTS 0
+#define W64_CVT "v_cvt_pk_f16_f32"
+#define W64_KERNEL fa_fwd16_w64d64_f16
+#include "fa_fwd16_w64_kernel.inc"
+#undef W64_T
+#undef W64_MFMA
+#undef W64_MFMA_QK
+#undef W64_CVT
+#undef W64_KERNEL
+#undef W64_BODY_INC
+#undef W64_DP
+#undef W64_I8
 // (W64_MSUM / W64_ONES_BITS / W64_LAZY_PARTS of the fp16 family stay defined for the int8 kernels below: fp16 P there too)
 
 // runtime-quantised variant: int8 QK^T, fp16 PV
@@ -161,7 +202,8 @@ static int w64_cu_count() { return device_cu_count(); }
 
 bool fwd_w64_supported(const FwdParams& p) {
     if (tuning().no_w64.load(std::memory_order_relaxed) || !fwd_16_supported(p)) return false;
-    if (p.D != 128 || p.mask_kind != MK_NONE) return false;
+    if ((p.D != 128 && p.D != 64) || p.mask_kind != MK_NONE) return false;
+    if (p.D == 64 && p.rope_cos) return false;  // the fused Q rotation exists at head_dim 128 only
     // rows are processed in blocks of 256: a ragged last block wastes its empty waves, so small ragged Sq stay on
     // the 128-row kernel; any Skv >= 64 works (a partial last key tile runs the masking variant of the tile body)
     if (p.Skv < 64 || p.Sq < 256 || (p.Sq % 256 != 0 && p.Sq < 1024)) return false;
@@ -174,7 +216,14 @@ bool fwd_w64_supported(const FwdParams& p) {
     if (!tuning().force_w64.load(std::memory_order_relaxed)) {
         const uint64_t cus = (uint64_t)w64_cu_count();
         const uint64_t nqb = (p.Sq + 255) / 256;
-        if (p.causal) {
+        if (p.D == 64) {
+            // half the MFMA time per tile step, the same prologue / drain / fold: the break-even sits higher.  us, w64 / 128-row
+            // (profiles/r3/d64_w64_vs_128row.jsonl): causal 160 jobs 31.1 / 27.6, 192 jobs 45.9 / 46.6, 256 jobs 32.4 / 36.4,
+            // 512 jobs 91.7 / 107; non-causal cut items 10 steps per CU 27.2 / 23.4, 12: 27.0 / 23.6, 16: 30.4 / 30.0,
+            // 96: 109 / 122; whole rounds B8 H16 S1024 42.1 / 46.2
+            const uint64_t items = (uint64_t)p.B * p.H * nqb, steps = items * ((p.Skv + 63) / 64);
+            if (p.causal ? (uint64_t)p.B * p.H * ((nqb + 1) / 2) * 4 < cus * 3 : (items % cus != 0 && steps < cus * 16)) return false;
+        } else if (p.causal) {
             if ((uint64_t)p.B * p.H * ((nqb + 1) / 2) * 8 < cus * 5) return false;  // 160 jobs: 78 / 85, 126 / 150, 217 / 258 us
         } else {
             // whole rounds (every workgroup one or more complete items, nothing to fold) win at any size: B1 H256 S256
@@ -249,6 +298,22 @@ hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cn
         *name = "fa_fwd16_w64<fp16,128,rope>";
         return p.causal ? launch_w64_kernel(fa_fwd16_w64_f16<_Float16, true, true>, p, wp, stream)
                         : launch_w64_kernel(fa_fwd16_w64_f16<_Float16, false, true>, p, wp, stream);
+    }
+    if (p.D == 64) {
+        const bool bf = p.in_prec == P_BF16;
+        *name = bf ? "fa_fwd16_w64<bf16,64>" : "fa_fwd16_w64<fp16,64>";
+        if (bf) {
+            if (p.causal)
+                return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64d64_bf16<float, true>, p, wp, stream)
+                                            : launch_w64_kernel(fa_fwd16_w64d64_bf16<__bf16, true>, p, wp, stream);
+            return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64d64_bf16<float, false>, p, wp, stream)
+                                        : launch_w64_kernel(fa_fwd16_w64d64_bf16<__bf16, false>, p, wp, stream);
+        }
+        if (p.causal)
+            return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64d64_f16<float, true>, p, wp, stream)
+                                        : launch_w64_kernel(fa_fwd16_w64d64_f16<_Float16, true>, p, wp, stream);
+        return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64d64_f16<float, false>, p, wp, stream)
+                                    : launch_w64_kernel(fa_fwd16_w64d64_f16<_Float16, false>, p, wp, stream);
     }
     if (p.in_prec == P_BF16) {
         *name = "fa_fwd16_w64<bf16,128>";
