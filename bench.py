@@ -510,6 +510,8 @@ def run_rank(args) -> None:
                                        f"heads dealt over {world} ranks in two chunks (umfa_torch.parallel.owned_heads), in-place all_gather_into_tensor "
                                        "per chunk on a side stream under the next chunk's kernel (RCCL over xGMI)"),
                        "gathered_equals_local": gathered_ok,
+                       **({"all_gather_form": {True: "in-place", False: "staged (in-place form refused or wrong on this runtime)"}.get(
+                           next(iter(parallel._INPLACE_OK.values()), None), "unknown")} if strong_ok and not rehearsal else {}),
                        "ranks": world},
             "settle": settle,
             **({"rehearsal": "UMFA_BENCH_ONE_DEVICE=1: all ranks on cuda:0 over gloo -- a code-path check, not a measurement"} if rehearsal else {}),

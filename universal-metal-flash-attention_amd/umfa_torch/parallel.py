@@ -142,6 +142,35 @@ def owned_heads(H: int, world: int, rank: int, chunks=None):
     return out
 
 
+_INPLACE_OK = {}
+
+
+def inplace_all_gather_ok(group, device) -> bool:
+    """Does this backend's `all_gather_into_tensor` accept input = the rank's own slice of the output (NCCL / RCCL's in-place
+    form) and produce the right answer?  Checked ONCE per (group, device) on 64 floats per rank, agreed over the ranks (MIN),
+    so that a runtime that rejects or mishandles the aliasing costs a staging copy, not the run."""
+    key = (id(group), str(device))
+    if key in _INPLACE_OK:
+        return _INPLACE_OK[key]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    ok = dist.get_backend(group) != "gloo"
+    if ok:
+        try:
+            buf = torch.full((world * 64,), -1.0, device=device, dtype=torch.float32)
+            mine = buf[rank * 64:(rank + 1) * 64]
+            mine.fill_(float(rank + 1))
+            dist.all_gather_into_tensor(buf, mine, group=group)
+            expect = torch.arange(1, world + 1, device=device, dtype=torch.float32).repeat_interleave(64)
+            ok = bool(torch.equal(buf, expect))
+        except Exception:  # noqa: BLE001  (argument validation of a torch build that refuses aliased tensors)
+            ok = False
+        flag = torch.tensor([1 if ok else 0], device=device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        ok = bool(int(flag.item()) == 1)
+    _INPLACE_OK[key] = ok
+    return ok
+
+
 def overlapped_sharded_sdpa(q, k, v, out_full: torch.Tensor, *, attention_fn: Callable, group=None, comm_stream=None,
                             chunks=None):
     """ONE [B=1, H, S, D] problem over the ranks of `group`, full O on every rank, the all-gather hidden behind compute.
@@ -160,6 +189,7 @@ def overlapped_sharded_sdpa(q, k, v, out_full: torch.Tensor, *, attention_fn: Ca
     on_gpu = out_full.is_cuda
     if on_gpu and comm_stream is None and world > 1:
         comm_stream = torch.cuda.Stream(device=out_full.device)
+    inplace = on_gpu and world > 1 and inplace_all_gather_ok(group, out_full.device)
     for a, b, g0, g1 in owned_heads(H, world, rank, chunks):
         attention_fn(q[:, a:b], k[:, a:b], v[:, a:b], out=out_full[:, a:b])
         if world == 1:
@@ -171,8 +201,10 @@ def overlapped_sharded_sdpa(q, k, v, out_full: torch.Tensor, *, attention_fn: Ca
             ev.record(torch.cuda.current_stream(out_full.device))
             with torch.cuda.stream(comm_stream):
                 comm_stream.wait_event(ev)
-                if dist.get_backend(group) != "gloo":
+                if inplace:
                     dist.all_gather_into_tensor(grp, mine, group=group)  # RCCL: sendbuff = recvbuff + rank * count is its in-place form
+                elif dist.get_backend(group) != "gloo":
+                    dist.all_gather_into_tensor(grp, mine.clone(), group=group)  # in-place form refused by this runtime: one staging copy
                 else:  # code-path rehearsal on one device (bench.py UMFA_BENCH_ONE_DEVICE): gloo gathers on the host
                     host = torch.empty(grp.shape, dtype=grp.dtype)
                     dist.all_gather_into_tensor(host, mine.cpu(), group=group)
