@@ -389,6 +389,8 @@ def test_native_sliding_window_long_sequence():
     B, H, S, D, W = 1, 4, 16384, 128, 512
     q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
     out = umfa_torch.attention_forward(q, k, v, causal=True, window=(W, 0), out_dtype=torch.float32)
+    kern = umfa_torch.last_kernel()
+    assert kern == "fa_fwd16_w64<bf16,128,window>", kern  # 256 items of 14 band tiles: one workgroup per CU
     for r0 in (0, 5000, 16383 - 64):
         rows = slice(r0, r0 + 64)
         lo = max(0, r0 - W)
@@ -399,4 +401,4 @@ def test_native_sliding_window_long_sequence():
         s = s.masked_fill(~((j <= i) & (j >= i - W)), float("-inf"))
         ref = torch.matmul(torch.softmax(s, -1), v[:, :, ks].float())
         from tolerances import check_forward
-        check_forward(out[:, :, rows].cpu().numpy(), ref.cpu().numpy(), torch.bfloat16, "fa_fwd16", f"window_rows{r0}")
+        check_forward(out[:, :, rows].cpu().numpy(), ref.cpu().numpy(), torch.bfloat16, kern, f"window_rows{r0}")

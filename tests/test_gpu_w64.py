@@ -318,6 +318,95 @@ def test_w64_head_dim_64_lazy_overflow_restart():
     assert float((o[:, 1] - oe[:, 1]).abs().max()) <= 8e-3 * float(oe[:, 1].abs().max())
 
 
+def _band(Sq, Skv, window, causal):
+    i = np.arange(Sq)[:, None]
+    j = np.arange(Skv)[None, :]
+    keep = (j >= i - window[0]) & (j <= i + window[1])
+    return keep & (j <= i) if causal else keep
+
+
+@pytest.mark.parametrize("shape,window,causal", [((1, 2, 512, 512), (100, 100), False), ((1, 3, 768, 1024), (64, 0), True),
+                                                 ((2, 2, 1024, 1024), (256, 0), True), ((1, 2, 1100, 777), (300, 50), False),
+                                                 ((1, 2, 512, 512), (0, 0), False), ((1, 1, 512, 256), (10, 10), False),
+                                                 ((1, 2, 2048, 2048), (1000, 1000), False), ((1, 2, 1024, 1024), (1024 + 128, 128), False),
+                                                 ((1, 5, 1280, 1280), (31, 97), False), ((1, 2, 256, 4096), (500, 700), False)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_w64_sliding_window_vs_oracle(shape, window, causal, dt):
+    """window=(left, right) on the one-wave-per-SIMD structure (fa_fwd16_w64<.,128,window>): every 256-row block sweeps only
+    the key tiles of its band; band-edge tiles (per wave) run the two-compare masking variant; waves whose rows see nothing in
+    a tile, rows that see no key at all (O = 0, LSE = -inf), cut items (stream-K over the band's steps), ragged Sq / Skv,
+    causal as right = 0"""
+    import umfa_torch
+    B, H, Sq, Skv = shape
+    torch.manual_seed(Sq + 3 * Skv + window[0])
+    q = torch.randn(B, H, Sq, 128, device="cuda", dtype=dt)
+    k = torch.randn(B, H, Skv, 128, device="cuda", dtype=dt)
+    v = torch.randn(B, H, Skv, 128, device="cuda", dtype=dt)
+    o, lse = umfa_torch.attention_forward(q, k, v, causal=causal, window=window, out_dtype=torch.float32, return_lse=True)
+    kern = umfa_torch.last_kernel()
+    assert kern == ("fa_fwd16_w64<bf16,128,window>" if dt == torch.bfloat16 else "fa_fwd16_w64<fp16,128,window>"), kern
+    keep = _band(Sq, Skv, window, causal)
+    from oracle.oracle import MASK_BOOL
+    ref, ref_lse = _oracle().sdpa_forward(npy(q), npy(k), npy(v), mask=np.ascontiguousarray(keep), mask_type=MASK_BOOL, return_lse=True)
+    on = o.cpu().numpy()
+    assert np.isfinite(on).all()
+    dead = ~keep.any(axis=1)  # rows that see no key: O = 0, LSE = -inf (the masked-row rule of the reference's kernels)
+    if dead.any():
+        assert (on[:, :, dead] == 0).all() and np.isneginf(lse.cpu().numpy().reshape(B, H, Sq)[:, :, dead]).all()
+    live = ~dead
+    check_forward(on[:, :, live], ref[:, :, live], dt, kern, "w64_window")
+    ln = lse.cpu().numpy().reshape(ref_lse.shape)
+    assert np.abs(ln[:, :, live] - ref_lse[:, :, live]).max() < 2e-2
+    assert torch.equal(o, umfa_torch.attention_forward(q, k, v, causal=causal, window=window, out_dtype=torch.float32))  # bitwise repeatable
+    o16 = umfa_torch.attention_forward(q, k, v, causal=causal, window=window)
+    assert o16.dtype == dt
+    assert (o16.float() - o).abs().max() <= (2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11) * o.abs().max() * 1.01
+    # the 128-row kernel's window path (exact running max, bit-identical to the bool band mask): two kernels, one answer
+    with umfa_torch.options(no_w64=1):
+        o128 = umfa_torch.attention_forward(q, k, v, causal=causal, window=window, out_dtype=torch.float32)
+        assert umfa_torch.last_kernel().startswith("fa_fwd16<")
+    assert float((o - o128).abs().max()) <= (2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10) * float(o128.abs().max())
+
+
+@pytest.mark.parametrize("mode", ["exact", "deferred", "lazy"])
+def test_w64_sliding_window_softmax_references(mode):
+    """every softmax-reference policy through the window kernel, scores scaled up (|s| of a few nats per sigma): waves whose
+    first tiles are fully masked start from the reference 0"""
+    import umfa_torch
+    torch.manual_seed(21)
+    B, H, S = 1, 4, 1536
+    q, k, v = (torch.randn(B, H, S, 128, device="cuda", dtype=torch.bfloat16) * 1.7 for _ in range(3))
+    win = (200, 120)
+    with umfa_torch.options(softmax_reference=mode):
+        o = umfa_torch.attention_forward(q, k, v, window=win, out_dtype=torch.float32)
+        kern = umfa_torch.last_kernel()
+        assert kern == "fa_fwd16_w64<bf16,128,window>"
+        from oracle.oracle import MASK_BOOL
+        ref = _oracle().sdpa_forward(bits(q), bits(k), bits(v), mask=np.ascontiguousarray(_band(S, S, win, False)), mask_type=MASK_BOOL)
+        check_forward(o.cpu().numpy(), ref, torch.bfloat16, kern, "w64_window_" + mode)
+
+
+def test_w64_sliding_window_flux_shape_dispatch_and_rows():
+    """FLUX shape +-512 without forcing: the dispatcher takes the window kernel; sampled rows against a dense band computation"""
+    import umfa_torch
+    umfa_torch.set_option("force_w64", 0)
+    torch.manual_seed(3)
+    B, H, S, D, W = 1, 24, 4096, 128, 512
+    q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    out = umfa_torch.attention_forward(q, k, v, window=(W, W), out_dtype=torch.float32)
+    kern = umfa_torch.last_kernel()
+    assert kern == "fa_fwd16_w64<bf16,128,window>", kern
+    assert torch.equal(out, umfa_torch.attention_forward(q, k, v, window=(W, W), out_dtype=torch.float32))
+    for r0 in (0, 448, 2000, 4096 - 64):
+        lo, hi_ = max(0, r0 - W), min(S, r0 + 64 + W)
+        s = torch.matmul(q[:, :, r0:r0 + 64].double(), k[:, :, lo:hi_].double().transpose(-1, -2)) * D ** -0.5
+        i = torch.arange(r0, r0 + 64, device="cuda")[:, None]
+        j = torch.arange(lo, hi_, device="cuda")[None, :]
+        s = s.masked_fill(~((j <= i + W) & (j >= i - W)), float("-inf"))
+        ref = torch.matmul(torch.softmax(s, -1), v[:, :, lo:hi_].double())
+        check_forward(out[:, :, r0:r0 + 64].cpu().numpy(), ref.cpu().numpy(), torch.bfloat16, kern, f"w64_window_flux_rows{r0}")
+
+
 def test_w64_small_ragged_sq_stays_on_the_128_row_kernel():
     import umfa_torch
     q, k, v = (torch.randn(1, 2, 300, 128, device="cuda", dtype=torch.bfloat16) for _ in range(3))

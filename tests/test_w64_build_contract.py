@@ -51,7 +51,8 @@ def test_compiler_stays_in_the_lower_register_halves(asm):
     # bf16 / fp16 x {fp32, 16-bit O} x {causal, not} + bf16 / fp16 x {causal, not} with the fused Q rotation (16-bit O)
     # + int8 x {causal, not} + int8-fp8 x {causal, not}
     # + the head_dim 64 family: bf16 / fp16 x {fp32, 16-bit O} x {causal, not}
-    assert len(kernels) == 24, sorted(kernels)
+    # + sliding-window instantiations at head_dim 128: bf16 / fp16 x {fp32, 16-bit O}
+    assert len(kernels) == 28, sorted(kernels)
     for name, lines in kernels.items():
         in_asm, vmax, amax, n_mfma, loop_scratch = False, 0, 0, 0, 0
         mfma_seen = 0
@@ -91,7 +92,7 @@ def test_every_kernel_gets_512_registers(asm):
     nxt = [int(x) for x in re.findall(r"\.amdhsa_next_free_vgpr (\d+)", asm)]
     acc = [int(x) for x in re.findall(r"\.amdhsa_accum_offset (\d+)", asm)]
     # the hardware allocates in granules of 8 registers: 511 (clobbers name v254 / a254, the highest names hipcc does not reserve) is 512
-    assert len(nxt) == 24 and all((n + 7) // 8 * 8 == 512 for n in nxt), nxt
+    assert len(nxt) == 28 and all((n + 7) // 8 * 8 == 512 for n in nxt), nxt
     assert all(a == 256 for a in acc), acc
 
 

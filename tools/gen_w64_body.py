@@ -257,7 +257,13 @@ def op_text(R, op):
         _, kb, qb, r = op
         v = base(R.new, kb, qb) + r
         c = 32 * kb - 32 * qb + (r & 3) + 8 * (r >> 2)
-        return (f'asm volatile("v_cmp_lt_i32 vcc, {-c}, %0\\n\\tv_cndmask_b32 v{v}, v{v}, %1, vcc" :: "v"(dmask[{qb}]), "v"(neg_inf) : "vcc");')
+        one = (f'asm volatile("v_cmp_lt_i32 vcc, {-c}, %0\\n\\tv_cndmask_b32 v{v}, v{v}, %1, vcc" :: "v"(dmask[{qb}]), "v"(neg_inf) : "vcc");')
+        if C.i8:
+            return one
+        # sliding-window instantiations (WINDOW): the other band edge as well, score masked <=> dleft + c < 0
+        two = (f'asm volatile("v_cmp_lt_i32 vcc, {-c}, %0\\n\\tv_cndmask_b32 v{v}, v{v}, %1, vcc\\n\\tv_cmp_gt_i32 vcc, {-c}, %2\\n\\t'
+               f'v_cndmask_b32 v{v}, v{v}, %1, vcc" :: "v"(dmask[{qb}]), "v"(neg_inf), "v"(dleft) : "vcc");')
+        return f'if constexpr (WINDOW) {{ {two} }} else {{ {one} }}'
     if kind == "DMAK" and DMASTAMP and op[1] == 0:
         return ('{ asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long d0_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); '
                 'asm volatile("s_mov_b32 m0, %0\\n\\ts_nop 0\\n\\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_wave_k + W64_KDST + 0), "v"(kdma[0]), "s"(k_srd) : "memory"); '

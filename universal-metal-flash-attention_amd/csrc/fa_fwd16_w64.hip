@@ -43,6 +43,8 @@ struct W64Params {
     float tau;            // deferred-max threshold (log2 units)
     uint32_t lazy;        // bf16 kernels: lazy reference mode (no row max after a segment's first tile; see the kernel)
     uint32_t skew;        // tiles moved from the folding part of a two-way cut item to the publishing part (see the kernel)
+    uint32_t Tw;          // WINDOW kernels: key tiles per item (the band of a 256-row block), <= T
+    int32_t win_left, win_right;  // WINDOW kernels: key attends iff row - win_left <= key <= row + win_right
     const float* rope_cos;  // fused rotary embedding of Q (FwdParams::rope_*), NULL = none
     const float* rope_sin;
     int64_t rope_tb;
@@ -200,9 +202,23 @@ static void w64_softmax_policy(int in_prec, float* tau, uint32_t* lazy) {
 
 static int w64_cu_count() { return device_cu_count(); }
 
+// Sliding window without a mask tensor (MK_WINDOW; with `causal` the right edge is the diagonal): the WINDOW instantiations
+// sweep, per 256-row block, only the key tiles of its band -- w64_window_tiles of them, the same count for every block.
+static bool w64_is_window(const FwdParams& p) { return p.mask_kind == MK_WINDOW; }
+static uint32_t w64_win_left(const FwdParams& p) { return p.win_left < p.Skv ? p.win_left : p.Skv; }
+static uint32_t w64_win_right(const FwdParams& p) { return p.causal ? 0u : (p.win_right < p.Skv ? p.win_right : p.Skv); }
+static uint32_t w64_tiles_per_item(const FwdParams& p) {
+    const uint32_t T = (p.Skv + 63) / 64;
+    if (!w64_is_window(p)) return T;
+    const uint64_t band = 256ull + w64_win_left(p) + w64_win_right(p);  // keys a 256-row block can see
+    const uint64_t tw = (band + 63) / 64 + 1;                          // + 1: the band need not start on a tile boundary
+    return tw < T ? (uint32_t)tw : T;
+}
+
 bool fwd_w64_supported(const FwdParams& p) {
     if (tuning().no_w64.load(std::memory_order_relaxed) || !fwd_16_supported(p)) return false;
-    if ((p.D != 128 && p.D != 64) || p.mask_kind != MK_NONE) return false;
+    if ((p.D != 128 && p.D != 64) || (p.mask_kind != MK_NONE && p.mask_kind != MK_WINDOW)) return false;
+    if (w64_is_window(p) && (p.D != 128 || p.rope_cos)) return false;  // window instantiations: head_dim 128, no fused rotation
     if (p.D == 64 && p.rope_cos) return false;  // the fused Q rotation exists at head_dim 128 only
     // rows are processed in blocks of 256: a ragged last block wastes its empty waves, so small ragged Sq stay on
     // the 128-row kernel; any Skv >= 64 works (a partial last key tile runs the masking variant of the tile body)
@@ -216,7 +232,11 @@ bool fwd_w64_supported(const FwdParams& p) {
     if (!tuning().force_w64.load(std::memory_order_relaxed)) {
         const uint64_t cus = (uint64_t)w64_cu_count();
         const uint64_t nqb = (p.Sq + 255) / 256;
-        if (p.D == 64) {
+        if (w64_is_window(p)) {
+            // the band's tile steps are what there is to share (thresholds of the unmasked kernel: cut items need 10 steps per CU)
+            const uint64_t items = (uint64_t)p.B * p.H * nqb, steps = items * w64_tiles_per_item(p);
+            if (items % cus != 0 && steps < cus * 10) return false;
+        } else if (p.D == 64) {
             // half the MFMA time per tile step, the same prologue / drain / fold: the break-even sits higher.  us, w64 / 128-row
             // (profiles/r3/d64_w64_vs_128row.jsonl): causal 160 jobs 31.1 / 27.6, 192 jobs 45.9 / 46.6, 256 jobs 32.4 / 36.4,
             // 512 jobs 91.7 / 107; non-causal cut items 10 steps per CU 27.2 / 23.4, 12: 27.0 / 23.6, 16: 30.4 / 30.0,
@@ -237,14 +257,15 @@ bool fwd_w64_supported(const FwdParams& p) {
 }
 
 static uint32_t w64_grid(const FwdParams& p) {
-    uint64_t total = (uint64_t)p.B * p.H * ((p.Sq + 255) / 256) * ((p.Skv + 63) / 64);  // (item, key tile) steps
-    if (p.causal) total = (uint64_t)p.B * p.H * (((p.Sq + 255) / 256 + 1) / 2);  // jobs = mirrored pairs of q-blocks
+    const bool pairs = p.causal && !w64_is_window(p);  // (a causal window is a window with right = 0: linear schedule)
+    uint64_t total = (uint64_t)p.B * p.H * ((p.Sq + 255) / 256) * w64_tiles_per_item(p);  // (item, key tile) steps
+    if (pairs) total = (uint64_t)p.B * p.H * (((p.Sq + 255) / 256 + 1) / 2);  // jobs = mirrored pairs of q-blocks
     const uint32_t cus = (uint32_t)w64_cu_count();
     if (const int gi = tuning().w64_grid.load(std::memory_order_relaxed)) {  // lab: force the number of workgroups
         const uint32_t g = (uint32_t)gi;
         if (gi > 0 && g <= cus && g <= total) return g;
     }
-    if (!p.causal) {
+    if (!pairs) {
         // few items (the strong-scaling shards of a problem: B1 H3 S4096 = 48 items): a whole number of EQUAL parts per item
         // (grid = items x floor(CUs / items): the slices total * w / G then start and end on part boundaries, every
         // workgroup has one segment and one prologue) instead of CUs ragged slices.  Graph-replayed us, aligned / ragged:
@@ -288,6 +309,7 @@ hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cn
     w64_softmax_policy(p.in_prec, &wp.tau, &wp.lazy);
     wp.skew = (uint32_t)tuning().w64_skew.load(std::memory_order_relaxed);
     wp.rope_cos = p.rope_cos; wp.rope_sin = p.rope_sin; wp.rope_tb = p.rope_tb;
+    wp.Tw = wp.T; wp.win_left = wp.win_right = 0;
     if (p.rope_cos) {  // fused-RoPE instantiations exist for O in the operand type only (runtime.hip asks first)
         if (p.out_prec != p.in_prec) return hipErrorNotSupported;
         if (p.in_prec == P_BF16) {
@@ -298,6 +320,19 @@ hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cn
         *name = "fa_fwd16_w64<fp16,128,rope>";
         return p.causal ? launch_w64_kernel(fa_fwd16_w64_f16<_Float16, true, true>, p, wp, stream)
                         : launch_w64_kernel(fa_fwd16_w64_f16<_Float16, false, true>, p, wp, stream);
+    }
+    if (w64_is_window(p)) {
+        wp.Tw = w64_tiles_per_item(p);
+        wp.win_left = (int32_t)w64_win_left(p);
+        wp.win_right = (int32_t)w64_win_right(p);
+        if (p.in_prec == P_BF16) {
+            *name = "fa_fwd16_w64<bf16,128,window>";
+            return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64_bf16<float, false, false, true>, p, wp, stream)
+                                        : launch_w64_kernel(fa_fwd16_w64_bf16<__bf16, false, false, true>, p, wp, stream);
+        }
+        *name = "fa_fwd16_w64<fp16,128,window>";
+        return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64_f16<float, false, false, true>, p, wp, stream)
+                                    : launch_w64_kernel(fa_fwd16_w64_f16<_Float16, false, false, true>, p, wp, stream);
     }
     if (p.D == 64) {
         const bool bf = p.in_prec == P_BF16;
