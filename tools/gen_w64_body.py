@@ -367,7 +367,7 @@ def vread8_stream():
 
 
 def bar_gap():
-    return C.NQK + 16  # MIDBAR: behind the PV MFMAs of 16-key steps 0 and 1
+    return C.NQK + 2 * C.PVS  # MIDBAR: behind the PV MFMAs of 16-key steps 0 and 1
 
 
 def vread_stream(have_new=True):
