@@ -39,6 +39,13 @@ def rel_err(a, ref):
 from tolerances import check_forward  # noqa: E402  (measured bounds, tests/tolerances.py)
 
 
+def _band(Sq, Skv, window, causal):
+    i = np.arange(Sq)[:, None]
+    j = np.arange(Skv)[None, :]
+    keep = (j >= i - window[0]) & (j <= i + window[1])
+    return keep & (j <= i) if causal else keep
+
+
 @pytest.mark.parametrize("shape", [(1, 2, 256, 64), (1, 2, 256, 128), (1, 1, 256, 192), (2, 3, 512, 256), (1, 2, 256, 1024),
                                    (1, 5, 768, 448)])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
@@ -183,6 +190,41 @@ def test_w64_lazy_overflow_restarts_the_segment_with_the_max_chain():
     assert torch.equal(o, umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32))  # bitwise repeatable
 
 
+@pytest.mark.parametrize("kind", ["causal", "window"])
+def test_w64_lazy_underflow_restarts_the_segment(kind):
+    """The other escape hatch of the lazy mode.  A row whose first tile of a segment holds no visible key (descending causal
+    sweep, band edge of a window) starts from the reference 0; if ALL of its scores then sit hundreds of nats below zero every
+    P underflows and l = 0.  The kernel must notice (a row that has keys in the segment and no row sum) and re-run the segment
+    with the max chain -- softmax is shift-invariant, the oracle's answer is ordinary."""
+    import umfa_torch
+    torch.manual_seed(9)
+    B, H, S, D = 1, 3, 768, 128
+    q = torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16)
+    # head 1: every query gets a unit component along d, every key -4000 along d: all scores drop by ~350 nats
+    d = torch.zeros(D, device="cuda")
+    d[0] = 1.0
+    qq, kk = q.float(), k.float()
+    qq[:, 1] = qq[:, 1] + 1.0 * d
+    qq[:, 1, :, 0] = qq[:, 1, :, 0].abs() + 0.5
+    kk[:, 1] = kk[:, 1] - 4000.0 * d
+    q, k = qq.to(torch.bfloat16), kk.to(torch.bfloat16)
+    kw = dict(causal=True) if kind == "causal" else dict(window=(100, 60))
+    o, lse = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32, return_lse=True, **kw)
+    kern = umfa_torch.last_kernel()
+    assert kern.startswith("fa_fwd16_w64<bf16,128"), kern
+    assert torch.isfinite(o).all(), "rows with a masked first tile lost every P to underflow"
+    if kind == "causal":
+        ref = _oracle().sdpa_forward(bits(q), bits(k), bits(v), causal=True)
+    else:
+        from oracle.oracle import MASK_BOOL
+        ref = _oracle().sdpa_forward(bits(q), bits(k), bits(v), mask=np.ascontiguousarray(_band(S, S, (100, 60), False)), mask_type=MASK_BOOL)
+    check_forward(o.cpu().numpy(), ref, torch.bfloat16, kern, "w64_lazy_underflow_" + kind, scale_max=1.5)
+    assert torch.isfinite(lse).all()
+    assert torch.equal(o, umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32, **kw))
+
+
 @pytest.mark.parametrize("shape", [(1, 2, 256, 256), (1, 2, 512, 512), (2, 3, 768, 768), (1, 2, 1024, 448), (1, 1, 256, 1024),
                                    (1, 4, 2048, 2048)])
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
@@ -316,13 +358,6 @@ def test_w64_head_dim_64_lazy_overflow_restart():
     with umfa_torch.options(softmax_reference="exact"):
         oe = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
     assert float((o[:, 1] - oe[:, 1]).abs().max()) <= 8e-3 * float(oe[:, 1].abs().max())
-
-
-def _band(Sq, Skv, window, causal):
-    i = np.arange(Sq)[:, None]
-    j = np.arange(Skv)[None, :]
-    keep = (j >= i - window[0]) & (j <= i + window[1])
-    return keep & (j <= i) if causal else keep
 
 
 @pytest.mark.parametrize("shape,window,causal", [((1, 2, 512, 512), (100, 100), False), ((1, 3, 768, 1024), (64, 0), True),
