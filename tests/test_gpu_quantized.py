@@ -153,6 +153,45 @@ def test_quantized_forward_w64_wide_dynamic_range(ctx, gain, outlier):
     assert np.abs(lse.reshape(rlse.shape) - rlse).max() < 2e-3 * max(1.0, np.abs(rlse).max() / 50)
 
 
+@pytest.mark.parametrize("kind", ["ramp_up", "ramp_down", "jump", "causal_shift"])
+def test_quantized_forward_w64_moving_reference(ctx, kind):
+    """The int8 kernel runs the lazy softmax reference with fp16 P (rebase at 2^6, give up at 2^15): scores that rise along
+    the key axis (many rebases), fall (none), jump by hundreds of nats inside one tile (overflow: the segment re-runs with the
+    max chain), and a causal sweep whose scores all sit far below zero (rows that start on the reference 0: the row-sum floor
+    of the fp16 mode re-runs them) -- against the oracle on the same quantised operands, and bit-equal to the deferred mode's
+    tolerance class"""
+    import umfa
+    orc = _oracle()
+    rng = np.random.default_rng(77)
+    B, H, Sq, Skv = 1, 2, 512, 1024
+    q = rng.standard_normal((B, H, Sq, 128)).astype(np.float32)
+    k = (rng.standard_normal((B, H, Skv, 128)) * 0.3).astype(np.float32)
+    v = rng.standard_normal((B, H, Skv, 128)).astype(np.float32)
+    d = q.mean(axis=2, keepdims=True)
+    d = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    ramp = np.linspace(0.0, 1.0, Skv, dtype=np.float32).reshape(1, 1, Skv, 1)
+    causal = False
+    if kind == "ramp_up":
+        k = k + ramp * 60.0 * 11.3 * d
+    elif kind == "ramp_down":
+        k = k - ramp * 60.0 * 11.3 * d
+    elif kind == "jump":
+        k[:, 1, 300:] += 4000.0 * d[:, 1]
+    else:
+        causal = True
+        q[:, 1, :, 0] = np.abs(q[:, 1, :, 0]) + 1.5
+        k[:, 1, :, 0] -= 300.0
+    o, lse = umfa.quantized_attention(ctx, q, k, v, causal=causal, precision="int8", quant_mode="blockwise", layout="bhsd", return_lse=True)
+    assert ctx.last_kernel.startswith("fa_fwd_w64_i8<"), ctx.last_kernel
+    ref, rlse = orc.quantized_forward(q, k, v, causal=causal, bits=8, quant_mode=2)
+    assert np.isfinite(o).all()
+    assert rel_err(o, ref) < 2e-3, (kind, rel_err(o, ref))
+    fin = np.isfinite(rlse)
+    assert np.abs(lse.reshape(rlse.shape) - rlse)[fin].max() < 2e-3 * max(1.0, np.abs(rlse[fin]).max() / 50)
+    o2, _ = umfa.quantized_attention(ctx, q, k, v, causal=causal, precision="int8", quant_mode="blockwise", layout="bhsd", return_lse=True)
+    assert np.array_equal(o, o2)
+
+
 @pytest.mark.parametrize("dt", ["fp32", "bf16", "fp16"])
 @pytest.mark.parametrize("bits,mode", [(8, 2), (8, 0), (4, 2)])
 def test_quantiser_is_bit_exact_with_the_oracle(dt, bits, mode):

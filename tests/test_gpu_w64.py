@@ -109,30 +109,32 @@ def test_w64_strided_inputs_and_cross_attention():
     check_forward(o.cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel(), inputs=(bits(q), bits(k), bits(v)), scale=0.05)
 
 
-def test_w64_deferred_max_rescale_paths():
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_w64_deferred_max_rescale_paths(dt):
     """Scores that keep rising along the key axis force the reference max to move many times (every rise of more
-    than 2^6 triggers the O rescale); scores that fall leave it untouched; both must match the oracle."""
+    than 2^6 triggers the O rescale; lazy: a power-of-two rebase whenever a row sum passes 2^30, with fp16 P 2^6);
+    scores that fall leave it untouched; both must match the oracle."""
     import umfa_torch
     torch.manual_seed(4)
     B, H, Sq, Skv, D = 1, 2, 256, 1024, 128
-    q = torch.randn(B, H, Sq, D, device="cuda", dtype=torch.bfloat16)
-    v = torch.randn(B, H, Skv, D, device="cuda", dtype=torch.bfloat16)
+    q = torch.randn(B, H, Sq, D, device="cuda", dtype=dt)
+    v = torch.randn(B, H, Skv, D, device="cuda", dtype=dt)
     base = torch.randn(B, H, Skv, D, device="cuda")
     ramp = torch.linspace(0.0, 1.0, Skv, device="cuda").view(1, 1, Skv, 1)
     # a common direction whose weight grows with the key index: q.k grows by ~40 natural-log units over the row
     direction = q.float().mean(dim=2, keepdim=True)
     direction = direction / direction.norm(dim=-1, keepdim=True)
     for sign in (+1.0, -1.0):
-        k = (base * 0.3 + sign * ramp * 60.0 * direction * 11.3).to(torch.bfloat16)
+        k = (base * 0.3 + sign * ramp * 60.0 * direction * 11.3).to(dt)
         o, lse = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32, return_lse=True)
         assert umfa_torch.last_kernel().startswith("fa_fwd16_w64")
-        ref, rl = _oracle().sdpa_forward(bits(q), bits(k), bits(v), return_lse=True)
+        ref, rl = _oracle().sdpa_forward(npy(q), npy(k), npy(v), return_lse=True)
         assert np.isfinite(o.cpu().numpy()).all()
         # hostile on purpose: the reference moves many times per row (lazy: power-of-two rebases off the row sums)
-        check_forward(o.cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel(), f"ramp{sign:+.0f}", scale_max=1.5)
+        check_forward(o.cpu().numpy(), ref, dt, umfa_torch.last_kernel(), f"ramp{sign:+.0f}", scale_max=1.5)
         with umfa_torch.options(softmax_reference="deferred", softmax_tau=6):  # the max-chain bodies: O rescale on every 2^6 rise
             o6 = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
-            check_forward(o6.cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel(), f"ramp{sign:+.0f}_tau6", scale_max=1.5)
+            check_forward(o6.cpu().numpy(), ref, dt, umfa_torch.last_kernel(), f"ramp{sign:+.0f}_tau6", scale_max=1.5)
         assert np.abs(lse.cpu().numpy().reshape(rl.shape) - rl).max() < 5e-2
 
 
@@ -159,28 +161,29 @@ def test_w64_stale_reference_tail_vs_exact_running_max():
     assert not torch.equal(o0, ol)
 
 
-def test_w64_lazy_overflow_restarts_the_segment_with_the_max_chain():
-    """The lazy mode's escape hatch: scores that jump by far more than 2^100 between two key tiles overflow the stale
-    reference (P = inf); the workgroup must notice, re-run the segment with the max chain, and still meet the oracle --
-    for the rows that jump AND for the ordinary rows that share their workgroup."""
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_w64_lazy_overflow_restarts_the_segment_with_the_max_chain(dt):
+    """The lazy mode's escape hatch: scores that jump by far more than 2^100 (fp16 P: 2^15) between two key tiles overflow
+    the stale reference (P = inf); the workgroup must notice, re-run the segment with the max chain, and still meet the
+    oracle -- for the rows that jump AND for the ordinary rows that share their workgroup."""
     import umfa_torch
     torch.manual_seed(5)
     B, H, Sq, Skv, D = 1, 3, 512, 768, 128
-    q = torch.randn(B, H, Sq, D, device="cuda", dtype=torch.bfloat16)
-    k = torch.randn(B, H, Skv, D, device="cuda", dtype=torch.bfloat16)
-    v = torch.randn(B, H, Skv, D, device="cuda", dtype=torch.bfloat16)
+    q = torch.randn(B, H, Sq, D, device="cuda", dtype=dt)
+    k = torch.randn(B, H, Skv, D, device="cuda", dtype=dt)
+    v = torch.randn(B, H, Skv, D, device="cuda", dtype=dt)
     # head 1: keys 300 ... 767 carry a huge component along the mean query direction: scores rise by ~400 nats at key 300
     d = q[:, 1].float().mean(dim=1, keepdim=True)
     d = d / d.norm(dim=-1, keepdim=True)
     kk = k.float()
     kk[:, 1, 300:] += 4000.0 * d
-    k = kk.to(torch.bfloat16)
+    k = kk.to(dt)
     o, lse = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32, return_lse=True)
     assert umfa_torch.last_kernel().startswith("fa_fwd16_w64")
-    ref, rl = _oracle().sdpa_forward(bits(q), bits(k), bits(v), return_lse=True)
+    ref, rl = _oracle().sdpa_forward(npy(q), npy(k), npy(v), return_lse=True)
     on = o.cpu().numpy()
     assert np.isfinite(on).all()
-    check_forward(on, ref, torch.bfloat16, umfa_torch.last_kernel(), "lazy_overflow", scale_max=1.5)
+    check_forward(on, ref, dt, umfa_torch.last_kernel(), "lazy_overflow", scale_max=1.5)
     finite = np.isfinite(rl)
     assert np.abs(lse.cpu().numpy().reshape(rl.shape) - rl)[finite].max() < 5e-2 * max(1.0, np.abs(rl[finite]).max() / 50)
     with umfa_torch.options(softmax_reference="exact"):
@@ -190,8 +193,9 @@ def test_w64_lazy_overflow_restarts_the_segment_with_the_max_chain():
     assert torch.equal(o, umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32))  # bitwise repeatable
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("kind", ["causal", "window"])
-def test_w64_lazy_underflow_restarts_the_segment(kind):
+def test_w64_lazy_underflow_restarts_the_segment(kind, dt):
     """The other escape hatch of the lazy mode.  A row whose first tile of a segment holds no visible key (descending causal
     sweep, band edge of a window) starts from the reference 0; if ALL of its scores then sit hundreds of nats below zero every
     P underflows and l = 0.  The kernel must notice (a row that has keys in the segment and no row sum) and re-run the segment
@@ -199,28 +203,33 @@ def test_w64_lazy_underflow_restarts_the_segment(kind):
     import umfa_torch
     torch.manual_seed(9)
     B, H, S, D = 1, 3, 768, 128
-    q = torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16)
-    k = torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16)
-    v = torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16)
-    # head 1: every query gets a unit component along d, every key -4000 along d: all scores drop by ~350 nats
+    q = torch.randn(B, H, S, D, device="cuda", dtype=dt)
+    k = torch.randn(B, H, S, D, device="cuda", dtype=dt)
+    v = torch.randn(B, H, S, D, device="cuda", dtype=dt)
+    # head 1: every query gets a unit component along d, every key -4000 along d: all scores drop by ~350 nats; head 2: by
+    # ~20 nats only -- nothing for bf16 P, but fp16 P against the reference 0 would be all zero: the fp16 threshold (a row
+    # with keys must have collected 2^-6) catches that too
     d = torch.zeros(D, device="cuda")
     d[0] = 1.0
     qq, kk = q.float(), k.float()
     qq[:, 1] = qq[:, 1] + 1.0 * d
     qq[:, 1, :, 0] = qq[:, 1, :, 0].abs() + 0.5
     kk[:, 1] = kk[:, 1] - 4000.0 * d
-    q, k = qq.to(torch.bfloat16), kk.to(torch.bfloat16)
+    qq[:, 2] = qq[:, 2] + 1.0 * d
+    qq[:, 2, :, 0] = qq[:, 2, :, 0].abs() + 0.5
+    kk[:, 2] = kk[:, 2] - 250.0 * d
+    q, k = qq.to(dt), kk.to(dt)
     kw = dict(causal=True) if kind == "causal" else dict(window=(100, 60))
     o, lse = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32, return_lse=True, **kw)
     kern = umfa_torch.last_kernel()
-    assert kern.startswith("fa_fwd16_w64<bf16,128"), kern
+    assert kern.startswith("fa_fwd16_w64<"), kern
     assert torch.isfinite(o).all(), "rows with a masked first tile lost every P to underflow"
     if kind == "causal":
-        ref = _oracle().sdpa_forward(bits(q), bits(k), bits(v), causal=True)
+        ref = _oracle().sdpa_forward(npy(q), npy(k), npy(v), causal=True)
     else:
         from oracle.oracle import MASK_BOOL
-        ref = _oracle().sdpa_forward(bits(q), bits(k), bits(v), mask=np.ascontiguousarray(_band(S, S, (100, 60), False)), mask_type=MASK_BOOL)
-    check_forward(o.cpu().numpy(), ref, torch.bfloat16, kern, "w64_lazy_underflow_" + kind, scale_max=1.5)
+        ref = _oracle().sdpa_forward(npy(q), npy(k), npy(v), mask=np.ascontiguousarray(_band(S, S, (100, 60), False)), mask_type=MASK_BOOL)
+    check_forward(o.cpu().numpy(), ref, dt, kern, "w64_lazy_underflow_" + kind, scale_max=1.5)
     assert torch.isfinite(lse).all()
     assert torch.equal(o, umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32, **kw))
 

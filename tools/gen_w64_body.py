@@ -938,7 +938,7 @@ def emit_body(out):
     emit_part(lines, Roles("b", "a"), True, True, masked=True)
     lines.append("#elif W64_PART == 7  // masking tile, even")
     emit_part(lines, Roles("a", "b"), True, True, masked=True)
-    if not C.i8:
+    if not C.f8:  # (fp8 P tops out at 448: no room for a stale reference)
         lines.append("#elif W64_PART == 8  // LAZY reference (no row max), steady state, odd tile")
         emit_part(lines, Roles("b", "a"), True, True, lazy=True)
         lines.append("#elif W64_PART == 9  // LAZY, even tile")

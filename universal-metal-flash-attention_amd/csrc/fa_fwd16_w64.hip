@@ -73,6 +73,7 @@ struct W64I8Params {
     float* part_buf;
     uint32_t* part_cnt;
     float tau;
+    uint32_t lazy;          // lazy reference mode (fp16 P thresholds; the fp8 variant has no lazy bodies and ignores it)
     uint32_t skew;
 };
 
@@ -101,7 +102,7 @@ struct W64I8Params {
 #define W64_MFMA_QK "v_mfma_f32_32x32x16_f16"
 #define W64_MSUM "v_mfma_f32_4x4x4_16b_f16"
 #define W64_ONES_BITS 0x3c003c00u              /* fp16 1.0 twice */
-#define W64_LAZY_PARTS 0
+#define W64_LAZY_PARTS 2                        /* fp16 P: the lazy mode with fp16's thresholds (see the kernel) */
 #define W64_CVT "v_cvt_pk_f16_f32"
 #define W64_KERNEL fa_fwd16_w64_f16
 #include "fa_fwd16_w64_kernel.inc"
@@ -141,7 +142,7 @@ struct W64I8Params {
 #define W64_MFMA_QK "v_mfma_f32_32x32x16_f16"
 #define W64_MSUM "v_mfma_f32_4x4x4_16b_f16"
 #define W64_ONES_BITS 0x3c003c00u
-#define W64_LAZY_PARTS 0
+#define W64_LAZY_PARTS 2
 #define W64_CVT "v_cvt_pk_f16_f32"
 #define W64_KERNEL fa_fwd16_w64d64_f16
 #include "fa_fwd16_w64_kernel.inc"
@@ -174,6 +175,8 @@ struct W64I8Params {
 // runtime-quantised, fp8 P V (opt-in fast mode, quant_mode 3): int8 QK^T, fp8 e4m3 P and V
 #undef W64_F8
 #define W64_F8 1
+#undef W64_LAZY_PARTS
+#define W64_LAZY_PARTS 0                        /* fp8 P tops out at 448: deferred max only */
 #define W64_BODY_INC "fa_fwd_w64_i8f8_body.inc"
 #define W64_T _Float16
 #define W64_MFMA "v_mfma_f32_32x32x16_f16"
@@ -193,11 +196,15 @@ struct W64I8Params {
 
 // Softmax reference policy of a launch (kernels.h SoftmaxRef, set by umfa_set_option): tau of the max-chain tile bodies and
 // whether the bf16 kernels run their lazy bodies.  Measured accuracy / time of the regimes: DESIGN.md §3.2.
+#ifndef W64_LAZY_FP16_DEFAULT
+#define W64_LAZY_FP16_DEFAULT 1
+#endif
 static void w64_softmax_policy(int in_prec, float* tau, uint32_t* lazy) {
     const int mode = tuning().sm_mode.load(std::memory_order_relaxed);
     const float t = tuning().sm_tau.load(std::memory_order_relaxed);
     *tau = mode == SM_EXACT ? 0.0f : t;
-    *lazy = (in_prec == P_BF16 && (mode == SM_DEFAULT || mode == SM_LAZY)) ? 1u : 0u;
+    // bf16 P: lazy by default.  fp16 P (fp16 kernels, the int8 kernel): the lazy bodies exist with fp16's thresholds
+    *lazy = (mode == SM_LAZY || (mode == SM_DEFAULT && (in_prec == P_BF16 || W64_LAZY_FP16_DEFAULT))) ? 1u : 0u;
 }
 
 static int w64_cu_count() { return device_cu_count(); }
@@ -387,8 +394,7 @@ hipError_t launch_fwd_w64_i8(const FwdParams& p, const QuantViews& v, float* par
     wp.T = (p.Skv + 63) / 64;
     wp.part_buf = part_buf;
     wp.part_cnt = part_cnt;
-    uint32_t lazy_unused = 0;
-    w64_softmax_policy(P_FP16, &wp.tau, &lazy_unused);  // fp16 P: deferred / exact max only
+    w64_softmax_policy(P_FP16, &wp.tau, &wp.lazy);  // fp16 P
     wp.skew = (uint32_t)tuning().w64_skew.load(std::memory_order_relaxed);
     const uint32_t grid = w64_grid(p);
     const size_t lds = 65536 + 4 * 32 * (512 + 16) + 16;
