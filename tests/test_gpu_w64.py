@@ -373,7 +373,8 @@ def test_w64_head_dim_64_lazy_overflow_restart():
                                                  ((2, 2, 1024, 1024), (256, 0), True), ((1, 2, 1100, 777), (300, 50), False),
                                                  ((1, 2, 512, 512), (0, 0), False), ((1, 1, 512, 256), (10, 10), False),
                                                  ((1, 2, 2048, 2048), (1000, 1000), False), ((1, 2, 1024, 1024), (1024 + 128, 128), False),
-                                                 ((1, 5, 1280, 1280), (31, 97), False), ((1, 2, 256, 4096), (500, 700), False)])
+                                                 ((1, 5, 1280, 1280), (31, 97), False), ((1, 2, 256, 4096), (500, 700), False),
+                                                 ((2, 3, 768, 640), (700, 0), False), ((1, 2, 1024, 512), (900, 30), False)])  # Sq > Skv, left > Skv
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 def test_w64_sliding_window_vs_oracle(shape, window, causal, dt):
     """window=(left, right) on the one-wave-per-SIMD structure (fa_fwd16_w64<.,128,window>): every 256-row block sweeps only

@@ -212,7 +212,9 @@ static int w64_cu_count() { return device_cu_count(); }
 // Sliding window without a mask tensor (MK_WINDOW; with `causal` the right edge is the diagonal): the WINDOW instantiations
 // sweep, per 256-row block, only the key tiles of its band -- w64_window_tiles of them, the same count for every block.
 static bool w64_is_window(const FwdParams& p) { return p.mask_kind == MK_WINDOW; }
-static uint32_t w64_win_left(const FwdParams& p) { return p.win_left < p.Skv ? p.win_left : p.Skv; }
+// (clamped to values that change nothing: key >= row - left holds for every row once left >= Sq, key <= row + right once
+// right >= Skv; the kernel adds them to 32-bit row / key differences)
+static uint32_t w64_win_left(const FwdParams& p) { return p.win_left < p.Sq ? p.win_left : p.Sq; }
 static uint32_t w64_win_right(const FwdParams& p) { return p.causal ? 0u : (p.win_right < p.Skv ? p.win_right : p.Skv); }
 static uint32_t w64_tiles_per_item(const FwdParams& p) {
     const uint32_t T = (p.Skv + 63) / 64;
