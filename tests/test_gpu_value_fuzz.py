@@ -34,3 +34,9 @@ def test_forward_adversarial_values(seed):
 def test_backward_adversarial_values(seed):
     msg = _fuzz().run_bwd_case(seed)
     assert msg is None, msg
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_w64_families_random_shapes(seed):
+    msg = _fuzz().run_shape_case(seed)
+    assert msg is None, msg
