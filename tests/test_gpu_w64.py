@@ -487,3 +487,30 @@ def test_w64_dispatch_gate_head_dim_64(shape, causal, expect_w64):
     umfa_torch.attention_forward(q, k, k, causal=causal)
     torch.cuda.synchronize()
     assert umfa_torch.last_kernel() == ("fa_fwd16_w64<bf16,64>" if expect_w64 else "fa_fwd16<bf16,64>"), umfa_torch.last_kernel()
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_w64_very_long_sequence_rows(causal):
+    """S = 131072 (B1 H2 D128: 2048 key tiles per item, 33 MB slabs, 32-bit offsets well past 2^24): sampled rows against an
+    fp64 restatement on the GPU; LSE; bitwise repeatable"""
+    import umfa_torch
+    umfa_torch.set_option("force_w64", 0)
+    torch.manual_seed(31)
+    B, H, S, D = 1, 2, 131072, 128
+    q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    out, lse = umfa_torch.attention_forward(q, k, v, causal=causal, out_dtype=torch.float32, return_lse=True)
+    kern = umfa_torch.last_kernel()
+    assert kern == "fa_fwd16_w64<bf16,128>", kern
+    assert torch.isfinite(out).all()
+    for r0 in (0, 255, 65536 - 32, 100000, S - 64):
+        rows = slice(r0, r0 + 64)
+        s = torch.matmul(q[:, :, rows].double(), k.double().transpose(-1, -2)) * D ** -0.5
+        if causal:
+            i = torch.arange(r0, r0 + 64, device="cuda")[:, None]
+            j = torch.arange(S, device="cuda")[None, :]
+            s = s.masked_fill(j > i, float("-inf"))
+        ref = torch.matmul(torch.softmax(s, -1), v.double())
+        check_forward(out[:, :, rows].cpu().numpy(), ref.cpu().numpy(), torch.bfloat16, kern, f"w64_S131072_rows{r0}")
+        assert (lse.view(B, H, S)[:, :, rows].double() - torch.logsumexp(s, -1)).abs().max().item() < 2e-2
+    del s, ref
+    assert torch.equal(out, umfa_torch.attention_forward(q, k, v, causal=causal, out_dtype=torch.float32))
