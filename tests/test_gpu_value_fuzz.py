@@ -40,3 +40,9 @@ def test_backward_adversarial_values(seed):
 def test_w64_families_random_shapes(seed):
     msg = _fuzz().run_shape_case(seed)
     assert msg is None, msg
+
+
+@pytest.mark.parametrize("seed", range(80))
+def test_quantized_forward_random_cases(seed):
+    msg = _fuzz().run_i8_case(seed)
+    assert msg is None, msg

@@ -201,6 +201,51 @@ def run_shape_case(seed):
     return None
 
 
+def run_i8_case(seed):
+    """runtime-quantised forward (in-stream entry): int8 / int4, per-tensor / block-wise, causal, float masks, arbitrary shapes at
+    head_dim 128 (the w64 int8 kernel when forced, else the 128-row int8 kernel) and 64, N(0,1) or scaled data -- against the
+    oracle's restatement of the quantised forward on the CPU"""
+    import numpy as np
+    from oracle import oracle
+    rng = random.Random(seed + 900000)
+    dt = rng.choice([torch.bfloat16, torch.float16])
+    D = rng.choice([64, 128, 128])
+    B, H = 1, rng.choice([1, 2, 3])
+    Sq = rng.choice([64, 100, 256, 257, 300, 512, 640, 777])
+    Skv = Sq if rng.random() < 0.6 else rng.choice([64, 65, 100, 128, 200, 320, 511, 777])
+    bits = rng.choice([8, 8, 4])
+    mode = rng.choice(["blockwise", "blockwise", "tensor"])
+    causal = rng.random() < 0.35
+    use_mask = (not causal) and rng.random() < 0.25
+    gain = rng.choice([1.0, 1.0, 0.05, 4.0])
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    q = (torch.randn(B, H, Sq, D, device="cuda", generator=g) * gain).to(dt)
+    k = (torch.randn(B, H, Skv, D, device="cuda", generator=g) * gain).to(dt)
+    v = torch.randn(B, H, Skv, D, device="cuda", dtype=dt, generator=g)
+    mask = (torch.randn(1, H, Sq, Skv, device="cuda", generator=g) * 2).float() if use_mask else None
+    umfa_torch.set_option("force_w64", 1 if rng.random() < 0.6 else 0)
+    try:
+        out, lse = umfa_torch.quantized_attention_forward_stream(q, k, v, causal=causal, mask=mask, bits=bits, quant_mode=mode, return_lse=True)
+        kern = umfa_torch.last_kernel()
+        what = (seed, str(dt), B, H, Sq, Skv, D, bits, mode, causal, use_mask, gain, kern)
+        torch.cuda.synchronize()
+        qn, kn, vn = (t.float().cpu().numpy() for t in (q, k, v))
+        r_o, r_l = oracle.quantized_forward(qn, kn, vn, causal=causal, mask=None if mask is None else mask.cpu().numpy(), bits=bits,
+                                            quant_mode=0 if mode == "tensor" else 2)
+        o = out.cpu().numpy()
+        if not np.isfinite(o).all():
+            return "non-finite %r" % (what,)
+        rel = float(np.abs(o - r_o).max() / max(np.abs(r_o).max(), 1e-30))
+        lerr = float(np.abs(lse.cpu().numpy().reshape(r_l.shape) - r_l).max() / max(1.0, np.abs(r_l).max() / 50))
+        if rel > 2.5e-3 or lerr > 2.5e-3:
+            return "rel %.3e lse %.3e %r" % (rel, lerr, what)
+    except Exception as e:  # noqa: BLE001
+        return "exception %r %s" % ((seed,), repr(e)[:300])
+    finally:
+        umfa_torch.set_option("force_w64", 0)
+    return None
+
+
 # gradients: P and dS rounded to the operand type (tests/test_gpu_fuzz.py: 3e-2 bf16, 8e-3 fp16 on N(0,1) data) x 4 for keys that
 # are hundreds of times larger than their neighbours (a rounding of dS at such a key is multiplied by it; measured worst over
 # 2100 seeds: 9.8e-2 bf16, 1.9e-2 fp16): this leg is about finiteness and the exp / LSE arithmetic, the forward leg is the sharp one
@@ -258,7 +303,7 @@ if __name__ == "__main__":
     first, count = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 200)
     bad = 0
     for seed in range(first, first + count):
-        for fn in ((run_case, run_bwd_case, run_shape_case) if len(sys.argv) < 4 else (globals()[sys.argv[3]],)):
+        for fn in ((run_case, run_bwd_case, run_shape_case, run_i8_case) if len(sys.argv) < 4 else (globals()[sys.argv[3]],)):
             msg = fn(seed)
             if msg:
                 bad += 1
