@@ -46,3 +46,15 @@ def test_w64_families_random_shapes(seed):
 def test_quantized_forward_random_cases(seed):
     msg = _fuzz().run_i8_case(seed)
     assert msg is None, msg
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_gqa_random_cases(seed):
+    msg = _fuzz().run_gqa_case(seed)
+    assert msg is None, msg
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_fused_rope_random_cases(seed):
+    msg = _fuzz().run_rope_case(seed)
+    assert msg is None, msg

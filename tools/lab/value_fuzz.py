@@ -246,6 +246,90 @@ def run_i8_case(seed):
     return None
 
 
+def run_gqa_case(seed):
+    """grouped K / V heads through the SDPA routing layer: inference (zero-copy slab views) and training (K / V read in place by
+    forward and backward, dK / dV summed per group) against fp64 autograd on repeat_interleave'd operands; random group sizes,
+    shapes, head dims 64 / 128, causal"""
+    rng = random.Random(seed + 1300000)
+    dt = rng.choice([torch.bfloat16, torch.float16])
+    D = rng.choice([64, 128])
+    Hkv = rng.choice([1, 2, 3, 4])
+    G = rng.choice([2, 3, 4, 8])
+    B = rng.choice([1, 2])
+    Sq = rng.choice([64, 128, 200, 256, 333, 512, 1024])
+    Skv = Sq if rng.random() < 0.7 else rng.choice([64, 100, 256, 640])
+    causal = rng.random() < 0.5
+    train = rng.random() < 0.6
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    q = torch.randn(B, Hkv * G, Sq, D, device="cuda", dtype=dt, generator=g)
+    k = torch.randn(B, Hkv, Skv, D, device="cuda", dtype=dt, generator=g)
+    v = torch.randn(B, Hkv, Skv, D, device="cuda", dtype=dt, generator=g)
+    do = torch.randn(B, Hkv * G, Sq, D, device="cuda", dtype=dt, generator=g)
+    try:
+        qr, kr, vr = (t.detach().double().requires_grad_(True) for t in (q, k, v))
+        ke, ve = kr.repeat_interleave(G, dim=1), vr.repeat_interleave(G, dim=1)
+        s = torch.matmul(qr, ke.transpose(-1, -2)) * D ** -0.5
+        if causal:
+            s = s.masked_fill(~torch.ones(Sq, Skv, dtype=torch.bool, device="cuda").tril(), float("-inf"))
+        ref = torch.matmul(torch.softmax(s, dim=-1), ve)
+        what = [seed, str(dt), B, Hkv, G, Sq, Skv, D, causal, train]
+        if train:
+            ref.backward(do.double())
+            qg, kg, vg = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
+            out = umfa_torch.scaled_dot_product_attention(qg, kg, vg, is_causal=causal, enable_gqa=True)
+            out.backward(do)
+            what.append(umfa_torch.last_kernel())
+            for got, rf, name in ((qg.grad, qr.grad, "dq"), (kg.grad, kr.grad, "dk"), (vg.grad, vr.grad, "dv")):
+                if got is None or got.shape != rf.shape or not torch.isfinite(got).all():
+                    return "bad grad %s %r" % (name, what)
+                rel = ((got.double() - rf).abs().max() / rf.abs().max().clamp_min(1e-3)).item()
+                if rel > (4.5e-2 if dt == torch.bfloat16 else 1.2e-2):
+                    return "%s rel %.3e %r" % (name, rel, what)
+        else:
+            out = umfa_torch.scaled_dot_product_attention(q, k, v, is_causal=causal, enable_gqa=True)
+            what.append(umfa_torch.last_kernel())
+        rel = ((out.double() - ref.detach()).abs().max() / ref.detach().abs().max()).item()
+        if not torch.isfinite(out).all() or rel > (2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10):
+            return "out rel %.3e %r" % (rel, what)
+    except Exception as e:  # noqa: BLE001
+        return "exception %r %s" % ((seed,), repr(e)[:300])
+    return None
+
+
+def run_rope_case(seed):
+    """fused RoPE + SDPA (umfa_rope_attention_forward_stream) against rotate(q), rotate(k), attend through the same library:
+    the SAME BITS on whatever kernel the shape lands on (in-register rotation on the w64 rope kernels, pre-pass elsewhere);
+    random shapes, head dims, batched / shared tables, causal"""
+    from umfa_torch import ops
+    rng = random.Random(seed + 1700000)
+    dt = rng.choice([torch.bfloat16, torch.float16])
+    D = rng.choice([64, 128, 128, 256])
+    B, H = rng.choice([1, 2]), rng.choice([1, 2, 3, 6])
+    S = rng.choice([64, 100, 192, 256, 300, 512, 768, 1024, 1280])
+    causal = rng.random() < 0.5
+    batched = rng.random() < 0.4
+    force = rng.random() < 0.6
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=dt, generator=g) for _ in range(3))
+    ang = torch.rand((B, S, D // 2) if batched else (S, D // 2), device="cuda", generator=g) * 6.283
+    cos, sin = ang.cos().repeat_interleave(2, -1), ang.sin().repeat_interleave(2, -1)
+    umfa_torch.set_option("force_w64", 1 if force else 0)
+    try:
+        out, lse = ops.rope_attention_forward(q, k, v, cos, sin, causal=causal, return_lse=True)
+        name = umfa_torch.last_kernel()
+        ref, lse_ref = ops.attention_forward(ops.rope_rotate(q, cos, sin), ops.rope_rotate(k, cos, sin), v, causal=causal, return_lse=True)
+        what = (seed, str(dt), B, H, S, D, causal, batched, force, name, umfa_torch.last_kernel())
+        if not torch.isfinite(out).all():
+            return "non-finite %r" % (what,)
+        if not (torch.equal(out, ref) and torch.equal(lse, lse_ref)):
+            return "fused differs from rotate-then-attend: max %.3e %r" % ((out.float() - ref.float()).abs().max().item(), what)
+    except Exception as e:  # noqa: BLE001
+        return "exception %r %s" % ((seed,), repr(e)[:300])
+    finally:
+        umfa_torch.set_option("force_w64", 0)
+    return None
+
+
 # gradients: P and dS rounded to the operand type (tests/test_gpu_fuzz.py: 3e-2 bf16, 8e-3 fp16 on N(0,1) data) x 4 for keys that
 # are hundreds of times larger than their neighbours (a rounding of dS at such a key is multiplied by it; measured worst over
 # 2100 seeds: 9.8e-2 bf16, 1.9e-2 fp16): this leg is about finiteness and the exp / LSE arithmetic, the forward leg is the sharp one
@@ -303,7 +387,7 @@ if __name__ == "__main__":
     first, count = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 200)
     bad = 0
     for seed in range(first, first + count):
-        for fn in ((run_case, run_bwd_case, run_shape_case, run_i8_case) if len(sys.argv) < 4 else (globals()[sys.argv[3]],)):
+        for fn in ((run_case, run_bwd_case, run_shape_case, run_i8_case, run_gqa_case, run_rope_case) if len(sys.argv) < 4 else (globals()[sys.argv[3]],)):
             msg = fn(seed)
             if msg:
                 bad += 1

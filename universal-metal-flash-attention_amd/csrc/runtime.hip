@@ -416,8 +416,9 @@ mfa_error_t umfa_rope_attention_forward_stream(mfa_context_t context, void* stre
     StreamScratch& sc = ctx->pool(dev, st);
     const size_t eb = elem_bytes(p.in_prec);
     const bool lowp = p.in_prec != P_FP32 && dense_prec(intermediate_precision) != P_FP32;
-    FwdParams probe = p;  // dense K for the kernel-selection predicates
+    FwdParams probe = p;  // dense K for the kernel-selection predicates; WITH the rotation (head_dim 64 has no fused-rope kernel)
     probe.k = k;
+    probe.rope_cos = cos_table; probe.rope_sin = sin_table; probe.rope_tb = table_batch_stride;
     // in-kernel Q rotation: the 256-row kernel only, O in the operand type (fa_fwd16_w64.hip); everything else takes Q
     // through the rotate kernel too (same result, one more pass)
     const bool fuse_q = lowp && p.out_prec == p.in_prec && fwd_w64_supported(probe);
