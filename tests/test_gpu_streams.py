@@ -161,3 +161,38 @@ def test_sync_entry_restores_current_device_and_rejects_unknown_mask_type():
         assert rc == 1  # UMFA_MASK_TYPE_WINDOW exists on the in-stream entry only
         for b in bufs:
             b.close()
+
+
+def test_split_kv_forward_in_a_graph_survives_many_replays():
+    """fa_fwd16's split-KV fold inside a captured graph.  Its tickets used to be zeroed by a hipMemsetAsync in front of every
+    launch; as a memset NODE in front of a kernel whose agent-scope atomics bypass the L2 that left some tickets non-zero on
+    later replays: the last part never saw "everybody has drawn", nobody folded, and O kept whatever the buffer held (the old
+    result -- invisible unless the outputs are cleared between replays, which is what this test does).  The tickets are now
+    zeroed once per block and reset by the folding workgroup: no memset node in the graph."""
+    import umfa_torch
+    torch.manual_seed(8)
+    q, k, v = (torch.randn(1, 2, 512, 128, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+
+    def fn():
+        o, lse = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32, return_lse=True)
+        return o, lse, torch.matmul(q.float(), k.float().transpose(-1, -2))
+    eager = [t.clone() for t in fn()]
+    assert umfa_torch.last_kernel() == "fa_fwd16<bf16,128>"  # 8 items on 256 CUs: split into key ranges
+    torch.cuda.synchronize()
+    side, replay_on = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        fn()
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            cap = fn()
+    torch.cuda.synchronize()
+    for rep in range(8):
+        for t in cap:
+            t.zero_()
+        replay_on.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(replay_on):
+            g.replay()
+        torch.cuda.synchronize()
+        for a, b in zip(eager, cap):
+            assert torch.equal(a, b), rep

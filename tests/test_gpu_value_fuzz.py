@@ -58,3 +58,15 @@ def test_gqa_random_cases(seed):
 def test_fused_rope_random_cases(seed):
     msg = _fuzz().run_rope_case(seed)
     assert msg is None, msg
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_concurrent_streams_random_cases(seed):
+    msg = _fuzz().run_streams_case(seed)
+    assert msg is None, msg
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_graph_capture_random_cases(seed):
+    msg = _fuzz().run_graph_case(seed)
+    assert msg is None, msg

@@ -5,6 +5,7 @@ sign flips from tile to tile, zero rows -- through every forward kernel family (
 window, the 128-row kernel, the int8 kernel), against an fp64 restatement on the GPU.  Prints one line per failure.
 
   python tools/lab/value_fuzz.py [first_seed] [n_seeds]"""
+import os
 import random
 import sys
 from pathlib import Path
@@ -330,6 +331,128 @@ def run_rope_case(seed):
     return None
 
 
+def run_streams_case(seed):
+    """three streams at once, each with its own random call (w64 with cut items and partials, split-KV on the 128-row kernel,
+    the runtime-quantised forward with its workspace, the backward): every result must equal, bit for bit, what the same call
+    gave alone -- scratch pools are per (device, stream), tickets are per launch"""
+    rng = random.Random(seed + 2100000)
+    jobs = []
+    for sidx in range(3):
+        kind = rng.choice(["w64_cut", "split", "int8", "bwd", "window", "masked"])
+        dt = rng.choice([torch.bfloat16, torch.float16])
+        g = torch.Generator(device="cuda").manual_seed(seed * 7 + sidx)
+        if kind == "w64_cut":
+            B, H, S, D, kw = 1, rng.choice([3, 5, 6]), rng.choice([512, 1024, 2048]), 128, dict(causal=rng.random() < 0.3)
+        elif kind == "split":
+            B, H, S, D, kw = 1, rng.choice([1, 2]), rng.choice([1024, 2048, 4096]), rng.choice([64, 128]), {}
+        elif kind == "window":
+            B, H, S, D, kw = 1, rng.choice([2, 4]), rng.choice([768, 1536]), 128, dict(window=(rng.choice([64, 300]), rng.choice([0, 100])))
+        elif kind == "masked":
+            B, H, S, D, kw = 1, 2, rng.choice([256, 640]), rng.choice([64, 128]), {}
+        else:
+            B, H, S, D, kw = 1, rng.choice([2, 4]), rng.choice([256, 512, 1024]), 128, dict(causal=rng.random() < 0.5)
+        q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=dt, generator=g) for _ in range(3))
+        if kind == "masked":
+            kw["mask"] = torch.rand(1, 1, S, S, device="cuda", generator=g) < 0.8
+            kw["mask"][..., 0] = True
+        do = torch.randn(B, H, S, D, device="cuda", dtype=dt, generator=g)
+        force = kind in ("w64_cut", "window")
+
+        def call(q=q, k=k, v=v, do=do, kind=kind, kw=kw, force=force):
+            umfa_torch.set_option("force_w64", 1 if force else 0)
+            if kind == "int8":
+                return umfa_torch.quantized_attention_forward_stream(q, k, v, causal=kw.get("causal", False), return_lse=True)
+            if kind == "bwd":
+                o, lse = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32, return_lse=True, **kw)
+                return (o,) + tuple(umfa_torch.attention_backward(do, q, k, v, o, lse, scale=q.shape[-1] ** -0.5, **kw))
+            return umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32, return_lse=True, **kw)
+        jobs.append((kind, call))
+    try:
+        alone = []
+        for kind, call in jobs:
+            alone.append([t.clone() for t in call()])
+            torch.cuda.synchronize()
+        streams = [torch.cuda.Stream() for _ in jobs]
+        for rep in range(3):
+            got = []
+            for (kind, call), st in zip(jobs, streams):
+                with torch.cuda.stream(st):
+                    got.append(call())
+            torch.cuda.synchronize()
+            for (kind, _), a, b in zip(jobs, alone, got):
+                for x, y in zip(a, b):
+                    if not torch.equal(x, y):
+                        return "stream result differs from the serial one: %s rep %d seed %d max %.3e" % (
+                            kind, rep, seed, (x.float() - y.float()).abs().max().item())
+    except Exception as e:  # noqa: BLE001
+        return "exception %r %s" % ((seed, [j[0] for j in jobs]), repr(e)[:300])
+    finally:
+        umfa_torch.set_option("force_w64", 0)
+    return None
+
+
+def run_graph_case(seed):
+    """a hipGraph of two or three random calls (forward on either kernel family, window, runtime-quantised forward, forward +
+    backward), captured on a side stream after a warm-up there, replayed twice -- once while ANOTHER stream runs eager launches
+    of the same shapes (a capture owns its scratch pool) -- must reproduce the eager results bit for bit"""
+    rng = random.Random(seed + 2500000)
+    calls, kinds = [], []
+    for j in range(rng.choice([2, 3])):
+        kind = rng.choice(["fwd", "fwd_w64", "window", "int8", "fwd_bwd"])
+        dt = rng.choice([torch.bfloat16, torch.float16])
+        g = torch.Generator(device="cuda").manual_seed(seed * 5 + j)
+        B, H, D = 1, rng.choice([2, 3, 6]), 128 if kind in ("window", "int8") else rng.choice([64, 128])
+        S = rng.choice([256, 512, 1024, 2048]) if kind != "fwd" else rng.choice([64, 200, 512])
+        causal = rng.random() < 0.4 and kind != "window"
+        q, k, v, do = (torch.randn(B, H, S, D, device="cuda", dtype=dt, generator=g) for _ in range(4))
+        win = (rng.choice([100, 300]), rng.choice([0, 64]))
+
+        def call(q=q, k=k, v=v, do=do, kind=kind, causal=causal, win=win):
+            umfa_torch.set_option("force_w64", 1 if kind in ("fwd_w64", "window", "int8") else 0)
+            if kind == "int8":
+                return tuple(umfa_torch.quantized_attention_forward_stream(q, k, v, causal=causal, return_lse=True))
+            if kind == "window":
+                return tuple(umfa_torch.attention_forward(q, k, v, window=win, out_dtype=torch.float32, return_lse=True))
+            o, lse = umfa_torch.attention_forward(q, k, v, causal=causal, out_dtype=torch.float32, return_lse=True)
+            if kind == "fwd_bwd":
+                return (o, lse) + tuple(umfa_torch.attention_backward(do, q, k, v, o, lse, scale=q.shape[-1] ** -0.5, causal=causal))
+            return (o, lse)
+        calls.append(call)
+        kinds.append((kind, str(dt), H, S, D, causal))
+    try:
+        eager = [[t.clone() for t in c()] for c in calls]
+        torch.cuda.synchronize()
+        side, other = torch.cuda.Stream(), torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            for c in calls:
+                c()
+            side.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=side):
+                captured = [c() for c in calls]
+        torch.cuda.synchronize()
+        for rep in range(2):
+            for cap in captured:
+                for t in cap:
+                    t.zero_()
+            gr.replay()
+            if rep == 1 and not os.environ.get("FUZZ_NO_CONCURRENT"):
+                with torch.cuda.stream(other):
+                    for c in calls:
+                        c()
+            torch.cuda.synchronize()
+            for ci, (e, cap) in enumerate(zip(eager, captured)):
+                for ti, (x, y) in enumerate(zip(e, cap)):
+                    if not torch.equal(x, y):
+                        return "graph replay %d differs from eager: seed %d call %d (%s) tensor %d max %.3e" % (
+                            rep, seed, ci, kinds[ci], ti, (x.float() - y.float()).abs().max().item())
+    except Exception as e:  # noqa: BLE001
+        return "exception %r %s" % ((seed,), repr(e)[:300])
+    finally:
+        umfa_torch.set_option("force_w64", 0)
+    return None
+
+
 # gradients: P and dS rounded to the operand type (tests/test_gpu_fuzz.py: 3e-2 bf16, 8e-3 fp16 on N(0,1) data) x 4 for keys that
 # are hundreds of times larger than their neighbours (a rounding of dS at such a key is multiplied by it; measured worst over
 # 2100 seeds: 9.8e-2 bf16, 1.9e-2 fp16): this leg is about finiteness and the exp / LSE arithmetic, the forward leg is the sharp one
@@ -387,7 +510,7 @@ if __name__ == "__main__":
     first, count = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 200)
     bad = 0
     for seed in range(first, first + count):
-        for fn in ((run_case, run_bwd_case, run_shape_case, run_i8_case, run_gqa_case, run_rope_case) if len(sys.argv) < 4 else (globals()[sys.argv[3]],)):
+        for fn in ((run_case, run_bwd_case, run_shape_case, run_i8_case, run_gqa_case, run_rope_case, run_streams_case, run_graph_case) if len(sys.argv) < 4 else (globals()[sys.argv[3]],)):
             msg = fn(seed)
             if msg:
                 bad += 1

@@ -52,7 +52,7 @@ struct FwdParams {
     uint32_t n_full;     // items handled whole (== all items when nsplit <= 1)
     uint32_t nsplit;     // parts per split item (0/1 = no split)
     float* part_buf;     // [split item][part][wave 4][reg 16*NDB+2][lane 64] fp32
-    uint32_t* part_cnt;  // [split item] arrival tickets, zeroed before every launch
+    uint32_t* part_cnt;  // [split item] arrival tickets: zero on entry, left zero by the folding workgroup
     // mask tile flags (fa_fwd_16, optional): one byte per (mask batch, mask head, 32-row block, 64-key tile) from
     // mask_flags_kernel -- 0 mixed, 1 every in-range element masked (the tile is skipped), 2 every in-range element
     // attends with a zero term (the tile runs without reading the mask)

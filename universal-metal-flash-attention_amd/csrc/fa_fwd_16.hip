@@ -98,10 +98,7 @@ static hipError_t launch_dma(const FwdParams& pin, hipStream_t stream) {
     const uint32_t items = nqb * p.B * p.H;
     if (p.nsplit < 2 || !p.part_buf || !p.part_cnt) { p.n_full = items; p.nsplit = 1; }
     const uint32_t grid = p.n_full + (items - p.n_full) * p.nsplit;
-    if (p.nsplit > 1) {
-        hipError_t e = hipMemsetAsync(p.part_cnt, 0, (((size_t)(items - p.n_full) * 4) + 15) & ~(size_t)15, stream);
-        if (e != hipSuccess) return e;
-    }
+    // (p.part_cnt is zero on entry and on exit: the runtime zeroes a ticket block once, the folding workgroup resets its word)
     const size_t lds = 4 * BN * DP * 2;
     auto kfn = fa_fwd16_kernel<T, DP, CAUSAL, HAS_MASK, OUT, DMA, BN>;
     if (hipError_t e = ensure_dynamic_lds((const void*)kfn, lds); e != hipSuccess) return e;

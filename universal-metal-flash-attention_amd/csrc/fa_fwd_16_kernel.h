@@ -587,6 +587,9 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
         const uint32_t ticket = ticket_s;
         if (ticket != nparts - 1) return;  // not the last part of this item
         if (tid == 0) {
+            // every part has drawn: the word is free again -- leave it zero for the next launch (no memset per launch, and no
+            // memset node in a captured graph)
+            __hip_atomic_store(p.part_cnt + sidx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }

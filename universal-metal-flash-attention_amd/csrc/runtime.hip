@@ -95,12 +95,12 @@ hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p,
         const FwdSplitPlan plan = fwd_16_split_plan(p);
         if (plan.nsplit > 1) {
             // tickets first (16-byte multiple at the allocation start), partials behind them
-            char* buf = (char*)sc.split.ensure(plan.cnt_bytes + plan.buf_bytes, stream);  // the launcher zeroes the tickets
+            char* buf = sc.ensure_split(plan.cnt_bytes, plan.buf_bytes, stream);  // tickets zero: at allocation, then by the kernel
             if (!buf) return hipErrorOutOfMemory;  // same shape, same kernel plan, every time: never a silent other plan
             pp.n_full = plan.n_full;
             pp.nsplit = plan.nsplit;
             pp.part_cnt = (uint32_t*)buf;
-            pp.part_buf = (float*)(buf + plan.cnt_bytes);
+            pp.part_buf = (float*)(buf + sc.split_cnt_bytes);
         }
         if (pp.mask_kind != MK_NONE && !tuning().no_mask_flags.load(std::memory_order_relaxed) && mask_flags_worthwhile(pp)) {
             // tile early-exit for masks: one pre-pass over the distinct mask elements classifies every (32 rows x 64

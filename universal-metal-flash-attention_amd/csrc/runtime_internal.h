@@ -126,41 +126,53 @@ struct GrowBuf {
 };
 
 struct StreamScratch {
-    GrowBuf split;      // fa_fwd16 split-KV: tickets, then partials
+    GrowBuf split;      // fa_fwd16 split-KV: zeroed tickets (the kernel leaves them zero), then partials
+    size_t split_cnt_bytes = 0;
     GrowBuf w64;        // fa_fwd16_w64: zeroed tickets (the kernel leaves them zero), then partials
     size_t w64_cnt_bytes = 0;
     GrowBuf mflags;     // mask tile flags
     GrowBuf workspace;  // quantiser output (int8 Q/K, V image, scales, fp32 copies for backward)
     GrowBuf rowc;       // bwd16: row constants [2][B*H*Sq] fp32 (-LSE log2 e, -D) from bwd16_dq for bwd16_dkdv
 
-    // tickets [0, cnt) zeroed on `stream` whenever the block is new, partials behind them at w64_cnt_bytes
-    char* ensure_w64(size_t cnt_bytes, size_t buf_bytes, hipStream_t stream) {
-        const size_t c = cnt_bytes > w64_cnt_bytes ? cnt_bytes : w64_cnt_bytes;
+    // Ticketed scratch: tickets [0, cnt) zeroed on `stream` whenever the block is new -- and never again: the kernels leave
+    // their tickets zero (the folding workgroup resets the word it drew from), so a captured graph carries no memset node.
+    // Partials sit behind the tickets at `cnt_state`.  (Round 3: the per-launch hipMemsetAsync of fa_fwd16's split path, as a
+    // graph node in front of a kernel whose agent-scope atomics bypass the L2, left some tickets non-zero on later replays --
+    // tools/lab/value_fuzz.py run_graph_case found it; eager launches were never affected.)
+    static char* ensure_ticketed(GrowBuf& g, size_t& cnt_state, size_t cnt_bytes, size_t buf_bytes, hipStream_t stream) {
+        const size_t c = cnt_bytes > cnt_state ? cnt_bytes : cnt_state;
         bool grew = false;
-        if (c != w64_cnt_bytes && w64.ptr) {  // the ticket area moves: take a fresh block so old launches keep their layout
+        if (c != cnt_state && g.ptr) {  // the ticket area moves: take a fresh block so old launches keep their layout
             if (stream_capturing(stream)) return nullptr;
-            w64.retired.push_back(w64.ptr);
-            w64.ptr = nullptr;
-            w64.bytes = 0;
+            g.retired.push_back(g.ptr);
+            g.ptr = nullptr;
+            g.bytes = 0;
         }
-        char* b = (char*)w64.ensure(c + buf_bytes, stream, &grew);
+        char* b = (char*)g.ensure(c + buf_bytes, stream, &grew);
         if (!b) return nullptr;
         if (grew) {
             if (hipMemsetAsync(b, 0, c, stream) != hipSuccess) {
                 // tickets not zeroed: this block must never be handed out as valid -- retire it, the next call starts over
                 (void)hipGetLastError();
-                w64.retired.push_back(w64.ptr);
-                w64.ptr = nullptr;
-                w64.bytes = 0;
+                g.retired.push_back(g.ptr);
+                g.ptr = nullptr;
+                g.bytes = 0;
                 return nullptr;
             }
-            w64_cnt_bytes = c;
+            cnt_state = c;
         }
         return b;
+    }
+    char* ensure_w64(size_t cnt_bytes, size_t buf_bytes, hipStream_t stream) {
+        return ensure_ticketed(w64, w64_cnt_bytes, cnt_bytes, buf_bytes, stream);
+    }
+    char* ensure_split(size_t cnt_bytes, size_t buf_bytes, hipStream_t stream) {
+        return ensure_ticketed(split, split_cnt_bytes, cnt_bytes, buf_bytes, stream);
     }
     void release() {
         split.release(); w64.release(); mflags.release(); workspace.release(); rowc.release();
         w64_cnt_bytes = 0;
+        split_cnt_bytes = 0;
     }
 };
 
