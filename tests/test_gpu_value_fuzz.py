@@ -70,3 +70,9 @@ def test_concurrent_streams_random_cases(seed):
 def test_graph_capture_random_cases(seed):
     msg = _fuzz().run_graph_case(seed)
     assert msg is None, msg
+
+
+@pytest.mark.parametrize("seed", range(100))
+def test_mask_tensor_random_cases(seed):
+    msg = _fuzz().run_mask_case(seed)
+    assert msg is None, msg

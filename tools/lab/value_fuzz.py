@@ -453,6 +453,104 @@ def run_graph_case(seed):
     return None
 
 
+def run_mask_case(seed):
+    """mask tensors through the in-stream forward: bool / fp16 / bf16 / fp32 additive, 2-D ... 4-D, broadcast batch / head / row
+    dims, non-contiguous (sliced) masks, structured content (bands, key padding, block-diagonal, -inf stripes, fully masked
+    rows and tiles, all-true) -- the tile-flag pre-pass with its skip / open / mixed classes and the vector mask reads -- against
+    an fp64 restatement; rows without a key must give O = 0 and LSE = -inf"""
+    rng = random.Random(seed + 3100000)
+    dt = rng.choice([torch.bfloat16, torch.float16, torch.float32])
+    D = rng.choice([32, 64, 80, 128]) if dt != torch.float32 else rng.choice([32, 64])
+    B, H = rng.choice([1, 2, 3]), rng.choice([1, 2, 4])
+    Sq = rng.choice([1, 17, 64, 100, 128, 200, 256, 333, 512, 777])
+    Skv = Sq if rng.random() < 0.5 else rng.choice([1, 33, 64, 65, 128, 200, 256, 511, 640])
+    if dt == torch.float32:
+        Sq, Skv = min(Sq, 333), min(Skv, 333)
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    q = torch.randn(B, H, Sq, D, device="cuda", dtype=dt, generator=g)
+    k = torch.randn(B, H, Skv, D, device="cuda", dtype=dt, generator=g)
+    v = torch.randn(B, H, Skv, D, device="cuda", dtype=dt, generator=g)
+    i = torch.arange(Sq, device="cuda")[:, None]
+    j = torch.arange(Skv, device="cuda")[None, :]
+    content = rng.choice(["random", "band", "padding", "blockdiag", "stripes", "dead_rows", "all_true", "all_false_tail"])
+    if content == "random":
+        keep = torch.rand(Sq, Skv, device="cuda", generator=g) < rng.choice([0.1, 0.5, 0.9])
+    elif content == "band":
+        w = rng.choice([1, 8, 64, 150])
+        keep = (i * Skv // max(Sq, 1) - j).abs() <= w
+    elif content == "padding":
+        keep = (j < rng.randrange(1, Skv + 1)).expand(Sq, Skv).clone()
+    elif content == "blockdiag":
+        bs = rng.choice([16, 64, 96])
+        keep = (i // bs) == (j // bs)
+    elif content == "stripes":
+        keep = ((j // rng.choice([3, 32, 64])) % 2 == 0).expand(Sq, Skv).clone()
+    elif content == "dead_rows":
+        keep = torch.rand(Sq, Skv, device="cuda", generator=g) < 0.6
+        keep[:: rng.choice([2, 5, 64])] = False
+    elif content == "all_true":
+        keep = torch.ones(Sq, Skv, dtype=torch.bool, device="cuda")
+    else:
+        keep = (j < max(1, Skv // 2)).expand(Sq, Skv).clone()
+    shape_kind = rng.choice(["2d", "3d", "4d_full", "4d_b1", "4d_h1", "4d_row1", "sliced"])
+    if content in ("padding", "stripes", "all_false_tail") and rng.random() < 0.5:
+        shape_kind = "4d_row1"
+    if shape_kind == "2d":
+        keep_m = keep
+    elif shape_kind == "3d":
+        keep_m = keep[None].expand(H, Sq, Skv).clone()
+    elif shape_kind == "4d_full":
+        keep_m = keep[None, None].expand(B, H, Sq, Skv).clone()
+        if B * H > 1 and content == "random":
+            keep_m = torch.rand(B, H, Sq, Skv, device="cuda", generator=g) < 0.6
+    elif shape_kind == "4d_b1":
+        keep_m = keep[None, None].expand(1, H, Sq, Skv).clone()
+    elif shape_kind == "4d_h1":
+        keep_m = keep[None, None].expand(B, 1, Sq, Skv).clone()
+    elif shape_kind == "4d_row1":
+        keep_m = keep[:1][None, None].clone()  # [1, 1, 1, Skv]
+    else:
+        wide = torch.zeros(B, H, Sq, 2 * Skv + 3, dtype=torch.bool, device="cuda")
+        wide[..., 1:2 * Skv + 1:2] = keep
+        keep_m = wide[..., 1:2 * Skv + 1:2]  # key stride 2, offset 1: no vector reads
+    mdt = rng.choice(["bool", "bool", "f32", "f16", "bf16"])
+    if mdt == "bool":
+        mask = keep_m
+    else:
+        add = torch.randn(keep_m.shape, device="cuda", generator=g) * rng.choice([0.0, 1.0, 3.0])
+        mask = add.masked_fill(~keep_m, float("-inf")).to({"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[mdt])
+        if shape_kind == "sliced":
+            wide = torch.zeros(B, H, Sq, 2 * Skv + 3, dtype=mask.dtype, device="cuda")
+            wide[..., 1:2 * Skv + 1:2] = mask
+            mask = wide[..., 1:2 * Skv + 1:2]
+    try:
+        out, lse = umfa_torch.attention_forward(q, k, v, mask=mask, out_dtype=torch.float32, return_lse=True)
+        kern = umfa_torch.last_kernel()
+        what = (seed, str(dt), B, H, Sq, Skv, D, content, shape_kind, mdt, kern)
+        s_ = torch.matmul(q.double(), k.double().transpose(-1, -2)) * D ** -0.5
+        mfull = mask if mask.dim() == 4 else mask.view((1,) * (4 - mask.dim()) + tuple(mask.shape))
+        s_ = s_.masked_fill(~mfull, float("-inf")) if mask.dtype == torch.bool else s_ + mfull.double()
+        rl = torch.logsumexp(s_, dim=-1)
+        p_ = torch.nan_to_num(torch.softmax(s_, dim=-1), nan=0.0)
+        ref = torch.matmul(p_, v.double())
+        if not torch.isfinite(out).all():
+            return "non-finite %r" % (what,)
+        tol = 2e-5 if dt == torch.float32 else CEIL[dt]
+        rel = ((out.double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+        fin = torch.isfinite(rl)
+        lg = lse.view(B, H, Sq).double()
+        lerr = ((lg - rl)[fin].abs() / rl[fin].abs().clamp_min(50.0)).max().item() if fin.any() else 0.0
+        dead_ok = bool(torch.isneginf(lg[~fin]).all()) and bool((out[(~fin).unsqueeze(-1).expand_as(out)] == 0).all())
+        if rel > tol or lerr > (1e-3 if dt != torch.float32 else 1e-5) or not dead_ok:
+            return "rel %.3e lse %.3e dead rows ok %s %r" % (rel, lerr, dead_ok, what)
+        o2 = umfa_torch.attention_forward(q, k, v, mask=mask, out_dtype=torch.float32)
+        if not torch.equal(out, o2):
+            return "not bitwise repeatable %r" % (what,)
+    except Exception as e:  # noqa: BLE001
+        return "exception %r %s" % ((seed, content, shape_kind, mdt), repr(e)[:300])
+    return None
+
+
 # gradients: P and dS rounded to the operand type (tests/test_gpu_fuzz.py: 3e-2 bf16, 8e-3 fp16 on N(0,1) data) x 4 for keys that
 # are hundreds of times larger than their neighbours (a rounding of dS at such a key is multiplied by it; measured worst over
 # 2100 seeds: 9.8e-2 bf16, 1.9e-2 fp16): this leg is about finiteness and the exp / LSE arithmetic, the forward leg is the sharp one
@@ -510,7 +608,7 @@ if __name__ == "__main__":
     first, count = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 200)
     bad = 0
     for seed in range(first, first + count):
-        for fn in ((run_case, run_bwd_case, run_shape_case, run_i8_case, run_gqa_case, run_rope_case, run_streams_case, run_graph_case) if len(sys.argv) < 4 else (globals()[sys.argv[3]],)):
+        for fn in ((run_case, run_bwd_case, run_shape_case, run_i8_case, run_gqa_case, run_rope_case, run_streams_case, run_graph_case, run_mask_case) if len(sys.argv) < 4 else (globals()[sys.argv[3]],)):
             msg = fn(seed)
             if msg:
                 bad += 1
