@@ -76,3 +76,9 @@ def test_graph_capture_random_cases(seed):
 def test_mask_tensor_random_cases(seed):
     msg = _fuzz().run_mask_case(seed)
     assert msg is None, msg
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_blocking_host_abi_random_cases(seed):
+    msg = _fuzz().run_host_case(seed)
+    assert msg is None, msg

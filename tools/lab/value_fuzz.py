@@ -551,6 +551,83 @@ def run_mask_case(seed):
     return None
 
 
+_HOST_CTX = None
+
+
+def run_host_case(seed):
+    """the BLOCKING C ABI with host (numpy) buffers, as the reference's python-ffi package uses it: mfa_attention_forward
+    (masks: bool / additive, broadcast), mfa_attention_forward_with_lse, mfa_attention_backward; fp32 / fp16 / bf16-bit
+    operands, 2-D and 4-D layouts -- against the CPU oracle"""
+    global _HOST_CTX
+    import numpy as np
+    import umfa
+    from oracle import oracle
+    if _HOST_CTX is None:
+        _HOST_CTX = umfa.MFAContext()
+    ctx = _HOST_CTX
+    rng = random.Random(seed + 3700000)
+    nrng = np.random.default_rng(seed)
+    prec = rng.choice(["fp32", "fp16", "bf16"])
+    D = rng.choice([16, 32, 64, 80, 128])
+    two_d = rng.random() < 0.2
+    B, H = (1, 1) if two_d else (rng.choice([1, 2]), rng.choice([1, 2, 3]))
+    Sq = rng.choice([1, 7, 64, 100, 128, 200, 257])
+    Skv = Sq if rng.random() < 0.6 else rng.choice([1, 33, 64, 129, 200])
+    causal = rng.random() < 0.35
+    what = [seed, prec, B, H, Sq, Skv, D, two_d, causal]
+
+    def conv(a):
+        if prec == "fp32":
+            return a.astype(np.float32)
+        if prec == "fp16":
+            return a.astype(np.float16)
+        return oracle.f32_to_bf16_bits(a.astype(np.float32)).reshape(a.shape)
+    shp_q, shp_k = ((Sq, D), (Skv, D)) if two_d else ((B, H, Sq, D), (B, H, Skv, D))
+    q, k, v = conv(nrng.standard_normal(shp_q)), conv(nrng.standard_normal(shp_k)), conv(nrng.standard_normal(shp_k))
+    q4, k4, v4 = (a.reshape((1, 1) + a.shape) if two_d else a for a in (q, k, v))
+    tol = {"fp32": 2e-5, "fp16": 2.0 ** -11 * 1.5, "bf16": 2.0 ** -8 * 1.5}[prec]
+    try:
+        mode = rng.choice(["plain", "mask_bool", "mask_add", "lse_bwd"])
+        what.append(mode)
+        kw = dict(causal=causal, input_precision=prec, intermediate_precision=prec, output_precision="fp32", layout="bhsd")
+        if mode in ("mask_bool", "mask_add"):
+            mshape = rng.choice([(Sq, Skv), (1, 1, Sq, Skv), (B, H, Sq, Skv), (1, 1, 1, Skv)]) if not two_d else (Sq, Skv)
+            if mode == "mask_bool":
+                m = nrng.random(mshape) < 0.7
+                m[..., 0] = True
+                o = umfa.flash_attention_forward(ctx, q, k, v, attn_mask=m, **kw)
+                ref = oracle.sdpa_forward(q4, k4, v4, causal=causal, mask=np.ascontiguousarray(m), mask_type=oracle.MASK_BOOL)
+            else:
+                m = (nrng.standard_normal(mshape) * 2).astype(np.float32)
+                o = umfa.flash_attention_forward(ctx, q, k, v, attn_mask=m, **kw)
+                ref = oracle.sdpa_forward(q4, k4, v4, causal=causal, mask=m, mask_type=oracle.MASK_ADDITIVE)
+            o = np.asarray(o, np.float32).reshape(ref.shape)
+            rel = float(np.abs(o - ref).max() / max(np.abs(ref).max(), 1e-30))
+            if not np.isfinite(o).all() or rel > tol:
+                return "rel %.3e %r" % (rel, what)
+            return None
+        o, lse = umfa.flash_attention_forward(ctx, q, k, v, return_lse=True, **kw)
+        ref, rlse = oracle.sdpa_forward(q4, k4, v4, causal=causal, return_lse=True)
+        o = np.asarray(o, np.float32).reshape(ref.shape)
+        rel = float(np.abs(o - ref).max() / max(np.abs(ref).max(), 1e-30))
+        if not np.isfinite(o).all() or rel > tol or np.abs(lse.reshape(rlse.shape) - rlse).max() > (2e-2 if prec != "fp32" else 1e-4):
+            return "fwd rel %.3e lse %.3e %r" % (rel, float(np.abs(lse.reshape(rlse.shape) - rlse).max()), what)
+        if mode == "lse_bwd" and not two_d:
+            do = conv(nrng.standard_normal(shp_q))
+            dq, dk, dv, dvec = umfa.attention_backward(ctx, do, q, k, v, o, lse, causal=causal, input_precision=prec, layout="bhsd")
+            rdq, rdk, rdv, _ = oracle.sdpa_backward(do, q, k, v, ref, rlse, causal=causal)
+            gt = {"fp32": 1e-4, "fp16": 8e-3, "bf16": 3e-2}[prec]
+            for got, rf, name in ((dq, rdq, "dq"), (dk, rdk, "dk"), (dv, rdv, "dv")):
+                # (a row with ONE visible key has dQ = 0 exactly: the floor of the denominator keeps the metric meaningful there;
+                # operands are N(0,1), ordinary gradients are O(0.1 ... 1))
+                r = float(np.abs(got - rf).max() / max(np.abs(rf).max(), 0.1))
+                if not np.isfinite(got).all() or r > gt:
+                    return "%s rel %.3e %r" % (name, r, what + [ctx.last_kernel])
+    except Exception as e:  # noqa: BLE001
+        return "exception %r %s" % (what, repr(e)[:300])
+    return None
+
+
 # gradients: P and dS rounded to the operand type (tests/test_gpu_fuzz.py: 3e-2 bf16, 8e-3 fp16 on N(0,1) data) x 4 for keys that
 # are hundreds of times larger than their neighbours (a rounding of dS at such a key is multiplied by it; measured worst over
 # 2100 seeds: 9.8e-2 bf16, 1.9e-2 fp16): this leg is about finiteness and the exp / LSE arithmetic, the forward leg is the sharp one
@@ -608,7 +685,7 @@ if __name__ == "__main__":
     first, count = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 200)
     bad = 0
     for seed in range(first, first + count):
-        for fn in ((run_case, run_bwd_case, run_shape_case, run_i8_case, run_gqa_case, run_rope_case, run_streams_case, run_graph_case, run_mask_case) if len(sys.argv) < 4 else (globals()[sys.argv[3]],)):
+        for fn in ((run_case, run_bwd_case, run_shape_case, run_i8_case, run_gqa_case, run_rope_case, run_streams_case, run_graph_case, run_mask_case, run_host_case) if len(sys.argv) < 4 else (globals()[sys.argv[3]],)):
             msg = fn(seed)
             if msg:
                 bad += 1
