@@ -2,8 +2,11 @@
 directions, large / tiny score scales, attention sinks, sign flips from key tile to key tile, zero rows) through every forward
 kernel family -- w64 bf16 / fp16 at head_dim 128 and 64, causal, sliding window, the 128-row kernel with and without masks, the
 int8 kernel -- against an fp64 restatement (16-bit kernels: max error <= 1.5 ulp of P at 1.0) or the oracle's quantised forward
-(int8: 2.5e-3).  Found in round 3 by this sweep: lazy-mode underflow of rows that start a segment on the reference 0, and a
-window whose left extent was clamped to Skv instead of Sq."""
+(int8: 2.5e-3); further legs: arbitrary shapes through the forced w64 families, the backward, the runtime-quantised forward and
+backward, grouped K / V heads, fused RoPE, mask tensors, the blocking host-buffer ABI, concurrent streams and hipGraph capture.
+Found in round 3 by these sweeps: lazy-mode underflow of rows that start a segment on the reference 0; a window whose left
+extent was clamped to Skv instead of Sq; fused RoPE at head_dim 64 failing with error 5; the split-KV fold silently missing from
+the second replay of a captured graph on."""
 import importlib.util
 import sys
 from pathlib import Path
@@ -81,4 +84,10 @@ def test_mask_tensor_random_cases(seed):
 @pytest.mark.parametrize("seed", range(60))
 def test_blocking_host_abi_random_cases(seed):
     msg = _fuzz().run_host_case(seed)
+    assert msg is None, msg
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_quantized_forward_backward_random_cases(seed):
+    msg = _fuzz().run_qbwd_case(seed)
     assert msg is None, msg

@@ -628,6 +628,53 @@ def run_host_case(seed):
     return None
 
 
+def run_qbwd_case(seed):
+    """in-stream runtime-quantised forward + backward (umfa_quantized_forward_stream / umfa_quantized_backward_stream: fp16
+    de-quantised operands on the 16-bit MFMA backward) on random shapes, against the CPU oracle's fp64 backward on the SAME
+    de-quantised operands (block-wise int8, 64-row blocks)"""
+    import numpy as np
+    from oracle import oracle
+    rng = random.Random(seed + 4300000)
+    dt = rng.choice([torch.bfloat16, torch.float16])
+    D = rng.choice([64, 128])
+    B, H = 1, rng.choice([1, 2, 3])
+    S = rng.choice([64, 128, 192, 256, 320, 512])
+    causal = rng.random() < 0.4
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    q, k, v, do = (torch.randn(B, H, S, D, device="cuda", dtype=dt, generator=g) for _ in range(4))
+    try:
+        o, lse = umfa_torch.quantized_attention_forward_stream(q, k, v, causal=causal, return_lse=True)
+        dq, dk, dv, status = umfa_torch.quantized_attention_backward_stream(do, q, k, v, o, lse, causal=causal)
+        torch.cuda.synchronize()
+        kern = umfa_torch.last_kernel()
+        what = (seed, str(dt), B, H, S, D, causal, kern, int(status.item()))
+        if int(status.item()) != 0:
+            return "overflow status on N(0,1) data %r" % (what,)
+
+        def fake(t):
+            x = t.float().cpu().numpy()
+            out = np.empty_like(x)
+            for h in range(H):
+                qv, sc = oracle.quantize_symmetric(x[0, h], group=64 * D)
+                out[0, h] = oracle.dequantize(qv, sc, group=64 * D).reshape(S, D)
+            return out
+        fq, fk, fv = fake(q), fake(k), fake(v)
+        ro, rlse = oracle.sdpa_forward(fq, fk, fv, causal=causal, return_lse=True)
+        on = o.cpu().numpy()
+        rel = float(np.abs(on - ro).max() / np.abs(ro).max())
+        if rel > 2.5e-3:
+            return "forward rel %.3e %r" % (rel, what)
+        rdq, rdk, rdv, _ = oracle.sdpa_backward(do.float().cpu().numpy(), fq, fk, fv, on, lse.cpu().numpy().reshape(B, H, S), causal=causal)
+        for got, rf, name in ((dq, rdq, "dq"), (dk, rdk, "dk"), (dv, rdv, "dv")):
+            gn = got.float().cpu().numpy()
+            err = float(np.abs(gn - rf).max() / max(1.0, np.abs(rf).max()))
+            if not np.isfinite(gn).all() or err > (3e-3 if got.dtype == torch.float32 else 1.2e-2):
+                return "%s err %.3e %r" % (name, err, what)
+    except Exception as e:  # noqa: BLE001
+        return "exception %r %s" % ((seed,), repr(e)[:300])
+    return None
+
+
 # gradients: P and dS rounded to the operand type (tests/test_gpu_fuzz.py: 3e-2 bf16, 8e-3 fp16 on N(0,1) data) x 4 for keys that
 # are hundreds of times larger than their neighbours (a rounding of dS at such a key is multiplied by it; measured worst over
 # 2100 seeds: 9.8e-2 bf16, 1.9e-2 fp16): this leg is about finiteness and the exp / LSE arithmetic, the forward leg is the sharp one
@@ -685,7 +732,7 @@ if __name__ == "__main__":
     first, count = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 200)
     bad = 0
     for seed in range(first, first + count):
-        for fn in ((run_case, run_bwd_case, run_shape_case, run_i8_case, run_gqa_case, run_rope_case, run_streams_case, run_graph_case, run_mask_case, run_host_case) if len(sys.argv) < 4 else (globals()[sys.argv[3]],)):
+        for fn in ((run_case, run_bwd_case, run_shape_case, run_i8_case, run_gqa_case, run_rope_case, run_streams_case, run_graph_case, run_mask_case, run_host_case, run_qbwd_case) if len(sys.argv) < 4 else (globals()[sys.argv[3]],)):
             msg = fn(seed)
             if msg:
                 bad += 1
