@@ -163,13 +163,14 @@ def test_sync_entry_restores_current_device_and_rejects_unknown_mask_type():
             b.close()
 
 
-def test_split_kv_forward_in_a_graph_survives_many_replays():
+def test_split_kv_forward_in_a_graph_survives_many_replays(umfa_opts):
     """fa_fwd16's split-KV fold inside a captured graph.  Its tickets used to be zeroed by a hipMemsetAsync in front of every
     launch; as a memset NODE in front of a kernel whose agent-scope atomics bypass the L2 that left some tickets non-zero on
     later replays: the last part never saw "everybody has drawn", nobody folded, and O kept whatever the buffer held (the old
     result -- invisible unless the outputs are cleared between replays, which is what this test does).  The tickets are now
     zeroed once per block and reset by the folding workgroup: no memset node in the graph."""
     import umfa_torch
+    umfa_opts(force_w64=0)  # (this file forces the w64 kernel for its other tests)
     torch.manual_seed(8)
     q, k, v = (torch.randn(1, 2, 512, 128, device="cuda", dtype=torch.bfloat16) for _ in range(3))
 
