@@ -675,6 +675,84 @@ def run_qbwd_case(seed):
     return None
 
 
+def run_prequant_case(seed):
+    """the pre-quantised backward ABI (mfa_attention_backward_{query,kv}_quantized_ex): caller-side int8 / packed int4 operands,
+    per-tensor scales with zero points or per-block scales (block sizes 16 / 32 / 64), grouped K / V heads, causal, head dims
+    64 / 128 / 256 / 80 (the last: the fp32-exact engine) -- against the oracle's fp64 backward on the de-quantised operands"""
+    global _HOST_CTX
+    import numpy as np
+    import umfa
+    from umfa.core import prequantized_backward
+    from oracle import oracle as orc
+    if _HOST_CTX is None:
+        _HOST_CTX = umfa.MFAContext()
+    ctx = _HOST_CTX
+    rng = random.Random(seed + 4900000)
+    nrng = np.random.default_rng(seed)
+    bits = rng.choice([8, 8, 4])
+    blockwise = rng.random() < 0.5
+    BS = rng.choice([16, 32, 64])
+    D = rng.choice([64, 64, 128, 80, 256])
+    Hkv = rng.choice([1, 2])
+    G = rng.choice([1, 1, 2, 3])
+    H = Hkv * G
+    B = rng.choice([1, 2])
+    Sq = rng.choice([16, 64, 80, 128, 200])
+    Skv = Sq if rng.random() < 0.5 else rng.choice([32, 96, 128, 160])
+    causal = rng.random() < 0.4
+    qmax = 127 if bits == 8 else 7
+    use_zp = (not blockwise) and bits == 8 and rng.random() < 0.4
+    what = [seed, bits, blockwise, BS, D, B, H, Hkv, Sq, Skv, causal, use_zp]
+
+    def quant(x):
+        if blockwise:
+            Bq, Hh, S, Dd = x.shape
+            nb = (S + BS - 1) // BS
+            scales = np.zeros((Bq, Hh, nb), np.float32)
+            qv = np.zeros(x.shape, np.int8)
+            for b in range(Bq):
+                for h in range(Hh):
+                    for j in range(nb):
+                        blk = x[b, h, j * BS:(j + 1) * BS]
+                        sc = max(np.abs(blk).max() / qmax, 1e-12)
+                        scales[b, h, j] = sc
+                        qv[b, h, j * BS:(j + 1) * BS] = np.clip(np.round(blk / sc), -qmax - 1, qmax)
+            deq = qv.astype(np.float32) * np.repeat(scales, BS, axis=2)[:, :, :S, None]
+            return qv, 1.0, 0, scales.ravel(), deq
+        zp = int(nrng.integers(-20, 21)) if use_zp else 0
+        sc = np.float32(np.abs(x).max() / (qmax - abs(zp) - 1 if use_zp else qmax))
+        qv = np.clip(np.round(x / sc) + zp, -qmax - 1, qmax).astype(np.int8)
+        return qv, float(sc), zp, None, (qv.astype(np.float32) - zp) * sc
+
+    try:
+        q = nrng.standard_normal((B, H, Sq, D), dtype=np.float32)
+        k = nrng.standard_normal((B, Hkv, Skv, D), dtype=np.float32)
+        v = nrng.standard_normal((B, Hkv, Skv, D), dtype=np.float32)
+        dout = nrng.standard_normal((B, H, Sq, D), dtype=np.float32)
+        (q8, qs, qz, qbs, qd), (k8, ks, kz, kbs, kd), (v8, vs, vz, vbs, vd) = quant(q), quant(k), quant(v)
+        kx, vx = np.repeat(kd, G, axis=1), np.repeat(vd, G, axis=1)
+        o, lse = orc.sdpa_forward(qd, kx, vx, causal=causal, return_lse=True)
+        dq, dkx, dvx, dvec = orc.sdpa_backward(dout, qd, kx, vx, o, lse, causal=causal)
+        dk = dkx.reshape(B, Hkv, G, Skv, D).sum(2)
+        dv = dvx.reshape(B, Hkv, G, Skv, D).sum(2)
+        raw = (lambda a: orc.pack_int4(a)) if bits == 4 else (lambda a: a)
+        pname = "int8" if bits == 8 else "int4"
+        gq, gk, gv, gd = prequantized_backward(
+            ctx, raw(q8), raw(k8), raw(v8), o, dout, lse.ravel(), q_scale=qs, k_scale=ks, v_scale=vs, q_zero_point=qz, k_zero_point=kz,
+            v_zero_point=vz, q_block_scales=qbs, k_block_scales=kbs, v_block_scales=vbs, q_block_size=BS if blockwise else 0,
+            k_block_size=BS if blockwise else 0, v_block_size=BS if blockwise else 0, q_precision=pname, k_precision=pname,
+            v_precision=pname, causal=causal, num_heads=H, num_kv_heads=Hkv, head_dim=D, seq_len_q=Sq, seq_len_kv=Skv, batch_size=B)
+        what.append(ctx.last_kernel)
+        tol = 2e-4 if ctx.last_kernel.startswith("fa_bwd_exact") else 2.5e-3
+        for got, ref, name in ((gq, dq, "dq"), (gk, dk, "dk"), (gv, dv, "dv"), (gd, dvec.ravel(), "D")):
+            err = float(np.abs(got - ref).max() / max(1.0, np.abs(ref).max()))
+            if not np.isfinite(got).all() or err > tol:
+                return "%s err %.3e %r" % (name, err, what)
+    except Exception as e:  # noqa: BLE001
+        return "exception %r %s" % (what, repr(e)[:300])
+    return None
+
+
 # gradients: P and dS rounded to the operand type (tests/test_gpu_fuzz.py: 3e-2 bf16, 8e-3 fp16 on N(0,1) data) x 4 for keys that
 # are hundreds of times larger than their neighbours (a rounding of dS at such a key is multiplied by it; measured worst over
 # 2100 seeds: 9.8e-2 bf16, 1.9e-2 fp16): this leg is about finiteness and the exp / LSE arithmetic, the forward leg is the sharp one
@@ -732,7 +810,7 @@ if __name__ == "__main__":
     first, count = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 200)
     bad = 0
     for seed in range(first, first + count):
-        for fn in ((run_case, run_bwd_case, run_shape_case, run_i8_case, run_gqa_case, run_rope_case, run_streams_case, run_graph_case, run_mask_case, run_host_case, run_qbwd_case) if len(sys.argv) < 4 else (globals()[sys.argv[3]],)):
+        for fn in ((run_case, run_bwd_case, run_shape_case, run_i8_case, run_gqa_case, run_rope_case, run_streams_case, run_graph_case, run_mask_case, run_host_case, run_qbwd_case, run_prequant_case) if len(sys.argv) < 4 else (globals()[sys.argv[3]],)):
             msg = fn(seed)
             if msg:
                 bad += 1
