@@ -97,3 +97,9 @@ def test_quantized_forward_backward_random_cases(seed):
 def test_prequantized_backward_random_cases(seed):
     msg = _fuzz().run_prequant_case(seed)
     assert msg is None, msg
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_rotations_random_cases(seed):
+    msg = _fuzz().run_aux_case(seed)
+    assert msg is None, msg

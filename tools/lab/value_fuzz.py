@@ -753,6 +753,57 @@ def run_prequant_case(seed):
     return None
 
 
+def run_aux_case(seed):
+    """the two rotations of SURVEY.md 8(f): mfa_rope_rotate_encode_mtl (random shapes, dtypes, strided sources, shared / batched
+    tables, inverse) and mfa_hadamard_rotate (power-of-two blocks up to 8192) against the CPU oracle"""
+    import numpy as np
+    from oracle import oracle
+    rng = random.Random(seed + 5300000)
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    try:
+        if rng.random() < 0.6:
+            dt = rng.choice([torch.float32, torch.float16, torch.bfloat16])
+            B, H = rng.choice([1, 2, 3]), rng.choice([1, 2, 5])
+            S = rng.choice([1, 9, 64, 100, 257, 1000])
+            D = rng.choice([2, 6, 32, 64, 80, 128, 256])
+            strided = rng.random() < 0.4
+            x = (torch.randn(B, S, H, D, device="cuda", dtype=dt, generator=g).permute(0, 2, 1, 3) if strided
+                 else torch.randn(B, H, S, D, device="cuda", dtype=dt, generator=g))
+            batched = rng.random() < 0.4
+            ang = torch.rand((B, S, D // 2) if batched else (S, D // 2), device="cuda", generator=g) * 6.283
+            cos, sin = ang.cos().repeat_interleave(2, -1), ang.sin().repeat_interleave(2, -1)
+            y = umfa_torch.rope_rotate(x, cos, sin)
+            xc = x.contiguous().cpu()
+            xb = xc.numpy() if dt != torch.bfloat16 else xc.view(torch.int16).numpy().view(np.uint16)
+            ref = oracle.rope_rotate(xb, cos.cpu().numpy(), sin.cpu().numpy())
+            tol = {torch.float32: 1e-6, torch.float16: 2e-3, torch.bfloat16: 1.6e-2}[dt]
+            err = float((y.float().cpu() - torch.from_numpy(ref)).abs().max()) / max(1.0, float(np.abs(ref).max()))
+            what = (seed, "rope", str(dt), B, H, S, D, strided, batched)
+            if y.dtype != dt or tuple(y.shape) != (B, H, S, D) or err > tol:
+                return "err %.3e %r" % (err, what)
+            back = umfa_torch.rope_rotate(y, cos, sin, negate_sin=True)
+            if float((back.float() - x.float()).abs().max()) > 3 * tol * max(1.0, float(x.float().abs().max())):
+                return "inverse rotation %r" % (what,)
+        else:
+            dt = rng.choice([torch.float32, torch.float16])
+            block = 2 ** rng.randrange(1, 14)
+            nblk = rng.choice([1, 2, 3, 7, 33])
+            x = torch.randn(nblk * block, device="cuda", dtype=dt, generator=g)
+            ref = oracle.hadamard(x.cpu().numpy(), block)
+            y = umfa_torch.hadamard_rotate(x.clone(), block)
+            tol = 2e-5 if dt == torch.float32 else 4e-3
+            err = float(np.abs(y.float().cpu().numpy() - ref).max()) / max(1.0, float(np.abs(ref).max()))
+            what = (seed, "hadamard", str(dt), block, nblk)
+            if err > tol:
+                return "err %.3e %r" % (err, what)
+            z = umfa_torch.hadamard_rotate(y.clone(), block)
+            if float((z.float() - x.float()).abs().max()) > 3 * tol * max(1.0, float(x.float().abs().max())):
+                return "not an involution %r" % (what,)
+    except Exception as e:  # noqa: BLE001
+        return "exception %r %s" % ((seed,), repr(e)[:300])
+    return None
+
+
 # gradients: P and dS rounded to the operand type (tests/test_gpu_fuzz.py: 3e-2 bf16, 8e-3 fp16 on N(0,1) data) x 4 for keys that
 # are hundreds of times larger than their neighbours (a rounding of dS at such a key is multiplied by it; measured worst over
 # 2100 seeds: 9.8e-2 bf16, 1.9e-2 fp16): this leg is about finiteness and the exp / LSE arithmetic, the forward leg is the sharp one
@@ -810,7 +861,7 @@ if __name__ == "__main__":
     first, count = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 200)
     bad = 0
     for seed in range(first, first + count):
-        for fn in ((run_case, run_bwd_case, run_shape_case, run_i8_case, run_gqa_case, run_rope_case, run_streams_case, run_graph_case, run_mask_case, run_host_case, run_qbwd_case, run_prequant_case) if len(sys.argv) < 4 else (globals()[sys.argv[3]],)):
+        for fn in ((run_case, run_bwd_case, run_shape_case, run_i8_case, run_gqa_case, run_rope_case, run_streams_case, run_graph_case, run_mask_case, run_host_case, run_qbwd_case, run_prequant_case, run_aux_case) if len(sys.argv) < 4 else (globals()[sys.argv[3]],)):
             msg = fn(seed)
             if msg:
                 bad += 1
