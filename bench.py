@@ -431,6 +431,8 @@ def run_rank(args) -> None:
         _flux_regime("cfg3_flux_bf16_tau0", torch.bfloat16, softmax_reference="exact")
         _flux_regime("cfg3_flux_bf16_tau6", torch.bfloat16, softmax_reference="deferred", softmax_tau=6)
         _flux_regime("cfg3_flux_fp16", torch.float16)
+        # bf16 operands with P and V of the second product in fp16 (option pv_fp16; the V cast pre-pass is inside the timed call)
+        _flux_regime("cfg3_flux_bf16_pv_fp16", torch.bfloat16, pv_fp16=1)
         o3, lse3 = umfa_torch.attention_forward(q, k, v, return_lse=True)
         do3 = torch.randn_like(q)
         tb_e = med(event_ms(lambda: umfa_torch.attention_backward(do3, q, k, v, o3, lse3, scale=D ** -0.5), 20))

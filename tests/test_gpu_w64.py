@@ -514,3 +514,55 @@ def test_w64_very_long_sequence_rows(causal):
         assert (lse.view(B, H, S)[:, :, rows].double() - torch.logsumexp(s, -1)).abs().max().item() < 2e-2
     del s, ref
     assert torch.equal(out, umfa_torch.attention_forward(q, k, v, causal=causal, out_dtype=torch.float32))
+
+
+@pytest.mark.parametrize("shape,causal", [((1, 2, 256, 256), False), ((2, 3, 768, 448), False), ((1, 2, 1100, 777), False),
+                                          ((1, 3, 1024, 1024), True), ((1, 2, 512, 1000), True)])
+def test_w64_bf16_operands_with_fp16_pv(shape, causal):
+    """option pv_fp16: bf16 Q / K / V, but P rounded to fp16 and multiplied with an fp16 copy of V (exact for |v| <= 65504): the
+    second product carries 11 bits instead of 8 and the bf16-input forward sits INSIDE the north-star's 1e-3 -- held here to
+    fp16's own format ceiling (one ulp of P at 1.0 = 2^-11) against the oracle on the bf16 inputs"""
+    import umfa_torch
+    B, H, Sq, Skv = shape
+    torch.manual_seed(Sq + Skv)
+    q = torch.randn(B, H, Sq, 128, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(B, H, Skv, 128, device="cuda", dtype=torch.bfloat16)
+    vs = torch.randn(B, Skv, H, 128, device="cuda", dtype=torch.bfloat16)
+    v = vs.transpose(1, 2)  # strided V: the cast pre-pass reads it in place
+    ref, ref_lse = _oracle().sdpa_forward(bits(q), bits(k), bits(v), causal=causal, return_lse=True)
+    with umfa_torch.options(pv_fp16=1):
+        o, lse = umfa_torch.attention_forward(q, k, v, causal=causal, out_dtype=torch.float32, return_lse=True)
+        kern = umfa_torch.last_kernel()
+        assert kern == "fa_fwd16_w64<bf16,128,pv16>", kern
+        o16 = umfa_torch.attention_forward(q, k, v, causal=causal)
+        assert torch.equal(o, umfa_torch.attention_forward(q, k, v, causal=causal, out_dtype=torch.float32))
+    on = o.cpu().numpy()
+    assert np.isfinite(on).all()
+    mx = float(np.abs(on - ref).max() / np.abs(ref).max())
+    assert mx < 2.0 ** -11, mx  # measured 2-3e-4; the plain bf16 kernel: 1-2e-3
+    assert np.abs(lse.cpu().numpy().reshape(ref_lse.shape) - ref_lse).max() < 2e-2
+    assert o16.dtype == torch.bfloat16 and (o16.float() - o).abs().max() <= 2.0 ** -8 * o.abs().max() * 1.01
+    o_plain = umfa_torch.attention_forward(q, k, v, causal=causal, out_dtype=torch.float32)
+    assert umfa_torch.last_kernel() == "fa_fwd16_w64<bf16,128>"
+    assert float(np.abs(o_plain.cpu().numpy() - ref).max() / np.abs(ref).max()) > mx  # the mode buys accuracy
+
+
+def test_w64_fp16_pv_flux_rows_and_saturation():
+    import umfa_torch
+    umfa_torch.set_option("force_w64", 0)
+    torch.manual_seed(2)
+    B, H, S, D = 1, 24, 4096, 128
+    q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    from oracle import parity
+    rows = parity.sample_rows(S)
+    ref = _oracle().sdpa_forward_rows(bits(q), bits(k), bits(v), rows)
+    with umfa_torch.options(pv_fp16=1):
+        o = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
+        assert umfa_torch.last_kernel() == "fa_fwd16_w64<bf16,128,pv16>"
+        mx = float(np.abs(o[:, :, rows].cpu().numpy() - ref).max() / np.abs(ref).max())
+        assert mx < 1.0e-3 / 2, mx  # the north-star's bound with a factor of two to spare
+        # V beyond fp16's range saturates at +-65504 (documented): finite output
+        vbig = v.clone()
+        vbig[0, 0, 5, 7] = 3.0e8
+        ob = umfa_torch.attention_forward(q, k, vbig, out_dtype=torch.float32)
+        assert torch.isfinite(ob).all()

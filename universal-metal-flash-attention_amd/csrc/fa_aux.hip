@@ -254,6 +254,39 @@ hipError_t launch_cast_f16(const void* src, int prec, void* dst, int64_t n, uint
     return hipGetLastError();
 }
 
+// V of the pv_fp16 forward mode: bf16 rows (any batch / head / row strides) -> dense fp16, saturating (bf16 reaches 3e38)
+__global__ __launch_bounds__(256) void cast_rows_bf16_f16_kernel(const uint16_t* src, int64_t sb, int64_t sh, int64_t ss, _Float16* dst,
+                                                                 uint32_t H, uint32_t S, uint32_t D8, int64_t n8) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const uint32_t c = (uint32_t)(i % D8);
+        const int64_t row = i / D8;
+        const uint32_t s_ = (uint32_t)(row % S);
+        const int64_t bh = row / S;
+        const uint32_t h = (uint32_t)(bh % H);
+        const int64_t b = bh / H;
+        const s16x8 raw = *(const s16x8*)(src + b * sb + h * sh + (int64_t)s_ * ss + 8 * c);
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float x = bf16_bits_to_float((uint16_t)raw[j]);
+            x = x > 65504.0f ? 65504.0f : (x < -65504.0f ? -65504.0f : x);  // (NaN passes through)
+            o[j] = (_Float16)x;
+        }
+        ((f16x8*)dst)[i] = o;
+    }
+}
+
+hipError_t launch_cast_rows_bf16_to_f16(const void* src, const int64_t* strides, void* dst, uint32_t B, uint32_t H, uint32_t S, uint32_t D,
+                                        hipStream_t stream) {
+    if (!src || !dst || (D & 7) || strides[3] != 1 || (strides[0] | strides[1] | strides[2]) % 8 || ((uintptr_t)src & 15)) return hipErrorInvalidValue;
+    const int64_t n8 = (int64_t)B * H * S * (D / 8);
+    if (n8 == 0) return hipSuccess;
+    const unsigned grid = (unsigned)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : 8192);
+    hipLaunchKernelGGL(cast_rows_bf16_f16_kernel, dim3(grid), dim3(256), 0, stream, (const uint16_t*)src, strides[0], strides[1], strides[2],
+                       (_Float16*)dst, H, S, D / 8, n8);
+    return hipGetLastError();
+}
+
 hipError_t launch_bwd16_rowc(const float* lse, const float* dvec, float* rowc, int64_t n, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);

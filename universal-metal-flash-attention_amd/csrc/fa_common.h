@@ -65,6 +65,9 @@ struct FwdParams {
     const float* rope_cos;
     const float* rope_sin;
     int64_t rope_tb;
+    // bf16 operands with the P V product in fp16 (option pv_fp16): v points at an fp16 copy of V (dense BHSD), P is rounded
+    // to fp16 -- 11 bits instead of 8 -- and the bf16-input forward then meets the 1e-3 bound (fa_fwd16_w64 only)
+    int pv16;
 };
 
 // Interleaved-pair rotary rotation of 8 consecutive elements (4 pairs) given the 8 table entries of their columns

@@ -19,7 +19,7 @@ struct Tuning {
     std::atomic<int> sm_mode{SM_DEFAULT};
     std::atomic<float> sm_tau{6.0f};
     std::atomic<int> force_w64{0}, no_w64{0}, w64_grid{0}, w64_skew{0}, no_mask_flags{0}, bwd_exact{0}, bwd_dq{0}, bwd_persist{0},
-        bwd_separate_delta{0}, no_split{0}, force_split{0}, no_dma{0}, bn64{0};
+        bwd_separate_delta{0}, no_split{0}, force_split{0}, no_dma{0}, bn64{0}, pv_fp16{0};
 };
 Tuning& tuning();
 bool set_tuning(const char* name, const char* value);  // false: unknown name or value out of range
@@ -90,6 +90,8 @@ struct DequantParams {
 hipError_t launch_dequant(const DequantParams& p, hipStream_t stream);
 // dense fp32 / bf16 -> fp16 (n % 8 == 0, 16-byte aligned); *overflow |= 1 when a value does not fit
 hipError_t launch_cast_f16(const void* src, int prec, void* dst, int64_t n, uint32_t* overflow, hipStream_t stream);
+// bf16 [B,H,S,D] with element strides (head_dim contiguous) -> dense fp16 [B,H,S,D], saturating at +-65504
+hipError_t launch_cast_rows_bf16_to_f16(const void* src, const int64_t* strides, void* dst, uint32_t B, uint32_t H, uint32_t S, uint32_t D, hipStream_t stream);
 // rowc[0 .. n) = -lse * log2 e, rowc[n .. 2n) = -dvec: what bwd16_dq leaves for bwd16_dkdv, for a dK / dV-only call
 hipError_t launch_bwd16_rowc(const float* lse, const float* dvec, float* rowc, int64_t n, hipStream_t stream);
 // dst: [B, Hkv, slab] in out_prec (fp32 default; fp16 / bf16: rounded once after the fp32 sum)

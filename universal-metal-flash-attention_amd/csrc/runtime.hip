@@ -84,10 +84,22 @@ hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p,
     hipError_t e;
     const bool lowp = p.in_prec != P_FP32 && intermediate_prec != P_FP32;
     if (lowp && fwd_w64_supported(p)) {
-        const FwdW64Plan plan = fwd_w64_plan(p);
+        FwdParams pv = p;
+        // option pv_fp16: bf16 operands, P and V of the second product in fp16 (11 bits of P instead of 8: the bf16-input forward
+        // then sits inside 1e-3).  V is cast once per call into the stream's workspace (dense, saturating at +-65504).
+        if (tuning().pv_fp16.load(std::memory_order_relaxed) && p.in_prec == P_BF16 && p.D == 128 && p.mask_kind == MK_NONE && !p.rope_cos) {
+            const size_t vbytes = (size_t)p.B * p.H * p.Skv * p.D * 2;
+            void* v16 = sc.workspace.ensure(vbytes + 256, stream);
+            if (!v16) return hipErrorOutOfMemory;
+            if ((e = launch_cast_rows_bf16_to_f16(p.v, p.vs, v16, p.B, p.H, p.Skv, p.D, stream)) != hipSuccess) return e;
+            pv.v = v16;
+            pv.vs[0] = (int64_t)p.H * p.Skv * p.D; pv.vs[1] = (int64_t)p.Skv * p.D; pv.vs[2] = p.D; pv.vs[3] = 1;
+            pv.pv16 = 1;
+        }
+        const FwdW64Plan plan = fwd_w64_plan(pv);
         char* w64 = sc.ensure_w64(plan.cnt_bytes, plan.buf_bytes, stream);
         if (!w64) return hipErrorOutOfMemory;
-        e = launch_fwd_w64(p, (float*)(w64 + sc.w64_cnt_bytes), (uint32_t*)w64, stream, &name);
+        e = launch_fwd_w64(pv, (float*)(w64 + sc.w64_cnt_bytes), (uint32_t*)w64, stream, &name);
     } else if (p.rope_cos) {
         return hipErrorNotSupported;  // only the 256-row kernel rotates Q in registers (the entry asks before it sets this)
     } else if (lowp && fwd_16_supported(p)) {
