@@ -76,13 +76,16 @@ def transform(rng, q, k, v, kind, info=None):
 
 KINDS = ["shift_m4000", "shift_m250", "shift_p250", "shift_p4000", "scale_big", "scale_tiny", "sink_first", "sink_last", "sink_mid",
          "tile_flip", "zero_rows", "ramp"]
-FAMILIES = ["w64", "w64_causal", "w64_window", "w64_d64", "w64_d64_causal", "r128", "r128_causal", "r128_mask", "int8", "int8_causal"]
+FAMILIES = ["w64", "w64_causal", "w64_window", "w64_d64", "w64_d64_causal", "r128", "r128_causal", "r128_mask", "int8", "int8_causal",
+            "w64_pv16", "w64_pv16_causal"]
 def run_case(seed):
     """one seeded case; returns None or a failure description"""
     rng = random.Random(seed)
     fam = FAMILIES[seed % len(FAMILIES)]
     kind = rng.choice(KINDS)
     dt = rng.choice([torch.bfloat16, torch.float16])
+    if "pv16" in fam:
+        dt = torch.bfloat16  # bf16 operands, fp16 P V (option pv_fp16): held to fp16's ceiling
     D = 64 if "d64" in fam else 128
     B, H = rng.choice([1, 2]), rng.choice([2, 3])
     Sq = rng.choice([256, 512, 768, 1024])
@@ -100,6 +103,7 @@ def run_case(seed):
     kw = dict(causal=causal)
     umfa_torch.set_option("force_w64", 1 if fam.startswith("w64") or fam.startswith("int8") else 0)
     umfa_torch.set_option("no_w64", 1 if fam.startswith("r128") else 0)
+    umfa_torch.set_option("pv_fp16", 1 if "pv16" in fam else 0)
     if fam == "w64_window":
         win = (rng.choice([0, 40, 200, 700]), rng.choice([0, 64, 130]))
         keep = (j >= i - win[0]) & (j <= i + win[1])
@@ -125,8 +129,10 @@ def run_case(seed):
         else:
             out, lse = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32, return_lse=True, **kw)
             ref, rl = ref64(q, k, v, scale, keep)
-            tol = CEIL[dt]
+            tol = CEIL[torch.float16 if "pv16" in fam else dt]
         kern = umfa_torch.last_kernel()
+        if "pv16" in fam and kern != "fa_fwd16_w64<bf16,128,pv16>":
+            return "pv_fp16 did not take its kernel: %s" % kern
         torch.cuda.synchronize()
         what = (seed, fam, kind, str(dt), B, H, Sq, Skv, D, kw.get("window"), kern)
         if not torch.isfinite(out).all():
@@ -141,6 +147,7 @@ def run_case(seed):
     finally:
         umfa_torch.set_option("force_w64", 0)
         umfa_torch.set_option("no_w64", 0)
+        umfa_torch.set_option("pv_fp16", 0)
     return None
 
 
