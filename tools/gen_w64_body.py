@@ -827,11 +827,17 @@ def emit_helpers(lines):
     """Helpers that touch the asm-owned O^T registers a[128:255] by literal number."""
     a = lines.append
     a("// GENERATED by tools/gen_w64_body.py -- helpers that address the asm-owned O^T registers a[128:255].")
+    a("// The clobbers of v254 / a254 are what makes the kernel descriptor allocate the whole register file (next_free_vgpr = 255")
+    a("// -> 256 + 256 after the hardware's granule; tests/test_w64_build_contract.py reads it back from the assembly).  hipcc")
+    a("// says \"clobber list contains reserved registers\": under amdgpu_num_vgpr(128) every register from 128 up is reserved FROM")
+    a("// THE ALLOCATOR -- which is the point: those registers are the generated stream's, the compiler never names them (the")
+    a("// same test checks that too).  The diagnostic is therefore expected here and only here, and switched off here and only here.")
+    a("#pragma clang diagnostic push")
+    a("#pragma clang diagnostic ignored \"-Winline-asm\"")
     a("__device__ __forceinline__ void zero_o() {")
     a("    asm volatile(" + " ".join(f'"v_accvgpr_write_b32 a{O_BASE + r}, 0\\n\\t"' for r in range(128)) + ' "s_nop 0" ::: "memory", "v254", "a254");')
     a("}")
-    a("// (the clobbers make the kernel descriptor allocate the whole register file: next_free = 255 rounds up to 256 + 256;")
-    a("// v255 / a255 themselves are names hipcc reserves, and naming them in a clobber list draws a warning)")
+    a("#pragma clang diagnostic pop")
     a("// ---- matrix-pipe row sums (tools/gen_w64_body.py MS_*): literal v[118:127], kernels compiled with amdgpu_num_vgpr(118)")
     a("__device__ __forceinline__ void ms_init_ones(unsigned bits) {")
     a(f'    asm volatile("v_mov_b32 v{MS_ONES}, %0\\n\\tv_mov_b32 v{MS_ONES + 1}, %0\\n\\ts_nop 1" :: "s"(bits) : "memory");')

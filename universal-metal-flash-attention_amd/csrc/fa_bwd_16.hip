@@ -182,6 +182,7 @@ __global__ __launch_bounds__(256, DP == 256 ? 1 : 2) void bwd16_dq_kernel(BwdPar
     uint32_t qb = vid % nqb;
     if (CAUSAL) qb = nqb - 1 - causal_rank(vid, nqb, bh, DP != 256);  // the last query block sees the most keys
     const uint32_t q_row = qb * 128 + wave * 32 + ql, wave_q0 = qb * 128 + wave * 32;
+    (void)wave_q0;  // (causal instantiations only)
     const bool qok = q_row < p.Sq;
     const T* qp = (const T*)p.q + (int64_t)bh * p.Sq * DP;
     const T* dop = (const T*)p.dout + (int64_t)bh * p.Sq * DP;
@@ -377,6 +378,7 @@ template <typename T, bool CAUSAL>
 __global__ __launch_bounds__(256, 1) void bwd16_dq2_kernel(BwdParams p) {
     constexpr int DP = 128;
     BWD16_GEO(DP);
+    (void)PD;  // (this kernel keeps PF = 8 row fragments in flight instead)
     typedef Mma16<T> M;
     typedef typename M::V8 V8;
     extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -135,6 +135,7 @@ struct W64I8Params {
 
 // head_dim 64: the same structure (tools/gen_w64_body.py Cfg(d64=True)): 32 MFMAs per 64-key tile, rows of 128 bytes in the
 // tile images, d-blocks 0 and 1 of head_dim 128's O^T register map
+#undef W64_DP  /* (the kernel text defaults it to 128) */
 #define W64_DP 64
 #define W64_BODY_INC "fa_fwd16_w64d64_body.inc"
 #undef W64_MSUM
