@@ -512,7 +512,7 @@ def start_streams(have_new, mfma_follows=True, masked=False):
 
 
 def lazy_streams(masked):
-    """Steady-state tiles of the LAZY reference mode (bf16 P only): no row max at all.  e = s*c - m against the reference
+    """Steady-state tiles of the LAZY reference mode (every body but the fp8 one; thresholds per P format in the includer): no row max at all.  e = s*c - m against the reference
     of the previous tiles as soon as a score block's MFMAs are done; whether the reference has to move is read off the
     row sums the matrix pipe delivers anyway (includer: W64_LAZY_CHECK on l after the body -- bf16 P and the fp32
     accumulators have fp32's exponent range, so a stale reference costs no accuracy until l nears 2^100; the includer

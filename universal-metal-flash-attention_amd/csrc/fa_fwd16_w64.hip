@@ -84,7 +84,7 @@ struct W64I8Params {
 #define W64_MFMA_QK "v_mfma_f32_32x32x16_bf16"
 #define W64_MSUM "v_mfma_f32_4x4x4_16b_bf16"   /* row sums: lane-local sum of four P values against an all-ones operand */
 #define W64_ONES_BITS 0x3f803f80u              /* bf16 1.0 twice */
-#define W64_LAZY_PARTS 1                        /* bf16 P has fp32's exponent range: the lazy reference mode exists here only */
+#define W64_LAZY_PARTS 1                        /* lazy reference mode, bf16 P: fp32's exponent range (2 = fp16 P: tighter thresholds) */
 #define W64_CVT "v_cvt_pk_bf16_f32"
 #define W64_KERNEL fa_fwd16_w64_bf16
 #include "fa_fwd16_w64_kernel.inc"
