@@ -413,6 +413,31 @@ def test_w64_sliding_window_vs_oracle(shape, window, causal, dt):
     assert float((o - o128).abs().max()) <= (2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10) * float(o128.abs().max())
 
 
+@pytest.mark.parametrize("shape,window,causal", [((1, 2, 512, 512), (100, 100), False), ((2, 3, 768, 1024), (64, 0), True),
+                                                 ((1, 2, 1100, 777), (300, 50), False), ((2, 2, 768, 640), (700, 0), False)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_w64_sliding_window_head_dim_64(shape, window, causal, dt):
+    """the window instantiations of the head_dim 64 family (the same kernel text, W64_DP = 64)"""
+    import umfa_torch
+    B, H, Sq, Skv = shape
+    torch.manual_seed(Sq + Skv + 64)
+    q = torch.randn(B, H, Sq, 64, device="cuda", dtype=dt)
+    k = torch.randn(B, H, Skv, 64, device="cuda", dtype=dt)
+    v = torch.randn(B, H, Skv, 64, device="cuda", dtype=dt)
+    o, lse = umfa_torch.attention_forward(q, k, v, causal=causal, window=window, out_dtype=torch.float32, return_lse=True)
+    kern = umfa_torch.last_kernel()
+    assert kern == ("fa_fwd16_w64<bf16,64,window>" if dt == torch.bfloat16 else "fa_fwd16_w64<fp16,64,window>"), kern
+    keep = _band(Sq, Skv, window, causal)
+    from oracle.oracle import MASK_BOOL
+    ref, ref_lse = _oracle().sdpa_forward(npy(q), npy(k), npy(v), mask=np.ascontiguousarray(keep), mask_type=MASK_BOOL, return_lse=True)
+    live = keep.any(axis=1)
+    on = o.cpu().numpy()
+    assert np.isfinite(on).all()
+    check_forward(on[:, :, live], ref[:, :, live], dt, kern, "w64_window_d64")
+    assert np.abs(lse.cpu().numpy().reshape(ref_lse.shape)[:, :, live] - ref_lse[:, :, live]).max() < 2e-2
+    assert torch.equal(o, umfa_torch.attention_forward(q, k, v, causal=causal, window=window, out_dtype=torch.float32))
+
+
 @pytest.mark.parametrize("mode", ["exact", "deferred", "lazy"])
 def test_w64_sliding_window_softmax_references(mode):
     """every softmax-reference policy through the window kernel, scores scaled up (|s| of a few nats per sigma): waves whose

@@ -248,7 +248,7 @@ static uint32_t w64_tiles_per_item(const FwdParams& p) {
 bool fwd_w64_supported(const FwdParams& p) {
     if (tuning().no_w64.load(std::memory_order_relaxed) || !fwd_16_supported(p)) return false;
     if ((p.D != 128 && p.D != 64) || (p.mask_kind != MK_NONE && p.mask_kind != MK_WINDOW)) return false;
-    if (w64_is_window(p) && (p.D != 128 || p.rope_cos)) return false;  // window instantiations: head_dim 128, no fused rotation
+    if (w64_is_window(p) && p.rope_cos) return false;  // window instantiations: no fused rotation
     if (p.D == 64 && p.rope_cos) return false;  // the fused Q rotation exists at head_dim 128 only
     // rows are processed in blocks of 256: a ragged last block wastes its empty waves, so small ragged Sq stay on
     // the 128-row kernel; any Skv >= 64 works (a partial last key tile runs the masking variant of the tile body)
@@ -364,6 +364,16 @@ hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cn
         wp.Tw = w64_tiles_per_item(p);
         wp.win_left = (int32_t)w64_win_left(p);
         wp.win_right = (int32_t)w64_win_right(p);
+        if (p.D == 64) {
+            if (p.in_prec == P_BF16) {
+                *name = "fa_fwd16_w64<bf16,64,window>";
+                return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64d64_bf16<float, false, false, true>, p, wp, stream)
+                                            : launch_w64_kernel(fa_fwd16_w64d64_bf16<__bf16, false, false, true>, p, wp, stream);
+            }
+            *name = "fa_fwd16_w64<fp16,64,window>";
+            return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64d64_f16<float, false, false, true>, p, wp, stream)
+                                        : launch_w64_kernel(fa_fwd16_w64d64_f16<_Float16, false, false, true>, p, wp, stream);
+        }
         if (p.in_prec == P_BF16) {
             *name = "fa_fwd16_w64<bf16,128,window>";
             return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64_bf16<float, false, false, true>, p, wp, stream)
