@@ -406,7 +406,7 @@ const char* umfa_last_kernel_name(mfa_context_t context);
  *   "force_w64" "no_w64" "w64_grid" "no_mask_flags" "bwd_exact" "bwd_dq" "bwd_persist" "no_split" "force_split"
  *   "no_dma" "bn64"      kernel-selection overrides used by tests and A/B benches ("0" / "1" or a number)
  *   "pv_fp16"            "0" | "1": bf16 operands with the P V product in fp16 (P rounded to fp16, V cast once per call to an
- *                        fp16 image saturating at +-65504): the bf16-input forward inside 1e-3 (head_dim 128, no mask)
+ *                        fp16 image saturating at +-65504): the bf16-input forward inside 1e-3 (head_dim 128 / 64, launches of the w64 kernels, no mask)
  * Returns MFA_ERROR_INVALID_ARGS for an unknown name or a value out of range.  Thread-safe; affects later launches. */
 mfa_error_t umfa_set_option(mfa_context_t context, const char* name, const char* value);
 

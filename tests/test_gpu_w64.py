@@ -572,6 +572,18 @@ def test_w64_bf16_operands_with_fp16_pv(shape, causal):
     assert float(np.abs(o_plain.cpu().numpy() - ref).max() / np.abs(ref).max()) > mx  # the mode buys accuracy
 
 
+@pytest.mark.parametrize("causal", [False, True])
+def test_w64_fp16_pv_head_dim_64(causal):
+    import umfa_torch
+    torch.manual_seed(64)
+    q, k, v = (torch.randn(2, 3, 768, 64, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    ref = _oracle().sdpa_forward(bits(q), bits(k), bits(v), causal=causal)
+    with umfa_torch.options(pv_fp16=1):
+        o = umfa_torch.attention_forward(q, k, v, causal=causal, out_dtype=torch.float32)
+        assert umfa_torch.last_kernel() == "fa_fwd16_w64<bf16,64,pv16>"
+    assert float(np.abs(o.cpu().numpy() - ref).max() / np.abs(ref).max()) < 2.0 ** -11
+
+
 def test_w64_fp16_pv_flux_rows_and_saturation():
     import umfa_torch
     umfa_torch.set_option("force_w64", 0)

@@ -54,7 +54,8 @@ def test_compiler_stays_in_the_lower_register_halves(asm):
     # + sliding-window instantiations at head_dim 128: bf16 / fp16 x {fp32, 16-bit O}
     # + bf16 Q / K with fp16 P V (option pv_fp16): {fp32, bf16 O} x {causal, not}
     # + sliding-window instantiations at head_dim 64: bf16 / fp16 x {fp32, 16-bit O}
-    assert len(kernels) == 36, sorted(kernels)
+    # + pv_fp16 at head_dim 64: {fp32, bf16 O} x {causal, not}
+    assert len(kernels) == 40, sorted(kernels)
     for name, lines in kernels.items():
         in_asm, vmax, amax, n_mfma, loop_scratch = False, 0, 0, 0, 0
         mfma_seen = 0
@@ -94,7 +95,7 @@ def test_every_kernel_gets_512_registers(asm):
     nxt = [int(x) for x in re.findall(r"\.amdhsa_next_free_vgpr (\d+)", asm)]
     acc = [int(x) for x in re.findall(r"\.amdhsa_accum_offset (\d+)", asm)]
     # the hardware allocates in granules of 8 registers: 511 (clobbers name v254 / a254, the highest names hipcc does not reserve) is 512
-    assert len(nxt) == 36 and all((n + 7) // 8 * 8 == 512 for n in nxt), nxt
+    assert len(nxt) == 40 and all((n + 7) // 8 * 8 == 512 for n in nxt), nxt
     assert all(a == 256 for a in acc), acc
 
 

@@ -158,6 +158,23 @@ struct W64I8Params {
 #undef W64_LAZY_PARTS
 #undef W64_CVT
 #undef W64_KERNEL
+#define W64_T __bf16                            /* bf16 Q / K, fp16 P V (option pv_fp16) at head_dim 64 */
+#define W64_MFMA "v_mfma_f32_32x32x16_f16"
+#define W64_MFMA_QK "v_mfma_f32_32x32x16_bf16"
+#define W64_MSUM "v_mfma_f32_4x4x4_16b_f16"
+#define W64_ONES_BITS 0x3c003c00u
+#define W64_LAZY_PARTS 2
+#define W64_CVT "v_cvt_pk_f16_f32"
+#define W64_KERNEL fa_fwd16_w64d64_bf16pv16
+#include "fa_fwd16_w64_kernel.inc"
+#undef W64_T
+#undef W64_MFMA
+#undef W64_MFMA_QK
+#undef W64_MSUM
+#undef W64_ONES_BITS
+#undef W64_LAZY_PARTS
+#undef W64_CVT
+#undef W64_KERNEL
 #define W64_T _Float16
 #define W64_MFMA "v_mfma_f32_32x32x16_f16"
 #define W64_MFMA_QK "v_mfma_f32_32x32x16_f16"
@@ -352,7 +369,15 @@ hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cn
                         : launch_w64_kernel(fa_fwd16_w64_f16<_Float16, false, true>, p, wp, stream);
     }
     if (p.pv16) {  // bf16 Q / K, fp16 P and V (runtime.hip hands over the fp16 V copy): head_dim 128, no window, no fused rotation
-        if (p.in_prec != P_BF16 || p.D != 128 || w64_is_window(p) || p.rope_cos) return hipErrorNotSupported;
+        if (p.in_prec != P_BF16 || w64_is_window(p) || p.rope_cos) return hipErrorNotSupported;
+        if (p.D == 64) {
+            *name = "fa_fwd16_w64<bf16,64,pv16>";
+            if (p.causal)
+                return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64d64_bf16pv16<float, true>, p, wp, stream)
+                                            : launch_w64_kernel(fa_fwd16_w64d64_bf16pv16<__bf16, true>, p, wp, stream);
+            return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64d64_bf16pv16<float, false>, p, wp, stream)
+                                        : launch_w64_kernel(fa_fwd16_w64d64_bf16pv16<__bf16, false>, p, wp, stream);
+        }
         *name = "fa_fwd16_w64<bf16,128,pv16>";
         if (p.causal)
             return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64_bf16pv16<float, true>, p, wp, stream)

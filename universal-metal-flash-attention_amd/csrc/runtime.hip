@@ -87,7 +87,7 @@ hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p,
         FwdParams pv = p;
         // option pv_fp16: bf16 operands, P and V of the second product in fp16 (11 bits of P instead of 8: the bf16-input forward
         // then sits inside 1e-3).  V is cast once per call into the stream's workspace (dense, saturating at +-65504).
-        if (tuning().pv_fp16.load(std::memory_order_relaxed) && p.in_prec == P_BF16 && p.D == 128 && p.mask_kind == MK_NONE && !p.rope_cos) {
+        if (tuning().pv_fp16.load(std::memory_order_relaxed) && p.in_prec == P_BF16 && (p.D == 128 || p.D == 64) && p.mask_kind == MK_NONE && !p.rope_cos) {
             const size_t vbytes = (size_t)p.B * p.H * p.Skv * p.D * 2;
             void* v16 = sc.workspace.ensure(vbytes + 256, stream);
             if (!v16) return hipErrorOutOfMemory;
