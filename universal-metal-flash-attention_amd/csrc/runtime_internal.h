@@ -198,10 +198,34 @@ struct Context {
         }
     };
     std::map<PoolKey, StreamScratch> pools;
+    // A capture-private pool lives as long as the graph it was captured into (and the executables instantiated from it): the
+    // first call of a capture hangs a HIP user object on the graph being built; its destructor -- which may not call HIP --
+    // only raises `released`, and the next eager call through this context frees the pool.  (Before: never freed unless the
+    // caller said umfa_release_scratch -- a process that keeps re-capturing leaked one pool per capture; the fuzz's graph leg
+    // filled 288 GB in 2 240 captures.)  If the runtime refuses the user object the old behaviour remains.
+    struct CaptureToken { std::atomic<int> released{0}; };
+    std::map<PoolKey, CaptureToken*> tokens;
+    static void capture_graph_destroyed(void* tok) { static_cast<CaptureToken*>(tok)->released.store(1, std::memory_order_release); }
+    void reap_released_captures() {  // mu held, caller's stream is not capturing
+        for (auto it = tokens.begin(); it != tokens.end();) {
+            if (!it->second->released.load(std::memory_order_acquire)) { ++it; continue; }
+            auto pit = pools.find(it->first);
+            if (pit != pools.end()) {
+                DeviceGuard g(it->first.dev);
+                pit->second.release();
+                pools.erase(pit);
+            }
+            delete it->second;
+            it = tokens.erase(it);
+        }
+    }
     // call with mu held; the returned object is stable (std::map nodes never move)
     StreamScratch& pool(int dev, hipStream_t stream) {
         const unsigned long long cap = capture_id(stream);
-        if (!cap) return pools[PoolKey{dev, stream, 0}];
+        if (!cap) {
+            if (!tokens.empty()) reap_released_captures();
+            return pools[PoolKey{dev, stream, 0}];
+        }
         const PoolKey ck{dev, stream, cap};
         auto it = pools.find(ck);
         if (it == pools.end()) {
@@ -211,6 +235,26 @@ struct Context {
             if (eager != pools.end()) {
                 it->second = std::move(eager->second);
                 pools.erase(eager);
+            }
+            hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+            unsigned long long id = 0;
+            hipGraph_t graph = nullptr;
+            if (hipStreamGetCaptureInfo_v2(stream, &st, &id, &graph, nullptr, nullptr) == hipSuccess && graph) {
+                CaptureToken* tok = new CaptureToken;
+                hipUserObject_t obj = nullptr;
+                if (hipUserObjectCreate(&obj, tok, capture_graph_destroyed, 1, hipUserObjectNoDestructorSync) == hipSuccess) {
+                    if (hipGraphRetainUserObject(graph, obj, 1, hipGraphUserObjectMove) == hipSuccess) {
+                        tokens[ck] = tok;
+                    } else {
+                        (void)hipGetLastError();
+                        (void)hipUserObjectRelease(obj, 1);  // its destructor still owns tok's flag: a few bytes stay behind
+                    }
+                } else {
+                    (void)hipGetLastError();
+                    delete tok;
+                }
+            } else {
+                (void)hipGetLastError();
             }
         }
         return it->second;
@@ -228,6 +272,7 @@ struct Context {
                 ++it;
             }
         }
+        // (tokens of pools released here stay until their graphs go: reap_released_captures then finds no pool and drops them)
         return n;
     }
 
