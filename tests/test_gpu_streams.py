@@ -225,3 +225,31 @@ def test_capture_pool_goes_away_with_its_graph():
         free, total = torch.cuda.mem_get_info()
         used.append(total - free)
     assert used[-1] - used[4] < 64 << 20, [u >> 20 for u in used]  # 19 leaked FLUX pools would be ~2 GB
+
+
+def test_two_shapes_in_one_capture_after_warming_both(umfa_opts):
+    """[A, B] captured after warming A then B, where B needs MORE ticket words and SMALLER partials than A: moving the ticket
+    area used to take a fresh block sized for B alone, and the capture then failed at A with error 2 (found by the fuzz's graph
+    leg).  The partial area of a ticketed block never shrinks now."""
+    import umfa_torch
+    umfa_opts(force_w64=0)
+    torch.manual_seed(3)
+    a = [torch.randn(1, 6, 1024, 128, device="cuda", dtype=torch.float16) for _ in range(3)]
+    b = [torch.randn(1, 6, 2048, 64, device="cuda", dtype=torch.float16) for _ in range(3)]
+    ea = umfa_torch.attention_forward(*a, out_dtype=torch.float32).clone()
+    eb = umfa_torch.attention_forward(*b, out_dtype=torch.float32).clone()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        umfa_torch.attention_forward(*a, out_dtype=torch.float32)
+        umfa_torch.attention_forward(*b, out_dtype=torch.float32)
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            ca = umfa_torch.attention_forward(*a, out_dtype=torch.float32)
+            cb = umfa_torch.attention_forward(*b, out_dtype=torch.float32)
+    for _ in range(3):
+        ca.zero_()
+        cb.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(ca, ea) and torch.equal(cb, eb)

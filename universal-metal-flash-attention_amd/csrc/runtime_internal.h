@@ -127,9 +127,9 @@ struct GrowBuf {
 
 struct StreamScratch {
     GrowBuf split;      // fa_fwd16 split-KV: zeroed tickets (the kernel leaves them zero), then partials
-    size_t split_cnt_bytes = 0;
+    size_t split_cnt_bytes = 0, split_buf_hw = 0;
     GrowBuf w64;        // fa_fwd16_w64: zeroed tickets (the kernel leaves them zero), then partials
-    size_t w64_cnt_bytes = 0;
+    size_t w64_cnt_bytes = 0, w64_buf_hw = 0;
     GrowBuf mflags;     // mask tile flags
     GrowBuf workspace;  // quantiser output (int8 Q/K, V image, scales, fp32 copies for backward)
     GrowBuf rowc;       // bwd16: row constants [2][B*H*Sq] fp32 (-LSE log2 e, -D) from bwd16_dq for bwd16_dkdv
@@ -139,8 +139,13 @@ struct StreamScratch {
     // Partials sit behind the tickets at `cnt_state`.  (Round 3: the per-launch hipMemsetAsync of fa_fwd16's split path, as a
     // graph node in front of a kernel whose agent-scope atomics bypass the L2, left some tickets non-zero on later replays --
     // tools/lab/value_fuzz.py run_graph_case found it; eager launches were never affected.)
-    static char* ensure_ticketed(GrowBuf& g, size_t& cnt_state, size_t cnt_bytes, size_t buf_bytes, hipStream_t stream) {
+    static char* ensure_ticketed(GrowBuf& g, size_t& cnt_state, size_t& buf_hw, size_t cnt_bytes, size_t buf_bytes, hipStream_t stream) {
         const size_t c = cnt_bytes > cnt_state ? cnt_bytes : cnt_state;
+        // the partial area never shrinks: a fresh block (ticket area moved) must still hold the largest partials any earlier
+        // call asked for, or a capture of [shape A, shape B] after a warm-up of the same two fails at A (error 2) when B has
+        // more tickets and smaller partials than A (the fuzz's graph leg, seed 31954)
+        if (buf_bytes > buf_hw) buf_hw = buf_bytes;
+        buf_bytes = buf_hw;
         bool grew = false;
         if (c != cnt_state && g.ptr) {  // the ticket area moves: take a fresh block so old launches keep their layout
             if (stream_capturing(stream)) return nullptr;
@@ -164,15 +169,16 @@ struct StreamScratch {
         return b;
     }
     char* ensure_w64(size_t cnt_bytes, size_t buf_bytes, hipStream_t stream) {
-        return ensure_ticketed(w64, w64_cnt_bytes, cnt_bytes, buf_bytes, stream);
+        return ensure_ticketed(w64, w64_cnt_bytes, w64_buf_hw, cnt_bytes, buf_bytes, stream);
     }
     char* ensure_split(size_t cnt_bytes, size_t buf_bytes, hipStream_t stream) {
-        return ensure_ticketed(split, split_cnt_bytes, cnt_bytes, buf_bytes, stream);
+        return ensure_ticketed(split, split_cnt_bytes, split_buf_hw, cnt_bytes, buf_bytes, stream);
     }
     void release() {
         split.release(); w64.release(); mflags.release(); workspace.release(); rowc.release();
         w64_cnt_bytes = 0;
         split_cnt_bytes = 0;
+        w64_buf_hw = split_buf_hw = 0;
     }
 };
 
@@ -207,6 +213,17 @@ struct Context {
     std::map<PoolKey, CaptureToken*> tokens;
     static void capture_graph_destroyed(void* tok) { static_cast<CaptureToken*>(tok)->released.store(1, std::memory_order_release); }
     void reap_released_captures() {  // mu held, caller's stream is not capturing
+        bool any = false;
+        for (auto& kv : tokens) any |= kv.second->released.load(std::memory_order_acquire) != 0;
+        if (!any) return;
+        // hipFree is a "potentially unsafe" call while ANOTHER thread captures in global mode (torch's default): it would fail
+        // and invalidate that capture.  This thread is not capturing: the relaxed mode lifts the prohibition for it.
+        hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+        const bool swapped = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;
+        struct Restore {
+            bool on; hipStreamCaptureMode m;
+            ~Restore() { if (on) (void)hipThreadExchangeStreamCaptureMode(&m); }
+        } restore{swapped, mode};
         for (auto it = tokens.begin(); it != tokens.end();) {
             if (!it->second->released.load(std::memory_order_acquire)) { ++it; continue; }
             auto pit = pools.find(it->first);
