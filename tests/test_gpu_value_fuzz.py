@@ -103,3 +103,9 @@ def test_prequantized_backward_random_cases(seed):
 def test_rotations_random_cases(seed):
     msg = _fuzz().run_aux_case(seed)
     assert msg is None, msg
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_host_threads_random_cases(seed):
+    msg = _fuzz().run_threads_case(seed)
+    assert msg is None, msg

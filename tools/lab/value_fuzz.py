@@ -814,6 +814,51 @@ def run_aux_case(seed):
     return None
 
 
+def run_threads_case(seed):
+    """four host threads, each on its own stream, each issuing its own sequence of forwards (ctypes drops the GIL inside the
+    library: the context mutex, the per-stream pools and the per-launch tickets are really exercised concurrently); every
+    result bit-equal to the same call made alone"""
+    import threading
+    rng = random.Random(seed + 5900000)
+    specs = []
+    for t in range(4):
+        dt = rng.choice([torch.bfloat16, torch.float16])
+        H, S, D = rng.choice([2, 3, 6]), rng.choice([256, 512, 1024, 2048]), rng.choice([64, 128])
+        causal = rng.random() < 0.4
+        g = torch.Generator(device="cuda").manual_seed(seed * 11 + t)
+        q, k, v = (torch.randn(1, H, S, D, device="cuda", dtype=dt, generator=g) for _ in range(3))
+        specs.append((q, k, v, causal))
+    try:
+        alone = [umfa_torch.attention_forward(q, k, v, causal=c, out_dtype=torch.float32).clone() for q, k, v, c in specs]
+        torch.cuda.synchronize()
+        errs = []
+
+        def worker(i):
+            try:
+                q, k, v, c = specs[i]
+                st = torch.cuda.Stream()
+                with torch.cuda.stream(st):
+                    for rep in range(6):
+                        o = umfa_torch.attention_forward(q, k, v, causal=c, out_dtype=torch.float32)
+                        st.synchronize()
+                        if not torch.equal(o, alone[i]):
+                            errs.append("thread %d rep %d differs: max %.3e" % (i, rep, (o - alone[i]).abs().max().item()))
+                            return
+            except Exception as e:  # noqa: BLE001
+                errs.append("thread %d exception %s" % (i, repr(e)[:200]))
+        ths = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        torch.cuda.synchronize()
+        if errs:
+            return "%r seed %d" % (errs[:2], seed)
+    except Exception as e:  # noqa: BLE001
+        return "exception %r %s" % ((seed,), repr(e)[:300])
+    return None
+
+
 # gradients: P and dS rounded to the operand type (tests/test_gpu_fuzz.py: 3e-2 bf16, 8e-3 fp16 on N(0,1) data) x 4 for keys that
 # are hundreds of times larger than their neighbours (a rounding of dS at such a key is multiplied by it; measured worst over
 # 2100 seeds: 9.8e-2 bf16, 1.9e-2 fp16): this leg is about finiteness and the exp / LSE arithmetic, the forward leg is the sharp one
@@ -876,7 +921,7 @@ if __name__ == "__main__":
     first, count = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 200)
     bad = 0
     for seed in range(first, first + count):
-        for fn in ((run_case, run_bwd_case, run_shape_case, run_i8_case, run_gqa_case, run_rope_case, run_streams_case, run_graph_case, run_mask_case, run_host_case, run_qbwd_case, run_prequant_case, run_aux_case) if len(sys.argv) < 4 else (globals()[sys.argv[3]],)):
+        for fn in ((run_case, run_bwd_case, run_shape_case, run_i8_case, run_gqa_case, run_rope_case, run_streams_case, run_graph_case, run_mask_case, run_host_case, run_qbwd_case, run_prequant_case, run_aux_case, run_threads_case) if len(sys.argv) < 4 else (globals()[sys.argv[3]],)):
             msg = fn(seed)
             if msg:
                 bad += 1
