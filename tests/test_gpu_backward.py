@@ -297,3 +297,18 @@ def test_backward_both_dq_kernels_head_dim_128(ctx, which, causal, umfa_opts):
         for got, ref, name in [(dq, rdq, "dq"), (dk, rdk, "dk"), (dv, rdv, "dv")]:
             rel = np.abs(got - ref).max() / np.abs(ref).max()
             assert np.isfinite(got).all() and rel < 2e-2, (which, causal, shape, name, rel)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_ds_store_form_gives_the_same_gradients(dt):
+    """lab option bwd_ds_store (5 products: dkdv also stores dS, dQ = scale dS K as a GEMM; measured slower, kept as a lab
+    build): bit-identical gradients to the two recomputing kernels"""
+    import umfa_torch
+    torch.manual_seed(12)
+    q, k, v, do = (torch.randn(2, 3, 512, 128, device="cuda", dtype=dt) for _ in range(4))
+    o, lse = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32, return_lse=True)
+    ref = [t.clone() for t in umfa_torch.attention_backward(do, q, k, v, o, lse, scale=128 ** -0.5)]
+    with umfa_torch.options(bwd_ds_store=1):
+        got = umfa_torch.attention_backward(do, q, k, v, o, lse, scale=128 ** -0.5)
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)

@@ -608,9 +608,123 @@ __global__ __launch_bounds__(256, 1) void bwd16_dq2_kernel(BwdParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ dQ = scale dS K (dS-store form)
+// The second half of bwd16_dq2 alone: dQ^T[d][q] += K^T[d][key] dS^T[key][q] with dS read back from the scratch bwd16_dkdv
+// wrote (row-major [q][key], operand type): no S, no dP, no exponentials.  HBM-bound (the dS matrix is read exactly once:
+// 805 MB at the FLUX shape); three workgroups per CU hide the load latency; K tiles by LDS-DMA, double-buffered, transposed
+// fragments as in bwd16_dq2.  Non-causal, head_dim 128, Sq % 128 == 0, Skv % 64 == 0 (the launcher checks).
+template <typename T>
+__global__ __launch_bounds__(256, 3) void bwd16_dq_gemm_kernel(BwdParams p) {
+    constexpr int DP = 128;
+    BWD16_GEO(DP);
+    (void)PD; (void)NKS;
+    typedef Mma16<T> M;
+    typedef typename M::V8 V8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KROWS = 64, KTILE_B = KROWS * ROW_B;
+    const int tid = threadIdx.x, lane = tid & 63, ql = lane & 31, hi = lane >> 5;
+    const int wave = tid >> 6, uw = __builtin_amdgcn_readfirstlane(wave);
+    const uint32_t nqb = p.Sq / 128;
+    const uint32_t vid = xcd_remap(blockIdx.x, nqb * p.B * p.H);
+    const uint32_t bh = vid / nqb, qb = vid % nqb;
+    const uint32_t q_row = qb * 128 + wave * 32 + ql;
+    const uint32_t kvbh = bwd16_kv_slab(p, bh);
+    const T* kp = (const T*)p.k + (int64_t)kvbh * p.Skv * DP;
+    const i32x4 k_srd = make_srd(kp, p.Skv * (uint32_t)ROW_B);
+    // this lane's row; B-operand element j of a 16-key step is key 8 (j >> 2) + 4 hi + (j & 3) (the accumulator-row order
+    // the transposed K fragments are paired with, as in bwd16_dq2): two 8-byte pieces per step
+    const T* dsr = (const T*)p.ds + ((int64_t)bh * p.Sq + q_row) * p.Skv + 4 * hi;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((LDS_AS char*)smem));
+    int dma_off[(2 * TILE_PIECES + 3) / 4];
+    dma_lane_offsets<2 * TILE_PIECES, DP>(dma_off, uw, lane);
+    auto stage = [&](uint32_t t) __attribute__((always_inline)) {
+        dma_rows_pre<2 * TILE_PIECES, DP>(k_srd, lds0 + (t & 1) * KTILE_B, t * KROWS, uw, dma_off);
+    };
+    const uint32_t ntiles = p.Skv / KROWS;
+    stage(0);
+    V8 dsf[2][2], dsn[2][2];
+    auto load_ds = [&](uint32_t t, V8 (&d)[2][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                typedef typename M::V4 V4;
+                const V4 lo = *(const V4*)(dsr + (int64_t)t * KROWS + 32 * u + 16 * s2);
+                const V4 hi4 = *(const V4*)(dsr + (int64_t)t * KROWS + 32 * u + 16 * s2 + 8);
+                d[u][s2] = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+    };
+    load_ds(0, dsf);
+    f32x16 acc[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    const int tr_qq = (lane >> 2) & 3, tr_pp = lane & 3, tr_g1 = (lane >> 4) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    constexpr int NF = 2 * NDB;
+    for (uint32_t t = 0; t < ntiles; ++t) {
+        const char* Kt = smem + (t & 1) * KTILE_B;
+        if (t + 1 < ntiles) {
+            stage(t + 1);
+            load_ds(t + 1, dsn);
+        }
+#pragma unroll
+        for (int j = 0; j < 2 * NF; ++j) {
+            const int u = j / NF, r = j % NF, i = r >> 1, s2 = r & 1;
+            acc[i] = M::mma(tr_frag<M, DP>(Kt + u * TILE_BYTES, i, s2, hi, tr_qq, tr_pp, tr_g1), dsf[u][s2], acc[i]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) dsf[u][s2] = dsn[u][s2];
+    }
+    if (p.grad_in_type) {  // operand-type dQ through per-wave LDS rows (see bwd16_dq2)
+        char* stg = smem + wave * 8192;
+        typedef T T4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int i = 0; i < NDB; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch = (4 * i + g) ^ (ql & 15);
+                *(T4*)(stg + ql * 256 + 16 * ch + 8 * hi) = T4{(T)(acc[i][4 * g] * p.scale), (T)(acc[i][4 * g + 1] * p.scale),
+                                                                (T)(acc[i][4 * g + 2] * p.scale), (T)(acc[i][4 * g + 3] * p.scale)};
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t wave_q0 = qb * 128 + wave * 32;
+        T* out = (T*)p.dq + ((int64_t)bh * p.Sq + wave_q0) * DP;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int r = 4 * it + (lane >> 4), c = lane & 15;
+            const i32x4 v16 = *(const i32x4*)(stg + r * 256 + 16 * (c ^ (r & 15)));
+            *(i32x4*)(out + r * DP + 8 * c) = v16;
+        }
+    } else {
+        const int64_t orow = ((int64_t)bh * p.Sq + q_row) * DP;
+#pragma unroll
+        for (int i = 0; i < NDB; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 val = {acc[i][4 * g] * p.scale, acc[i][4 * g + 1] * p.scale, acc[i][4 * g + 2] * p.scale,
+                             acc[i][4 * g + 3] * p.scale};
+                store_grad4<T>(p.dq, orow + 32 * i + 8 * g + 4 * hi, val, false);
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ dK, dV
-template <typename T, bool CAUSAL, int DP>
+// STORE_DS (head_dim 128, non-causal): every dS = P (dP - D) the kernel forms is also written, in the operand type, to
+// p.ds[bh][q][key] -- bwd16_dq_gemm then needs no S, dP or exponentials of its own (the dS-store form of the backward)
+template <typename T, bool CAUSAL, int DP, bool STORE_DS = false>
 __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdParams p) {
+    static_assert(!STORE_DS || (DP == 128 && !CAUSAL), "the dS-store form exists at head_dim 128, non-causal");
     BWD16_GEO(DP);
 #ifdef BWD16_LAB_STAMP
     const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime();
@@ -643,6 +757,12 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
     const i32x4 q_srd = make_srd(qp, p.Sq * (uint32_t)ROW_B), do_srd = make_srd(dop, p.Sq * (uint32_t)ROW_B);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((LDS_AS char*)smem));
     float* const vec = (float*)(smem + VEC);
+    // dS-store form: this (batch, head)'s [Sq][Skv] slab of the scratch; a lane writes column `key`, rows 4 hi + ... of a group
+    const uint32_t ds_row_b = p.Skv * 2u;
+    const auto ds_rsrc = __builtin_amdgcn_make_buffer_rsrc(STORE_DS ? (void*)((char*)p.ds + (int64_t)bh * p.Sq * ds_row_b) : (void*)nullptr, 0,
+                                                           STORE_DS ? (int)(p.Sq * ds_row_b) : 0, 0x00020000);
+    const int ds_voff = (int)(key * 2u + 4u * (uint32_t)hi * ds_row_b);
+    (void)ds_rsrc; (void)ds_voff;
 
     if (item == blockIdx.x) {
 #pragma unroll
@@ -803,7 +923,11 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
                         float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[u][r], c, l2c[u][g][e]));  // l2c = -LSE log2(e)
                         if (edge && key > qb0 + 8 * g + 4 * hi + e) pr = 0.0f;
                         pb[u][r >> 3][r & 7] = (T)pr;
-                        sb[u][r >> 3][r & 7] = (T)(pr * dp[u][r]);                                      // dp = dP - D (accumulator started at -D)
+                        const T dsv = (T)(pr * dp[u][r]);                                                // dp = dP - D (accumulator started at -D)
+                        sb[u][r >> 3][r & 7] = dsv;
+                        if constexpr (STORE_DS)  // row qb0 + 8 g + 4 hi + e, this lane's key: 64 contiguous bytes per (row, half-wave)
+                            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, dsv), ds_rsrc, ds_voff,
+                                                                  (int)((qb0 + 8u * g + e) * ds_row_b), 0);
                     }
                 };
                 constexpr int NF = 4 * NDBH, PT = 4;  // dV / dK MFMAs of one sub-tile; transposed fragments in flight
@@ -1033,6 +1157,19 @@ static hipError_t launch_bwd16_t(const BwdParams& p, hipStream_t stream) {
     // (it also writes D and the row constants), bit 2 = dK / dV -- alone, the row constants are rebuilt from the caller's
     // (LSE, D) first
     const int ph = p.phases ? p.phases : 7;
+    if constexpr (DP == 128 && !CAUSAL) {
+        if (p.ds && ph == 7) {
+            // dS-store form: D, row constants, dK / dV (+ dS to the scratch), dQ = scale dS K
+            hipLaunchKernelGGL(bwd16_delta_kernel<DP>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, p);
+            if (hipError_t e = launch_bwd16_rowc(p.lse, p.dvec, p.rowc, rows, stream); e != hipSuccess) return e;
+            if (hipError_t e = ensure_dynamic_lds((const void*)bwd16_dkdv_kernel<T, false, DP, true>, lds_kv); e != hipSuccess) return e;
+            hipLaunchKernelGGL((bwd16_dkdv_kernel<T, false, DP, true>), dim3(nkb * p.B * p.H), dim3(256), lds_kv, stream, p);
+            const size_t lds_g = 2 * 64 * 2 * DP;
+            if (hipError_t e = ensure_dynamic_lds((const void*)bwd16_dq_gemm_kernel<T>, lds_g); e != hipSuccess) return e;
+            hipLaunchKernelGGL((bwd16_dq_gemm_kernel<T>), dim3(nqb * p.B * p.H), dim3(256), lds_g, stream, p);
+            return hipGetLastError();
+        }
+    }
     if (!(ph & 3)) {
         if (hipError_t e = launch_bwd16_rowc(p.lse, p.dvec, p.rowc, rows, stream); e != hipSuccess) return e;
     } else

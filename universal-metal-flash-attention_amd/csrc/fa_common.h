@@ -129,6 +129,9 @@ struct BwdParams {
     uint32_t Hkv;   // bwd16 only: K / V hold Hkv heads (grouped-query attention, H % Hkv == 0; 0 = H): query head h reads K / V head
                     // h / (H / Hkv) in place (no expanded copies); dK / dV still come out per QUERY head, the caller sums the groups
     int dkdv_fp32;  // bwd16 only: dK / dV in fp32 even when grad_in_type asks for operand-type dQ (they are summed over a group next)
+    void* ds;       // bwd16 "dS-store" form (option bwd_ds_store, head_dim 128, non-causal): scratch [B*H][Sq][Skv] in the operand
+                    // type -- bwd16_dkdv writes dS = P (dP - D) there, bwd16_dq_gemm computes dQ = scale dS K from it: 5 products
+                    // instead of 7 for B H Sq Skv 2 bytes of HBM (805 MB at the FLUX shape); NULL = the two recomputing kernels
 };
 
 __device__ __forceinline__ float bf16_bits_to_float(uint16_t b) {

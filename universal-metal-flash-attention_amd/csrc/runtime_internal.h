@@ -133,6 +133,7 @@ struct StreamScratch {
     GrowBuf mflags;     // mask tile flags
     GrowBuf workspace;  // quantiser output (int8 Q/K, V image, scales, fp32 copies for backward)
     GrowBuf rowc;       // bwd16: row constants [2][B*H*Sq] fp32 (-LSE log2 e, -D) from bwd16_dq for bwd16_dkdv
+    GrowBuf dsbuf;      // bwd16, option bwd_ds_store: dS [B*H][Sq][Skv] in the operand type
 
     // Ticketed scratch: tickets [0, cnt) zeroed on `stream` whenever the block is new -- and never again: the kernels leave
     // their tickets zero (the folding workgroup resets the word it drew from), so a captured graph carries no memset node.
@@ -175,7 +176,7 @@ struct StreamScratch {
         return ensure_ticketed(split, split_cnt_bytes, split_buf_hw, cnt_bytes, buf_bytes, stream);
     }
     void release() {
-        split.release(); w64.release(); mflags.release(); workspace.release(); rowc.release();
+        split.release(); w64.release(); mflags.release(); workspace.release(); rowc.release(); dsbuf.release();
         w64_cnt_bytes = 0;
         split_cnt_bytes = 0;
         w64_buf_hw = split_buf_hw = 0;

@@ -115,8 +115,15 @@ mfa_error_t umfa_attention_backward_stream(mfa_context_t context, void* stream, 
     const int dev = stream_device((hipStream_t)stream);
     DeviceGuard guard(dev);
     if (mfma16) {  // row constants of the second kernel, from the scratch pool of this (device, stream)
-        p.rowc = (float*)ctx->pool(dev, (hipStream_t)stream).rowc.ensure((size_t)2 * batch_size * num_heads * seq_len_q * sizeof(float), (hipStream_t)stream);
+        StreamScratch& sc = ctx->pool(dev, (hipStream_t)stream);
+        p.rowc = (float*)sc.rowc.ensure((size_t)2 * batch_size * num_heads * seq_len_q * sizeof(float), (hipStream_t)stream);
         if (!p.rowc) return MFA_ERROR_MEMORY_ALLOCATION;
+        // option bwd_ds_store: the dS-store form (5 products instead of 7 for a [B H Sq Skv] scratch in the operand type: HBM
+        // capacity traded for matrix work on a 288 GB part).  Head_dim 128, non-causal, whole 128-blocks, scratch <= 8 GiB.
+        if (tuning().bwd_ds_store.load(std::memory_order_relaxed) && head_dim == 128 && !causal && seq_len_q % 128 == 0 && seq_len_kv % 128 == 0) {
+            const size_t bytes = (size_t)batch_size * num_heads * seq_len_q * seq_len_kv * 2;
+            if (bytes <= ((size_t)8 << 30)) p.ds = sc.dsbuf.ensure(bytes, (hipStream_t)stream);  // NULL (capture, allocation): the recomputing form
+        }
     }
     hipError_t e = mfma16 ? launch_bwd_16(p, (hipStream_t)stream, &name) : launch_bwd(p, (hipStream_t)stream, &name);
     ctx->last_kernel = name;

@@ -54,6 +54,7 @@ Tuning& tuning() {
         x->no_dma.store(env_flag("UMFA_NO_DMA"));
         x->bn64.store(env_flag("UMFA_BN64"));
         x->pv_fp16.store(env_flag("UMFA_PV_FP16"));
+        x->bwd_ds_store.store(env_flag("UMFA_BWD_DS_STORE"));
         return x;
     }();
     return *t;
@@ -84,7 +85,7 @@ bool set_tuning(const char* name, const char* value) {
         {"no_mask_flags", &t.no_mask_flags, true}, {"bwd_exact", &t.bwd_exact, true}, {"bwd_dq", &t.bwd_dq, false},
         {"bwd_persist", &t.bwd_persist, true}, {"bwd_separate_delta", &t.bwd_separate_delta, true},
         {"no_split", &t.no_split, true}, {"force_split", &t.force_split, false}, {"no_dma", &t.no_dma, true},
-        {"bn64", &t.bn64, true}, {"pv_fp16", &t.pv_fp16, true},
+        {"bn64", &t.bn64, true}, {"pv_fp16", &t.pv_fp16, true}, {"bwd_ds_store", &t.bwd_ds_store, true},
     };
     for (auto& e : tab)
         if (!strcmp(name, e.n)) {

@@ -47,7 +47,7 @@ def release_scratch(stream=None, all_streams: bool = False) -> None:
 # launcher switches (include/umfa_abi.h umfa_set_option); the library's defaults, for options() to restore
 _OPTION_DEFAULTS = {"softmax_reference": "default", "softmax_tau": "6", "force_w64": "0", "no_w64": "0", "w64_grid": "0", "w64_skew": "0",
                     "no_mask_flags": "0", "bwd_exact": "0", "bwd_dq": "0", "bwd_persist": "0", "no_split": "0",
-                    "force_split": "0", "no_dma": "0", "bn64": "0", "pv_fp16": "0"}
+                    "force_split": "0", "no_dma": "0", "bn64": "0", "pv_fp16": "0", "bwd_ds_store": "0"}
 _option_state = {}
 
 
