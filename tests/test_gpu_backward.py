@@ -302,7 +302,7 @@ def test_backward_both_dq_kernels_head_dim_128(ctx, which, causal, umfa_opts):
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 def test_ds_store_form_gives_the_same_gradients(dt):
     """lab option bwd_ds_store (5 products: dkdv also stores dS, dQ = scale dS K as a GEMM; measured slower, kept as a lab
-    build): dK / dV bit-identical, dQ within one rounding of the output"""
+    build): the same gradients to one rounding of the output"""
     import umfa_torch
     torch.manual_seed(12)
     q, k, v, do = (torch.randn(2, 3, 512, 128, device="cuda", dtype=dt) for _ in range(4))
@@ -310,8 +310,9 @@ def test_ds_store_form_gives_the_same_gradients(dt):
     ref = [t.clone() for t in umfa_torch.attention_backward(do, q, k, v, o, lse, scale=128 ** -0.5)]
     with umfa_torch.options(bwd_ds_store=1):
         got = umfa_torch.attention_backward(do, q, k, v, o, lse, scale=128 ** -0.5)
-    # dK / dV come from the same kernel text (bit-equal); dQ sums the SAME dS values bwd16_dkdv rounds (dP - D out of the MFMA
-    # chain) where bwd16_dq2 forms its own (dP, then - D): one rounding of the output apart
-    assert torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2])
+    # D comes from the stand-alone row-sum kernel here (another summation order than the one fused into bwd16_dq2), and dQ sums
+    # the dS values bwd16_dkdv rounds (dP - D out of the MFMA chain) where bwd16_dq2 forms its own: one rounding of the output apart
     ulp = 2.0 ** -7 if dt == torch.bfloat16 else 2.0 ** -10
-    assert float((got[0].float() - ref[0].float()).abs().max()) <= ulp * float(ref[0].float().abs().max())
+    for a, b in zip(got, ref):
+        assert float((a.float() - b.float()).abs().max()) <= ulp * float(b.float().abs().max())
+    assert torch.equal(got[2], ref[2])  # dV = P^T dO does not see D
