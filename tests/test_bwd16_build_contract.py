@@ -52,7 +52,11 @@ def test_pinned_pipelines_are_unrolled_and_scratch_free(asm):
                 seen += 1
                 assert k["scratch"] == 0 and k["spill"] == 0, (name, k["scratch"], k["spill"])
                 assert k["body"].count("v_mfma") == n_mfma, (name, k["body"].count("v_mfma"), n_mfma)
-    assert seen == 6, sorted(ks)  # {dkdv, dq, dq2} x {causal, not}, bf16 (the lab switch compiles bf16 head_dim 128 only)
+    # {dkdv, dq, dq2} x {causal, not} + the dS-storing dkdv of the lab option bwd_ds_store, bf16 (the lab switch compiles bf16
+    # head_dim 128 only)
+    assert seen == 7, sorted(ks)
+    gemm = [k for n, k in ks.items() if "bwd16_dq_gemm_kernel" in n]
+    assert len(gemm) == 1 and gemm[0]["scratch"] == 0 and gemm[0]["spill"] == 0 and gemm[0]["body"].count("v_mfma") == 16
 
 
 def test_steady_loops_have_no_accvgpr_copies(asm):
