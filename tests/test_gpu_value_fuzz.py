@@ -109,3 +109,9 @@ def test_rotations_random_cases(seed):
 def test_host_threads_random_cases(seed):
     msg = _fuzz().run_threads_case(seed)
     assert msg is None, msg
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_launch_size_random_cases(seed):
+    msg = _fuzz().run_big_case(seed)
+    assert msg is None, msg

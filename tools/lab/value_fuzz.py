@@ -859,6 +859,66 @@ def run_threads_case(seed):
     return None
 
 
+def run_big_case(seed):
+    """launch-size shapes (S 2048 ... 8192, 4 ... 24 heads) through the dispatcher's own choice of kernel, N(0,1) or adversarial
+    values, causal / window / plain, pv_fp16 on and off: 96 sampled rows per head against fp64"""
+    rng = random.Random(seed + 6700000)
+    dt = rng.choice([torch.bfloat16, torch.bfloat16, torch.float16])
+    D = rng.choice([64, 128, 128])
+    B, H = rng.choice([1, 2]), rng.choice([4, 8, 16, 24])
+    S = rng.choice([2048, 3072, 4096, 8192])
+    if B * H * S > 24 * 8192:
+        H = 8
+    Skv = S if rng.random() < 0.8 else rng.choice([1024, 4096, 5000])
+    mode = rng.choice(["none", "none", "causal", "window"])
+    kind = rng.choice(["plain", "plain"] + KINDS)
+    pv = dt == torch.bfloat16 and rng.random() < 0.3
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    q = torch.randn(B, H, S, D, device="cuda", dtype=dt, generator=g)
+    k = torch.randn(B, H, Skv, D, device="cuda", dtype=dt, generator=g)
+    v = torch.randn(B, H, Skv, D, device="cuda", dtype=dt, generator=g)
+    if kind != "plain":
+        q, k, v = transform(rng, q, k, v, kind)
+    kw = {}
+    if mode == "causal":
+        kw["causal"] = True
+    if mode == "window":
+        kw["window"] = (rng.choice([128, 512, 1500]), rng.choice([0, 256, 700]))
+    rows = torch.tensor(sorted(rng.sample(range(S), 96)), device="cuda")
+    umfa_torch.set_option("pv_fp16", 1 if pv else 0)
+    try:
+        out, lse = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32, return_lse=True, **kw)
+        kern = umfa_torch.last_kernel()
+        what = (seed, str(dt), B, H, S, Skv, D, mode, kw.get("window"), kind, pv, kern)
+        s_ = torch.matmul(q[:, :, rows].double(), k.double().transpose(-1, -2)) * D ** -0.5
+        i = rows[:, None]
+        j = torch.arange(Skv, device="cuda")[None, :]
+        keep = None
+        if mode == "causal":
+            keep = j <= i
+        if mode == "window":
+            keep = (j >= i - kw["window"][0]) & (j <= i + kw["window"][1])
+        if keep is not None:
+            s_ = s_.masked_fill(~keep, float("-inf"))
+        rl = torch.logsumexp(s_, dim=-1)
+        ref = torch.matmul(torch.nan_to_num(torch.softmax(s_, dim=-1), nan=0.0), v.double())
+        o = out[:, :, rows]
+        if not torch.isfinite(out).all():
+            return "non-finite %r" % (what,)
+        tol = CEIL[torch.float16 if (pv and kern.endswith(",pv16>")) else dt]
+        rel = ((o.double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+        fin = torch.isfinite(rl)
+        lg = lse.view(B, H, S)[:, :, rows].double()
+        lerr = ((lg - rl)[fin].abs() / rl[fin].abs().clamp_min(50.0)).max().item() if fin.any() else 0.0
+        if rel > tol or lerr > 1e-3:
+            return "rel %.3e lse %.3e %r" % (rel, lerr, what)
+    except Exception as e:  # noqa: BLE001
+        return "exception %r %s" % ((seed, mode, kind), repr(e)[:300])
+    finally:
+        umfa_torch.set_option("pv_fp16", 0)
+    return None
+
+
 # gradients: P and dS rounded to the operand type (tests/test_gpu_fuzz.py: 3e-2 bf16, 8e-3 fp16 on N(0,1) data) x 4 for keys that
 # are hundreds of times larger than their neighbours (a rounding of dS at such a key is multiplied by it; measured worst over
 # 2100 seeds: 9.8e-2 bf16, 1.9e-2 fp16): this leg is about finiteness and the exp / LSE arithmetic, the forward leg is the sharp one
@@ -921,7 +981,7 @@ if __name__ == "__main__":
     first, count = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 200)
     bad = 0
     for seed in range(first, first + count):
-        for fn in ((run_case, run_bwd_case, run_shape_case, run_i8_case, run_gqa_case, run_rope_case, run_streams_case, run_graph_case, run_mask_case, run_host_case, run_qbwd_case, run_prequant_case, run_aux_case, run_threads_case) if len(sys.argv) < 4 else (globals()[sys.argv[3]],)):
+        for fn in ((run_case, run_bwd_case, run_shape_case, run_i8_case, run_gqa_case, run_rope_case, run_streams_case, run_graph_case, run_mask_case, run_host_case, run_qbwd_case, run_prequant_case, run_aux_case, run_threads_case, run_big_case) if len(sys.argv) < 4 else (globals()[sys.argv[3]],)):
             msg = fn(seed)
             if msg:
                 bad += 1
