@@ -115,3 +115,9 @@ def test_host_threads_random_cases(seed):
 def test_launch_size_random_cases(seed):
     msg = _fuzz().run_big_case(seed)
     assert msg is None, msg
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_backward_random_shapes(seed):
+    msg = _fuzz().run_bwd_shape_case(seed)
+    assert msg is None, msg

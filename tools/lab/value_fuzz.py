@@ -919,6 +919,46 @@ def run_big_case(seed):
     return None
 
 
+def run_bwd_shape_case(seed):
+    """the in-stream backward over arbitrary shapes: ragged Sq / Skv, head_dim 32 ... 256 (16-bit MFMA engine at 64 / 128 / 256,
+    the fp32-exact engine elsewhere and for fp32 operands), causal, O handed over in fp32 or in the operand type, gradients in
+    the operand type or fp32 -- against fp64 autograd"""
+    rng = random.Random(seed + 7300000)
+    dt = rng.choice([torch.bfloat16, torch.float16, torch.float32])
+    D = rng.choice([32, 64, 64, 80, 128, 128, 256]) if dt != torch.float32 else rng.choice([32, 64, 96])
+    B, H = rng.choice([1, 2]), rng.choice([1, 2, 3, 5])
+    Sq = rng.choice([1, 17, 64, 100, 128, 255, 256, 333, 512, 777, 1024, 2048])
+    Skv = Sq if rng.random() < 0.6 else rng.choice([1, 33, 64, 129, 256, 500, 1024])
+    if dt == torch.float32:
+        Sq, Skv = min(Sq, 333), min(Skv, 333)
+    causal = rng.random() < 0.4
+    o_typed = dt != torch.float32 and rng.random() < 0.5
+    keep32 = rng.random() < 0.3
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    q, k, v = (torch.randn(B, H, s_, D, device="cuda", dtype=dt, generator=g) for s_ in (Sq, Skv, Skv))
+    do = torch.randn(B, H, Sq, D, device="cuda", dtype=dt, generator=g)
+    try:
+        qr, kr, vr = (t.detach().double().requires_grad_(True) for t in (q, k, v))
+        s = torch.matmul(qr, kr.transpose(-1, -2)) * D ** -0.5
+        if causal:
+            s = s.masked_fill(~torch.ones(Sq, Skv, dtype=torch.bool, device="cuda").tril(), float("-inf"))
+        torch.matmul(torch.softmax(s, dim=-1), vr).backward(do.double())
+        o, lse = umfa_torch.attention_forward(q, k, v, causal=causal, out_dtype=dt if o_typed else torch.float32, return_lse=True)
+        grads = umfa_torch.attention_backward(do, q, k, v, o, lse, scale=D ** -0.5, causal=causal, keep_fp32=keep32)
+        kern = umfa_torch.last_kernel()
+        what = (seed, str(dt), B, H, Sq, Skv, D, causal, o_typed, keep32, kern)
+        tol = {torch.bfloat16: 4.5e-2, torch.float16: 1.2e-2, torch.float32: 2e-4}[dt]
+        for got, ref, name in zip(grads, (qr.grad, kr.grad, vr.grad), ("dq", "dk", "dv")):
+            if got.dtype != (torch.float32 if (keep32 or dt == torch.float32) else dt) or not torch.isfinite(got).all():
+                return "bad %s (dtype %s) %r" % (name, got.dtype, what)
+            rel = ((got.double() - ref).abs().max() / ref.abs().max().clamp_min(0.1)).item()
+            if rel > tol:
+                return "%s rel %.3e %r" % (name, rel, what)
+    except Exception as e:  # noqa: BLE001
+        return "exception %r %s" % ((seed, str(dt), B, H, Sq, Skv, D, causal), repr(e)[:300])
+    return None
+
+
 # gradients: P and dS rounded to the operand type (tests/test_gpu_fuzz.py: 3e-2 bf16, 8e-3 fp16 on N(0,1) data) x 4 for keys that
 # are hundreds of times larger than their neighbours (a rounding of dS at such a key is multiplied by it; measured worst over
 # 2100 seeds: 9.8e-2 bf16, 1.9e-2 fp16): this leg is about finiteness and the exp / LSE arithmetic, the forward leg is the sharp one
@@ -981,7 +1021,7 @@ if __name__ == "__main__":
     first, count = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 200)
     bad = 0
     for seed in range(first, first + count):
-        for fn in ((run_case, run_bwd_case, run_shape_case, run_i8_case, run_gqa_case, run_rope_case, run_streams_case, run_graph_case, run_mask_case, run_host_case, run_qbwd_case, run_prequant_case, run_aux_case, run_threads_case, run_big_case) if len(sys.argv) < 4 else (globals()[sys.argv[3]],)):
+        for fn in ((run_case, run_bwd_case, run_shape_case, run_i8_case, run_gqa_case, run_rope_case, run_streams_case, run_graph_case, run_mask_case, run_host_case, run_qbwd_case, run_prequant_case, run_aux_case, run_threads_case, run_big_case, run_bwd_shape_case) if len(sys.argv) < 4 else (globals()[sys.argv[3]],)):
             msg = fn(seed)
             if msg:
                 bad += 1
