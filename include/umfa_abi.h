@@ -405,6 +405,8 @@ const char* umfa_last_kernel_name(mfa_context_t context);
  *   "softmax_tau"        "0" ... "16" (log2 units, default 6)
  *   "force_w64" "no_w64" "w64_grid" "no_mask_flags" "bwd_exact" "bwd_dq" "bwd_persist" "no_split" "force_split"
  *   "no_dma" "bn64"      kernel-selection overrides used by tests and A/B benches ("0" / "1" or a number)
+ *   "bwd_ds_store"       "0" | "1": lab -- the dS-store form of the head_dim 128 non-causal backward (5 products, a
+ *                        [B H Sq Skv] scratch in the operand type); measured slower than the default, kept for A/B
  *   "pv_fp16"            "0" | "1": bf16 operands with the P V product in fp16 (P rounded to fp16, V cast once per call to an
  *                        fp16 image saturating at +-65504): the bf16-input forward inside 1e-3 (head_dim 128 / 64, launches of the w64 kernels, no mask)
  * Returns MFA_ERROR_INVALID_ARGS for an unknown name or a value out of range.  Thread-safe; affects later launches. */
