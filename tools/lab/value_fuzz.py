@@ -1,10 +1,20 @@
 #!/usr/bin/env python3
-"""Adversarial VALUE fuzz of the forward kernels (the shape fuzz of tests/test_gpu_fuzz.py runs N(0,1) data only): per-head score
-shifts of hundreds of nats in both directions, large / tiny score scales, attention sinks at the first / last / a middle key,
-sign flips from tile to tile, zero rows -- through every forward kernel family (w64 bf16 / fp16 at head_dim 128 and 64, causal,
-window, the 128-row kernel, the int8 kernel), against an fp64 restatement on the GPU.  Prints one line per failure.
+"""Seeded fuzz of every entry point, one function per leg (each returns None or a failure description; tests/test_gpu_value_fuzz.py
+runs the first seeds of each, `python tools/lab/value_fuzz.py <first seed> <n> [leg]` soaks them):
 
-  python tools/lab/value_fuzz.py [first_seed] [n_seeds]"""
+  run_case            adversarial VALUES through every forward family (w64 bf16 / fp16 / pv_fp16 at head_dim 128 and 64, causal,
+                      window, the 128-row kernel with and without masks, the int8 kernel): score shifts of hundreds of nats, large /
+                      tiny scales, attention sinks, sign flips from tile to tile, zero rows -- against fp64 / the oracle
+  run_shape_case      arbitrary shapes through the forced w64 families (ragged, windows of any extent, strided inputs, dead rows)
+  run_big_case        launch-size shapes through the dispatcher's own choice, sampled rows
+  run_mask_case       mask tensors: dtypes, ranks, broadcast dims, sliced masks, structured content
+  run_i8_case         runtime-quantised forward (int8 / int4, tensor / block-wise, masks) against the oracle
+  run_qbwd_case       runtime-quantised forward + backward;  run_prequant_case: the pre-quantised backward ABI
+  run_bwd_case        adversarial values through the backward;  run_bwd_shape_case: the backward over arbitrary shapes / engines
+  run_gqa_case        grouped K / V heads, inference and training;  run_rope_case: fused RoPE == rotate-then-attend, bit for bit
+  run_aux_case        RoPE / Hadamard rotations against the oracle;  run_host_case: the blocking host-buffer ABI against the oracle
+  run_streams_case    three streams at once;  run_threads_case: four host threads;  run_graph_case: hipGraph capture + replay
+"""
 import os
 import random
 import sys
