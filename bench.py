@@ -9,7 +9,8 @@ under `python -m torch.distributed.run ... bench.py --gpus N` (WORLD_SIZE alread
 A child that fails makes the whole run exit non-zero.
 
 Headline (`value`, `scaling: "strong"`): ONE FLUX-shape problem B=1 H=24 S=4096 D=128, bf16, forward, through the in-stream
-C-ABI entry (umfa_attention_forward_stream -> fa_fwd16_w64<bf16,128>), inputs resident in HBM.  At N = 1 the whole
+C-ABI entry (umfa_attention_forward_stream -> V cast pre-pass + fa_fwd16_w64<bf16,128,pv16>: the default bf16 arithmetic, P V
+product in fp16, inside the stated 1e-3), fp32 O as the C ABI writes it, inputs resident in HBM.  At N = 1 the whole
 problem on the GPU; at N > 1 its 24 heads dealt over the ranks and the full O assembled on EVERY rank by RCCL all-gathers
 over xGMI that run on a side stream under the next head chunk's kernel (umfa_torch.parallel.overlapped_sharded_sdpa; the
 north-star's split).  Exactly K steps between barrier + synchronize brackets, max over ranks; value = the problem's FLOPs
@@ -268,6 +269,7 @@ def run_rank(args) -> None:
                     fn()
         dt = region()
         return dt, {"cold_start_ms_per_step": round(cold / steps * 1e3, 4), "settle_untimed_steps": n_settle * steps,
+                    "untimed_steps_before_the_timed_region": max(1, warmup) + (steps if graph else 0) + steps + n_settle * steps,
                     "why": "a region started from an idle board sits in the firmware's power-averaging transient (tools/lab/settle_probe.py, "
                            "profiles/r3/lab_notes.md); `value` is the sustained state, the cold region is reported here"}
 
@@ -311,7 +313,9 @@ def run_rank(args) -> None:
     # ranks, the full O on every rank through all-gathers overlapped with the next head chunk
     torch.manual_seed(1234)  # the same full problem on every rank
     q, k, v = (torch.randn(B, H, S, D, device=dev, dtype=torch.float32).to(torch.bfloat16) for _ in range(3))
-    out = torch.empty(B, H, S, D, device=dev, dtype=torch.bfloat16)
+    # O in fp32: the C ABI's contract (mfa_attention_encode_mtl writes fp32 O, MFABridge.swift:1089) and the output the stated
+    # tolerance is checked on (`parity.cfg3_flux_fp32O`); the fused bf16 cast-back epilogue is timed beside it (`configs`)
+    out = torch.empty(B, H, S, D, device=dev, dtype=torch.float32)
     flops = FLOPS_PER_STEP * (0.5 if args.causal else 1.0)
     strong_ok = world > 1 and H % world == 0
 
@@ -422,17 +426,18 @@ def run_rank(args) -> None:
                 kn = umfa_torch.last_kernel()
                 o32 = umfa_torch.attention_forward(fq, fk, fv, out_dtype=torch.float32)
                 torch.cuda.synchronize()
-            pr = _par.forward_rel_err(fq, fk, fv, o32, floor_kind="fp16" if dt_ == torch.float16 else "bf16")
+            pr = _par.forward_rel_err(fq, fk, fv, o32, floor_kind="fp16" if (dt_ == torch.float16 or ",pv16" in kn) else "bf16")
             configs[name] = {"ms": round(tg, 5), "tflops": round(FLOPS_PER_STEP / tg / 1e9, 1), "frac": round(FLOPS_PER_STEP / tg / 1e9 / PEAK_BF16_TFLOPS, 4),
                              "kernel": kn, "rel": pr["rel"], "rms": pr["rms"], "format_floor_rel": pr.get("format_floor"),
                              "format_floor_rms": pr.get("format_floor_rms"), "fp32_out_for_rel": True, "options": {k_: str(v_) for k_, v_ in opts.items()}}
 
-        _flux_regime("cfg3_flux_bf16_lazy", torch.bfloat16)
-        _flux_regime("cfg3_flux_bf16_tau0", torch.bfloat16, softmax_reference="exact")
-        _flux_regime("cfg3_flux_bf16_tau6", torch.bfloat16, softmax_reference="deferred", softmax_tau=6)
+        # the default (bf16 operands, P V product in fp16: inside 1e-3) with the bf16 cast-back epilogue -- `value` times fp32 O --,
+        # then the bf16 P V kernels (pv_fp16 = 0: round 3's default and today's fall-back) in their three softmax-reference
+        # regimes, then fp16 operands
+        _flux_regime("cfg3_flux_bf16_default_bf16O", torch.bfloat16)
+        _flux_regime("cfg3_flux_bf16_pvbf16_lazy", torch.bfloat16, pv_fp16=0)
+        _flux_regime("cfg3_flux_bf16_pvbf16_exact", torch.bfloat16, pv_fp16=0, softmax_reference="exact")
         _flux_regime("cfg3_flux_fp16", torch.float16)
-        # bf16 operands with P and V of the second product in fp16 (option pv_fp16; the V cast pre-pass is inside the timed call)
-        _flux_regime("cfg3_flux_bf16_pv_fp16", torch.bfloat16, pv_fp16=1)
         o3, lse3 = umfa_torch.attention_forward(q, k, v, return_lse=True)
         do3 = torch.randn_like(q)
         tb_e = med(event_ms(lambda: umfa_torch.attention_backward(do3, q, k, v, o3, lse3, scale=D ** -0.5), 20))
@@ -495,7 +500,8 @@ def run_rank(args) -> None:
             "unit": "TFLOP/s",
             "n_gpus": world,
             "steps": args.steps,
-            "warmup": args.warmup,
+            "warmup": settle["untimed_steps_before_the_timed_region"],
+            "warmup_arg": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "strong",
@@ -503,7 +509,7 @@ def run_rank(args) -> None:
             "dtype": "bf16",
             "data": "synthetic N(0,1) Q/K/V, torch.manual_seed(1234) on every rank (one shared problem)",
             "config": {"workload": f"FLUX-shape SDPA forward B={B} H={H} S={S} D={D} bf16{' causal' if args.causal else ''}, "
-                                   "ONE problem, bf16 O (fused cast-back epilogue)" +
+                                   "ONE problem, fp32 O (the C ABI's contract), default options: P V product in fp16, V cast pre-pass inside the step" +
                                    (f", {H // world} heads per rank + RCCL all-gather of O to every rank" if world > 1 else ""),
                        "kernel": kernel_name, "entry": "umfa_attention_forward_stream (in-stream C ABI)",
                        "launch": ("eager launches (RCCL collectives are not captured)" if (world > 1 or args.no_graph) else
@@ -519,8 +525,11 @@ def run_rank(args) -> None:
             **({"rehearsal": "UMFA_BENCH_ONE_DEVICE=1: all ranks on cuda:0 over gloo -- a code-path check, not a measurement"} if rehearsal else {}),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
+                         "traffic_kind": "static",
                          "kernel_ms_mean": round(mean_ms, 5), "kernel_ms_min": round(durs[0], 5),
-                         "flops_per_launch": local_flops},
+                         "flops_per_launch": local_flops,
+                         "launch": "one step = the call's kernels on the launch stream: the V cast pre-pass (bf16 -> fp16, HBM-bound) + the attention "
+                                   "kernel; HIP events around the call, so `achieved` prices BOTH against the attention kernel's FLOPs"},
         }
         if weak:
             line["weak"] = weak
@@ -542,11 +551,13 @@ def bench_int8(torch, umfa_torch, event_ms, med):
         torch.manual_seed(0)
         q, k, v = (torch.randn(Bx, Hx, Sx, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
         out = torch.empty(Bx, Hx, Sx, D, device="cuda", dtype=torch.float32)
+        out8 = torch.empty(Bx, Hx, Sx, D, device="cuda", dtype=torch.float32)
+        lse8 = torch.empty(Bx * Hx * Sx, device="cuda", dtype=torch.float32)
         bf = med(event_ms(lambda: umfa_torch.attention_forward(q, k, v, out=out), 20))
         kb = umfa_torch.last_kernel()
-        i8 = med(event_ms(lambda: umfa_torch.quantized_attention_forward_stream(q, k, v), 20))
+        i8 = med(event_ms(lambda: umfa_torch.quantized_attention_forward_stream(q, k, v, out=out8, lse=lse8), 20))
         k8 = umfa_torch.last_kernel()
-        f8 = med(event_ms(lambda: umfa_torch.quantized_attention_forward_stream(q, k, v, quant_mode="blockwise_fp8pv"), 20))
+        f8 = med(event_ms(lambda: umfa_torch.quantized_attention_forward_stream(q, k, v, quant_mode="blockwise_fp8pv", out=out8, lse=lse8), 20))
         fl = 4.0 * Bx * Hx * Sx * Sx * D
         # mixed peak of the reference's int8 arithmetic: half the FLOPs (QK^T) on the int8 MFMA at 2x the
         # bf16 rate, half (P V) on the fp16 MFMA: time floor = flops / 2 / 5000 + flops / 2 / 2500 -> 3333 TFLOP/s
@@ -559,7 +570,7 @@ def bench_int8(torch, umfa_torch, event_ms, med):
                      "modes": "int8 = quant_mode 2, the reference's arithmetic (int8 Q K V block-wise, P and P V in fp16); fp8pv = quant_mode 3 "
                               "(opt-in: int8 Q K^T, fp8 e4m3 P and V on the 2x-rate MFMA; rel-err in parity.cfg4_fp8pv)",
                      "timer": "HIP events on the launch stream, median of 20, every side"}
-        del q, k, v, out
+        del q, k, v, out, out8, lse8
     return res
 
 

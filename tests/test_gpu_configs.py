@@ -22,7 +22,7 @@ def rel_err(a, ref):
     return float(np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-30))
 
 
-from tolerances import check_forward, errors, record  # noqa: E402  (measured bounds: tests/tolerances.py)
+from tolerances import check_forward, errors, fam, record  # noqa: E402  (measured bounds: tests/tolerances.py)
 
 
 def check_rows(q, k, v, o, rows, causal, kernel, tag, out_dt=None):
@@ -76,7 +76,7 @@ def test_config2_causal_bf16_B4_H16_S1024_D64():
     q, k, v = (torch.randn(4, 16, 1024, 64, device="cuda", dtype=torch.bfloat16) for _ in range(3))
     o = umfa_torch.attention_forward(q, k, v, causal=True, out_dtype=torch.float32)
     kern = umfa_torch.last_kernel()
-    assert kern == "fa_fwd16<bf16,64>" and torch.isfinite(o).all()
+    assert fam(kern) == "fa_fwd16<bf16,64>" and torch.isfinite(o).all()
     assert torch.equal(o, umfa_torch.attention_forward(q, k, v, causal=True, out_dtype=torch.float32))
     # the WHOLE tensor against the oracle (8.6 GFLOP of fp64: seconds on the box's host cores)
     ref = _oracle().sdpa_forward(bits(q), bits(k), bits(v), causal=True)

@@ -65,7 +65,7 @@ def test_fused_strided_operands_and_routing(umfa_opts):
     cos, sin = _tables(S, D)
     umfa_torch.reset_dispatch_stats()
     out = umfa_torch.rope_scaled_dot_product_attention(q, k, v, cos, sin)
-    assert umfa_torch.last_kernel() == "fa_fwd16_w64<bf16,128,rope>"
+    assert fam(umfa_torch.last_kernel()) == "fa_fwd16_w64<bf16,128,rope>"
     st = umfa_torch.get_dispatch_stats()
     assert st["total"] == 1 and st["rope_instream"] == 1 and st["fp32_instream"] == 1
     ref = ops.attention_forward(ops.rope_rotate(q, cos, sin), ops.rope_rotate(k, cos, sin), v)
@@ -77,7 +77,7 @@ def test_fused_vs_oracle(dt, umfa_opts):
     import umfa_torch  # noqa: F401
     from umfa_torch import ops
     from oracle import oracle
-    from tolerances import check_forward
+    from tolerances import check_forward, fam
     umfa_opts(force_w64=1)
     B, H, S, D = 1, 2, 512, 128
     torch.manual_seed(13)

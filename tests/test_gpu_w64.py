@@ -36,7 +36,7 @@ def rel_err(a, ref):
     return float(np.abs(a - ref).max() / max(np.abs(ref).max(), 1e-30))
 
 
-from tolerances import check_forward  # noqa: E402  (measured bounds, tests/tolerances.py)
+from tolerances import check_forward, fam  # noqa: E402  (measured bounds, tests/tolerances.py)
 
 
 def _band(Sq, Skv, window, causal):
@@ -75,7 +75,7 @@ def test_w64_flux_shape_matches_oracle_rows_and_is_deterministic():
     B, H, S, D = 1, 24, 4096, 128
     q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
     o, lse = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32, return_lse=True)
-    assert umfa_torch.last_kernel() == "fa_fwd16_w64<bf16,128>"
+    assert fam(umfa_torch.last_kernel()) == "fa_fwd16_w64<bf16,128>"
     assert torch.isfinite(o).all()
     assert torch.equal(o, umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32))
     orc = _oracle()
@@ -262,7 +262,7 @@ def test_w64_causal_flux_shape_rows():
     B, H, S, D = 1, 24, 4096, 128
     q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
     o = umfa_torch.attention_forward(q, k, v, causal=True, out_dtype=torch.float32)
-    assert umfa_torch.last_kernel() == "fa_fwd16_w64<bf16,128>"
+    assert fam(umfa_torch.last_kernel()) == "fa_fwd16_w64<bf16,128>"
     assert torch.isfinite(o).all()
     assert torch.equal(o, umfa_torch.attention_forward(q, k, v, causal=True, out_dtype=torch.float32))
     rows = np.array([0, 1, 63, 64, 255, 256, 1000, 2047, 2048, 4095] + list(range(3000, 3064)))
@@ -314,7 +314,7 @@ def test_w64_head_dim_64_vs_oracle(shape, dt):
     out = pool[65536:65536 + B * H * Sq * 64].view(B, H, Sq, 64)
     o, lse = umfa_torch.attention_forward(q, k, v, causal=causal, out_dtype=torch.float32, return_lse=True, out=out)
     kern = umfa_torch.last_kernel()
-    assert kern == ("fa_fwd16_w64<bf16,64>" if dt == torch.bfloat16 else "fa_fwd16_w64<fp16,64>"), kern
+    assert fam(kern) == ("fa_fwd16_w64<bf16,64>" if dt == torch.bfloat16 else "fa_fwd16_w64<fp16,64>"), kern
     assert bool((pool[:65536] == 7.0).all()) and bool((pool[65536 + B * H * Sq * 64:] == 7.0).all())
     ref, ref_lse = _oracle().sdpa_forward(npy(q), npy(k), npy(v), causal=causal, return_lse=True)
     assert np.isfinite(o.cpu().numpy()).all()
@@ -342,7 +342,7 @@ def test_w64_head_dim_64_softmax_references_and_strides(mode):
     with umfa_torch.options(softmax_reference=mode):
         o = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
         kern = umfa_torch.last_kernel()
-        assert kern == "fa_fwd16_w64<bf16,64>"
+        assert fam(kern) == "fa_fwd16_w64<bf16,64>"
         ref = _oracle().sdpa_forward(bits(q), bits(k), bits(v))
         check_forward(o.cpu().numpy(), ref, torch.bfloat16, kern, "w64_d64_" + mode, inputs=(bits(q), bits(k), bits(v)))
 
@@ -360,7 +360,7 @@ def test_w64_head_dim_64_lazy_overflow_restart():
     kk[:, 1, 300:] += 4000.0 * d
     k = kk.to(torch.bfloat16)
     o = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
-    assert umfa_torch.last_kernel() == "fa_fwd16_w64<bf16,64>"
+    assert fam(umfa_torch.last_kernel()) == "fa_fwd16_w64<bf16,64>"
     ref = _oracle().sdpa_forward(bits(q), bits(k), bits(v))
     assert torch.isfinite(o).all()
     check_forward(o.cpu().numpy(), ref, torch.bfloat16, umfa_torch.last_kernel(), "w64_d64_lazy_overflow", scale_max=1.5)
@@ -389,7 +389,7 @@ def test_w64_sliding_window_vs_oracle(shape, window, causal, dt):
     v = torch.randn(B, H, Skv, 128, device="cuda", dtype=dt)
     o, lse = umfa_torch.attention_forward(q, k, v, causal=causal, window=window, out_dtype=torch.float32, return_lse=True)
     kern = umfa_torch.last_kernel()
-    assert kern == ("fa_fwd16_w64<bf16,128,window>" if dt == torch.bfloat16 else "fa_fwd16_w64<fp16,128,window>"), kern
+    assert fam(kern) == ("fa_fwd16_w64<bf16,128,window>" if dt == torch.bfloat16 else "fa_fwd16_w64<fp16,128,window>"), kern
     keep = _band(Sq, Skv, window, causal)
     from oracle.oracle import MASK_BOOL
     ref, ref_lse = _oracle().sdpa_forward(npy(q), npy(k), npy(v), mask=np.ascontiguousarray(keep), mask_type=MASK_BOOL, return_lse=True)
@@ -426,7 +426,7 @@ def test_w64_sliding_window_head_dim_64(shape, window, causal, dt):
     v = torch.randn(B, H, Skv, 64, device="cuda", dtype=dt)
     o, lse = umfa_torch.attention_forward(q, k, v, causal=causal, window=window, out_dtype=torch.float32, return_lse=True)
     kern = umfa_torch.last_kernel()
-    assert kern == ("fa_fwd16_w64<bf16,64,window>" if dt == torch.bfloat16 else "fa_fwd16_w64<fp16,64,window>"), kern
+    assert fam(kern) == ("fa_fwd16_w64<bf16,64,window>" if dt == torch.bfloat16 else "fa_fwd16_w64<fp16,64,window>"), kern
     keep = _band(Sq, Skv, window, causal)
     from oracle.oracle import MASK_BOOL
     ref, ref_lse = _oracle().sdpa_forward(npy(q), npy(k), npy(v), mask=np.ascontiguousarray(keep), mask_type=MASK_BOOL, return_lse=True)
@@ -450,7 +450,7 @@ def test_w64_sliding_window_softmax_references(mode):
     with umfa_torch.options(softmax_reference=mode):
         o = umfa_torch.attention_forward(q, k, v, window=win, out_dtype=torch.float32)
         kern = umfa_torch.last_kernel()
-        assert kern == "fa_fwd16_w64<bf16,128,window>"
+        assert fam(kern) == "fa_fwd16_w64<bf16,128,window>"
         from oracle.oracle import MASK_BOOL
         ref = _oracle().sdpa_forward(bits(q), bits(k), bits(v), mask=np.ascontiguousarray(_band(S, S, win, False)), mask_type=MASK_BOOL)
         check_forward(o.cpu().numpy(), ref, torch.bfloat16, kern, "w64_window_" + mode)
@@ -465,7 +465,7 @@ def test_w64_sliding_window_flux_shape_dispatch_and_rows():
     q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
     out = umfa_torch.attention_forward(q, k, v, window=(W, W), out_dtype=torch.float32)
     kern = umfa_torch.last_kernel()
-    assert kern == "fa_fwd16_w64<bf16,128,window>", kern
+    assert fam(kern) == "fa_fwd16_w64<bf16,128,window>", kern
     assert torch.equal(out, umfa_torch.attention_forward(q, k, v, window=(W, W), out_dtype=torch.float32))
     for r0 in (0, 448, 2000, 4096 - 64):
         lo, hi_ = max(0, r0 - W), min(S, r0 + 64 + W)
@@ -481,7 +481,7 @@ def test_w64_small_ragged_sq_stays_on_the_128_row_kernel():
     import umfa_torch
     q, k, v = (torch.randn(1, 2, 300, 128, device="cuda", dtype=torch.bfloat16) for _ in range(3))
     umfa_torch.attention_forward(q, k, v)
-    assert umfa_torch.last_kernel() == "fa_fwd16<bf16,128>"
+    assert fam(umfa_torch.last_kernel()) == "fa_fwd16<bf16,128>"
 
 
 @pytest.mark.parametrize("shape,causal,expect_w64", [((1, 24, 4096, 4096), False, True), ((1, 24, 1024, 1024), False, False),
@@ -511,7 +511,7 @@ def test_w64_dispatch_gate_head_dim_64(shape, causal, expect_w64):
     k = torch.randn(B, H, Skv, 64, device="cuda", dtype=torch.bfloat16)
     umfa_torch.attention_forward(q, k, k, causal=causal)
     torch.cuda.synchronize()
-    assert umfa_torch.last_kernel() == ("fa_fwd16_w64<bf16,64>" if expect_w64 else "fa_fwd16<bf16,64>"), umfa_torch.last_kernel()
+    assert fam(umfa_torch.last_kernel()) == ("fa_fwd16_w64<bf16,64>" if expect_w64 else "fa_fwd16<bf16,64>"), umfa_torch.last_kernel()
 
 
 @pytest.mark.parametrize("causal", [False, True])
@@ -525,7 +525,7 @@ def test_w64_very_long_sequence_rows(causal):
     q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
     out, lse = umfa_torch.attention_forward(q, k, v, causal=causal, out_dtype=torch.float32, return_lse=True)
     kern = umfa_torch.last_kernel()
-    assert kern == "fa_fwd16_w64<bf16,128>", kern
+    assert fam(kern) == "fa_fwd16_w64<bf16,128>", kern
     assert torch.isfinite(out).all()
     for r0 in (0, 255, 65536 - 32, 100000, S - 64):
         rows = slice(r0, r0 + 64)
@@ -544,32 +544,34 @@ def test_w64_very_long_sequence_rows(causal):
 @pytest.mark.parametrize("shape,causal", [((1, 2, 256, 256), False), ((2, 3, 768, 448), False), ((1, 2, 1100, 777), False),
                                           ((1, 3, 1024, 1024), True), ((1, 2, 512, 1000), True)])
 def test_w64_bf16_operands_with_fp16_pv(shape, causal):
-    """option pv_fp16: bf16 Q / K / V, but P rounded to fp16 and multiplied with an fp16 copy of V (exact for |v| <= 65504): the
-    second product carries 11 bits instead of 8 and the bf16-input forward sits INSIDE the north-star's 1e-3 -- held here to
-    fp16's own format ceiling (one ulp of P at 1.0 = 2^-11) against the oracle on the bf16 inputs"""
+    """the default bf16 forward (option pv_fp16, on): bf16 Q / K / V, P rounded to fp16 and multiplied with V converted bf16 -> fp16
+    inside the kernel (exact over fp16's range): the second product carries 11 bits instead of 8 and the bf16-input forward sits
+    INSIDE the north-star's 1e-3 -- held here to fp16's own format ceiling (one ulp of P at 1.0 = 2^-11) against the oracle on the
+    bf16 inputs"""
     import umfa_torch
     B, H, Sq, Skv = shape
     torch.manual_seed(Sq + Skv)
     q = torch.randn(B, H, Sq, 128, device="cuda", dtype=torch.bfloat16)
     k = torch.randn(B, H, Skv, 128, device="cuda", dtype=torch.bfloat16)
     vs = torch.randn(B, Skv, H, 128, device="cuda", dtype=torch.bfloat16)
-    v = vs.transpose(1, 2)  # strided V: the cast pre-pass reads it in place
+    v = vs.transpose(1, 2)  # strided V: the kernel's V loads take the caller's strides
     ref, ref_lse = _oracle().sdpa_forward(bits(q), bits(k), bits(v), causal=causal, return_lse=True)
-    with umfa_torch.options(pv_fp16=1):
-        o, lse = umfa_torch.attention_forward(q, k, v, causal=causal, out_dtype=torch.float32, return_lse=True)
-        kern = umfa_torch.last_kernel()
-        assert kern == "fa_fwd16_w64<bf16,128,pv16>", kern
-        o16 = umfa_torch.attention_forward(q, k, v, causal=causal)
-        assert torch.equal(o, umfa_torch.attention_forward(q, k, v, causal=causal, out_dtype=torch.float32))
+    o, lse = umfa_torch.attention_forward(q, k, v, causal=causal, out_dtype=torch.float32, return_lse=True)
+    kern = umfa_torch.last_kernel()
+    assert kern == "fa_fwd16_w64<bf16,128,pv16>", kern
+    o16 = umfa_torch.attention_forward(q, k, v, causal=causal)
+    assert torch.equal(o, umfa_torch.attention_forward(q, k, v, causal=causal, out_dtype=torch.float32))
     on = o.cpu().numpy()
     assert np.isfinite(on).all()
     mx = float(np.abs(on - ref).max() / np.abs(ref).max())
-    assert mx < 2.0 ** -11, mx  # measured 2-3e-4; the plain bf16 kernel: 1-2e-3
+    assert mx < 2.0 ** -11, mx  # measured 2-3e-4; the bf16 P V kernel: 1-2e-3
     assert np.abs(lse.cpu().numpy().reshape(ref_lse.shape) - ref_lse).max() < 2e-2
     assert o16.dtype == torch.bfloat16 and (o16.float() - o).abs().max() <= 2.0 ** -8 * o.abs().max() * 1.01
-    o_plain = umfa_torch.attention_forward(q, k, v, causal=causal, out_dtype=torch.float32)
-    assert umfa_torch.last_kernel() == "fa_fwd16_w64<bf16,128>"
-    assert float(np.abs(o_plain.cpu().numpy() - ref).max() / np.abs(ref).max()) > mx  # the mode buys accuracy
+    with umfa_torch.options(pv_fp16=0):
+        o_plain = umfa_torch.attention_forward(q, k, v, causal=causal, out_dtype=torch.float32)
+        assert umfa_torch.last_kernel() == "fa_fwd16_w64<bf16,128>"
+    assert float(np.abs(o_plain.cpu().numpy() - ref).max() / np.abs(ref).max()) > mx  # what the fp16 product buys
+    assert umfa_torch.pv_fp16_status() == 0
 
 
 @pytest.mark.parametrize("causal", [False, True])
@@ -578,13 +580,17 @@ def test_w64_fp16_pv_head_dim_64(causal):
     torch.manual_seed(64)
     q, k, v = (torch.randn(2, 3, 768, 64, device="cuda", dtype=torch.bfloat16) for _ in range(3))
     ref = _oracle().sdpa_forward(bits(q), bits(k), bits(v), causal=causal)
-    with umfa_torch.options(pv_fp16=1):
-        o = umfa_torch.attention_forward(q, k, v, causal=causal, out_dtype=torch.float32)
-        assert umfa_torch.last_kernel() == "fa_fwd16_w64<bf16,64,pv16>"
+    o = umfa_torch.attention_forward(q, k, v, causal=causal, out_dtype=torch.float32)
+    assert umfa_torch.last_kernel() == "fa_fwd16_w64<bf16,64,pv16>"
     assert float(np.abs(o.cpu().numpy() - ref).max() / np.abs(ref).max()) < 2.0 ** -11
 
 
-def test_w64_fp16_pv_flux_rows_and_saturation():
+def test_w64_fp16_pv_flux_rows_and_range_fallback():
+    """the default bf16 forward at the FLUX shape inside 1e-3 (with a factor of two to spare), and what happens when V leaves
+    fp16's range: the in-stream call's output is non-finite where the value reached (loud, not silent), the status word is
+    raised, the NEXT in-stream call runs the bf16 P V kernel (sticky until re-armed); the blocking C-ABI entry repeats the
+    call itself and returns the bf16 P V result"""
+    import umfa
     import umfa_torch
     umfa_torch.set_option("force_w64", 0)
     torch.manual_seed(2)
@@ -593,13 +599,61 @@ def test_w64_fp16_pv_flux_rows_and_saturation():
     from oracle import parity
     rows = parity.sample_rows(S)
     ref = _oracle().sdpa_forward_rows(bits(q), bits(k), bits(v), rows)
-    with umfa_torch.options(pv_fp16=1):
-        o = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
-        assert umfa_torch.last_kernel() == "fa_fwd16_w64<bf16,128,pv16>"
-        mx = float(np.abs(o[:, :, rows].cpu().numpy() - ref).max() / np.abs(ref).max())
-        assert mx < 1.0e-3 / 2, mx  # the north-star's bound with a factor of two to spare
-        # V beyond fp16's range saturates at +-65504 (documented): finite output
+    umfa_torch.set_option("pv_fp16", 1)  # (re-)arm
+    o = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
+    assert umfa_torch.last_kernel() == "fa_fwd16_w64<bf16,128,pv16>"
+    mx = float(np.abs(o[:, :, rows].cpu().numpy() - ref).max() / np.abs(ref).max())
+    assert mx < 1.0e-3 / 2, mx  # the north-star's bound with a factor of two to spare
+    torch.cuda.synchronize()
+    assert umfa_torch.pv_fp16_status() == 0
+    try:
         vbig = v.clone()
         vbig[0, 0, 5, 7] = 3.0e8
         ob = umfa_torch.attention_forward(q, k, vbig, out_dtype=torch.float32)
-        assert torch.isfinite(ob).all()
+        torch.cuda.synchronize()
+        assert not torch.isfinite(ob[0, 0, :, 7]).all() and torch.isfinite(ob[0, 1:]).all()  # only what the value touched
+        assert umfa_torch.pv_fp16_status() & 1
+        ob2 = umfa_torch.attention_forward(q, k, vbig, out_dtype=torch.float32)  # sees the word: bf16 P V from now on
+        assert umfa_torch.last_kernel() == "fa_fwd16_w64<bf16,128>"
+        torch.cuda.synchronize()
+        assert torch.isfinite(ob2).all() and umfa_torch.pv_fp16_status() & 4
+        refb = _oracle().sdpa_forward_rows(bits(q[:, :1]), bits(k[:, :1]), bits(vbig[:, :1]), rows)
+        assert float(np.abs(ob2[:, :1, rows].cpu().numpy() - refb).max() / np.abs(refb).max()) < 2.0 ** -8
+    finally:
+        umfa_torch.set_option("pv_fp16", 1)
+    assert umfa_torch.pv_fp16_status() == 0
+    o3 = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
+    assert umfa_torch.last_kernel() == "fa_fwd16_w64<bf16,128,pv16>" and torch.equal(o3, o)
+    # the blocking entry (mfa_attention_forward: waits anyway) repeats the call on the bf16 P V kernels by itself
+    qs, ks, vbs = (t[:, :2, :512].contiguous() for t in (q, k, vbig))
+    with umfa.MFAContext() as ctx:
+        oh = umfa.flash_attention_forward(ctx, bits(qs), bits(ks), bits(vbs), input_precision="bf16", intermediate_precision="bf16",
+                                          layout="bhsd")
+        assert ctx.last_kernel in ("fa_fwd16<bf16,128>", "fa_fwd16_w64<bf16,128>"), ctx.last_kernel
+    assert np.isfinite(oh).all()
+    refh = _oracle().sdpa_forward(bits(qs), bits(ks), bits(vbs))
+    assert float(np.abs(oh - refh).max() / np.abs(refh).max()) < 2.0 ** -8
+    assert umfa_torch.pv_fp16_status() == 0 and int(umfa_torch.get_option("pv_fp16_fallbacks")) >= 2
+
+
+def test_fp16_pv_small_outputs_fall_back():
+    """values of V below 2^-17 are not exact in fp16: a launch whose outputs are all below 2^-11 raises status bit 1 and the next
+    in-stream call keeps bf16's exponent range (the bf16 P V kernel)"""
+    import umfa_torch
+    torch.manual_seed(3)
+    q, k = (torch.randn(1, 2, 512, 128, device="cuda", dtype=torch.bfloat16) for _ in range(2))
+    v = (torch.randn(1, 2, 512, 128, device="cuda") * 1e-6).to(torch.bfloat16)
+    umfa_torch.set_option("pv_fp16", 1)
+    try:
+        umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
+        assert "pv16" in umfa_torch.last_kernel()
+        torch.cuda.synchronize()
+        assert umfa_torch.pv_fp16_status() & 2
+        o = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
+        assert "pv16" not in umfa_torch.last_kernel()
+        ref = _oracle().sdpa_forward(bits(q), bits(k), bits(v))
+        assert float(np.abs(o.cpu().numpy() - ref).max() / np.abs(ref).max()) < 2.0 ** -8
+    finally:
+        umfa_torch.set_option("pv_fp16", 1)
+
+

@@ -15,11 +15,14 @@ Two assertions, both independent of what any kernel measured last week:
        longer exactly 1.0, so the dominant key takes the ordinary half-ulp too)
    The rms bound is the sharp one: a kernel that got 15 % worse everywhere fails it in every regime.
 2. FORMAT CEILING (every call, also without inputs: masks, windows, fuzz shapes): max <= one ulp of P at 1.0
-   (2^-8 bf16, 2^-11 fp16), rms <= half of it.  The reference's own tolerances are 1e-2 (bf16) / 1e-3 (fp16)
+   (2^-8 bf16, 2^-11 fp16), rms <= 0.6 of it.  The reference's own tolerances are 1e-2 (bf16) / 1e-3 (fp16)
    (examples/pytorch-custom-op-ffi/tests/conftest.py:186-199).
 
-fp16 additionally meets the north-star's 1e-3 everywhere (asserted); bf16 cannot -- its floor is above 1e-3 from
-S ~ 1024 on -- and is held to the floor instead.
+The north-star's 1e-3 is ASSERTED for every kernel whose P V product runs in fp16: the fp16 kernels and -- the default since
+round 4 -- the bf16-input kernels ("pv16" in the kernel name: bf16 Q K^T, P rounded to fp16, V converted bf16 -> fp16 inside
+the kernel).  The format that matters for the bounds is P's, so those kernels are held to fp16's floor and ceiling.  Only the
+bf16 P V kernels (option pv_fp16 = 0, or the fallback after a status word was raised) keep bf16's floor: it is above 1e-3 from
+S ~ 1024 on.
 """
 from __future__ import annotations
 
@@ -58,15 +61,20 @@ def record(tag: str, **vals) -> None:
             f.write(json.dumps({"tag": tag, "test": os.environ.get("PYTEST_CURRENT_TEST", ""), **vals}) + "\n")
 
 
+def fam(kernel: str) -> str:
+    """kernel family: the name without the ",pv16" tag (bf16 operands, P V product in fp16 -- the default bf16 arithmetic)"""
+    return kernel.replace(",pv16", "")
+
+
 def regime_of(kernel: str) -> str:
     """"exact": the kernel's softmax reference is the exact running max; "stale": fa_fwd16_w64 in its lazy / deferred modes."""
     if not kernel.startswith("fa_fwd16_w64"):
         return "exact"
-    try:
+    try:  # the LIBRARY's live values (they may have been seeded from the environment: UMFA_W64_TAU, UMFA_W64_LAZY)
         from umfa_torch import ops
-        mode = ops._option_state.get("softmax_reference", "default")
-        tau = float(ops._option_state.get("softmax_tau", "6"))
-    except Exception:  # noqa: BLE001  (callers that only use the ctypes package: library defaults)
+        mode = ops.get_option("softmax_reference")
+        tau = float(ops.get_option("softmax_tau"))
+    except Exception:  # noqa: BLE001  (no device / an older library: its defaults)
         mode, tau = "default", 6.0
     return "exact" if mode == "exact" or (mode == "deferred" and tau == 0.0) else "stale"
 
@@ -86,9 +94,13 @@ def check_forward(o, ref, dt, kernel: str, tag: str = "", scale_max: float = 1.0
     bounds for deliberately hostile inputs (stated at the call site); out_dt: the element type O was stored in when it is
     not fp32."""
     name = _name(dt)
+    if name == "bf16" and "pv16" in kernel:
+        name = "fp16"  # the format of P (and of V inside the kernel) decides the bounds
     regime = regime_of(kernel)
     mx, rms = errors(o, ref)
-    cmax, crms = ULP_AT_ONE[name], 0.5 * ULP_AT_ONE[name]
+    # rms: 0.6 ulp -- a row that spreads over very many keys (S = 131072, flat) sits at the rounding level of P itself, ulp x 0.41 ...
+    # 0.5 (measured with fp16 P: 0.503 ulp); the sharp rms bound is the floor-relative one below
+    cmax, crms = ULP_AT_ONE[name], 0.6 * ULP_AT_ONE[name]
     if out_dt is not None and _name(out_dt) in OUT_HALF_ULP:
         h = OUT_HALF_ULP[_name(out_dt)]
         cmax, crms = float(np.hypot(cmax, 0.5 * h)), float(np.hypot(crms, 0.5 * h))
@@ -109,7 +121,7 @@ def check_forward(o, ref, dt, kernel: str, tag: str = "", scale_max: float = 1.0
     record(tag or kernel, **rec)
     assert mx < cmax * scale_max, (tag, kernel, "format ceiling, max", mx, cmax * scale_max)
     if name == "fp16" and scale_max == 1.0:
-        assert mx <= NORTH_STAR, (tag, kernel, "north-star 1e-3", mx)  # fp16 meets the stated tolerance everywhere
+        assert mx <= NORTH_STAR, (tag, kernel, "north-star 1e-3", mx)  # fp16 P V (fp16 inputs, or bf16 inputs by default) meets the stated tolerance everywhere
     if np.asarray(ref).size >= min_elems_for_rms:
         assert rms < crms * scale_max, (tag, kernel, "format ceiling, rms", rms, crms * scale_max)
     if fl is not None:

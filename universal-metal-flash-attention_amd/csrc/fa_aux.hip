@@ -254,36 +254,51 @@ hipError_t launch_cast_f16(const void* src, int prec, void* dst, int64_t n, uint
     return hipGetLastError();
 }
 
-// V of the pv_fp16 forward mode: bf16 rows (any batch / head / row strides) -> dense fp16, saturating (bf16 reaches 3e38)
-__global__ __launch_bounds__(256) void cast_rows_bf16_f16_kernel(const uint16_t* src, int64_t sb, int64_t sh, int64_t ss, _Float16* dst,
-                                                                 uint32_t H, uint32_t S, uint32_t D8, int64_t n8) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
-        const uint32_t c = (uint32_t)(i % D8);
-        const int64_t row = i / D8;
-        const uint32_t s_ = (uint32_t)(row % S);
-        const int64_t bh = row / S;
-        const uint32_t h = (uint32_t)(bh % H);
-        const int64_t b = bh / H;
-        const s16x8 raw = *(const s16x8*)(src + b * sb + h * sh + (int64_t)s_ * ss + 8 * c);
-        f16x8 o;
+// V of the default bf16 forward (P V product in fp16, FwdParams::pv16): bf16 rows (any batch / head / row strides, head_dim
+// contiguous) -> a dense fp16 image [B, H, S, D].  HBM-bound: one read + one write of V.  A workgroup owns U * 256 / (D / 8)
+// consecutive rows of one (batch, head) slab; every thread has U independent 16-byte loads in flight before the first
+// conversion; no per-element index arithmetic (the round-3 form divided three 64-bit indices per chunk and ran at 2 TB/s).
+// Round to nearest even: exact for 2^-17 <= |v| < 65536; a value beyond fp16's range becomes +-inf ON PURPOSE -- the attention
+// kernel's epilogue then sees non-finite outputs and raises the status word (fa_fwd16_w64_kernel.inc), nothing saturates silently.
+template <int U>
+__global__ __launch_bounds__(256) void cast_rows_bf16_f16_kernel(const uint16_t* __restrict__ src, int64_t sb, int64_t sh, int64_t ss,
+                                                                 _Float16* __restrict__ dst, uint32_t H, uint32_t S, uint32_t D8) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const uint32_t bh = blockIdx.x, b = bh / H, h = bh - b * H;  // (grid.x may be large; grid.y <= 65535 holds the row chunks)
+    const uint32_t rpw = 256u / D8;                       // rows one pass of the workgroup covers (D8 divides 256: head_dim 64 ... 256 x8; else see launcher)
+    const uint32_t tr = threadIdx.x / D8, c = threadIdx.x - tr * D8;
+    const uint32_t row0 = blockIdx.y * (U * rpw) + tr;
+    const uint16_t* sp = src + (int64_t)b * sb + (int64_t)h * sh + 8 * c;
+    _Float16* dp = dst + ((int64_t)bh * S) * (8 * D8) + 8 * c;
+    u32x4 raw[U];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float x = bf16_bits_to_float((uint16_t)raw[j]);
-            x = x > 65504.0f ? 65504.0f : (x < -65504.0f ? -65504.0f : x);  // (NaN passes through)
-            o[j] = (_Float16)x;
+    for (int u = 0; u < U; ++u) {
+        const uint32_t r = row0 + u * rpw;
+        raw[u] = r < S && tr < rpw ? __builtin_nontemporal_load((const u32x4*)(sp + (int64_t)r * ss)) : u32x4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint32_t r = row0 + u * rpw;
+        u32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned lo = raw[u][j] << 16, hi = raw[u][j] & 0xffff0000u;
+            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(o[j]) : "v"(lo), "v"(hi));
         }
-        ((f16x8*)dst)[i] = o;
+        if (r < S && tr < rpw) *(u32x4*)(dp + (int64_t)r * (8 * D8)) = o;
     }
 }
 
 hipError_t launch_cast_rows_bf16_to_f16(const void* src, const int64_t* strides, void* dst, uint32_t B, uint32_t H, uint32_t S, uint32_t D,
                                         hipStream_t stream) {
-    if (!src || !dst || (D & 7) || strides[3] != 1 || (strides[0] | strides[1] | strides[2]) % 8 || ((uintptr_t)src & 15)) return hipErrorInvalidValue;
-    const int64_t n8 = (int64_t)B * H * S * (D / 8);
-    if (n8 == 0) return hipSuccess;
-    const unsigned grid = (unsigned)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : 8192);
-    hipLaunchKernelGGL(cast_rows_bf16_f16_kernel, dim3(grid), dim3(256), 0, stream, (const uint16_t*)src, strides[0], strides[1], strides[2],
-                       (_Float16*)dst, H, S, D / 8, n8);
+    if (!src || !dst || (D & 7) || D > 2048 || strides[3] != 1 || (strides[0] | strides[1] | strides[2]) % 8 || ((uintptr_t)src & 15)) return hipErrorInvalidValue;
+    if ((int64_t)B * H * S * D == 0) return hipSuccess;
+    const uint32_t D8 = D / 8, rpw = 256u / D8;  // (a head_dim that does not divide 2048 leaves 256 % D8 threads idle)
+    constexpr int U = 4;
+    const dim3 grid(B * H, (S + U * rpw - 1) / (U * rpw));
+    if (grid.y > 65535u) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(cast_rows_bf16_f16_kernel<U>, grid, dim3(256), 0, stream, (const uint16_t*)src, strides[0], strides[1], strides[2],
+                       (_Float16*)dst, H, S, D8);
     return hipGetLastError();
 }
 

@@ -65,9 +65,13 @@ struct FwdParams {
     const float* rope_cos;
     const float* rope_sin;
     int64_t rope_tb;
-    // bf16 operands with the P V product in fp16 (option pv_fp16): v points at an fp16 copy of V (dense BHSD), P is rounded
-    // to fp16 -- 11 bits instead of 8 -- and the bf16-input forward then meets the 1e-3 bound (fa_fwd16_w64 only)
+    // bf16 operands with the P V product in fp16 (option pv_fp16, the default): P is rounded to fp16 -- 11 bits instead of 8 -- and V
+    // is converted bf16 -> fp16 inside the kernel on its way into LDS; the bf16-input forward then meets the 1e-3 bound.  fp16's
+    // range is the price: status[0] is raised when an output came out non-finite (a V value beyond +-65504 became inf),
+    // status[1] when a wave's outputs are all below 2^-11 (values of V under 2^-17 are not exact in fp16).  The runtime reads
+    // the words (host-visible memory) and falls back to the bf16 P V kernels (dispatch_forward).
     int pv16;
+    uint32_t* status;
 };
 
 // Interleaved-pair rotary rotation of 8 consecutive elements (4 pairs) given the 8 table entries of their columns

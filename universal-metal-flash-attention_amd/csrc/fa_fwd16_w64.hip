@@ -48,6 +48,8 @@ struct W64Params {
     const float* rope_cos;  // fused rotary embedding of Q (FwdParams::rope_*), NULL = none
     const float* rope_sin;
     int64_t rope_tb;
+    uint32_t* status;       // pv16 kernels (bf16 operands, fp16 P V): [0] = 1 when an output is not finite (a V value outside fp16's range),
+                            // [1] = 1 when a wave's outputs are all below 2^-11 (V's fp16 image may have lost bits); host-visible, may be NULL
 };
 
 // ---- asm-owned accumulator registers: helpers with literal register numbers (generated)
@@ -97,8 +99,13 @@ struct W64I8Params {
 #undef W64_CVT
 #undef W64_KERNEL
 
-// bf16 Q / K with the P V product in fp16 (option pv_fp16): the same streams, S = K Q^T on the bf16 MFMA, P rounded to fp16
-// (v_cvt_pk_f16_f32), O^T += V^T P^T on the fp16 MFMA against an fp16 copy of V; the lazy reference with fp16's thresholds
+// bf16 Q / K / V with the P V product in fp16 -- the DEFAULT bf16 forward (option pv_fp16, on unless switched off or a call
+// raised the status word): S = K Q^T on the bf16 MFMA, P rounded to fp16 (v_cvt_pk_f16_f32: 11 bits instead of bf16's 8, which
+// is what puts the bf16-input forward inside the north-star's 1e-3), O^T += V^T P^T on the fp16 MFMA against an fp16 image of V
+// (the runtime's cast pre-pass, fa_aux.hip; exact over fp16's range, checked in the epilogue: W64_PVCHK); the lazy reference
+// with fp16's thresholds
+#undef W64_PVCHK
+#define W64_PVCHK 1
 #define W64_T __bf16
 #define W64_MFMA "v_mfma_f32_32x32x16_f16"
 #define W64_MFMA_QK "v_mfma_f32_32x32x16_bf16"
@@ -116,6 +123,8 @@ struct W64I8Params {
 #undef W64_LAZY_PARTS
 #undef W64_CVT
 #undef W64_KERNEL
+#undef W64_PVCHK
+#define W64_PVCHK 0
 
 #define W64_T _Float16
 #define W64_MFMA "v_mfma_f32_32x32x16_f16"
@@ -158,7 +167,9 @@ struct W64I8Params {
 #undef W64_LAZY_PARTS
 #undef W64_CVT
 #undef W64_KERNEL
-#define W64_T __bf16                            /* bf16 Q / K, fp16 P V (option pv_fp16) at head_dim 64 */
+#undef W64_PVCHK
+#define W64_PVCHK 1                             /* bf16 operands, fp16 P V against the fp16 image of V: the default bf16 forward at head_dim 64 */
+#define W64_T __bf16
 #define W64_MFMA "v_mfma_f32_32x32x16_f16"
 #define W64_MFMA_QK "v_mfma_f32_32x32x16_bf16"
 #define W64_MSUM "v_mfma_f32_4x4x4_16b_f16"
@@ -175,6 +186,8 @@ struct W64I8Params {
 #undef W64_LAZY_PARTS
 #undef W64_CVT
 #undef W64_KERNEL
+#undef W64_PVCHK
+#define W64_PVCHK 0
 #define W64_T _Float16
 #define W64_MFMA "v_mfma_f32_32x32x16_f16"
 #define W64_MFMA_QK "v_mfma_f32_32x32x16_f16"
@@ -357,87 +370,44 @@ hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cn
     wp.skew = (uint32_t)tuning().w64_skew.load(std::memory_order_relaxed);
     wp.rope_cos = p.rope_cos; wp.rope_sin = p.rope_sin; wp.rope_tb = p.rope_tb;
     wp.Tw = wp.T; wp.win_left = wp.win_right = 0;
-    if (p.rope_cos) {  // fused-RoPE instantiations exist for O in the operand type only (runtime.hip asks first)
-        if (p.out_prec != p.in_prec) return hipErrorNotSupported;
-        if (p.in_prec == P_BF16) {
-            *name = "fa_fwd16_w64<bf16,128,rope>";
-            return p.causal ? launch_w64_kernel(fa_fwd16_w64_bf16<__bf16, true, true>, p, wp, stream)
-                            : launch_w64_kernel(fa_fwd16_w64_bf16<__bf16, false, true>, p, wp, stream);
-        }
-        *name = "fa_fwd16_w64<fp16,128,rope>";
-        return p.causal ? launch_w64_kernel(fa_fwd16_w64_f16<_Float16, true, true>, p, wp, stream)
-                        : launch_w64_kernel(fa_fwd16_w64_f16<_Float16, false, true>, p, wp, stream);
-    }
-    if (p.pv16) {  // bf16 Q / K, fp16 P and V (runtime.hip hands over the fp16 V copy): head_dim 128, no window, no fused rotation
-        if (p.in_prec != P_BF16 || w64_is_window(p) || p.rope_cos) return hipErrorNotSupported;
-        if (p.D == 64) {
-            *name = "fa_fwd16_w64<bf16,64,pv16>";
-            if (p.causal)
-                return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64d64_bf16pv16<float, true>, p, wp, stream)
-                                            : launch_w64_kernel(fa_fwd16_w64d64_bf16pv16<__bf16, true>, p, wp, stream);
-            return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64d64_bf16pv16<float, false>, p, wp, stream)
-                                        : launch_w64_kernel(fa_fwd16_w64d64_bf16pv16<__bf16, false>, p, wp, stream);
-        }
-        *name = "fa_fwd16_w64<bf16,128,pv16>";
-        if (p.causal)
-            return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64_bf16pv16<float, true>, p, wp, stream)
-                                        : launch_w64_kernel(fa_fwd16_w64_bf16pv16<__bf16, true>, p, wp, stream);
-        return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64_bf16pv16<float, false>, p, wp, stream)
-                                    : launch_w64_kernel(fa_fwd16_w64_bf16pv16<__bf16, false>, p, wp, stream);
-    }
-    if (w64_is_window(p)) {
+    const bool rope = p.rope_cos != nullptr, window = w64_is_window(p), fp32o = p.out_prec == P_FP32;
+    if (rope && p.out_prec != p.in_prec) return hipErrorNotSupported;  // fused-RoPE instantiations: O in the operand type only (runtime.hip asks first)
+    if (window) {
         wp.Tw = w64_tiles_per_item(p);
         wp.win_left = (int32_t)w64_win_left(p);
         wp.win_right = (int32_t)w64_win_right(p);
-        if (p.D == 64) {
-            if (p.in_prec == P_BF16) {
-                *name = "fa_fwd16_w64<bf16,64,window>";
-                return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64d64_bf16<float, false, false, true>, p, wp, stream)
-                                            : launch_w64_kernel(fa_fwd16_w64d64_bf16<__bf16, false, false, true>, p, wp, stream);
-            }
-            *name = "fa_fwd16_w64<fp16,64,window>";
-            return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64d64_f16<float, false, false, true>, p, wp, stream)
-                                        : launch_w64_kernel(fa_fwd16_w64d64_f16<_Float16, false, false, true>, p, wp, stream);
-        }
-        if (p.in_prec == P_BF16) {
-            *name = "fa_fwd16_w64<bf16,128,window>";
-            return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64_bf16<float, false, false, true>, p, wp, stream)
-                                        : launch_w64_kernel(fa_fwd16_w64_bf16<__bf16, false, false, true>, p, wp, stream);
-        }
-        *name = "fa_fwd16_w64<fp16,128,window>";
-        return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64_f16<float, false, false, true>, p, wp, stream)
-                                    : launch_w64_kernel(fa_fwd16_w64_f16<_Float16, false, false, true>, p, wp, stream);
     }
+    wp.status = p.status;
+    // one kernel family = one (operand type, P V type, head_dim); its instantiations: <OUT, causal>, <OUT, false, false, window>,
+    // and at head_dim 128 <operand type, causal, rope>
+#define W64_FAMILY(FAM, T16, HAS_ROPE)                                                                                         \
+    do {                                                                                                                       \
+        if constexpr (HAS_ROPE) {                                                                                              \
+            if (rope) return p.causal ? launch_w64_kernel(FAM<T16, true, true>, p, wp, stream) : launch_w64_kernel(FAM<T16, false, true>, p, wp, stream); \
+        }                                                                                                                      \
+        if (window) return fp32o ? launch_w64_kernel(FAM<float, false, false, true>, p, wp, stream) : launch_w64_kernel(FAM<T16, false, false, true>, p, wp, stream); \
+        if (p.causal) return fp32o ? launch_w64_kernel(FAM<float, true>, p, wp, stream) : launch_w64_kernel(FAM<T16, true>, p, wp, stream); \
+        return fp32o ? launch_w64_kernel(FAM<float, false>, p, wp, stream) : launch_w64_kernel(FAM<T16, false>, p, wp, stream); \
+    } while (0)
+    static const char* const names[3][2][3] = {
+        {{"fa_fwd16_w64<bf16,128>", "fa_fwd16_w64<bf16,128,rope>", "fa_fwd16_w64<bf16,128,window>"},
+         {"fa_fwd16_w64<bf16,64>", "fa_fwd16_w64<bf16,64,rope>", "fa_fwd16_w64<bf16,64,window>"}},
+        {{"fa_fwd16_w64<bf16,128,pv16>", "fa_fwd16_w64<bf16,128,pv16,rope>", "fa_fwd16_w64<bf16,128,pv16,window>"},
+         {"fa_fwd16_w64<bf16,64,pv16>", "fa_fwd16_w64<bf16,64,pv16,rope>", "fa_fwd16_w64<bf16,64,pv16,window>"}},
+        {{"fa_fwd16_w64<fp16,128>", "fa_fwd16_w64<fp16,128,rope>", "fa_fwd16_w64<fp16,128,window>"},
+         {"fa_fwd16_w64<fp16,64>", "fa_fwd16_w64<fp16,64,rope>", "fa_fwd16_w64<fp16,64,window>"}}};
+    if (p.D == 64 && rope) return hipErrorNotSupported;
+    const int fam = p.in_prec == P_BF16 ? (p.pv16 ? 1 : 0) : 2;
+    *name = names[fam][p.D == 64 ? 1 : 0][rope ? 1 : window ? 2 : 0];
     if (p.D == 64) {
-        const bool bf = p.in_prec == P_BF16;
-        *name = bf ? "fa_fwd16_w64<bf16,64>" : "fa_fwd16_w64<fp16,64>";
-        if (bf) {
-            if (p.causal)
-                return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64d64_bf16<float, true>, p, wp, stream)
-                                            : launch_w64_kernel(fa_fwd16_w64d64_bf16<__bf16, true>, p, wp, stream);
-            return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64d64_bf16<float, false>, p, wp, stream)
-                                        : launch_w64_kernel(fa_fwd16_w64d64_bf16<__bf16, false>, p, wp, stream);
-        }
-        if (p.causal)
-            return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64d64_f16<float, true>, p, wp, stream)
-                                        : launch_w64_kernel(fa_fwd16_w64d64_f16<_Float16, true>, p, wp, stream);
-        return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64d64_f16<float, false>, p, wp, stream)
-                                    : launch_w64_kernel(fa_fwd16_w64d64_f16<_Float16, false>, p, wp, stream);
+        if (fam == 0) W64_FAMILY(fa_fwd16_w64d64_bf16, __bf16, false);
+        if (fam == 1) W64_FAMILY(fa_fwd16_w64d64_bf16pv16, __bf16, false);
+        W64_FAMILY(fa_fwd16_w64d64_f16, _Float16, false);
     }
-    if (p.in_prec == P_BF16) {
-        *name = "fa_fwd16_w64<bf16,128>";
-        if (p.causal)
-            return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64_bf16<float, true>, p, wp, stream)
-                                        : launch_w64_kernel(fa_fwd16_w64_bf16<__bf16, true>, p, wp, stream);
-        return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64_bf16<float, false>, p, wp, stream)
-                                    : launch_w64_kernel(fa_fwd16_w64_bf16<__bf16, false>, p, wp, stream);
-    }
-    *name = "fa_fwd16_w64<fp16,128>";
-    if (p.causal)
-        return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64_f16<float, true>, p, wp, stream)
-                                    : launch_w64_kernel(fa_fwd16_w64_f16<_Float16, true>, p, wp, stream);
-    return p.out_prec == P_FP32 ? launch_w64_kernel(fa_fwd16_w64_f16<float, false>, p, wp, stream)
-                                : launch_w64_kernel(fa_fwd16_w64_f16<_Float16, false>, p, wp, stream);
+    if (fam == 0) W64_FAMILY(fa_fwd16_w64_bf16, __bf16, true);
+    if (fam == 1) W64_FAMILY(fa_fwd16_w64_bf16pv16, __bf16, true);
+    W64_FAMILY(fa_fwd16_w64_f16, _Float16, true);
+#undef W64_FAMILY
 }
 
 // ---- runtime-quantised variant ---------------------------------------------------------------------------------

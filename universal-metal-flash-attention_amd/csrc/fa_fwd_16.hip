@@ -91,7 +91,7 @@ FwdSplitPlan fwd_16_split_plan(const FwdParams& p) {
     return plan;
 }
 
-template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT, bool DMA, int BN>
+template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT, bool DMA, int BN, bool PV16 = false>
 static hipError_t launch_dma(const FwdParams& pin, hipStream_t stream) {
     FwdParams p = pin;
     const uint32_t nqb = (p.Sq + 127) / 128;
@@ -100,7 +100,7 @@ static hipError_t launch_dma(const FwdParams& pin, hipStream_t stream) {
     const uint32_t grid = p.n_full + (items - p.n_full) * p.nsplit;
     // (p.part_cnt is zero on entry and on exit: the runtime zeroes a ticket block once, the folding workgroup resets its word)
     const size_t lds = 4 * BN * DP * 2;
-    auto kfn = fa_fwd16_kernel<T, DP, CAUSAL, HAS_MASK, OUT, DMA, BN>;
+    auto kfn = fa_fwd16_kernel<T, DP, CAUSAL, HAS_MASK, OUT, DMA, BN, PV16>;
     if (hipError_t e = ensure_dynamic_lds((const void*)kfn, lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, stream, p);
     return hipGetLastError();
@@ -111,6 +111,14 @@ static bool dma_enabled() { return !tuning().no_dma.load(std::memory_order_relax
 // LDS-DMA staging when head_dim fills the padded row exactly; register staging otherwise.
 template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT>
 static hipError_t launch_one(const FwdParams& p, hipStream_t stream) {
+    if constexpr (__is_same(T, __bf16)) {
+        // bf16 operands, fp16 P V (FwdParams::pv16, the default): V tiles go through registers (converted on the way), K keeps
+        // LDS-DMA; 64-key tiles throughout (the 32-key / three-workgroup variant has no room for the V staging registers)
+        if (p.pv16) {
+            if ((int)p.D == DP && dma_enabled()) return launch_dma<T, DP, CAUSAL, HAS_MASK, OUT, true, 64, true>(p, stream);
+            return launch_dma<T, DP, CAUSAL, HAS_MASK, OUT, false, 64, true>(p, stream);
+        }
+    }
     if ((int)p.D == DP && dma_enabled()) {
         // 32-key tiles + LDS-DMA at head_dim 128: 166 VGPR / 32 KiB LDS -> three resident workgroups per CU
         // (lab, same box: FLUX 768 items 264 -> 242 us; 3072 items 895 -> 870 us; never slower)
@@ -141,10 +149,11 @@ static hipError_t launch_out(const FwdParams& p, hipStream_t stream) {
 template <typename T>
 static hipError_t launch_dp(const FwdParams& p, hipStream_t stream, const char** name) {
     constexpr bool bf = sizeof(T) == 2 && __is_same(T, __bf16);
-    if (p.D <= 32) { *name = bf ? "fa_fwd16<bf16,32>" : "fa_fwd16<fp16,32>"; return launch_out<T, 32>(p, stream); }
-    if (p.D <= 64) { *name = bf ? "fa_fwd16<bf16,64>" : "fa_fwd16<fp16,64>"; return launch_out<T, 64>(p, stream); }
-    if (p.D <= 128) { *name = bf ? "fa_fwd16<bf16,128>" : "fa_fwd16<fp16,128>"; return launch_out<T, 128>(p, stream); }
-    *name = bf ? "fa_fwd16<bf16,256>" : "fa_fwd16<fp16,256>";
+    const bool pv = bf && p.pv16;
+    if (p.D <= 32) { *name = pv ? "fa_fwd16<bf16,32,pv16>" : bf ? "fa_fwd16<bf16,32>" : "fa_fwd16<fp16,32>"; return launch_out<T, 32>(p, stream); }
+    if (p.D <= 64) { *name = pv ? "fa_fwd16<bf16,64,pv16>" : bf ? "fa_fwd16<bf16,64>" : "fa_fwd16<fp16,64>"; return launch_out<T, 64>(p, stream); }
+    if (p.D <= 128) { *name = pv ? "fa_fwd16<bf16,128,pv16>" : bf ? "fa_fwd16<bf16,128>" : "fa_fwd16<fp16,128>"; return launch_out<T, 128>(p, stream); }
+    *name = pv ? "fa_fwd16<bf16,256,pv16>" : bf ? "fa_fwd16<bf16,256>" : "fa_fwd16<fp16,256>";
     return launch_out<T, 256>(p, stream);
 }
 

@@ -1,6 +1,8 @@
 // fa_fwd_16_kernel.h -- the bf16/fp16 MFMA forward kernel template (see fa_fwd_16.hip for the design notes).
 // Kept in a header so that tools/fwd_lab.hip can instantiate ONE variant for ablation/tuning builds.
 #pragma once
+#include <type_traits>
+
 #include "fa_common.h"
 
 namespace umfa {
@@ -73,11 +75,25 @@ __device__ __forceinline__ float max_xor32(float x) {
 // The loads are inline asm on purpose: for the builtin hipcc (ROCm 7.2) waits vmcnt(0) before every later LDS
 // read (no alias information), which serialises the tile; here the only wait is ours, before the tile's barrier.
 // BN = keys per tile (64, or 32: half the LDS and fewer live registers -> a third resident workgroup per CU).
-template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT, bool DMA = false, int BN = 64>
+// bf16 pair -> fp16 pair (round to nearest even; exact for 2^-17 <= |x| < 65536, +-inf beyond fp16's range -- which is how the
+// PV16 kernels notice: FwdParams::status)
+__device__ __forceinline__ unsigned bf16x2_to_f16x2(unsigned x) {
+    unsigned lo = x << 16, hi = x & 0xffff0000u, d;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(d) : "v"(lo), "v"(hi));
+    return d;
+}
+
+// PV16 (T = bf16 only; FwdParams::pv16, the default bf16 forward): the second product runs in fp16 -- P is rounded to fp16 (11
+// bits instead of bf16's 8: the bf16-input forward inside 1e-3) and V is converted bf16 -> fp16 on its way into LDS: V tiles
+// then always go through registers (buffer_load -> convert -> ds_write), K keeps LDS-DMA where it had it.
+template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT, bool DMA = false, int BN = 64, bool PV16 = false>
 __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_fwd16_kernel(FwdParams p) {
+    static_assert(!PV16 || __is_same(T, __bf16), "PV16: bf16 operands");
     typedef Mma16<T> M;
     typedef typename M::V8 V8;
-    typedef typename M::V4 V4;
+    typedef Mma16<typename std::conditional<PV16, _Float16, T>::type> MP;  // the P V product
+    typedef typename MP::V8 PV8;
+    typedef typename std::conditional<PV16, _Float16, T>::type PT;
     constexpr int BM = 128;
     constexpr int NKB = BN / 32;            // 32-key blocks per tile
     constexpr int NST = BN / 16;            // 16-key MFMA k-steps of PV per tile
@@ -173,17 +189,21 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
 
     // ---- tile staging (register path): thread owns chunks c = tid + 256 i  ->  (row, ch); offsets are tile-invariant
     constexpr int LPTR = DMA ? 1 : LPT;
-    int koff[LPTR], voff[LPTR], klds[LPTR], vlds[LPTR];
+    constexpr bool VREG = !DMA || PV16;      // V tiles through registers
+    constexpr int LPTV = VREG ? LPT : 1;
+    int koff[LPTR], voff[LPTV], klds[LPTR], vlds[LPTV];
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 kreg[LPTR], vreg[LPTR];
-    if constexpr (!DMA) {
+    u32x4 kreg[LPTR], vreg[LPTV];
+    if constexpr (VREG) {
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
             const int c = tid + 256 * i, row = c / NCH, ch = c % NCH;
             const bool colok = ch * 8 < D;
-            koff[i] = colok ? row * k_stride_b + ch * 16 : OOB;
+            if constexpr (!DMA) {
+                koff[i] = colok ? row * k_stride_b + ch * 16 : OOB;
+                klds[i] = k_off<DP>(row, ch);
+            }
             voff[i] = colok ? row * v_stride_b + ch * 16 : OOB;
-            klds[i] = k_off<DP>(row, ch);
             vlds[i] = v_off<DP>(row, ch);
         }
     }
@@ -236,9 +256,17 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
                 if (which & 1)
                     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
                                  ::"s"(kdst + j * 1024), "v"(kdma[j] + ktile), "s"(k_srd) : "memory");
-                if (which & 2)
-                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                                 ::"s"(vdst + j * 1024), "v"(vdma[j] + vtile), "s"(v_srd) : "memory");
+                if constexpr (!PV16) {
+                    if (which & 2)
+                        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                                     ::"s"(vdst + j * 1024), "v"(vdma[j] + vtile), "s"(v_srd) : "memory");
+                }
+            }
+            if constexpr (PV16) {
+                if (which & 2) {
+#pragma unroll
+                    for (int i = 0; i < LPT; ++i) vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, voff[i] + vtile, 0, 0);
+                }
             }
         } else {
             const int ksoff = (int)(t * BN) * k_stride_b, vsoff = (int)(t * BN) * v_stride_b;
@@ -258,11 +286,21 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
             // s_waitcnt vmcnt(3) ... vmcnt(0) in front of the first MFMAs of every tile -- right behind the issue of
             // the next tile's LDS-DMA, i.e. every tile waited for its successor's prefetch (tools/trace_waits.py)
             __builtin_amdgcn_s_waitcnt(0x0F70);
+            if constexpr (PV16) {
+#pragma unroll
+                for (int i = 0; i < LPT; ++i)
+                    *(u32x4*)(Vbuf + buf * TILE_BYTES + vlds[i]) = u32x4{bf16x2_to_f16x2(vreg[i][0]), bf16x2_to_f16x2(vreg[i][1]),
+                                                                         bf16x2_to_f16x2(vreg[i][2]), bf16x2_to_f16x2(vreg[i][3])};
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < LPT; ++i) {
                 *(u32x4*)(Kbuf + buf * TILE_BYTES + klds[i]) = kreg[i];
-                *(u32x4*)(Vbuf + buf * TILE_BYTES + vlds[i]) = vreg[i];
+                if constexpr (PV16)
+                    *(u32x4*)(Vbuf + buf * TILE_BYTES + vlds[i]) = u32x4{bf16x2_to_f16x2(vreg[i][0]), bf16x2_to_f16x2(vreg[i][1]),
+                                                                         bf16x2_to_f16x2(vreg[i][2]), bf16x2_to_f16x2(vreg[i][3])};
+                else
+                    *(u32x4*)(Vbuf + buf * TILE_BYTES + vlds[i]) = vreg[i];
             }
         }
     };
@@ -291,9 +329,9 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
     for (int i = 0; i < NDB; ++i) vtr[i] = v_off<DP>(4 * hi + tr_qq, 4 * i + 2 * tr_g1 + (tr_pp >> 1)) + 8 * (tr_pp & 1);
     // the swizzles of v_off depend on row bits 0-1 only (DP >= 128) / bit 1 (DP == 64): adding a multiple
     // of 4 rows is a pure byte offset, so every other read of the tile is vtr[i] + const
-    auto v_frag = [&](const char* Vt, int i, int st) -> V8 {
-        const V4 lo = M::tr_read(Vt + vtr[i] + (16 * st) * (2 * DP));
-        const V4 hi4 = M::tr_read(Vt + vtr[i] + (16 * st + 8) * (2 * DP));
+    auto v_frag = [&](const char* Vt, int i, int st) -> PV8 {
+        const typename MP::V4 lo = MP::tr_read(Vt + vtr[i] + (16 * st) * (2 * DP));
+        const typename MP::V4 hi4 = MP::tr_read(Vt + vtr[i] + (16 * st + 8) * (2 * DP));
         return __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
     };
 
@@ -414,7 +452,7 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
             }
 #endif
             // first V^T fragments requested before the softmax so their LDS latency hides under it
-            V8 va[NST];
+            PV8 va[NST];
 #pragma unroll
             for (int st = 0; st < NST; ++st) va[st] = v_frag(Vt, 0, st);
 
@@ -509,7 +547,7 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
                     for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
                 m = m_new;
             }
-            V8 pf[NST];
+            PV8 pf[NST];
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
@@ -521,13 +559,13 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
                                              : __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], c2, -m_use));
 #endif
                     l4[r & 3] += e;
-                    pf[2 * kb + (r >> 3)][r & 7] = (T)e;
+                    pf[2 * kb + (r >> 3)][r & 7] = (PT)e;
                 }
 
             // ---------------- O^T += V^T P^T (fragments of block i+1 requested before block i's MFMAs) ----
 #pragma unroll
             for (int i = 0; i < NDB; ++i) {
-                V8 vb[NST];
+                PV8 vb[NST];
                 if (i + 1 < NDB) {
 #pragma unroll
                     for (int st = 0; st < NST; ++st) vb[st] = v_frag(Vt, i + 1, st);
@@ -537,7 +575,7 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
                 for (int st = 0; st < NST; ++st) acc[i][st] += (float)va[st][0] * (float)pf[st][0];
 #else
 #pragma unroll
-                for (int st = 0; st < NST; ++st) acc[i] = M::mma(va[st], pf[st], acc[i]);
+                for (int st = 0; st < NST; ++st) acc[i] = MP::mma(va[st], pf[st], acc[i]);
 #endif
                 if (i + 1 < NDB) {
 #pragma unroll
@@ -621,6 +659,25 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
         }
     }
     const float inv = lt > 0.0f ? 1.0f / lt : 0.0f;
+    if constexpr (PV16) {
+        // fp16 image of V (fa_fwd16_w64_kernel.inc has the same check): a value beyond fp16's range went in as +-inf and made its
+        // O columns inf / NaN; a wave whose outputs are all below 2^-11 may have met values of V that are not exact in fp16
+        if (p.status) {
+            float chk_nan = 0.0f, chk_max = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float val = acc[i][r] * inv;
+                    chk_nan = __builtin_fmaf(val, 0.0f, chk_nan);
+                    chk_max = fmaxf(chk_max, __builtin_fabsf(val));
+                }
+            const bool bad = __builtin_amdgcn_ballot_w64(chk_nan != chk_nan) != 0;
+            const bool tiny = __builtin_amdgcn_ballot_w64(chk_max >= 0x1p-11f) == 0 && __builtin_amdgcn_ballot_w64(chk_max > 0.0f) != 0;
+            if (bad && lane == 0) __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (tiny && lane == 0) __hip_atomic_store(p.status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
     if (q_row < p.Sq) {
         OUT* __restrict__ op = (OUT*)p.o + ((int64_t)bh * p.Sq + q_row) * D;
 #pragma unroll

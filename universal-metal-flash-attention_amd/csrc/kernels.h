@@ -23,6 +23,7 @@ struct Tuning {
 };
 Tuning& tuning();
 bool set_tuning(const char* name, const char* value);  // false: unknown name or value out of range
+bool get_tuning(const char* name, char* out, size_t n);  // the live value as text; false: unknown name / buffer too small
 // per-device launch state (tuning.hip): CU count of the CURRENT device; MaxDynamicSharedMemorySize of `kernel` on the
 // current device raised to >= bytes (once per device and kernel)
 int device_cu_count();

@@ -131,7 +131,8 @@ struct StreamScratch {
     GrowBuf w64;        // fa_fwd16_w64: zeroed tickets (the kernel leaves them zero), then partials
     size_t w64_cnt_bytes = 0, w64_buf_hw = 0;
     GrowBuf mflags;     // mask tile flags
-    GrowBuf workspace;  // quantiser output (int8 Q/K, V image, scales, fp32 copies for backward)
+    GrowBuf workspace;  // quantiser output (int8 Q/K, V image, scales, fp32 copies for backward); rotated K / Q of the fused-RoPE entry
+    GrowBuf v16;        // default bf16 forward on the w64 kernels: the fp16 image of V (never the workspace: the RoPE entry's K lives there)
     GrowBuf rowc;       // bwd16: row constants [2][B*H*Sq] fp32 (-LSE log2 e, -D) from bwd16_dq for bwd16_dkdv
     GrowBuf dsbuf;      // bwd16, option bwd_ds_store: dS [B*H][Sq][Skv] in the operand type
 
@@ -176,7 +177,7 @@ struct StreamScratch {
         return ensure_ticketed(split, split_cnt_bytes, split_buf_hw, cnt_bytes, buf_bytes, stream);
     }
     void release() {
-        split.release(); w64.release(); mflags.release(); workspace.release(); rowc.release(); dsbuf.release();
+        split.release(); w64.release(); mflags.release(); workspace.release(); v16.release(); rowc.release(); dsbuf.release();
         w64_cnt_bytes = 0;
         split_cnt_bytes = 0;
         w64_buf_hw = split_buf_hw = 0;
@@ -193,6 +194,14 @@ struct Context {
     void* scratch = nullptr;  // host-mask staging of the synchronous entries (used under mu, then synchronised)
     size_t scratch_bytes = 0;
     std::vector<float> q_scales, k_scales, v_scales;  // mfa_set_scale_arrays: stored, never read
+    // bf16 forward with the P V product in fp16 (FwdParams::pv16, the default): four host-visible words the kernels raise --
+    // [0] an output came out non-finite (a V value beyond fp16's range), [1] a wave's outputs were all below 2^-11 (V's fp16
+    // image may have lost bits).  Synchronous entries read them behind their synchronise and repeat the call on the bf16 P V
+    // kernels; in-stream entries cannot wait: they look at the words when the NEXT call comes in and stay on the bf16 P V
+    // kernels from then on (pv16_sticky, until umfa_set_option(ctx, "pv_fp16", "1") re-arms).  pv16_fallbacks counts both.
+    volatile uint32_t* pv16_status = nullptr;
+    uint32_t pv16_sticky = 0;
+    std::atomic<uint64_t> pv16_fallbacks{0};
     std::atomic<int> refs{0};
     std::mutex mu;  // guards the pools, last_kernel / latency, and serialises lookup + launch of every entry
 

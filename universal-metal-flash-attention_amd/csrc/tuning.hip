@@ -6,6 +6,7 @@
 // and getenv is not thread-safe against setenv.  Now: the environment gives the INITIAL value, once, when the table is
 // first touched; afterwards only umfa_set_option (include/umfa_abi.h) changes a switch, and a launch reads each one once
 // (relaxed atomics: a switch is a hint to the NEXT launch, not a synchronisation point).
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -53,7 +54,7 @@ Tuning& tuning() {
         x->force_split.store(env_int("UMFA_FORCE_SPLIT", 0));
         x->no_dma.store(env_flag("UMFA_NO_DMA"));
         x->bn64.store(env_flag("UMFA_BN64"));
-        x->pv_fp16.store(env_flag("UMFA_PV_FP16"));
+        x->pv_fp16.store(env_int("UMFA_PV_FP16", 1) != 0);  // bf16 forward: P V in fp16 (inside 1e-3) unless switched off
         x->bwd_ds_store.store(env_flag("UMFA_BWD_DS_STORE"));
         return x;
     }();
@@ -93,6 +94,34 @@ bool set_tuning(const char* name, const char* value) {
             return true;
         }
     return false;
+}
+
+// the live value of a switch as text (what set_tuning would take); false: unknown name or buffer too small
+bool get_tuning(const char* name, char* out, size_t n) {
+    if (!name || !out || n < 2) return false;
+    Tuning& t = tuning();
+    char buf[32];
+    if (!strcmp(name, "softmax_reference")) {
+        const int m = t.sm_mode.load();
+        snprintf(buf, sizeof(buf), "%s", m == SM_EXACT ? "exact" : m == SM_DEFERRED ? "deferred" : m == SM_LAZY ? "lazy" : "default");
+    } else if (!strcmp(name, "softmax_tau") || !strcmp(name, "w64_tau")) {
+        snprintf(buf, sizeof(buf), "%g", (double)t.sm_tau.load());
+    } else {
+        struct { const char* n; std::atomic<int>* v; } tab[] = {
+            {"force_w64", &t.force_w64}, {"no_w64", &t.no_w64}, {"w64_grid", &t.w64_grid}, {"w64_skew", &t.w64_skew},
+            {"no_mask_flags", &t.no_mask_flags}, {"bwd_exact", &t.bwd_exact}, {"bwd_dq", &t.bwd_dq}, {"bwd_persist", &t.bwd_persist},
+            {"bwd_separate_delta", &t.bwd_separate_delta}, {"no_split", &t.no_split}, {"force_split", &t.force_split},
+            {"no_dma", &t.no_dma}, {"bn64", &t.bn64}, {"pv_fp16", &t.pv_fp16}, {"bwd_ds_store", &t.bwd_ds_store},
+        };
+        const std::atomic<int>* v = nullptr;
+        for (auto& e : tab)
+            if (!strcmp(name, e.n)) v = e.v;
+        if (!v) return false;
+        snprintf(buf, sizeof(buf), "%d", v->load());
+    }
+    if (strlen(buf) + 1 > n) return false;
+    strcpy(out, buf);
+    return true;
 }
 
 // ---- per-DEVICE launch state.  The in-stream entries launch on streams of any device (DeviceGuard), so nothing about a

@@ -170,6 +170,8 @@ def _load_library(path: str | None = None) -> ctypes.CDLL:
         sig("umfa_release_scratch", mfa_error_t, [mfa_context_t, _vp, _i32])
     if path is None or hasattr(lib, "umfa_set_option"):  # (tools/ab_inproc.py also loads older builds by explicit path)
         sig("umfa_set_option", _i32, [mfa_context_t, ctypes.c_char_p, ctypes.c_char_p])
+    if path is None or hasattr(lib, "umfa_get_option"):
+        sig("umfa_get_option", _i32, [mfa_context_t, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t])
     sig("umfa_quantize_rows", _i32, [mfa_context_t, _vp, _vp, _i32, _u32, _u32, _u32, _i32, _i32, _vp, _vp,
                                      ctypes.POINTER(_u32)])
     return lib

@@ -44,36 +44,57 @@ def release_scratch(stream=None, all_streams: bool = False) -> None:
     _check_error(_lib.umfa_release_scratch(context(), ctypes.c_void_p(st), 1 if all_streams else 0))
 
 
-# launcher switches (include/umfa_abi.h umfa_set_option); the library's defaults, for options() to restore
-_OPTION_DEFAULTS = {"softmax_reference": "default", "softmax_tau": "6", "force_w64": "0", "no_w64": "0", "w64_grid": "0", "w64_skew": "0",
-                    "no_mask_flags": "0", "bwd_exact": "0", "bwd_dq": "0", "bwd_persist": "0", "no_split": "0",
-                    "force_split": "0", "no_dma": "0", "bn64": "0", "pv_fp16": "0", "bwd_ds_store": "0"}
-_option_state = {}
+# launcher switches (include/umfa_abi.h umfa_set_option / umfa_get_option).  The LIBRARY holds the state (seeded once from the
+# environment: UMFA_FORCE_W64, UMFA_W64_TAU, ...); this module only reads and writes it.
+_OPTION_NAMES = ("softmax_reference", "softmax_tau", "w64_tau", "force_w64", "no_w64", "w64_grid", "w64_skew", "no_mask_flags", "bwd_exact",
+                 "bwd_dq", "bwd_persist", "bwd_separate_delta", "no_split", "force_split", "no_dma", "bn64", "pv_fp16", "bwd_ds_store")
+
+
+def get_option(name: str) -> str:
+    """The live value of a launcher switch (or of the read-only "pv_fp16_status" / "pv_fp16_fallbacks") as text."""
+    buf = ctypes.create_string_buffer(64)
+    _check_error(_lib.umfa_get_option(context(), name.encode(), buf, 64))
+    return buf.value.decode()
 
 
 def set_option(name: str, value) -> None:
     """Context-wide launcher switch, e.g. set_option("softmax_reference", "exact") -- see umfa_set_option in the header."""
     _check_error(_lib.umfa_set_option(context(), name.encode(), str(value).encode()))
-    _option_state[name] = str(value)
+
+
+def pv_fp16_status() -> int:
+    """bf16 forward with the P V product in fp16 (the default): bit 0 = a launch produced a non-finite output (a V value beyond
+    fp16's range), bit 1 = a launch's outputs were below 2^-11 (V's fp16 image may have lost bits), bit 2 = in-stream calls
+    have switched to the bf16 P V kernels because of it; set_option("pv_fp16", 1) re-arms."""
+    return int(get_option("pv_fp16_status"))
 
 
 class options:
-    """with umfa_torch.options(softmax_reference="exact", force_w64=1): ...  -- sets the switches, restores the previous
-    values (the library defaults for switches never set through this module) on exit."""
+    """with umfa_torch.options(softmax_reference="exact", force_w64=1): ...  -- sets the switches and puts the values the
+    library held before back on exit.  Names are validated before anything is applied."""
 
     def __init__(self, **kw):
+        unknown = [k for k in kw if k not in _OPTION_NAMES]
+        if unknown:
+            raise KeyError(f"unknown launcher switch(es) {unknown}; known: {_OPTION_NAMES}")
         self.kw = kw
         self.prev = {}
 
     def __enter__(self):
+        prev = {k: get_option(k) for k in self.kw}  # everything read before anything is written
+        if "w64_tau" in self.kw or "softmax_tau" in self.kw:  # w64_tau also moves the reference policy
+            prev.setdefault("softmax_reference", get_option("softmax_reference"))
         for k, v in self.kw.items():
-            self.prev[k] = _option_state.get(k, _OPTION_DEFAULTS[k])
             set_option(k, v)
+        self.prev = prev
         return self
 
     def __exit__(self, *exc):
+        ref = self.prev.pop("softmax_reference", None)
         for k, v in self.prev.items():
-            set_option(k, v)
+            set_option("softmax_tau" if k == "w64_tau" else k, v)
+        if ref is not None:
+            set_option("softmax_reference", ref)
         return False
 
 
@@ -212,16 +233,20 @@ def quantized_attention_forward(q, k, v, *, scale=None, causal=False, mask=None,
 
 
 def quantized_attention_forward_stream(q, k, v, *, scale=None, causal=False, mask=None, bits: int = 8,
-                                       quant_mode: str = "blockwise", return_lse: bool = False):
+                                       quant_mode: str = "blockwise", return_lse: bool = False, out=None, lse=None):
     """quantized_attention_forward without the host round trips: umfa_quantized_forward_stream on torch's current
-    stream (asynchronous).  Same numbers as the blocking entry."""
+    stream (asynchronous).  Same numbers as the blocking entry.  out / lse: caller-provided fp32 [B,H,Sq,D] / [B*H*Sq]
+    (no allocation on the launch path, like attention_forward's out=)."""
     B, H, Sq, D = q.shape
     Skv = k.shape[2]
     if scale is None:
         scale = D ** -0.5
     q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
-    out = torch.empty((B, H, Sq, D), dtype=torch.float32, device=q.device)
-    lse = torch.empty((B * H * Sq,), dtype=torch.float32, device=q.device)
+    if out is None:
+        out = torch.empty((B, H, Sq, D), dtype=torch.float32, device=q.device)
+    if lse is None:
+        lse = torch.empty((B * H * Sq,), dtype=torch.float32, device=q.device)
+    assert out.dtype == torch.float32 and out.is_contiguous() and lse.dtype == torch.float32 and lse.numel() == B * H * Sq
     m32 = None
     if mask is not None:
         m32 = torch.zeros((B, H, Sq, Skv), dtype=torch.float32, device=q.device)
