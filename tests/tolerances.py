@@ -103,7 +103,7 @@ def check_forward(o, ref, dt, kernel: str, tag: str = "", scale_max: float = 1.0
     cmax, crms = ULP_AT_ONE[name], 0.6 * ULP_AT_ONE[name]
     if out_dt is not None and _name(out_dt) in OUT_HALF_ULP:
         h = OUT_HALF_ULP[_name(out_dt)]
-        cmax, crms = float(np.hypot(cmax, 0.5 * h)), float(np.hypot(crms, 0.5 * h))
+        cmax, crms = cmax + 0.5 * h, float(np.hypot(crms, 0.5 * h))  # max: the two can meet in one element; rms: independent
     rec = dict(dtype=name, kernel=kernel, regime=regime, out=_name(out_dt) if out_dt is not None else "fp32", max=mx, rms=rms,
                ceiling_max=cmax * scale_max, ceiling_rms=crms * scale_max, n=int(np.asarray(ref).size))
     fl = None

@@ -66,10 +66,12 @@ struct FwdParams {
     const float* rope_sin;
     int64_t rope_tb;
     // bf16 operands with the P V product in fp16 (option pv_fp16, the default): P is rounded to fp16 -- 11 bits instead of 8 -- and V
-    // is converted bf16 -> fp16 inside the kernel on its way into LDS; the bf16-input forward then meets the 1e-3 bound.  fp16's
-    // range is the price: status[0] is raised when an output came out non-finite (a V value beyond +-65504 became inf),
-    // status[1] when a wave's outputs are all below 2^-11 (values of V under 2^-17 are not exact in fp16).  The runtime reads
-    // the words (host-visible memory) and falls back to the bf16 P V kernels (dispatch_forward).
+    // becomes fp16 (the w64 kernels: `v` points at the fp16 image the runtime's cast pre-pass wrote; the 128-row kernel converts
+    // bf16 -> fp16 on V's way into LDS); the bf16-input forward then meets the 1e-3 bound.  fp16's range is the price and it is
+    // checked: status[0] is raised when a V value does not fit (>= 65536, inf, NaN: it went in as +-inf), status[1] when V / the
+    // outputs are so small that fp16's image may have lost bits (cast pass: a 64-row chunk with every |v| < 2^-6; 128-row kernel:
+    // a wave whose outputs are all below 2^-11).  The runtime reads the words (host-visible memory) and falls back to the bf16
+    // P V kernels (runtime.hip dispatch_forward).
     int pv16;
     uint32_t* status;
 };

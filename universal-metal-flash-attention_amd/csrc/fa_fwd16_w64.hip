@@ -48,8 +48,6 @@ struct W64Params {
     const float* rope_cos;  // fused rotary embedding of Q (FwdParams::rope_*), NULL = none
     const float* rope_sin;
     int64_t rope_tb;
-    uint32_t* status;       // pv16 kernels (bf16 operands, fp16 P V): [0] = 1 when an output is not finite (a V value outside fp16's range),
-                            // [1] = 1 when a wave's outputs are all below 2^-11 (V's fp16 image may have lost bits); host-visible, may be NULL
 };
 
 // ---- asm-owned accumulator registers: helpers with literal register numbers (generated)
@@ -102,10 +100,13 @@ struct W64I8Params {
 // bf16 Q / K / V with the P V product in fp16 -- the DEFAULT bf16 forward (option pv_fp16, on unless switched off or a call
 // raised the status word): S = K Q^T on the bf16 MFMA, P rounded to fp16 (v_cvt_pk_f16_f32: 11 bits instead of bf16's 8, which
 // is what puts the bf16-input forward inside the north-star's 1e-3), O^T += V^T P^T on the fp16 MFMA against an fp16 image of V
-// (the runtime's cast pre-pass, fa_aux.hip; exact over fp16's range, checked in the epilogue: W64_PVCHK); the lazy reference
-// with fp16's thresholds
-#undef W64_PVCHK
-#define W64_PVCHK 1
+// (the runtime's cast pre-pass, fa_aux.hip: exact over fp16's range, and the pass itself raises the status words when V does
+// not fit -- the runtime then falls back to the bf16 P V kernels); the lazy reference with fp16's thresholds.
+// (Round 4 also built the conversion INSIDE this kernel -- register-staged V tiles, 48 vector instructions + 4 ds_write per tile
+// per wave: +23 % cycles per tile, +15 % loop time at the FLUX shape (in-kernel stamps 167.6 vs 145.3 us,
+// profiles/r4/lab_notes.md): every workgroup converts every V tile again, 16 x redundantly at FLUX; the pre-pass converts once
+// at HBM speed.  An epilogue check of the outputs was dropped too: two more live registers there cost the TILE LOOP 76
+// accumulator-register moves and the kernel 8-13 %.)
 #define W64_T __bf16
 #define W64_MFMA "v_mfma_f32_32x32x16_f16"
 #define W64_MFMA_QK "v_mfma_f32_32x32x16_bf16"
@@ -123,8 +124,6 @@ struct W64I8Params {
 #undef W64_LAZY_PARTS
 #undef W64_CVT
 #undef W64_KERNEL
-#undef W64_PVCHK
-#define W64_PVCHK 0
 
 #define W64_T _Float16
 #define W64_MFMA "v_mfma_f32_32x32x16_f16"
@@ -167,8 +166,7 @@ struct W64I8Params {
 #undef W64_LAZY_PARTS
 #undef W64_CVT
 #undef W64_KERNEL
-#undef W64_PVCHK
-#define W64_PVCHK 1                             /* bf16 operands, fp16 P V against the fp16 image of V: the default bf16 forward at head_dim 64 */
+/* bf16 operands, fp16 P V against the fp16 image of V: the default bf16 forward at head_dim 64 */
 #define W64_T __bf16
 #define W64_MFMA "v_mfma_f32_32x32x16_f16"
 #define W64_MFMA_QK "v_mfma_f32_32x32x16_bf16"
@@ -186,8 +184,6 @@ struct W64I8Params {
 #undef W64_LAZY_PARTS
 #undef W64_CVT
 #undef W64_KERNEL
-#undef W64_PVCHK
-#define W64_PVCHK 0
 #define W64_T _Float16
 #define W64_MFMA "v_mfma_f32_32x32x16_f16"
 #define W64_MFMA_QK "v_mfma_f32_32x32x16_f16"
@@ -377,7 +373,6 @@ hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cn
         wp.win_left = (int32_t)w64_win_left(p);
         wp.win_right = (int32_t)w64_win_right(p);
     }
-    wp.status = p.status;
     // one kernel family = one (operand type, P V type, head_dim); its instantiations: <OUT, causal>, <OUT, false, false, window>,
     // and at head_dim 128 <operand type, causal, rope>
 #define W64_FAMILY(FAM, T16, HAS_ROPE)                                                                                         \

@@ -111,7 +111,7 @@ hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p,
             const size_t vbytes = (size_t)p.B * p.H * p.Skv * p.D * 2;
             void* v16 = sc.v16.ensure(vbytes + 256, stream);
             if (!v16) return hipErrorOutOfMemory;
-            if ((e = launch_cast_rows_bf16_to_f16(p.v, p.vs, v16, p.B, p.H, p.Skv, p.D, stream)) != hipSuccess) return e;
+            if ((e = launch_cast_rows_bf16_to_f16(p.v, p.vs, v16, p.B, p.H, p.Skv, p.D, pv.status, stream)) != hipSuccess) return e;
             pv.v = v16;
             pv.vs[0] = (int64_t)p.H * p.Skv * p.D; pv.vs[1] = (int64_t)p.Skv * p.D; pv.vs[2] = p.D; pv.vs[3] = 1;
         }
