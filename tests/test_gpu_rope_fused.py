@@ -5,6 +5,7 @@ on (in-register rotation on fa_fwd16_w64, pre-pass on the 128-row / exact kernel
 rope_rotate -> sdpa_forward within the path's usual bounds."""
 import numpy as np
 import pytest
+from tolerances import fam
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -77,7 +78,7 @@ def test_fused_vs_oracle(dt, umfa_opts):
     import umfa_torch  # noqa: F401
     from umfa_torch import ops
     from oracle import oracle
-    from tolerances import check_forward, fam
+    from tolerances import check_forward
     umfa_opts(force_w64=1)
     B, H, S, D = 1, 2, 512, 128
     torch.manual_seed(13)

@@ -103,7 +103,9 @@ def check_forward(o, ref, dt, kernel: str, tag: str = "", scale_max: float = 1.0
     cmax, crms = ULP_AT_ONE[name], 0.6 * ULP_AT_ONE[name]
     if out_dt is not None and _name(out_dt) in OUT_HALF_ULP:
         h = OUT_HALF_ULP[_name(out_dt)]
-        cmax, crms = cmax + 0.5 * h, float(np.hypot(crms, 0.5 * h))  # max: the two can meet in one element; rms: independent
+        # max: the kernel's error and the output rounding can meet in one element, and an element just above a power of two is off
+        # by up to h of ITSELF (measured at config 5's shard, bf16 O: 3.04e-3 of max|O|); rms: independent, uniform inside a binade
+        cmax, crms = cmax + h, float(np.hypot(crms, 0.5 * h))
     rec = dict(dtype=name, kernel=kernel, regime=regime, out=_name(out_dt) if out_dt is not None else "fp32", max=mx, rms=rms,
                ceiling_max=cmax * scale_max, ceiling_rms=crms * scale_max, n=int(np.asarray(ref).size))
     fl = None
@@ -120,7 +122,7 @@ def check_forward(o, ref, dt, kernel: str, tag: str = "", scale_max: float = 1.0
         rec.update(floor_max=fmax, floor_rms=frms, max_on_floor_rows=kmax, rms_on_floor_rows=krms)
     record(tag or kernel, **rec)
     assert mx < cmax * scale_max, (tag, kernel, "format ceiling, max", mx, cmax * scale_max)
-    if name == "fp16" and scale_max == 1.0:
+    if name == "fp16" and scale_max == 1.0 and out_dt is None:  # (a 16-bit O adds its own rounding: up to 2^-8 of an element for bf16)
         assert mx <= NORTH_STAR, (tag, kernel, "north-star 1e-3", mx)  # fp16 P V (fp16 inputs, or bf16 inputs by default) meets the stated tolerance everywhere
     if np.asarray(ref).size >= min_elems_for_rms:
         assert rms < crms * scale_max, (tag, kernel, "format ceiling, rms", rms, crms * scale_max)

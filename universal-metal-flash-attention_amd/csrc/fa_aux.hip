@@ -245,6 +245,21 @@ __global__ __launch_bounds__(256) void group_sum_kernel(const float* src, void* 
     }
 }
 
+__global__ __launch_bounds__(256) void group_sum_scalar_kernel(const float* __restrict__ src, void* __restrict__ dst, uint32_t B, uint32_t H, uint32_t Hkv,
+                                                               int64_t slab, int out_prec) {
+    const uint32_t g = H / Hkv;
+    const int64_t n = (int64_t)B * Hkv * slab;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t e = i % slab, bh = i / slab;
+        const int64_t b = bh / Hkv, hk = bh % Hkv;
+        float acc = 0.0f;
+        for (uint32_t j = 0; j < g; ++j) acc += src[(b * H + hk * g + j) * slab + e];
+        if (out_prec == P_FP16) ((_Float16*)dst)[i] = (_Float16)acc;
+        else if (out_prec == P_BF16) ((__bf16*)dst)[i] = (__bf16)acc;
+        else ((float*)dst)[i] = acc;
+    }
+}
+
 hipError_t launch_cast_f16(const void* src, int prec, void* dst, int64_t n, uint32_t* overflow, hipStream_t stream) {
     if (!src || !dst || (n & 7) || (prec != P_FP32 && prec != P_BF16)) return hipErrorInvalidValue;
     if (n == 0) return hipSuccess;
@@ -344,9 +359,39 @@ hipError_t launch_group_sum(const float* src, void* dst, uint32_t B, uint32_t H,
                             int out_prec) {
     const int64_t n = (int64_t)B * Hkv * slab;
     if (n == 0) return hipSuccess;
-    if (slab % 4 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return hipErrorInvalidValue;
+    if (slab % 4 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) {
+        // slabs that are not a whole number of 16-byte groups (Skv * D % 4 != 0: head_dim 30 with an odd Skv, head_dim 2 ...) or
+        // unaligned pointers: one element per thread (the exact engine accepts any head_dim <= 256 with grouped K / V)
+        const unsigned grid1 = (unsigned)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+        hipLaunchKernelGGL(group_sum_scalar_kernel, dim3(grid1), dim3(256), 0, stream, src, dst, B, H, Hkv, slab, out_prec);
+        return hipGetLastError();
+    }
     const unsigned grid = (unsigned)((n / 4 + 255) / 256 < 8192 ? (n / 4 + 255) / 256 : 8192);
     hipLaunchKernelGGL(group_sum_kernel, dim3(grid), dim3(256), 0, stream, src, dst, B, H, Hkv, slab, out_prec);
+    return hipGetLastError();
+}
+
+// *flag |= 1 when any of x[0 .. n) is not finite.  The 16-bit MFMA backward on fp16 operands (quantised backward entries) rounds
+// dS = P (dP - D) to fp16: dP is a sum of head_dim products and can pass 65504 while every operand is in range (|dO| ~ 1e2 with
+// |V| ~ 10, loss-scaled dO); the operand checks of the quantiser / cast do not see that, the gradients do (inf / NaN).
+__global__ __launch_bounds__(256) void nonfinite_flag_kernel(const float* __restrict__ x, int64_t n4, int64_t n, uint32_t* flag) {
+    float acc = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 v = ((const f32x4*)x)[i];
+        acc = __builtin_fmaf(v[0], 0.0f, acc); acc = __builtin_fmaf(v[1], 0.0f, acc);
+        acc = __builtin_fmaf(v[2], 0.0f, acc); acc = __builtin_fmaf(v[3], 0.0f, acc);
+    }
+    for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)  // tail / unaligned x
+        acc = __builtin_fmaf(x[i], 0.0f, acc);
+    if (__builtin_amdgcn_ballot_w64(acc != acc) != 0 && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
+hipError_t launch_nonfinite_flag(const float* x, int64_t n, uint32_t* flag, hipStream_t stream) {
+    if (!x || !flag || n <= 0) return hipSuccess;
+    const int64_t n4 = ((uintptr_t)x & 15) ? 0 : n / 4;  // an unaligned (wrapped caller) buffer: element by element
+    const int64_t work = n4 ? n4 : n;
+    const unsigned grid = (unsigned)((work + 255) / 256 < 4096 ? (work + 255) / 256 : 4096);
+    hipLaunchKernelGGL(nonfinite_flag_kernel, dim3(grid), dim3(256), 0, stream, x, n4, n, flag);
     return hipGetLastError();
 }
 

@@ -95,6 +95,8 @@ hipError_t launch_cast_f16(const void* src, int prec, void* dst, int64_t n, uint
 // value does not fit fp16 (it becomes +-inf), [1] = 1 when a 64-row chunk's values are all below 2^-6
 hipError_t launch_cast_rows_bf16_to_f16(const void* src, const int64_t* strides, void* dst, uint32_t B, uint32_t H, uint32_t S, uint32_t D,
                                         uint32_t* status, hipStream_t stream);
+// *flag |= 1 when any of x[0 .. n) (fp32, 16-byte aligned) is not finite
+hipError_t launch_nonfinite_flag(const float* x, int64_t n, uint32_t* flag, hipStream_t stream);
 // rowc[0 .. n) = -lse * log2 e, rowc[n .. 2n) = -dvec: what bwd16_dq leaves for bwd16_dkdv, for a dK / dV-only call
 hipError_t launch_bwd16_rowc(const float* lse, const float* dvec, float* rowc, int64_t n, hipStream_t stream);
 // dst: [B, Hkv, slab] in out_prec (fp32 default; fp16 / bf16: rounded once after the fp32 sum)

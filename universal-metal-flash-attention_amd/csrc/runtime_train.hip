@@ -122,7 +122,9 @@ mfa_error_t umfa_attention_backward_stream(mfa_context_t context, void* stream, 
         // capacity traded for matrix work on a 288 GB part).  Head_dim 128, non-causal, whole 128-blocks, scratch <= 8 GiB.
         if (tuning().bwd_ds_store.load(std::memory_order_relaxed) && head_dim == 128 && !causal && seq_len_q % 128 == 0 && seq_len_kv % 128 == 0) {
             const size_t bytes = (size_t)batch_size * num_heads * seq_len_q * seq_len_kv * 2;
-            if (bytes <= ((size_t)8 << 30)) p.ds = sc.dsbuf.ensure(bytes, (hipStream_t)stream);  // NULL (capture, allocation): the recomputing form
+            // (one (batch, head) slab of dS is addressed through a 32-bit buffer descriptor: Sq * Skv * 2 bytes must stay below 2 GiB)
+            if (bytes <= ((size_t)8 << 30) && (uint64_t)seq_len_q * seq_len_kv * 2 < ((uint64_t)1 << 31))
+                p.ds = sc.dsbuf.ensure(bytes, (hipStream_t)stream);  // NULL (capture, allocation): the recomputing form
         }
     }
     hipError_t e = mfma16 ? launch_bwd_16(p, (hipStream_t)stream, &name) : launch_bwd(p, (hipStream_t)stream, &name);
@@ -372,6 +374,10 @@ int32_t mfa_quantized_backward(mfa_context_t context, mfa_buffer_t q, mfa_buffer
         if (e != hipSuccess) return e == hipErrorInvalidValue ? MFA_ERROR_INVALID_ARGS : MFA_ERROR_EXECUTION_FAILED;
         lat.stop();
         uint32_t overflow = 0;
+        // dS = P (dP - D) is rounded to fp16 inside the kernels and can leave fp16's range with every OPERAND inside it: the
+        // gradients then carry inf / NaN -- look at them (three HBM-speed passes, ~2 % of the call) before trusting the flag
+        if (fast && (launch_nonfinite_flag(p.dq, (int64_t)nq, flag, stream) != hipSuccess || launch_nonfinite_flag(p.dk, (int64_t)nkv, flag, stream) != hipSuccess ||
+                     launch_nonfinite_flag(p.dv, (int64_t)nkv, flag, stream) != hipSuccess)) return MFA_ERROR_EXECUTION_FAILED;
         if (fast && hipMemcpyAsync(&overflow, flag, 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
         for (Buffer* b : {bdq, bdk, bdv})
             if (b->download(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
@@ -437,6 +443,10 @@ mfa_error_t umfa_quantized_backward_stream(mfa_context_t context, void* stream_h
         p.rowc = (float*)(ws + o_rowc);
         if (!bwd_16_supported(p)) return MFA_ERROR_INVALID_ARGS;  // 16-byte alignment of the caller's tensors
         e = launch_bwd_16(p, stream, &name);
+        // dS is rounded to fp16 inside the kernels: it can overflow with every operand in range -- the gradients show it
+        const size_t nkv = (size_t)B * H * Skv * D;
+        if (e == hipSuccess && (launch_nonfinite_flag(dq, (int64_t)nq, flag, stream) != hipSuccess || launch_nonfinite_flag(dk, (int64_t)nkv, flag, stream) != hipSuccess ||
+                                launch_nonfinite_flag(dv, (int64_t)nkv, flag, stream) != hipSuccess)) return MFA_ERROR_EXECUTION_FAILED;
     } else {
         p.dout = dout; p.q = views.qf; p.k = views.kf; p.v = views.vf;
         p.in_prec = P_FP32; p.dout_prec = prec;
@@ -591,6 +601,7 @@ int32_t mfa_attention_backward_query_quantized_ex(
         if (e != hipSuccess) return e == hipErrorInvalidValue ? MFA_ERROR_INVALID_ARGS : MFA_ERROR_EXECUTION_FAILED;
         lat.stop();
         uint32_t overflow = 0;
+        if (fast && launch_nonfinite_flag(p.dq, (int64_t)nq, flag, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;  // dS rounded to fp16: see mfa_quantized_backward
         if (fast && hipMemcpyAsync(&overflow, flag, 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
         if (bdq->download(stream) != hipSuccess || bd->download(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
         if (hipStreamSynchronize(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
@@ -675,6 +686,9 @@ int32_t mfa_attention_backward_kv_quantized_ex(
         }
         lat.stop();
         uint32_t overflow = 0;
+        if (fast && (launch_nonfinite_flag((const float*)bdk->dev, (int64_t)a.B * a.Hkv * a.Skv * a.D, flag, stream) != hipSuccess ||
+                     launch_nonfinite_flag((const float*)bdv->dev, (int64_t)a.B * a.Hkv * a.Skv * a.D, flag, stream) != hipSuccess))
+            return MFA_ERROR_EXECUTION_FAILED;  // dS rounded to fp16: see mfa_quantized_backward
         if (fast && hipMemcpyAsync(&overflow, flag, 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
         if (bdk->download(stream) != hipSuccess || bdv->download(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
         if (hipStreamSynchronize(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
