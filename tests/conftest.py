@@ -21,6 +21,7 @@ GOLDEN = ROOT / "tests" / "golden"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run via gpurun / the driver)")
+    config.addinivalue_line("markers", "no_gpu_init: the test itself must not initialise the GPU in this process (it starts child processes)")
 
 
 @pytest.fixture(scope="session")
@@ -32,7 +33,7 @@ def golden_dir():
 def _rearm_fp16_pv(request):
     """GPU tests start with the bf16 forward on its default arithmetic (fp16 P V): a test that drove V out of fp16's range on
     purpose leaves the in-stream entries on the bf16 P V kernels (sticky by design) -- the next test must not inherit that."""
-    if request.node.get_closest_marker("gpu") is not None:
+    if request.node.get_closest_marker("gpu") is not None and request.node.get_closest_marker("no_gpu_init") is None:
         try:
             import umfa_torch
             umfa_torch.set_option("pv_fp16", os.environ.get("UMFA_PV_FP16", "1"))

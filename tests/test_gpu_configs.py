@@ -191,9 +191,11 @@ def test_config5_long_context_one_shard_S32768_D128():
     check_rows(q, k, v, oc, rows, True, umfa_torch.last_kernel(), "cfg5_shard_causal_bf16O", out_dt=torch.bfloat16)
 
 
-@pytest.mark.parametrize("heads", [3, 6, 12])
+@pytest.mark.parametrize("heads", [1, 2, 3, 6, 12])
 def test_flux_strong_scaling_shards(heads):
-    """The per-rank shards of the strong-scaling leg (bench.py `strong`): the FLUX problem's 24 heads over 8 / 4 / 2 ranks.
+    """The per-rank shards of the strong-scaling leg (bench.py `strong`): the FLUX problem's 24 heads over 8 / 4 / 2 ranks -- and
+    the exact launch shapes of the overlapped form (umfa_torch.parallel.owned_heads deals the heads in two chunks: N = 8 launches
+    2 heads and then 1, N = 4 launches 3 and 3, N = 2 6 and 6).
     Few items per launch: fa_fwd16_w64 cuts every item into a whole number of equal parts (grid = items x floor(CUs / items))
     and folds them; the result must meet the same bounds as the uncut launch, and two launches must agree bit for bit."""
     import umfa_torch

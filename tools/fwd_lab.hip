@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
@@ -24,7 +25,16 @@ using namespace umfa;
     } while (0)
 
 int main(int argc, char** argv) {
-    const uint32_t H = argc > 1 ? atoi(argv[1]) : 24, S = argc > 2 ? atoi(argv[2]) : 4096, D = 128, B = 1;
+#ifndef UMFA_LAB_D
+#define UMFA_LAB_D 128   /* -DUMFA_LAB_D=64 -DUMFA_LAB_CAUSAL=1 -DUMFA_LAB_DMA [-DUMFA_LAB_PV16=1]: BASELINE config 2's kernel (H 16, S 1024, reps, B 4) */
+#endif
+#ifndef UMFA_LAB_CAUSAL
+#define UMFA_LAB_CAUSAL 0
+#endif
+#ifndef UMFA_LAB_PV16
+#define UMFA_LAB_PV16 0
+#endif
+    const uint32_t H = argc > 1 ? atoi(argv[1]) : 24, S = argc > 2 ? atoi(argv[2]) : 4096, D = UMFA_LAB_D, B = argc > 4 ? atoi(argv[4]) : 1;
     const int reps = argc > 3 ? atoi(argv[3]) : 30;
     const size_t n = (size_t)B * H * S * D;
     std::vector<uint16_t> h(n);
@@ -52,7 +62,9 @@ int main(int argc, char** argv) {
     p.B = B; p.H = H; p.Sq = S; p.Skv = S; p.D = D;
     for (auto* s : {p.qs, p.ks, p.vs}) { s[0] = (int64_t)H * S * D; s[1] = (int64_t)S * D; s[2] = D; s[3] = 1; }
     p.os[0] = D; p.os[1] = 1;
-    p.scale = 0.08838834764831845f;
+    p.scale = 1.0f / sqrtf((float)D);
+    p.causal = UMFA_LAB_CAUSAL;
+    p.pv16 = UMFA_LAB_PV16;
     p.in_prec = P_BF16; p.out_prec = P_BF16;
     const uint32_t items = ((S + 127) / 128) * B * H;
     p.n_full = items; p.nsplit = 1;
@@ -65,11 +77,11 @@ int main(int argc, char** argv) {
 #define UMFA_LAB_BN 64
 #endif
 #ifdef UMFA_LAB_DMA
-    auto kfn = fa_fwd16_kernel<__bf16, 128, false, false, __bf16, true, UMFA_LAB_BN>;
+    auto kfn = fa_fwd16_kernel<__bf16, UMFA_LAB_D, UMFA_LAB_CAUSAL != 0, false, __bf16, true, UMFA_LAB_BN, UMFA_LAB_PV16 != 0>;
 #else
-    auto kfn = fa_fwd16_kernel<__bf16, 128, false, false, __bf16, false, UMFA_LAB_BN>;
+    auto kfn = fa_fwd16_kernel<__bf16, UMFA_LAB_D, UMFA_LAB_CAUSAL != 0, false, __bf16, false, UMFA_LAB_BN, UMFA_LAB_PV16 != 0>;
 #endif
-    const size_t lds = 4 * UMFA_LAB_BN * 128 * 2;
+    const size_t lds = 4 * UMFA_LAB_BN * UMFA_LAB_D * 2;
     CK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -105,10 +117,17 @@ int main(int argc, char** argv) {
         }
         printf("mean prologue %.2f us, loop %.2f us, epilogue %.2f us; last end %.2f us; mean in-kernel clock %.3f GHz\n",
                pro / items, loop / items, epi / items, last_end, clk / items);
+        // when do workgroups start / end: deciles of the start and end stamps, and the longest workgroup
+        std::vector<double> st, en, du;
+        for (uint32_t i = 0; i < items; ++i) { st.push_back(us(hd[i * 8])); en.push_back(us(hd[i * 8 + 3])); du.push_back(us(hd[i * 8 + 3]) - us(hd[i * 8])); }
+        std::sort(st.begin(), st.end()); std::sort(en.begin(), en.end()); std::sort(du.begin(), du.end());
+        printf("start us: p0 %.2f p50 %.2f p90 %.2f p100 %.2f | end us: p10 %.2f p50 %.2f p90 %.2f p100 %.2f | duration us: p10 %.2f p50 %.2f p90 %.2f max %.2f\n",
+               st[0], st[items / 2], st[items * 9 / 10], st[items - 1], en[items / 10], en[items / 2], en[items * 9 / 10], en[items - 1],
+               du[items / 10], du[items / 2], du[items * 9 / 10], du[items - 1]);
     }
 #endif
     std::sort(ts.begin(), ts.end());
-    const double fl = 4.0 * B * H * (double)S * S * D;
+    const double fl = 4.0 * B * H * (double)S * S * D * (UMFA_LAB_CAUSAL ? 0.5 : 1.0);
     printf("H=%u S=%u wgs=%u  median %.1f us  min %.1f us  %.1f TFLOP/s (median)\n", H, S, items, ts[ts.size() / 2] * 1e3,
            ts[0] * 1e3, fl / (ts[ts.size() / 2] * 1e-3) / 1e12);
     return 0;

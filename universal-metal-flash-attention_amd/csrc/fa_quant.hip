@@ -186,16 +186,21 @@ __global__ __launch_bounds__(256) void quantize_kernel(QuantParams p) {
             int q[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                int qv = (int)roundf(fast_div ? div_by_block_scale(x[c][j], sc, rcp1) : x[c][j] / sc);
-                q[j] = qv < p.qlo ? p.qlo : (qv > p.qhi ? p.qhi : qv);
+                const float y = fast_div ? div_by_block_scale(x[c][j], sc, rcp1) : x[c][j] / sc;
+                // roundf (half away from zero, the reference's .rounded()) as trunc(y + copysign(nextbelow(0.5), y)): one add and
+                // the truncating convert instead of trunc / sub / compare / select / add -- bit-identical for |y| < 2^22 (checked
+                // exhaustively over every float in [2^-3, 2^9); below that both give 0; |y| <= 127.x here by construction)
+                const float half = __builtin_copysignf(0x1.fffffep-2f, y);
+                const int qv = (int)(y + half);
+                q[j] = max(min(qv, p.qhi), p.qlo);  // v_med3_i32
             }
             if (t < 2) {
-                uint32_t w0 = 0, w1 = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    w0 |= (uint32_t)(uint8_t)(int8_t)q[j] << (8 * j);
-                    w1 |= (uint32_t)(uint8_t)(int8_t)q[4 + j] << (8 * j);
-                }
+                // four int8 per word: two byte permutes + one or (the values are inside int8 already)
+                const uint32_t a0 = __builtin_amdgcn_perm((uint32_t)q[1], (uint32_t)q[0], 0x0c0c0400u);  // {q0.b0, q1.b0, 0, 0}
+                const uint32_t a1 = __builtin_amdgcn_perm((uint32_t)q[3], (uint32_t)q[2], 0x04000c0cu);  // {0, 0, q2.b0, q3.b0}
+                const uint32_t b0 = __builtin_amdgcn_perm((uint32_t)q[5], (uint32_t)q[4], 0x0c0c0400u);
+                const uint32_t b1 = __builtin_amdgcn_perm((uint32_t)q[7], (uint32_t)q[6], 0x04000c0cu);
+                const uint32_t w0 = a0 | a1, w1 = b0 | b1;
                 int8_t* dst = (t == 0 ? p.q8 : p.k8) + (orow0 + r) * p.DPQ + d0;
                 *(uint2*)dst = make_uint2(w0, w1);
             } else {

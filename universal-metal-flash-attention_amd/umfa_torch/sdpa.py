@@ -284,7 +284,13 @@ def scaled_dot_product_attention(query, key, value, attn_mask: Optional[torch.Te
     mask = None
     if attn_mask is not None:
         mask = attn_mask
-        if mask.dtype == torch.bool and mask.numel() > 0 and os.environ.get("UMFA_STRIP_TRUE_MASKS") == "1":
+        # An all-true bool mask is a no-op: strip it and take the unmasked fast path (metal_sdpa_backend.cpp:1771-1784: models such as
+        # Z-Image always pass an encoder mask).  The test is the reference's own -- mask.all().item(), a host synchronisation --
+        # and on by default like there; UMFA_STRIP_TRUE_MASKS=0 keeps the call sync-free (the mask is then read in-tile and its
+        # fully open tiles run without mask reads anyway: same numbers, the 128-row kernel instead of the 256-row one).  Never
+        # while the stream is being captured (a synchronisation would invalidate the capture).
+        if (mask.dtype == torch.bool and mask.numel() > 0 and os.environ.get("UMFA_STRIP_TRUE_MASKS", "1") != "0"
+                and not (mask.is_cuda and torch.cuda.is_current_stream_capturing())):
             if bool(mask.all().item()):
                 _bump("mask_all_true_skipped")
                 mask = None
