@@ -342,7 +342,7 @@ def run_rank(args) -> None:
         gathered_ok = True
         for r_ in (0, world - 1):
             a_, b_, _, _ = parallel.owned_heads(H, world, r_)[0]
-            chk = umfa_torch.attention_forward(q[:, a_:b_], k[:, a_:b_], v[:, a_:b_], causal=args.causal)
+            chk = umfa_torch.attention_forward(q[:, a_:b_], k[:, a_:b_], v[:, a_:b_], causal=args.causal, out_dtype=out.dtype)
             torch.cuda.synchronize()
             gathered_ok = gathered_ok and bool(torch.equal(out[:, a_:b_], chk))
 

@@ -19,8 +19,7 @@
 #include <cstdlib>
 
 #include "fa_common.h"
-#include "fa_fwd_16_kernel.h"
-#include "kernels.h"
+#include "fa_fwd_16_launch.h"
 
 namespace umfa {
 
@@ -91,33 +90,11 @@ FwdSplitPlan fwd_16_split_plan(const FwdParams& p) {
     return plan;
 }
 
-template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT, bool DMA, int BN, bool PV16 = false>
-static hipError_t launch_dma(const FwdParams& pin, hipStream_t stream) {
-    FwdParams p = pin;
-    const uint32_t nqb = (p.Sq + 127) / 128;
-    const uint32_t items = nqb * p.B * p.H;
-    if (p.nsplit < 2 || !p.part_buf || !p.part_cnt) { p.n_full = items; p.nsplit = 1; }
-    const uint32_t grid = p.n_full + (items - p.n_full) * p.nsplit;
-    // (p.part_cnt is zero on entry and on exit: the runtime zeroes a ticket block once, the folding workgroup resets its word)
-    const size_t lds = 4 * BN * DP * 2;
-    auto kfn = fa_fwd16_kernel<T, DP, CAUSAL, HAS_MASK, OUT, DMA, BN, PV16>;
-    if (hipError_t e = ensure_dynamic_lds((const void*)kfn, lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, stream, p);
-    return hipGetLastError();
-}
-
-static bool dma_enabled() { return !tuning().no_dma.load(std::memory_order_relaxed); }
-
 // LDS-DMA staging when head_dim fills the padded row exactly; register staging otherwise.
 template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT>
 static hipError_t launch_one(const FwdParams& p, hipStream_t stream) {
     if constexpr (__is_same(T, __bf16)) {
-        // bf16 operands, fp16 P V (FwdParams::pv16, the default): V tiles go through registers (converted on the way), K keeps
-        // LDS-DMA; 64-key tiles throughout (the 32-key / three-workgroup variant has no room for the V staging registers)
-        if (p.pv16) {
-            if ((int)p.D == DP && dma_enabled()) return launch_dma<T, DP, CAUSAL, HAS_MASK, OUT, true, 64, true>(p, stream);
-            return launch_dma<T, DP, CAUSAL, HAS_MASK, OUT, false, 64, true>(p, stream);
-        }
+        if (p.pv16) return launch_fwd16_pv<DP, CAUSAL, HAS_MASK, OUT>(p, stream);  // bf16 operands, fp16 P V (the default): fa_fwd_16_pv.hip
     }
     if ((int)p.D == DP && dma_enabled()) {
         // 32-key tiles + LDS-DMA at head_dim 128: 166 VGPR / 32 KiB LDS -> three resident workgroups per CU

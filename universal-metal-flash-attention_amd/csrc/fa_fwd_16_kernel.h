@@ -84,16 +84,21 @@ __device__ __forceinline__ unsigned bf16x2_to_f16x2(unsigned x) {
 }
 
 // PV16 (T = bf16 only; FwdParams::pv16, the default bf16 forward): the second product runs in fp16 -- P is rounded to fp16 (11
-// bits instead of bf16's 8: the bf16-input forward inside 1e-3) and V is converted bf16 -> fp16 on its way into LDS: V tiles
-// then always go through registers (buffer_load -> convert -> ds_write), K keeps LDS-DMA where it had it.
-template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT, bool DMA = false, int BN = 64, bool PV16 = false>
+// bits instead of bf16's 8: the bf16-input forward inside 1e-3) and V is fp16:
+//   PV16 = 1  V is converted bf16 -> fp16 on its way into LDS: V tiles then always go through registers (buffer_load ->
+//             convert -> ds_write), K keeps LDS-DMA where it had it.  Short launches (a cast pre-pass would cost more than it saves).
+//   PV16 = 2  p.v already points at an fp16 image of V (the runtime's cast pre-pass, as for fa_fwd16_w64): V staged like K.
+//             Long launches: the conversion is 24 (head_dim 64) ... 48 (128) vector instructions per tile per wave in a kernel
+//             that is vector-bound, and every workgroup repeats it.
+template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT, bool DMA = false, int BN = 64, int PV16 = 0>
 __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_fwd16_kernel(FwdParams p) {
     static_assert(!PV16 || __is_same(T, __bf16), "PV16: bf16 operands");
+    constexpr bool VCONV = PV16 == 1;  // convert V in the kernel
     typedef Mma16<T> M;
     typedef typename M::V8 V8;
-    typedef Mma16<typename std::conditional<PV16, _Float16, T>::type> MP;  // the P V product
+    typedef Mma16<typename std::conditional<PV16 != 0, _Float16, T>::type> MP;  // the P V product
     typedef typename MP::V8 PV8;
-    typedef typename std::conditional<PV16, _Float16, T>::type PT;
+    typedef typename std::conditional<PV16 != 0, _Float16, T>::type PT;
     constexpr int BM = 128;
     constexpr int NKB = BN / 32;            // 32-key blocks per tile
     constexpr int NST = BN / 16;            // 16-key MFMA k-steps of PV per tile
@@ -102,13 +107,19 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
     constexpr int NDB = DP / 32;            // 32-row blocks of O^T
     constexpr int TILE_BYTES = BN * DP * 2;
     constexpr int LPT = BN * NCH / 256;     // 16-byte loads per thread per tile
-    constexpr bool SPLIT_DMA = DMA && (DP == 256 || (DP == 64 && !CAUSAL));
+    // Ring depth of the LDS-DMA staging.  Head dims <= 64: FOUR slots (tile t + 3 is requested while tile t is computed).  A
+    // 64 x 64 tile is ~0.5 us of work for a wave -- less than an L2 / HBM round trip -- so with two slots every tile waited for
+    // its successor: BASELINE config 2 (B4 H16 S1024 D64 causal) sat in s_waitcnt 44 % of its wave cycles with the vector unit
+    // half idle (PMC + in-kernel stamps, profiles/r4/lab_notes.md section 2).  8-KiB tiles make four slots 64 KiB per workgroup:
+    // two workgroups per CU still fit.  Larger head dims keep two (a 128-wide tile is 16 KiB and twice the work).
+    constexpr int NS = (DMA && DP <= 64) ? 4 : 2;
+    constexpr bool SPLIT_DMA = DMA && NS == 2 && (DP == 256 || (DP == 64 && !CAUSAL));
     static_assert(LPT >= 1, "tile too small for 256 threads");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // [K buf0][K buf1][V buf0][V buf1]
+    // [K slot 0 .. NS-1][V slot 0 .. NS-1]
     char* const Kbuf = smem;
-    char* const Vbuf = smem + 2 * TILE_BYTES;
+    char* const Vbuf = smem + NS * TILE_BYTES;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, ql = lane & 31, hi = lane >> 5;
 #ifdef UMFA_LAB_STAMPS
@@ -189,7 +200,7 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
 
     // ---- tile staging (register path): thread owns chunks c = tid + 256 i  ->  (row, ch); offsets are tile-invariant
     constexpr int LPTR = DMA ? 1 : LPT;
-    constexpr bool VREG = !DMA || PV16;      // V tiles through registers
+    constexpr bool VREG = !DMA;               // V tiles through registers (DMA + VCONV: converted in place in LDS, below)
     constexpr int LPTV = VREG ? LPT : 1;
     int koff[LPTR], voff[LPTV], klds[LPTR], vlds[LPTV];
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -240,7 +251,7 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
         lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((LDS_AS char*)smem) + uw * IPW * 1024);
         // rows past Skv are range-checked away by the hardware; start from zeros so they can never hold NaNs
 #pragma unroll
-        for (int i = 0; i < 4 * TILE_BYTES / 4096; ++i) *(i32x4*)(smem + i * 4096 + tid * 16) = i32x4{0, 0, 0, 0};
+        for (int i = 0; i < 2 * NS * TILE_BYTES / 4096; ++i) *(i32x4*)(smem + i * 4096 + tid * 16) = i32x4{0, 0, 0, 0};
         __syncthreads();
     }
     // which: 1 = K tile, 2 = V tile, 3 = both.  SPLIT_DMA: the V half is issued behind the QK^T MFMAs instead of back
@@ -250,23 +261,15 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
     auto stage_load = [&](uint32_t t, int which = 3) {
         if constexpr (DMA) {
             const int ktile = (int)(t * BN) * k_stride_b, vtile = (int)(t * BN) * v_stride_b;
-            const unsigned kdst = lds_wave + (t & 1) * TILE_BYTES, vdst = kdst + 2 * TILE_BYTES;
+            const unsigned kdst = lds_wave + (t % NS) * TILE_BYTES, vdst = kdst + NS * TILE_BYTES;
 #pragma unroll
             for (int j = 0; j < IPW; ++j) {
                 if (which & 1)
                     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
                                  ::"s"(kdst + j * 1024), "v"(kdma[j] + ktile), "s"(k_srd) : "memory");
-                if constexpr (!PV16) {
-                    if (which & 2)
-                        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-                                     ::"s"(vdst + j * 1024), "v"(vdma[j] + vtile), "s"(v_srd) : "memory");
-                }
-            }
-            if constexpr (PV16) {
-                if (which & 2) {
-#pragma unroll
-                    for (int i = 0; i < LPT; ++i) vreg[i] = __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, voff[i] + vtile, 0, 0);
-                }
+                if (which & 2)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                                 ::"s"(vdst + j * 1024), "v"(vdma[j] + vtile), "s"(v_srd) : "memory");
             }
         } else {
             const int ksoff = (int)(t * BN) * k_stride_b, vsoff = (int)(t * BN) * v_stride_b;
@@ -278,25 +281,34 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
             }
         }
     };
-    auto stage_write = [&](int buf) {
+    auto stage_write = [&](int buf, bool first = false) {
         if constexpr (DMA) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's LDS-DMA has landed (then the barrier)
+            // this wave's LDS-DMA of the tile in slot `buf` has landed (then the barrier).  The counter runs in issue order: the
+            // NS - 2 tiles requested after it (2 IPW instructions each) may stay in flight -- except in the prologue (`first`),
+            // which drains everything once so that the compiler's own scoreboard (the Q fragment loads) is empty when the loop starts
+            if (NS == 2 || first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * 2 * IPW) : "memory");
             // the same wait as a builtin keeps hipcc's scoreboard empty too: it cannot see the LDS-DMA loads, and with
             // the Q fragment loads (issued before the loop, first used inside it) still "pending" in its model it put
             // s_waitcnt vmcnt(3) ... vmcnt(0) in front of the first MFMAs of every tile -- right behind the issue of
             // the next tile's LDS-DMA, i.e. every tile waited for its successor's prefetch (tools/trace_waits.py)
-            __builtin_amdgcn_s_waitcnt(0x0F70);
-            if constexpr (PV16) {
+            if (NS == 2 || first) __builtin_amdgcn_s_waitcnt(0x0F70);
+            if constexpr (VCONV) {
+                // bf16 -> fp16 IN PLACE (both are 16-bit): every wave converts the quarter of the V tile its own LDS-DMA
+                // instructions filled (lane l of instruction j owns 16 bytes at (wave IPW + j) KiB + 16 l), so the vmcnt wait
+                // above is all the ordering it needs; the barrier that follows publishes the converted tile
+                char* const vq = Vbuf + buf * TILE_BYTES + (wave * IPW) * 1024 + lane * 16;
 #pragma unroll
-                for (int i = 0; i < LPT; ++i)
-                    *(u32x4*)(Vbuf + buf * TILE_BYTES + vlds[i]) = u32x4{bf16x2_to_f16x2(vreg[i][0]), bf16x2_to_f16x2(vreg[i][1]),
-                                                                         bf16x2_to_f16x2(vreg[i][2]), bf16x2_to_f16x2(vreg[i][3])};
+                for (int j = 0; j < IPW; ++j) {
+                    const u32x4 r = *(const u32x4*)(vq + j * 1024);
+                    *(u32x4*)(vq + j * 1024) = u32x4{bf16x2_to_f16x2(r[0]), bf16x2_to_f16x2(r[1]), bf16x2_to_f16x2(r[2]), bf16x2_to_f16x2(r[3])};
+                }
             }
         } else {
 #pragma unroll
             for (int i = 0; i < LPT; ++i) {
                 *(u32x4*)(Kbuf + buf * TILE_BYTES + klds[i]) = kreg[i];
-                if constexpr (PV16)
+                if constexpr (VCONV)
                     *(u32x4*)(Vbuf + buf * TILE_BYTES + vlds[i]) = u32x4{bf16x2_to_f16x2(vreg[i][0]), bf16x2_to_f16x2(vreg[i][1]),
                                                                          bf16x2_to_f16x2(vreg[i][2]), bf16x2_to_f16x2(vreg[i][3])};
                 else
@@ -392,15 +404,16 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
         t_end = hi1 < t_end ? hi1 : t_end;
         if (t_end < t_begin) t_end = t_begin;
     }
-    stage_load(t_begin);
-    stage_write(t_begin & 1);
+#pragma unroll
+    for (int i = 0; i < NS - 1; ++i) stage_load(t_begin + i);  // (tiles past the end: all zeros, same instruction count)
+    stage_write(t_begin % NS, true);
     __syncthreads();
 #ifdef UMFA_LAB_STAMPS
     stamp[1] = __builtin_amdgcn_s_memrealtime();
 #endif
 
     for (uint32_t t = t_begin; t < t_end; ++t) {
-        const int cur = t & 1;
+        const int cur = t % NS;
         const char* Kt = Kbuf + cur * TILE_BYTES;
         const char* Vt = Vbuf + cur * TILE_BYTES;
         const uint32_t key_base = t * BN;
@@ -424,7 +437,7 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
 #ifndef UMFA_ABL_NO_LOAD
         // next tile in flight under this tile's MFMAs (T14); past the end: all zeros.  SPLIT_DMA: only the K half
         // here, the V half behind the QK^T MFMAs of an active tile
-        stage_load(t + 1, (SPLIT_DMA && active) ? 1 : 3);
+        stage_load(t + NS - 1, (SPLIT_DMA && active) ? 1 : 3);
 #endif
 
         if (active) {
@@ -447,7 +460,7 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
 #ifndef UMFA_ABL_NO_LOAD
             if constexpr (SPLIT_DMA) {
                 __builtin_amdgcn_sched_barrier(0);
-                stage_load(t + 1, 2);
+                stage_load(t + NS - 1, 2);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #endif
@@ -585,7 +598,7 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
         }
 
 #ifndef UMFA_ABL_NO_LOAD
-        stage_write(cur ^ 1);
+        stage_write((t + 1) % NS);
 #endif
 #ifndef UMFA_ABL_NO_BARRIER
         __syncthreads();
@@ -659,8 +672,8 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
         }
     }
     const float inv = lt > 0.0f ? 1.0f / lt : 0.0f;
-    if constexpr (PV16) {
-        // fp16 image of V (fa_fwd16_w64_kernel.inc has the same check): a value beyond fp16's range went in as +-inf and made its
+    if constexpr (VCONV) {
+        // fp16 image of V made here (the cast pre-pass of the other forms checks V itself): a value beyond fp16's range went in as +-inf and made its
         // O columns inf / NaN; a wave whose outputs are all below 2^-11 may have met values of V that are not exact in fp16
         if (p.status) {
             float chk_nan = 0.0f, chk_max = 0.0f;

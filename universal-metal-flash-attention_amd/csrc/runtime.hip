@@ -123,6 +123,18 @@ hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p,
         return hipErrorNotSupported;  // only the 256-row kernel rotates Q in registers (the entry asks before it sets this)
     } else if (lowp && fwd_16_supported(p)) {
         FwdParams pp = pv;
+        if (pp.pv16 && (size_t)p.B * p.H * p.Skv * p.D * 2 >= ((size_t)16 << 20)) {
+            // the 128-row kernel converts V in-kernel (24 ... 48 vector instructions per tile per wave in a vector-bound kernel, repeated
+            // by every workgroup): right for short launches, where a pre-pass costs its launch; from 16 MB of V on the HBM-speed cast
+            // pass is cheaper (FLUX-size masked calls: ~11 us against ~15 % of the kernel).  Without a block (capture): in-kernel.
+            void* v16 = sc.v16.ensure((size_t)p.B * p.H * p.Skv * p.D * 2 + 256, stream);
+            if (v16) {
+                if ((e = launch_cast_rows_bf16_to_f16(p.v, p.vs, v16, p.B, p.H, p.Skv, p.D, pv.status, stream)) != hipSuccess) return e;
+                pp.v = v16;
+                pp.vs[0] = (int64_t)p.H * p.Skv * p.D; pp.vs[1] = (int64_t)p.Skv * p.D; pp.vs[2] = p.D; pp.vs[3] = 1;
+                pp.pv16 = 2;
+            }
+        }
         const FwdSplitPlan plan = fwd_16_split_plan(p);
         if (plan.nsplit > 1) {
             // tickets first (16-byte multiple at the allocation start), partials behind them
