@@ -438,6 +438,32 @@ def run_rank(args) -> None:
         _flux_regime("cfg3_flux_bf16_pvbf16_lazy", torch.bfloat16, pv_fp16=0)
         _flux_regime("cfg3_flux_bf16_pvbf16_exact", torch.bfloat16, pv_fp16=0, softmax_reference="exact")
         _flux_regime("cfg3_flux_fp16", torch.float16)
+        # mask tensors at the FLUX shape (the north-star's "arbitrary-mask tile early-exit"): key padding [1,1,1,S] and a
+        # block-diagonal mask [1,1,S,S] (four documents of 1024 tokens) -- the 128-row kernel with the tile-flag pre-pass (fully
+        # masked tiles skipped, fully open ones without mask reads); rel on fp32 O against the oracle WITH the mask, row subset
+        import numpy as _np
+        from oracle import oracle as _orc
+        _i = torch.arange(S, device=dev)
+        _masks = {"cfg3_flux_bf16_mask_padding": ((_i < 3000)[None, None, None, :]).contiguous(),
+                  "cfg3_flux_bf16_mask_blockdiag": ((_i[:, None] // 1024) == (_i[None, :] // 1024))[None, None].contiguous()}
+        for _name, _m in _masks.items():
+            fo = torch.empty(B, H, S, D, device=dev, dtype=torch.float32)
+            tg = graph_ms(lambda: umfa_torch.attention_forward(q, k, v, mask=_m, out=fo), 20)
+            kn = umfa_torch.last_kernel()
+            umfa_torch.attention_forward(q, k, v, mask=_m, out=fo)
+            torch.cuda.synchronize()
+            rows = _par.sample_rows(S)
+            mrows = _np.ascontiguousarray(_np.broadcast_to(_m[0, 0].cpu().numpy()[rows if _m.shape[2] > 1 else [0] * len(rows)], (len(rows), S)))
+            ref = _orc.sdpa_forward(_np.ascontiguousarray(_par.bits(q)[:, :, rows]), _par.bits(k), _par.bits(v), mask=mrows,
+                                    mask_type=_orc.MASK_BOOL).astype(_np.float64)
+            dd = fo[:, :, rows].cpu().numpy().astype(_np.float64) - ref
+            vis = float(_m.float().mean().item())  # fraction of (row, key) pairs that attend: the work a skipping kernel has to do
+            configs[_name] = {"ms": round(tg, 5), "kernel": kn, "visible_fraction": round(vis, 4),
+                              "tflops_of_visible_work": round(FLOPS_PER_STEP * vis / tg / 1e9, 1),
+                              "frac_of_visible_work": round(FLOPS_PER_STEP * vis / tg / 1e9 / PEAK_BF16_TFLOPS, 4),
+                              "rel": float(_np.abs(dd).max() / _np.abs(ref).max()), "fp32_out": True,
+                              "mask": {"cfg3_flux_bf16_mask_padding": "bool [1,1,1,S], keys < 3000 attend", "cfg3_flux_bf16_mask_blockdiag": "bool [1,1,S,S], four blocks of 1024"}[_name]}
+            del fo
         o3, lse3 = umfa_torch.attention_forward(q, k, v, return_lse=True)
         do3 = torch.randn_like(q)
         tb_e = med(event_ms(lambda: umfa_torch.attention_backward(do3, q, k, v, o3, lse3, scale=D ** -0.5), 20))

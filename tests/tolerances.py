@@ -67,7 +67,10 @@ def fam(kernel: str) -> str:
 
 
 def regime_of(kernel: str) -> str:
-    """"exact": the kernel's softmax reference is the exact running max; "stale": fa_fwd16_w64 in its lazy / deferred modes."""
+    """"exact": the kernel's softmax reference is the exact running max; "stale": fa_fwd16_w64 in its lazy / deferred modes and, since
+    round 4, the 128-row fa_fwd16 (deferred reference, tau = 6: fa_fwd_16_kernel.h)."""
+    if kernel.startswith("fa_fwd16<"):
+        return "stale"
     if not kernel.startswith("fa_fwd16_w64"):
         return "exact"
     try:  # the LIBRARY's live values (they may have been seeded from the environment: UMFA_W64_TAU, UMFA_W64_LAZY)

@@ -81,11 +81,7 @@ int main(int argc, char** argv) {
 #else
     auto kfn = fa_fwd16_kernel<__bf16, UMFA_LAB_D, UMFA_LAB_CAUSAL != 0, false, __bf16, false, UMFA_LAB_BN, UMFA_LAB_PV16 != 0>;
 #endif
-#ifdef UMFA_LAB_DMA
-    const size_t lds = (size_t)(UMFA_LAB_D <= 64 ? 8 : 4) * UMFA_LAB_BN * UMFA_LAB_D * 2;  // ring depth 4 at head_dim <= 64 (fa_fwd_16_kernel.h NS)
-#else
     const size_t lds = 4 * UMFA_LAB_BN * UMFA_LAB_D * 2;
-#endif
     CK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));

@@ -107,12 +107,11 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
     constexpr int NDB = DP / 32;            // 32-row blocks of O^T
     constexpr int TILE_BYTES = BN * DP * 2;
     constexpr int LPT = BN * NCH / 256;     // 16-byte loads per thread per tile
-    // Ring depth of the LDS-DMA staging.  Head dims <= 64: FOUR slots (tile t + 3 is requested while tile t is computed).  A
-    // 64 x 64 tile is ~0.5 us of work for a wave -- less than an L2 / HBM round trip -- so with two slots every tile waited for
-    // its successor: BASELINE config 2 (B4 H16 S1024 D64 causal) sat in s_waitcnt 44 % of its wave cycles with the vector unit
-    // half idle (PMC + in-kernel stamps, profiles/r4/lab_notes.md section 2).  8-KiB tiles make four slots 64 KiB per workgroup:
-    // two workgroups per CU still fit.  Larger head dims keep two (a 128-wide tile is 16 KiB and twice the work).
-    constexpr int NS = (DMA && DP <= 64) ? 4 : 2;
+    // Ring depth of the LDS-DMA staging (the code below is written for any depth: tile t + NS - 1 is requested while tile t is
+    // computed, waits leave the NS - 2 younger tiles in flight).  TWO: round 4 measured four slots at head_dim 64 (config 2 sits
+    // in waits 44 % of its wave cycles) -- in-kernel stamps 21.2 vs 21.4 us per launch, kernel time unchanged: the waits are not
+    // the successor tile's latency, the two waves of a SIMD queue for its vector unit (profiles/r4/lab_notes.md section 2).
+    constexpr int NS = 2;
     constexpr bool SPLIT_DMA = DMA && NS == 2 && (DP == 256 || (DP == 64 && !CAUSAL));
     static_assert(LPT >= 1, "tile too small for 256 threads");
 
@@ -548,10 +547,18 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
                 mx *= c2;  // scale > 0 on this path
             }
             mx = max_xor32(mx);
-            const float m_new = fmaxf(m, mx);
-            const float m_use = (HAS_MASK && m_new == -INFINITY) ? 0.0f : m_new;
-            if (!__all(m_new == m)) {
-                const float alpha = __builtin_amdgcn_exp2f(m - m_use);
+            // Deferred reference (round 4; the one-wave-per-SIMD kernels' "deferred" policy, tau = 6): a row's reference moves
+            // only when this tile's max exceeds it by more than 2^tau -- P <= 64 fits fp16 and bf16 alike, the row sums are
+            // fp32 -- so after a row's first tile the 36 rescale multiplies (O^T, l) run almost never instead of on nearly every
+            // tile of a short causal sweep.  This kernel is vector-bound (config 2: 267 vector instructions per 16 MFMAs).
+            // A row that has seen no key yet has m = -inf: its first finite max always moves it.
+            constexpr float TAU16 = 6.0f;
+            const bool move = mx > m + TAU16;
+            float m_use = (HAS_MASK && m == -INFINITY) ? 0.0f : m;
+            if (__any(move)) {
+                const float m_new = move ? mx : m;
+                m_use = (HAS_MASK && m_new == -INFINITY) ? 0.0f : m_new;
+                const float alpha = __builtin_amdgcn_exp2f(m - m_use);  // exactly 1 for the rows that stay
 #pragma unroll
                 for (int j = 0; j < 4; ++j) l4[j] *= alpha;
 #pragma unroll

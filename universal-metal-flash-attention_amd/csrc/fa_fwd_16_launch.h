@@ -14,7 +14,7 @@ static inline hipError_t launch_dma(const FwdParams& pin, hipStream_t stream) {
     if (p.nsplit < 2 || !p.part_buf || !p.part_cnt) { p.n_full = items; p.nsplit = 1; }
     const uint32_t grid = p.n_full + (items - p.n_full) * p.nsplit;
     // (p.part_cnt is zero on entry and on exit: the runtime zeroes a ticket block once, the folding workgroup resets its word)
-    const size_t lds = (size_t)(DMA && DP <= 64 ? 8 : 4) * BN * DP * 2;  // 2 x ring depth tiles (fa_fwd_16_kernel.h NS)
+    const size_t lds = 4 * BN * DP * 2;  // 2 x ring depth (fa_fwd_16_kernel.h NS = 2) tiles
     auto kfn = fa_fwd16_kernel<T, DP, CAUSAL, HAS_MASK, OUT, DMA, BN, PV16>;
     if (hipError_t e = ensure_dynamic_lds((const void*)kfn, lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, stream, p);

@@ -18,6 +18,8 @@
 #include <climits>
 #include <cstring>
 
+#include <type_traits>
+
 #include "fa_common.h"
 #include "kernels.h"
 
@@ -75,11 +77,16 @@ __device__ __forceinline__ float div_by_block_scale(float a, float b, float r1) 
     return __builtin_fmaf(e2, r1, q1);
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void quantize_kernel(QuantParams p) {
+// IN16: 16-bit inputs stay PACKED in registers (4 per 8-element chunk instead of 8 floats) and are decoded where they are used
+// (twice: absmax, then quantise).  The pass is latency-bound, not vector-bound -- round 4 took a quarter of its vector
+// instructions out (rounding / clamp / pack) and it stayed at 40 us, round 3 the same with the division -- so registers are
+// worth more than instructions: 32 instead of 64 data registers doubles the resident workgroups and the bytes in flight per CU.
+template <int MODE, bool IN16>
+__global__ __launch_bounds__(256, IN16 ? 8 : 4) void quantize_kernel(QuantParams p) {  // 16-bit inputs: <= 64 registers, 8 workgroups per CU
     __shared__ float red[4];
     __shared__ __attribute__((aligned(16))) unsigned char v8img[8192];
     constexpr int MAXC = 8;  // chunks per thread: 64 rows * (256 / 8) chunks / 256 threads
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     uint32_t id = blockIdx.x;
     int t = 0;
     while (t < 2 && id >= p.BH * p.nblk[t]) { id -= p.BH * p.nblk[t]; ++t; }
@@ -90,30 +97,38 @@ __global__ __launch_bounds__(256) void quantize_kernel(QuantParams p) {
     const uint32_t cpr = p.D / 8;           // chunks per row (D % 8 == 0)
     const uint32_t nchunks = nrows * cpr;   // <= 2048
     const int tid = threadIdx.x;
+    const bool is_bf16 = p.in_prec == P_BF16;
 
-    float x[MAXC][8];
+    typename std::conditional<IN16, u32x4, f32x4>::type xr[MAXC][IN16 ? 1 : 2];
+    auto X = [&](int c, int j) -> float {  // element j of chunk c
+        if constexpr (IN16) {
+            const unsigned w = xr[c][0][j >> 1];
+            if (is_bf16) return __uint_as_float((j & 1) ? (w & 0xffff0000u) : (w << 16));
+            return (float)__builtin_bit_cast(_Float16, (uint16_t)((j & 1) ? (w >> 16) : (w & 0xffffu)));
+        } else {
+            return xr[c][j >> 2][j & 3];
+        }
+    };
     float amax = 0.0f;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
         const uint32_t ch = tid + 256 * c;
         if (ch < nchunks) {
             const int64_t e0 = base + (int64_t)ch * 8;
-            if (p.in_prec == P_FP32) {
-                const f32x4 lo = *(const f32x4*)((const float*)p.src[t] + e0);
-                const f32x4 hi = *(const f32x4*)((const float*)p.src[t] + e0 + 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { x[c][j] = lo[j]; x[c][4 + j] = hi[j]; }
-            } else if (p.in_prec == P_FP16) {
-                const f16x8 raw = *(const f16x8*)((const _Float16*)p.src[t] + e0);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) x[c][j] = (float)raw[j];
+            if constexpr (IN16) {
+                xr[c][0] = *(const u32x4*)((const uint16_t*)p.src[t] + e0);
             } else {
-                const s16x8 raw = *(const s16x8*)((const uint16_t*)p.src[t] + e0);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) x[c][j] = bf16_bits_to_float((uint16_t)raw[j]);
+                xr[c][0] = *(const f32x4*)((const float*)p.src[t] + e0);
+                xr[c][1] = *(const f32x4*)((const float*)p.src[t] + e0 + 4);
             }
+        }
+    }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(x[c][j]));
+    for (int c = 0; c < MAXC; ++c) {
+        const uint32_t ch = tid + 256 * c;
+        if (ch < nchunks) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(X(c, j)));
         }
     }
     float sc;
@@ -156,7 +171,7 @@ __global__ __launch_bounds__(256) void quantize_kernel(QuantParams p) {
                 const int r = (int)(ch / cpr), d0 = (int)(ch % cpr) * 8;
 #pragma unroll
                 for (int j = 0; j < 8; j += 2) {
-                    const unsigned w = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(x[c][j] * inv, x[c][j + 1] * inv, 0, false);
+                    const unsigned w = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(X(c, j) * inv, X(c, j + 1) * inv, 0, false);
                     v8img[v8_off(r, d0 + j)] = (unsigned char)(w & 0xff);
                     v8img[v8_off(r, d0 + j + 1)] = (unsigned char)((w >> 8) & 0xff);
                 }
@@ -186,7 +201,8 @@ __global__ __launch_bounds__(256) void quantize_kernel(QuantParams p) {
             int q[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float y = fast_div ? div_by_block_scale(x[c][j], sc, rcp1) : x[c][j] / sc;
+                const float xv = X(c, j);
+                const float y = fast_div ? div_by_block_scale(xv, sc, rcp1) : xv / sc;
                 // roundf (half away from zero, the reference's .rounded()) as trunc(y + copysign(nextbelow(0.5), y)): one add and
                 // the truncating convert instead of trunc / sub / compare / select / add -- bit-identical for |y| < 2^22 (checked
                 // exhaustively over every float in [2^-3, 2^9); below that both give 0; |y| <= 127.x here by construction)
@@ -589,13 +605,17 @@ hipError_t launch_quantize(const void* q, const void* k, const void* v, int in_p
         qp.v_e8 = (uint32_t*)(ws + w.sv + (size_t)align256(qp.BH * qp.nblk[2] * 4));
     }
     if (quant_mode == 3) quant_mode = 2;
+    const bool in16 = in_prec != P_FP32;
     if (quant_mode == 2) {
-        hipLaunchKernelGGL(quantize_kernel<2>, dim3(grid), dim3(256), 0, stream, qp);
+        if (in16) hipLaunchKernelGGL((quantize_kernel<2, true>), dim3(grid), dim3(256), 0, stream, qp);
+        else hipLaunchKernelGGL((quantize_kernel<2, false>), dim3(grid), dim3(256), 0, stream, qp);
     } else {
-        hipLaunchKernelGGL(quantize_kernel<0>, dim3(grid), dim3(256), 0, stream, qp);
+        if (in16) hipLaunchKernelGGL((quantize_kernel<0, true>), dim3(grid), dim3(256), 0, stream, qp);
+        else hipLaunchKernelGGL((quantize_kernel<0, false>), dim3(grid), dim3(256), 0, stream, qp);
         hipLaunchKernelGGL(tensor_scale_kernel, dim3(3), dim3(256), 0, stream, qp.scale[0], qp.BH * qp.nblk[0],
                            qp.scale[1], qp.BH * qp.nblk[1], qp.scale[2], qp.BH * qp.nblk[2], qp.qmax);
-        hipLaunchKernelGGL(quantize_kernel<1>, dim3(grid), dim3(256), 0, stream, qp);
+        if (in16) hipLaunchKernelGGL((quantize_kernel<1, true>), dim3(grid), dim3(256), 0, stream, qp);
+        else hipLaunchKernelGGL((quantize_kernel<1, false>), dim3(grid), dim3(256), 0, stream, qp);
     }
     if (views) {
         views->q8 = qp.q8; views->k8 = qp.k8; views->v16 = qp.v16;
