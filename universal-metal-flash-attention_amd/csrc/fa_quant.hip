@@ -80,9 +80,11 @@ __device__ __forceinline__ float div_by_block_scale(float a, float b, float r1) 
 // IN16: 16-bit inputs stay PACKED in registers (4 per 8-element chunk instead of 8 floats) and are decoded where they are used
 // (twice: absmax, then quantise).  The pass is latency-bound, not vector-bound -- round 4 took a quarter of its vector
 // instructions out (rounding / clamp / pack) and it stayed at 40 us, round 3 the same with the division -- so registers are
-// worth more than instructions: 32 instead of 64 data registers doubles the resident workgroups and the bytes in flight per CU.
+// cheap: 74 instead of 104 registers, 6 instead of 4 resident workgroups per CU.  (It did not move the pass either -- 40.1 us, also
+// with 8 workgroups per CU forced at the price of 11 spills: 126 MB at 3.15 TB/s against 4.6 TB/s for the one-phase V cast pass.
+// What is left is the two-phase shape itself: load a block, reduce its absmax across the workgroup, only then convert and store.)
 template <int MODE, bool IN16>
-__global__ __launch_bounds__(256, IN16 ? 8 : 4) void quantize_kernel(QuantParams p) {  // 16-bit inputs: <= 64 registers, 8 workgroups per CU
+__global__ __launch_bounds__(256) void quantize_kernel(QuantParams p) {
     __shared__ float red[4];
     __shared__ __attribute__((aligned(16))) unsigned char v8img[8192];
     constexpr int MAXC = 8;  // chunks per thread: 64 rows * (256 / 8) chunks / 256 threads
