@@ -1,0 +1,146 @@
+"""Bool mask tensors on the one-wave-per-SIMD forward (fa_fwd16_w64<., 128, mask>, round 4): the runtime re-packs the caller's mask
+(any <= 4-D broadcastable bool tensor with its own strides) into per-lane bit words, per-wave tile classes and the visited-tile list
+of every 256-row block (fa_aux.hip mask_pack_kernel / mask_list_kernel); the kernel sweeps the list.  Semantics are the
+reference's (MFABridge.swift:157-242: non-zero attends, size-1 dims broadcast, a row with every key masked gives O = 0,
+LSE = -inf), checked against the CPU oracle WITH the mask, against the 128-row kernel (option no_w64_mask) and for run-to-run
+bitwise repeatability."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from tolerances import check_forward  # noqa: E402
+
+
+def _oracle():
+    from oracle import oracle
+    return oracle
+
+
+def bits(t):
+    return t.cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def npy(t):
+    return bits(t) if t.dtype == torch.bfloat16 else t.cpu().contiguous().numpy()
+
+
+def _mask(kind, B, H, Sq, Skv, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    i = torch.arange(Sq, device="cuda")[:, None]
+    j = torch.arange(Skv, device="cuda")[None, :]
+    if kind == "random_per_head":
+        m = torch.rand(B, H, Sq, Skv, device="cuda", generator=g) < 0.7
+        m[..., 0] = True
+        return m
+    if kind == "random_2d":
+        m = torch.rand(Sq, Skv, device="cuda", generator=g) < 0.5
+        m[:, 3] = True
+        return m
+    if kind == "padding":                      # [B, 1, 1, Skv]: per-batch key padding
+        lens = torch.tensor([max(1, Skv - 37 - 211 * b) for b in range(B)], device="cuda")
+        return (j[None] < lens[:, None, None])[:, None]
+    if kind == "blockdiag":                    # [1, 1, Sq, Skv]: documents of 192 rows / 160 keys (not on the tile grid)
+        return ((i // 192) == (j // 160))[None, None]
+    if kind == "all_open":
+        return torch.ones(1, 1, Sq, Skv, dtype=torch.bool, device="cuda")
+    if kind == "empty_rows_and_blocks":        # rows 5.., a whole 256-row block and a whole head see nothing
+        m = torch.rand(B, H, Sq, Skv, device="cuda", generator=g) < 0.6
+        m[:, :, 5::17] = False
+        m[:, 0, 256:512] = False
+        if H > 1:
+            m[:, 1] = False
+        return m
+    if kind == "strided_view":                 # a non-contiguous mask: every second column of a wider tensor
+        wide = torch.rand(B, 1, Sq, 2 * Skv, device="cuda", generator=g) < 0.6
+        wide[..., 0] = True
+        return wide[..., ::2]
+    raise ValueError(kind)
+
+
+KINDS = ["random_per_head", "random_2d", "padding", "blockdiag", "all_open", "empty_rows_and_blocks", "strided_view"]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape", [(2, 2, 512, 512), (1, 3, 1280, 777)])
+def test_w64_mask_tensor_vs_oracle(kind, dt, shape, umfa_opts):
+    import umfa_torch
+    umfa_opts(force_w64=1)
+    B, H, Sq, Skv = shape
+    torch.manual_seed(Sq + Skv)
+    q = torch.randn(B, H, Sq, 128, device="cuda", dtype=dt)
+    k = torch.randn(B, H, Skv, 128, device="cuda", dtype=dt)
+    v = torch.randn(B, H, Skv, 128, device="cuda", dtype=dt)
+    m = _mask(kind, B, H, Sq, Skv, seed=Sq)
+    o, lse = umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32, return_lse=True)
+    kern = umfa_torch.last_kernel()
+    assert kern in ("fa_fwd16_w64<bf16,128,pv16,mask>", "fa_fwd16_w64<fp16,128,mask>"), kern
+    mfull = m.expand(B, H, Sq, Skv) if m.dim() == 4 else m.expand(Sq, Skv)
+    ref, ref_lse = _oracle().sdpa_forward(npy(q), npy(k), npy(v), mask=np.ascontiguousarray(mfull.cpu().numpy()),
+                                          mask_type=_oracle().MASK_BOOL, return_lse=True)
+    on = o.cpu().numpy()
+    assert np.isfinite(on).all()
+    check_forward(on, ref, dt, kern, f"w64_mask_{kind}")
+    dead = ~mfull.expand(B, H, Sq, Skv).any(-1).cpu().numpy() if m.dim() == 4 else np.broadcast_to(~mfull.any(-1).cpu().numpy(), (B, H, Sq))
+    ln = lse.cpu().numpy().reshape(B, H, Sq)
+    assert (on[dead] == 0).all() and np.isneginf(ln[dead]).all()          # rows that see no key: O = 0, LSE = -inf
+    assert np.abs(ln[~dead] - ref_lse[~dead]).max() < 2e-2
+    # bitwise repeatable, and the same numbers class as the 128-row kernel's tile-flag path
+    o2 = umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32)
+    assert torch.equal(o, o2)
+    with umfa_torch.options(no_w64_mask=1, force_w64=0):
+        o3 = umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32)
+        assert umfa_torch.last_kernel().startswith("fa_fwd16<"), umfa_torch.last_kernel()
+    assert float((o - o3).abs().max()) <= 2.0 ** -9 * float(o3.abs().max())
+    # 16-bit output epilogue
+    o16 = umfa_torch.attention_forward(q, k, v, mask=m)
+    assert o16.dtype == dt and float((o16.float() - o).abs().max()) <= 2.0 ** -8 * float(o.abs().max()) * 1.01
+
+
+@pytest.mark.parametrize("kind", ["padding", "blockdiag"])
+def test_w64_mask_flux_shape_rows(kind, umfa_opts):
+    """the bench's masked FLUX entries (B1 H24 S4096 D128): default routing takes the mask kernel (384 items >= the CU count),
+    rows against the oracle with the mask, inside the north-star's 1e-3"""
+    import umfa_torch
+    umfa_opts(force_w64=0)
+    from oracle import parity
+    B, H, S, D = 1, 24, 4096, 128
+    torch.manual_seed(5)
+    q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    i = torch.arange(S, device="cuda")
+    m = (i < 3000)[None, None, None, :].contiguous() if kind == "padding" else ((i[:, None] // 1024) == (i[None, :] // 1024))[None, None].contiguous()
+    o = umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32)
+    assert umfa_torch.last_kernel() == "fa_fwd16_w64<bf16,128,pv16,mask>", umfa_torch.last_kernel()
+    rows = parity.sample_rows(S)
+    mrows = np.ascontiguousarray(np.broadcast_to(m[0, 0].cpu().numpy()[rows if m.shape[2] > 1 else [0] * len(rows)], (len(rows), S)))
+    ref = _oracle().sdpa_forward(np.ascontiguousarray(bits(q)[:, :, rows]), bits(k), bits(v), mask=mrows, mask_type=_oracle().MASK_BOOL)
+    err = float(np.abs(o[:, :, rows].cpu().numpy() - ref).max() / np.abs(ref).max())
+    assert err < 1.0e-3, err
+    assert torch.equal(o, umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32))
+
+
+def test_w64_mask_routing_gate(umfa_opts):
+    """few items (fewer 256-row blocks than CUs), additive masks, causal + mask, head_dim 64 and bf16 P V stay on the 128-row kernel"""
+    import umfa_torch
+    umfa_opts(force_w64=0)
+    torch.manual_seed(1)
+    q, k, v = (torch.randn(1, 4, 512, 128, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    mb = torch.rand(1, 1, 512, 512, device="cuda") < 0.5
+    mb[..., 0] = True
+    umfa_torch.attention_forward(q, k, v, mask=mb)
+    assert umfa_torch.last_kernel().startswith("fa_fwd16<"), umfa_torch.last_kernel()     # 8 items
+    umfa_opts(force_w64=1)
+    umfa_torch.attention_forward(q, k, v, mask=mb)
+    assert umfa_torch.last_kernel().endswith(",mask>")
+    umfa_torch.attention_forward(q, k, v, mask=mb, causal=True)
+    assert umfa_torch.last_kernel().startswith("fa_fwd16<")
+    umfa_torch.attention_forward(q, k, v, mask=torch.zeros(1, 1, 512, 512, device="cuda"))
+    assert umfa_torch.last_kernel().startswith("fa_fwd16<")
+    with umfa_torch.options(pv_fp16=0):
+        umfa_torch.attention_forward(q, k, v, mask=mb)
+        assert umfa_torch.last_kernel() == "fa_fwd16<bf16,128>"
+    q6, k6, v6 = (torch.randn(1, 4, 512, 64, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    umfa_torch.attention_forward(q6, k6, v6, mask=mb)
+    assert umfa_torch.last_kernel().startswith("fa_fwd16<")

@@ -263,7 +263,10 @@ def op_text(R, op):
         # sliding-window instantiations (WINDOW): the other band edge as well, score masked <=> dleft + c < 0
         two = (f'asm volatile("v_cmp_lt_i32 vcc, {-c}, %0\\n\\tv_cndmask_b32 v{v}, v{v}, %1, vcc\\n\\tv_cmp_gt_i32 vcc, {-c}, %2\\n\\t'
                f'v_cndmask_b32 v{v}, v{v}, %1, vcc" :: "v"(dmask[{qb}]), "v"(neg_inf), "v"(dleft) : "vcc");')
-        return f'if constexpr (WINDOW) {{ {two} }} else {{ {one} }}'
+        # mask-tensor instantiations (MASKT): bit 16 kb + r of the lane's word mwc[qb] (fa_aux.hip mask_pack_kernel) says whether the
+        # score attends: sign-extend the bit to a select mask, keep the score or take -inf
+        mt = (f'asm volatile("v_bfe_i32 %0, %1, {16 * kb + r}, 1\\n\\tv_bfi_b32 v{v}, %0, v{v}, %2" : "=&v"(mtmp) : "v"(mwc[{qb}]), "v"(neg_inf));')
+        return f'if constexpr (MASKT) {{ {mt} }} else if constexpr (WINDOW) {{ {two} }} else {{ {one} }}'
     if kind == "DMAK" and DMASTAMP and op[1] == 0:
         return ('{ asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long d0_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); '
                 'asm volatile("s_mov_b32 m0, %0\\n\\ts_nop 0\\n\\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_wave_k + W64_KDST + 0), "v"(kdma[0]), "s"(k_srd) : "memory"); '

@@ -477,6 +477,114 @@ hipError_t launch_mask_flags(FwdParams& p, uint8_t* flags, hipStream_t stream) {
 // Is the pre-pass worth its read of the mask?  Byte masks: always (at worst +15 % for a dense random per-head mask, 2-4x
 // for banded / padded ones).  Additive float masks are usually dense biases with nothing to skip: only when the distinct
 // mask bytes stay below twice the Q + K + V + O traffic (e.g. one [Sq, Skv] bias shared by the heads).
+// ------------------------------------------------------------------ bool masks for the one-wave-per-SIMD kernels (fa_fwd16_w64, MASKT)
+// A bool mask tensor is re-packed once per call into what a wave of that kernel consumes directly:
+//   bits  [mb][mh][rb64][tile][qb 2][lane 64] u32: bit 16 kb + r of lane (ql, hi) = "row 64 rb64 + 32 qb + ql attends key
+//         64 tile + 32 kb + (r & 3) + 8 (r >> 2) + 4 hi" -- i.e. bit j is the mask of score register r of score block (kb, qb)
+//         of that lane (fa_common.h acc_row); keys >= Skv and rows >= Sq are 0;
+//   wflag [mb][mh][rb64][tile] u8: 1 = no (row < Sq, key < Skv) element attends, 2 = every element of a whole 64 x 64 tile attends
+//         (the tile runs the plain tile body), 0 = mixed (the masking body with bits);
+//   list  [mb][mh][qblk][T] u32 + cnt [mb][mh][qblk]: the key tiles a 256-row block visits, ascending -- those in which not all
+//         four of its waves are fully masked -- as tile | class(wave 0) << 16 | class(wave 1) << 18 | ... (mask_list_kernel).
+// One read of every distinct mask byte (broadcast dims are not expanded); the bit image is 1/8 of the mask (2 MB for [1,1,4096,4096]).
+__global__ __launch_bounds__(256) void mask_pack_kernel(FwdParams p, uint32_t* bits, uint8_t* wflag, uint32_t Bm, uint32_t Hm, uint32_t nrb64, uint32_t T) {
+    const uint32_t lane = threadIdx.x & 63, ql = lane & 31, hi = lane >> 5;
+    const uint64_t wid = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t total = (uint64_t)Bm * Hm * nrb64 * T;
+    if (wid >= total) return;
+    const uint32_t tile = (uint32_t)(wid % T);
+    const uint32_t rb = (uint32_t)((wid / T) % nrb64);
+    const uint32_t slab = (uint32_t)(wid / ((uint64_t)T * nrb64));
+    const uint32_t hm = slab % Hm, bm = slab / Hm;
+    const uint8_t* base = (const uint8_t*)p.mask + (int64_t)bm * p.ms[0] + (int64_t)hm * p.ms[1];
+    const bool vec4 = p.ms[3] == 1 && ((p.ms[0] | p.ms[1] | p.ms[2]) & 3) == 0 && ((uintptr_t)p.mask & 3) == 0;
+    bool all_open = (uint64_t)tile * 64 + 64 <= p.Skv, any_open = false;
+    uint32_t w[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const uint32_t row = rb * 64 + 32 * qb + ql;
+        uint32_t word = 0;
+        if (row < p.Sq) {
+            const uint8_t* rp = base + (int64_t)row * p.ms[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint32_t key0 = tile * 64 + 32 * kb + 8 * g + 4 * hi;
+                    uint32_t four = 0;  // byte e = mask[row][key0 + e]
+                    if (vec4 && key0 + 4 <= p.Skv) {
+                        four = *(const uint32_t*)(rp + key0);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (key0 + e < p.Skv) four |= (uint32_t)rp[(int64_t)(key0 + e) * p.ms[3]] << (8 * e);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) word |= ((four >> (8 * e)) & 0xffu) ? 1u << (16 * kb + 4 * g + e) : 0u;
+                }
+            all_open = all_open && word == 0xffffffffu;
+            any_open = any_open || word != 0;
+        }
+        w[qb] = word;
+    }
+    uint32_t* dst = bits + ((wid * 2) * 64 + lane);
+    dst[0] = w[0];
+    dst[64] = w[1];
+    const bool open = __builtin_amdgcn_ballot_w64(any_open) != 0, full = __builtin_amdgcn_ballot_w64(!all_open) == 0;
+    if (lane == 0) wflag[wid] = !open ? 1 : (full ? 2 : 0);
+}
+
+// one wave per (mask batch, mask head, 256-row block): compact the visited tiles
+__global__ __launch_bounds__(64) void mask_list_kernel(const uint8_t* wflag, uint32_t* list, uint32_t* cnt, uint32_t nrb64, uint32_t nqb, uint32_t T) {
+    const uint32_t lane = threadIdx.x, qblk = blockIdx.x % nqb, slab = blockIdx.x / nqb;
+    const uint8_t* wf = wflag + (uint64_t)slab * nrb64 * T;
+    uint32_t* out = list + (uint64_t)blockIdx.x * T;
+    uint32_t n = 0;
+    for (uint32_t t0 = 0; t0 < T; t0 += 64) {
+        const uint32_t t = t0 + lane;
+        uint32_t cls = 0;
+        bool visit = false;
+        if (t < T) {
+#pragma unroll
+            for (uint32_t wv = 0; wv < 4; ++wv) {
+                const uint32_t rb = 4 * qblk + wv;
+                const uint32_t c = rb < nrb64 ? wf[(uint64_t)rb * T + t] : 1u;  // waves past Sq: nothing to do
+                cls |= c << (16 + 2 * wv);
+                visit = visit || c != 1u;
+            }
+        }
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(visit);
+        if (visit) out[n + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = t | cls;
+        n += (uint32_t)__builtin_popcountll(bal);
+    }
+    if (n == 0 && lane == 0) out[0] = 0u | (0x55u << 16);  // a block that sees nothing: one tile, every wave fully masked -> O = 0, LSE = -inf
+    if (lane == 0) cnt[blockIdx.x] = n ? n : 1u;
+}
+
+size_t mask_pack_bytes(const FwdParams& p) {
+    const uint64_t Bm = p.ms[0] ? p.B : 1, Hm = p.ms[1] ? p.H : 1, nrb64 = (p.Sq + 63) / 64, nqb = (p.Sq + 255) / 256, T = (p.Skv + 63) / 64;
+    const uint64_t slabs = Bm * Hm;
+    return (size_t)(slabs * nrb64 * T * 512 + ((slabs * nrb64 * T + 255) & ~255ull) + slabs * nqb * T * 4 + ((slabs * nqb * 4 + 255) & ~255ull) + 1024);
+}
+
+hipError_t launch_mask_pack(FwdParams& p, void* scratch, hipStream_t stream) {
+    if (p.mask_kind != MK_BOOL || !p.mask || !scratch) return hipErrorInvalidValue;
+    const uint32_t Bm = p.ms[0] ? p.B : 1, Hm = p.ms[1] ? p.H : 1, nrb64 = (p.Sq + 63) / 64, nqb = (p.Sq + 255) / 256, T = (p.Skv + 63) / 64;
+    const uint64_t slabs = (uint64_t)Bm * Hm, total = slabs * nrb64 * T;
+    if (total == 0 || total > 0x7fffffffull * 4 || T > 0xffffu) return hipErrorInvalidValue;
+    char* base = (char*)scratch;
+    uint32_t* bits = (uint32_t*)base;
+    uint8_t* wflag = (uint8_t*)(base + total * 512);
+    uint32_t* list = (uint32_t*)(base + total * 512 + ((total + 255) & ~255ull));
+    uint32_t* cnt = (uint32_t*)((char*)list + slabs * nqb * T * 4);
+    hipLaunchKernelGGL(mask_pack_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream, p, bits, wflag, Bm, Hm, nrb64, T);
+    hipLaunchKernelGGL(mask_list_kernel, dim3((unsigned)(slabs * nqb)), dim3(64), 0, stream, wflag, list, cnt, nrb64, nqb, T);
+    p.mk_bits = bits; p.mk_list = list; p.mk_cnt = cnt;
+    p.mk_bs = p.ms[0] ? Hm : 0; p.mk_hs = p.ms[1] ? 1 : 0;  // slab index of (b, h) = b * mk_bs + h * mk_hs
+    p.mk_nrb64 = nrb64; p.mk_T = T;
+    return hipGetLastError();
+}
+
 bool mask_flags_worthwhile(const FwdParams& p) {
     if (p.mask_kind == MK_WINDOW) return false;  // its tile flags are arithmetic, inside the kernel
     if (p.mask_kind == MK_BOOL) return true;

@@ -60,6 +60,12 @@ struct FwdParams {
     uint32_t mf_bs, mf_hs;         // flag-row strides of batch / head in units of (mf_nrb * mf_ntiles); 0 = broadcast
     uint32_t mf_nrb, mf_ntiles;    // 32-row blocks, 64-key tiles
     uint32_t win_left, win_right;  // MK_WINDOW: sliding window (in-stream entry, mask type 3); tile flags are arithmetic
+    // bool mask re-packed for fa_fwd16_w64 (fa_aux.hip mask_pack_kernel): per-lane bit words, the visited-tile list of every 256-row
+    // block and its length; slab of (b, h) = b * mk_bs + h * mk_hs (0 = broadcast)
+    const uint32_t* mk_bits;
+    const uint32_t* mk_list;
+    const uint32_t* mk_cnt;
+    uint32_t mk_bs, mk_hs, mk_nrb64, mk_T;
     // fused rotary embedding of Q (umfa_rope_attention_forward_stream): fp32 tables [Sq, D] (or [B, Sq, D] with
     // rope_tb = Sq * D), pair-duplicated, applied to the Q fragments right after their load; K arrives already rotated
     const float* rope_cos;

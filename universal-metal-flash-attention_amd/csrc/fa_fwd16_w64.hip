@@ -48,6 +48,10 @@ struct W64Params {
     const float* rope_cos;  // fused rotary embedding of Q (FwdParams::rope_*), NULL = none
     const float* rope_sin;
     int64_t rope_tb;
+    const uint32_t* mk_bits;  // MASKT kernels: the packed bool mask (FwdParams::mk_*, fa_aux.hip mask_pack_kernel)
+    const uint32_t* mk_list;
+    const uint32_t* mk_cnt;
+    uint32_t mk_bs, mk_hs, mk_nrb64;
 };
 
 // ---- asm-owned accumulator registers: helpers with literal register numbers (generated)
@@ -273,7 +277,16 @@ static uint32_t w64_tiles_per_item(const FwdParams& p) {
 
 bool fwd_w64_supported(const FwdParams& p) {
     if (tuning().no_w64.load(std::memory_order_relaxed) || !fwd_16_supported(p)) return false;
-    if ((p.D != 128 && p.D != 64) || (p.mask_kind != MK_NONE && p.mask_kind != MK_WINDOW)) return false;
+    if ((p.D != 128 && p.D != 64) || (p.mask_kind != MK_NONE && p.mask_kind != MK_WINDOW && p.mask_kind != MK_BOOL)) return false;
+    if (p.mask_kind == MK_BOOL) {
+        // bool mask tensors (MASKT instantiations): head_dim 128, the fp16-P-V families (bf16 operands by default, fp16 operands), no
+        // causal flag / rotation on top; whole items per workgroup, so at least one item per CU
+        if (tuning().no_w64_mask.load(std::memory_order_relaxed) || !p.mask || p.D != 128 || p.causal || p.rope_cos) return false;
+        if (p.in_prec == P_BF16 && !p.pv16) return false;
+        if (p.Skv < 64 || p.Sq < 256 || (p.Sq % 256 != 0 && p.Sq < 1024) || ((p.Skv + 63) / 64) > 0xffffu) return false;
+        if (p.out_prec != P_FP32 && p.out_prec != p.in_prec) return false;
+        return tuning().force_w64.load(std::memory_order_relaxed) || (uint64_t)p.B * p.H * ((p.Sq + 255) / 256) >= (uint64_t)w64_cu_count();
+    }
     if (w64_is_window(p) && p.rope_cos) return false;  // window instantiations: no fused rotation
     if (p.D == 64 && p.rope_cos) return false;  // the fused Q rotation exists at head_dim 128 only
     // rows are processed in blocks of 256: a ragged last block wastes its empty waves, so small ragged Sq stay on
@@ -313,6 +326,11 @@ bool fwd_w64_supported(const FwdParams& p) {
 }
 
 static uint32_t w64_grid(const FwdParams& p) {
+    if (p.mask_kind == MK_BOOL) {  // mask tensors: whole items, one workgroup per CU at most
+        const uint64_t items = (uint64_t)p.B * p.H * ((p.Sq + 255) / 256);
+        const uint64_t cus = (uint64_t)w64_cu_count();
+        return (uint32_t)(items < cus ? items : cus);
+    }
     const bool pairs = p.causal && !w64_is_window(p);  // (a causal window is a window with right = 0: linear schedule)
     uint64_t total = (uint64_t)p.B * p.H * ((p.Sq + 255) / 256) * w64_tiles_per_item(p);  // (item, key tile) steps
     if (pairs) total = (uint64_t)p.B * p.H * (((p.Sq + 255) / 256 + 1) / 2);  // jobs = mirrored pairs of q-blocks
@@ -366,7 +384,13 @@ hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cn
     wp.skew = (uint32_t)tuning().w64_skew.load(std::memory_order_relaxed);
     wp.rope_cos = p.rope_cos; wp.rope_sin = p.rope_sin; wp.rope_tb = p.rope_tb;
     wp.Tw = wp.T; wp.win_left = wp.win_right = 0;
-    const bool rope = p.rope_cos != nullptr, window = w64_is_window(p), fp32o = p.out_prec == P_FP32;
+    const bool rope = p.rope_cos != nullptr, window = w64_is_window(p), fp32o = p.out_prec == P_FP32, maskt = p.mask_kind == MK_BOOL;
+    if (maskt) {
+        if (!p.mk_bits || !p.mk_list || !p.mk_cnt) return hipErrorInvalidValue;  // runtime.hip packs the mask first (launch_mask_pack)
+        wp.mk_bits = p.mk_bits; wp.mk_list = p.mk_list; wp.mk_cnt = p.mk_cnt;
+        wp.mk_bs = p.mk_bs; wp.mk_hs = p.mk_hs; wp.mk_nrb64 = p.mk_nrb64;
+        wp.lazy = 0;  // the max chain: which rows have keys in a segment is not arithmetic (kernel: MASKT)
+    }
     if (rope && p.out_prec != p.in_prec) return hipErrorNotSupported;  // fused-RoPE instantiations: O in the operand type only (runtime.hip asks first)
     if (window) {
         wp.Tw = w64_tiles_per_item(p);
@@ -377,7 +401,10 @@ hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cn
     // and at head_dim 128 <operand type, causal, rope>
 #define W64_FAMILY(FAM, T16, HAS_ROPE)                                                                                         \
     do {                                                                                                                       \
-        if constexpr (HAS_ROPE) {                                                                                              \
+        if constexpr (HAS_ROPE == 2) {  /* families with mask-tensor instantiations */                                        \
+            if (maskt) return fp32o ? launch_w64_kernel(FAM<float, false, false, false, true>, p, wp, stream) : launch_w64_kernel(FAM<T16, false, false, false, true>, p, wp, stream); \
+        }                                                                                                                      \
+        if constexpr (HAS_ROPE != 0) {                                                                                         \
             if (rope) return p.causal ? launch_w64_kernel(FAM<T16, true, true>, p, wp, stream) : launch_w64_kernel(FAM<T16, false, true>, p, wp, stream); \
         }                                                                                                                      \
         if (window) return fp32o ? launch_w64_kernel(FAM<float, false, false, true>, p, wp, stream) : launch_w64_kernel(FAM<T16, false, false, true>, p, wp, stream); \
@@ -393,15 +420,16 @@ hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cn
          {"fa_fwd16_w64<fp16,64>", "fa_fwd16_w64<fp16,64,rope>", "fa_fwd16_w64<fp16,64,window>"}}};
     if (p.D == 64 && rope) return hipErrorNotSupported;
     const int fam = p.in_prec == P_BF16 ? (p.pv16 ? 1 : 0) : 2;
-    *name = names[fam][p.D == 64 ? 1 : 0][rope ? 1 : window ? 2 : 0];
+    if (maskt && (fam == 0 || p.D != 128)) return hipErrorNotSupported;
+    *name = maskt ? (fam == 1 ? "fa_fwd16_w64<bf16,128,pv16,mask>" : "fa_fwd16_w64<fp16,128,mask>") : names[fam][p.D == 64 ? 1 : 0][rope ? 1 : window ? 2 : 0];
     if (p.D == 64) {
-        if (fam == 0) W64_FAMILY(fa_fwd16_w64d64_bf16, __bf16, false);
-        if (fam == 1) W64_FAMILY(fa_fwd16_w64d64_bf16pv16, __bf16, false);
-        W64_FAMILY(fa_fwd16_w64d64_f16, _Float16, false);
+        if (fam == 0) W64_FAMILY(fa_fwd16_w64d64_bf16, __bf16, 0);
+        if (fam == 1) W64_FAMILY(fa_fwd16_w64d64_bf16pv16, __bf16, 0);
+        W64_FAMILY(fa_fwd16_w64d64_f16, _Float16, 0);
     }
-    if (fam == 0) W64_FAMILY(fa_fwd16_w64_bf16, __bf16, true);
-    if (fam == 1) W64_FAMILY(fa_fwd16_w64_bf16pv16, __bf16, true);
-    W64_FAMILY(fa_fwd16_w64_f16, _Float16, true);
+    if (fam == 0) W64_FAMILY(fa_fwd16_w64_bf16, __bf16, 1);
+    if (fam == 1) W64_FAMILY(fa_fwd16_w64_bf16pv16, __bf16, 2);
+    W64_FAMILY(fa_fwd16_w64_f16, _Float16, 2);
 #undef W64_FAMILY
 }
 

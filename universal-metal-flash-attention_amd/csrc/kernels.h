@@ -19,7 +19,7 @@ struct Tuning {
     std::atomic<int> sm_mode{SM_DEFAULT};
     std::atomic<float> sm_tau{6.0f};
     std::atomic<int> force_w64{0}, no_w64{0}, w64_grid{0}, w64_skew{0}, no_mask_flags{0}, bwd_exact{0}, bwd_dq{0}, bwd_persist{0},
-        bwd_separate_delta{0}, no_split{0}, force_split{0}, no_dma{0}, bn64{0}, pv_fp16{0}, bwd_ds_store{0};
+        bwd_separate_delta{0}, no_split{0}, force_split{0}, no_dma{0}, bn64{0}, pv_fp16{0}, bwd_ds_store{0}, no_w64_mask{0};
 };
 Tuning& tuning();
 bool set_tuning(const char* name, const char* value);  // false: unknown name or value out of range
@@ -136,6 +136,9 @@ hipError_t launch_quantized_fwd(const FwdParams& fp, int bits, int quant_mode, v
 bool fwd_w64_i8_supported(const FwdParams& p);
 hipError_t launch_fwd_w64_i8(const FwdParams& p, const QuantViews& v, float* part_buf, uint32_t* part_cnt, hipStream_t stream);
 
+// bool mask -> per-lane bit words + visited-tile lists for fa_fwd16_w64's MASKT instantiations (fa_aux.hip); fills p.mk_*
+size_t mask_pack_bytes(const FwdParams& p);
+hipError_t launch_mask_pack(FwdParams& p, void* scratch, hipStream_t stream);
 // mask tile flags for fa_fwd16's tile early-exit (fa_aux.hip); launch_mask_flags fills p.mask_flags / mf_*
 size_t mask_flags_bytes(const FwdParams& p);
 bool mask_flags_worthwhile(const FwdParams& p);

@@ -115,6 +115,14 @@ hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p,
             pv.v = v16;
             pv.vs[0] = (int64_t)p.H * p.Skv * p.D; pv.vs[1] = (int64_t)p.Skv * p.D; pv.vs[2] = p.D; pv.vs[3] = 1;
         }
+        if (pv.mask_kind == MK_BOOL) {
+            // bool mask tensor on the one-wave-per-SIMD structure: one pre-pass re-packs it into per-lane bit words, per-wave tile
+            // classes and the visited-tile list of every 256-row block (fa_aux.hip mask_pack_kernel); the kernel then never stages
+            // a tile no row of the block attends to and reads no mask bytes at all
+            void* mk = sc.mflags.ensure(mask_pack_bytes(pv), stream);
+            if (!mk) return hipErrorOutOfMemory;
+            if ((e = launch_mask_pack(pv, mk, stream)) != hipSuccess) return e;
+        }
         const FwdW64Plan plan = fwd_w64_plan(pv);
         char* w64 = sc.ensure_w64(plan.cnt_bytes, plan.buf_bytes, stream);
         if (!w64) return hipErrorOutOfMemory;
