@@ -484,48 +484,86 @@ hipError_t launch_mask_flags(FwdParams& p, uint8_t* flags, hipStream_t stream) {
 //         of that lane (fa_common.h acc_row); keys >= Skv and rows >= Sq are 0;
 //   wflag [mb][mh][rb64][tile] u8: 1 = no (row < Sq, key < Skv) element attends, 2 = every element of a whole 64 x 64 tile attends
 //         (the tile runs the plain tile body), 0 = mixed (the masking body with bits);
-//   list  [mb][mh][qblk][T] u32 + cnt [mb][mh][qblk]: the key tiles a 256-row block visits, ascending -- those in which not all
-//         four of its waves are fully masked -- as tile | class(wave 0) << 16 | class(wave 1) << 18 | ... (mask_list_kernel).
+//   list  [mb][mh][qblk][T][2] u32 + cnt [mb][mh][qblk]: the key tiles a 256-row block visits, ascending -- those in which not all
+//         four of its waves are fully masked -- as { tile | class(wave 0) << 16 | class(wave 1) << 18 | ..., next listed tile | the one
+//         after it << 16 } (past the end: the last tile again), so that the kernel needs nothing but its current entry (mask_list_kernel).
 // One read of every distinct mask byte (broadcast dims are not expanded); the bit image is 1/8 of the mask (2 MB for [1,1,4096,4096]).
+template <bool VEC16>
 __global__ __launch_bounds__(256) void mask_pack_kernel(FwdParams p, uint32_t* bits, uint8_t* wflag, uint32_t Bm, uint32_t Hm, uint32_t nrb64, uint32_t T) {
-    const uint32_t lane = threadIdx.x & 63, ql = lane & 31, hi = lane >> 5;
-    const uint64_t wid = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ __attribute__((aligned(16))) uint8_t stage[4][64 * 80];  // per wave: a 64 x 64 byte tile, rows padded to 80 bytes (bank spread)
+    const uint32_t lane = threadIdx.x & 63, ql = lane & 31, hi = lane >> 5, wv = threadIdx.x >> 6;
+    const uint64_t wid = (uint64_t)blockIdx.x * 4 + wv;
     const uint64_t total = (uint64_t)Bm * Hm * nrb64 * T;
-    if (wid >= total) return;
+    if (wid >= total) return;  // (whole waves: no barrier below, every wave works on its own LDS area)
     const uint32_t tile = (uint32_t)(wid % T);
     const uint32_t rb = (uint32_t)((wid / T) % nrb64);
     const uint32_t slab = (uint32_t)(wid / ((uint64_t)T * nrb64));
     const uint32_t hm = slab % Hm, bm = slab / Hm;
     const uint8_t* base = (const uint8_t*)p.mask + (int64_t)bm * p.ms[0] + (int64_t)hm * p.ms[1];
-    const bool vec4 = p.ms[3] == 1 && ((p.ms[0] | p.ms[1] | p.ms[2]) & 3) == 0 && ((uintptr_t)p.mask & 3) == 0;
     bool all_open = (uint64_t)tile * 64 + 64 <= p.Skv, any_open = false;
     uint32_t w[2];
+    if constexpr (VEC16) {
+        // contiguous, 16-byte aligned rows with Skv % 16 == 0: the tile comes in as 16-byte loads in row order (a wave-load covers
+        // 16 rows x 64 bytes, coalesced), goes through the wave's LDS area and comes out in the lane order the attention kernel wants
+        uint8_t* st = stage[wv];
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-        const uint32_t row = rb * 64 + 32 * qb + ql;
-        uint32_t word = 0;
-        if (row < p.Sq) {
-            const uint8_t* rp = base + (int64_t)row * p.ms[2];
+        for (int ps = 0; ps < 4; ++ps) {
+            const uint32_t r = 16 * ps + (lane >> 2), c = lane & 3, row = rb * 64 + r, key0 = tile * 64 + 16 * c;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (row < p.Sq && key0 < p.Skv) v = *(const u32x4*)(base + (int64_t)row * p.ms[2] + key0);
+            *(u32x4*)(st + r * 80 + 16 * c) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const uint32_t r = 32 * qb + ql;
+            uint32_t word = 0;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const uint32_t key0 = tile * 64 + 32 * kb + 8 * g + 4 * hi;
-                    uint32_t four = 0;  // byte e = mask[row][key0 + e]
-                    if (vec4 && key0 + 4 <= p.Skv) {
-                        four = *(const uint32_t*)(rp + key0);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (key0 + e < p.Skv) four |= (uint32_t)rp[(int64_t)(key0 + e) * p.ms[3]] << (8 * e);
-                    }
+                    const uint32_t four = *(const uint32_t*)(st + r * 80 + 32 * kb + 8 * g + 4 * hi);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) word |= ((four >> (8 * e)) & 0xffu) ? 1u << (16 * kb + 4 * g + e) : 0u;
                 }
-            all_open = all_open && word == 0xffffffffu;
-            any_open = any_open || word != 0;
+            if (rb * 64 + r < p.Sq) {
+                all_open = all_open && word == 0xffffffffu;
+                any_open = any_open || word != 0;
+            }
+            w[qb] = word;
         }
-        w[qb] = word;
+    } else {
+        const bool vec4 = p.ms[3] == 1 && ((p.ms[0] | p.ms[1] | p.ms[2]) & 3) == 0 && ((uintptr_t)p.mask & 3) == 0;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const uint32_t row = rb * 64 + 32 * qb + ql;
+            uint32_t word = 0;
+            if (row < p.Sq) {
+                const uint8_t* rp = base + (int64_t)row * p.ms[2];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const uint32_t key0 = tile * 64 + 32 * kb + 8 * g + 4 * hi;
+                        uint32_t four = 0;  // byte e = mask[row][key0 + e]
+                        if (vec4 && key0 + 4 <= p.Skv) {
+                            four = *(const uint32_t*)(rp + key0);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (key0 + e < p.Skv) four |= (uint32_t)rp[(int64_t)(key0 + e) * p.ms[3]] << (8 * e);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) word |= ((four >> (8 * e)) & 0xffu) ? 1u << (16 * kb + 4 * g + e) : 0u;
+                    }
+                all_open = all_open && word == 0xffffffffu;
+                any_open = any_open || word != 0;
+            }
+            w[qb] = word;
+        }
     }
     uint32_t* dst = bits + ((wid * 2) * 64 + lane);
     dst[0] = w[0];
@@ -538,7 +576,7 @@ __global__ __launch_bounds__(256) void mask_pack_kernel(FwdParams p, uint32_t* b
 __global__ __launch_bounds__(64) void mask_list_kernel(const uint8_t* wflag, uint32_t* list, uint32_t* cnt, uint32_t nrb64, uint32_t nqb, uint32_t T) {
     const uint32_t lane = threadIdx.x, qblk = blockIdx.x % nqb, slab = blockIdx.x / nqb;
     const uint8_t* wf = wflag + (uint64_t)slab * nrb64 * T;
-    uint32_t* out = list + (uint64_t)blockIdx.x * T;
+    uint32_t* out = list + (uint64_t)blockIdx.x * T * 2;
     uint32_t n = 0;
     for (uint32_t t0 = 0; t0 < T; t0 += 64) {
         const uint32_t t = t0 + lane;
@@ -554,17 +592,24 @@ __global__ __launch_bounds__(64) void mask_list_kernel(const uint8_t* wflag, uin
             }
         }
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(visit);
-        if (visit) out[n + __builtin_popcountll(bal & ((1ull << lane) - 1ull))] = t | cls;
+        if (visit) out[2 * (n + __builtin_popcountll(bal & ((1ull << lane) - 1ull)))] = t | cls;
         n += (uint32_t)__builtin_popcountll(bal);
     }
     if (n == 0 && lane == 0) out[0] = 0u | (0x55u << 16);  // a block that sees nothing: one tile, every wave fully masked -> O = 0, LSE = -inf
-    if (lane == 0) cnt[blockIdx.x] = n ? n : 1u;
+    if (n == 0) n = 1;
+    if (lane == 0) cnt[blockIdx.x] = n;
+    __threadfence_block();  // (one wave: its own stores above are visible to its loads below once they have completed)
+    __builtin_amdgcn_s_waitcnt(0);
+    for (uint32_t j = lane; j < n; j += 64) {
+        const uint32_t j1 = j + 1 < n ? j + 1 : n - 1, j2 = j + 2 < n ? j + 2 : n - 1;
+        out[2 * j + 1] = (out[2 * j1] & 0xffffu) | ((out[2 * j2] & 0xffffu) << 16);
+    }
 }
 
 size_t mask_pack_bytes(const FwdParams& p) {
     const uint64_t Bm = p.ms[0] ? p.B : 1, Hm = p.ms[1] ? p.H : 1, nrb64 = (p.Sq + 63) / 64, nqb = (p.Sq + 255) / 256, T = (p.Skv + 63) / 64;
     const uint64_t slabs = Bm * Hm;
-    return (size_t)(slabs * nrb64 * T * 512 + ((slabs * nrb64 * T + 255) & ~255ull) + slabs * nqb * T * 4 + ((slabs * nqb * 4 + 255) & ~255ull) + 1024);
+    return (size_t)(slabs * nrb64 * T * 512 + ((slabs * nrb64 * T + 255) & ~255ull) + slabs * nqb * T * 8 + ((slabs * nqb * 4 + 255) & ~255ull) + 1024);
 }
 
 hipError_t launch_mask_pack(FwdParams& p, void* scratch, hipStream_t stream) {
@@ -576,8 +621,10 @@ hipError_t launch_mask_pack(FwdParams& p, void* scratch, hipStream_t stream) {
     uint32_t* bits = (uint32_t*)base;
     uint8_t* wflag = (uint8_t*)(base + total * 512);
     uint32_t* list = (uint32_t*)(base + total * 512 + ((total + 255) & ~255ull));
-    uint32_t* cnt = (uint32_t*)((char*)list + slabs * nqb * T * 4);
-    hipLaunchKernelGGL(mask_pack_kernel, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream, p, bits, wflag, Bm, Hm, nrb64, T);
+    uint32_t* cnt = (uint32_t*)((char*)list + slabs * nqb * T * 8);
+    const bool vec16 = p.ms[3] == 1 && (p.Skv & 15) == 0 && ((p.ms[0] | p.ms[1] | p.ms[2]) & 15) == 0 && ((uintptr_t)p.mask & 15) == 0;
+    if (vec16) hipLaunchKernelGGL(mask_pack_kernel<true>, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream, p, bits, wflag, Bm, Hm, nrb64, T);
+    else hipLaunchKernelGGL(mask_pack_kernel<false>, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream, p, bits, wflag, Bm, Hm, nrb64, T);
     hipLaunchKernelGGL(mask_list_kernel, dim3((unsigned)(slabs * nqb)), dim3(64), 0, stream, wflag, list, cnt, nrb64, nqb, T);
     p.mk_bits = bits; p.mk_list = list; p.mk_cnt = cnt;
     p.mk_bs = p.ms[0] ? Hm : 0; p.mk_hs = p.ms[1] ? 1 : 0;  // slab index of (b, h) = b * mk_bs + h * mk_hs

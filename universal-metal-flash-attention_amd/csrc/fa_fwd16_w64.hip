@@ -283,7 +283,7 @@ bool fwd_w64_supported(const FwdParams& p) {
         // causal flag / rotation on top; whole items per workgroup, so at least one item per CU
         if (tuning().no_w64_mask.load(std::memory_order_relaxed) || !p.mask || p.D != 128 || p.causal || p.rope_cos) return false;
         if (p.in_prec == P_BF16 && !p.pv16) return false;
-        if (p.Skv < 64 || p.Sq < 256 || (p.Sq % 256 != 0 && p.Sq < 1024) || ((p.Skv + 63) / 64) > 0xffffu) return false;
+        if (p.Skv < 64 || p.Sq < 256 || (p.Sq % 256 != 0 && p.Sq < 1024) || ((p.Skv + 63) / 64) > 1024u) return false;  // (a block's tile list sits in 4 KiB of LDS)
         if (p.out_prec != P_FP32 && p.out_prec != p.in_prec) return false;
         return tuning().force_w64.load(std::memory_order_relaxed) || (uint64_t)p.B * p.H * ((p.Sq + 255) / 256) >= (uint64_t)w64_cu_count();
     }
@@ -362,7 +362,7 @@ FwdW64Plan fwd_w64_plan(const FwdParams& p) {
 template <typename KFN>
 static hipError_t launch_w64_kernel(KFN kfn, const FwdParams& p, const W64Params& wp, hipStream_t stream) {
     const uint32_t grid = w64_grid(p);
-    const size_t lds = 65536 + 4 * 32 * (512 + 16) + 16;  // K/V rings + per-wave output staging + the lazy mode's overflow flag
+    const size_t lds = 65536 + 4 * 32 * (512 + 16) + 64 + 4096 + 8192;  // K/V rings + per-wave output staging + flag / ticket words + the mask kernels' bit-word ring and tile list
     if (hipError_t e = ensure_dynamic_lds((const void*)kfn, lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, stream, wp);
     return hipGetLastError();
