@@ -62,8 +62,9 @@ def record(tag: str, **vals) -> None:
 
 
 def fam(kernel: str) -> str:
-    """kernel family: the name without the ",pv16" tag (bf16 operands, P V product in fp16 -- the default bf16 arithmetic)"""
-    return kernel.replace(",pv16", "")
+    """kernel family: the name without the ",pv16" tag (bf16 operands, P V product in fp16 -- the default bf16 arithmetic) and without
+    ",ks2" (the key-split form of the 128-row head_dim-64 kernel: same arithmetic, eight waves per workgroup)"""
+    return kernel.replace(",pv16", "").replace(",ks2", "").replace(",pipe", "")
 
 
 def regime_of(kernel: str) -> str:

@@ -31,6 +31,12 @@ int main(int argc, char** argv) {
 #ifndef UMFA_LAB_CAUSAL
 #define UMFA_LAB_CAUSAL 0
 #endif
+#ifndef UMFA_LAB_KS
+#define UMFA_LAB_KS 1   /* 2: the key-split form (head_dim 64, LDS-DMA) */
+#endif
+#ifndef UMFA_LAB_PIPE
+#define UMFA_LAB_PIPE 0   /* 1: the software-pipelined loop (head_dim 64, LDS-DMA) */
+#endif
 #ifndef UMFA_LAB_PV16
 #define UMFA_LAB_PV16 0
 #endif
@@ -70,27 +76,31 @@ int main(int argc, char** argv) {
     p.n_full = items; p.nsplit = 1;
 #ifdef UMFA_LAB_STAMPS
     unsigned long long* dbg;
-    CK(hipMalloc(&dbg, (size_t)items * 64));
+    CK(hipMalloc(&dbg, (size_t)items * 112));  // [items][8] stamps, then [items][6] loop buckets (UMFA_LAB_LOOP_STAMPS)
     p.part_buf = (float*)dbg;
 #endif
     #ifndef UMFA_LAB_BN
 #define UMFA_LAB_BN 64
 #endif
 #ifdef UMFA_LAB_DMA
-    auto kfn = fa_fwd16_kernel<__bf16, UMFA_LAB_D, UMFA_LAB_CAUSAL != 0, false, __bf16, true, UMFA_LAB_BN, UMFA_LAB_PV16 != 0>;
+    auto kfn = fa_fwd16_kernel<__bf16, UMFA_LAB_D, UMFA_LAB_CAUSAL != 0, false, __bf16, true, UMFA_LAB_BN, UMFA_LAB_PV16, UMFA_LAB_KS, UMFA_LAB_PIPE>;
 #else
-    auto kfn = fa_fwd16_kernel<__bf16, UMFA_LAB_D, UMFA_LAB_CAUSAL != 0, false, __bf16, false, UMFA_LAB_BN, UMFA_LAB_PV16 != 0>;
+    auto kfn = fa_fwd16_kernel<__bf16, UMFA_LAB_D, UMFA_LAB_CAUSAL != 0, false, __bf16, false, UMFA_LAB_BN, UMFA_LAB_PV16>;
 #endif
-    const size_t lds = 4 * UMFA_LAB_BN * UMFA_LAB_D * 2;
+#ifndef UMFA_LAB_NS
+#define UMFA_LAB_NS (UMFA_LAB_KS == 2 ? 4 : 2)   /* ring depth of the LDS-DMA staging */
+#endif
+    size_t lds = 2 * UMFA_LAB_NS * UMFA_LAB_BN * UMFA_LAB_D * 2;
+    if (UMFA_LAB_KS == 2 && lds < 4 * (16 * (UMFA_LAB_D / 32) + 2) * 256) lds = 4 * (16 * (UMFA_LAB_D / 32) + 2) * 256;
     CK(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kfn, dim3(items), dim3(256), lds, 0, p);
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kfn, dim3(items), dim3(256 * UMFA_LAB_KS), lds, 0, p);
     CK(hipDeviceSynchronize());
     std::vector<float> ts;
     for (int i = 0; i < reps; ++i) {
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(kfn, dim3(items), dim3(256), lds, 0, p);
+        hipLaunchKernelGGL(kfn, dim3(items), dim3(256 * UMFA_LAB_KS), lds, 0, p);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -115,6 +125,23 @@ int main(int argc, char** argv) {
                 printf("%5u  %3llu  %8.2f  %8.2f  %8.2f  %8.2f  %8.2f\n", i, d[6], us(d[0]), us(d[1]) - us(d[0]),
                        us(d[2]) - us(d[1]), us(d[3]) - us(d[2]), us(d[3]));
         }
+#ifdef UMFA_LAB_LOOP_STAMPS
+        {
+            std::vector<unsigned long long> lp((size_t)items * 6);
+            CK(hipMemcpy(lp.data(), dbg + (size_t)items * 8, lp.size() * 8, hipMemcpyDeviceToHost));
+            // the longest workgroups (q-block nqb - 1) and the mean: cycles of wave 0 per bucket
+            double mean[6] = {0, 0, 0, 0, 0, 0};
+            uint32_t longest = 0;
+            for (uint32_t i = 0; i < items; ++i) {
+                for (int j = 0; j < 6; ++j) mean[j] += (double)lp[i * 6 + j] / items;
+                if (hd[i * 8 + 2] - hd[i * 8 + 1] > hd[longest * 8 + 2] - hd[longest * 8 + 1]) longest = i;
+            }
+            printf("loop cycles of wave 0 (request issue | compute issue | next-tile wait | barrier | compute: to last QK MFMA | softmax): mean %.0f %.0f %.0f %.0f %.0f %.0f; "
+                   "longest workgroup (%u, loop %.2f us) %llu %llu %llu %llu %llu %llu\n",
+                   mean[0], mean[1], mean[2], mean[3], mean[4], mean[5], longest, us(hd[longest * 8 + 2]) - us(hd[longest * 8 + 1]), lp[longest * 6], lp[longest * 6 + 1],
+                   lp[longest * 6 + 2], lp[longest * 6 + 3], lp[longest * 6 + 4], lp[longest * 6 + 5]);
+        }
+#endif
         printf("mean prologue %.2f us, loop %.2f us, epilogue %.2f us; last end %.2f us; mean in-kernel clock %.3f GHz\n",
                pro / items, loop / items, epi / items, last_end, clk / items);
         // when do workgroups start / end: deciles of the start and end stamps, and the longest workgroup

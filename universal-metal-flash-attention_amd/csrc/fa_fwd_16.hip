@@ -103,6 +103,13 @@ static hipError_t launch_one(const FwdParams& p, hipStream_t stream) {
         if constexpr (DP == 128 && !HAS_MASK && !CAUSAL) {
             if (!tuning().bn64.load(std::memory_order_relaxed)) return launch_dma<T, DP, CAUSAL, HAS_MASK, OUT, true, 32>(p, stream);
         }
+        if constexpr (DP == 64 && !HAS_MASK) {
+#ifdef UMFA_D64_FORMS
+            const int form = fwd16_d64_form(p);
+            if (form == 1) return launch_dma<T, DP, CAUSAL, HAS_MASK, OUT, true, 64, 0, 1, 1>(p, stream);
+            if (form == 2) return launch_dma<T, DP, CAUSAL, HAS_MASK, OUT, true, 64, 0, 2>(p, stream);
+#endif
+        }
         return launch_dma<T, DP, CAUSAL, HAS_MASK, OUT, true, 64>(p, stream);
     }
     return launch_dma<T, DP, CAUSAL, HAS_MASK, OUT, false, 64>(p, stream);
@@ -128,7 +135,13 @@ static hipError_t launch_dp(const FwdParams& p, hipStream_t stream, const char**
     constexpr bool bf = sizeof(T) == 2 && __is_same(T, __bf16);
     const bool pv = bf && p.pv16;
     if (p.D <= 32) { *name = pv ? "fa_fwd16<bf16,32,pv16>" : bf ? "fa_fwd16<bf16,32>" : "fa_fwd16<fp16,32>"; return launch_out<T, 32>(p, stream); }
-    if (p.D <= 64) { *name = pv ? "fa_fwd16<bf16,64,pv16>" : bf ? "fa_fwd16<bf16,64>" : "fa_fwd16<fp16,64>"; return launch_out<T, 64>(p, stream); }
+    if (p.D <= 64) {
+        const int form = fwd16_d64_form(p);
+        if (form == 1) *name = pv ? "fa_fwd16<bf16,64,pv16,pipe>" : bf ? "fa_fwd16<bf16,64,pipe>" : "fa_fwd16<fp16,64,pipe>";
+        else if (form == 2) *name = pv ? "fa_fwd16<bf16,64,pv16,ks2>" : bf ? "fa_fwd16<bf16,64,ks2>" : "fa_fwd16<fp16,64,ks2>";
+        else *name = pv ? "fa_fwd16<bf16,64,pv16>" : bf ? "fa_fwd16<bf16,64>" : "fa_fwd16<fp16,64>";
+        return launch_out<T, 64>(p, stream);
+    }
     if (p.D <= 128) { *name = pv ? "fa_fwd16<bf16,128,pv16>" : bf ? "fa_fwd16<bf16,128>" : "fa_fwd16<fp16,128>"; return launch_out<T, 128>(p, stream); }
     *name = pv ? "fa_fwd16<bf16,256,pv16>" : bf ? "fa_fwd16<bf16,256>" : "fa_fwd16<fp16,256>";
     return launch_out<T, 256>(p, stream);

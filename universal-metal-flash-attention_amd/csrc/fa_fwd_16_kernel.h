@@ -90,9 +90,27 @@ __device__ __forceinline__ unsigned bf16x2_to_f16x2(unsigned x) {
 //   PV16 = 2  p.v already points at an fp16 image of V (the runtime's cast pre-pass, as for fa_fwd16_w64): V staged like K.
 //             Long launches: the conversion is 24 (head_dim 64) ... 48 (128) vector instructions per tile per wave in a kernel
 //             that is vector-bound, and every workgroup repeats it.
-template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT, bool DMA = false, int BN = 64, int PV16 = 0>
-__global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_fwd16_kernel(FwdParams p) {
+//
+// KS = 2 ("key-split", head_dim 64 only, round 4): the workgroup has EIGHT waves -- wave = 4 kh + rw; row-wave rw owns the
+// same 32 query rows as before, key half kh the 32-key block kh of every 64-key tile, with a running max / sum / O^T of its
+// own; the two halves of a row-wave meet once, in LDS, after the sweep (the split-KV fold's arithmetic without its fences).
+// Why: at head_dim 64 a tile's softmax is 17 vector instructions per MFMA, and a launch like BASELINE config 2 (512 items
+// = one round of two workgroups per CU) has two waves per SIMD that mostly take turns on it (vector unit 54 % busy, matrix
+// pipe 23 %, profiles/r4/lab_notes.md section 2).  There are no more ROWS to make waves of; halving each wave's keys gives four
+// waves per SIMD (<= 128 registers each at this head_dim), and a causal diagonal tile is skipped by the half it does not touch.
+//
+// PIPE = 1 ("software-pipelined", head_dim 64, round 4): S(t+1) = K(t+1) Q^T is issued INSIDE tile t's softmax -- the eight
+// MFMAs of the next tile's scores between the exponentials of this tile's -- so a wave's matrix work runs under its own vector
+// work instead of before it.  Measured why (in-kernel s_memtime buckets, profiles/r4/lab_notes.md section 2b): at config 2 the
+// longest workgroup's wave spends 1613 cycles per tile in "compute" for ~860 cycles of issue; its Q K^T phase (LDS reads + a
+// chain of MFMAs, 440 cycles) and its softmax (1007) follow each other, and the second wave of the SIMD is in the same phase.
+// The K stream runs one tile ahead of the V stream (same two slots each: K(t)'s slot is free once S(t) exists).
+template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT, bool DMA = false, int BN = 64, int PV16 = 0, int KS = 1, int PIPE = 0>
+__global__ __launch_bounds__(256 * KS, KS * (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_fwd16_kernel(FwdParams p) {
+    static_assert(!PIPE || (DMA && !HAS_MASK && KS == 1 && DP <= 64 && BN == 64), "pipelined loop: head_dim <= 64, LDS-DMA staging, no mask tensor");
     static_assert(!PV16 || __is_same(T, __bf16), "PV16: bf16 operands");
+    static_assert(KS == 1 || (KS == 2 && DMA && !HAS_MASK && DP == 64 && BN == 64), "key-split: head_dim 64, LDS-DMA staging, no mask tensor");
+    constexpr int NT = 256 * KS;            // threads per workgroup
     constexpr bool VCONV = PV16 == 1;  // convert V in the kernel
     typedef Mma16<T> M;
     typedef typename M::V8 V8;
@@ -105,14 +123,21 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
     constexpr int NCH = DP / 8;             // 16-byte chunks per row
     constexpr int NKS = DP / 16;            // k-steps of QK^T
     constexpr int NDB = DP / 32;            // 32-row blocks of O^T
+    constexpr int NKBW = NKB / KS, NSTW = NST / KS;  // ... of them per wave (KS = 2: a wave sees half of every tile's keys)
     constexpr int TILE_BYTES = BN * DP * 2;
     constexpr int LPT = BN * NCH / 256;     // 16-byte loads per thread per tile
     // Ring depth of the LDS-DMA staging (the code below is written for any depth: tile t + NS - 1 is requested while tile t is
     // computed, waits leave the NS - 2 younger tiles in flight).  TWO: round 4 measured four slots at head_dim 64 (config 2 sits
     // in waits 44 % of its wave cycles) -- in-kernel stamps 21.2 vs 21.4 us per launch, kernel time unchanged: the waits are not
     // the successor tile's latency, the two waves of a SIMD queue for its vector unit (profiles/r4/lab_notes.md section 2).
-    constexpr int NS = 2;
-    constexpr bool SPLIT_DMA = DMA && NS == 2 && (DP == 256 || (DP == 64 && !CAUSAL));
+    // KS = 2 (key-split): FOUR -- there a wave's share of a tile is ~500 issue cycles, less than an L2 -> LDS round trip, and with
+    // two slots every iteration ended waiting for the tile it had requested at its start.
+#ifdef UMFA_LAB_NS
+    constexpr int NS = UMFA_LAB_NS;
+#else
+    constexpr int NS = KS == 2 ? 4 : 2;
+#endif
+    constexpr bool SPLIT_DMA = DMA && NS == 2 && !PIPE && (DP == 256 || (DP == 64 && !CAUSAL));
     static_assert(LPT >= 1, "tile too small for 256 threads");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -121,6 +146,7 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
     char* const Vbuf = smem + NS * TILE_BYTES;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, ql = lane & 31, hi = lane >> 5;
+    const int rw = KS == 1 ? wave : (wave & 3), kh = KS == 1 ? 0 : (wave >> 2);  // row-wave, key half
 #ifdef UMFA_LAB_STAMPS
     unsigned long long stamp[6];
     stamp[0] = __builtin_amdgcn_s_memrealtime();
@@ -173,8 +199,8 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
 #endif
     }
     const uint32_t b = bh / p.H, h = bh % p.H;
-    const uint32_t q_row = qb * BM + wave * 32 + ql;
-    const uint32_t wave_q0 = qb * BM + wave * 32;
+    const uint32_t q_row = qb * BM + rw * 32 + ql;
+    const uint32_t wave_q0 = qb * BM + rw * 32;
     const int D = (int)p.D;
 
     // Hardware-bounds-checked buffer loads (T8): rows past the end of a (batch, head) slab and
@@ -222,7 +248,8 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
     // r = l / NCH, chunk slot c = l % NCH and therefore FETCHES source chunk c ^ swz(row) (rule 21: the swizzle
     // goes on the source address; k_off / v_off are involutions in the chunk index).
     constexpr int RPI = 1024 / (2 * DP);          // rows per wave-instruction
-    constexpr int IPW = TILE_BYTES / 1024 / 4;    // instructions per wave per tile (K and V each)
+    constexpr int IPW = TILE_BYTES / 1024 / (4 * KS);  // instructions per wave per tile (K and V each)
+    static_assert(!DMA || IPW >= 1, "tile too small for the workgroup's waves");
     constexpr int IPWR = DMA ? IPW : 1;
     int kdma[IPWR], vdma[IPWR];
     i32x4 k_srd, v_srd;
@@ -250,17 +277,18 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
         lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((LDS_AS char*)smem) + uw * IPW * 1024);
         // rows past Skv are range-checked away by the hardware; start from zeros so they can never hold NaNs
 #pragma unroll
-        for (int i = 0; i < 2 * NS * TILE_BYTES / 4096; ++i) *(i32x4*)(smem + i * 4096 + tid * 16) = i32x4{0, 0, 0, 0};
+        for (int i = 0; i < 2 * NS * TILE_BYTES / (NT * 16); ++i) *(i32x4*)(smem + i * (NT * 16) + tid * 16) = i32x4{0, 0, 0, 0};
         __syncthreads();
     }
     // which: 1 = K tile, 2 = V tile, 3 = both.  SPLIT_DMA: the V half is issued behind the QK^T MFMAs instead of back
     // to back with the K half (LDS-DMA instructions in a row stall the MFMA behind them, profiles/r1/lab_notes.md).
     // Same-box A/B: head_dim 256 (16 DMA instructions per wave per tile) 1132 -> 1001-1029 us at B2 H24 S4096,
     // head_dim 64 non-causal +2.5 %, head_dim 128 neutral, the tiny causal head_dim-64 case -3 % (left unsplit).
-    auto stage_load = [&](uint32_t t, int which = 3) {
+    auto stage_load = [&](uint32_t t, int which = 3, uint32_t tk_ahead = 0) {  // tk_ahead: the K tile requested is t + tk_ahead (PIPE)
         if constexpr (DMA) {
-            const int ktile = (int)(t * BN) * k_stride_b, vtile = (int)(t * BN) * v_stride_b;
-            const unsigned kdst = lds_wave + (t % NS) * TILE_BYTES, vdst = kdst + NS * TILE_BYTES;
+            const uint32_t tk = t + tk_ahead;
+            const int ktile = (int)(tk * BN) * k_stride_b, vtile = (int)(t * BN) * v_stride_b;
+            const unsigned kdst = lds_wave + (tk % NS) * TILE_BYTES, vdst = lds_wave + (t % NS) * TILE_BYTES + NS * TILE_BYTES;
 #pragma unroll
             for (int j = 0; j < IPW; ++j) {
                 if (which & 1)
@@ -403,21 +431,184 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
         t_end = hi1 < t_end ? hi1 : t_end;
         if (t_end < t_begin) t_end = t_begin;
     }
+    if constexpr (!PIPE) {
 #pragma unroll
-    for (int i = 0; i < NS - 1; ++i) stage_load(t_begin + i);  // (tiles past the end: all zeros, same instruction count)
-    stage_write(t_begin % NS, true);
-    __syncthreads();
+        for (int i = 0; i < NS - 1; ++i) stage_load(t_begin + i);  // (tiles past the end: all zeros, same instruction count)
+        stage_write(t_begin % NS, true);
+        __syncthreads();
+    }
 #ifdef UMFA_LAB_STAMPS
     stamp[1] = __builtin_amdgcn_s_memrealtime();
 #endif
 
+#ifdef UMFA_LAB_LOOP_STAMPS
+    // cycles of this wave: tile request issue | compute issue | wait for the next tile (+ V conversion) | barrier | of compute: until the
+    // last Q K^T MFMA is issued | from there until the first P V MFMA
+    uint32_t lp[6] = {0, 0, 0, 0, 0, 0};
+#ifdef UMFA_LAB_LOOP_STAMPS_FINE
+#define UMFA_LP_STAMP(x) __builtin_amdgcn_sched_barrier(0); const uint32_t x = (uint32_t)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0)
+#else
+#define UMFA_LP_STAMP(x) const uint32_t x = (uint32_t)__builtin_amdgcn_s_memtime()
+#endif
+#else
+#define UMFA_LP_STAMP(x)
+#endif
+    if constexpr (PIPE) {
+        // ---------------- software-pipelined sweep (see the template's comment) ----------------
+        const uint32_t ntiles_all = (p.Skv + BN - 1) / BN;
+        auto act = [&](uint32_t t) { return !CAUSAL || t * BN <= wave_q0 + 31; };
+        auto clampt = [&](uint32_t t) { return t < ntiles_all ? t : ntiles_all; };  // (a tile past the end reads as zeros whatever its index)
+        auto k_frags = [&](const char* Kt, V8 (&kf)[NKB][NKS]) {
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) kf[kb][ks] = *(const V8*)(Kt + k_off<DP>(32 * kb + ql, 2 * ks + hi));
+        };
+        auto qk = [&](const V8 (&kf)[NKB][NKS], f32x16 (&s)[NKB]) {
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) s[kb] = M::mma(kf[kb][ks], qf[ks], s[kb]);
+            }
+        };
+        // softmax of one tile's scores + P V; NEXT: the next tile's Q K^T (its K fragments in kf) is issued between the exponentials
+        auto tile = [&](f32x16 (&s)[NKB], const char* Vt, uint32_t key_base, bool edge, auto has_next, auto&& next) {
+            constexpr bool NEXT = decltype(has_next)::value;
+            PV8 va[NST];
+#pragma unroll
+            for (int st = 0; st < NST; ++st) va[st] = v_frag(Vt, 0, st);
+            if (edge) {
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const uint32_t key = key_base + 32 * kb + acc_row(r, hi);
+                        if (key >= p.Skv || (CAUSAL && key > q_row)) s[kb][r] = -INFINITY;
+                    }
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+            mx = max_xor32(mx * c2);
+            constexpr float TAU16 = 6.0f;  // the deferred reference of the ordinary loop below
+            const bool move = mx > m + TAU16;
+            float m_use = m;
+            if (__any(move)) {
+                m_use = move ? mx : m;
+                const float alpha = __builtin_amdgcn_exp2f(m - m_use);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) l4[j] *= alpha;
+#pragma unroll
+                for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
+                m = m_use;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NEXT) next();
+            PV8 pf[NST];
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], c2, -m_use));
+                    l4[r & 3] += e;
+                    pf[2 * kb + (r >> 3)][r & 7] = (PT)e;
+                }
+            if constexpr (NEXT) {
+                // one MFMA, then its share of the 3 vector instructions per score hipcc emits here (fma, exp, half a cvt_pk, half a packed add)
+                constexpr int NM = NKB * NKS, PER = (NKB * 16 * 3) / NM;
+#pragma unroll
+                for (int i = 0; i < NM; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, PER, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NDB; ++i) {
+                PV8 vb[NST];
+                if (i + 1 < NDB) {
+#pragma unroll
+                    for (int st = 0; st < NST; ++st) vb[st] = v_frag(Vt, i + 1, st);
+                }
+#pragma unroll
+                for (int st = 0; st < NST; ++st) acc[i] = MP::mma(va[st], pf[st], acc[i]);
+                if (i + 1 < NDB) {
+#pragma unroll
+                    for (int st = 0; st < NST; ++st) va[st] = vb[st];
+                }
+            }
+        };
+        // prologue: K(t_begin), V(t_begin) requested first (then the barrier), K(t_begin + 1) behind them
+        stage_load(t_begin, 3);
+        stage_write(t_begin % NS, true);
+        __syncthreads();
+        stage_load(t_begin, 1, 1);
+        f32x16 sA[NKB], sB[NKB];
+        if (act(t_begin)) {
+            V8 kf[NKB][NKS];
+            k_frags(Kbuf + (t_begin % NS) * TILE_BYTES, kf);
+            qk(kf, sA);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        auto step = [&](uint32_t t, f32x16 (&s_in)[NKB], f32x16 (&s_out)[NKB]) {
+            const char* Kn = Kbuf + ((t + 1) % NS) * TILE_BYTES;  // K(t + 1): landed before the barrier that ended step t - 1
+            const char* Vt = Vbuf + (t % NS) * TILE_BYTES;
+            const uint32_t key_base = t * BN;
+            // K(t + 2) into K(t)'s slot (S(t) exists), V(t + 1) into V(t - 1)'s
+            {
+                const uint32_t tv = clampt(t + 1), tk = clampt(t + 2);
+                const int ktile = (int)(tk * BN) * k_stride_b, vtile = (int)(tv * BN) * v_stride_b;
+                const unsigned kdst = lds_wave + (t % NS) * TILE_BYTES, vdst = lds_wave + ((t + 1) % NS) * TILE_BYTES + NS * TILE_BYTES;
+#pragma unroll
+                for (int j = 0; j < IPW; ++j) {
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                                 ::"s"(kdst + j * 1024), "v"(kdma[j] + ktile), "s"(k_srd) : "memory");
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                                 ::"s"(vdst + j * 1024), "v"(vdma[j] + vtile), "s"(v_srd) : "memory");
+                }
+            }
+            const bool a_cur = act(t), a_next = t + 1 < t_end && act(t + 1);
+            const bool edge = (key_base + BN > p.Skv) || (CAUSAL && key_base + BN - 1 > wave_q0);
+            if (a_cur && a_next && !edge) {
+                V8 kf[NKB][NKS];
+                k_frags(Kn, kf);
+                tile(s_in, Vt, key_base, false, std::true_type{}, [&]() { qk(kf, s_out); });
+            } else {
+                if (a_next) {
+                    V8 kf[NKB][NKS];
+                    k_frags(Kn, kf);
+                    qk(kf, s_out);
+                }
+                if (a_cur) tile(s_in, Vt, key_base, edge, std::false_type{}, []() {});
+            }
+            stage_write((t + 1) % NS);
+            __syncthreads();
+        };
+        for (uint32_t t = t_begin; t < t_end; t += 2) {
+            step(t, sA, sB);
+            if (t + 1 < t_end) step(t + 1, sB, sA);
+        }
+    } else {
     for (uint32_t t = t_begin; t < t_end; ++t) {
+        UMFA_LP_STAMP(lp_t0);
         const int cur = t % NS;
-        const char* Kt = Kbuf + cur * TILE_BYTES;
-        const char* Vt = Vbuf + cur * TILE_BYTES;
-        const uint32_t key_base = t * BN;
+        // (KS = 2: this wave's half of the tile -- both swizzles depend on row bits below 32 / 4 only, so a whole number of
+        // 32-key blocks is a pure byte offset)
+        const char* Kt = Kbuf + cur * TILE_BYTES + kh * (32 * NKBW) * (2 * DP);
+        const char* Vt = Vbuf + cur * TILE_BYTES + kh * (32 * NKBW) * (2 * DP);
+        const uint32_t key_base = t * BN + kh * (32 * NKBW);  // first key of this wave's part of the tile
+        constexpr uint32_t BNW = BN / KS;                     // keys of it
         // wave-uniform: is any part of this tile visible to this wave's rows?
         bool active = !CAUSAL || key_base <= wave_q0 + 31;
+        if (KS == 2) active = active && key_base < p.Skv;  // (the second half of a ragged last tile may hold no key at all)
         int mflag = 0;  // 1: every element of this wave's tile is masked (skip), 2: none is (no mask reads)
         if (HAS_MASK && mf_row) {
             if (t == t_begin || (t & 63) == 0) {
@@ -428,7 +619,7 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
             active = active && mflag != 1;
         } else if (HAS_MASK && p.mask_kind == MK_WINDOW) {
             // sliding window: the flags of this wave's 32 rows x this tile's keys are arithmetic
-            const uint32_t k1 = key_base + BN - 1, r1 = wave_q0 + 31;
+            const uint32_t k1 = key_base + BNW - 1, r1 = wave_q0 + 31;
             if (k1 + p.win_left < wave_q0 || key_base > r1 + p.win_right) mflag = 1;
             else if (key_base + p.win_left >= r1 && k1 <= wave_q0 + p.win_right) mflag = 2;
             active = active && mflag != 1;
@@ -438,12 +629,13 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
         // here, the V half behind the QK^T MFMAs of an active tile
         stage_load(t + NS - 1, (SPLIT_DMA && active) ? 1 : 3);
 #endif
+        UMFA_LP_STAMP(lp_t1);
 
         if (active) {
             // ---------------- S^T = K Q^T ----------------
-            f32x16 s[NKB];
+            f32x16 s[NKBW];
 #pragma unroll
-            for (int kb = 0; kb < NKB; ++kb) {
+            for (int kb = 0; kb < NKBW; ++kb) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[kb][r] = 0.0f;
 #pragma unroll
@@ -463,18 +655,22 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
                 __builtin_amdgcn_sched_barrier(0);
             }
 #endif
+#ifdef UMFA_LAB_LOOP_STAMPS_FINE
+            UMFA_LP_STAMP(lp_tq);
+            lp[4] += lp_tq - lp_t1;
+#endif
             // first V^T fragments requested before the softmax so their LDS latency hides under it
-            PV8 va[NST];
+            PV8 va[NSTW];
 #pragma unroll
-            for (int st = 0; st < NST; ++st) va[st] = v_frag(Vt, 0, st);
+            for (int st = 0; st < NSTW; ++st) va[st] = v_frag(Vt, 0, st);
 
             // ---------------- online softmax (log2 domain) ----------------
-            const bool edge = (key_base + BN > p.Skv) || (CAUSAL && key_base + BN - 1 > wave_q0);
+            const bool edge = (key_base + BNW > p.Skv) || (CAUSAL && key_base + BNW - 1 > wave_q0);
             float mx = -INFINITY;
             if (HAS_MASK && mvec && mflag != 2) {
                 // registers 4g .. 4g+3 of a 32-key block are keys 8g + 4hi + 0..3: one aligned dword of the mask row
 #pragma unroll
-                for (int kb = 0; kb < NKB; ++kb)
+                for (int kb = 0; kb < NKBW; ++kb)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const uint32_t key0 = key_base + 32 * kb + 8 * g + 4 * hi;
@@ -510,7 +706,7 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
             } else if (HAS_MASK && mflag == 2 && !edge) {
                 // fully open interior tile: nothing to read, nothing to compare
 #pragma unroll
-                for (int kb = 0; kb < NKB; ++kb)
+                for (int kb = 0; kb < NKBW; ++kb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         s[kb][r] *= c2;
@@ -518,7 +714,7 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
                     }
             } else if (HAS_MASK) {
 #pragma unroll
-                for (int kb = 0; kb < NKB; ++kb)
+                for (int kb = 0; kb < NKBW; ++kb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const uint32_t key = key_base + 32 * kb + acc_row(r, hi);
@@ -533,7 +729,7 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
             } else {
                 if (edge) {
 #pragma unroll
-                    for (int kb = 0; kb < NKB; ++kb)
+                    for (int kb = 0; kb < NKBW; ++kb)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const uint32_t key = key_base + 32 * kb + acc_row(r, hi);
@@ -541,7 +737,7 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
                         }
                 }
 #pragma unroll
-                for (int kb = 0; kb < NKB; ++kb)
+                for (int kb = 0; kb < NKBW; ++kb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
                 mx *= c2;  // scale > 0 on this path
@@ -554,10 +750,12 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
             // A row that has seen no key yet has m = -inf: its first finite max always moves it.
             constexpr float TAU16 = 6.0f;
             const bool move = mx > m + TAU16;
-            float m_use = (HAS_MASK && m == -INFINITY) ? 0.0f : m;
+            // (rows that have seen no key: under a mask tensor, and -- KS = 2 -- the rows of a causal diagonal block's second key half)
+            constexpr bool EMPTY_ROWS = HAS_MASK || KS == 2;
+            float m_use = (EMPTY_ROWS && m == -INFINITY) ? 0.0f : m;
             if (__any(move)) {
                 const float m_new = move ? mx : m;
-                m_use = (HAS_MASK && m_new == -INFINITY) ? 0.0f : m_new;
+                m_use = (EMPTY_ROWS && m_new == -INFINITY) ? 0.0f : m_new;
                 const float alpha = __builtin_amdgcn_exp2f(m - m_use);  // exactly 1 for the rows that stay
 #pragma unroll
                 for (int j = 0; j < 4; ++j) l4[j] *= alpha;
@@ -567,9 +765,9 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
                     for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
                 m = m_new;
             }
-            PV8 pf[NST];
+            PV8 pf[NSTW];
 #pragma unroll
-            for (int kb = 0; kb < NKB; ++kb)
+            for (int kb = 0; kb < NKBW; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
 #ifdef UMFA_ABL_NO_EXP
@@ -582,35 +780,48 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
                     pf[2 * kb + (r >> 3)][r & 7] = (PT)e;
                 }
 
+#ifdef UMFA_LAB_LOOP_STAMPS_FINE
+            UMFA_LP_STAMP(lp_ts);
+            lp[5] += lp_ts - lp_tq;
+#endif
             // ---------------- O^T += V^T P^T (fragments of block i+1 requested before block i's MFMAs) ----
 #pragma unroll
             for (int i = 0; i < NDB; ++i) {
-                PV8 vb[NST];
+                PV8 vb[NSTW];
                 if (i + 1 < NDB) {
 #pragma unroll
-                    for (int st = 0; st < NST; ++st) vb[st] = v_frag(Vt, i + 1, st);
+                    for (int st = 0; st < NSTW; ++st) vb[st] = v_frag(Vt, i + 1, st);
                 }
 #ifdef UMFA_ABL_NO_PV
 #pragma unroll
-                for (int st = 0; st < NST; ++st) acc[i][st] += (float)va[st][0] * (float)pf[st][0];
+                for (int st = 0; st < NSTW; ++st) acc[i][st] += (float)va[st][0] * (float)pf[st][0];
 #else
 #pragma unroll
-                for (int st = 0; st < NST; ++st) acc[i] = MP::mma(va[st], pf[st], acc[i]);
+                for (int st = 0; st < NSTW; ++st) acc[i] = MP::mma(va[st], pf[st], acc[i]);
 #endif
                 if (i + 1 < NDB) {
 #pragma unroll
-                    for (int st = 0; st < NST; ++st) va[st] = vb[st];
+                    for (int st = 0; st < NSTW; ++st) va[st] = vb[st];
                 }
             }
         }
 
+        UMFA_LP_STAMP(lp_t2);
 #ifndef UMFA_ABL_NO_LOAD
         stage_write((t + 1) % NS);
 #endif
+        UMFA_LP_STAMP(lp_t3);
 #ifndef UMFA_ABL_NO_BARRIER
         __syncthreads();
 #endif
+#ifdef UMFA_LAB_LOOP_STAMPS
+        {
+            UMFA_LP_STAMP(lp_t4);
+            lp[0] += lp_t1 - lp_t0; lp[1] += lp_t2 - lp_t1; lp[2] += lp_t3 - lp_t2; lp[3] += lp_t4 - lp_t3;
+        }
+#endif
     }
+    }  // !PIPE
 
 #ifdef UMFA_LAB_STAMPS
     stamp[2] = __builtin_amdgcn_s_memrealtime();
@@ -619,7 +830,38 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
     // ---------------- epilogue ----------------
     float l = (l4[0] + l4[1]) + (l4[2] + l4[3]);
     float lt = l + xor32(l);
-    if (nparts > 1) {
+    if constexpr (KS == 2) {
+        // the two key halves of a row-wave meet in LDS: half 1 publishes its un-normalised (O^T, m, l), half 0 folds it in
+        // (the split-KV fold's arithmetic) and stores.  The tile area is free: every LDS-DMA write has landed (the loop's last
+        // stage_write waited vmcnt(0)) and the loop's last barrier is behind every wave's last tile read.
+        constexpr int NREG = 16 * NDB + 2;
+        float* const ex = (float*)smem + rw * (NREG * 64) + lane;
+        if constexpr (NS > 2) {  // the ring's youngest requests (tiles past the end) are still on their way into the tile area
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if (kh == 1) {
+#pragma unroll
+            for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ex[(16 * i + r) * 64] = acc[i][r];
+            ex[(16 * NDB) * 64] = m;
+            ex[(16 * NDB + 1) * 64] = lt;
+        }
+        __syncthreads();
+        if (kh == 1) return;
+        const float mo = ex[(16 * NDB) * 64], lo = ex[(16 * NDB + 1) * 64];
+        const float mn = fmaxf(m, mo);
+        const float mu = mn == -INFINITY ? 0.0f : mn;
+        const float a0 = __builtin_amdgcn_exp2f(m - mu), a1 = __builtin_amdgcn_exp2f(mo - mu);
+#pragma unroll
+        for (int i = 0; i < NDB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = acc[i][r] * a0 + ex[(16 * i + r) * 64] * a1;
+        lt = lt * a0 + lo * a1;
+        m = mn;
+    }
+    if (KS == 1 && nparts > 1) {
         // Split-KV combine (cdna_hip_programming.md Guideline 16, counter form): every part publishes its
         // un-normalised (O^T, m, l) with plain stores -> vmcnt(0) -> barrier -> ONE agent-scope release ->
         // ticket; the part that draws the last ticket acquires once and folds the others into its registers.
@@ -733,6 +975,10 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
         unsigned hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         dbg[7] = hwid;
+#ifdef UMFA_LAB_LOOP_STAMPS
+        dbg = (unsigned long long*)p.part_buf + (size_t)gridDim.x * 8 + (size_t)blockIdx.x * 6;
+        for (int i = 0; i < 6; ++i) dbg[i] = lp[i];
+#endif
     }
 #endif
 }

@@ -6,19 +6,34 @@
 
 namespace umfa {
 
-template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT, bool DMA, int BN, int PV16 = 0>
+template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT, bool DMA, int BN, int PV16 = 0, int KS = 1, int PIPE = 0>
 static inline hipError_t launch_dma(const FwdParams& pin, hipStream_t stream) {
     FwdParams p = pin;
     const uint32_t nqb = (p.Sq + 127) / 128;
     const uint32_t items = nqb * p.B * p.H;
-    if (p.nsplit < 2 || !p.part_buf || !p.part_cnt) { p.n_full = items; p.nsplit = 1; }
+    if (KS != 1 || PIPE || p.nsplit < 2 || !p.part_buf || !p.part_cnt) { p.n_full = items; p.nsplit = 1; }
     const uint32_t grid = p.n_full + (items - p.n_full) * p.nsplit;
     // (p.part_cnt is zero on entry and on exit: the runtime zeroes a ticket block once, the folding workgroup resets its word)
-    const size_t lds = 4 * BN * DP * 2;  // 2 x ring depth (fa_fwd_16_kernel.h NS = 2) tiles
-    auto kfn = fa_fwd16_kernel<T, DP, CAUSAL, HAS_MASK, OUT, DMA, BN, PV16>;
+    // 2 x ring depth (fa_fwd_16_kernel.h NS: 2, key-split form 4) tiles; the key halves' exchange (4 x 34 x 256 bytes at head_dim 64) fits inside
+    const size_t lds = (KS == 2 ? 8 : 4) * BN * DP * 2;
+    static_assert(KS == 1 || 8 * BN * DP * 2 >= 4 * (16 * (DP / 32) + 2) * 256, "exchange area");
+    auto kfn = fa_fwd16_kernel<T, DP, CAUSAL, HAS_MASK, OUT, DMA, BN, PV16, KS, PIPE>;
     if (hipError_t e = ensure_dynamic_lds((const void*)kfn, lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(256 * KS), lds, stream, p);
     return hipGetLastError();
+}
+
+// The two other forms of the head_dim-64 kernel (fa_fwd_16_kernel.h): calls whose K / V rows are exactly 64 elements (LDS-DMA
+// staging), without a mask tensor / window, and without a split-KV plan.
+//   1  software-pipelined loop (PIPE: the next tile's Q K^T inside this tile's softmax) -- bit-identical results, 0.80 ... 1.00 x the plain form's speed
+//   2  key-split (KS = 2: eight waves per workgroup, option "ksplit") -- 0.94 ... 1.07 x
+static inline int fwd16_d64_form(const FwdParams& p) {
+#ifndef UMFA_D64_FORMS
+    return 0;  // neither form is in the product build: both measured null or slower (profiles/r4/lab_notes.md section 2b); -DUMFA_D64_FORMS builds them in
+#endif
+    if (p.D != 64 || p.mask_kind != MK_NONE || tuning().no_dma.load(std::memory_order_relaxed) || !(p.nsplit < 2 || !p.part_buf || !p.part_cnt)) return 0;
+    if (tuning().ksplit.load(std::memory_order_relaxed)) return 2;
+    return tuning().no_pipe.load(std::memory_order_relaxed) ? 0 : 1;
 }
 
 static inline bool dma_enabled() { return !tuning().no_dma.load(std::memory_order_relaxed); }

@@ -11,6 +11,17 @@ hipError_t launch_fwd16_pv(const FwdParams& p, hipStream_t stream) {
     // runtime's cast pre-pass wrote, staged like K.  64-key tiles throughout (the 32-key / three-workgroup variant of the bf16
     // P V kernel has no room for V staging registers).
     const bool dma = (int)p.D == DP && dma_enabled();
+    if constexpr (DP == 64 && !HAS_MASK) {
+#ifdef UMFA_D64_FORMS
+        const int form = dma ? fwd16_d64_form(p) : 0;
+        if (form == 1)
+            return p.pv16 == 2 ? launch_dma<__bf16, DP, CAUSAL, HAS_MASK, OUT, true, 64, 2, 1, 1>(p, stream)
+                               : launch_dma<__bf16, DP, CAUSAL, HAS_MASK, OUT, true, 64, 1, 1, 1>(p, stream);
+        if (form == 2)
+            return p.pv16 == 2 ? launch_dma<__bf16, DP, CAUSAL, HAS_MASK, OUT, true, 64, 2, 2>(p, stream)
+                               : launch_dma<__bf16, DP, CAUSAL, HAS_MASK, OUT, true, 64, 1, 2>(p, stream);
+#endif
+    }
     if (p.pv16 == 2)
         return dma ? launch_dma<__bf16, DP, CAUSAL, HAS_MASK, OUT, true, 64, 2>(p, stream) : launch_dma<__bf16, DP, CAUSAL, HAS_MASK, OUT, false, 64, 2>(p, stream);
     return dma ? launch_dma<__bf16, DP, CAUSAL, HAS_MASK, OUT, true, 64, 1>(p, stream) : launch_dma<__bf16, DP, CAUSAL, HAS_MASK, OUT, false, 64, 1>(p, stream);

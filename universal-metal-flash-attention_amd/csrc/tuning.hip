@@ -57,6 +57,8 @@ Tuning& tuning() {
         x->pv_fp16.store(env_int("UMFA_PV_FP16", 1) != 0);  // bf16 forward: P V in fp16 (inside 1e-3) unless switched off
         x->bwd_ds_store.store(env_flag("UMFA_BWD_DS_STORE"));
         x->no_w64_mask.store(env_flag("UMFA_NO_W64_MASK"));
+        x->ksplit.store(env_flag("UMFA_KSPLIT"));
+        x->no_pipe.store(env_flag("UMFA_NO_PIPE"));
         return x;
     }();
     return *t;
@@ -87,7 +89,7 @@ bool set_tuning(const char* name, const char* value) {
         {"no_mask_flags", &t.no_mask_flags, true}, {"bwd_exact", &t.bwd_exact, true}, {"bwd_dq", &t.bwd_dq, false},
         {"bwd_persist", &t.bwd_persist, true}, {"bwd_separate_delta", &t.bwd_separate_delta, true},
         {"no_split", &t.no_split, true}, {"force_split", &t.force_split, false}, {"no_dma", &t.no_dma, true},
-        {"bn64", &t.bn64, true}, {"pv_fp16", &t.pv_fp16, true}, {"bwd_ds_store", &t.bwd_ds_store, true}, {"no_w64_mask", &t.no_w64_mask, true},
+        {"bn64", &t.bn64, true}, {"pv_fp16", &t.pv_fp16, true}, {"bwd_ds_store", &t.bwd_ds_store, true}, {"no_w64_mask", &t.no_w64_mask, true}, {"ksplit", &t.ksplit, true}, {"no_pipe", &t.no_pipe, true},
     };
     for (auto& e : tab)
         if (!strcmp(name, e.n)) {
@@ -112,7 +114,7 @@ bool get_tuning(const char* name, char* out, size_t n) {
             {"force_w64", &t.force_w64}, {"no_w64", &t.no_w64}, {"w64_grid", &t.w64_grid}, {"w64_skew", &t.w64_skew},
             {"no_mask_flags", &t.no_mask_flags}, {"bwd_exact", &t.bwd_exact}, {"bwd_dq", &t.bwd_dq}, {"bwd_persist", &t.bwd_persist},
             {"bwd_separate_delta", &t.bwd_separate_delta}, {"no_split", &t.no_split}, {"force_split", &t.force_split},
-            {"no_dma", &t.no_dma}, {"bn64", &t.bn64}, {"pv_fp16", &t.pv_fp16}, {"bwd_ds_store", &t.bwd_ds_store}, {"no_w64_mask", &t.no_w64_mask},
+            {"no_dma", &t.no_dma}, {"bn64", &t.bn64}, {"pv_fp16", &t.pv_fp16}, {"bwd_ds_store", &t.bwd_ds_store}, {"no_w64_mask", &t.no_w64_mask}, {"ksplit", &t.ksplit}, {"no_pipe", &t.no_pipe},
         };
         const std::atomic<int>* v = nullptr;
         for (auto& e : tab)
