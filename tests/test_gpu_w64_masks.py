@@ -43,6 +43,8 @@ def _mask(kind, B, H, Sq, Skv, seed):
         return (j[None] < lens[:, None, None])[:, None]
     if kind == "blockdiag":                    # [1, 1, Sq, Skv]: documents of 192 rows / 160 keys (not on the tile grid)
         return ((i // 192) == (j // 160))[None, None]
+    if kind == "one_tile":                     # [1, 1, 1, Skv]: every block lists ONE key tile (fewer shared steps than workgroups)
+        return (j < 10)[None, None]
     if kind == "all_open":
         return torch.ones(1, 1, Sq, Skv, dtype=torch.bool, device="cuda")
     if kind == "empty_rows_and_blocks":        # rows 5.., a whole 256-row block and a whole head see nothing
@@ -97,6 +99,41 @@ def test_w64_mask_tensor_vs_oracle(kind, dt, shape, umfa_opts):
     # 16-bit output epilogue
     o16 = umfa_torch.attention_forward(q, k, v, mask=m)
     assert o16.dtype == dt and float((o16.float() - o).abs().max()) <= 2.0 ** -8 * float(o.abs().max()) * 1.01
+
+
+@pytest.mark.parametrize("kind", ["random_per_head", "padding", "blockdiag", "empty_rows_and_blocks", "strided_view", "one_tile"])
+@pytest.mark.parametrize("shape,grid", [((2, 2, 512, 512), 3), ((2, 2, 512, 512), 5), ((1, 3, 1280, 777), 4), ((1, 3, 1280, 777), 7), ((1, 3, 1280, 777), 14)])
+def test_w64_mask_cut_blocks(kind, shape, grid, umfa_opts):
+    """more blocks than workgroups with a remainder: the last n % grid blocks are cut ALONG THEIR TILE LISTS into grid equal slices (the
+    running sums of their list lengths come from mask_prefix_kernel) and folded like the unmasked kernel's cut items.  Forced here with
+    the lab option w64_grid on small shapes; the FLUX-shape test below meets it by itself (384 blocks on 256 CUs)."""
+    import umfa_torch
+    B, H, Sq, Skv = shape
+    torch.manual_seed(Sq + Skv + grid)
+    q = torch.randn(B, H, Sq, 128, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(B, H, Skv, 128, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn(B, H, Skv, 128, device="cuda", dtype=torch.bfloat16)
+    m = _mask(kind, B, H, Sq, Skv, seed=Sq + grid)
+    umfa_opts(force_w64=1, w64_grid=grid)
+    o, lse = umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32, return_lse=True)
+    kern = umfa_torch.last_kernel()
+    assert kern == "fa_fwd16_w64<bf16,128,pv16,mask>", kern
+    assert torch.equal(o, umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32))  # whoever folds: the same bits
+    mfull = m.expand(B, H, Sq, Skv)
+    ref, ref_lse = _oracle().sdpa_forward(npy(q), npy(k), npy(v), mask=np.ascontiguousarray(mfull.cpu().numpy()),
+                                          mask_type=_oracle().MASK_BOOL, return_lse=True)
+    on = o.cpu().numpy()
+    assert np.isfinite(on).all()
+    check_forward(on, ref, torch.bfloat16, kern, f"w64_mask_cut_{kind}")
+    dead = ~mfull.any(-1).cpu().numpy()
+    ln = lse.cpu().numpy().reshape(B, H, Sq)
+    assert (on[dead] == 0).all() and np.isneginf(ln[dead]).all()
+    assert np.abs(ln[~dead] - ref_lse[~dead]).max() < 2e-2
+    # whole blocks only (grid = number of blocks): a part rounds its P against its own running reference, so the two results differ like
+    # two fp16-P kernels do -- each within half an ulp of P at 1.0 of the truth
+    umfa_opts(force_w64=1, w64_grid=0)
+    o_whole = umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32)
+    assert float((o - o_whole).abs().max()) <= 2.0 ** -10 * float(o_whole.abs().max())
 
 
 @pytest.mark.parametrize("kind", ["padding", "blockdiag"])

@@ -36,7 +36,7 @@ def graph_ms(fn, n=10):
     return sorted(ts)[len(ts) // 2]
 
 
-for (B, H, S) in [(1, 24, 4096), (2, 16, 4096), (4, 16, 4096), (1, 16, 8192)]:
+for (B, H, S) in [(1, 24, 4096), (1, 20, 4096), (3, 24, 4096), (2, 16, 4096), (4, 16, 4096), (1, 16, 8192)]:
     torch.manual_seed(0)
     q, k, v = (torch.randn(B, H, S, 128, device="cuda", dtype=torch.bfloat16) for _ in range(3))
     o = torch.empty(B, H, S, 128, device="cuda", dtype=torch.float32)
@@ -47,10 +47,13 @@ for (B, H, S) in [(1, 24, 4096), (2, 16, 4096), (4, 16, 4096), (1, 16, 8192)]:
              "random_80pct [1,H,S,S]": torch.rand(1, H, S, S, device="cuda") < 0.8}
     for name, m in masks.items():
         row = {"shape": f"B{B} H{H} S{S}", "mask": name, "visible": round(float(m.float().mean()), 4)}
+        outs = {}
         for route, opts in (("w64", {}), ("r128", {"no_w64_mask": 1})):
             with umfa_torch.options(**opts):
                 row[route + "_ms"] = round(graph_ms(lambda: umfa_torch.attention_forward(q, k, v, mask=m, out=o)), 5)
                 row[route + "_kernel"] = umfa_torch.last_kernel()
+                outs[route] = o.clone()
+        row["max_rel_diff"] = float((outs["w64"] - outs["r128"]).abs().max() / outs["r128"].abs().max())
         row["r128_over_w64"] = round(row["r128_ms"] / row["w64_ms"], 3)
         print(json.dumps(row), flush=True)
     row = {"shape": f"B{B} H{H} S{S}", "mask": "none", "ms": round(graph_ms(lambda: umfa_torch.attention_forward(q, k, v, out=o)), 5), "kernel": umfa_torch.last_kernel()}

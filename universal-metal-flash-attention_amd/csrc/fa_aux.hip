@@ -606,10 +606,33 @@ __global__ __launch_bounds__(64) void mask_list_kernel(const uint8_t* wflag, uin
     }
 }
 
+// Running sums of the list lengths of the last n_items % G blocks (the ones the attention kernel's G workgroups share, in item order):
+// prefix[0] = 0, prefix[j + 1] = prefix[j] + cnt(block first + j).  One workgroup; fewer than 512 blocks.
+__global__ __launch_bounds__(512) void mask_prefix_kernel(const uint32_t* cnt, uint32_t* prefix, uint32_t n_items, uint32_t G, uint32_t nqb, uint32_t H,
+                                                          uint32_t mk_bs, uint32_t mk_hs) {
+    __shared__ uint32_t sc[512];
+    const uint32_t rem = n_items % G, first = n_items - rem, t = threadIdx.x;
+    uint32_t c = 0;
+    if (t < rem) {
+        const uint32_t item = first + t, bh = item / nqb;
+        c = cnt[((bh / H) * mk_bs + (bh % H) * mk_hs) * nqb + item % nqb];
+    }
+    sc[t] = c;
+    __syncthreads();
+    for (uint32_t off = 1; off < 512; off <<= 1) {
+        const uint32_t add = t >= off ? sc[t - off] : 0u;
+        __syncthreads();
+        sc[t] += add;
+        __syncthreads();
+    }
+    if (t == 0) prefix[0] = 0;
+    if (t < rem) prefix[t + 1] = sc[t];
+}
+
 size_t mask_pack_bytes(const FwdParams& p) {
     const uint64_t Bm = p.ms[0] ? p.B : 1, Hm = p.ms[1] ? p.H : 1, nrb64 = (p.Sq + 63) / 64, nqb = (p.Sq + 255) / 256, T = (p.Skv + 63) / 64;
     const uint64_t slabs = Bm * Hm;
-    return (size_t)(slabs * nrb64 * T * 512 + ((slabs * nrb64 * T + 255) & ~255ull) + slabs * nqb * T * 8 + ((slabs * nqb * 4 + 255) & ~255ull) + 1024);
+    return (size_t)(slabs * nrb64 * T * 512 + ((slabs * nrb64 * T + 255) & ~255ull) + slabs * nqb * T * 8 + ((slabs * nqb * 4 + 255) & ~255ull) + 1024 + 2304);
 }
 
 hipError_t launch_mask_pack(FwdParams& p, void* scratch, hipStream_t stream) {
@@ -622,6 +645,7 @@ hipError_t launch_mask_pack(FwdParams& p, void* scratch, hipStream_t stream) {
     uint8_t* wflag = (uint8_t*)(base + total * 512);
     uint32_t* list = (uint32_t*)(base + total * 512 + ((total + 255) & ~255ull));
     uint32_t* cnt = (uint32_t*)((char*)list + slabs * nqb * T * 8);
+    uint32_t* prefix = (uint32_t*)((char*)cnt + ((slabs * nqb * 4 + 255) & ~255ull));
     const bool vec16 = p.ms[3] == 1 && (p.Skv & 15) == 0 && ((p.ms[0] | p.ms[1] | p.ms[2]) & 15) == 0 && ((uintptr_t)p.mask & 15) == 0;
     if (vec16) hipLaunchKernelGGL(mask_pack_kernel<true>, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream, p, bits, wflag, Bm, Hm, nrb64, T);
     else hipLaunchKernelGGL(mask_pack_kernel<false>, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream, p, bits, wflag, Bm, Hm, nrb64, T);
@@ -629,6 +653,13 @@ hipError_t launch_mask_pack(FwdParams& p, void* scratch, hipStream_t stream) {
     p.mk_bits = bits; p.mk_list = list; p.mk_cnt = cnt;
     p.mk_bs = p.ms[0] ? Hm : 0; p.mk_hs = p.ms[1] ? 1 : 0;  // slab index of (b, h) = b * mk_bs + h * mk_hs
     p.mk_nrb64 = nrb64; p.mk_T = T;
+    p.mk_prefix = nullptr;
+    const uint32_t n_items = p.B * p.H * nqb, G = fwd_w64_grid(p);
+    if (G && n_items % G) {
+        if (G > 512) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(mask_prefix_kernel, dim3(1), dim3(512), 0, stream, cnt, prefix, n_items, G, nqb, p.H, p.mk_bs, p.mk_hs);
+        p.mk_prefix = prefix;
+    }
     return hipGetLastError();
 }
 

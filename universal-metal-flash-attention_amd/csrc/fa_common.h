@@ -66,6 +66,7 @@ struct FwdParams {
     const uint32_t* mk_list;
     const uint32_t* mk_cnt;
     uint32_t mk_bs, mk_hs, mk_nrb64, mk_T;
+    const uint32_t* mk_prefix;  // running sums of the list lengths of the blocks the one-wave-per-SIMD mask kernel shares between workgroups
     // fused rotary embedding of Q (umfa_rope_attention_forward_stream): fp32 tables [Sq, D] (or [B, Sq, D] with
     // rope_tb = Sq * D), pair-duplicated, applied to the Q fragments right after their load; K arrives already rotated
     const float* rope_cos;

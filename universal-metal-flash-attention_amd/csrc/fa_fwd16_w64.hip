@@ -52,6 +52,7 @@ struct W64Params {
     const uint32_t* mk_list;
     const uint32_t* mk_cnt;
     uint32_t mk_bs, mk_hs, mk_nrb64;
+    const uint32_t* mk_prefix;  // [n_items % grid + 1] running sums of the shared blocks' list lengths (fa_aux.hip mask_prefix_kernel)
 };
 
 // ---- asm-owned accumulator registers: helpers with literal register numbers (generated)
@@ -326,10 +327,13 @@ bool fwd_w64_supported(const FwdParams& p) {
 }
 
 static uint32_t w64_grid(const FwdParams& p) {
-    if (p.mask_kind == MK_BOOL) {  // mask tensors: whole items, one workgroup per CU at most
+    if (p.mask_kind == MK_BOOL) {  // mask tensors: one workgroup per CU at most; whole blocks in rounds, the last n % grid blocks cut along their tile lists
         const uint64_t items = (uint64_t)p.B * p.H * ((p.Sq + 255) / 256);
         const uint64_t cus = (uint64_t)w64_cu_count();
-        return (uint32_t)(items < cus ? items : cus);
+        if (const int gi = tuning().w64_grid.load(std::memory_order_relaxed)) {  // lab / tests: force the number of workgroups
+            if (gi > 0 && (uint64_t)gi <= cus && (uint64_t)gi <= items && gi <= 512) return (uint32_t)gi;
+        }
+        return (uint32_t)(items < cus ? items : (cus < 512 ? cus : 512));  // (the shared blocks' running sums sit in 2 KiB of LDS)
     }
     const bool pairs = p.causal && !w64_is_window(p);  // (a causal window is a window with right = 0: linear schedule)
     uint64_t total = (uint64_t)p.B * p.H * ((p.Sq + 255) / 256) * w64_tiles_per_item(p);  // (item, key tile) steps
@@ -350,6 +354,8 @@ static uint32_t w64_grid(const FwdParams& p) {
     return total < cus ? (uint32_t)total : cus;  // never more workgroups than steps: every slice is non-empty
 }
 
+uint32_t fwd_w64_grid(const FwdParams& p) { return w64_grid(p); }
+
 FwdW64Plan fwd_w64_plan(const FwdParams& p) {
     FwdW64Plan plan;
     const uint32_t items = p.B * p.H * ((p.Sq + 255) / 256);
@@ -362,7 +368,8 @@ FwdW64Plan fwd_w64_plan(const FwdParams& p) {
 template <typename KFN>
 static hipError_t launch_w64_kernel(KFN kfn, const FwdParams& p, const W64Params& wp, hipStream_t stream) {
     const uint32_t grid = w64_grid(p);
-    const size_t lds = 65536 + 4 * 32 * (512 + 16) + 64 + 4096 + 8192;  // K/V rings + per-wave output staging + flag / ticket words + the mask kernels' bit-word ring and tile list
+    // K/V rings + per-wave output staging + flag / ticket words + the mask kernels' bit-word ring, tile list and shared-block running sums
+    const size_t lds = 65536 + 4 * 32 * (512 + 16) + 64 + 4096 + 8192 + 2048 + 64;
     if (hipError_t e = ensure_dynamic_lds((const void*)kfn, lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, stream, wp);
     return hipGetLastError();
@@ -389,6 +396,8 @@ hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cn
         if (!p.mk_bits || !p.mk_list || !p.mk_cnt) return hipErrorInvalidValue;  // runtime.hip packs the mask first (launch_mask_pack)
         wp.mk_bits = p.mk_bits; wp.mk_list = p.mk_list; wp.mk_cnt = p.mk_cnt;
         wp.mk_bs = p.mk_bs; wp.mk_hs = p.mk_hs; wp.mk_nrb64 = p.mk_nrb64;
+        wp.mk_prefix = p.mk_prefix;
+        if (wp.n_items % w64_grid(p) != 0 && !p.mk_prefix) return hipErrorInvalidValue;
         wp.lazy = 0;  // the max chain: which rows have keys in a segment is not arithmetic (kernel: MASKT)
     }
     if (rope && p.out_prec != p.in_prec) return hipErrorNotSupported;  // fused-RoPE instantiations: O in the operand type only (runtime.hip asks first)

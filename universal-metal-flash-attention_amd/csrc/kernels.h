@@ -50,6 +50,7 @@ struct FwdW64Plan {
     size_t buf_bytes, cnt_bytes;
 };
 bool fwd_w64_supported(const FwdParams& p);
+uint32_t fwd_w64_grid(const FwdParams& p);  // workgroups launch_fwd_w64 will start for this call
 FwdW64Plan fwd_w64_plan(const FwdParams& p);
 hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cnt, hipStream_t stream, const char** name);
 
