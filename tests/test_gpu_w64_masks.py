@@ -158,6 +158,33 @@ def test_w64_mask_flux_shape_rows(kind, umfa_opts):
     assert torch.equal(o, umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32))
 
 
+def test_w64_mask_few_blocks_key_padding(umfa_opts):
+    """fewer 256-row blocks than CUs (B1 H8 S4096: 128): a mask WITHOUT a row dimension (key padding) takes the mask kernel by default, every
+    block shared between workgroups and folded; a [Sq, Skv] mask of the same call stays on the 128-row kernel (how dense it is the host
+    cannot know).  Rows against the oracle with the mask, inside 1e-3; bitwise repeatable."""
+    import umfa_torch
+    umfa_opts(force_w64=0)
+    from oracle import parity
+    B, H, S, D = 1, 8, 4096, 128
+    torch.manual_seed(9)
+    q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    i = torch.arange(S, device="cuda")
+    m = (i < 3333)[None, None, None, :].contiguous()
+    o, lse = umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32, return_lse=True)
+    if torch.cuda.get_device_properties(0).multi_processor_count * 10 <= B * H * (S // 256) * (S // 64):
+        assert umfa_torch.last_kernel() == "fa_fwd16_w64<bf16,128,pv16,mask>", umfa_torch.last_kernel()
+    rows = parity.sample_rows(S)
+    mrows = np.ascontiguousarray(np.broadcast_to(m[0, 0].cpu().numpy(), (len(rows), S)))
+    ref, ref_lse = _oracle().sdpa_forward(np.ascontiguousarray(bits(q)[:, :, rows]), bits(k), bits(v), mask=mrows, mask_type=_oracle().MASK_BOOL, return_lse=True)
+    err = float(np.abs(o[:, :, rows].cpu().numpy() - ref).max() / np.abs(ref).max())
+    assert err < 1.0e-3, err
+    assert np.abs(lse.reshape(B, H, S)[:, :, rows].cpu().numpy() - ref_lse).max() < 2e-2
+    assert torch.equal(o, umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32))
+    m2 = ((i[:, None] // 1024) == (i[None, :] // 1024))[None, None].contiguous()
+    umfa_torch.attention_forward(q, k, v, mask=m2)
+    assert umfa_torch.last_kernel().startswith("fa_fwd16<"), umfa_torch.last_kernel()
+
+
 def test_w64_mask_routing_gate(umfa_opts):
     """few items (fewer 256-row blocks than CUs), additive masks, causal + mask, head_dim 64 and bf16 P V stay on the 128-row kernel"""
     import umfa_torch

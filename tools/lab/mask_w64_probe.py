@@ -36,7 +36,10 @@ def graph_ms(fn, n=10):
     return sorted(ts)[len(ts) // 2]
 
 
-for (B, H, S) in [(1, 24, 4096), (1, 20, 4096), (3, 24, 4096), (2, 16, 4096), (4, 16, 4096), (1, 16, 8192)]:
+SHAPES = [(1, 24, 4096), (1, 20, 4096), (3, 24, 4096), (2, 16, 4096), (4, 16, 4096), (1, 16, 8192)]
+if len(sys.argv) > 1 and sys.argv[1] == "few":  # fewer 256-row blocks than CUs
+    SHAPES = [(1, 8, 4096), (1, 12, 4096), (1, 4, 8192), (2, 4, 2048), (1, 2, 16384), (1, 8, 2048)]
+for (B, H, S) in SHAPES:
     torch.manual_seed(0)
     q, k, v = (torch.randn(B, H, S, 128, device="cuda", dtype=torch.bfloat16) for _ in range(3))
     o = torch.empty(B, H, S, 128, device="cuda", dtype=torch.float32)

@@ -17,6 +17,7 @@
 // reads AND ds_read_b64_tr_b16 transposed reads (tools/lds_bank_check.py).  Tiles arrive by LDS-DMA with the swizzle
 // on the source chunk.
 // P and dS are rounded to the input type before their second product, like P in the forward.
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 
@@ -609,19 +610,21 @@ __global__ __launch_bounds__(256, 1) void bwd16_dq2_kernel(BwdParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------ dQ = scale dS K (dS-store form)
-// The second half of bwd16_dq2 alone: dQ^T[d][q] += K^T[d][key] dS^T[key][q] with dS read back from the scratch bwd16_dkdv
-// wrote (row-major [q][key], operand type): no S, no dP, no exponentials.  HBM-bound (the dS matrix is read exactly once:
-// 805 MB at the FLUX shape); three workgroups per CU hide the load latency; K tiles by LDS-DMA, double-buffered, transposed
-// fragments as in bwd16_dq2.  Non-causal, head_dim 128, Sq % 128 == 0, Skv % 64 == 0 (the launcher checks).
+// The second half of bwd16_dq2 alone: dQ^T[d][q] += K^T[d][key] dS^T[key][q] with dS^T read back from the scratch bwd16_dkdv wrote
+// (tiles [key tile 64][q-block 128][64][128], operand type): no S, no dP, no exponentials.  HBM-bound -- the dS matrix is read
+// exactly once, 805 MB at the FLUX shape -- so what matters is bytes in flight: one workgroup per CU with a FOUR-slot LDS-DMA ring of
+// (K tile, dS^T tile) pairs (3 x 16 KiB of dS per CU on their way = latency x the CU's share of the bandwidth), both operands as
+// transposed-read fragments of the same dual-use image (a dS^T tile IS a [64][128] image with queries for columns).
+// Non-causal, head_dim 128, Sq % 128 == 0, Skv % 64 == 0 (the launcher checks).
 template <typename T>
-__global__ __launch_bounds__(256, 3) void bwd16_dq_gemm_kernel(BwdParams p) {
+__global__ __launch_bounds__(256, 1) void bwd16_dq_gemm_kernel(BwdParams p) {
     constexpr int DP = 128;
     BWD16_GEO(DP);
     (void)PD; (void)NKS;
     typedef Mma16<T> M;
-    typedef typename M::V8 V8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int KROWS = 64, KTILE_B = KROWS * ROW_B;
+    constexpr int KROWS = 64, KTILE_B = KROWS * ROW_B, NS = 4, SLOT_B = 2 * KTILE_B;  // slot = [K tile][dS^T tile]
+    constexpr int NPW = (2 * TILE_PIECES + 3) / 4;                                  // LDS-DMA instructions per wave and image
     const int tid = threadIdx.x, lane = tid & 63, ql = lane & 31, hi = lane >> 5;
     const int wave = tid >> 6, uw = __builtin_amdgcn_readfirstlane(wave);
     const uint32_t nqb = p.Sq / 128;
@@ -631,59 +634,67 @@ __global__ __launch_bounds__(256, 3) void bwd16_dq_gemm_kernel(BwdParams p) {
     const uint32_t kvbh = bwd16_kv_slab(p, bh);
     const T* kp = (const T*)p.k + (int64_t)kvbh * p.Skv * DP;
     const i32x4 k_srd = make_srd(kp, p.Skv * (uint32_t)ROW_B);
-    // this lane's row; B-operand element j of a 16-key step is key 8 (j >> 2) + 4 hi + (j & 3) (the accumulator-row order
-    // the transposed K fragments are paired with, as in bwd16_dq2): two 8-byte pieces per step
-    const T* dsr = (const T*)p.ds + ((int64_t)bh * p.Sq + q_row) * p.Skv + 4 * hi;
+    // the slab as one image of 256-byte rows: tile (kt, qb) = rows (kt * nqb + qb) * 64 ... + 63
+    const i32x4 ds_srd = make_srd((const char*)p.ds + (int64_t)bh * p.Sq * p.Skv * 2, p.Sq * p.Skv * 2u);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((LDS_AS char*)smem));
-    int dma_off[(2 * TILE_PIECES + 3) / 4];
+    int dma_off[NPW], ds_off[NPW];
     dma_lane_offsets<2 * TILE_PIECES, DP>(dma_off, uw, lane);
-    auto stage = [&](uint32_t t) __attribute__((always_inline)) {
-        dma_rows_pre<2 * TILE_PIECES, DP>(k_srd, lds0 + (t & 1) * KTILE_B, t * KROWS, uw, dma_off);
-    };
+    // a dS^T tile in memory: 8-byte unit (query group gq of 32, key k of 64) at (gq * 64 + k) * 8 (bwd16_dkdv).  In LDS the same, with
+    // the 16-byte chunk index XORed with (gq & 7) << 1: the 32 lanes of a transposed read touch 8 query groups x 4 keys, and unswizzled
+    // every group would start on the same bank (512-byte rows).  The swizzle goes on the SOURCE chunk (LDS-DMA writes lanes linearly).
+#pragma unroll
+    for (int i = 0; i < NPW; ++i) {
+        const int sig = 64 * (4 * i + uw) + lane;  // LDS chunk slot of this lane in piece 4 i + uw
+        ds_off[i] = (sig ^ (((sig >> 5) & 7) << 1)) * 16;
+    }
     const uint32_t ntiles = p.Skv / KROWS;
-    stage(0);
-    V8 dsf[2][2], dsn[2][2];
-    auto load_ds = [&](uint32_t t, V8 (&d)[2][2]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                typedef typename M::V4 V4;
-                const V4 lo = *(const V4*)(dsr + (int64_t)t * KROWS + 32 * u + 16 * s2);
-                const V4 hi4 = *(const V4*)(dsr + (int64_t)t * KROWS + 32 * u + 16 * s2 + 8);
-                d[u][s2] = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
-            }
+    auto stage = [&](uint32_t t) __attribute__((always_inline)) {  // (tiles past the end: range-checked away, same instruction count)
+        dma_rows_pre<2 * TILE_PIECES, DP>(k_srd, lds0 + (t % NS) * SLOT_B, t * KROWS, uw, dma_off);
+        dma_rows_pre<2 * TILE_PIECES, DP>(ds_srd, lds0 + (t % NS) * SLOT_B + KTILE_B, t < ntiles ? (t * nqb + qb) * KROWS : 0x7fffffu, uw, ds_off);
     };
-    load_ds(0, dsf);
+#pragma unroll
+    for (int i = 0; i < NS - 1; ++i) stage(i);
     f32x16 acc[NDB];
 #pragma unroll
     for (int i = 0; i < NDB; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
     const int tr_qq = (lane >> 2) & 3, tr_pp = lane & 3, tr_g1 = (lane >> 4) & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
-    constexpr int NF = 2 * NDB;
-    for (uint32_t t = 0; t < ntiles; ++t) {
-        const char* Kt = smem + (t & 1) * KTILE_B;
-        if (t + 1 < ntiles) {
-            stage(t + 1);
-            load_ds(t + 1, dsn);
-        }
-#pragma unroll
-        for (int j = 0; j < 2 * NF; ++j) {
-            const int u = j / NF, r = j % NF, i = r >> 1, s2 = r & 1;
-            acc[i] = M::mma(tr_frag<M, DP>(Kt + u * TILE_BYTES, i, s2, hi, tr_qq, tr_pp, tr_g1), dsf[u][s2], acc[i]);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        __syncthreads();
+    // this lane's unit of a B fragment: query group 8 wave + 4 g1 + pp, keys 16 (2 u + s2) + 4 hi + qq (and + 8): byte offsets in the tile
+    int dsu[2][2][2];
+    {
+        const int gq = 8 * wave + 4 * tr_g1 + tr_pp;
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) dsf[u][s2] = dsn[u][s2];
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int h8 = 0; h8 < 2; ++h8) {
+                    const int k = 32 * u + 16 * s2 + 8 * h8 + 4 * hi + tr_qq;
+                    dsu[u][s2][h8] = gq * 512 + ((k * 8) ^ ((gq & 7) << 5));
+                }
     }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * 2 * NPW) : "memory");  // tile 0 has landed; the two younger ones stay in flight
+    __syncthreads();
+    for (uint32_t t = 0; t < ntiles; ++t) {
+        const char* Kt = smem + (t % NS) * SLOT_B;
+        const char* Dt = Kt + KTILE_B;
+        stage(t + NS - 1);  // into the slot tile t - 1 was read from (every wave is past the barrier that ended it)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                // B operand: lane (q, hi) holds dS^T[16-key step][q] in the accumulator-row key order the transposed K fragments use
+                const typename M::V4 blo = M::tr_read(Dt + dsu[u][s2][0]), bhi = M::tr_read(Dt + dsu[u][s2][1]);
+                const typename M::V8 b = __builtin_shufflevector(blo, bhi, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int i = 0; i < NDB; ++i) acc[i] = M::mma(tr_frag<M, DP>(Kt + u * TILE_BYTES, i, s2, hi, tr_qq, tr_pp, tr_g1), b, acc[i]);
+            }
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * 2 * NPW) : "memory");  // tile t + 1 has landed
+        __syncthreads();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring's last (out-of-range) requests: the epilogue below reuses the tile area
+    __syncthreads();
     if (p.grad_in_type) {  // operand-type dQ through per-wave LDS rows (see bwd16_dq2)
         char* stg = smem + wave * 8192;
         typedef T T4 __attribute__((ext_vector_type(4)));
@@ -757,12 +768,38 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
     const i32x4 q_srd = make_srd(qp, p.Sq * (uint32_t)ROW_B), do_srd = make_srd(dop, p.Sq * (uint32_t)ROW_B);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((LDS_AS char*)smem));
     float* const vec = (float*)(smem + VEC);
-    // dS-store form: this (batch, head)'s [Sq][Skv] slab of the scratch; a lane writes column `key`, rows 4 hi + ... of a group
-    const uint32_t ds_row_b = p.Skv * 2u;
-    const auto ds_rsrc = __builtin_amdgcn_make_buffer_rsrc(STORE_DS ? (void*)((char*)p.ds + (int64_t)bh * p.Sq * ds_row_b) : (void*)nullptr, 0,
-                                                           STORE_DS ? (int)(p.Sq * ds_row_b) : 0, 0x00020000);
-    const int ds_voff = (int)(key * 2u + 4u * (uint32_t)hi * ds_row_b);
-    (void)ds_rsrc; (void)ds_voff;
+    // dS-store form: this (batch, head)'s slab of the scratch holds dS^T as 16-KiB tiles [key tile of 64][q-block of 128], inside a tile
+    // [query group of 4: 32][key: 64][4 queries] in the operand type.  A lane (key, hi) holds 4 consecutive queries per register group =
+    // one 8-byte unit, and the 32 lanes of a half are 32 consecutive keys of ONE query group: every store instruction writes two
+    // contiguous 256-byte runs (lanes index keys -- in a [key][query] layout each lane's 16 bytes were a memory request of their own,
+    // 50 M requests per FLUX backward: +90 us on this kernel; in [query][key] they are 32 two-byte stores per tile, +111 us).
+    // bwd16_dq_gemm reads the units back with transposed LDS reads (any arrangement of 8-byte units serves those).
+    const uint32_t ds_nqb = p.Sq / 128u;
+    const auto ds_rsrc = __builtin_amdgcn_make_buffer_rsrc(STORE_DS ? (void*)((char*)p.ds + (int64_t)bh * p.Sq * p.Skv * 2) : (void*)nullptr, 0,
+                                                           STORE_DS ? (int)(p.Sq * p.Skv * 2u) : 0, 0x00020000);
+    const int ds_voff = ((wave & 1) * 32 + kl) * 8 + hi * 512;         // key row of the 64-key tile; the odd query group of a register group
+    const uint32_t ds_kt = 2u * kb + (uint32_t)(uw >> 1);              // this wave's key tile
+    (void)ds_rsrc; (void)ds_voff; (void)ds_nqb; (void)ds_kt;
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    // sub-tile (32 queries from q0_sub) of this lane's key: register groups 0, 1 in a, 2, 3 in b (two dwords each)
+    auto ds_store = [&](uint32_t q0_sub, const u32x4_t& a, const u32x4_t& b) __attribute__((always_inline)) {
+        if constexpr (STORE_DS) {
+            const uint32_t tile = (p.ds_lab & 1) ? 0u : ds_kt * ds_nqb + q0_sub / 128u;
+            const int soff = (int)(tile * 16384u + ((q0_sub % 128u) / 4u) * 512u);  // query group 8 u' of the tile; register group g: + 2 g groups
+#ifndef BWD16_DS_AUX
+#define BWD16_DS_AUX 0
+#endif
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{a[0], a[1]}, ds_rsrc, ds_voff, soff, BWD16_DS_AUX);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{a[2], a[3]}, ds_rsrc, ds_voff, soff + 1024, BWD16_DS_AUX);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{b[0], b[1]}, ds_rsrc, ds_voff, soff + 2048, BWD16_DS_AUX);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{b[2], b[3]}, ds_rsrc, ds_voff, soff + 3072, BWD16_DS_AUX);
+        }
+    };
+    // the second sub-tile's units are stored at the top of the NEXT tile (issued late in a tile they would still be on their way at its
+    // end-of-tile vmcnt(0), which the LDS-DMA ring needs)
+    u32x4_t ds_carry[2] = {u32x4_t{0, 0, 0, 0}, u32x4_t{0, 0, 0, 0}};
+    uint32_t ds_carry_q0 = 0xffffffffu;
 
     if (item == blockIdx.x) {
 #pragma unroll
@@ -925,9 +962,6 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
                         pb[u][r >> 3][r & 7] = (T)pr;
                         const T dsv = (T)(pr * dp[u][r]);                                                // dp = dP - D (accumulator started at -D)
                         sb[u][r >> 3][r & 7] = dsv;
-                        if constexpr (STORE_DS)  // row qb0 + 8 g + 4 hi + e, this lane's key: 64 contiguous bytes per (row, half-wave)
-                            __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, dsv), ds_rsrc, ds_voff,
-                                                                  (int)((qb0 + 8u * g + e) * ds_row_b), 0);
                     }
                 };
                 constexpr int NF = 4 * NDBH, PT = 4;  // dV / dK MFMAs of one sub-tile; transposed fragments in flight
@@ -938,6 +972,9 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
                 };
                 constexpr int PF = 2 * PD;  // row fragments in flight
                 BWD_STAMP(1);
+                if constexpr (STORE_DS) {
+                    if (ds_carry_q0 != 0xffffffffu) ds_store(ds_carry_q0, ds_carry[0], ds_carry[1]);
+                }
     #pragma unroll
                 for (int f = 0; f < PF; ++f) rd(f);
                 __builtin_amdgcn_sched_barrier(0);
@@ -962,6 +999,10 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
                     if (f >= 2 * NKS + 1 && (f - (2 * NKS + 1)) % 2 == 0) softmax_pair(0, f - (2 * NKS + 1));
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if constexpr (STORE_DS) {  // sub-tile 0 is complete (its last pair ran behind the P1b MFMAs)
+                    ds_store(q_base, __builtin_bit_cast(u32x4_t, sb[0][0]), __builtin_bit_cast(u32x4_t, sb[0][1]));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
     #pragma unroll
                 for (int j = 0; j < 2 * NF; ++j) {
                     const int u = j / NF, r = j % NF, i = r >> 2, s2 = (r >> 1) & 1;
@@ -973,6 +1014,13 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
                     __builtin_amdgcn_sched_barrier(0);
                     // P2a: the 8 score pairs of sub-tile 1 behind every second MFMA, from the second one on
                     if (j < NF && j % 2 == 1) softmax_pair(1, j - 1);
+                    if constexpr (STORE_DS) {
+                        if (j == NF + 1) {  // sub-tile 1 complete: stored at the top of the next tile
+                            ds_carry[0] = __builtin_bit_cast(u32x4_t, sb[1][0]);
+                            ds_carry[1] = __builtin_bit_cast(u32x4_t, sb[1][1]);
+                            ds_carry_q0 = q_base + 32u;
+                        }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {  // head_dim 64 (two workgroups per CU, 256 registers) and 256 (two passes): hipcc's own order
@@ -1069,6 +1117,10 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
         step(t + 1, std::false_type{}, std::integral_constant<int, 1>{});
     }
     for (; t < ntiles; ++t) step(t, std::true_type{}, std::integral_constant<int, -1>{});
+    if constexpr (STORE_DS) {
+        if (ds_carry_q0 != 0xffffffffu) ds_store(ds_carry_q0, ds_carry[0], ds_carry[1]);
+        ds_carry_q0 = 0xffffffffu;
+    }
 #ifdef BWD16_LAB_STAMP
     rt_loop1 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1159,12 +1211,15 @@ static hipError_t launch_bwd16_t(const BwdParams& p, hipStream_t stream) {
     const int ph = p.phases ? p.phases : 7;
     if constexpr (DP == 128 && !CAUSAL) {
         if (p.ds && ph == 7) {
+            BwdParams pl = p;
+            if (const char* e = getenv("UMFA_LAB_DS")) pl.ds_lab = atoi(e);
+            const BwdParams& p = pl;
             // dS-store form: D, row constants, dK / dV (+ dS to the scratch), dQ = scale dS K
             hipLaunchKernelGGL(bwd16_delta_kernel<DP>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, p);
             if (hipError_t e = launch_bwd16_rowc(p.lse, p.dvec, p.rowc, rows, stream); e != hipSuccess) return e;
             if (hipError_t e = ensure_dynamic_lds((const void*)bwd16_dkdv_kernel<T, false, DP, true>, lds_kv); e != hipSuccess) return e;
             hipLaunchKernelGGL((bwd16_dkdv_kernel<T, false, DP, true>), dim3(nkb * p.B * p.H), dim3(256), lds_kv, stream, p);
-            const size_t lds_g = 2 * 64 * 2 * DP;
+            const size_t lds_g = 4 * 2 * 64 * 2 * DP;  // four slots of (K tile, dS^T tile)
             if (hipError_t e = ensure_dynamic_lds((const void*)bwd16_dq_gemm_kernel<T>, lds_g); e != hipSuccess) return e;
             hipLaunchKernelGGL((bwd16_dq_gemm_kernel<T>), dim3(nqb * p.B * p.H), dim3(256), lds_g, stream, p);
             return hipGetLastError();

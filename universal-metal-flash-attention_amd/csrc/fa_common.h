@@ -145,6 +145,7 @@ struct BwdParams {
     void* ds;       // bwd16 "dS-store" form (option bwd_ds_store, head_dim 128, non-causal): scratch [B*H][Sq][Skv] in the operand
                     // type -- bwd16_dkdv writes dS = P (dP - D) there, bwd16_dq_gemm computes dQ = scale dS K from it: 5 products
                     // instead of 7 for B H Sq Skv 2 bytes of HBM (805 MB at the FLUX shape); NULL = the two recomputing kernels
+    int ds_lab;     // lab (env UMFA_LAB_DS, timing only): bit 0 = every dS store goes to tile 0 of the slab (no HBM write stream)
 };
 
 __device__ __forceinline__ float bf16_bits_to_float(uint16_t b) {

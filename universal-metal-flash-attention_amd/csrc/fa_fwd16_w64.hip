@@ -286,7 +286,13 @@ bool fwd_w64_supported(const FwdParams& p) {
         if (p.in_prec == P_BF16 && !p.pv16) return false;
         if (p.Skv < 64 || p.Sq < 256 || (p.Sq % 256 != 0 && p.Sq < 1024) || ((p.Skv + 63) / 64) > 1024u) return false;  // (a block's tile list sits in 4 KiB of LDS)
         if (p.out_prec != P_FP32 && p.out_prec != p.in_prec) return false;
-        return tuning().force_w64.load(std::memory_order_relaxed) || (uint64_t)p.B * p.H * ((p.Sq + 255) / 256) >= (uint64_t)w64_cu_count();
+        // at least one block per CU; or -- fewer blocks, every block then shared between workgroups (w64_grid) -- a mask WITHOUT a row
+        // dimension (key padding, [B, 1 | H, 1, Skv]) and the unmasked kernel's 10 tile steps per CU.  Measured with fewer blocks than CUs
+        // (profiles/r4/mask_w64_few_blocks.jsonl, this kernel / 128-row kernel): padding 1.15-1.49 x, dense random per-head 1.7-2.4 x, but
+        // block-diagonal and window TENSORS 0.75-0.96 x (short lists: two parts + a fold per block) -- and how dense a [Sq, Skv] mask is
+        // the host cannot know without reading it back
+        const uint64_t blocks = (uint64_t)p.B * p.H * ((p.Sq + 255) / 256), cus = (uint64_t)w64_cu_count();
+        return tuning().force_w64.load(std::memory_order_relaxed) || blocks >= cus || (p.ms[2] == 0 && blocks * ((p.Skv + 63) / 64) >= cus * 10);
     }
     if (w64_is_window(p) && p.rope_cos) return false;  // window instantiations: no fused rotation
     if (p.D == 64 && p.rope_cos) return false;  // the fused Q rotation exists at head_dim 128 only
@@ -333,7 +339,9 @@ static uint32_t w64_grid(const FwdParams& p) {
         if (const int gi = tuning().w64_grid.load(std::memory_order_relaxed)) {  // lab / tests: force the number of workgroups
             if (gi > 0 && (uint64_t)gi <= cus && (uint64_t)gi <= items && gi <= 512) return (uint32_t)gi;
         }
-        return (uint32_t)(items < cus ? items : (cus < 512 ? cus : 512));  // (the shared blocks' running sums sit in 2 KiB of LDS)
+        const uint64_t gmax = cus < 512 ? cus : 512;  // (the shared blocks' running sums sit in 2 KiB of LDS)
+        if (items < cus) return (uint32_t)((p.ms[2] == 0 && items * ((p.Skv + 63) / 64) >= cus * 10) ? gmax : items);  // few blocks, key-padding mask: every block shared
+        return (uint32_t)gmax;
     }
     const bool pairs = p.causal && !w64_is_window(p);  // (a causal window is a window with right = 0: linear schedule)
     uint64_t total = (uint64_t)p.B * p.H * ((p.Sq + 255) / 256) * w64_tiles_per_item(p);  // (item, key tile) steps
