@@ -158,6 +158,51 @@ def test_w64_mask_flux_shape_rows(kind, umfa_opts):
     assert torch.equal(o, umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32))
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_w64_mask_schedule_fuzz(seed, umfa_opts):
+    """random shapes x random bool masks (any broadcast pattern, any density, empty rows / blocks / heads) x a random number of workgroups:
+    whole rounds, cut blocks, more workgroups than shared steps, one workgroup for everything.  Against the 128-row kernel's tile-flag
+    path on the same inputs (two fp16-P kernels: each within half an ulp of P at 1.0 of the truth) and for bitwise repeatability."""
+    import umfa_torch
+    rng = np.random.default_rng(1000 + seed)
+    B, H = int(rng.integers(1, 3)), int(rng.integers(1, 5))
+    Sq = int(rng.choice([256, 512, 768, 1024, 1280, 1100, 1536]))
+    Skv = int(rng.choice([64, 100, 256, 333, 512, 777, 1024, 1500]))
+    dt = torch.bfloat16 if seed % 3 else torch.float16
+    torch.manual_seed(seed)
+    q = torch.randn(B, H, Sq, 128, device="cuda", dtype=dt)
+    k = torch.randn(B, H, Skv, 128, device="cuda", dtype=dt)
+    v = torch.randn(B, H, Skv, 128, device="cuda", dtype=dt)
+    mb, mh, mq = (B if rng.random() < 0.5 else 1), (H if rng.random() < 0.5 else 1), (Sq if rng.random() < 0.7 else 1)
+    dens = float(rng.choice([0.02, 0.3, 0.7, 0.97]))
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    m = torch.rand(mb, mh, mq, Skv, device="cuda", generator=g) < dens
+    if rng.random() < 0.5:  # structure on top: a band of fully masked key tiles, a fully masked row range
+        lo = int(rng.integers(0, Skv))
+        m[..., lo:lo + int(rng.integers(1, 300))] = False
+        if mq > 1:
+            r0 = int(rng.integers(0, Sq))
+            m[:, :, r0:r0 + int(rng.integers(1, 400))] = False
+    items = B * H * ((Sq + 255) // 256)
+    grid = int(rng.integers(1, min(items, 16) + 1))
+    umfa_opts(force_w64=1, w64_grid=grid)
+    o, lse = umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32, return_lse=True)
+    kern = umfa_torch.last_kernel()
+    assert kern.endswith(",mask>"), (kern, B, H, Sq, Skv, grid)
+    assert torch.equal(o, umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32)), (B, H, Sq, Skv, grid)
+    assert torch.isfinite(o).all()
+    with umfa_torch.options(no_w64_mask=1, force_w64=0, w64_grid=0):
+        o2, lse2 = umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32, return_lse=True)
+        assert umfa_torch.last_kernel().startswith("fa_fwd16<"), umfa_torch.last_kernel()
+    dead = ~m.expand(B, H, Sq, Skv).any(-1)
+    assert (o[dead] == 0).all() and torch.isneginf(lse.reshape(B, H, Sq)[dead]).all()
+    scale = float(o2.abs().max()) if float(o2.abs().max()) > 0 else 1.0
+    assert float((o - o2).abs().max()) <= 2.0 ** -10 * scale, (B, H, Sq, Skv, grid, dens)
+    live = ~dead
+    if live.any():
+        assert float((lse.reshape(B, H, Sq)[live] - lse2.reshape(B, H, Sq)[live]).abs().max()) < 1e-3
+
+
 def test_w64_mask_few_blocks_key_padding(umfa_opts):
     """fewer 256-row blocks than CUs (B1 H8 S4096: 128): a mask WITHOUT a row dimension (key padding) takes the mask kernel by default, every
     block shared between workgroups and folded; a [Sq, Skv] mask of the same call stays on the 128-row kernel (how dense it is the host
