@@ -203,6 +203,37 @@ def test_w64_mask_schedule_fuzz(seed, umfa_opts):
         assert float((lse.reshape(B, H, Sq)[live] - lse2.reshape(B, H, Sq)[live]).abs().max()) < 1e-3
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("gain", [1.0, 6.0, 20.0])
+def test_w64_mask_key_padding_lazy_reference(dt, gain, umfa_opts):
+    """masks without a row dimension run the LAZY tile bodies (no row max after a segment's first tile; rebases and the give-up path are read
+    off the row sums): hostile score ranges (gain 20: jumps of hundreds of nats between tiles -> rebases, overflow hand-shake, re-run
+    with the max chain) against the oracle with the mask, and against the same launch with the max chain (option no_w64_mask_lazy)"""
+    import umfa_torch
+    umfa_opts(force_w64=1, w64_grid=3)
+    B, H, Sq, Skv = 2, 2, 512, 1100
+    torch.manual_seed(int(gain))
+    q = torch.randn(B, H, Sq, 128, device="cuda", dtype=dt) * gain
+    k = torch.randn(B, H, Skv, 128, device="cuda", dtype=dt)
+    v = torch.randn(B, H, Skv, 128, device="cuda", dtype=dt)
+    j = torch.arange(Skv, device="cuda")
+    lens = torch.tensor([1000, 333], device="cuda")
+    m = ((j[None] < lens[:, None]) & (j[None] % 7 != 3))[:, None, None, :]  # [B, 1, 1, Skv]: padding + holes
+    o, lse = umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32, return_lse=True)
+    kern = umfa_torch.last_kernel()
+    assert kern.endswith(",mask>"), kern
+    assert torch.equal(o, umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32))
+    mfull = m.expand(B, H, Sq, Skv)
+    ref, ref_lse = _oracle().sdpa_forward(npy(q), npy(k), npy(v), mask=np.ascontiguousarray(mfull.cpu().numpy()),
+                                          mask_type=_oracle().MASK_BOOL, return_lse=True)
+    check_forward(o.cpu().numpy(), ref, dt, kern, f"w64_mask_lazy_gain{gain}", scale_max=1.0 if gain == 1.0 else 2.0)
+    assert np.abs(lse.cpu().numpy().reshape(B, H, Sq) - ref_lse).max() < 2e-2 * max(1.0, gain)
+    with umfa_torch.options(no_w64_mask_lazy=1):
+        o2 = umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32)
+        assert umfa_torch.last_kernel() == kern
+    assert float((o - o2).abs().max()) <= 2.0 ** -9 * float(o2.abs().max())
+
+
 def test_w64_mask_few_blocks_key_padding(umfa_opts):
     """fewer 256-row blocks than CUs (B1 H8 S4096: 128): a mask WITHOUT a row dimension (key padding) takes the mask kernel by default, every
     block shared between workgroups and folded; a [Sq, Skv] mask of the same call stays on the 128-row kernel (how dense it is the host

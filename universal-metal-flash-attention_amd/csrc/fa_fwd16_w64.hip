@@ -406,7 +406,9 @@ hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cn
         wp.mk_bs = p.mk_bs; wp.mk_hs = p.mk_hs; wp.mk_nrb64 = p.mk_nrb64;
         wp.mk_prefix = p.mk_prefix;
         if (wp.n_items % w64_grid(p) != 0 && !p.mk_prefix) return hipErrorInvalidValue;
-        wp.lazy = 0;  // the max chain: which rows have keys in a segment is not arithmetic (kernel: MASKT)
+        // the max chain, unless the mask has no row dimension (key padding: a listed tile holds a key for every row, the lazy bodies are as safe as
+        // without a mask); with one, which rows have keys in a segment is not arithmetic
+        if (p.ms[2] != 0 || tuning().no_w64_mask_lazy.load(std::memory_order_relaxed)) wp.lazy = 0;
     }
     if (rope && p.out_prec != p.in_prec) return hipErrorNotSupported;  // fused-RoPE instantiations: O in the operand type only (runtime.hip asks first)
     if (window) {
