@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""bf16 forward with few 256-row q-blocks per head (the fp16 image of V is then re-read only once or twice): the dispatcher's choice against the
+128-row kernel (option no_w64: V converted in the kernel), graph-replayed us"""
+import json
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent.parent
+sys.path[:0] = [str(ROOT), str(ROOT / "universal-metal-flash-attention_amd")]
+import torch  # noqa: E402
+
+import umfa_torch  # noqa: E402
+sys.path.insert(0, str(ROOT / "tools" / "lab"))
+from split_probe import graph_us  # noqa: E402
+
+for (B, H, Sq, Skv, D, causal) in [(8, 32, 256, 8192, 128, False), (8, 32, 512, 4096, 128, False), (16, 16, 512, 512, 128, False), (4, 32, 768, 2048, 128, False),
+                                   (2, 32, 1024, 1024, 128, False), (16, 16, 256, 256, 128, False), (8, 32, 256, 8192, 64, False), (16, 16, 512, 512, 64, False),
+                                   (8, 16, 512, 512, 128, True), (4, 32, 768, 768, 128, True)]:
+    torch.manual_seed(0)
+    q = torch.randn(B, H, Sq, D, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(B, H, Skv, D, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn(B, H, Skv, D, device="cuda", dtype=torch.bfloat16)
+    o = torch.empty(B, H, Sq, D, device="cuda", dtype=torch.float32)
+    row = {"shape": f"B{B} H{H} Sq{Sq} Skv{Skv} D{D} {'causal' if causal else 'full'}"}
+    for name, opts in (("default", {}), ("r128", {"no_w64": 1})):
+        with umfa_torch.options(**opts):
+            row[name + "_us"] = graph_us(lambda: umfa_torch.attention_forward(q, k, v, causal=causal, out=o))
+            row[name + "_kernel"] = umfa_torch.last_kernel()
+    row["r128_over_default"] = round(row["r128_us"] / row["default_us"], 3)
+    print(json.dumps(row), flush=True)

@@ -292,7 +292,9 @@ bool fwd_w64_supported(const FwdParams& p) {
         // block-diagonal and window TENSORS 0.75-0.96 x (short lists: two parts + a fold per block) -- and how dense a [Sq, Skv] mask is
         // the host cannot know without reading it back
         const uint64_t blocks = (uint64_t)p.B * p.H * ((p.Sq + 255) / 256), cus = (uint64_t)w64_cu_count();
-        return tuning().force_w64.load(std::memory_order_relaxed) || blocks >= cus || (p.ms[2] == 0 && blocks * ((p.Skv + 63) / 64) >= cus * 10);
+        if (tuning().force_w64.load(std::memory_order_relaxed)) return true;
+        if (p.in_prec == P_BF16 && p.Sq < 1024) return false;  // (the fp16 image of V is re-read by too few q-blocks: see below)
+        return blocks >= cus || (p.ms[2] == 0 && blocks * ((p.Skv + 63) / 64) >= cus * 10);
     }
     if (w64_is_window(p) && p.rope_cos) return false;  // window instantiations: no fused rotation
     if (p.D == 64 && p.rope_cos) return false;  // the fused Q rotation exists at head_dim 128 only
@@ -308,6 +310,11 @@ bool fwd_w64_supported(const FwdParams& p) {
     if (!tuning().force_w64.load(std::memory_order_relaxed)) {
         const uint64_t cus = (uint64_t)w64_cu_count();
         const uint64_t nqb = (p.Sq + 255) / 256;
+        // bf16 operands with the fp16 P V product: this kernel needs the fp16 image of V (a cast pre-pass: two more passes over V), and with
+        // nqb q-blocks per head the pass costs ~1 / nqb of the kernel's own time.  The 128-row kernel converts V in place in LDS for ~12 %.
+        // Graph-replayed us, this kernel + pass / 128-row kernel (profiles/r4/small_nqb_probe.jsonl): Sq 256: 444 / 353, 30 / 22, 254 / 201 (D 64);
+        // Sq 512: 331 / 327, 66 / 54, 40 / 31; Sq 768: 131 / 125, causal 54 / 51; Sq 1024: 49 / 51.
+        if (p.in_prec == P_BF16 && p.pv16 && p.Sq < 1024) return false;
         if (w64_is_window(p)) {
             // the band's tile steps are what there is to share (thresholds of the unmasked kernel: cut items need 10 steps per CU)
             const uint64_t items = (uint64_t)p.B * p.H * nqb, steps = items * w64_tiles_per_item(p);

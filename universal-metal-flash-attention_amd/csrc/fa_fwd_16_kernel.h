@@ -862,60 +862,76 @@ __global__ __launch_bounds__(256 * KS, KS * (DP > 128 ? 1 : (BN == 32 ? 3 : 2)))
         m = mn;
     }
     if (KS == 1 && nparts > 1) {
-        // Split-KV combine (cdna_hip_programming.md Guideline 16, counter form): every part publishes its
-        // un-normalised (O^T, m, l) with plain stores -> vmcnt(0) -> barrier -> ONE agent-scope release ->
-        // ticket; the part that draws the last ticket acquires once and folds the others into its registers.
+        // Split-KV combine (cdna_hip_programming.md Guideline 16, "every load sc1" form -- the fold protocol of fa_fwd16_w64): every
+        // part publishes its un-normalised (O^T, m, l) with WRITE-THROUGH (sc1) stores -> vmcnt(0) -> barrier -> relaxed ticket; the part
+        // that draws the last ticket folds the others with sc1 loads.  No release / acquire fence anywhere: an agent-scope release is
+        // a write-back of the XCD's whole L2, and a launch of a few hundred parts paid for a few hundred of them (round 3: the causal
+        // half-split 2 x SLOWER than no split, profiles/r3/cfg2_causal_split_ab.json; round 4 with this protocol: lab notes section 6).
         constexpr int NREG = 16 * NDB + 2;
         // every static __shared__ object would shift the dynamic LDS base (Guideline 17): reuse the tile area
         volatile uint32_t& ticket_s = *(volatile uint32_t*)smem;
         const uint32_t sidx = item - p.n_full;
-        float* mine = p.part_buf + (((size_t)sidx * nparts + part) * 4 + wave) * (size_t)(NREG * 64);
+        const size_t item_floats = (size_t)nparts * 4 * (size_t)(NREG * 64);
+        const auto prs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.part_buf + (size_t)sidx * item_floats), 0, (int)(item_floats * 4), 0x00020000);
+        auto slot = [&](uint32_t part_, int reg) -> int { return (int)(((part_ * 4 + (uint32_t)wave) * NREG + (uint32_t)reg) * 256u); };
+        constexpr int SC1 = 16;  // cache policy bit of the buffer builtins: system-coherent level 1 = write-through / read-around the XCD's L2
 #pragma unroll
         for (int i = 0; i < NDB; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mine[(16 * i + r) * 64 + lane] = acc[i][r];
-        mine[(16 * NDB) * 64 + lane] = m;
-        mine[(16 * NDB + 1) * 64 + lane] = lt;
+            for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][r]), prs, lane * 4, slot(part, 16 * i + r), SC1);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m), prs, lane * 4, slot(part, 16 * NDB), SC1);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(lt), prs, lane * 4, slot(part, 16 * NDB + 1), SC1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // also: every wave is done with the K/V tiles, so smem[0..3] is free
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            ticket_s = __hip_atomic_fetch_add(p.part_cnt + sidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (tid == 0) ticket_s = __hip_atomic_fetch_add(p.part_cnt + sidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const uint32_t ticket = ticket_s;
         if (ticket != nparts - 1) return;  // not the last part of this item
-        if (tid == 0) {
-            // every part has drawn: the word is free again -- leave it zero for the next launch (no memset per launch, and no
-            // memset node in a captured graph)
-            __hip_atomic_store(p.part_cnt + sidx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
-        // fold the parts in index order (own part re-read from memory too): the result does not depend on
+        // every part has drawn: the word is free again -- leave it zero for the next launch (no memset per launch, and no
+        // memset node in a captured graph)
+        if (tid == 0) __hip_atomic_store(p.part_cnt + sidx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler-only: the payload loads stay below the ticket
+        // fold the parts in index order (own part from registers: the same values): the result does not depend on
         // which part arrived last, so two launches are bitwise identical
-        {
-            const float* p0 = p.part_buf + (((size_t)sidx * nparts) * 4 + wave) * (size_t)(NREG * 64);
+        auto ld = [&](uint32_t part_, int reg) -> float {
+            return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(prs, lane * 4, slot(part_, reg), SC1));
+        };
+        f32x16 own[NDB];
 #pragma unroll
-            for (int i = 0; i < NDB; ++i)
+        for (int i = 0; i < NDB; ++i) own[i] = acc[i];
+        const float m_own = m, l_own = lt;
+        bool first = true;
+        for (uint32_t o = 0; o < nparts; ++o) {
+            f32x16 x[NDB];
+            float mo, lo;
+            if (o == part) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][r] = p0[(16 * i + r) * 64 + lane];
-            m = p0[(16 * NDB) * 64 + lane];
-            lt = p0[(16 * NDB + 1) * 64 + lane];
-        }
-        for (uint32_t o = 1; o < nparts; ++o) {
-            const float* other = p.part_buf + (((size_t)sidx * nparts + o) * 4 + wave) * (size_t)(NREG * 64);
-            const float mo = other[(16 * NDB) * 64 + lane];
-            const float lo = other[(16 * NDB + 1) * 64 + lane];
+                for (int i = 0; i < NDB; ++i) x[i] = own[i];
+                mo = m_own;
+                lo = l_own;
+            } else {
+#pragma unroll
+                for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) x[i][r] = ld(o, 16 * i + r);
+                mo = ld(o, 16 * NDB);
+                lo = ld(o, 16 * NDB + 1);
+            }
+            if (first) {
+#pragma unroll
+                for (int i = 0; i < NDB; ++i) acc[i] = x[i];
+                m = mo;
+                lt = lo;
+                first = false;
+                continue;
+            }
             const float mn = fmaxf(m, mo);
             const float mu = mn == -INFINITY ? 0.0f : mn;
             const float a0 = __builtin_amdgcn_exp2f(m - mu), a1 = __builtin_amdgcn_exp2f(mo - mu);
 #pragma unroll
             for (int i = 0; i < NDB; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][r] = acc[i][r] * a0 + other[(16 * i + r) * 64 + lane] * a1;
+                for (int r = 0; r < 16; ++r) acc[i][r] = acc[i][r] * a0 + x[i][r] * a1;
             lt = lt * a0 + lo * a1;
             m = mn;
         }

@@ -131,10 +131,12 @@ hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p,
         return hipErrorNotSupported;  // only the 256-row kernel rotates Q in registers (the entry asks before it sets this)
     } else if (lowp && fwd_16_supported(p)) {
         FwdParams pp = pv;
-        if (pp.pv16 && (size_t)p.B * p.H * p.Skv * p.D * 2 >= ((size_t)16 << 20)) {
+        if (pp.pv16 && (size_t)p.B * p.H * p.Skv * p.D * 2 >= ((size_t)16 << 20) && p.Sq >= 1024) {
             // the 128-row kernel converts V in-kernel (24 ... 48 vector instructions per tile per wave in a vector-bound kernel, repeated
             // by every workgroup): right for short launches, where a pre-pass costs its launch; from 16 MB of V on the HBM-speed cast
-            // pass is cheaper (FLUX-size masked calls: ~11 us against ~15 % of the kernel).  Without a block (capture): in-kernel.
+            // pass is cheaper (FLUX-size masked calls: ~11 us against ~15 % of the kernel) -- IF the tiles are re-read: with fewer than eight
+            // 128-row q-blocks per head (decode-like calls: K / V are swept once) two more passes over V cost more than the kernel's own
+            // sweep (B8 H32 Sq1 Skv8192: 393 us with the pass, see profiles/r4/lab_notes.md section 6).  Without a block (capture): in-kernel.
             void* v16 = sc.v16.ensure((size_t)p.B * p.H * p.Skv * p.D * 2 + 256, stream);
             if (v16) {
                 if ((e = launch_cast_rows_bf16_to_f16(p.v, p.vs, v16, p.B, p.H, p.Skv, p.D, pv.status, stream)) != hipSuccess) return e;
