@@ -488,7 +488,8 @@ def test_w64_small_ragged_sq_stays_on_the_128_row_kernel():
                                                      ((4, 16, 1024, 1024), True, False), ((8, 16, 1024, 1024), True, True),
                                                      ((1, 4, 4096, 4096), False, True), ((1, 16, 2048, 2048), True, False),
                                                      ((1, 256, 256, 256), False, False), ((1, 8, 2048, 2048), False, True),
-                                                     ((2, 32, 1024, 1024), False, True), ((8, 32, 512, 4096), False, False)])
+                                                     ((2, 32, 1024, 1024), False, True), ((8, 32, 512, 4096), False, False),
+                                                     ((2, 24, 1100, 1100), False, False), ((4, 32, 1280, 1280), True, False), ((2, 24, 2100, 2100), False, True)])
 def test_w64_dispatch_gate(shape, causal, expect_w64):
     """without UMFA_FORCE_W64: one-workgroup-per-CU kernel only when there is work for (most of) the CUs -- and, for bf16 operands (whose fp16 P V
     product needs the V cast pass), only from four 256-row q-blocks per head on (round 4: with fewer, the pass costs more than the 128-row
@@ -502,10 +503,6 @@ def test_w64_dispatch_gate(shape, causal, expect_w64):
     assert umfa_torch.last_kernel().startswith("fa_fwd16_w64") == expect_w64, umfa_torch.last_kernel()
 
 
-@pytest.mark.parametrize("shape,causal,expect_w64", [((1, 24, 4096, 4096), False, True), ((8, 16, 1024, 1024), False, True),
-                                                     ((1, 40, 1024, 1024), False, False), ((4, 16, 1024, 1024), True, False),
-                                                     ((5, 16, 1024, 1024), True, False), ((8, 16, 1024, 1024), True, True),
-                                                     ((4, 16, 4096, 4096), True, True)])
 def test_w64_dispatch_gate_fp16_operands_keep_short_query_ranges():
     """fp16 operands need no cast pass: the one-workgroup-per-CU kernel keeps its round-3 gate (whole rounds win at any size)"""
     import umfa_torch
@@ -514,6 +511,10 @@ def test_w64_dispatch_gate_fp16_operands_keep_short_query_ranges():
     assert umfa_torch.last_kernel() == "fa_fwd16_w64<fp16,128>", umfa_torch.last_kernel()
 
 
+@pytest.mark.parametrize("shape,causal,expect_w64", [((1, 24, 4096, 4096), False, True), ((8, 16, 2048, 2048), False, True), ((8, 16, 1024, 1024), False, False),
+                                                     ((1, 40, 1024, 1024), False, False), ((4, 16, 1024, 1024), True, False),
+                                                     ((5, 16, 1024, 1024), True, False), ((8, 16, 1024, 1024), True, False), ((8, 16, 2048, 2048), True, True),
+                                                     ((4, 16, 4096, 4096), True, True)])
 def test_w64_dispatch_gate_head_dim_64(shape, causal, expect_w64):
     """head_dim 64: half the MFMA time per tile step, so the gate sits higher (BASELINE config 2 stays on the 128-row kernel)"""
     import umfa_torch

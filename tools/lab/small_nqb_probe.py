@@ -13,7 +13,10 @@ import umfa_torch  # noqa: E402
 sys.path.insert(0, str(ROOT / "tools" / "lab"))
 from split_probe import graph_us  # noqa: E402
 
-for (B, H, Sq, Skv, D, causal) in [(8, 32, 256, 8192, 128, False), (8, 32, 512, 4096, 128, False), (16, 16, 512, 512, 128, False), (4, 32, 768, 2048, 128, False),
+CASES2 = [(2, 32, 1024, 4096, 128, False), (4, 16, 1024, 1024, 128, False), (1, 64, 1024, 8192, 128, False), (2, 32, 1536, 1536, 128, False), (1, 32, 2048, 2048, 128, False),
+          (8, 16, 1024, 1024, 128, True), (4, 32, 1280, 1280, 128, True), (8, 16, 1024, 1024, 64, False), (8, 16, 1024, 1024, 64, True), (4, 64, 1024, 1024, 64, False),
+          (1, 24, 1024, 4096, 128, False), (2, 24, 1100, 1100, 128, False)]
+for (B, H, Sq, Skv, D, causal) in CASES2 if len(sys.argv) > 1 and sys.argv[1] == "gate" else [(8, 32, 256, 8192, 128, False), (8, 32, 512, 4096, 128, False), (16, 16, 512, 512, 128, False), (4, 32, 768, 2048, 128, False),
                                    (2, 32, 1024, 1024, 128, False), (16, 16, 256, 256, 128, False), (8, 32, 256, 8192, 64, False), (16, 16, 512, 512, 64, False),
                                    (8, 16, 512, 512, 128, True), (4, 32, 768, 768, 128, True)]:
     torch.manual_seed(0)

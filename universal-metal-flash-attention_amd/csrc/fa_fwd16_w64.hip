@@ -314,7 +314,9 @@ bool fwd_w64_supported(const FwdParams& p) {
         // nqb q-blocks per head the pass costs ~1 / nqb of the kernel's own time.  The 128-row kernel converts V in place in LDS for ~12 %.
         // Graph-replayed us, this kernel + pass / 128-row kernel (profiles/r4/small_nqb_probe.jsonl): Sq 256: 444 / 353, 30 / 22, 254 / 201 (D 64);
         // Sq 512: 331 / 327, 66 / 54, 40 / 31; Sq 768: 131 / 125, causal 54 / 51; Sq 1024: 49 / 51.
-        if (p.in_prec == P_BF16 && p.pv16 && p.Sq < 1024) return false;
+        // Sq 1024 ... 2048 (gate_probe.jsonl): head_dim 128, whole blocks 1.04-1.22 x the 128-row kernel; ragged Sq 1100 0.81 x; causal with an odd
+        // number of q-blocks (Sq 1280: the middle block has no mirror) 0.89 x; head_dim 64 at Sq 1024 0.96-0.99 x
+        if (p.in_prec == P_BF16 && p.pv16 && (p.Sq < 1024 || (p.Sq < 2048 && (p.Sq % 256 != 0 || p.D == 64 || (p.causal && (nqb & 1)))))) return false;
         if (w64_is_window(p)) {
             // the band's tile steps are what there is to share (thresholds of the unmasked kernel: cut items need 10 steps per CU)
             const uint64_t items = (uint64_t)p.B * p.H * nqb, steps = items * w64_tiles_per_item(p);
