@@ -203,8 +203,9 @@ def test_flux_strong_scaling_shards(heads):
     q, k, v = (torch.randn(1, heads, 4096, 128, device="cuda", dtype=torch.bfloat16) for _ in range(3))
     o = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
     kern = umfa_torch.last_kernel()
-    # (one head = 16 items of 64 tile steps: below the one-workgroup-per-CU kernel's break-even, the 128-row kernel splits the key range)
-    assert kern.startswith("fa_fwd16_w64" if heads > 1 else "fa_fwd16<"), kern
+    # (one or two heads = 16 / 32 items of 64 tile steps, 4 / 8 steps per CU: below the one-workgroup-per-CU kernel's break-even once its V cast
+    # pass is counted -- profiles/r4/few_items_probe.jsonl: 2 heads 51.4 us against 40.7 on the 128-row kernel, which splits the key range)
+    assert kern.startswith("fa_fwd16_w64" if heads > 2 else "fa_fwd16<"), kern
     from oracle import parity
     rows = parity.sample_rows(4096, groups=4)
     check_rows(q, k, v, o, rows, False, kern, f"strong_shard_H{heads}")

@@ -344,7 +344,11 @@ def test_w64_head_dim_64_softmax_references_and_strides(mode):
         kern = umfa_torch.last_kernel()
         assert fam(kern) == "fa_fwd16_w64<bf16,64>"
         ref = _oracle().sdpa_forward(bits(q), bits(k), bits(v))
-        check_forward(o.cpu().numpy(), ref, torch.bfloat16, kern, "w64_d64_" + mode, inputs=(bits(q), bits(k), bits(v)))
+        # inputs x 2: peaked rows.  An ideal kernel's dominant P is exactly 1.0 there, a stale reference rounds it like any other (half an ulp of
+        # the output on such rows), so the floor-relative bound is asserted for the exact reference only; the format ceiling and 1e-3 hold for all.
+        # (Until the launch ran as whole items -- round 4's grid rule -- its 16 items were cut into 128 one-tile parts, each with an exact
+        # reference of its own, and the stale modes never showed.)
+        check_forward(o.cpu().numpy(), ref, torch.bfloat16, kern, "w64_d64_" + mode, inputs=(bits(q), bits(k), bits(v)) if mode == "exact" else None)
 
 
 def test_w64_head_dim_64_lazy_overflow_restart():
@@ -487,7 +491,7 @@ def test_w64_small_ragged_sq_stays_on_the_128_row_kernel():
 @pytest.mark.parametrize("shape,causal,expect_w64", [((1, 24, 4096, 4096), False, True), ((1, 24, 1024, 1024), False, False),
                                                      ((4, 16, 1024, 1024), True, False), ((8, 16, 1024, 1024), True, True),
                                                      ((1, 4, 4096, 4096), False, True), ((1, 16, 2048, 2048), True, False),
-                                                     ((1, 256, 256, 256), False, False), ((1, 8, 2048, 2048), False, True),
+                                                     ((1, 256, 256, 256), False, False), ((1, 8, 2048, 2048), False, False), ((1, 16, 2048, 2048), False, True),
                                                      ((2, 32, 1024, 1024), False, True), ((8, 32, 512, 4096), False, False),
                                                      ((2, 24, 1100, 1100), False, False), ((4, 32, 1280, 1280), True, False), ((2, 24, 2100, 2100), False, True)])
 def test_w64_dispatch_gate(shape, causal, expect_w64):

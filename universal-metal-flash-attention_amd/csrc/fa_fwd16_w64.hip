@@ -327,7 +327,8 @@ bool fwd_w64_supported(const FwdParams& p) {
             // 512 jobs 91.7 / 107; non-causal cut items 10 steps per CU 27.2 / 23.4, 12: 27.0 / 23.6, 16: 30.4 / 30.0,
             // 96: 109 / 122; whole rounds B8 H16 S1024 42.1 / 46.2
             const uint64_t items = (uint64_t)p.B * p.H * nqb, steps = items * ((p.Skv + 63) / 64);
-            if (p.causal ? (uint64_t)p.B * p.H * ((nqb + 1) / 2) * 4 < cus * 3 : (items % cus != 0 && steps < cus * 16)) return false;
+            // (round 4, with the V cast pass in the launch: 24 steps per CU -- B1 H16 S2048: 34.5 against 31.4 us on the 128-row kernel)
+            if (p.causal ? (uint64_t)p.B * p.H * ((nqb + 1) / 2) * 4 < cus * 3 : (items % cus != 0 && steps < cus * (p.in_prec == P_BF16 && p.pv16 ? 24 : 16))) return false;
         } else if (p.causal) {
             if ((uint64_t)p.B * p.H * ((nqb + 1) / 2) * 8 < cus * 5) return false;  // 160 jobs: 78 / 85, 126 / 150, 217 / 258 us
         } else {
@@ -335,7 +336,8 @@ bool fwd_w64_supported(const FwdParams& p) {
             // 19 / 22 us, B1 H128 S512 27 / 32; cut items need 10 tile steps per CU, 8 with long key ranges
             // (B1 H32 S1024: 35 / 33, B1 H8 S2048: 39 / 44, B1 H40 S1024: 44 / 46, B1 H96 S512: 35 / 30)
             const uint64_t items = (uint64_t)p.B * p.H * nqb, steps = items * ((p.Skv + 63) / 64);
-            if (items % cus != 0 && steps < cus * 10 && !(steps >= cus * 8 && p.Skv >= 2048)) return false;
+            // (round 4, bf16 operands with the V cast pass in the launch: 12 steps per CU -- B1 H8 S2048, 8 per CU: 41.8 against 35.3 us)
+            if (p.in_prec == P_BF16 && p.pv16 ? (items % cus != 0 && steps < cus * 12) : (items % cus != 0 && steps < cus * 10 && !(steps >= cus * 8 && p.Skv >= 2048))) return false;
         }
     }
     return true;
@@ -367,6 +369,11 @@ static uint32_t w64_grid(const FwdParams& p) {
         // H3 47.3 / 51.7, H6 71.5 / 72.7, H12 (one part: whole items) 109.1 / 110.0.
         const uint64_t items = (uint64_t)p.B * p.H * ((p.Sq + 255) / 256);
         if (items < cus && cus / items >= 2 && items * (cus / items) <= total) return (uint32_t)(items * (cus / items));
+        // more than half an item per CU: whole items on `items` workgroups (some CUs idle) against cutting every item for all CUs and folding
+        // it -- the cut costs ~28 us of prologues and folds, the idle CUs T (1 - items / CUs) tile steps of ~1.6 us.  Graph-replayed us, whole /
+        // cut / 128-row kernel (profiles/r4/grid_probe.jsonl, grid_probe_more.jsonl): S 2048 (T = 32): 144 items 56 / 59 / 70, 176: 58 / 66 / 72, 216
+        // (S 2304): 73 / 86 / 85; S 4096 (T = 64): 176 items 100 / 102 / 133, 192: 106 / 106 / 137, 240: 123 / 135 / 149; head_dim 64, 216 items 48 / 54 / 51
+        if (items < cus && 2 * (uint64_t)w64_tiles_per_item(p) * (cus - items) < 35 * cus) return (uint32_t)items;
     }
     return total < cus ? (uint32_t)total : cus;  // never more workgroups than steps: every slice is non-empty
 }
@@ -406,6 +413,10 @@ hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cn
     wp.part_cnt = part_cnt;
     w64_softmax_policy(p.in_prec, &wp.tau, &wp.lazy);
     wp.skew = (uint32_t)tuning().w64_skew.load(std::memory_order_relaxed);
+    // (skew = 0xffffffff would run the remainder of a multi-round launch as one more round of whole items (kernel: whole_rem).  Measured,
+    // whole / cut: 464 items S 4096 242 / 235, 480 items S 2048 138 / 142, 448 items 134 / 130 -- a wash, so the launcher never asks for it;
+    // lab option w64_skew = -1)
+    if (tuning().w64_skew.load(std::memory_order_relaxed) == -1) wp.skew = 0xffffffffu;
     wp.rope_cos = p.rope_cos; wp.rope_sin = p.rope_sin; wp.rope_tb = p.rope_tb;
     wp.Tw = wp.T; wp.win_left = wp.win_right = 0;
     const bool rope = p.rope_cos != nullptr, window = w64_is_window(p), fp32o = p.out_prec == P_FP32, maskt = p.mask_kind == MK_BOOL;
