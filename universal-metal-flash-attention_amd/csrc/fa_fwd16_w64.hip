@@ -328,7 +328,8 @@ bool fwd_w64_supported(const FwdParams& p) {
             // 96: 109 / 122; whole rounds B8 H16 S1024 42.1 / 46.2
             const uint64_t items = (uint64_t)p.B * p.H * nqb, steps = items * ((p.Skv + 63) / 64);
             // (round 4, with the V cast pass in the launch: 24 steps per CU -- B1 H16 S2048: 34.5 against 31.4 us on the 128-row kernel)
-            if (p.causal ? (uint64_t)p.B * p.H * ((nqb + 1) / 2) * 4 < cus * 3 : (items % cus != 0 && steps < cus * (p.in_prec == P_BF16 && p.pv16 ? 24 : 16))) return false;
+            // (causal, bf16 with the cast pass: 1.5 jobs per CU -- few_items_probe_causal.jsonl: 192 jobs 61.0 / 49.9 us at S 2048, 90.5 / 90.2 at S 4096)
+            if (p.causal ? (uint64_t)p.B * p.H * ((nqb + 1) / 2) * 4 < cus * (p.in_prec == P_BF16 && p.pv16 ? 6 : 3) : (items % cus != 0 && steps < cus * (p.in_prec == P_BF16 && p.pv16 ? 24 : 16))) return false;
         } else if (p.causal) {
             if ((uint64_t)p.B * p.H * ((nqb + 1) / 2) * 8 < cus * 5) return false;  // 160 jobs: 78 / 85, 126 / 150, 217 / 258 us
         } else {
