@@ -404,9 +404,10 @@ const char* umfa_last_kernel_name(mfa_context_t context);
  *                        default = lazy for bf16, deferred for fp16 and the int8 kernels.
  *   "softmax_tau"        "0" ... "16" (log2 units, default 6)
  *   "force_w64" "no_w64" "w64_grid" "no_mask_flags" "bwd_exact" "bwd_dq" "bwd_persist" "no_split" "force_split"
- *   "no_dma" "bn64"      kernel-selection overrides used by tests and A/B benches ("0" / "1" or a number)
+ *   "no_dma" "bn64" "w64_skew" "no_w64_mask" "no_w64_mask_lazy" "ksplit" "no_pipe"
+ *                        kernel-selection overrides used by tests and A/B benches ("0" / "1" or a number)
  *   "bwd_ds_store"       "0" | "1": lab -- the dS-store form of the head_dim 128 non-causal backward (5 products, a
- *                        [B H Sq Skv] scratch in the operand type); measured slower than the default, kept for A/B
+ *                        [B H Sq Skv] scratch in the operand type); measured level with the default (round 4), kept for A/B
  *   "pv_fp16"            "1" (default) | "0": bf16 operands with the P V product in fp16 -- S = K Q^T on the bf16 MFMA, P rounded
  *                        to fp16 (11 bits instead of bf16's 8), V converted bf16 -> fp16 inside the kernels on its way into LDS
  *                        (exact for 2^-17 <= |v| < 65536): the bf16-input forward then sits inside 1e-3 of fp64 SDPA at every
