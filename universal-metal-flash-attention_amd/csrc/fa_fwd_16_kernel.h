@@ -85,8 +85,9 @@ __device__ __forceinline__ unsigned bf16x2_to_f16x2(unsigned x) {
 
 // PV16 (T = bf16 only; FwdParams::pv16, the default bf16 forward): the second product runs in fp16 -- P is rounded to fp16 (11
 // bits instead of bf16's 8: the bf16-input forward inside 1e-3) and V is fp16:
-//   PV16 = 1  V is converted bf16 -> fp16 on its way into LDS: V tiles then always go through registers (buffer_load ->
-//             convert -> ds_write), K keeps LDS-DMA where it had it.  Short launches (a cast pre-pass would cost more than it saves).
+//   PV16 = 1  V is converted bf16 -> fp16 inside the kernel: with LDS-DMA staging the tile lands as bf16 and every wave converts the
+//             quarter its own DMA instructions filled, in place, before the tile's barrier (stage_write); with register staging on
+//             the way into LDS.  Launches whose V tiles are not re-read often enough for a cast pre-pass to pay (runtime.hip).
 //   PV16 = 2  p.v already points at an fp16 image of V (the runtime's cast pre-pass, as for fa_fwd16_w64): V staged like K.
 //             Long launches: the conversion is 24 (head_dim 64) ... 48 (128) vector instructions per tile per wave in a kernel
 //             that is vector-bound, and every workgroup repeats it.
