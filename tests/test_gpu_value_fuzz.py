@@ -20,11 +20,14 @@ ROOT = Path(__file__).resolve().parent.parent
 
 
 def _fuzz():
-    spec = importlib.util.spec_from_file_location("value_fuzz", ROOT / "tools" / "lab" / "value_fuzz.py")
-    mod = importlib.util.module_from_spec(spec)
-    sys.modules.setdefault("value_fuzz", mod)
-    spec.loader.exec_module(mod)
-    return mod
+    # loaded ONCE: the module puts its directories in front of sys.path when it runs, and a sys.path that has grown by three entries per
+    # test becomes a PYTHONPATH too long to exec with (torch.compile's worker pool in a later test: "Argument list too long")
+    if "value_fuzz" not in sys.modules:
+        spec = importlib.util.spec_from_file_location("value_fuzz", ROOT / "tools" / "lab" / "value_fuzz.py")
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules["value_fuzz"] = mod
+        spec.loader.exec_module(mod)
+    return sys.modules["value_fuzz"]
 
 
 @pytest.mark.parametrize("seed", range(150))

@@ -108,12 +108,14 @@ hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p,
             // the one-wave-per-SIMD kernels take V as a dense fp16 image: one HBM-speed cast pass per call into a block of its
             // own (the workspace may hold the rotated K / Q of the fused-RoPE entry).  Converting inside these kernels was
             // built and measured: +15 % (every workgroup re-converts every tile); the 128-row kernel below does convert in-kernel.
-            const size_t vbytes = (size_t)p.B * p.H * p.Skv * p.D * 2;
+            // (a broadcast batch / head dimension of V -- the zero-copy GQA views: stride 0 -- stays one: its slab is cast once)
+            const uint32_t vB = p.vs[0] == 0 ? 1u : p.B, vH = p.vs[1] == 0 ? 1u : p.H;
+            const size_t vbytes = (size_t)vB * vH * p.Skv * p.D * 2;
             void* v16 = sc.v16.ensure(vbytes + 256, stream);
             if (!v16) return hipErrorOutOfMemory;
-            if ((e = launch_cast_rows_bf16_to_f16(p.v, p.vs, v16, p.B, p.H, p.Skv, p.D, pv.status, stream)) != hipSuccess) return e;
+            if ((e = launch_cast_rows_bf16_to_f16(p.v, p.vs, v16, vB, vH, p.Skv, p.D, pv.status, stream)) != hipSuccess) return e;
             pv.v = v16;
-            pv.vs[0] = (int64_t)p.H * p.Skv * p.D; pv.vs[1] = (int64_t)p.Skv * p.D; pv.vs[2] = p.D; pv.vs[3] = 1;
+            pv.vs[0] = p.vs[0] == 0 ? 0 : (int64_t)vH * p.Skv * p.D; pv.vs[1] = p.vs[1] == 0 ? 0 : (int64_t)p.Skv * p.D; pv.vs[2] = p.D; pv.vs[3] = 1;
         }
         if (pv.mask_kind == MK_BOOL) {
             // bool mask tensor on the one-wave-per-SIMD structure: one pre-pass re-packs it into per-lane bit words, per-wave tile
@@ -131,17 +133,18 @@ hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p,
         return hipErrorNotSupported;  // only the 256-row kernel rotates Q in registers (the entry asks before it sets this)
     } else if (lowp && fwd_16_supported(p)) {
         FwdParams pp = pv;
-        if (pp.pv16 && (size_t)p.B * p.H * p.Skv * p.D * 2 >= ((size_t)16 << 20) && p.Sq >= 1024) {
+        if (pp.pv16 && (size_t)(p.vs[0] == 0 ? 1u : p.B) * (p.vs[1] == 0 ? 1u : p.H) * p.Skv * p.D * 2 >= ((size_t)16 << 20) && p.Sq >= 1024) {
             // the 128-row kernel converts V in-kernel (24 ... 48 vector instructions per tile per wave in a vector-bound kernel, repeated
             // by every workgroup): right for short launches, where a pre-pass costs its launch; from 16 MB of V on the HBM-speed cast
             // pass is cheaper (FLUX-size masked calls: ~11 us against ~15 % of the kernel) -- IF the tiles are re-read: with fewer than eight
             // 128-row q-blocks per head (decode-like calls: K / V are swept once) two more passes over V cost more than the kernel's own
             // sweep (B8 H32 Sq1 Skv8192: 393 us with the pass, see profiles/r4/lab_notes.md section 6).  Without a block (capture): in-kernel.
-            void* v16 = sc.v16.ensure((size_t)p.B * p.H * p.Skv * p.D * 2 + 256, stream);
+            const uint32_t vB = p.vs[0] == 0 ? 1u : p.B, vH = p.vs[1] == 0 ? 1u : p.H;  // (broadcast dimensions stay broadcast)
+            void* v16 = sc.v16.ensure((size_t)vB * vH * p.Skv * p.D * 2 + 256, stream);
             if (v16) {
-                if ((e = launch_cast_rows_bf16_to_f16(p.v, p.vs, v16, p.B, p.H, p.Skv, p.D, pv.status, stream)) != hipSuccess) return e;
+                if ((e = launch_cast_rows_bf16_to_f16(p.v, p.vs, v16, vB, vH, p.Skv, p.D, pv.status, stream)) != hipSuccess) return e;
                 pp.v = v16;
-                pp.vs[0] = (int64_t)p.H * p.Skv * p.D; pp.vs[1] = (int64_t)p.Skv * p.D; pp.vs[2] = p.D; pp.vs[3] = 1;
+                pp.vs[0] = p.vs[0] == 0 ? 0 : (int64_t)vH * p.Skv * p.D; pp.vs[1] = p.vs[1] == 0 ? 0 : (int64_t)p.Skv * p.D; pp.vs[2] = p.D; pp.vs[3] = 1;
                 pp.pv16 = 2;
             }
         }
