@@ -77,11 +77,19 @@ FwdSplitPlan fwd_16_split_plan(const FwdParams& p) {
     // One q-block per (batch, head) -- decode-like calls: no two items share K / V, the sweep is bound by how many
     // tile loads a CU keeps in flight, so aim for two resident workgroups per CU (B8 H32 Sq1 Skv8192: 297 -> 243 us
     // with 2 parts, B4 H32: 172 -> 133 us with 4; with more items than 2 x CUs splitting only loses)
-    if (nqb == 1) { k = 2 * cus / items; kmax = 16; }
+    if (nqb == 1) { k = 2 * cus / items; kmax = items * 16 < cus ? 32 : 16; }  // (very few heads: 16 parts would leave CUs without any)
     const int force = tuning().force_split.load(std::memory_order_relaxed);  // experiments: split every item k ways
     if (force >= 2 && force <= 8) k = (uint32_t)force;
     if (k > kmax) k = kmax;
     if (k > ntiles / 4) k = ntiles / 4;  // keep >= 4 key tiles per part
+    // the folding workgroup reads the other parts one after the other (a dependent round trip of write-through memory each, ~2 us): a part
+    // costs the fold about what 1.7 key tiles cost a sweep, so beyond sqrt(0.6 ntiles) parts the fold grows faster than the sweeps shrink
+    // (B1 H4 Sq1 Skv8192: 128 tiles, 32 parts 100 us; round 4, profiles/r4/lab_notes.md section 6)
+    if (force < 2) {
+        uint32_t kc = 2;
+        while ((uint64_t)(kc + 1) * (kc + 1) * 5 <= (uint64_t)ntiles * 3) ++kc;
+        if (k > kc) k = kc;
+    }
     if (k < 2) return plan;
     plan.n_full = 0;
     plan.nsplit = k;
