@@ -13,6 +13,7 @@ import umfa_torch  # noqa: E402
 sys.path.insert(0, str(ROOT / "tools" / "lab"))
 from split_probe import graph_us  # noqa: E402
 
+DT = torch.float16 if "fp16" in sys.argv else torch.bfloat16
 CASES2 = [(2, 32, 1024, 4096, 128, False), (4, 16, 1024, 1024, 128, False), (1, 64, 1024, 8192, 128, False), (2, 32, 1536, 1536, 128, False), (1, 32, 2048, 2048, 128, False),
           (8, 16, 1024, 1024, 128, True), (4, 32, 1280, 1280, 128, True), (8, 16, 1024, 1024, 64, False), (8, 16, 1024, 1024, 64, True), (4, 64, 1024, 1024, 64, False),
           (1, 24, 1024, 4096, 128, False), (2, 24, 1100, 1100, 128, False)]
@@ -23,9 +24,9 @@ for (B, H, Sq, Skv, D, causal) in CASES3 if len(sys.argv) > 1 and sys.argv[1] ==
                                    (2, 32, 1024, 1024, 128, False), (16, 16, 256, 256, 128, False), (8, 32, 256, 8192, 64, False), (16, 16, 512, 512, 64, False),
                                    (8, 16, 512, 512, 128, True), (4, 32, 768, 768, 128, True)]:
     torch.manual_seed(0)
-    q = torch.randn(B, H, Sq, D, device="cuda", dtype=torch.bfloat16)
-    k = torch.randn(B, H, Skv, D, device="cuda", dtype=torch.bfloat16)
-    v = torch.randn(B, H, Skv, D, device="cuda", dtype=torch.bfloat16)
+    q = torch.randn(B, H, Sq, D, device="cuda", dtype=DT)
+    k = torch.randn(B, H, Skv, D, device="cuda", dtype=DT)
+    v = torch.randn(B, H, Skv, D, device="cuda", dtype=DT)
     o = torch.empty(B, H, Sq, D, device="cuda", dtype=torch.float32)
     row = {"shape": f"B{B} H{H} Sq{Sq} Skv{Skv} D{D} {'causal' if causal else 'full'}"}
     for name, opts in (("default", {}), ("r128", {"no_w64": 1})):

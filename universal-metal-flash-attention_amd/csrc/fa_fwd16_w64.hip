@@ -329,7 +329,7 @@ bool fwd_w64_supported(const FwdParams& p) {
             const uint64_t items = (uint64_t)p.B * p.H * nqb, steps = items * ((p.Skv + 63) / 64);
             // (round 4, with the V cast pass in the launch: 24 steps per CU -- B1 H16 S2048: 34.5 against 31.4 us on the 128-row kernel)
             // (causal, bf16 with the cast pass: 1.5 jobs per CU -- few_items_probe_causal.jsonl: 192 jobs 61.0 / 49.9 us at S 2048, 90.5 / 90.2 at S 4096)
-            if (p.causal ? (uint64_t)p.B * p.H * ((nqb + 1) / 2) * 4 < cus * (p.in_prec == P_BF16 && p.pv16 ? 6 : 3) : (items % cus != 0 && steps < cus * (p.in_prec == P_BF16 && p.pv16 ? 24 : 16))) return false;
+            if (p.causal ? (uint64_t)p.B * p.H * ((nqb + 1) / 2) * 4 < cus * (p.in_prec == P_BF16 && p.pv16 ? 6 : 3) : (items % cus != 0 && steps < cus * 24)) return false;  // (fp16 operands too: routing_sweep_fp16.jsonl, B1 H16 S2048 30.1 against 26.9 us)
         } else if (p.causal) {
             if ((uint64_t)p.B * p.H * ((nqb + 1) / 2) * 8 < cus * 5) return false;  // 160 jobs: 78 / 85, 126 / 150, 217 / 258 us
         } else {
@@ -338,7 +338,11 @@ bool fwd_w64_supported(const FwdParams& p) {
             // (B1 H32 S1024: 35 / 33, B1 H8 S2048: 39 / 44, B1 H40 S1024: 44 / 46, B1 H96 S512: 35 / 30)
             const uint64_t items = (uint64_t)p.B * p.H * nqb, steps = items * ((p.Skv + 63) / 64);
             // (round 4, bf16 operands with the V cast pass in the launch: 12 steps per CU -- B1 H8 S2048, 8 per CU: 41.8 against 35.3 us)
-            if (p.in_prec == P_BF16 && p.pv16 ? (items % cus != 0 && steps < cus * 12) : (items % cus != 0 && steps < cus * 10 && !(steps >= cus * 8 && p.Skv >= 2048))) return false;
+            // (fp16 operands, no pass, lose the same launches by 7 %: routing_sweep_fp16.jsonl -- one threshold for both)
+            if (items % cus != 0 && steps < cus * 12) return false;
+            // short key ranges (fewer than 16 tiles per item): a cut item is a few tiles and a fold -- B1 H24 Sq4096 Skv512 (8 tiles, 12 steps per CU)
+            // 40.0 us fp16 / 43.0 bf16 against 36.5 / 41.6 on the 128-row kernel
+            if (items % cus != 0 && (p.Skv + 63) / 64 < 16 && steps < cus * 24) return false;
         }
     }
     return true;
