@@ -511,8 +511,11 @@ def test_w64_dispatch_gate_fp16_operands_keep_short_query_ranges():
     """fp16 operands need no cast pass: the one-workgroup-per-CU kernel keeps its round-3 gate (whole rounds win at any size)"""
     import umfa_torch
     q = torch.randn(1, 256, 256, 128, device="cuda", dtype=torch.float16)
-    umfa_torch.attention_forward(q, q, q)
+    k = torch.randn(1, 256, 512, 128, device="cuda", dtype=torch.float16)
+    umfa_torch.attention_forward(q, k, k)
     assert umfa_torch.last_kernel() == "fa_fwd16_w64<fp16,128>", umfa_torch.last_kernel()
+    umfa_torch.attention_forward(q, q, q)  # (key ranges of fewer than eight tiles: an item is mostly prologue and output)
+    assert umfa_torch.last_kernel() == "fa_fwd16<fp16,128>", umfa_torch.last_kernel()
 
 
 @pytest.mark.parametrize("shape,causal,expect_w64", [((1, 24, 4096, 4096), False, True), ((8, 16, 2048, 2048), False, True), ((8, 16, 1024, 1024), False, False),

@@ -316,7 +316,14 @@ bool fwd_w64_supported(const FwdParams& p) {
         // Sq 512: 331 / 327, 66 / 54, 40 / 31; Sq 768: 131 / 125, causal 54 / 51; Sq 1024: 49 / 51.
         // Sq 1024 ... 2048 (gate_probe.jsonl): head_dim 128, whole blocks 1.04-1.22 x the 128-row kernel; ragged Sq 1100 0.81 x; causal with an odd
         // number of q-blocks (Sq 1280: the middle block has no mirror) 0.89 x; head_dim 64 at Sq 1024 0.96-0.99 x
-        if (p.in_prec == P_BF16 && p.pv16 && (p.Sq < 1024 || (p.Sq < 2048 && (p.Sq % 256 != 0 || p.D == 64 || (p.causal && (nqb & 1)))))) return false;
+        // Long key ranges shift it (random-size audit, routing_random_bf16_before.jsonl): with 64 or more key tiles per item this kernel's lead over the
+        // 128-row kernel is 1.4 x and pays for the pass from three q-blocks on -- B8 H5 Sq768 Skv8192 148 against 182 us, head_dim 64 B2 H12 Sq1536
+        // Skv8192 104 against 147
+        const bool long_keys = !p.causal && (p.Skv + 63) / 64 >= 64;
+        if (p.in_prec == P_BF16 && p.pv16) {
+            if (p.Sq < 768 || (p.Sq < 1024 && !(long_keys && p.D == 128))) return false;
+            if (p.Sq < 2048 && (p.Sq % 256 != 0 || (p.D == 64 && !(long_keys && p.Sq >= 1024)) || (p.causal && (nqb & 1)))) return false;
+        }
         if (w64_is_window(p)) {
             // the band's tile steps are what there is to share (thresholds of the unmasked kernel: cut items need 10 steps per CU)
             const uint64_t items = (uint64_t)p.B * p.H * nqb, steps = items * w64_tiles_per_item(p);
@@ -329,9 +336,23 @@ bool fwd_w64_supported(const FwdParams& p) {
             const uint64_t items = (uint64_t)p.B * p.H * nqb, steps = items * ((p.Skv + 63) / 64);
             // (round 4, with the V cast pass in the launch: 24 steps per CU -- B1 H16 S2048: 34.5 against 31.4 us on the 128-row kernel)
             // (causal, bf16 with the cast pass: 1.5 jobs per CU -- few_items_probe_causal.jsonl: 192 jobs 61.0 / 49.9 us at S 2048, 90.5 / 90.2 at S 4096)
-            if (p.causal ? (uint64_t)p.B * p.H * ((nqb + 1) / 2) * 4 < cus * (p.in_prec == P_BF16 && p.pv16 ? 6 : 3) : (items % cus != 0 && steps < cus * 24)) return false;  // (fp16 operands too: routing_sweep_fp16.jsonl, B1 H16 S2048 30.1 against 26.9 us)
+            // (causal jobs are whole -- no cut: a last round that is mostly empty is paid in full.  More than a quarter of the rounds' slots empty and
+            // the 128-row kernel wins at head_dim 64: B1 H34 S8192 (2.1 rounds) 442 against 407 us, fp16 B8 H12 S3072 (2.25) 196 / 166, B1 H32 S6144 (1.5) 235 / 223)
+            if (p.causal) {
+                const uint64_t jobs = (uint64_t)p.B * p.H * ((nqb + 1) / 2), rounds = (jobs + cus - 1) / cus;
+                if (rounds * cus * 4 > jobs * 5) return false;
+            }
+            // (second pass: long jobs amortise the pass and the prologues -- 240 jobs of 24 + 24 q-blocks (S 6144) 127 us here against 168; so: 1.5 jobs
+            // per CU, or 0.9 per CU, or 0.75 per CU with twenty or more q-blocks per head)
+            const uint64_t cjobs = (uint64_t)p.B * p.H * ((nqb + 1) / 2);
+            const bool c_ok = !(p.in_prec == P_BF16 && p.pv16) ? cjobs * 4 >= cus * 3 : (cjobs * 4 >= cus * 6 || cjobs * 10 >= cus * 9 || (nqb >= 20 && cjobs * 4 >= cus * 3));
+            if (p.causal ? !c_ok : (items % cus != 0 && (steps < cus * 24 || (p.Skv + 63) / 64 < 32))) return false;  // (fp16 operands too: routing_sweep_fp16.jsonl, B1 H16 S2048 30.1 against 26.9 us; cut items of fewer than 32 tiles: fp16 B8 H8 S1280 47.4 / 42.1)
         } else if (p.causal) {
             if ((uint64_t)p.B * p.H * ((nqb + 1) / 2) * 8 < cus * 5) return false;  // 160 jobs: 78 / 85, 126 / 150, 217 / 258 us
+            // (whole jobs, no cut: from the second round on a mostly empty last round is paid in full -- B1 H64 S2304, 320 jobs = 1.25 rounds: 171 us
+            // against 140 on the 128-row kernel)
+            const uint64_t jobs = (uint64_t)p.B * p.H * ((nqb + 1) / 2), rounds = (jobs + cus - 1) / cus;
+            if (rounds >= 2 && rounds * cus * 2 > jobs * 3) return false;
         } else {
             // whole rounds (every workgroup one or more complete items, nothing to fold) win at any size: B1 H256 S256
             // 19 / 22 us, B1 H128 S512 27 / 32; cut items need 10 tile steps per CU, 8 with long key ranges
@@ -339,7 +360,10 @@ bool fwd_w64_supported(const FwdParams& p) {
             const uint64_t items = (uint64_t)p.B * p.H * nqb, steps = items * ((p.Skv + 63) / 64);
             // (round 4, bf16 operands with the V cast pass in the launch: 12 steps per CU -- B1 H8 S2048, 8 per CU: 41.8 against 35.3 us)
             // (fp16 operands, no pass, lose the same launches by 7 %: routing_sweep_fp16.jsonl -- one threshold for both)
-            if (items % cus != 0 && steps < cus * 12) return false;
+            // (second pass, random-size audit: 10, not 12 -- B8 H1 S2304, 10.1 steps per CU: 41 us here against 50 on the 128-row kernel (fp16), 45 / 48 (bf16))
+            if (items % cus != 0 && steps < cus * 10) return false;
+            // (key ranges of a few tiles: an item is mostly prologue and output -- fp16 B2 H128 Sq3072 Skv256, 12 whole rounds: 205 us against 186)
+            if ((p.Skv + 63) / 64 < 8) return false;
             // short key ranges (fewer than 16 tiles per item): a cut item is a few tiles and a fold -- B1 H24 Sq4096 Skv512 (8 tiles, 12 steps per CU)
             // 40.0 us fp16 / 43.0 bf16 against 36.5 / 41.6 on the 128-row kernel
             if (items % cus != 0 && (p.Skv + 63) / 64 < 16 && steps < cus * 24) return false;

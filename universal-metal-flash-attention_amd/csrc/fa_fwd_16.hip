@@ -73,7 +73,10 @@ FwdSplitPlan fwd_16_split_plan(const FwdParams& p) {
         plan.cnt_bytes = ((size_t)(items / 2) * sizeof(uint32_t) + 15) & ~(size_t)15;
         return plan;
     }
-    uint32_t k = cus / items, kmax = 8;
+    // (round 4: between half a workgroup and one workgroup per CU the plan was cus / items = 1 part -- no split, CUs idle.  With the fence-free fold
+    // two workgroups per CU pay: 144 items 57.7 -> 47.3 us with 3 parts, 160 items 92.7 -> 70.0, 240 items 182.6 -> 157.0, 256 items 189.9 -> 173.5 with 2
+    // (profiles/r4/split_gap_probe.jsonl); at most one item per CU only -- with more, splitting loses)
+    uint32_t k = items > cus / 2 ? 2 * cus / items : cus / items, kmax = 8;
     // One q-block per (batch, head) -- decode-like calls: no two items share K / V, the sweep is bound by how many
     // tile loads a CU keeps in flight, so aim for two resident workgroups per CU (B8 H32 Sq1 Skv8192: 297 -> 243 us
     // with 2 parts, B4 H32: 172 -> 133 us with 4; with more items than 2 x CUs splitting only loses)
