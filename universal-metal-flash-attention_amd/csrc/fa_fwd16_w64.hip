@@ -324,6 +324,12 @@ bool fwd_w64_supported(const FwdParams& p) {
             if (p.Sq < 768 || (p.Sq < 1024 && !(long_keys && p.D == 128))) return false;
             if (p.Sq < 2048 && (p.Sq % 256 != 0 || (p.D == 64 && !(long_keys && p.Sq >= 1024)) || (p.causal && (nqb & 1)))) return false;
         }
+        // (causal with an odd, small number of q-blocks -- the middle block has no mirror, its job is half as long as the others -- for every operand type:
+        // fp16 B4 H32 S1280 104 us against 90 on the 128-row kernel)
+        if (p.causal && !w64_is_window(p) && (nqb & 1) && nqb < 8) return false;
+        // (key ranges of a few tiles: an item is mostly prologue and output -- fp16 B2 H128 Sq3072 Skv256, 12 whole rounds: 205 us against 186; head_dim 64
+        // B8 H12 Sq2048 Skv77 29.0 / 23.4)
+        if (!w64_is_window(p) && (p.Skv + 63) / 64 < (p.D == 64 ? 16u : 8u)) return false;  // (head_dim 64, 8 tiles, nine whole rounds: 123 / 112)
         if (w64_is_window(p)) {
             // the band's tile steps are what there is to share (thresholds of the unmasked kernel: cut items need 10 steps per CU)
             const uint64_t items = (uint64_t)p.B * p.H * nqb, steps = items * w64_tiles_per_item(p);
@@ -346,7 +352,7 @@ bool fwd_w64_supported(const FwdParams& p) {
             // per CU, or 0.9 per CU, or 0.75 per CU with twenty or more q-blocks per head)
             const uint64_t cjobs = (uint64_t)p.B * p.H * ((nqb + 1) / 2);
             const bool c_ok = !(p.in_prec == P_BF16 && p.pv16) ? cjobs * 4 >= cus * 3 : (cjobs * 4 >= cus * 6 || cjobs * 10 >= cus * 9 || (nqb >= 20 && cjobs * 4 >= cus * 3));
-            if (p.causal ? !c_ok : (items % cus != 0 && (steps < cus * 24 || (p.Skv + 63) / 64 < 32))) return false;  // (fp16 operands too: routing_sweep_fp16.jsonl, B1 H16 S2048 30.1 against 26.9 us; cut items of fewer than 32 tiles: fp16 B8 H8 S1280 47.4 / 42.1)
+            if (p.causal ? !c_ok : (items % cus != 0 && (steps < cus * 20 || (p.Skv + 63) / 64 < 32 || (items > cus && (p.Skv + 63) / 64 < 40)))) return false;  // (20: fp16 B2 H10 S2048 37.6 here / 39.7; a remainder of SHORT items behind whole rounds: fp16 B4 H10 S2304 (36 tiles) 78 / 70 -- long ones win: B4 H6 Sq3072 Skv8192 183 / 221)  // (fp16 operands too: routing_sweep_fp16.jsonl, B1 H16 S2048 30.1 against 26.9 us; cut items of fewer than 32 tiles: fp16 B8 H8 S1280 47.4 / 42.1)
         } else if (p.causal) {
             if ((uint64_t)p.B * p.H * ((nqb + 1) / 2) * 8 < cus * 5) return false;  // 160 jobs: 78 / 85, 126 / 150, 217 / 258 us
             // (whole jobs, no cut: from the second round on a mostly empty last round is paid in full -- B1 H64 S2304, 320 jobs = 1.25 rounds: 171 us
@@ -362,8 +368,7 @@ bool fwd_w64_supported(const FwdParams& p) {
             // (fp16 operands, no pass, lose the same launches by 7 %: routing_sweep_fp16.jsonl -- one threshold for both)
             // (second pass, random-size audit: 10, not 12 -- B8 H1 S2304, 10.1 steps per CU: 41 us here against 50 on the 128-row kernel (fp16), 45 / 48 (bf16))
             if (items % cus != 0 && steps < cus * 10) return false;
-            // (key ranges of a few tiles: an item is mostly prologue and output -- fp16 B2 H128 Sq3072 Skv256, 12 whole rounds: 205 us against 186)
-            if ((p.Skv + 63) / 64 < 8) return false;
+
             // short key ranges (fewer than 16 tiles per item): a cut item is a few tiles and a fold -- B1 H24 Sq4096 Skv512 (8 tiles, 12 steps per CU)
             // 40.0 us fp16 / 43.0 bf16 against 36.5 / 41.6 on the 128-row kernel
             if (items % cus != 0 && (p.Skv + 63) / 64 < 16 && steps < cus * 24) return false;
