@@ -294,7 +294,14 @@ bool fwd_w64_supported(const FwdParams& p) {
         const uint64_t blocks = (uint64_t)p.B * p.H * ((p.Sq + 255) / 256), cus = (uint64_t)w64_cu_count();
         if (tuning().force_w64.load(std::memory_order_relaxed)) return true;
         if (p.in_prec == P_BF16 && p.Sq < 1024) return false;  // (the fp16 image of V is re-read by too few q-blocks: see below)
-        return blocks >= cus || (p.ms[2] == 0 && blocks * ((p.Skv + 63) / 64) >= cus * 10);
+        // (1024 <= Sq < 2048, masks shared by every (batch, head) or without a row dimension: B4 H12 S1536 window 78 us against 62, B4 H8 S1536 padding 72 / 65,
+        // B1 H64 S1024 window 48 / 44 -- the pass and the per-block prologues against short lists)
+        if (p.in_prec == P_BF16 && p.Sq < 2048 && ((p.ms[0] == 0 && p.ms[1] == 0) || p.ms[2] == 0)) return false;
+        // (random-size audit, routing_random_masks_*.jsonl: with WHOLE blocks on `blocks` workgroups -- nothing cut, some CUs idle -- DENSE masks with a row
+        // dimension win here too from three eighths of a block per CU (random per-head masks B4 H6 S1536 68 us against 112, B2 H4 S4096 139 / 162), sparse
+        // structured ones lose as much (block-diagonal, 8 documents, B4 H6 S1536 47 / 30).  The host cannot see the density; it can see the shape: a mask with
+        // a batch or head dimension of its own is not a window or a document mask, one shared by every (batch, head) usually is)
+        return blocks >= cus || (p.ms[2] == 0 && blocks * ((p.Skv + 63) / 64) >= cus * 10) || ((p.ms[0] != 0 || p.ms[1] != 0) && blocks * 8 >= cus * 3);
     }
     if (w64_is_window(p) && p.rope_cos) return false;  // window instantiations: no fused rotation
     if (p.D == 64 && p.rope_cos) return false;  // the fused Q rotation exists at head_dim 128 only
