@@ -353,7 +353,8 @@ bool fwd_w64_supported(const FwdParams& p) {
             // the 128-row kernel wins at head_dim 64: B1 H34 S8192 (2.1 rounds) 442 against 407 us, fp16 B8 H12 S3072 (2.25) 196 / 166, B1 H32 S6144 (1.5) 235 / 223)
             if (p.causal) {
                 const uint64_t jobs = (uint64_t)p.B * p.H * ((nqb + 1) / 2), rounds = (jobs + cus - 1) / cus;
-                if (rounds * cus * 4 > jobs * 5) return false;
+                if (rounds >= 2 && rounds * cus * 4 > jobs * 5) return false;  // (a single partly filled round is fine: B4 H3 S8192, 192 jobs, 151 us here / 200)
+                if ((nqb & 1) && nqb < 16) return false;                        // (odd q-block counts: the unpaired middle block -- B8 H16 S2304 176 / 148)
             }
             // (second pass: long jobs amortise the pass and the prologues -- 240 jobs of 24 + 24 q-blocks (S 6144) 127 us here against 168; so: 1.5 jobs
             // per CU, or 0.9 per CU, or 0.75 per CU with twenty or more q-blocks per head)

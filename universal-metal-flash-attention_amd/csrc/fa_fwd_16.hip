@@ -73,25 +73,30 @@ FwdSplitPlan fwd_16_split_plan(const FwdParams& p) {
         plan.cnt_bytes = ((size_t)(items / 2) * sizeof(uint32_t) + 15) & ~(size_t)15;
         return plan;
     }
-    // (round 4: between half a workgroup and one workgroup per CU the plan was cus / items = 1 part -- no split, CUs idle.  With the fence-free fold
-    // two workgroups per CU pay: 144 items 57.7 -> 47.3 us with 3 parts, 160 items 92.7 -> 70.0, 240 items 182.6 -> 157.0, 256 items 189.9 -> 173.5 with 2
-    // (profiles/r4/split_gap_probe.jsonl); at most one item per CU only -- with more, splitting loses)
-    uint32_t k = items > cus / 2 ? 2 * cus / items : cus / items, kmax = 8;
-    // One q-block per (batch, head) -- decode-like calls: no two items share K / V, the sweep is bound by how many
-    // tile loads a CU keeps in flight, so aim for two resident workgroups per CU (B8 H32 Sq1 Skv8192: 297 -> 243 us
-    // with 2 parts, B4 H32: 172 -> 133 us with 4; with more items than 2 x CUs splitting only loses)
-    if (nqb == 1) { k = 2 * cus / items; kmax = items * 16 < cus ? 32 : 16; }  // (very few heads: 16 parts would leave CUs without any)
+    // How many parts (round 4, from measurements: profiles/r4/decode_k_probe.jsonl, split_gap_probe.jsonl, split_plan_random*.jsonl).  A launch of
+    // items x k workgroups puts w = ceil(items k / CUs) of them on the fullest CU; two co-resident workgroups run ~1.6 x as fast as one after the
+    // other, a third waits for a slot (R = 2 workgroups fit; one at head_dim 256); a part costs the fold ~3 key tiles (the folding workgroup reads the
+    // parts one after the other, a dependent round trip of write-through memory each).  In key tiles:
+    //     cost(k) = ntiles / k x f(w) + 3 k,   f(1) = 1, f(2) = 1.25, f(3) = 2.25, f(4) = 2.5, ...
+    // and the plan is its minimum over k = 1 ... min(kmax, ntiles / 4).  This replaces three rules that each fitted one regime: "one workgroup per CU"
+    // (left 192 workgroups on 256 CUs at 96 items), "two per CU for decode-like calls" (B1 H32 Sq1 Skv8192: 16 parts 75 us, 8 parts 51), "no split
+    // above half an item per CU" (160 items, three parts: 92.7 -> 69.5 us).  Checked against every forced part count: split_plan_random*.jsonl.
+    const uint32_t kmax = nqb == 1 ? 32u : 8u;
+    const uint32_t R = dp > 128 ? 1u : 2u;
     const int force = tuning().force_split.load(std::memory_order_relaxed);  // experiments: split every item k ways
-    if (force >= 2 && force <= 8) k = (uint32_t)force;
-    if (k > kmax) k = kmax;
-    if (k > ntiles / 4) k = ntiles / 4;  // keep >= 4 key tiles per part
-    // the folding workgroup reads the other parts one after the other (a dependent round trip of write-through memory each, ~2 us): a part
-    // costs the fold about what 1.7 key tiles cost a sweep, so beyond sqrt(0.6 ntiles) parts the fold grows faster than the sweeps shrink
-    // (B1 H4 Sq1 Skv8192: 128 tiles, 32 parts 100 us; round 4, profiles/r4/lab_notes.md section 6)
-    if (force < 2) {
-        uint32_t kc = 2;
-        while ((uint64_t)(kc + 1) * (kc + 1) * 5 <= (uint64_t)ntiles * 3) ++kc;
-        if (k > kc) k = kc;
+    uint32_t k = 1;
+    if (force >= 2 && force <= 32) {
+        k = (uint32_t)force;
+        if (k > ntiles / 4) k = ntiles / 4;
+    } else if (items <= cus) {  // (more than one item per CU: the dispatcher refills slots as they free up, splitting only adds folds)
+        double best = 1e30;
+        for (uint32_t kk = 1; kk <= kmax && (kk == 1 || kk <= ntiles / 4); ++kk) {
+            const uint64_t w = ((uint64_t)items * kk + cus - 1) / cus;
+            const uint64_t rounds = (w + R - 1) / R, last = w - (rounds - 1) * R;  // full rounds of R co-resident workgroups, then `last`
+            const double f = (double)(rounds - 1) * (R == 2 ? 1.25 : 1.0) + (last == 2 ? 1.25 : 1.0);
+            const double cost = (double)ntiles / kk * f + (kk > 1 ? 3.0 * kk : 0.0);
+            if (cost < best * 0.97) { best = cost; k = kk; }  // (a tie goes to fewer parts)
+        }
     }
     if (k < 2) return plan;
     plan.n_full = 0;
