@@ -43,10 +43,10 @@ static int cu_count() { return device_cu_count(); }
 
 static inline uint32_t dp16_of(uint32_t D) { return D <= 32 ? 32 : D <= 64 ? 64 : D <= 128 ? 128 : 256; }
 
-// Split-KV plan.  Measured on MI355X (tools/bench_one.py, B1 S4096 D128): a second resident workgroup per CU
-// adds only ~15 % throughput, so splitting pays exactly when there are fewer work items than CUs
-// (64 items: 90 -> 48 us with 4 parts; 128 items: 95 -> 73 us with 2) and loses once every CU already
-// has an item (256 items: 111 -> 120 us).  Hence: split only while items * parts <= CUs.
+// Split-KV plan.  Rounds 1-3 (tools/bench_one.py, B1 S4096 D128; the fold then cost an agent-scope release fence per part): splitting paid exactly
+// when there were fewer work items than CUs (64 items: 90 -> 48 us with 4 parts; 128 items: 95 -> 73 us with 2) and lost once every CU had an item
+// (256 items: 111 -> 120 us).  Round 4 (fence-free fold, fp16 P V conversion inside the kernel): the number of parts is the minimum of a small cost
+// model -- see below -- for launches of at most one item per CU.
 FwdSplitPlan fwd_16_split_plan(const FwdParams& p) {
     FwdSplitPlan plan;
     const uint32_t nqb = (p.Sq + 127) / 128, items = nqb * p.B * p.H;
