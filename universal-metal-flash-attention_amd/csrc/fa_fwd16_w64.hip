@@ -375,11 +375,14 @@ bool fwd_w64_supported(const FwdParams& p) {
             // (round 4, bf16 operands with the V cast pass in the launch: 12 steps per CU -- B1 H8 S2048, 8 per CU: 41.8 against 35.3 us)
             // (fp16 operands, no pass, lose the same launches by 7 %: routing_sweep_fp16.jsonl -- one threshold for both)
             // (second pass, random-size audit: 10, not 12 -- B8 H1 S2304, 10.1 steps per CU: 41 us here against 50 on the 128-row kernel (fp16), 45 / 48 (bf16))
-            if (items % cus != 0 && steps < cus * 10) return false;
+            // (not when the launch runs WHOLE items on `items` workgroups (w64_grid): nothing is cut then -- fp16 B8 H6 S768, 144 items of 12 tiles: 26.5 us
+            // here against 30.3)
+            const bool whole = items < cus && items * 2 > cus && 2 * ((p.Skv + 63) / 64) * (cus - items) < 35 * cus;  // (as w64_grid decides)
+            if (!whole && items % cus != 0 && steps < cus * 10) return false;
 
             // short key ranges (fewer than 16 tiles per item): a cut item is a few tiles and a fold -- B1 H24 Sq4096 Skv512 (8 tiles, 12 steps per CU)
             // 40.0 us fp16 / 43.0 bf16 against 36.5 / 41.6 on the 128-row kernel
-            if (items % cus != 0 && (p.Skv + 63) / 64 < 16 && steps < cus * 24) return false;
+            if (!whole && items % cus != 0 && (p.Skv + 63) / 64 < 16 && steps < cus * 24) return false;
         }
     }
     return true;
