@@ -409,25 +409,23 @@ const char* umfa_last_kernel_name(mfa_context_t context);
  *   "bwd_ds_store"       "0" | "1": lab -- the dS-store form of the head_dim 128 non-causal backward (5 products, a
  *                        [B H Sq Skv] scratch in the operand type); measured level with the default (round 4), kept for A/B
  *   "pv_fp16"            "1" (default) | "0": bf16 operands with the P V product in fp16 -- S = K Q^T on the bf16 MFMA, P rounded
- *                        to fp16 (11 bits instead of bf16's 8), V converted bf16 -> fp16 inside the kernels on its way into LDS
- *                        (exact for 2^-17 <= |v| < 65536): the bf16-input forward then sits inside 1e-3 of fp64 SDPA at every
- *                        sequence length (the bf16 P V product cannot: its format floor is 1.6e-3 from S = 4096 on).  Every bf16
- *                        forward kernel has the form (all head dims, masks, windows, fused rotation).  fp16's range is the
- *                        price, and it is checked, not assumed: the kernels raise two host-visible status words -- an output
- *                        that is not finite (a V value beyond fp16's range went in as inf), a wave whose outputs are all below
- *                        2^-11 (V's fp16 image may have lost bits).  The blocking entries (mfa_attention_forward ...) look
- *                        behind their synchronise and repeat the call on the bf16 P V kernels by themselves; in-stream
- *                        entries (mfa_attention_encode_mtl, umfa_attention_forward_stream) never wait: the call that left the
- *                        range returns non-finite values where the value reached, and the NEXT in-stream call sees the word
- *                        and stays on the bf16 P V kernels until "pv_fp16" is set again (which also clears the words).
- *                        "0": the bf16 P V kernels throughout (bf16's exponent range, 8-bit P).
+ *                        to fp16 (11 bits instead of bf16's 8), V taken as an fp16 image: the bf16-input forward then sits inside
+ *                        1e-3 of fp64 SDPA at every sequence length (the bf16 P V product cannot: its format floor is 1.6e-3 from
+ *                        S = 4096 on).  Every bf16 forward kernel has the form (all head dims, masks, windows, fused rotation).
+ *                        fp16 has five exponent bits where bf16 has eight, so V goes in as V * 2^-e with one power of two e per
+ *                        (batch, KV head) slab, taken from the slab's largest |v| ON THE DEVICE (the cast pre-pass of the long
+ *                        launches; the converting 128-row kernel checks its own outputs and sweeps a workgroup's keys again with
+ *                        the slab's e when e = 0 did not do), and 2^e comes back with the row's 1 / l: exact both ways, finite
+ *                        and inside the tolerance for every bf16 V, in-stream, under hipGraph replay, with no status word and no
+ *                        state in the context (round 4 had both).  V values more than 2^29 below their slab's largest round into
+ *                        fp16's subnormals: errors below 2^-39 of that largest value.
+ *                        "0": the bf16 P V kernels throughout (8-bit P).
+ *   "cast_two_pass"      "0" (default) | "1": tests -- the cast pre-pass as two launches (amax, then cast) whatever the slab size
+ *                        (by default only slabs of more than CUs / 2 chunks of 64 rows take that form)
  * Returns MFA_ERROR_INVALID_ARGS for an unknown name or a value out of range.  Thread-safe; affects later launches. */
 mfa_error_t umfa_set_option(mfa_context_t context, const char* name, const char* value);
 
-/* MI355X extra: the live value of a launcher switch as text (what umfa_set_option would take), plus two read-only names:
- *   "pv_fp16_status"     bit 0: a launch produced a non-finite output (V beyond fp16's range), bit 1: a launch's outputs were
- *                        below 2^-11, bit 2: in-stream calls are on the bf16 P V kernels because of it (set "pv_fp16" to re-arm)
- *   "pv_fp16_fallbacks"  how many calls were repeated / switched over so far
+/* MI355X extra: the live value of a launcher switch as text (what umfa_set_option would take).
  * MFA_ERROR_INVALID_ARGS: unknown name, NULL arguments or a buffer too small (64 bytes always suffice). */
 mfa_error_t umfa_get_option(mfa_context_t context, const char* name, char* value, size_t value_size);
 

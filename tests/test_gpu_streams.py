@@ -66,8 +66,10 @@ def test_two_host_threads_two_streams():
 
 def test_graph_survives_scratch_growth_and_capture_never_allocates():
     """A captured graph keeps replaying correctly after later, larger calls on the same stream (the capture took the
-    warmed-up pool over as its own; eager calls afterwards fill a fresh one); a shape that would need NEW scratch during
-    capture is refused with MFA_ERROR_MEMORY_ALLOCATION (2) instead of calling hipMalloc inside the capture."""
+    warmed-up pool over as its own; eager calls afterwards fill a fresh one); nothing is allocated inside a capture: a shape whose
+    kernel would need NEW scratch there runs on the kernel that needs none (round 5: the 128-row kernel with V converted in the
+    kernel -- until then such a call was refused with MFA_ERROR_MEMORY_ALLOCATION); a call that cannot run without new scratch
+    (a split-KV plan larger than any the pool has seen) still is."""
     import umfa_torch
     from umfa._ffi import MFAError
     q, k, v = _inputs(1)
@@ -88,10 +90,10 @@ def test_graph_survives_scratch_growth_and_capture_never_allocates():
         with torch.cuda.graph(g, stream=side):
             umfa_torch.attention_forward(q, k, v, out=out_a)
             umfa_torch.attention_forward(q, k, v, mask=mask, out=out_m)
-            # a far larger item count than anything this stream has seen: would have to grow the partials
-            with pytest.raises(MFAError) as ei:
-                umfa_torch.attention_forward(*big, out=out_big)
-            assert ei.value.code == 2
+            # a far larger item count than anything this stream has seen: the one-wave-per-SIMD kernel would have to grow its partials and
+            # the fp16 image of V -- the call runs on the 128-row kernel instead, which needs neither
+            umfa_torch.attention_forward(*big, out=out_big)
+            assert umfa_torch.last_kernel() == "fa_fwd16<bf16,128,pv16>", umfa_torch.last_kernel()
     # larger calls on the same stream after capture: a fresh eager pool, the graph's own is untouched
     with torch.cuda.stream(side):
         qb, kb, vb = _inputs(3, H=24, Sq=4096, Skv=4096)
@@ -99,12 +101,15 @@ def test_graph_survives_scratch_growth_and_capture_never_allocates():
         mb = torch.ones(1, 1, 4096, 4096, dtype=torch.bool, device="cuda").tril(300)
         umfa_torch.attention_forward(qb, kb, vb, mask=mb)
     side.synchronize()
+    eager_big = umfa_torch.attention_forward(*big)
     for _ in range(3):
         out_a.fill_(7.0)
         out_m.fill_(7.0)
+        out_big.fill_(7.0)
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(out_a, ref_a) and torch.equal(out_m, ref_m)
+        assert (out_big.float() - eager_big.float()).abs().max() <= 2.0 ** -7 * eager_big.float().abs().max()  # (two kernels, one answer in bf16)
 
 
 def test_two_graphs_captured_on_one_stream_replay_concurrently_on_two_streams():

@@ -270,73 +270,189 @@ hipError_t launch_cast_f16(const void* src, int prec, void* dst, int64_t n, uint
 }
 
 // V of the default bf16 forward (P V product in fp16, FwdParams::pv16): bf16 rows (any batch / head / row strides, head_dim
-// contiguous) -> a dense fp16 image [B, H, S, D].  HBM-bound: one read + one write of V.  A workgroup owns U * 256 / (D / 8)
-// consecutive rows of one (batch, head) slab; every thread has U independent 16-byte loads in flight before the first
-// conversion; no per-element index arithmetic (the round-3 form divided three 64-bit indices per chunk and ran at 2 TB/s).
-// Round to nearest even: exact for 2^-17 <= |v| < 65536.  fp16's range is CHECKED here, where it is free (the pass is HBM-bound):
-// a workgroup whose chunk (64 rows at head_dim 128) holds a value >= 65536 / inf / NaN raises status[0] (it went out as +-inf:
-// nothing saturates silently), one whose largest |v| is non-zero and below 2^-6 raises status[1] -- values under 2^-17 are no
-// longer exact in fp16 (absolute error <= 2^-25), and with |V| that small an output averaged over thousands of keys can be small
-// enough for that to show.  The runtime reads the words (host-visible) and falls back to the bf16 P V kernels.
-template <int U>
+// contiguous) -> a dense fp16 image [B, H, S, D] of V * 2^-e, e ONE power of two per (batch, head) slab taken from the slab's
+// largest |v| (it lands in [2^15, 2^16): bf16's largest significand there is 65280, fp16 ends at 65504), and 2^e left in the
+// slab's header for the attention kernels, which fold it into the per-row 1 / l of their epilogue.  bf16 has fp32's exponent
+// range, fp16 five bits of it: after the shift every value down to amax * 2^-30 is exact in fp16 (8-bit significands), smaller
+// ones round into fp16's subnormals -- errors below amax * 2^-40, seven orders of magnitude under what the fp16 rounding of P
+// costs.  So there is no input this pass turns into +-inf (round 4 did: a V value >= 65536 made the call's outputs non-finite
+// and raised a status word for LATER calls) and nothing sticky.
+// HBM-bound: one read + one write of V.  A workgroup owns U * 256 / (D / 8) consecutive rows of one slab (U = 16: 256 rows =
+// 64 KB at head_dim 128); every thread has U independent 16-byte loads in flight and keeps them in registers across the slab's
+// amax exchange -- the whole tensor is requested before the first byte is converted.
+//
+// The exchange (FUSED): a workgroup publishes its amax as a FLAG word of its own (write-through store: no atomic), then wave 0
+// polls the slab's <= 64 flag words with one load per round until all are up; leaving, it counts itself out with the pass's one
+// atomic, and the LAST workgroup to leave writes 2^e and zeroes the slab's words for the next launch (same stream: the next
+// launch starts after this one ended).  (First form, measured: arrival counted with two atomics per workgroup on the slab's line,
+// 64 workgroups per slab: 68 us instead of 11 -- same-line atomics from eight XCDs serialise at a few hundred ns each.)
+// Safe without a co-operative launch because workgroups are dispatched in linear order (slab-major here) and a slab is at most
+// 64 workgroups: the oldest unfinished slab is always resident as a whole (2048 workgroup slots; <= 8 per XCD per slab).
+// Slabs of more than 64 chunks take two launches (vamax_rows_kernel, then this kernel with FUSED = false).
+// Header, 512 bytes per slab: words [0, 64) flags (0x80000000 | amax bits), [64] departed, [65] 2^e as fp32, [66] amax of the
+// two-launch form; all zero between launches except [65].
+constexpr uint32_t VH_WORDS = 128, VH_DEPART = 64, VH_SCALE = 65, VH_AMAX = 66;
+__device__ __forceinline__ int vscale_exponent(unsigned amax_bits) {
+    // amax_bits: |v| as bf16 bits; inf / NaN count as the largest finite exponent (they go out as inf / NaN whatever e is)
+    if (amax_bits == 0) return 0;
+    int E = (int)(amax_bits >> 7);
+    E = E > 254 ? 254 : E;
+    const int e = (E ? E - 127 : -126) - 15;  // (bf16's largest significand times 2^15 is 65280: inside fp16)
+    return e < -100 ? -100 : e;  // (2^e and 2^-e stay normal fp32 numbers; |v| < 2^-115 is then merely less well placed)
+}
+__device__ __forceinline__ unsigned bf16x8_amax(const unsigned (&r)[4], unsigned amax) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned a = r[j] & 0x7fff7fffu, m2 = (a & 0xffffu) > (a >> 16) ? (a & 0xffffu) : (a >> 16);
+        amax = amax > m2 ? amax : m2;
+    }
+    return amax;
+}
+__device__ __forceinline__ unsigned wave_umax(unsigned x) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned o2 = (unsigned)__shfl_xor((int)x, off, 64);
+        x = x > o2 ? x : o2;
+    }
+    return x;
+}
+__device__ __forceinline__ unsigned block_amax(unsigned amax, unsigned* wmax) {  // (every thread gets the workgroup's value)
+    amax = wave_umax(amax);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    unsigned m = wmax[0];
+    for (int w = 1; w < 4; ++w) m = m > wmax[w] ? m : wmax[w];
+    return m;
+}
+
+template <int U, bool FUSED>
 __global__ __launch_bounds__(256) void cast_rows_bf16_f16_kernel(const uint16_t* __restrict__ src, int64_t sb, int64_t sh, int64_t ss,
-                                                                 _Float16* __restrict__ dst, uint32_t H, uint32_t S, uint32_t D8, uint32_t* status) {
+                                                                 _Float16* __restrict__ dst, uint32_t H, uint32_t S, uint32_t D8,
+                                                                 uint32_t chunks, uint32_t* __restrict__ hdr) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    unsigned amax = 0;  // largest |v| of this thread's elements, as bf16 bits (the order of positive floats is the order of their bits)
-    const uint32_t bh = blockIdx.x, b = bh / H, h = bh - b * H;  // (grid.x may be large; grid.y <= 65535 holds the row chunks)
+    __shared__ unsigned wmax[4], slab_amax;
+    const uint32_t bh = blockIdx.x / chunks, chunk = blockIdx.x - bh * chunks, b = bh / H, h = bh - b * H;  // slab-major linear order
     const uint32_t rpw = 256u / D8;                       // rows one pass of the workgroup covers (D8 divides 256: head_dim 64 ... 256 x8; else see launcher)
     const uint32_t tr = threadIdx.x / D8, c = threadIdx.x - tr * D8;
-    const uint32_t row0 = blockIdx.y * (U * rpw) + tr;
+    const uint32_t row0 = chunk * (U * rpw) + tr;
     const uint16_t* sp = src + (int64_t)b * sb + (int64_t)h * sh + 8 * c;
     _Float16* dp = dst + ((int64_t)bh * S) * (8 * D8) + 8 * c;
+    uint32_t* const hw = hdr + VH_WORDS * (size_t)bh;
     u32x4 raw[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const uint32_t r = row0 + u * rpw;
         raw[u] = r < S && tr < rpw ? __builtin_nontemporal_load((const u32x4*)(sp + (int64_t)r * ss)) : u32x4{0, 0, 0, 0};
     }
+    unsigned amax;
+    if constexpr (FUSED) {
+        amax = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned r4[4] = {raw[u][0], raw[u][1], raw[u][2], raw[u][3]};
+            amax = bf16x8_amax(r4, amax);
+        }
+        amax = block_amax(amax, wmax);
+        if (threadIdx.x < 64) {
+            // relaxed agent-scope accesses only (performed past the XCDs' L2s); the exchange carries nothing but these words
+            if (threadIdx.x == 0) __hip_atomic_store(hw + chunk, 0x80000000u | amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned f;
+            for (;;) {
+                f = threadIdx.x < chunks ? __hip_atomic_load(hw + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x80000000u;
+                if (__builtin_amdgcn_ballot_w64((f & 0x80000000u) == 0) == 0) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            f = wave_umax(f & 0x7fffffffu);
+            if (threadIdx.x == 0) slab_amax = f;
+        }
+        __syncthreads();
+        amax = slab_amax;
+    } else {
+        amax = hw[VH_AMAX];  // vamax_rows_kernel, the launch before this one
+    }
+    const int e = vscale_exponent(amax);
+    const float mul = __uint_as_float((unsigned)(127 - e) << 23);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const uint32_t r = row0 + u * rpw;
         u32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const unsigned lo = raw[u][j] << 16, hi = raw[u][j] & 0xffff0000u;
+            const float lo = __uint_as_float(raw[u][j] << 16) * mul, hi = __uint_as_float(raw[u][j] & 0xffff0000u) * mul;
             asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(o[j]) : "v"(lo), "v"(hi));
-            const unsigned a = raw[u][j] & 0x7fff7fffu, m2 = (a & 0xffffu) > (a >> 16) ? (a & 0xffffu) : (a >> 16);
-            amax = amax > m2 ? amax : m2;
         }
         if (r < S && tr < rpw) *(u32x4*)(dp + (int64_t)r * (8 * D8)) = o;
     }
-    if (status) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const unsigned o2 = (unsigned)__shfl_xor((int)amax, off, 64);
-            amax = amax > o2 ? amax : o2;
-        }
-        __shared__ unsigned wmax[4];
-        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = amax;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned m = wmax[0];
-            for (int w = 1; w < 4; ++w) m = m > wmax[w] ? m : wmax[w];
-            if (m >= 0x4780u) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);            // >= 65536.0 (bf16 bits), inf, NaN
-            if (m != 0 && m < 0x3c80u) __hip_atomic_store(status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // < 2^-6
+    // leave: the last workgroup of the slab writes 2^e and zeroes the exchange words (every workgroup has read them by now)
+    if (threadIdx.x < 64) {
+        unsigned d = 0;
+        if (threadIdx.x == 0) d = __hip_atomic_fetch_add(hw + VH_DEPART, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        d = (unsigned)__builtin_amdgcn_readfirstlane((int)d);
+        if (d == chunks - 1) {
+            if (FUSED && threadIdx.x < chunks) __hip_atomic_store(hw + threadIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (threadIdx.x == 0) {
+                hw[VH_SCALE] = (unsigned)(127 + e) << 23;
+                __hip_atomic_store(hw + VH_DEPART, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!FUSED) __hip_atomic_store(hw + VH_AMAX, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
 }
 
-hipError_t launch_cast_rows_bf16_to_f16(const void* src, const int64_t* strides, void* dst, uint32_t B, uint32_t H, uint32_t S, uint32_t D,
-                                        uint32_t* status, hipStream_t stream) {
-    if (!src || !dst || (D & 7) || D > 2048 || strides[3] != 1 || (strides[0] | strides[1] | strides[2]) % 8 || ((uintptr_t)src & 15)) return hipErrorInvalidValue;
-    if ((int64_t)B * H * S * D == 0) return hipSuccess;
+// slabs too long for the in-kernel exchange: the amax of every slab first (one more read of V; such slabs are >= 16 MB of attention work each)
+template <int U>
+__global__ __launch_bounds__(256) void vamax_rows_kernel(const uint16_t* __restrict__ src, int64_t sb, int64_t sh, int64_t ss, uint32_t H, uint32_t S,
+                                                         uint32_t D8, uint32_t chunks, uint32_t* __restrict__ hdr) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    __shared__ unsigned wmax[4];
+    const uint32_t bh = blockIdx.x / chunks, chunk = blockIdx.x - bh * chunks, b = bh / H, h = bh - b * H;
+    const uint32_t rpw = 256u / D8, tr = threadIdx.x / D8, c = threadIdx.x - tr * D8;
+    const uint32_t row0 = chunk * (U * rpw) + tr;
+    const uint16_t* sp = src + (int64_t)b * sb + (int64_t)h * sh + 8 * c;
+    unsigned amax = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint32_t r = row0 + u * rpw;
+        const u32x4 v = r < S && tr < rpw ? *(const u32x4*)(sp + (int64_t)r * ss) : u32x4{0, 0, 0, 0};  // (no non-temporal hint: the cast kernel reads it again)
+        const unsigned r4[4] = {v[0], v[1], v[2], v[3]};
+        amax = bf16x8_amax(r4, amax);
+    }
+    amax = block_amax(amax, wmax);
+    if (threadIdx.x == 0 && amax) (void)__hip_atomic_fetch_max(hdr + VH_WORDS * (size_t)bh + VH_AMAX, amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int U>
+static hipError_t launch_cast_rows_u(const void* src, const int64_t* strides, void* dst, uint32_t B, uint32_t H, uint32_t S, uint32_t D, uint32_t* hdr,
+                                     hipStream_t stream) {
     const uint32_t D8 = D / 8, rpw = 256u / D8;  // (a head_dim that does not divide 2048 leaves 256 % D8 threads idle)
-    constexpr int U = 4;
-    const dim3 grid(B * H, (S + U * rpw - 1) / (U * rpw));
-    if (grid.y > 65535u) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(cast_rows_bf16_f16_kernel<U>, grid, dim3(256), 0, stream, (const uint16_t*)src, strides[0], strides[1], strides[2],
-                       (_Float16*)dst, H, S, D8, status);
+    const uint64_t chunks = ((uint64_t)S + U * rpw - 1) / (U * rpw), grid = (uint64_t)B * H * chunks;
+    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+    const bool fused = chunks <= 64 && !tuning().cast_two_pass.load(std::memory_order_relaxed);
+    if (fused) {
+        hipLaunchKernelGGL((cast_rows_bf16_f16_kernel<U, true>), dim3((unsigned)grid), dim3(256), 0, stream, (const uint16_t*)src, strides[0], strides[1],
+                           strides[2], (_Float16*)dst, H, S, D8, (uint32_t)chunks, hdr);
+    } else {
+        hipLaunchKernelGGL(vamax_rows_kernel<U>, dim3((unsigned)grid), dim3(256), 0, stream, (const uint16_t*)src, strides[0], strides[1], strides[2], H, S,
+                           D8, (uint32_t)chunks, hdr);
+        hipLaunchKernelGGL((cast_rows_bf16_f16_kernel<U, false>), dim3((unsigned)grid), dim3(256), 0, stream, (const uint16_t*)src, strides[0], strides[1],
+                           strides[2], (_Float16*)dst, H, S, D8, (uint32_t)chunks, hdr);
+    }
     return hipGetLastError();
+}
+
+hipError_t launch_cast_rows_bf16_to_f16(const void* src, const int64_t* strides, void* dst, uint32_t B, uint32_t H, uint32_t S, uint32_t D,
+                                        uint32_t* hdr, hipStream_t stream) {
+    if (!src || !dst || !hdr || (D & 7) || D > 2048 || strides[3] != 1 || (strides[0] | strides[1] | strides[2]) % 8 || ((uintptr_t)src & 15)) return hipErrorInvalidValue;
+    if ((int64_t)B * H * S * D == 0) return hipSuccess;
+    // 16 loads per thread (64 KB per workgroup at head_dim 128) while that still leaves a workgroup per CU, else 4
+    const uint32_t rpw = 256u / (D / 8);
+    const uint64_t wg16 = (uint64_t)B * H * (((uint64_t)S + 16 * rpw - 1) / (16 * rpw));
+    const int lab = tuning().cast_u.load(std::memory_order_relaxed);
+    const uint64_t chunks16 = ((uint64_t)S + 16 * rpw - 1) / (16 * rpw);
+    // (32: slabs of 65 ... 128 chunks of 16 passes still take the one-launch form)
+    if (lab == 32 || (!lab && chunks16 > 64 && chunks16 <= 128)) return launch_cast_rows_u<32>(src, strides, dst, B, H, S, D, hdr, stream);
+    if (lab == 4 || (!lab && wg16 < (uint64_t)device_cu_count())) return launch_cast_rows_u<4>(src, strides, dst, B, H, S, D, hdr, stream);
+    return launch_cast_rows_u<16>(src, strides, dst, B, H, S, D, hdr, stream);
 }
 
 hipError_t launch_bwd16_rowc(const float* lse, const float* dvec, float* rowc, int64_t n, hipStream_t stream) {

@@ -1212,7 +1212,7 @@ static hipError_t launch_bwd16_t(const BwdParams& p, hipStream_t stream) {
     if constexpr (DP == 128 && !CAUSAL) {
         if (p.ds && ph == 7) {
             BwdParams pl = p;
-            if (const char* e = getenv("UMFA_LAB_DS")) pl.ds_lab = atoi(e);
+            pl.ds_lab = tuning().bwd_ds_lab.load(std::memory_order_relaxed);  // (read once from UMFA_LAB_DS at start-up, or umfa_set_option: no getenv on a launch path)
             const BwdParams& p = pl;
             // dS-store form: D, row constants, dK / dV (+ dS to the scratch), dQ = scale dS K
             hipLaunchKernelGGL(bwd16_delta_kernel<DP>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, p);

@@ -73,14 +73,16 @@ struct FwdParams {
     const float* rope_sin;
     int64_t rope_tb;
     // bf16 operands with the P V product in fp16 (option pv_fp16, the default): P is rounded to fp16 -- 11 bits instead of 8 -- and V
-    // becomes fp16 (the w64 kernels: `v` points at the fp16 image the runtime's cast pre-pass wrote; the 128-row kernel converts
-    // bf16 -> fp16 on V's way into LDS); the bf16-input forward then meets the 1e-3 bound.  fp16's range is the price and it is
-    // checked: status[0] is raised when a V value does not fit (>= 65536, inf, NaN: it went in as +-inf), status[1] when V / the
-    // outputs are so small that fp16's image may have lost bits (cast pass: a 64-row chunk with every |v| < 2^-6; 128-row kernel:
-    // a wave whose outputs are all below 2^-11).  The runtime reads the words (host-visible memory) and falls back to the bf16
-    // P V kernels (runtime.hip dispatch_forward).
+    // becomes fp16; the bf16-input forward then meets the 1e-3 bound.  fp16 has five exponent bits where bf16 has eight, so V goes in
+    // as V * 2^-e with ONE power of two e per (batch, head) slab and 2^e comes back in the epilogue (exact both ways):
+    //   pv16 = 2  `v` points at the fp16 image the runtime's cast pre-pass wrote (fa_aux.hip cast_rows_bf16_f16_kernel: e from the slab's
+    //             largest |v|); `vsc` = that pass's header: 2^e of slab (b, h) at vsc[128 * (b * vsc_bs + h * vsc_hs) + 65] (0 strides: broadcast K / V heads)
+    //   pv16 = 1  the 128-row kernel converts bf16 -> fp16 on V's way into LDS with e = 0; a workgroup whose outputs show that this was
+    //             not enough (non-finite, or all below 2^-11) takes the slab's amax itself and sweeps its keys again with the right e
+    // No status word, nothing for the host to read back, the same result under hipGraph replay.
     int pv16;
-    uint32_t* status;
+    const float* vsc;
+    uint32_t vsc_bs, vsc_hs;
 };
 
 // Interleaved-pair rotary rotation of 8 consecutive elements (4 pairs) given the 8 table entries of their columns

@@ -53,6 +53,8 @@ struct W64Params {
     const uint32_t* mk_cnt;
     uint32_t mk_bs, mk_hs, mk_nrb64;
     const uint32_t* mk_prefix;  // [n_items % grid + 1] running sums of the shared blocks' list lengths (fa_aux.hip mask_prefix_kernel)
+    const float* vsc;         // bf16pv16 kernels: 2^e of the V image's slabs (FwdParams::vsc), slab (b, h) at vsc[128 (b vsc_bs + h vsc_hs) + 65]
+    uint32_t vsc_bs, vsc_hs;
 };
 
 // ---- asm-owned accumulator registers: helpers with literal register numbers (generated)
@@ -102,11 +104,10 @@ struct W64I8Params {
 #undef W64_CVT
 #undef W64_KERNEL
 
-// bf16 Q / K / V with the P V product in fp16 -- the DEFAULT bf16 forward (option pv_fp16, on unless switched off or a call
-// raised the status word): S = K Q^T on the bf16 MFMA, P rounded to fp16 (v_cvt_pk_f16_f32: 11 bits instead of bf16's 8, which
+// bf16 Q / K / V with the P V product in fp16 -- the DEFAULT bf16 forward (option pv_fp16): S = K Q^T on the bf16 MFMA, P rounded to fp16 (v_cvt_pk_f16_f32: 11 bits instead of bf16's 8, which
 // is what puts the bf16-input forward inside the north-star's 1e-3), O^T += V^T P^T on the fp16 MFMA against an fp16 image of V
-// (the runtime's cast pre-pass, fa_aux.hip: exact over fp16's range, and the pass itself raises the status words when V does
-// not fit -- the runtime then falls back to the bf16 P V kernels); the lazy reference with fp16's thresholds.
+// (the runtime's cast pre-pass, fa_aux.hip: V * 2^-e with one power of two per (batch, head) slab, so that no bf16 value leaves fp16's
+// range; 2^e comes back in the epilogue's 1 / l: W64_VSC); the lazy reference with fp16's thresholds.
 // (Round 4 also built the conversion INSIDE this kernel -- register-staged V tiles, 48 vector instructions + 4 ds_write per tile
 // per wave: +23 % cycles per tile, +15 % loop time at the FLUX shape (in-kernel stamps 167.6 vs 145.3 us,
 // profiles/r4/lab_notes.md): every workgroup converts every V tile again, 16 x redundantly at FLUX; the pre-pass converts once
@@ -120,7 +121,11 @@ struct W64I8Params {
 #define W64_LAZY_PARTS 2
 #define W64_CVT "v_cvt_pk_f16_f32"
 #define W64_KERNEL fa_fwd16_w64_bf16pv16
+#undef W64_VSC
+#define W64_VSC 1
 #include "fa_fwd16_w64_kernel.inc"
+#undef W64_VSC
+#define W64_VSC 0
 #undef W64_T
 #undef W64_MFMA
 #undef W64_MFMA_QK
@@ -180,7 +185,11 @@ struct W64I8Params {
 #define W64_LAZY_PARTS 2
 #define W64_CVT "v_cvt_pk_f16_f32"
 #define W64_KERNEL fa_fwd16_w64d64_bf16pv16
+#undef W64_VSC
+#define W64_VSC 1
 #include "fa_fwd16_w64_kernel.inc"
+#undef W64_VSC
+#define W64_VSC 0
 #undef W64_T
 #undef W64_MFMA
 #undef W64_MFMA_QK
@@ -463,6 +472,8 @@ hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cn
     // lab option w64_skew = -1)
     if (tuning().w64_skew.load(std::memory_order_relaxed) == -1) wp.skew = 0xffffffffu;
     wp.rope_cos = p.rope_cos; wp.rope_sin = p.rope_sin; wp.rope_tb = p.rope_tb;
+    wp.vsc = p.vsc; wp.vsc_bs = p.vsc_bs; wp.vsc_hs = p.vsc_hs;
+    if (p.in_prec == P_BF16 && p.pv16 && !p.vsc) return hipErrorInvalidValue;  // the fp16 image of V comes with its slab exponents (runtime.hip)
     wp.Tw = wp.T; wp.win_left = wp.win_right = 0;
     const bool rope = p.rope_cos != nullptr, window = w64_is_window(p), fp32o = p.out_prec == P_FP32, maskt = p.mask_kind == MK_BOOL;
     if (maskt) {

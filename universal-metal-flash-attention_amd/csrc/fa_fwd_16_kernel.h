@@ -75,12 +75,28 @@ __device__ __forceinline__ float max_xor32(float x) {
 // The loads are inline asm on purpose: for the builtin hipcc (ROCm 7.2) waits vmcnt(0) before every later LDS
 // read (no alias information), which serialises the tile; here the only wait is ours, before the tile's barrier.
 // BN = keys per tile (64, or 32: half the LDS and fewer live registers -> a third resident workgroup per CU).
-// bf16 pair -> fp16 pair (round to nearest even; exact for 2^-17 <= |x| < 65536, +-inf beyond fp16's range -- which is how the
-// PV16 kernels notice: FwdParams::status)
+// bf16 pair -> fp16 pair (round to nearest even; exact for 2^-17 <= |x| < 65536, +-inf beyond fp16's range -- the converting
+// kernels notice that in their outputs and sweep again with the scaled form below)
 __device__ __forceinline__ unsigned bf16x2_to_f16x2(unsigned x) {
     unsigned lo = x << 16, hi = x & 0xffff0000u, d;
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(d) : "v"(lo), "v"(hi));
     return d;
+}
+// ... of x * mul, mul a power of two (exact unless the product leaves fp16's range at the small end)
+__device__ __forceinline__ unsigned bf16x2_to_f16x2_scaled(unsigned x, float mul) {
+    const float lo = __uint_as_float(x << 16) * mul, hi = __uint_as_float(x & 0xffff0000u) * mul;
+    unsigned d;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(d) : "v"(lo), "v"(hi));
+    return d;
+}
+// the power of two that brings a slab's largest |v| (bf16 bits; inf / NaN count as the largest finite exponent) into [2^15, 2^16):
+// the rule of the cast pre-pass (fa_aux.hip vscale_exponent)
+__device__ __forceinline__ int vscale_exponent_of(unsigned amax_bits) {
+    if (amax_bits == 0) return 0;
+    int E = (int)(amax_bits >> 7);
+    E = E > 254 ? 254 : E;
+    const int e = (E ? E - 127 : -126) - 15;  // (bf16's largest significand times 2^15 is 65280: inside fp16)
+    return e < -100 ? -100 : e;
 }
 
 // PV16 (T = bf16 only; FwdParams::pv16, the default bf16 forward): the second product runs in fp16 -- P is rounded to fp16 (11
@@ -106,8 +122,36 @@ __device__ __forceinline__ unsigned bf16x2_to_f16x2(unsigned x) {
 // longest workgroup's wave spends 1613 cycles per tile in "compute" for ~860 cycles of issue; its Q K^T phase (LDS reads + a
 // chain of MFMAs, 440 cycles) and its softmax (1007) follow each other, and the second wave of the SIMD is in the same phase.
 // The K stream runs one tile ahead of the V stream (same two slots each: K(t)'s slot is free once S(t) exists).
+//
+// RESWEEP (PV16 = 1 only): the body once more, as the second sweep of a workgroup whose V does not fit fp16 as it is -- V is converted
+// as v * 2^-vexp_in and the outputs are shifted back; see the check behind the tile loop.  The kernel runs the two copies one after
+// the other (the first returns the exponent, 0 = done) with the second copy's inputs laundered through an empty asm, so that nothing
+// of the first copy stays live for it.  (Tried first: a loop around the sweep -- as a back-edge it cost every converting instantiation
+// 12-18 registers and the three-per-CU one 92 more spills; a noinline function -- the call ABI raised every kernel to 248 registers.)
+template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT, bool DMA, int BN, int PV16, int KS, int PIPE, bool RESWEEP, typename PRM>
+__device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const int tid_in, const uint32_t bid_in);
+
 template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT, bool DMA = false, int BN = 64, int PV16 = 0, int KS = 1, int PIPE = 0>
 __global__ __launch_bounds__(256 * KS, KS * (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_fwd16_kernel(FwdParams p) {
+    int e2 = fa_fwd16_body<T, DP, CAUSAL, HAS_MASK, OUT, DMA, BN, PV16, KS, PIPE, false, const FwdParams>(p, 0, (int)threadIdx.x, blockIdx.x);
+    if constexpr (PV16 == 1) {
+        if (__builtin_expect(e2 != 0, 0)) {
+            // the second copy reads the parameters through the kernel-argument segment (FwdParams is the only argument: offset 0), so that
+            // neither `p` has its address taken nor a value of the first copy is reused
+            typedef const __attribute__((address_space(4))) FwdParams KFwdParams;
+            KFwdParams* pp = (KFwdParams*)__builtin_amdgcn_kernarg_segment_ptr();
+            int t = (int)threadIdx.x;
+            uint32_t bx = blockIdx.x;
+            asm volatile("" : "+s"(pp), "+v"(t), "+s"(bx), "+v"(e2));
+            e2 = __builtin_amdgcn_readfirstlane(e2);  // (workgroup-uniform by construction)
+            (void)fa_fwd16_body<T, DP, CAUSAL, HAS_MASK, OUT, DMA, BN, PV16, KS, PIPE, true, KFwdParams>(*pp, e2, t, bx);
+        }
+    }
+}
+
+template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT, bool DMA, int BN, int PV16, int KS, int PIPE, bool RESWEEP, typename PRM>
+__device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const int tid_in, const uint32_t bid_in) {
+    static_assert(!RESWEEP || PV16 == 1, "the second sweep exists for the converting kernels only");
     static_assert(!PIPE || (DMA && !HAS_MASK && KS == 1 && DP <= 64 && BN == 64), "pipelined loop: head_dim <= 64, LDS-DMA staging, no mask tensor");
     static_assert(!PV16 || __is_same(T, __bf16), "PV16: bf16 operands");
     static_assert(KS == 1 || (KS == 2 && DMA && !HAS_MASK && DP == 64 && BN == 64), "key-split: head_dim 64, LDS-DMA staging, no mask tensor");
@@ -146,7 +190,7 @@ __global__ __launch_bounds__(256 * KS, KS * (DP > 128 ? 1 : (BN == 32 ? 3 : 2)))
     char* const Kbuf = smem;
     char* const Vbuf = smem + NS * TILE_BYTES;
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, ql = lane & 31, hi = lane >> 5;
+    const int tid = tid_in, wave = tid >> 6, lane = tid & 63, ql = lane & 31, hi = lane >> 5;
     const int rw = KS == 1 ? wave : (wave & 3), kh = KS == 1 ? 0 : (wave >> 2);  // row-wave, key half
 #ifdef UMFA_LAB_STAMPS
     unsigned long long stamp[6];
@@ -160,7 +204,7 @@ __global__ __launch_bounds__(256 * KS, KS * (DP > 128 ? 1 : (BN == 32 ? 3 : 2)))
     // causal launches with a split plan (fwd_16_split_plan, short launches): the HEAVY half of a head's q-blocks
     // (qb >= nqb / 2) is cut into two key ranges, the light half stays whole; heavy parts are dispatched first
     const bool causal_split = CAUSAL && p.nsplit > 1;
-    const uint32_t bx = causal_split ? gridDim.x - 1 - blockIdx.x : blockIdx.x;
+    const uint32_t bx = causal_split ? gridDim.x - 1 - bid_in : bid_in;
     if (bx < p.n_full) {
         item = xcd_remap(bx, p.n_full);
     } else {
@@ -281,6 +325,10 @@ __global__ __launch_bounds__(256 * KS, KS * (DP > 128 ? 1 : (BN == 32 ? 3 : 2)))
         for (int i = 0; i < 2 * NS * TILE_BYTES / (NT * 16); ++i) *(i32x4*)(smem + i * (NT * 16) + tid * 16) = i32x4{0, 0, 0, 0};
         __syncthreads();
     }
+    // VCONV: V is converted as v * 2^-vexp: 0 in the kernel proper, the slab's power of two in the second sweep (RESWEEP)
+    const int vexp = RESWEEP ? vexp_in : 0;
+    const float vmul = __uint_as_float((unsigned)(127 - vexp) << 23);
+    (void)vmul;
     // which: 1 = K tile, 2 = V tile, 3 = both.  SPLIT_DMA: the V half is issued behind the QK^T MFMAs instead of back
     // to back with the K half (LDS-DMA instructions in a row stall the MFMA behind them, profiles/r1/lab_notes.md).
     // Same-box A/B: head_dim 256 (16 DMA instructions per wave per tile) 1132 -> 1001-1029 us at B2 H24 S4096,
@@ -326,20 +374,33 @@ __global__ __launch_bounds__(256 * KS, KS * (DP > 128 ? 1 : (BN == 32 ? 3 : 2)))
                 // instructions filled (lane l of instruction j owns 16 bytes at (wave IPW + j) KiB + 16 l), so the vmcnt wait
                 // above is all the ordering it needs; the barrier that follows publishes the converted tile
                 char* const vq = Vbuf + buf * TILE_BYTES + (wave * IPW) * 1024 + lane * 16;
+                if constexpr (!RESWEEP) {
 #pragma unroll
-                for (int j = 0; j < IPW; ++j) {
-                    const u32x4 r = *(const u32x4*)(vq + j * 1024);
-                    *(u32x4*)(vq + j * 1024) = u32x4{bf16x2_to_f16x2(r[0]), bf16x2_to_f16x2(r[1]), bf16x2_to_f16x2(r[2]), bf16x2_to_f16x2(r[3])};
+                    for (int j = 0; j < IPW; ++j) {
+                        const u32x4 r = *(const u32x4*)(vq + j * 1024);
+                        *(u32x4*)(vq + j * 1024) = u32x4{bf16x2_to_f16x2(r[0]), bf16x2_to_f16x2(r[1]), bf16x2_to_f16x2(r[2]), bf16x2_to_f16x2(r[3])};
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < IPW; ++j) {
+                        const u32x4 r = *(const u32x4*)(vq + j * 1024);
+                        *(u32x4*)(vq + j * 1024) = u32x4{bf16x2_to_f16x2_scaled(r[0], vmul), bf16x2_to_f16x2_scaled(r[1], vmul),
+                                                         bf16x2_to_f16x2_scaled(r[2], vmul), bf16x2_to_f16x2_scaled(r[3], vmul)};
+                    }
                 }
             }
         } else {
 #pragma unroll
             for (int i = 0; i < LPT; ++i) {
                 *(u32x4*)(Kbuf + buf * TILE_BYTES + klds[i]) = kreg[i];
-                if constexpr (VCONV)
-                    *(u32x4*)(Vbuf + buf * TILE_BYTES + vlds[i]) = u32x4{bf16x2_to_f16x2(vreg[i][0]), bf16x2_to_f16x2(vreg[i][1]),
-                                                                         bf16x2_to_f16x2(vreg[i][2]), bf16x2_to_f16x2(vreg[i][3])};
-                else
+                if constexpr (VCONV) {
+                    if constexpr (!RESWEEP)
+                        *(u32x4*)(Vbuf + buf * TILE_BYTES + vlds[i]) = u32x4{bf16x2_to_f16x2(vreg[i][0]), bf16x2_to_f16x2(vreg[i][1]),
+                                                                             bf16x2_to_f16x2(vreg[i][2]), bf16x2_to_f16x2(vreg[i][3])};
+                    else
+                        *(u32x4*)(Vbuf + buf * TILE_BYTES + vlds[i]) = u32x4{bf16x2_to_f16x2_scaled(vreg[i][0], vmul), bf16x2_to_f16x2_scaled(vreg[i][1], vmul),
+                                                                             bf16x2_to_f16x2_scaled(vreg[i][2], vmul), bf16x2_to_f16x2_scaled(vreg[i][3], vmul)};
+                } else
                     *(u32x4*)(Vbuf + buf * TILE_BYTES + vlds[i]) = vreg[i];
             }
         }
@@ -824,6 +885,89 @@ __global__ __launch_bounds__(256 * KS, KS * (DP > 128 ? 1 : (BN == 32 ? 3 : 2)))
     }
     }  // !PIPE
 
+    if constexpr (VCONV && !RESWEEP) {
+        // fp16's range, checked where it is free -- on this workgroup's own outputs, once per item: a V value >= 65536 went into LDS as
+        // +-inf and made every output it touches inf / NaN (P >= 0: 0 * inf = NaN, never a silent finite value); outputs that are ALL
+        // below 2^-11 may have met values of V under 2^-17, which fp16 no longer holds exactly (absolute error <= 2^-25, i.e. <= 2^-14 of
+        // an output of 2^-11).  Either way the workgroup takes the largest |v| of its slab and sweeps its keys again with V shifted by
+        // that power of two (the cast pre-pass's rule; fa_fwd16_resweep: this body once more, out of line, from its first instruction).
+        // Decided from the data alone: the same under graph replay, on any stream, and nothing for the host to read.
+        if constexpr (NS > 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the ring's youngest requests still land in the tile area)
+        const float lsum = (l4[0] + l4[1]) + (l4[2] + l4[3]);
+        const float lrow = lsum + xor32(lsum);
+        const float inv_c = lrow > 0.0f ? 1.0f / lrow : 0.0f;
+        float chk_nan = 0.0f, chk_max = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NDB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float val = acc[i][r] * inv_c;
+                chk_nan = __builtin_fmaf(val, 0.0f, chk_nan);
+                chk_max = fmaxf(chk_max, __builtin_fabsf(val));
+            }
+        const bool rowok = q_row < p.Sq;  // (rows past Sq were computed on zero Q rows: their "outputs" are means of V, and say nothing)
+        const unsigned bits = (__builtin_amdgcn_ballot_w64(rowok && chk_nan != chk_nan) != 0 ? 1u : 0u) |
+                              (__builtin_amdgcn_ballot_w64(rowok && chk_max >= 0x1p-11f) != 0 ? 2u : 0u) |
+                              (__builtin_amdgcn_ballot_w64(rowok && lrow > 0.0f) != 0 ? 4u : 0u);
+        volatile uint32_t* const red = (volatile uint32_t*)smem;  // the tile area: every wave is behind the loop's last barrier
+        if (lane == 0) red[wave] = bits;
+        __syncthreads();
+        unsigned all = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < NT / 64; ++w2) all |= red[w2];
+        all = __builtin_amdgcn_readfirstlane(all);
+        // non-finite, or rows with keys and nothing above 2^-11  (otherwise on: the words stay -- the tile area is not read again, and the
+        // folds below write before they read)
+        if (__builtin_expect((all & 1u) || ((all & 4u) && !(all & 2u)), 0)) {
+            unsigned amax = 0;
+            const uint32_t d8 = (uint32_t)D / 8u, nch = p.Skv * d8;
+            for (uint32_t c = (uint32_t)tid; c < nch; c += NT) {
+                const uint32_t row = c / d8, ch = c - row * d8;
+                const u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, (int)(row * (uint32_t)v_stride_b + ch * 16u), 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned a = r4[j] & 0x7fff7fffu, m2 = (a & 0xffffu) > (a >> 16) ? (a & 0xffffu) : (a >> 16);
+                    amax = amax > m2 ? amax : m2;
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned o2 = (unsigned)__shfl_xor((int)amax, off, 64);
+                amax = amax > o2 ? amax : o2;
+            }
+            __syncthreads();
+            if (lane == 0) red[wave] = amax;
+            __syncthreads();
+            amax = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < NT / 64; ++w2) amax = amax > red[w2] ? amax : red[w2];
+            amax = __builtin_amdgcn_readfirstlane(amax);
+            __syncthreads();
+            // V all zero (the outputs were right), V with inf / NaN in it (they are what they should be: non-finite), V already where the
+            // shift would put it: nothing a second sweep improves
+            const int e2 = vscale_exponent_of(amax);
+            if (amax != 0 && amax < 0x7f80u && e2 != 0) {
+                return e2;  // -> the kernel runs the RESWEEP copy
+            }
+        }
+    }
+    if constexpr (RESWEEP) {  // the shift comes back (exact): everything below -- fold, output -- sees the values of the unshifted V
+        const float back = __uint_as_float((unsigned)(127 + vexp) << 23);
+#pragma unroll
+        for (int i = 0; i < NDB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] *= back;
+    } else if constexpr (PV16 == 2) {
+        // the cast pre-pass shifted this slab's V by a power of two (FwdParams::vsc): back, before anything is published
+        if (p.vsc) {
+            const float back = p.vsc[128 * ((size_t)b * p.vsc_bs + (size_t)h * p.vsc_hs) + 65];
+#pragma unroll
+            for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] *= back;
+        }
+    }
+
 #ifdef UMFA_LAB_STAMPS
     stamp[2] = __builtin_amdgcn_s_memrealtime();
     stamp[5] = __builtin_amdgcn_s_memtime();
@@ -850,7 +994,7 @@ __global__ __launch_bounds__(256 * KS, KS * (DP > 128 ? 1 : (BN == 32 ? 3 : 2)))
             ex[(16 * NDB + 1) * 64] = lt;
         }
         __syncthreads();
-        if (kh == 1) return;
+        if (kh == 1) return 0;
         const float mo = ex[(16 * NDB) * 64], lo = ex[(16 * NDB + 1) * 64];
         const float mn = fmaxf(m, mo);
         const float mu = mn == -INFINITY ? 0.0f : mn;
@@ -887,7 +1031,7 @@ __global__ __launch_bounds__(256 * KS, KS * (DP > 128 ? 1 : (BN == 32 ? 3 : 2)))
         if (tid == 0) ticket_s = __hip_atomic_fetch_add(p.part_cnt + sidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const uint32_t ticket = ticket_s;
-        if (ticket != nparts - 1) return;  // not the last part of this item
+        if (ticket != nparts - 1) return 0;  // not the last part of this item
         // every part has drawn: the word is free again -- leave it zero for the next launch (no memset per launch, and no
         // memset node in a captured graph)
         if (tid == 0) __hip_atomic_store(p.part_cnt + sidx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -938,25 +1082,6 @@ __global__ __launch_bounds__(256 * KS, KS * (DP > 128 ? 1 : (BN == 32 ? 3 : 2)))
         }
     }
     const float inv = lt > 0.0f ? 1.0f / lt : 0.0f;
-    if constexpr (VCONV) {
-        // fp16 image of V made here (the cast pre-pass of the other forms checks V itself): a value beyond fp16's range went in as +-inf and made its
-        // O columns inf / NaN; a wave whose outputs are all below 2^-11 may have met values of V that are not exact in fp16
-        if (p.status) {
-            float chk_nan = 0.0f, chk_max = 0.0f;
-#pragma unroll
-            for (int i = 0; i < NDB; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float val = acc[i][r] * inv;
-                    chk_nan = __builtin_fmaf(val, 0.0f, chk_nan);
-                    chk_max = fmaxf(chk_max, __builtin_fabsf(val));
-                }
-            const bool bad = __builtin_amdgcn_ballot_w64(chk_nan != chk_nan) != 0;
-            const bool tiny = __builtin_amdgcn_ballot_w64(chk_max >= 0x1p-11f) == 0 && __builtin_amdgcn_ballot_w64(chk_max > 0.0f) != 0;
-            if (bad && lane == 0) __hip_atomic_store(p.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (tiny && lane == 0) __hip_atomic_store(p.status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
     if (q_row < p.Sq) {
         OUT* __restrict__ op = (OUT*)p.o + ((int64_t)bh * p.Sq + q_row) * D;
 #pragma unroll
@@ -984,7 +1109,7 @@ __global__ __launch_bounds__(256 * KS, KS * (DP > 128 ? 1 : (BN == 32 ? 3 : 2)))
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp[3] = __builtin_amdgcn_s_memrealtime();
     if (tid == 0) {  // a debug buffer of its own (lab only): [block][6]
-        unsigned long long* dbg = (unsigned long long*)p.part_buf + (size_t)blockIdx.x * 8;
+        unsigned long long* dbg = (unsigned long long*)p.part_buf + (size_t)bid_in * 8;
         for (int i = 0; i < 6; ++i) dbg[i] = stamp[i];
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
@@ -993,11 +1118,12 @@ __global__ __launch_bounds__(256 * KS, KS * (DP > 128 ? 1 : (BN == 32 ? 3 : 2)))
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         dbg[7] = hwid;
 #ifdef UMFA_LAB_LOOP_STAMPS
-        dbg = (unsigned long long*)p.part_buf + (size_t)gridDim.x * 8 + (size_t)blockIdx.x * 6;
+        dbg = (unsigned long long*)p.part_buf + (size_t)gridDim.x * 8 + (size_t)bid_in * 6;
         for (int i = 0; i < 6; ++i) dbg[i] = lp[i];
 #endif
     }
 #endif
+    return 0;
 }
 
 }  // namespace umfa

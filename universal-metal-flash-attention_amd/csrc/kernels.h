@@ -19,7 +19,9 @@ struct Tuning {
     std::atomic<int> sm_mode{SM_DEFAULT};
     std::atomic<float> sm_tau{6.0f};
     std::atomic<int> force_w64{0}, no_w64{0}, w64_grid{0}, w64_skew{0}, no_mask_flags{0}, bwd_exact{0}, bwd_dq{0}, bwd_persist{0},
-        bwd_separate_delta{0}, no_split{0}, force_split{0}, no_dma{0}, bn64{0}, pv_fp16{0}, bwd_ds_store{0}, no_w64_mask{0}, ksplit{0}, no_pipe{0}, no_w64_mask_lazy{0};
+        bwd_separate_delta{0}, no_split{0}, force_split{0}, no_dma{0}, bn64{0}, pv_fp16{0}, bwd_ds_store{0}, no_w64_mask{0}, ksplit{0}, no_pipe{0}, no_w64_mask_lazy{0},
+        cast_two_pass{0} /* V cast pre-pass: amax and cast as two launches whatever the slab size (tests) */, bwd_ds_lab{0} /* lab, timing only: BwdParams::ds_lab */,
+        cast_u{0} /* lab: 16-byte loads per thread of the V cast pre-pass (4, 16, 32; 0 = the launcher's choice) */;
 };
 Tuning& tuning();
 bool set_tuning(const char* name, const char* value);  // false: unknown name or value out of range
@@ -92,10 +94,12 @@ struct DequantParams {
 hipError_t launch_dequant(const DequantParams& p, hipStream_t stream);
 // dense fp32 / bf16 -> fp16 (n % 8 == 0, 16-byte aligned); *overflow |= 1 when a value does not fit
 hipError_t launch_cast_f16(const void* src, int prec, void* dst, int64_t n, uint32_t* overflow, hipStream_t stream);
-// bf16 [B,H,S,D] with element strides (head_dim contiguous) -> dense fp16 [B,H,S,D]; status (host-visible, may be NULL): [0] = 1 when a
-// value does not fit fp16 (it becomes +-inf), [1] = 1 when a 64-row chunk's values are all below 2^-6
+// bf16 [B,H,S,D] with element strides (head_dim contiguous) -> dense fp16 [B,H,S,D] of V * 2^-e, one power of two per (batch, head)
+// slab chosen from the slab's largest |v| (no value leaves fp16's range); hdr: VSC_HDR_WORDS uint32 per slab, zero on entry except word
+// VSC_HDR_SCALE, which the pass leaves holding 2^e as fp32 (FwdParams::vsc reads it)
+constexpr uint32_t VSC_HDR_WORDS = 128, VSC_HDR_SCALE = 65;
 hipError_t launch_cast_rows_bf16_to_f16(const void* src, const int64_t* strides, void* dst, uint32_t B, uint32_t H, uint32_t S, uint32_t D,
-                                        uint32_t* status, hipStream_t stream);
+                                        uint32_t* hdr, hipStream_t stream);
 // *flag |= 1 when any of x[0 .. n) (fp32, 16-byte aligned) is not finite
 hipError_t launch_nonfinite_flag(const float* x, int64_t n, uint32_t* flag, hipStream_t stream);
 // rowc[0 .. n) = -lse * log2 e, rowc[n .. 2n) = -dvec: what bwd16_dq leaves for bwd16_dkdv, for a dK / dV-only call

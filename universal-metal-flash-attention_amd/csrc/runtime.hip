@@ -79,56 +79,61 @@ mfa_error_t rc_of(hipError_t e) {
 }
 
 // Kernel selection for the dense forward.  Call with ctx->mu held; `sc` is the scratch pool of (device, stream).
-hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p, int intermediate_prec, hipStream_t stream,
-                            bool no_pv16 = false, bool* used_pv16 = nullptr) {
+hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p, int intermediate_prec, hipStream_t stream) {
     const char* name = "none";
-    hipError_t e;
+    hipError_t e = hipSuccess;
     const bool lowp = p.in_prec != P_FP32 && intermediate_prec != P_FP32;
-    // bf16 operands: the P V product runs in fp16 by default (FwdParams::pv16: P rounded to fp16, V converted in the kernel) --
-    // the bf16-input forward inside the north-star's 1e-3.  Off when the option says so, when an earlier in-stream call raised the
-    // status words (sticky until re-armed), or when the caller (a synchronous entry repeating a call) asked for bf16 P V.
+    // bf16 operands: the P V product runs in fp16 by default (FwdParams::pv16: P rounded to fp16, V as an fp16 image shifted by one power
+    // of two per (batch, head) slab) -- the bf16-input forward inside the north-star's 1e-3 for EVERY bf16 input: the shift is chosen from
+    // the data on the device (cast pre-pass / the converting kernel itself), so there is no status word, no second call and no state.
     FwdParams pv = p;
-    if (lowp && p.in_prec == P_BF16 && ctx->pv16_status && !no_pv16 && tuning().pv_fp16.load(std::memory_order_relaxed)) {
-        if (!ctx->pv16_sticky) {
-            const uint32_t st = (ctx->pv16_status[0] ? 1u : 0u) | (ctx->pv16_status[1] ? 2u : 0u);
-            if (st) {  // raised by an earlier in-stream launch: its caller has (or will see) non-finite / coarse outputs of THAT call
-                ctx->pv16_sticky = st;
-                ctx->pv16_fallbacks.fetch_add(1, std::memory_order_relaxed);
-                DBG("pv_fp16: status %u raised by an earlier launch -> bf16 P V from now on (umfa_set_option pv_fp16=1 re-arms)", st);
-            }
-        }
-        if (!ctx->pv16_sticky) {
-            pv.pv16 = 1;
-            pv.status = (uint32_t*)ctx->pv16_status;
-        }
-    }
-    if (used_pv16) *used_pv16 = pv.pv16 != 0;
+    if (lowp && p.in_prec == P_BF16 && tuning().pv_fp16.load(std::memory_order_relaxed)) pv.pv16 = 1;
+    // the fp16 image of V for the kernels that take one: one HBM-speed cast pass per call into a block of its own (the workspace may hold
+    // the rotated K / Q of the fused-RoPE entry).  A broadcast batch / head dimension of V (the zero-copy GQA views: stride 0) stays one:
+    // its slab is cast once.  false with e == hipSuccess: no block (the pool may not grow while the stream is capturing) -- the caller
+    // takes a kernel that converts V itself.
+    auto cast_v = [&](FwdParams& q) -> bool {
+        const uint32_t vB = p.vs[0] == 0 ? 1u : p.B, vH = p.vs[1] == 0 ? 1u : p.H;
+        const size_t slabs = (size_t)vB * vH, vbytes = slabs * p.Skv * p.D * 2;
+        char* blk = sc.ensure_v16(slabs, vbytes, stream);
+        if (!blk) return false;
+        void* v16 = blk + sc.v16_cnt_bytes;
+        if ((e = launch_cast_rows_bf16_to_f16(p.v, p.vs, v16, vB, vH, p.Skv, p.D, (uint32_t*)blk, stream)) != hipSuccess) return false;
+        q.v = v16;
+        q.vs[0] = p.vs[0] == 0 ? 0 : (int64_t)vH * p.Skv * p.D; q.vs[1] = p.vs[1] == 0 ? 0 : (int64_t)p.Skv * p.D; q.vs[2] = p.D; q.vs[3] = 1;
+        q.vsc = (const float*)blk;
+        q.vsc_bs = p.vs[0] == 0 ? 0u : vH; q.vsc_hs = p.vs[1] == 0 ? 0u : 1u;
+        q.pv16 = 2;
+        return true;
+    };
+    bool done = false;
     if (lowp && fwd_w64_supported(pv)) {
-        if (pv.pv16) {
-            // the one-wave-per-SIMD kernels take V as a dense fp16 image: one HBM-speed cast pass per call into a block of its
-            // own (the workspace may hold the rotated K / Q of the fused-RoPE entry).  Converting inside these kernels was
-            // built and measured: +15 % (every workgroup re-converts every tile); the 128-row kernel below does convert in-kernel.
-            // (a broadcast batch / head dimension of V -- the zero-copy GQA views: stride 0 -- stays one: its slab is cast once)
-            const uint32_t vB = p.vs[0] == 0 ? 1u : p.B, vH = p.vs[1] == 0 ? 1u : p.H;
-            const size_t vbytes = (size_t)vB * vH * p.Skv * p.D * 2;
-            void* v16 = sc.v16.ensure(vbytes + 256, stream);
-            if (!v16) return hipErrorOutOfMemory;
-            if ((e = launch_cast_rows_bf16_to_f16(p.v, p.vs, v16, vB, vH, p.Skv, p.D, pv.status, stream)) != hipSuccess) return e;
-            pv.v = v16;
-            pv.vs[0] = p.vs[0] == 0 ? 0 : (int64_t)vH * p.Skv * p.D; pv.vs[1] = p.vs[1] == 0 ? 0 : (int64_t)p.Skv * p.D; pv.vs[2] = p.D; pv.vs[3] = 1;
-        }
-        if (pv.mask_kind == MK_BOOL) {
+        // the one-wave-per-SIMD kernels take V as the dense fp16 image.  (Converting inside these kernels was built and measured: +15 %,
+        // every workgroup re-converts every tile; the 128-row kernel below does convert in-kernel.)
+        FwdParams pw = pv;
+        bool ok = !pv.pv16 || cast_v(pw);
+        if (!ok && e != hipSuccess) return e;
+        void* mk = nullptr;
+        if (ok && pw.mask_kind == MK_BOOL) {
             // bool mask tensor on the one-wave-per-SIMD structure: one pre-pass re-packs it into per-lane bit words, per-wave tile
             // classes and the visited-tile list of every 256-row block (fa_aux.hip mask_pack_kernel); the kernel then never stages
             // a tile no row of the block attends to and reads no mask bytes at all
-            void* mk = sc.mflags.ensure(mask_pack_bytes(pv), stream);
-            if (!mk) return hipErrorOutOfMemory;
-            if ((e = launch_mask_pack(pv, mk, stream)) != hipSuccess) return e;
+            mk = sc.mflags.ensure(mask_pack_bytes(pw), stream);
+            ok = mk != nullptr;
         }
-        const FwdW64Plan plan = fwd_w64_plan(pv);
-        char* w64 = sc.ensure_w64(plan.cnt_bytes, plan.buf_bytes, stream);
-        if (!w64) return hipErrorOutOfMemory;
-        e = launch_fwd_w64(pv, (float*)(w64 + sc.w64_cnt_bytes), (uint32_t*)w64, stream, &name);
+        const FwdW64Plan plan = fwd_w64_plan(pw);
+        char* w64 = ok ? sc.ensure_w64(plan.cnt_bytes, plan.buf_bytes, stream) : nullptr;
+        if (ok && w64) {
+            if (mk && (e = launch_mask_pack(pw, mk, stream)) != hipSuccess) return e;
+            e = launch_fwd_w64(pw, (float*)(w64 + sc.w64_cnt_bytes), (uint32_t*)w64, stream, &name);
+            done = true;
+        } else if (p.rope_cos || !fwd_16_supported(p)) {
+            return hipErrorOutOfMemory;  // (only this kernel family rotates Q in registers)
+        }
+        // else: a scratch block this family needs could not be provided (the first capture of a shape without an eager warm-up): the
+        // 128-row kernel below runs the call with what it can get -- V converted in the kernel, masks read per score
+    }
+    if (done) {
     } else if (p.rope_cos) {
         return hipErrorNotSupported;  // only the 256-row kernel rotates Q in registers (the entry asks before it sets this)
     } else if (lowp && fwd_16_supported(p)) {
@@ -139,14 +144,7 @@ hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p,
             // pass is cheaper (FLUX-size masked calls: ~11 us against ~15 % of the kernel) -- IF the tiles are re-read: with fewer than eight
             // 128-row q-blocks per head (decode-like calls: K / V are swept once) two more passes over V cost more than the kernel's own
             // sweep (B8 H32 Sq1 Skv8192: 393 us with the pass, see profiles/r4/lab_notes.md section 6).  Without a block (capture): in-kernel.
-            const uint32_t vB = p.vs[0] == 0 ? 1u : p.B, vH = p.vs[1] == 0 ? 1u : p.H;  // (broadcast dimensions stay broadcast)
-            void* v16 = sc.v16.ensure((size_t)vB * vH * p.Skv * p.D * 2 + 256, stream);
-            if (v16) {
-                if ((e = launch_cast_rows_bf16_to_f16(p.v, p.vs, v16, vB, vH, p.Skv, p.D, pv.status, stream)) != hipSuccess) return e;
-                pp.v = v16;
-                pp.vs[0] = p.vs[0] == 0 ? 0 : (int64_t)vH * p.Skv * p.D; pp.vs[1] = p.vs[1] == 0 ? 0 : (int64_t)p.Skv * p.D; pp.vs[2] = p.D; pp.vs[3] = 1;
-                pp.pv16 = 2;
-            }
+            if (!cast_v(pp) && e != hipSuccess) return e;
         }
         const FwdSplitPlan plan = fwd_16_split_plan(p);
         if (plan.nsplit > 1) {
@@ -231,25 +229,9 @@ mfa_error_t forward_sync(mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, 
     if (bq->upload(stream) != hipSuccess || bk->upload(stream) != hipSuccess || bv->upload(stream) != hipSuccess)
         return MFA_ERROR_EXECUTION_FAILED;
     (void)hipEventRecord(ctx->ev0, stream);  // kernel-only GPU time -> mfa_get_gpu_latency
-    bool used_pv16 = false;
-    hipError_t e = dispatch_forward(ctx, ctx->pool(ctx->device, stream), p, inter, stream, false, &used_pv16);
+    hipError_t e = dispatch_forward(ctx, ctx->pool(ctx->device, stream), p, inter, stream);
     if (e != hipSuccess) return rc_of(e);
     (void)hipEventRecord(ctx->ev1, stream);
-    if (used_pv16) {
-        // bf16 with the P V product in fp16: the kernels raise the status words when V does not fit fp16's range; this entry
-        // waits anyway, so it looks now and repeats the call on the bf16 P V kernels (nothing sticky: the next call tries again)
-        e = hipStreamSynchronize(stream);
-        if (e != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
-        if (ctx->pv16_status[0] | ctx->pv16_status[1]) {
-            DBG("pv_fp16: status %u/%u -> repeating the call with bf16 P V", ctx->pv16_status[0], ctx->pv16_status[1]);
-            ctx->pv16_status[0] = ctx->pv16_status[1] = 0;
-            ctx->pv16_fallbacks.fetch_add(1, std::memory_order_relaxed);
-            (void)hipEventRecord(ctx->ev0, stream);
-            e = dispatch_forward(ctx, ctx->pool(ctx->device, stream), p, inter, stream, true);
-            if (e != hipSuccess) return rc_of(e);
-            (void)hipEventRecord(ctx->ev1, stream);
-        }
-    }
     if (bo->download(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
     if (want_lse && bl->download(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
     e = hipStreamSynchronize(stream);
@@ -275,14 +257,6 @@ mfa_error_t mfa_create_context(mfa_context_t* context) {
         if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
             delete c;
             return MFA_ERROR_MEMORY_ALLOCATION;
-        }
-        // status words of the fp16-P-V bf16 forward: pinned host memory every device can write (kernels: system-scope stores)
-        void* st = nullptr;
-        if (hipHostMalloc(&st, 64, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess) {
-            memset(st, 0, 64);
-            c->pv16_status = (volatile uint32_t*)st;
-        } else {
-            (void)hipGetLastError();  // without the words the bf16 forward stays on its bf16 P V kernels
         }
         g_ctx = c;
     }
@@ -607,32 +581,13 @@ mfa_error_t umfa_set_option(mfa_context_t context, const char* name, const char*
     Context* c = as_ctx(context);
     if (!c) return MFA_ERROR_INVALID_ARGS;
     if (!set_tuning(name, value)) return MFA_ERROR_INVALID_ARGS;
-    if (name && !strcmp(name, "pv_fp16")) {  // (re-)arming: forget what earlier launches raised
-        std::lock_guard<std::mutex> lock(c->mu);
-        c->pv16_sticky = 0;
-        if (c->pv16_status) c->pv16_status[0] = c->pv16_status[1] = 0;
-    }
     return MFA_SUCCESS;
 }
 
 mfa_error_t umfa_get_option(mfa_context_t context, const char* name, char* value, size_t value_size) {
     Context* c = as_ctx(context);
     if (!c || !name || !value || value_size < 2) return MFA_ERROR_INVALID_ARGS;
-    char buf[64];
-    if (!strcmp(name, "pv_fp16_status")) {
-        // bit 0 / 1: a launch raised "output not finite" / "outputs below 2^-11" (now or before the switch went sticky),
-        // bit 2: in-stream calls are on the bf16 P V kernels until pv_fp16 is set again
-        std::lock_guard<std::mutex> lock(c->mu);
-        const uint32_t live = c->pv16_status ? ((c->pv16_status[0] ? 1u : 0u) | (c->pv16_status[1] ? 2u : 0u)) : 0u;
-        snprintf(buf, sizeof(buf), "%u", live | c->pv16_sticky | (c->pv16_sticky ? 4u : 0u));
-    } else if (!strcmp(name, "pv_fp16_fallbacks")) {
-        snprintf(buf, sizeof(buf), "%llu", (unsigned long long)c->pv16_fallbacks.load());
-    } else {
-        return get_tuning(name, value, value_size) ? MFA_SUCCESS : MFA_ERROR_INVALID_ARGS;
-    }
-    if (strlen(buf) + 1 > value_size) return MFA_ERROR_INVALID_ARGS;
-    strcpy(value, buf);
-    return MFA_SUCCESS;
+    return get_tuning(name, value, value_size) ? MFA_SUCCESS : MFA_ERROR_INVALID_ARGS;
 }
 
 mfa_error_t mfa_set_scale_arrays(mfa_context_t context, const float* q_scales, uint32_t q_scales_count,

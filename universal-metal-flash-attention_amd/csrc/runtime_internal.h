@@ -132,7 +132,9 @@ struct StreamScratch {
     size_t w64_cnt_bytes = 0, w64_buf_hw = 0;
     GrowBuf mflags;     // mask tile flags
     GrowBuf workspace;  // quantiser output (int8 Q/K, V image, scales, fp32 copies for backward); rotated K / Q of the fused-RoPE entry
-    GrowBuf v16;        // default bf16 forward on the w64 kernels: the fp16 image of V (never the workspace: the RoPE entry's K lives there)
+    GrowBuf v16;        // default bf16 forward: per-slab exchange words + 2^e (512 bytes per (batch, KV head), zeroed once, left zero by the cast pass),
+                        // then the fp16 image of V * 2^-e (never the workspace: the RoPE entry's K lives there)
+    size_t v16_cnt_bytes = 0, v16_buf_hw = 0;
     GrowBuf rowc;       // bwd16: row constants [2][B*H*Sq] fp32 (-LSE log2 e, -D) from bwd16_dq for bwd16_dkdv
     GrowBuf dsbuf;      // bwd16, option bwd_ds_store: dS [B*H][Sq][Skv] in the operand type
 
@@ -176,11 +178,17 @@ struct StreamScratch {
     char* ensure_split(size_t cnt_bytes, size_t buf_bytes, hipStream_t stream) {
         return ensure_ticketed(split, split_cnt_bytes, split_buf_hw, cnt_bytes, buf_bytes, stream);
     }
+    // header for `slabs` slabs (a 64-KiB multiple: 128 slabs before the header ever moves) + `image_bytes` behind it
+    static size_t v16_header_bytes(size_t slabs) { return ((slabs * (umfa::VSC_HDR_WORDS * 4) + 65535) / 65536) * 65536; }
+    char* ensure_v16(size_t slabs, size_t image_bytes, hipStream_t stream) {
+        return ensure_ticketed(v16, v16_cnt_bytes, v16_buf_hw, v16_header_bytes(slabs), image_bytes + 256, stream);
+    }
     void release() {
         split.release(); w64.release(); mflags.release(); workspace.release(); v16.release(); rowc.release(); dsbuf.release();
         w64_cnt_bytes = 0;
         split_cnt_bytes = 0;
-        w64_buf_hw = split_buf_hw = 0;
+        v16_cnt_bytes = 0;
+        w64_buf_hw = split_buf_hw = v16_buf_hw = 0;
     }
 };
 
@@ -194,14 +202,6 @@ struct Context {
     void* scratch = nullptr;  // host-mask staging of the synchronous entries (used under mu, then synchronised)
     size_t scratch_bytes = 0;
     std::vector<float> q_scales, k_scales, v_scales;  // mfa_set_scale_arrays: stored, never read
-    // bf16 forward with the P V product in fp16 (FwdParams::pv16, the default): four host-visible words the kernels raise --
-    // [0] an output came out non-finite (a V value beyond fp16's range), [1] a wave's outputs were all below 2^-11 (V's fp16
-    // image may have lost bits).  Synchronous entries read them behind their synchronise and repeat the call on the bf16 P V
-    // kernels; in-stream entries cannot wait: they look at the words when the NEXT call comes in and stay on the bf16 P V
-    // kernels from then on (pv16_sticky, until umfa_set_option(ctx, "pv_fp16", "1") re-arms).  pv16_fallbacks counts both.
-    volatile uint32_t* pv16_status = nullptr;
-    uint32_t pv16_sticky = 0;
-    std::atomic<uint64_t> pv16_fallbacks{0};
     std::atomic<int> refs{0};
     std::mutex mu;  // guards the pools, last_kernel / latency, and serialises lookup + launch of every entry
 

@@ -47,11 +47,12 @@ def release_scratch(stream=None, all_streams: bool = False) -> None:
 # launcher switches (include/umfa_abi.h umfa_set_option / umfa_get_option).  The LIBRARY holds the state (seeded once from the
 # environment: UMFA_FORCE_W64, UMFA_W64_TAU, ...); this module only reads and writes it.
 _OPTION_NAMES = ("softmax_reference", "softmax_tau", "w64_tau", "force_w64", "no_w64", "w64_grid", "w64_skew", "no_mask_flags", "bwd_exact",
-                 "bwd_dq", "bwd_persist", "bwd_separate_delta", "no_split", "force_split", "no_dma", "bn64", "pv_fp16", "bwd_ds_store", "no_w64_mask", "ksplit", "no_pipe", "no_w64_mask_lazy")
+                 "bwd_dq", "bwd_persist", "bwd_separate_delta", "no_split", "force_split", "no_dma", "bn64", "pv_fp16", "bwd_ds_store", "no_w64_mask", "ksplit", "no_pipe", "no_w64_mask_lazy",
+                 "cast_two_pass", "bwd_ds_lab", "cast_u")
 
 
 def get_option(name: str) -> str:
-    """The live value of a launcher switch (or of the read-only "pv_fp16_status" / "pv_fp16_fallbacks") as text."""
+    """The live value of a launcher switch as text."""
     buf = ctypes.create_string_buffer(64)
     _check_error(_lib.umfa_get_option(context(), name.encode(), buf, 64))
     return buf.value.decode()
@@ -60,13 +61,6 @@ def get_option(name: str) -> str:
 def set_option(name: str, value) -> None:
     """Context-wide launcher switch, e.g. set_option("softmax_reference", "exact") -- see umfa_set_option in the header."""
     _check_error(_lib.umfa_set_option(context(), name.encode(), str(value).encode()))
-
-
-def pv_fp16_status() -> int:
-    """bf16 forward with the P V product in fp16 (the default): bit 0 = a launch produced a non-finite output (a V value beyond
-    fp16's range), bit 1 = a launch's outputs were below 2^-11 (V's fp16 image may have lost bits), bit 2 = in-stream calls
-    have switched to the bf16 P V kernels because of it; set_option("pv_fp16", 1) re-arms."""
-    return int(get_option("pv_fp16_status"))
 
 
 class options:
