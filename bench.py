@@ -464,6 +464,29 @@ def run_rank(args) -> None:
                               "rel": float(_np.abs(dd).max() / _np.abs(ref).max()), "fp32_out": True,
                               "mask": {"cfg3_flux_bf16_mask_padding": "bool [1,1,1,S], keys < 3000 attend", "cfg3_flux_bf16_mask_blockdiag": "bool [1,1,S,S], four blocks of 1024"}[_name]}
             del fo
+        # sliding window WITHOUT a mask tensor (the in-stream entry's UMFA_MASK_TYPE_WINDOW; the north-star's "sliding-window tile early-exit"):
+        # +-512 keys around the row -- the same band as the window TENSORS of the mask tests, with no S x S mask anywhere
+        try:
+            fo = torch.empty(B, H, S, D, device=dev, dtype=torch.float32)
+            tg = graph_ms(lambda: umfa_torch.attention_forward(q, k, v, window=(512, 512), out=fo), 20)
+            kn = umfa_torch.last_kernel()
+            umfa_torch.attention_forward(q, k, v, window=(512, 512), out=fo)
+            torch.cuda.synchronize()
+            rows = _par.sample_rows(S)
+            band = (_np.abs(_np.arange(S)[None, :] - _np.asarray(rows)[:, None]) <= 512)
+            ref = _orc.sdpa_forward(_np.ascontiguousarray(_par.bits(q)[:, :, rows]), _par.bits(k), _par.bits(v), mask=_np.ascontiguousarray(band),
+                                    mask_type=_orc.MASK_BOOL).astype(_np.float64)
+            dd = fo[:, :, rows].cpu().numpy().astype(_np.float64) - ref
+            _r = _np.arange(S)
+            vis = float((_np.minimum(_r + 512, S - 1) - _np.maximum(_r - 512, 0) + 1).sum() / (S * S))
+            configs["cfg3_flux_bf16_window512"] = {"ms": round(tg, 5), "kernel": kn, "visible_fraction": round(vis, 4),
+                                                   "tflops_of_visible_work": round(FLOPS_PER_STEP * vis / tg / 1e9, 1),
+                                                   "frac_of_visible_work": round(FLOPS_PER_STEP * vis / tg / 1e9 / PEAK_BF16_TFLOPS, 4),
+                                                   "rel": float(_np.abs(dd).max() / _np.abs(ref).max()), "fp32_out": True,
+                                                   "mask": "none: window = (512, 512) through UMFA_MASK_TYPE_WINDOW"}
+            del fo
+        except Exception as exc:  # noqa: BLE001
+            configs["cfg3_flux_bf16_window512"] = {"error": repr(exc)}
         o3, lse3 = umfa_torch.attention_forward(q, k, v, return_lse=True)
         do3 = torch.randn_like(q)
         tb_e = med(event_ms(lambda: umfa_torch.attention_backward(do3, q, k, v, o3, lse3, scale=D ** -0.5), 20))
@@ -502,7 +525,7 @@ def run_rank(args) -> None:
             configs["cfg4_int8_bwd"] = {"error": repr(exc)}
         extra["configs"] = configs
         try:
-            extra["int8"] = bench_int8(torch, umfa_torch, event_ms, med)
+            extra["int8"] = bench_int8(torch, umfa_torch, event_ms, med, graph_ms)
         except Exception as exc:  # noqa: BLE001  reported, never silently replaced by another path
             extra["int8"] = {"error": repr(exc)}
         if not args.no_parity:
@@ -550,7 +573,9 @@ def run_rank(args) -> None:
             "settle": settle,
             **({"rehearsal": "UMFA_BENCH_ONE_DEVICE=1: all ranks on cuda:0 over gloo -- a code-path check, not a measurement"} if rehearsal else {}),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                         "frac_of_2516": round(achieved / 2516.0, 4),  # SURVEY.md section 8d quotes the dense bf16 peak as 2.516 PFLOP/s (256 CUs x 4096 FLOP/clk x 2.4 GHz)
+                         "traffic": traffic, "traffic_source": tsrc,
                          "traffic_kind": "static",
                          "kernel_ms_mean": round(mean_ms, 5), "kernel_ms_min": round(durs[0], 5),
                          "flops_per_launch": local_flops,
@@ -569,7 +594,7 @@ def run_rank(args) -> None:
         dist.destroy_process_group()
 
 
-def bench_int8(torch, umfa_torch, event_ms, med):
+def bench_int8(torch, umfa_torch, event_ms, med, graph_ms):
     """int8 block-quantised forward (quantiser pre-pass INCLUDED) vs the bf16 forward with the same fp32 O, both through
     their in-stream entries on the same stream, both timed by the same HIP events."""
     res = {}
@@ -579,11 +604,22 @@ def bench_int8(torch, umfa_torch, event_ms, med):
         out = torch.empty(Bx, Hx, Sx, D, device="cuda", dtype=torch.float32)
         out8 = torch.empty(Bx, Hx, Sx, D, device="cuda", dtype=torch.float32)
         lse8 = torch.empty(Bx * Hx * Sx, device="cuda", dtype=torch.float32)
-        bf = med(event_ms(lambda: umfa_torch.attention_forward(q, k, v, out=out), 20))
+        # graph-replayed like the headline and the configs (round 5; per-call eager events until then: a call timed from an idle queue
+        # carries its launch latency, and the three sides did not carry the same -- one box read the FLUX int8 call at 0.236 ms where
+        # back-to-back launches of the same build measure 0.183).  Median of three graphs of 20 calls, the sides interleaved.
+        fns = {"bf": lambda: umfa_torch.attention_forward(q, k, v, out=out),
+               "i8": lambda: umfa_torch.quantized_attention_forward_stream(q, k, v, out=out8, lse=lse8),
+               "f8": lambda: umfa_torch.quantized_attention_forward_stream(q, k, v, quant_mode="blockwise_fp8pv", out=out8, lse=lse8)}
+        ts = {n_: [] for n_ in fns}
+        for _ in range(3):
+            for n_, fn_ in fns.items():
+                ts[n_].append(graph_ms(fn_, 20))
+        bf, i8, f8 = (med(ts[n_]) for n_ in ("bf", "i8", "f8"))
+        fns["bf"]()
         kb = umfa_torch.last_kernel()
-        i8 = med(event_ms(lambda: umfa_torch.quantized_attention_forward_stream(q, k, v, out=out8, lse=lse8), 20))
+        fns["i8"]()
         k8 = umfa_torch.last_kernel()
-        f8 = med(event_ms(lambda: umfa_torch.quantized_attention_forward_stream(q, k, v, quant_mode="blockwise_fp8pv", out=out8, lse=lse8), 20))
+        fns["f8"]()
         fl = 4.0 * Bx * Hx * Sx * Sx * D
         # mixed peak of the reference's int8 arithmetic: half the FLOPs (QK^T) on the int8 MFMA at 2x the
         # bf16 rate, half (P V) on the fp16 MFMA: time floor = flops / 2 / 5000 + flops / 2 / 2500 -> 3333 TFLOP/s
@@ -595,8 +631,15 @@ def bench_int8(torch, umfa_torch, event_ms, med):
                      "fp8pv_ms_incl_quantiser": round(f8, 4), "fp8pv_speedup": round(bf / f8, 3), "fp8pv_kernel": umfa_torch.last_kernel(),
                      "modes": "int8 = quant_mode 2, the reference's arithmetic (int8 Q K V block-wise, P and P V in fp16); fp8pv = quant_mode 3 "
                               "(opt-in: int8 Q K^T, fp8 e4m3 P and V on the 2x-rate MFMA; rel-err in parity.cfg4_fp8pv)",
-                     "timer": "HIP events on the launch stream, median of 20, every side"}
+                     "timer": "HIP events around hipGraph replays of 20 calls, median of 3 graphs, the three sides interleaved"}
         del q, k, v, out, out8, lse8
+    try:
+        fx, c4 = res["flux_B1_H24_S4096_D128"], res["cfg4_B1_H16_S8192_D128"]
+        res["summary"] = (f"against the default bf16 forward, quantiser included: the reference's int8 arithmetic {c4['speedup']:.2f}x at config 4 "
+                          f"({fx['speedup']:.2f}x at the FLUX shape); the SageAttention2-style fp8 P V mode {c4['fp8pv_speedup']:.2f}x "
+                          f"({fx['fp8pv_speedup']:.2f}x) at 2x the quantisation error (parity.cfg4_fp8pv)")
+    except Exception:  # noqa: BLE001
+        pass
     return res
 
 

@@ -6,6 +6,11 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+# the bf16 MFMA backward against the oracle's fp64 gradients: P and dS are rounded to bf16 before their second products, so a gradient
+# carries ~2^-9 per term, averaged down by the sums: measured 3.5e-3 ... 4.5e-3 of the tensor's largest gradient (smoke: 3.96e-3).
+# Until round 5 this bar stood at 2e-2.
+BWD16_TOL = 8.0e-3
 torch = pytest.importorskip("torch")
 
 
@@ -137,7 +142,24 @@ def test_config3_flux_fwd_bwd_bf16():
                                                    bits(k[:, :1, :S2].contiguous()), bits(v[:, :1, :S2].contiguous()),
                                                    o_s, l_s.ravel(), input_precision="bf16")
     for g, r in ((gdq, rdq), (gdk, rdk), (gdv, rdv)):
-        assert np.abs(g - r).max() < 2e-2 * np.abs(r).max()  # bf16 MFMA backward (P, dS rounded to bf16)
+        assert np.abs(g - r).max() < BWD16_TOL * np.abs(r).max()  # bf16 MFMA backward (P, dS rounded to bf16): measured 4e-3
+    # ... and AT config size: a gradient row depends on its own row of Q / dO / O / LSE and every key (dQ), a gradient key row on its own
+    # K / V row and every query row (dK, dV) -- the oracle is handed the GPU forward's fp32 O and LSE (what the kernels were handed), so a
+    # row subset of the oracle's backward IS the full-size gradient on those rows
+    from oracle import parity
+    heads = [0, 11, 23]
+    rows = parity.sample_rows(S, groups=4)
+    keys = parity.sample_rows(S, groups=2)
+    o_np, lse_np = o32.cpu().numpy(), lse.view(B, H, S).cpu().numpy()
+    for h in heads:
+        hq, hk, hv, hdo = (bits(t[:, h:h + 1].contiguous()) for t in (q, k, v, do))
+        rdq_r, _, _, _ = orc.sdpa_backward(np.ascontiguousarray(hdo[:, :, rows]), np.ascontiguousarray(hq[:, :, rows]), hk, hv,
+                                           np.ascontiguousarray(o_np[:, h:h + 1][:, :, rows]), np.ascontiguousarray(lse_np[:, h:h + 1][:, :, rows]))
+        _, rdk_k, rdv_k, _ = orc.sdpa_backward(hdo, hq, np.ascontiguousarray(hk[:, :, keys]), np.ascontiguousarray(hv[:, :, keys]),
+                                               o_np[:, h:h + 1], lse_np[:, h:h + 1])
+        for name, g, r in (("dq", dq[:, h:h + 1][:, :, rows], rdq_r), ("dk", dk[:, h:h + 1][:, :, keys], rdk_k), ("dv", dv[:, h:h + 1][:, :, keys], rdv_k)):
+            e = float(np.abs(g.cpu().numpy() - r).max() / np.abs(r).max())
+            assert e < BWD16_TOL, (name, h, e)
 
 
 def test_config4_int8_blockwise_S8192_H16_D128():

@@ -28,10 +28,18 @@ def i64(v):
 
 class Lib:
     def __init__(self, name, path):
+        # path[:option=value,...] -- the options go to THAT library's switch table (umfa_set_option; a library loaded from a copy of the
+        # file has a table of its own)
+        path, _, opts = path.partition(":")
         self.name = name
         self.lib = _ffi._lib if path == "intree" else _ffi._load_library(str(Path(path).resolve()))
         self.ctx = _ffi.mfa_context_t()
         _ffi._check_error(self.lib.mfa_create_context(ctypes.byref(self.ctx)))
+        for kv in filter(None, opts.split(",")):
+            k_, v_ = kv.split("=")
+            self.lib.umfa_set_option.restype = ctypes.c_int
+            rc = self.lib.umfa_set_option(self.ctx, k_.encode(), v_.encode())
+            assert rc == 0, (name, kv, rc)
 
     def forward(self, q, k, v, out, causal, lse=None):
         B, H, Sq, D = q.shape
@@ -66,6 +74,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=12)
     ap.add_argument("--inner", type=int, default=20)
     ap.add_argument("--parity", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="time hipGraph replays of `inner` launches (short kernels: the Python launch path is not what is measured)")
     ap.add_argument("--quant", type=int, default=0, help="2 / 3: time umfa_quantized_forward_stream with that quant_mode (fp32 O)")
     ap.add_argument("libs", nargs="+")
     a = ap.parse_args()
@@ -84,13 +93,33 @@ def main():
             L.forward(q, k, v, out, a.causal)
     torch.cuda.synchronize()
     times = {L.name: [] for L in libs}
+    graphs = {}
+    if a.graph:
+        side = torch.cuda.Stream()
+        for L in libs:
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    L.forward(q, k, v, out, a.causal)
+                side.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    for _ in range(a.inner):
+                        L.forward(q, k, v, out, a.causal)
+            graphs[L.name] = g
+        torch.cuda.synchronize()
+        for g in graphs.values():
+            g.replay()
+        torch.cuda.synchronize()
     for r in range(a.rounds):
         order = libs if r % 2 == 0 else libs[::-1]
         for L in order:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(a.inner):
-                L.forward(q, k, v, out, a.causal)
+            if a.graph:
+                graphs[L.name].replay()
+            else:
+                for _ in range(a.inner):
+                    L.forward(q, k, v, out, a.causal)
             e1.record()
             torch.cuda.synchronize()
             times[L.name].append(e0.elapsed_time(e1) / a.inner)

@@ -47,6 +47,7 @@ struct QuantParams {
     int in_prec;
     float qmax;           // 127 or 7
     int qlo, qhi;         // clamp range
+    int t_first, t_end;   // the tensors (0 Q, 1 K, 2 V) this launch covers: [t_first, t_end)
 };
 
 // mode 0: write block absmax only; mode 1: quantise with scales already in scale[]; mode 2: both (fused).
@@ -77,6 +78,22 @@ __device__ __forceinline__ float div_by_block_scale(float a, float b, float r1) 
     return __builtin_fmaf(e2, r1, q1);
 }
 
+// The same five operations on two elements at once (v_pk_mul_f32 / v_pk_fma_f32: the packed forms round each half like the scalar
+// ones) followed by the reference's round-half-away and clamp: q = clamp(trunc(y + copysign(nextbelow(0.5), y))).
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void quant_pair_fast(float a0, float a1, float b, float r1, int qlo, int qhi, int& q0, int& q1) {
+    const f32x2_t a = {a0, a1}, bb = {b, b}, rr = {r1, r1};
+    const f32x2_t y0 = a * rr;
+    const f32x2_t e1 = __builtin_elementwise_fma(-bb, y0, a);
+    const f32x2_t y1 = __builtin_elementwise_fma(e1, rr, y0);
+    const f32x2_t e2 = __builtin_elementwise_fma(-bb, y1, a);
+    const f32x2_t y = __builtin_elementwise_fma(e2, rr, y1);
+    const f32x2_t h = {__builtin_copysignf(0x1.fffffep-2f, y[0]), __builtin_copysignf(0x1.fffffep-2f, y[1])};
+    const f32x2_t t = y + h;
+    q0 = max(min((int)t[0], qhi), qlo);
+    q1 = max(min((int)t[1], qhi), qlo);
+}
+
 // IN16: 16-bit inputs stay PACKED in registers (4 per 8-element chunk instead of 8 floats) and are decoded where they are used
 // (twice: absmax, then quantise).  The pass is latency-bound, not vector-bound -- round 4 took a quarter of its vector
 // instructions out (rounding / clamp / pack) and it stayed at 40 us, round 3 the same with the division -- so registers are
@@ -90,8 +107,8 @@ __global__ __launch_bounds__(256) void quantize_kernel(QuantParams p) {
     constexpr int MAXC = 8;  // chunks per thread: 64 rows * (256 / 8) chunks / 256 threads
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     uint32_t id = blockIdx.x;
-    int t = 0;
-    while (t < 2 && id >= p.BH * p.nblk[t]) { id -= p.BH * p.nblk[t]; ++t; }
+    int t = p.t_first;
+    while (t < p.t_end - 1 && id >= p.BH * p.nblk[t]) { id -= p.BH * p.nblk[t]; ++t; }
     const uint32_t bh = id / p.nblk[t], blk = id % p.nblk[t];
     const uint32_t row0 = blk * QBLK;
     const uint32_t nrows = min((uint32_t)QBLK, p.rows[t] - row0);
@@ -204,7 +221,7 @@ __global__ __launch_bounds__(256) void quantize_kernel(QuantParams p) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float xv = X(c, j);
-                const float y = fast_div ? div_by_block_scale(xv, sc, rcp1) : xv / sc;
+                const float y = fast_div ? div_by_block_scale(xv, sc, rcp1) : xv / sc;  // (quantize_wave_kernel: the packed form of the same five operations)
                 // roundf (half away from zero, the reference's .rounded()) as trunc(y + copysign(nextbelow(0.5), y)): one add and
                 // the truncating convert instead of trunc / sub / compare / select / add -- bit-identical for |y| < 2^22 (checked
                 // exhaustively over every float in [2^-3, 2^9); below that both give 0; |y| <= 127.x here by construction)
@@ -253,6 +270,103 @@ __global__ __launch_bounds__(256) void quantize_kernel(QuantParams p) {
             if (t < 2) *(uint2*)((t == 0 ? p.q8 : p.k8) + (orow0 + r) * p.DPQ + d0) = make_uint2(0u, 0u);
             else *(i32x4*)(p.v16 + (orow0 + r) * p.DPQ + d0) = i32x4{0, 0, 0, 0};
         }
+    }
+}
+
+// The block-wise quantiser of the hot configuration -- 16-bit operands, head_dim 64 / 128, no copies for a backward -- with ONE WAVE
+// per 64-row block (round 5).  Same arithmetic, same bits (tests/test_gpu_quantized.py holds both kernels to the oracle's integers);
+// what changes is the shape.  quantize_kernel gives a block to a workgroup: 4 loads per thread in flight, then a workgroup barrier
+// between the absmax and the conversion -- 126 MB at 3.15 TB/s whatever its instruction or register count was (rounds 3, 4).  The V
+// cast pass of the bf16 forward showed what that shape costs (same 16 KB per workgroup: 3.1 TB/s; 64 KB per workgroup: 4.1 TB/s).
+// Here a lane holds its block's 16 (head_dim 128) chunks in registers -- every load of the block is in flight before the first use --
+// the absmax is six wave shuffles, and nothing in the kernel waits for another wave.
+typedef unsigned u32x4_q __attribute__((ext_vector_type(4)));
+template <bool BF16> __device__ __forceinline__ float q16_elem(const u32x4_q& x, int j) {
+    const unsigned w = x[j >> 1];
+    if constexpr (BF16) return __uint_as_float((j & 1) ? (w & 0xffff0000u) : (w << 16));
+    return (float)__builtin_bit_cast(_Float16, (uint16_t)((j & 1) ? (w >> 16) : (w & 0xffffu)));
+}
+// one lane's CPL chunks -> int8 rows (Q / K) or de-quantised fp16 rows (V); FAST: the block's divisor allows the packed division
+template <int CPL, bool BF16, bool FAST, bool ISV>
+__device__ __forceinline__ void quantize_wave_convert(const u32x4_q (&xr)[CPL], int lane, uint32_t nchunks, float sc, float rcp1, int qlo, int qhi,
+                                                      int8_t* __restrict__ dst8, _Float16* __restrict__ dst16) {
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const uint32_t ch = (uint32_t)lane + 64u * c;
+        if (ch < nchunks) {
+            int q[8];
+            if constexpr (FAST) {
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) quant_pair_fast(q16_elem<BF16>(xr[c], j), q16_elem<BF16>(xr[c], j + 1), sc, rcp1, qlo, qhi, q[j], q[j + 1]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float y = q16_elem<BF16>(xr[c], j) / sc;
+                    const float half = __builtin_copysignf(0x1.fffffep-2f, y);
+                    q[j] = max(min((int)(y + half), qhi), qlo);
+                }
+            }
+            if constexpr (!ISV) {
+                const uint32_t a0 = __builtin_amdgcn_perm((uint32_t)q[1], (uint32_t)q[0], 0x0c0c0400u);
+                const uint32_t a1 = __builtin_amdgcn_perm((uint32_t)q[3], (uint32_t)q[2], 0x04000c0cu);
+                const uint32_t b0 = __builtin_amdgcn_perm((uint32_t)q[5], (uint32_t)q[4], 0x0c0c0400u);
+                const uint32_t b1 = __builtin_amdgcn_perm((uint32_t)q[7], (uint32_t)q[6], 0x04000c0cu);
+                *(uint2*)(dst8 + (int64_t)ch * 8) = make_uint2(a0 | a1, b0 | b1);  // (rows are D = 8 CPL bytes: chunk ch sits at byte 8 ch of the block)
+            } else {
+                f16x8 hv;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) hv[j] = (_Float16)((float)q[j] * sc);
+                *(f16x8*)(dst16 + (int64_t)ch * 8) = hv;
+            }
+        }
+    }
+}
+
+template <int CPL, bool BF16>  // 16-byte chunks per lane: 64 rows * (D / 8) / 64 lanes = D / 8
+__global__ __launch_bounds__(256) void quantize_wave_kernel(QuantParams p) {
+    const int lane = threadIdx.x & 63;
+    uint32_t id = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int t = p.t_first;
+    while (t < p.t_end - 1 && id >= p.BH * p.nblk[t]) { id -= p.BH * p.nblk[t]; ++t; }
+    if (id >= p.BH * p.nblk[t]) return;  // (the last workgroup's spare waves)
+    const uint32_t bh = id / p.nblk[t], blk = id % p.nblk[t];
+    const uint32_t row0 = blk * QBLK;
+    const uint32_t nrows = min((uint32_t)QBLK, p.rows[t] - row0);
+    constexpr uint32_t cpr = CPL;           // chunks per row = D / 8 = chunks per lane
+    const uint32_t nchunks = nrows * cpr;
+    const int64_t base = ((int64_t)bh * p.rows[t] + row0) * (int64_t)(8 * cpr);  // elements: the block's rows are contiguous (dense [rows][D])
+    const uint16_t* __restrict__ src = (const uint16_t*)p.src[t] + base;
+    u32x4_q xr[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const uint32_t ch = (uint32_t)lane + 64u * c;
+        xr[c] = ch < nchunks ? __builtin_nontemporal_load((const u32x4_q*)(src + (int64_t)ch * 8)) : u32x4_q{0, 0, 0, 0};
+    }
+    float amax = 0.0f;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(q16_elem<BF16>(xr[c], j)));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+    // (the packed inputs are decoded AGAIN for the conversion: without this the decoded floats of the absmax phase stay live across the
+    // shuffles -- 128 registers per lane at head_dim 128, two waves per SIMD instead of four)
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) asm volatile("" : "+v"(xr[c]));
+    const float sc = amax > 0.0f ? amax / p.qmax : 1.0f;
+    if (lane == 0) p.scale[t][bh * p.nblk[t] + blk] = sc;
+    const float rcp0 = __builtin_amdgcn_rcpf(sc);
+    const float rcp1 = __builtin_fmaf(__builtin_fmaf(-sc, rcp0, 1.0f), rcp0, rcp0);
+    // wave-uniform choices are scalar branches around whole loops (as per-element selects hipcc emitted both divides and a branch per element)
+    const bool fast_div = __builtin_amdgcn_readfirstlane((int)(sc >= 0x1p-60f && sc <= 0x1p60f)) != 0;
+    int8_t* const d8 = (t == 0 ? p.q8 : p.k8) + base;
+    _Float16* const d16 = p.v16 + base;
+    if (t == 2) {
+        if (fast_div) quantize_wave_convert<CPL, BF16, true, true>(xr, lane, nchunks, sc, rcp1, p.qlo, p.qhi, d8, d16);
+        else quantize_wave_convert<CPL, BF16, false, true>(xr, lane, nchunks, sc, rcp1, p.qlo, p.qhi, d8, d16);
+    } else {
+        if (fast_div) quantize_wave_convert<CPL, BF16, true, false>(xr, lane, nchunks, sc, rcp1, p.qlo, p.qhi, d8, d16);
+        else quantize_wave_convert<CPL, BF16, false, false>(xr, lane, nchunks, sc, rcp1, p.qlo, p.qhi, d8, d16);
     }
 }
 
@@ -608,7 +722,20 @@ hipError_t launch_quantize(const void* q, const void* k, const void* v, int in_p
     }
     if (quant_mode == 3) quant_mode = 2;
     const bool in16 = in_prec != P_FP32;
-    if (quant_mode == 2) {
+    qp.t_first = 0; qp.t_end = 3;
+    if (quant_mode == 2 && in16 && !want_f32 && !f8v && (D == 128 || D == 64) && !tuning().quant_block_wg.load(std::memory_order_relaxed) &&
+        ((uintptr_t)q & 15) == 0 && ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0) {
+        // the hot configuration: one wave per block (quantize_wave_kernel).  (The fp8 P V mode keeps the workgroup form for all three
+        // tensors: its V image needs the workgroup's LDS transpose, and a second launch for Q / K alone cost 4 us of a 165-us call.)
+        QuantParams qw = qp;
+        uint32_t nb = 0;
+        for (int t = 0; t < qw.t_end; ++t) nb += qp.BH * qp.nblk[t];
+        const dim3 gw((nb + 3) / 4);
+        if (D == 128 && in_prec == P_BF16) hipLaunchKernelGGL((quantize_wave_kernel<16, true>), gw, dim3(256), 0, stream, qw);
+        else if (D == 128) hipLaunchKernelGGL((quantize_wave_kernel<16, false>), gw, dim3(256), 0, stream, qw);
+        else if (in_prec == P_BF16) hipLaunchKernelGGL((quantize_wave_kernel<8, true>), gw, dim3(256), 0, stream, qw);
+        else hipLaunchKernelGGL((quantize_wave_kernel<8, false>), gw, dim3(256), 0, stream, qw);
+    } else if (quant_mode == 2) {
         if (in16) hipLaunchKernelGGL((quantize_kernel<2, true>), dim3(grid), dim3(256), 0, stream, qp);
         else hipLaunchKernelGGL((quantize_kernel<2, false>), dim3(grid), dim3(256), 0, stream, qp);
     } else {

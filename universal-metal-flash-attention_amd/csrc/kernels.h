@@ -21,7 +21,8 @@ struct Tuning {
     std::atomic<int> force_w64{0}, no_w64{0}, w64_grid{0}, w64_skew{0}, no_mask_flags{0}, bwd_exact{0}, bwd_dq{0}, bwd_persist{0},
         bwd_separate_delta{0}, no_split{0}, force_split{0}, no_dma{0}, bn64{0}, pv_fp16{0}, bwd_ds_store{0}, no_w64_mask{0}, ksplit{0}, no_pipe{0}, no_w64_mask_lazy{0},
         cast_two_pass{0} /* V cast pre-pass: amax and cast as two launches whatever the slab size (tests) */, bwd_ds_lab{0} /* lab, timing only: BwdParams::ds_lab */,
-        cast_u{0} /* lab: 16-byte loads per thread of the V cast pre-pass (4, 16, 32; 0 = the launcher's choice) */;
+        cast_u{0} /* lab: 16-byte loads per thread of the V cast pre-pass (4, 16, 32; 0 = the launcher's choice) */,
+        quant_block_wg{0} /* tests / A-B: the block-wise quantiser in its one-workgroup-per-block form everywhere */;
 };
 Tuning& tuning();
 bool set_tuning(const char* name, const char* value);  // false: unknown name or value out of range
@@ -33,6 +34,10 @@ hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes);
 
 // fp32-exact forward (any input type, any D <= 256, masks, causal, LSE).
 hipError_t launch_fwd_exact(const FwdParams& p, hipStream_t stream, const char** name);
+
+// head dims 257 ... 1024 (fa_fwd_wide.hip): fp32 arithmetic, any operand type / strides / mask; the reference's callers admit them
+// (metal_sdpa_backend.cpp:1078-1086), nothing tuned depends on them
+hipError_t launch_fwd_wide(const FwdParams& p, hipStream_t stream, const char** name);
 
 // bf16 / fp16 MFMA forward.  Requires in_prec in {FP16, BF16}, D % 8 == 0, D <= 256,
 // 16-byte aligned operands/strides, scale > 0.  Returns hipErrorNotSupported otherwise

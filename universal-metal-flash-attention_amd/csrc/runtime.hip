@@ -165,7 +165,7 @@ hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p,
         }
         e = launch_fwd_16(pp, stream, &name);
     } else {
-        e = launch_fwd_exact(p, stream, &name);
+        e = p.D > 256 ? launch_fwd_wide(p, stream, &name) : launch_fwd_exact(p, stream, &name);
     }
     ctx->last_kernel = name;
     DBG("forward B%u H%u Sq%u Skv%u D%u causal%d mask%d -> %s (%s)", p.B, p.H, p.Sq, p.Skv, p.D, p.causal,
@@ -207,7 +207,7 @@ mfa_error_t forward_sync(mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, 
     if (!bq->fits(nq * eb) || !bk->fits(nkv * eb) || !bv->fits(nkv * eb) || !bo->fits(nq * 4)) return MFA_ERROR_INVALID_ARGS;
     if (want_lse && !bl->fits((size_t)B * H * Sq * 4)) return MFA_ERROR_INVALID_ARGS;
     if (nq == 0 || nkv == 0) return MFA_SUCCESS;  // nothing to compute
-    if (D > 256) return MFA_ERROR_INVALID_ARGS;
+    if (D > 1024) return MFA_ERROR_INVALID_ARGS;  // the reference's callers' own limit (metal_sdpa_backend.cpp:1082-1084); 257 ... 1024: fa_fwd_wide.hip
 
     p.q = bq->dev; p.k = bk->dev; p.v = bv->dev; p.o = bo->dev;
     p.lse = want_lse ? (float*)bl->dev : nullptr;
@@ -389,7 +389,7 @@ mfa_error_t umfa_attention_forward_stream(mfa_context_t context, void* stream, c
                                           int32_t intermediate_precision) {
     Context* ctx = as_ctx(context);
     if (!ctx || !q || !k || !v || !out) return MFA_ERROR_INVALID_ARGS;
-    if (head_dim == 0 || head_dim > 256) return MFA_ERROR_INVALID_ARGS;
+    if (head_dim == 0 || head_dim > 1024) return MFA_ERROR_INVALID_ARGS;
     FwdParams p;
     memset(&p, 0, sizeof(p));
     p.B = batch_size; p.H = num_heads; p.Sq = seq_len_q; p.Skv = seq_len_kv; p.D = head_dim;

@@ -192,7 +192,7 @@ def _gqa_zero_copy(q, k, v, attn_mask, dropout_p, is_causal, scale):
     if (q.dim() != 4 or k.dim() != 4 or v.dim() != 4 or not (q.is_cuda and k.is_cuda and v.is_cuda) or dropout_p > 0.0
             or q.requires_grad or k.requires_grad or v.requires_grad or _quant_precision != QUANT_NONE
             or q.dtype not in _SUPPORTED or k.dtype != q.dtype or v.dtype != q.dtype or k.shape != v.shape
-            or q.size(0) != k.size(0) or q.size(3) != k.size(3) or q.size(3) == 0 or q.size(3) > 256):
+            or q.size(0) != k.size(0) or q.size(3) != k.size(3) or q.size(3) == 0 or q.size(3) > 1024):
         return None
     B, Hq, Sq, D = q.shape
     Hkv, Skv = k.size(1), k.size(2)
@@ -276,7 +276,7 @@ def scaled_dot_product_attention(query, key, value, attn_mask: Optional[torch.Te
                    or q.size(0) != k.size(0) or q.size(0) != v.size(0) or q.size(1) != k.size(1)
                    or q.size(1) != v.size(1) or q.size(3) != k.size(3) or q.size(3) != v.size(3)
                    or q.dtype not in _SUPPORTED or k.dtype != q.dtype or v.dtype != q.dtype
-                   or q.size(3) > 256 or q.size(3) == 0)
+                   or q.size(3) > 1024 or q.size(3) == 0)  # (the reference's own limit: metal_sdpa_backend.cpp:1082-1084)
     if unsupported or dropout_p > 0.0:
         return fallback()
 
@@ -307,7 +307,7 @@ def scaled_dot_product_attention(query, key, value, attn_mask: Optional[torch.Te
         return out.to(query.dtype)
     if q.requires_grad or k.requires_grad or v.requires_grad:
         if mask is not None or q.size(3) > 256:
-            return fallback()  # dense backward takes no mask (:1798-1803)
+            return fallback()  # dense backward takes no mask (:1798-1803); head dims above 256 have a forward only (fa_fwd_wide.hip)
         _bump("fp32_autograd")
         return _FlashAttentionFn.apply(q, k, v, bool(is_causal), sm_scale)
     # inference: in-stream, zero-copy, output directly in the input dtype (v)
