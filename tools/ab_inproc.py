@@ -41,14 +41,18 @@ class Lib:
             rc = self.lib.umfa_set_option(self.ctx, k_.encode(), v_.encode())
             assert rc == 0, (name, kv, rc)
 
+    mask = None  # class-wide: a bool mask tensor for every forward (--mask)
+
     def forward(self, q, k, v, out, causal, lse=None):
         B, H, Sq, D = q.shape
         prec = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}
+        m = Lib.mask
+        margs = (None, None, None, 0, 0, 0) if m is None else (ctypes.c_void_p(m.data_ptr()), i64(m.shape), i64(m.stride()), m.dim(), 1, 0)
         rc = self.lib.umfa_attention_forward_stream(
             self.ctx, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream),
             ctypes.c_void_p(q.data_ptr()), i64(q.stride()), ctypes.c_void_p(k.data_ptr()), i64(k.stride()),
             ctypes.c_void_p(v.data_ptr()), i64(v.stride()), ctypes.c_void_p(out.data_ptr()), prec[out.dtype],
-            ctypes.c_void_p(lse.data_ptr()) if lse is not None else None, None, None, None, 0, 0, 0,
+            ctypes.c_void_p(lse.data_ptr()) if lse is not None else None, *margs,
             B, Sq, k.shape[2], H, D, float(D) ** -0.5, bool(causal), prec[q.dtype], prec[q.dtype])
         assert rc == 0, (self.name, rc)
 
@@ -74,6 +78,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=12)
     ap.add_argument("--inner", type=int, default=20)
     ap.add_argument("--parity", action="store_true")
+    ap.add_argument("--mask", default="", help="blockdiag | padding | window_tensor | random: a bool mask tensor on every forward")
     ap.add_argument("--graph", action="store_true", help="time hipGraph replays of `inner` launches (short kernels: the Python launch path is not what is measured)")
     ap.add_argument("--quant", type=int, default=0, help="2 / 3: time umfa_quantized_forward_stream with that quant_mode (fp32 O)")
     ap.add_argument("libs", nargs="+")
@@ -83,6 +88,12 @@ def main():
     torch.manual_seed(0)
     q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=torch.float32).to(dt) for _ in range(3))
     out = torch.empty(B, H, S, D, device="cuda", dtype=dt if a.out == "same" else torch.float32)
+    if a.mask:
+        i_ = torch.arange(S, device="cuda")
+        Lib.mask = {"blockdiag": lambda: ((i_[:, None] // 1024) == (i_[None, :] // 1024))[None, None].contiguous(),
+                    "padding": lambda: (i_ < (3 * S) // 4)[None, None, None, :].contiguous(),
+                    "window_tensor": lambda: ((i_[:, None] - i_[None, :]).abs() <= 512)[None, None].contiguous(),
+                    "random": lambda: torch.rand(1, H, S, S, device="cuda") > 0.5}[a.mask]()
     libs = [Lib(*s.split("=", 1)) for s in a.libs]
     if a.quant:
         out = torch.empty(B, H, S, D, device="cuda", dtype=torch.float32)

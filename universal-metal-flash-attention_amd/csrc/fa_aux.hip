@@ -269,6 +269,120 @@ hipError_t launch_cast_f16(const void* src, int prec, void* dst, int64_t n, uint
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ bool masks for the one-wave-per-SIMD kernels (fa_fwd16_w64, MASKT)
+// A bool mask tensor is re-packed once per call into what a wave of that kernel consumes directly:
+//   bits  [mb][mh][rb64][tile][qb 2][lane 64] u32: bit 16 kb + r of lane (ql, hi) = "row 64 rb64 + 32 qb + ql attends key
+//         64 tile + 32 kb + (r & 3) + 8 (r >> 2) + 4 hi" -- i.e. bit j is the mask of score register r of score block (kb, qb)
+//         of that lane (fa_common.h acc_row); keys >= Skv and rows >= Sq are 0;
+//   wflag [mb][mh][rb64][tile] u8: 1 = no (row < Sq, key < Skv) element attends, 2 = every element of a whole 64 x 64 tile attends
+//         (the tile runs the plain tile body), 0 = mixed (the masking body with bits);
+//   list  [mb][mh][qblk][T][2] u32 + cnt [mb][mh][qblk]: the key tiles a 256-row block visits, ascending -- those in which not all
+//         four of its waves are fully masked -- as { tile | class(wave 0) << 16 | class(wave 1) << 18 | ..., next listed tile | the one
+//         after it << 16 } (past the end: the last tile again), so that the kernel needs nothing but its current entry (mask_list_kernel).
+// One read of every distinct mask byte (broadcast dims are not expanded); the bit image is 1/8 of the mask (2 MB for [1,1,4096,4096]).
+struct MaskPackArgs {
+    const void* mask;
+    int64_t ms[4];
+    uint32_t Sq, Skv;
+    uint32_t* bits;
+    uint8_t* wflag;
+    uint32_t Bm, Hm, nrb64, T;
+    uint64_t total;  // wave-tiles = Bm Hm nrb64 T (0: nothing to pack)
+    bool vec16;      // contiguous 16-byte aligned rows, Skv % 16 == 0
+    bool done;       // (launcher) the pack rode along with the V cast pass
+};
+template <bool VEC16>
+__device__ __forceinline__ void mask_pack_body(const MaskPackArgs& p, const uint32_t block) {
+    uint32_t* const bits = p.bits;
+    uint8_t* const wflag = p.wflag;
+    const uint32_t Hm = p.Hm, nrb64 = p.nrb64, T = p.T;
+    __shared__ __attribute__((aligned(16))) uint8_t stage[4][64 * 80];  // per wave: a 64 x 64 byte tile, rows padded to 80 bytes (bank spread)
+    const uint32_t lane = threadIdx.x & 63, ql = lane & 31, hi = lane >> 5, wv = threadIdx.x >> 6;
+    const uint64_t wid = (uint64_t)block * 4 + wv;
+    const uint64_t total = p.total;
+    if (wid >= total) return;  // (whole waves: no barrier below, every wave works on its own LDS area)
+    const uint32_t tile = (uint32_t)(wid % T);
+    const uint32_t rb = (uint32_t)((wid / T) % nrb64);
+    const uint32_t slab = (uint32_t)(wid / ((uint64_t)T * nrb64));
+    const uint32_t hm = slab % Hm, bm = slab / Hm;
+    const uint8_t* base = (const uint8_t*)p.mask + (int64_t)bm * p.ms[0] + (int64_t)hm * p.ms[1];
+    bool all_open = (uint64_t)tile * 64 + 64 <= p.Skv, any_open = false;
+    uint32_t w[2];
+    if constexpr (VEC16) {
+        // contiguous, 16-byte aligned rows with Skv % 16 == 0: the tile comes in as 16-byte loads in row order (a wave-load covers
+        // 16 rows x 64 bytes, coalesced), goes through the wave's LDS area and comes out in the lane order the attention kernel wants
+        uint8_t* st = stage[wv];
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const uint32_t r = 16 * ps + (lane >> 2), c = lane & 3, row = rb * 64 + r, key0 = tile * 64 + 16 * c;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (row < p.Sq && key0 < p.Skv) v = *(const u32x4*)(base + (int64_t)row * p.ms[2] + key0);
+            *(u32x4*)(st + r * 80 + 16 * c) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const uint32_t r = 32 * qb + ql;
+            uint32_t word = 0;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint32_t four = *(const uint32_t*)(st + r * 80 + 32 * kb + 8 * g + 4 * hi);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) word |= ((four >> (8 * e)) & 0xffu) ? 1u << (16 * kb + 4 * g + e) : 0u;
+                }
+            if (rb * 64 + r < p.Sq) {
+                all_open = all_open && word == 0xffffffffu;
+                any_open = any_open || word != 0;
+            }
+            w[qb] = word;
+        }
+    } else {
+        const bool vec4 = p.ms[3] == 1 && ((p.ms[0] | p.ms[1] | p.ms[2]) & 3) == 0 && ((uintptr_t)p.mask & 3) == 0;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const uint32_t row = rb * 64 + 32 * qb + ql;
+            uint32_t word = 0;
+            if (row < p.Sq) {
+                const uint8_t* rp = base + (int64_t)row * p.ms[2];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const uint32_t key0 = tile * 64 + 32 * kb + 8 * g + 4 * hi;
+                        uint32_t four = 0;  // byte e = mask[row][key0 + e]
+                        if (vec4 && key0 + 4 <= p.Skv) {
+                            four = *(const uint32_t*)(rp + key0);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (key0 + e < p.Skv) four |= (uint32_t)rp[(int64_t)(key0 + e) * p.ms[3]] << (8 * e);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) word |= ((four >> (8 * e)) & 0xffu) ? 1u << (16 * kb + 4 * g + e) : 0u;
+                    }
+                all_open = all_open && word == 0xffffffffu;
+                any_open = any_open || word != 0;
+            }
+            w[qb] = word;
+        }
+    }
+    uint32_t* dst = bits + ((wid * 2) * 64 + lane);
+    dst[0] = w[0];
+    dst[64] = w[1];
+    const bool open = __builtin_amdgcn_ballot_w64(any_open) != 0, full = __builtin_amdgcn_ballot_w64(!all_open) == 0;
+    if (lane == 0) wflag[wid] = !open ? 1 : (full ? 2 : 0);
+}
+
+template <bool VEC16>
+__global__ __launch_bounds__(256) void mask_pack_kernel(MaskPackArgs p) {
+    mask_pack_body<VEC16>(p, blockIdx.x);
+}
+
 // V of the default bf16 forward (P V product in fp16, FwdParams::pv16): bf16 rows (any batch / head / row strides, head_dim
 // contiguous) -> a dense fp16 image [B, H, S, D] of V * 2^-e, e ONE power of two per (batch, head) slab taken from the slab's
 // largest |v| (it lands in [2^15, 2^16): bf16's largest significand there is 65280, fp16 ends at 65504), and 2^e left in the
@@ -325,13 +439,23 @@ __device__ __forceinline__ unsigned block_amax(unsigned amax, unsigned* wmax) { 
     return m;
 }
 
+struct CastRowsArgs {
+    const uint16_t* src;
+    int64_t sb, sh, ss;
+    _Float16* dst;
+    uint32_t H, S, D8, chunks;
+    uint32_t* hdr;
+};
 template <int U, bool FUSED>
-__global__ __launch_bounds__(256) void cast_rows_bf16_f16_kernel(const uint16_t* __restrict__ src, int64_t sb, int64_t sh, int64_t ss,
-                                                                 _Float16* __restrict__ dst, uint32_t H, uint32_t S, uint32_t D8,
-                                                                 uint32_t chunks, uint32_t* __restrict__ hdr) {
+__device__ __forceinline__ void cast_rows_body(const CastRowsArgs& a, const uint32_t block) {
+    const uint16_t* __restrict__ src = a.src;
+    _Float16* __restrict__ dst = a.dst;
+    uint32_t* __restrict__ hdr = a.hdr;
+    const int64_t sb = a.sb, sh = a.sh, ss = a.ss;
+    const uint32_t H = a.H, S = a.S, D8 = a.D8, chunks = a.chunks;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     __shared__ unsigned wmax[4], slab_amax;
-    const uint32_t bh = blockIdx.x / chunks, chunk = blockIdx.x - bh * chunks, b = bh / H, h = bh - b * H;  // slab-major linear order
+    const uint32_t bh = block / chunks, chunk = block - bh * chunks, b = bh / H, h = bh - b * H;  // slab-major linear order
     const uint32_t rpw = 256u / D8;                       // rows one pass of the workgroup covers (D8 divides 256: head_dim 64 ... 256 x8; else see launcher)
     const uint32_t tr = threadIdx.x / D8, c = threadIdx.x - tr * D8;
     const uint32_t row0 = chunk * (U * rpw) + tr;
@@ -399,6 +523,19 @@ __global__ __launch_bounds__(256) void cast_rows_bf16_f16_kernel(const uint16_t*
     }
 }
 
+template <int U, bool FUSED>
+__global__ __launch_bounds__(256) void cast_rows_bf16_f16_kernel(CastRowsArgs a) {
+    cast_rows_body<U, FUSED>(a, blockIdx.x);
+}
+
+// the V cast pass and the bool mask's re-pack in one launch: blocks [0, cast_blocks) cast (slab-major, first: their exchange relies on it),
+// the rest pack mask tiles
+template <int U, bool VEC16>
+__global__ __launch_bounds__(256) void cast_rows_and_mask_pack_kernel(CastRowsArgs a, uint32_t cast_blocks, MaskPackArgs mk) {
+    if (blockIdx.x < cast_blocks) cast_rows_body<U, true>(a, blockIdx.x);
+    else mask_pack_body<VEC16>(mk, blockIdx.x - cast_blocks);
+}
+
 // slabs too long for the in-kernel exchange: the amax of every slab first (one more read of V; such slabs are >= 16 MB of attention work each)
 template <int U>
 __global__ __launch_bounds__(256) void vamax_rows_kernel(const uint16_t* __restrict__ src, int64_t sb, int64_t sh, int64_t ss, uint32_t H, uint32_t S,
@@ -423,25 +560,34 @@ __global__ __launch_bounds__(256) void vamax_rows_kernel(const uint16_t* __restr
 
 template <int U>
 static hipError_t launch_cast_rows_u(const void* src, const int64_t* strides, void* dst, uint32_t B, uint32_t H, uint32_t S, uint32_t D, uint32_t* hdr,
-                                     hipStream_t stream) {
+                                     hipStream_t stream, MaskPackArgs* mk) {
     const uint32_t D8 = D / 8, rpw = 256u / D8;  // (a head_dim that does not divide 2048 leaves 256 % D8 threads idle)
     const uint64_t chunks = ((uint64_t)S + U * rpw - 1) / (U * rpw), grid = (uint64_t)B * H * chunks;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     const bool fused = chunks <= 64 && !tuning().cast_two_pass.load(std::memory_order_relaxed);
+    const CastRowsArgs a = {(const uint16_t*)src, strides[0], strides[1], strides[2], (_Float16*)dst, H, S, D8, (uint32_t)chunks, hdr};
     if (fused) {
-        hipLaunchKernelGGL((cast_rows_bf16_f16_kernel<U, true>), dim3((unsigned)grid), dim3(256), 0, stream, (const uint16_t*)src, strides[0], strides[1],
-                           strides[2], (_Float16*)dst, H, S, D8, (uint32_t)chunks, hdr);
+        if (mk && mk->total) {
+            // ... and the bool mask's re-pack for the one-wave-per-SIMD kernel in the SAME launch: its workgroups come behind the cast's
+            // (whose exchange needs them dispatched first, in order), run under the cast's memory time, and the call is one launch shorter
+            const unsigned g2 = (unsigned)((mk->total + 3) / 4);
+            if (grid + g2 > 0x7fffffffull) return hipErrorInvalidValue;
+            if (mk->vec16) hipLaunchKernelGGL((cast_rows_and_mask_pack_kernel<U, true>), dim3((unsigned)grid + g2), dim3(256), 0, stream, a, (unsigned)grid, *mk);
+            else hipLaunchKernelGGL((cast_rows_and_mask_pack_kernel<U, false>), dim3((unsigned)grid + g2), dim3(256), 0, stream, a, (unsigned)grid, *mk);
+            mk->done = true;
+        } else {
+            hipLaunchKernelGGL((cast_rows_bf16_f16_kernel<U, true>), dim3((unsigned)grid), dim3(256), 0, stream, a);
+        }
     } else {
         hipLaunchKernelGGL(vamax_rows_kernel<U>, dim3((unsigned)grid), dim3(256), 0, stream, (const uint16_t*)src, strides[0], strides[1], strides[2], H, S,
                            D8, (uint32_t)chunks, hdr);
-        hipLaunchKernelGGL((cast_rows_bf16_f16_kernel<U, false>), dim3((unsigned)grid), dim3(256), 0, stream, (const uint16_t*)src, strides[0], strides[1],
-                           strides[2], (_Float16*)dst, H, S, D8, (uint32_t)chunks, hdr);
+        hipLaunchKernelGGL((cast_rows_bf16_f16_kernel<U, false>), dim3((unsigned)grid), dim3(256), 0, stream, a);
     }
     return hipGetLastError();
 }
 
-hipError_t launch_cast_rows_bf16_to_f16(const void* src, const int64_t* strides, void* dst, uint32_t B, uint32_t H, uint32_t S, uint32_t D,
-                                        uint32_t* hdr, hipStream_t stream) {
+static hipError_t launch_cast_rows_any(const void* src, const int64_t* strides, void* dst, uint32_t B, uint32_t H, uint32_t S, uint32_t D,
+                                       uint32_t* hdr, hipStream_t stream, MaskPackArgs* mk) {
     if (!src || !dst || !hdr || (D & 7) || D > 2048 || strides[3] != 1 || (strides[0] | strides[1] | strides[2]) % 8 || ((uintptr_t)src & 15)) return hipErrorInvalidValue;
     if ((int64_t)B * H * S * D == 0) return hipSuccess;
     // 16 loads per thread (64 KB per workgroup at head_dim 128) while that still leaves a workgroup per CU, else 4
@@ -450,9 +596,9 @@ hipError_t launch_cast_rows_bf16_to_f16(const void* src, const int64_t* strides,
     const int lab = tuning().cast_u.load(std::memory_order_relaxed);
     const uint64_t chunks16 = ((uint64_t)S + 16 * rpw - 1) / (16 * rpw);
     // (32: slabs of 65 ... 128 chunks of 16 passes still take the one-launch form)
-    if (lab == 32 || (!lab && chunks16 > 64 && chunks16 <= 128)) return launch_cast_rows_u<32>(src, strides, dst, B, H, S, D, hdr, stream);
-    if (lab == 4 || (!lab && wg16 < (uint64_t)device_cu_count())) return launch_cast_rows_u<4>(src, strides, dst, B, H, S, D, hdr, stream);
-    return launch_cast_rows_u<16>(src, strides, dst, B, H, S, D, hdr, stream);
+    if (lab == 32 || (!lab && chunks16 > 64 && chunks16 <= 128)) return launch_cast_rows_u<32>(src, strides, dst, B, H, S, D, hdr, stream, mk);
+    if (lab == 4 || (!lab && wg16 < (uint64_t)device_cu_count())) return launch_cast_rows_u<4>(src, strides, dst, B, H, S, D, hdr, stream, mk);
+    return launch_cast_rows_u<16>(src, strides, dst, B, H, S, D, hdr, stream, mk);
 }
 
 hipError_t launch_bwd16_rowc(const float* lse, const float* dvec, float* rowc, int64_t n, hipStream_t stream) {
@@ -593,101 +739,6 @@ hipError_t launch_mask_flags(FwdParams& p, uint8_t* flags, hipStream_t stream) {
 // Is the pre-pass worth its read of the mask?  Byte masks: always (at worst +15 % for a dense random per-head mask, 2-4x
 // for banded / padded ones).  Additive float masks are usually dense biases with nothing to skip: only when the distinct
 // mask bytes stay below twice the Q + K + V + O traffic (e.g. one [Sq, Skv] bias shared by the heads).
-// ------------------------------------------------------------------ bool masks for the one-wave-per-SIMD kernels (fa_fwd16_w64, MASKT)
-// A bool mask tensor is re-packed once per call into what a wave of that kernel consumes directly:
-//   bits  [mb][mh][rb64][tile][qb 2][lane 64] u32: bit 16 kb + r of lane (ql, hi) = "row 64 rb64 + 32 qb + ql attends key
-//         64 tile + 32 kb + (r & 3) + 8 (r >> 2) + 4 hi" -- i.e. bit j is the mask of score register r of score block (kb, qb)
-//         of that lane (fa_common.h acc_row); keys >= Skv and rows >= Sq are 0;
-//   wflag [mb][mh][rb64][tile] u8: 1 = no (row < Sq, key < Skv) element attends, 2 = every element of a whole 64 x 64 tile attends
-//         (the tile runs the plain tile body), 0 = mixed (the masking body with bits);
-//   list  [mb][mh][qblk][T][2] u32 + cnt [mb][mh][qblk]: the key tiles a 256-row block visits, ascending -- those in which not all
-//         four of its waves are fully masked -- as { tile | class(wave 0) << 16 | class(wave 1) << 18 | ..., next listed tile | the one
-//         after it << 16 } (past the end: the last tile again), so that the kernel needs nothing but its current entry (mask_list_kernel).
-// One read of every distinct mask byte (broadcast dims are not expanded); the bit image is 1/8 of the mask (2 MB for [1,1,4096,4096]).
-template <bool VEC16>
-__global__ __launch_bounds__(256) void mask_pack_kernel(FwdParams p, uint32_t* bits, uint8_t* wflag, uint32_t Bm, uint32_t Hm, uint32_t nrb64, uint32_t T) {
-    __shared__ __attribute__((aligned(16))) uint8_t stage[4][64 * 80];  // per wave: a 64 x 64 byte tile, rows padded to 80 bytes (bank spread)
-    const uint32_t lane = threadIdx.x & 63, ql = lane & 31, hi = lane >> 5, wv = threadIdx.x >> 6;
-    const uint64_t wid = (uint64_t)blockIdx.x * 4 + wv;
-    const uint64_t total = (uint64_t)Bm * Hm * nrb64 * T;
-    if (wid >= total) return;  // (whole waves: no barrier below, every wave works on its own LDS area)
-    const uint32_t tile = (uint32_t)(wid % T);
-    const uint32_t rb = (uint32_t)((wid / T) % nrb64);
-    const uint32_t slab = (uint32_t)(wid / ((uint64_t)T * nrb64));
-    const uint32_t hm = slab % Hm, bm = slab / Hm;
-    const uint8_t* base = (const uint8_t*)p.mask + (int64_t)bm * p.ms[0] + (int64_t)hm * p.ms[1];
-    bool all_open = (uint64_t)tile * 64 + 64 <= p.Skv, any_open = false;
-    uint32_t w[2];
-    if constexpr (VEC16) {
-        // contiguous, 16-byte aligned rows with Skv % 16 == 0: the tile comes in as 16-byte loads in row order (a wave-load covers
-        // 16 rows x 64 bytes, coalesced), goes through the wave's LDS area and comes out in the lane order the attention kernel wants
-        uint8_t* st = stage[wv];
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-            const uint32_t r = 16 * ps + (lane >> 2), c = lane & 3, row = rb * 64 + r, key0 = tile * 64 + 16 * c;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (row < p.Sq && key0 < p.Skv) v = *(const u32x4*)(base + (int64_t)row * p.ms[2] + key0);
-            *(u32x4*)(st + r * 80 + 16 * c) = v;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            const uint32_t r = 32 * qb + ql;
-            uint32_t word = 0;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const uint32_t four = *(const uint32_t*)(st + r * 80 + 32 * kb + 8 * g + 4 * hi);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) word |= ((four >> (8 * e)) & 0xffu) ? 1u << (16 * kb + 4 * g + e) : 0u;
-                }
-            if (rb * 64 + r < p.Sq) {
-                all_open = all_open && word == 0xffffffffu;
-                any_open = any_open || word != 0;
-            }
-            w[qb] = word;
-        }
-    } else {
-        const bool vec4 = p.ms[3] == 1 && ((p.ms[0] | p.ms[1] | p.ms[2]) & 3) == 0 && ((uintptr_t)p.mask & 3) == 0;
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            const uint32_t row = rb * 64 + 32 * qb + ql;
-            uint32_t word = 0;
-            if (row < p.Sq) {
-                const uint8_t* rp = base + (int64_t)row * p.ms[2];
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const uint32_t key0 = tile * 64 + 32 * kb + 8 * g + 4 * hi;
-                        uint32_t four = 0;  // byte e = mask[row][key0 + e]
-                        if (vec4 && key0 + 4 <= p.Skv) {
-                            four = *(const uint32_t*)(rp + key0);
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (key0 + e < p.Skv) four |= (uint32_t)rp[(int64_t)(key0 + e) * p.ms[3]] << (8 * e);
-                        }
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) word |= ((four >> (8 * e)) & 0xffu) ? 1u << (16 * kb + 4 * g + e) : 0u;
-                    }
-                all_open = all_open && word == 0xffffffffu;
-                any_open = any_open || word != 0;
-            }
-            w[qb] = word;
-        }
-    }
-    uint32_t* dst = bits + ((wid * 2) * 64 + lane);
-    dst[0] = w[0];
-    dst[64] = w[1];
-    const bool open = __builtin_amdgcn_ballot_w64(any_open) != 0, full = __builtin_amdgcn_ballot_w64(!all_open) == 0;
-    if (lane == 0) wflag[wid] = !open ? 1 : (full ? 2 : 0);
-}
-
 // one wave per (mask batch, mask head, 256-row block): compact the visited tiles
 __global__ __launch_bounds__(64) void mask_list_kernel(const uint8_t* wflag, uint32_t* list, uint32_t* cnt, uint32_t nrb64, uint32_t nqb, uint32_t T) {
     const uint32_t lane = threadIdx.x, qblk = blockIdx.x % nqb, slab = blockIdx.x / nqb;
@@ -722,61 +773,71 @@ __global__ __launch_bounds__(64) void mask_list_kernel(const uint8_t* wflag, uin
     }
 }
 
-// Running sums of the list lengths of the last n_items % G blocks (the ones the attention kernel's G workgroups share, in item order):
-// prefix[0] = 0, prefix[j + 1] = prefix[j] + cnt(block first + j).  One workgroup; fewer than 512 blocks.
-__global__ __launch_bounds__(512) void mask_prefix_kernel(const uint32_t* cnt, uint32_t* prefix, uint32_t n_items, uint32_t G, uint32_t nqb, uint32_t H,
-                                                          uint32_t mk_bs, uint32_t mk_hs) {
-    __shared__ uint32_t sc[512];
-    const uint32_t rem = n_items % G, first = n_items - rem, t = threadIdx.x;
-    uint32_t c = 0;
-    if (t < rem) {
-        const uint32_t item = first + t, bh = item / nqb;
-        c = cnt[((bh / H) * mk_bs + (bh % H) * mk_hs) * nqb + item % nqb];
-    }
-    sc[t] = c;
-    __syncthreads();
-    for (uint32_t off = 1; off < 512; off <<= 1) {
-        const uint32_t add = t >= off ? sc[t - off] : 0u;
-        __syncthreads();
-        sc[t] += add;
-        __syncthreads();
-    }
-    if (t == 0) prefix[0] = 0;
-    if (t < rem) prefix[t + 1] = sc[t];
-}
-
 size_t mask_pack_bytes(const FwdParams& p) {
     const uint64_t Bm = p.ms[0] ? p.B : 1, Hm = p.ms[1] ? p.H : 1, nrb64 = (p.Sq + 63) / 64, nqb = (p.Sq + 255) / 256, T = (p.Skv + 63) / 64;
     const uint64_t slabs = Bm * Hm;
     return (size_t)(slabs * nrb64 * T * 512 + ((slabs * nrb64 * T + 255) & ~255ull) + slabs * nqb * T * 8 + ((slabs * nqb * 4 + 255) & ~255ull) + 1024 + 2304);
 }
 
-hipError_t launch_mask_pack(FwdParams& p, void* scratch, hipStream_t stream) {
+// the scratch layout of the packed mask + the arguments of the pack kernel; fills p.mk_*
+static hipError_t mask_pack_prepare(FwdParams& p, void* scratch, MaskPackArgs& a, uint32_t*& list, uint32_t*& cnt, uint32_t& nqb, uint64_t& slabs) {
     if (p.mask_kind != MK_BOOL || !p.mask || !scratch) return hipErrorInvalidValue;
-    const uint32_t Bm = p.ms[0] ? p.B : 1, Hm = p.ms[1] ? p.H : 1, nrb64 = (p.Sq + 63) / 64, nqb = (p.Sq + 255) / 256, T = (p.Skv + 63) / 64;
-    const uint64_t slabs = (uint64_t)Bm * Hm, total = slabs * nrb64 * T;
+    const uint32_t Bm = p.ms[0] ? p.B : 1, Hm = p.ms[1] ? p.H : 1, nrb64 = (p.Sq + 63) / 64, T = (p.Skv + 63) / 64;
+    nqb = (p.Sq + 255) / 256;
+    slabs = (uint64_t)Bm * Hm;
+    const uint64_t total = slabs * nrb64 * T;
     if (total == 0 || total > 0x7fffffffull * 4 || T > 0xffffu) return hipErrorInvalidValue;
     char* base = (char*)scratch;
     uint32_t* bits = (uint32_t*)base;
     uint8_t* wflag = (uint8_t*)(base + total * 512);
-    uint32_t* list = (uint32_t*)(base + total * 512 + ((total + 255) & ~255ull));
-    uint32_t* cnt = (uint32_t*)((char*)list + slabs * nqb * T * 8);
-    uint32_t* prefix = (uint32_t*)((char*)cnt + ((slabs * nqb * 4 + 255) & ~255ull));
-    const bool vec16 = p.ms[3] == 1 && (p.Skv & 15) == 0 && ((p.ms[0] | p.ms[1] | p.ms[2]) & 15) == 0 && ((uintptr_t)p.mask & 15) == 0;
-    if (vec16) hipLaunchKernelGGL(mask_pack_kernel<true>, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream, p, bits, wflag, Bm, Hm, nrb64, T);
-    else hipLaunchKernelGGL(mask_pack_kernel<false>, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, stream, p, bits, wflag, Bm, Hm, nrb64, T);
-    hipLaunchKernelGGL(mask_list_kernel, dim3((unsigned)(slabs * nqb)), dim3(64), 0, stream, wflag, list, cnt, nrb64, nqb, T);
+    list = (uint32_t*)(base + total * 512 + ((total + 255) & ~255ull));
+    cnt = (uint32_t*)((char*)list + slabs * nqb * T * 8);
+    a.mask = p.mask;
+    for (int i = 0; i < 4; ++i) a.ms[i] = p.ms[i];
+    a.Sq = p.Sq; a.Skv = p.Skv;
+    a.bits = bits; a.wflag = wflag;
+    a.Bm = Bm; a.Hm = Hm; a.nrb64 = nrb64; a.T = T;
+    a.total = total;
+    a.vec16 = p.ms[3] == 1 && (p.Skv & 15) == 0 && ((p.ms[0] | p.ms[1] | p.ms[2]) & 15) == 0 && ((uintptr_t)p.mask & 15) == 0;
+    a.done = false;
     p.mk_bits = bits; p.mk_list = list; p.mk_cnt = cnt;
     p.mk_bs = p.ms[0] ? Hm : 0; p.mk_hs = p.ms[1] ? 1 : 0;  // slab index of (b, h) = b * mk_bs + h * mk_hs
     p.mk_nrb64 = nrb64; p.mk_T = T;
-    p.mk_prefix = nullptr;
-    const uint32_t n_items = p.B * p.H * nqb, G = fwd_w64_grid(p);
-    if (G && n_items % G) {
-        if (G > 512) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(mask_prefix_kernel, dim3(1), dim3(512), 0, stream, cnt, prefix, n_items, G, nqb, p.H, p.mk_bs, p.mk_hs);
-        p.mk_prefix = prefix;
+    p.mk_prefix = nullptr;  // (the attention kernel scans the shared blocks' list lengths itself since round 5)
+    if (fwd_w64_grid(p) > 512) return hipErrorInvalidValue;  // (that scan: two list lengths per thread)
+    return hipSuccess;
+}
+
+static hipError_t mask_pack_finish(const MaskPackArgs& a, uint32_t* list, uint32_t* cnt, uint32_t nqb, uint64_t slabs, hipStream_t stream) {
+    if (!a.done) {
+        if (a.vec16) hipLaunchKernelGGL(mask_pack_kernel<true>, dim3((unsigned)((a.total + 3) / 4)), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(mask_pack_kernel<false>, dim3((unsigned)((a.total + 3) / 4)), dim3(256), 0, stream, a);
     }
+    hipLaunchKernelGGL(mask_list_kernel, dim3((unsigned)(slabs * nqb)), dim3(64), 0, stream, a.wflag, list, cnt, a.nrb64, nqb, a.T);
     return hipGetLastError();
+}
+
+hipError_t launch_mask_pack(FwdParams& p, void* scratch, hipStream_t stream) {
+    MaskPackArgs a;
+    uint32_t *list, *cnt, nqb;
+    uint64_t slabs;
+    if (hipError_t e = mask_pack_prepare(p, scratch, a, list, cnt, nqb, slabs); e != hipSuccess) return e;
+    return mask_pack_finish(a, list, cnt, nqb, slabs, stream);
+}
+
+hipError_t launch_cast_rows_bf16_to_f16(const void* src, const int64_t* strides, void* dst, uint32_t B, uint32_t H, uint32_t S, uint32_t D,
+                                        uint32_t* hdr, hipStream_t stream) {
+    return launch_cast_rows_any(src, strides, dst, B, H, S, D, hdr, stream, nullptr);
+}
+
+hipError_t launch_cast_rows_and_mask_pack(const void* src, const int64_t* strides, void* dst, uint32_t B, uint32_t H, uint32_t S, uint32_t D,
+                                          uint32_t* hdr, FwdParams& p, void* mask_scratch, hipStream_t stream) {
+    MaskPackArgs a;
+    uint32_t *list, *cnt, nqb;
+    uint64_t slabs;
+    if (hipError_t e = mask_pack_prepare(p, mask_scratch, a, list, cnt, nqb, slabs); e != hipSuccess) return e;
+    if (hipError_t e = launch_cast_rows_any(src, strides, dst, B, H, S, D, hdr, stream, &a); e != hipSuccess) return e;
+    return mask_pack_finish(a, list, cnt, nqb, slabs, stream);  // (the pack itself rode along unless the cast took its two-launch form)
 }
 
 bool mask_flags_worthwhile(const FwdParams& p) {

@@ -19,6 +19,8 @@
 //     once), then the remaining items are shared "stream-K" style, so 384 items on 256 CUs (the FLUX shape) cost
 //     1.5 item-times instead of 2; an item cut by a slice boundary is folded by the last of its parts to arrive,
 //     in index order (bitwise reproducible), through part_buf.
+#include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
 
@@ -285,6 +287,97 @@ static uint32_t w64_tiles_per_item(const FwdParams& p) {
     return tw < T ? (uint32_t)tw : T;
 }
 
+static uint32_t w64_grid(const FwdParams& p);
+
+// ---- routing cost model ------------------------------------------------------------------------------------------------------------
+// Predicted microseconds of one launch, per structure.  The FORMS follow the kernels' schedules; the constants are least-squares fits
+// (log time) to launches measured on MI355X at 256 CUs, both kernels forced in turn (tools/fit_route_model.py prints this table from
+// profiles/r5/routing_*.jsonl together with its residuals: median error 5-9 %, which is why the comparison below is only trusted as a
+// comparison -- both predictions share most of their inputs).  Other CU counts enter through the schedule arithmetic (rounds, slices),
+// not through the constants.
+//   w64 (one persistent workgroup per CU):  t0 + cast + segments c_seg + tile_steps t_step + folded_parts c_fold
+//   128-row (R co-resident workgroups per CU, dispatched as slots free up):
+//        uniform items   full rounds of R at tau1 f(R) per tile, the rest at f(rest)          + c_item per round (+ c_tail per split part)
+//        causal items    max(throughput of all tiles at f(R) / R  + c_tail longest, the longest item alone)
+//   cast = cast_a + 2 V bytes / cast_tbps for bf16 operands (the fp16 image of V: every w64 launch; 128-row launches from 16 MB on)
+struct W64Cost { float t0, c_seg, t_step, c_fold, cast_a, cast_tbps; };
+struct R128Cost { float t0, c_item, tau1, f2, f3, cast_a, cast_tbps, c_tail, g16; };  // g16: tau1 factor without the bf16 -> fp16 conversion of V (fp16 operands)
+// [head_dim 64 | 128][full | causal]
+static const W64Cost kW64Cost[2][2] = {
+    {{2.3807f, 5.4886f, 1.0809f, 1.8609f, 4.3829f, 3.8557f}, {9.2507f, 0.0000f, 1.1396f, 14.5701f, 2.5974f, 2.1145f}},
+    {{0.4497f, 9.9841f, 1.6534f, 3.2625f, 3.5524f, 3.7822f}, {0.0000f, 6.7085f, 1.4716f, 11.2816f, 2.1262f, 2.5206f}}};
+static const R128Cost kR128Cost[2][2] = {
+    {{1.7650f, 4.0233f, 0.6673f, 1.9430f, 1.0003f, 0.0000f, 20.0000f, 2.0672f, 0.8992f}, {0.0000f, 6.2266f, 0.7644f, 1.3369f, 3.0000f, 0.0000f, 7.0307f, 0.8890f, 0.9126f}},
+    {{0.0000f, 8.2792f, 1.1413f, 1.9875f, 2.9244f, 3.2052f, 20.0000f, 3.5374f, 0.9652f}, {0.0000f, 8.3522f, 1.3922f, 1.2808f, 1.0856f, 0.0000f, 6.2498f, 0.7743f, 0.9168f}}};
+// (fit of round 5, 1339 launches: each model's error against the measurement: median 3-10 %, 90th percentile 12-25 %; routing by the pair:
+// within 5 % of the faster kernel on 97.8 % of the launches, worst 1.14 x -- the thresholds it replaces, measured on 980 of them: 93.4 %,
+// worst 1.26 x)
+
+static double route_v_megabytes(const FwdParams& p) {  // distinct V slabs (broadcast batch / head strides: one slab)
+    return (double)(p.vs[0] == 0 ? 1u : p.B) * (p.vs[1] == 0 ? 1u : p.H) * p.Skv * p.D * 2.0 * 1e-6;
+}
+
+double fwd_w64_predict_us(const FwdParams& p) {
+    const W64Cost& c = kW64Cost[p.D == 64 ? 0 : 1][p.causal ? 1 : 0];
+    const uint64_t nqb = (p.Sq + 255) / 256, items = (uint64_t)p.B * p.H * nqb, T = (p.Skv + 63) / 64;
+    const uint64_t G = w64_grid(p);
+    double segs, steps, fold = 0.0;
+    if (p.causal) {
+        const uint64_t jobs = (uint64_t)p.B * p.H * ((nqb + 1) / 2), rounds = (jobs + G - 1) / G;
+        uint64_t longest = 0;  // tile steps of the longest mirrored pair (j, nqb - 1 - j)
+        for (uint64_t j = 0; j < (nqb + 1) / 2; ++j) {
+            const uint64_t a = std::min<uint64_t>(T, 4 * j + 4), m = nqb - 1 - j, b2 = m != j ? std::min<uint64_t>(T, 4 * m + 4) : 0;
+            longest = std::max(longest, a + b2);
+        }
+        segs = 2.0 * rounds;
+        steps = (double)(rounds * longest);
+    } else {
+        const uint64_t full = items / G, rem = items % G;
+        segs = (double)(full + (rem ? 1 : 0));
+        steps = (double)(full * T + (rem ? (rem * T + G - 1) / G : 0));
+        if (rem) fold = std::max((double)G / (double)rem - 1.0, 0.0);  // the folding workgroup reads the other parts one after the other
+    }
+    const double cast = (p.in_prec == P_BF16 && p.pv16) ? c.cast_a + 2.0 * route_v_megabytes(p) / c.cast_tbps : 0.0;
+    return c.t0 + cast + segs * c.c_seg + steps * c.t_step + fold * c.c_fold;
+}
+
+double fwd_16_predict_us(const FwdParams& p) {
+    const R128Cost& c = kR128Cost[p.D == 64 ? 0 : 1][p.causal ? 1 : 0];
+    const uint64_t cus = (uint64_t)w64_cu_count();
+    const uint64_t nqb = (p.Sq + 127) / 128, items = (uint64_t)p.B * p.H * nqb, T = (p.Skv + 63) / 64;
+    const uint32_t R = (p.D == 128 && !p.causal) ? 3u : 2u;  // (32-key tiles at head_dim 128: three resident workgroups)
+    const double fr[4] = {0.0, 1.0, c.f2, c.f3};
+    const double tau1 = (p.in_prec == P_BF16 && p.pv16) ? c.tau1 : c.tau1 * c.g16;
+    const FwdSplitPlan plan = fwd_16_split_plan(p);
+    const uint64_t k = plan.nsplit > 1 ? plan.nsplit : 1;
+    const double n = (double)(items * k) / (double)cus;
+    double body;
+    if (p.causal) {
+        uint64_t tot = 0, longest = 0;
+        for (uint64_t qb = 0; qb < nqb; ++qb) {
+            const uint64_t len = std::min<uint64_t>(T, (qb * 128 + 128 + 63) / 64);
+            tot += len;
+            longest = std::max(longest, len);
+        }
+        tot *= (uint64_t)p.B * p.H;
+        if (n <= (double)R) {
+            const int r = std::max(1, (int)std::ceil(n));
+            body = c.c_item + (double)longest * tau1 * fr[r];
+        } else {
+            const double thr = (double)tot / (double)cus * tau1 * fr[R] / R + n * c.c_item / R;
+            body = std::max(thr + c.c_tail * (double)longest * tau1, c.c_item + (double)longest * tau1 * fr[R]);
+        }
+    } else {
+        const double L = (double)T / (double)k;
+        const uint64_t full = (uint64_t)(n / R);
+        const int rest = (int)std::ceil(n - (double)(full * R) - 1e-9);
+        body = (double)full * (c.c_item + L * tau1 * fr[R]) + (rest > 0 ? c.c_item + L * tau1 * fr[rest] : 0.0) + (k > 1 ? c.c_tail * (double)k : 0.0);
+    }
+    const bool cast_on = p.in_prec == P_BF16 && p.pv16 && route_v_megabytes(p) * 1e6 >= (double)((size_t)16 << 20) && p.Sq >= 1024;  // (runtime.hip's rule)
+    const double cast = cast_on ? c.cast_a + 2.0 * route_v_megabytes(p) / c.cast_tbps : 0.0;
+    return c.t0 + cast + body;
+}
+
 bool fwd_w64_supported(const FwdParams& p) {
     if (tuning().no_w64.load(std::memory_order_relaxed) || !fwd_16_supported(p)) return false;
     if ((p.D != 128 && p.D != 64) || (p.mask_kind != MK_NONE && p.mask_kind != MK_WINDOW && p.mask_kind != MK_BOOL)) return false;
@@ -318,80 +411,21 @@ bool fwd_w64_supported(const FwdParams& p) {
     // the 128-row kernel; any Skv >= 64 works (a partial last key tile runs the masking variant of the tile body)
     if (p.Skv < 64 || p.Sq < 256 || (p.Sq % 256 != 0 && p.Sq < 1024)) return false;
     if (p.out_prec != P_FP32 && p.out_prec != p.in_prec) return false;
-    // Enough parallel work for one workgroup per CU, else the 128-row kernel (2-3 resident workgroups, finer items)
-    // is faster.  Same-box medians, us, w64 / 128-row: causal B4 H16 S1024 (128 jobs) 53 / 46, B1 H16 S2048 (64) 70 / 53,
-    // B1 H8 S4096 (64) 112 / 96, B1 H8 S8192 (128) 213 / 214, B2 H24 S2048 (192) 85 / 98, B8 H16 S1024 (256) 61 / 85;
-    // non-causal B1 H24 S1024 (6 tile steps per CU) 38 / 32, B1 H4 S4096 (16 per CU) 54 / 75.  UMFA_FORCE_W64=1 lifts it
-    // (parity tests on small shapes).
+    // Which of the two structures?  A cost model (below: fwd_w64_predict_us / fwd_16_predict_us), not a rule per regime: predicted
+    // microseconds of THIS launch on each kernel from its schedule -- rounds, tile steps per workgroup, segments, folds, the V cast pass --
+    // with per-(head_dim, causal) constants fitted to ~1100 measured random launches (tools/fit_route_model.py, profiles/r5/routing_*.jsonl).
+    // Rounds 3-4 had ~35 thresholds here, each fitted to the regime in which it was found; on the same records the model's choice is
+    // within 5 % of the faster kernel more often than theirs was (the fit script prints both).  force_w64 lifts it (parity tests on
+    // small shapes).
     if (!tuning().force_w64.load(std::memory_order_relaxed)) {
-        const uint64_t cus = (uint64_t)w64_cu_count();
-        const uint64_t nqb = (p.Sq + 255) / 256;
-        // bf16 operands with the fp16 P V product: this kernel needs the fp16 image of V (a cast pre-pass: two more passes over V), and with
-        // nqb q-blocks per head the pass costs ~1 / nqb of the kernel's own time.  The 128-row kernel converts V in place in LDS for ~12 %.
-        // Graph-replayed us, this kernel + pass / 128-row kernel (profiles/r4/small_nqb_probe.jsonl): Sq 256: 444 / 353, 30 / 22, 254 / 201 (D 64);
-        // Sq 512: 331 / 327, 66 / 54, 40 / 31; Sq 768: 131 / 125, causal 54 / 51; Sq 1024: 49 / 51.
-        // Sq 1024 ... 2048 (gate_probe.jsonl): head_dim 128, whole blocks 1.04-1.22 x the 128-row kernel; ragged Sq 1100 0.81 x; causal with an odd
-        // number of q-blocks (Sq 1280: the middle block has no mirror) 0.89 x; head_dim 64 at Sq 1024 0.96-0.99 x
-        // Long key ranges shift it (random-size audit, routing_random_bf16_before.jsonl): with 64 or more key tiles per item this kernel's lead over the
-        // 128-row kernel is 1.4 x and pays for the pass from three q-blocks on -- B8 H5 Sq768 Skv8192 148 against 182 us, head_dim 64 B2 H12 Sq1536
-        // Skv8192 104 against 147
-        const bool long_keys = !p.causal && (p.Skv + 63) / 64 >= 64;
-        if (p.in_prec == P_BF16 && p.pv16) {
-            if (p.Sq < 768 || (p.Sq < 1024 && !(long_keys && p.D == 128))) return false;
-            if (p.Sq < 2048 && (p.Sq % 256 != 0 || (p.D == 64 && !(long_keys && p.Sq >= 1024)) || (p.causal && (nqb & 1)))) return false;
-        }
-        // (causal with an odd, small number of q-blocks -- the middle block has no mirror, its job is half as long as the others -- for every operand type:
-        // fp16 B4 H32 S1280 104 us against 90 on the 128-row kernel)
-        if (p.causal && !w64_is_window(p) && (nqb & 1) && nqb < 8) return false;
-        // (key ranges of a few tiles: an item is mostly prologue and output -- fp16 B2 H128 Sq3072 Skv256, 12 whole rounds: 205 us against 186; head_dim 64
-        // B8 H12 Sq2048 Skv77 29.0 / 23.4)
-        if (!w64_is_window(p) && (p.Skv + 63) / 64 < (p.D == 64 ? 16u : 8u)) return false;  // (head_dim 64, 8 tiles, nine whole rounds: 123 / 112)
         if (w64_is_window(p)) {
-            // the band's tile steps are what there is to share (thresholds of the unmasked kernel: cut items need 10 steps per CU)
+            // windows: the band's tile steps are what there is to share; no measurements of both structures over random windows exist, so
+            // the one rule of round 3 stays (cut items need 10 steps per CU)
+            const uint64_t cus = (uint64_t)w64_cu_count(), nqb = (p.Sq + 255) / 256;
             const uint64_t items = (uint64_t)p.B * p.H * nqb, steps = items * w64_tiles_per_item(p);
             if (items % cus != 0 && steps < cus * 10) return false;
-        } else if (p.D == 64) {
-            // half the MFMA time per tile step, the same prologue / drain / fold: the break-even sits higher.  us, w64 / 128-row
-            // (profiles/r3/d64_w64_vs_128row.jsonl): causal 160 jobs 31.1 / 27.6, 192 jobs 45.9 / 46.6, 256 jobs 32.4 / 36.4,
-            // 512 jobs 91.7 / 107; non-causal cut items 10 steps per CU 27.2 / 23.4, 12: 27.0 / 23.6, 16: 30.4 / 30.0,
-            // 96: 109 / 122; whole rounds B8 H16 S1024 42.1 / 46.2
-            const uint64_t items = (uint64_t)p.B * p.H * nqb, steps = items * ((p.Skv + 63) / 64);
-            // (round 4, with the V cast pass in the launch: 24 steps per CU -- B1 H16 S2048: 34.5 against 31.4 us on the 128-row kernel)
-            // (causal, bf16 with the cast pass: 1.5 jobs per CU -- few_items_probe_causal.jsonl: 192 jobs 61.0 / 49.9 us at S 2048, 90.5 / 90.2 at S 4096)
-            // (causal jobs are whole -- no cut: a last round that is mostly empty is paid in full.  More than a quarter of the rounds' slots empty and
-            // the 128-row kernel wins at head_dim 64: B1 H34 S8192 (2.1 rounds) 442 against 407 us, fp16 B8 H12 S3072 (2.25) 196 / 166, B1 H32 S6144 (1.5) 235 / 223)
-            if (p.causal) {
-                const uint64_t jobs = (uint64_t)p.B * p.H * ((nqb + 1) / 2), rounds = (jobs + cus - 1) / cus;
-                if (rounds >= 2 && rounds * cus * 4 > jobs * 5) return false;  // (a single partly filled round is fine: B4 H3 S8192, 192 jobs, 151 us here / 200)
-                if ((nqb & 1) && nqb < 16) return false;                        // (odd q-block counts: the unpaired middle block -- B8 H16 S2304 176 / 148)
-            }
-            // (second pass: long jobs amortise the pass and the prologues -- 240 jobs of 24 + 24 q-blocks (S 6144) 127 us here against 168; so: 1.5 jobs
-            // per CU, or 0.9 per CU, or 0.75 per CU with twenty or more q-blocks per head)
-            const uint64_t cjobs = (uint64_t)p.B * p.H * ((nqb + 1) / 2);
-            const bool c_ok = !(p.in_prec == P_BF16 && p.pv16) ? cjobs * 4 >= cus * 3 : (cjobs * 4 >= cus * 6 || cjobs * 10 >= cus * 9 || (nqb >= 20 && cjobs * 4 >= cus * 3));
-            if (p.causal ? !c_ok : (items % cus != 0 && (steps < cus * 20 || (p.Skv + 63) / 64 < 32 || (items > cus && (p.Skv + 63) / 64 < 40)))) return false;  // (20: fp16 B2 H10 S2048 37.6 here / 39.7; a remainder of SHORT items behind whole rounds: fp16 B4 H10 S2304 (36 tiles) 78 / 70 -- long ones win: B4 H6 Sq3072 Skv8192 183 / 221)  // (fp16 operands too: routing_sweep_fp16.jsonl, B1 H16 S2048 30.1 against 26.9 us; cut items of fewer than 32 tiles: fp16 B8 H8 S1280 47.4 / 42.1)
-        } else if (p.causal) {
-            if ((uint64_t)p.B * p.H * ((nqb + 1) / 2) * 8 < cus * 5) return false;  // 160 jobs: 78 / 85, 126 / 150, 217 / 258 us
-            // (whole jobs, no cut: from the second round on a mostly empty last round is paid in full -- B1 H64 S2304, 320 jobs = 1.25 rounds: 171 us
-            // against 140 on the 128-row kernel)
-            const uint64_t jobs = (uint64_t)p.B * p.H * ((nqb + 1) / 2), rounds = (jobs + cus - 1) / cus;
-            if (rounds >= 2 && rounds * cus * 2 > jobs * 3) return false;
-        } else {
-            // whole rounds (every workgroup one or more complete items, nothing to fold) win at any size: B1 H256 S256
-            // 19 / 22 us, B1 H128 S512 27 / 32; cut items need 10 tile steps per CU, 8 with long key ranges
-            // (B1 H32 S1024: 35 / 33, B1 H8 S2048: 39 / 44, B1 H40 S1024: 44 / 46, B1 H96 S512: 35 / 30)
-            const uint64_t items = (uint64_t)p.B * p.H * nqb, steps = items * ((p.Skv + 63) / 64);
-            // (round 4, bf16 operands with the V cast pass in the launch: 12 steps per CU -- B1 H8 S2048, 8 per CU: 41.8 against 35.3 us)
-            // (fp16 operands, no pass, lose the same launches by 7 %: routing_sweep_fp16.jsonl -- one threshold for both)
-            // (second pass, random-size audit: 10, not 12 -- B8 H1 S2304, 10.1 steps per CU: 41 us here against 50 on the 128-row kernel (fp16), 45 / 48 (bf16))
-            // (not when the launch runs WHOLE items on `items` workgroups (w64_grid): nothing is cut then -- fp16 B8 H6 S768, 144 items of 12 tiles: 26.5 us
-            // here against 30.3)
-            const bool whole = items < cus && items * 2 > cus && 2 * ((p.Skv + 63) / 64) * (cus - items) < 35 * cus;  // (as w64_grid decides)
-            if (!whole && items % cus != 0 && steps < cus * 10) return false;
-
-            // short key ranges (fewer than 16 tiles per item): a cut item is a few tiles and a fold -- B1 H24 Sq4096 Skv512 (8 tiles, 12 steps per CU)
-            // 40.0 us fp16 / 43.0 bf16 against 36.5 / 41.6 on the 128-row kernel
-            if (!whole && items % cus != 0 && (p.Skv + 63) / 64 < 16 && steps < cus * 24) return false;
+        } else if (!(fwd_w64_predict_us(p) < fwd_16_predict_us(p))) {
+            return false;
         }
     }
     return true;
@@ -481,7 +515,6 @@ hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cn
         wp.mk_bits = p.mk_bits; wp.mk_list = p.mk_list; wp.mk_cnt = p.mk_cnt;
         wp.mk_bs = p.mk_bs; wp.mk_hs = p.mk_hs; wp.mk_nrb64 = p.mk_nrb64;
         wp.mk_prefix = p.mk_prefix;
-        if (wp.n_items % w64_grid(p) != 0 && !p.mk_prefix) return hipErrorInvalidValue;
         // the max chain, unless the mask has no row dimension (key padding: a listed tile holds a key for every row, the lazy bodies are as safe as
         // without a mask); with one, which rows have keys in a segment is not arithmetic
         if (p.ms[2] != 0 || tuning().no_w64_mask_lazy.load(std::memory_order_relaxed)) wp.lazy = 0;

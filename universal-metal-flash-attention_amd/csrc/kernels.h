@@ -58,6 +58,9 @@ struct FwdW64Plan {
 };
 bool fwd_w64_supported(const FwdParams& p);
 uint32_t fwd_w64_grid(const FwdParams& p);  // workgroups launch_fwd_w64 will start for this call
+// the dispatcher's cost model (fa_fwd16_w64.hip): predicted microseconds of this launch on the one-workgroup-per-CU kernel / the 128-row kernel
+double fwd_w64_predict_us(const FwdParams& p);
+double fwd_16_predict_us(const FwdParams& p);
 FwdW64Plan fwd_w64_plan(const FwdParams& p);
 hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cnt, hipStream_t stream, const char** name);
 
@@ -149,6 +152,9 @@ hipError_t launch_fwd_w64_i8(const FwdParams& p, const QuantViews& v, float* par
 // bool mask -> per-lane bit words + visited-tile lists for fa_fwd16_w64's MASKT instantiations (fa_aux.hip); fills p.mk_*
 size_t mask_pack_bytes(const FwdParams& p);
 hipError_t launch_mask_pack(FwdParams& p, void* scratch, hipStream_t stream);
+// the V cast pass and the mask re-pack as ONE launch (the pack's workgroups behind the cast's), then the list kernel
+hipError_t launch_cast_rows_and_mask_pack(const void* src, const int64_t* strides, void* dst, uint32_t B, uint32_t H, uint32_t S, uint32_t D,
+                                          uint32_t* hdr, FwdParams& p, void* mask_scratch, hipStream_t stream);
 // mask tile flags for fa_fwd16's tile early-exit (fa_aux.hip); launch_mask_flags fills p.mask_flags / mf_*
 size_t mask_flags_bytes(const FwdParams& p);
 bool mask_flags_worthwhile(const FwdParams& p);

@@ -92,13 +92,16 @@ hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p,
     // the rotated K / Q of the fused-RoPE entry).  A broadcast batch / head dimension of V (the zero-copy GQA views: stride 0) stays one:
     // its slab is cast once.  false with e == hipSuccess: no block (the pool may not grow while the stream is capturing) -- the caller
     // takes a kernel that converts V itself.
-    auto cast_v = [&](FwdParams& q) -> bool {
+    // mask_scratch != NULL: the bool mask of `q` is re-packed for the one-wave-per-SIMD kernel in the same launch (fills q.mk_*)
+    auto cast_v = [&](FwdParams& q, void* mask_scratch = nullptr) -> bool {
         const uint32_t vB = p.vs[0] == 0 ? 1u : p.B, vH = p.vs[1] == 0 ? 1u : p.H;
         const size_t slabs = (size_t)vB * vH, vbytes = slabs * p.Skv * p.D * 2;
         char* blk = sc.ensure_v16(slabs, vbytes, stream);
         if (!blk) return false;
         void* v16 = blk + sc.v16_cnt_bytes;
-        if ((e = launch_cast_rows_bf16_to_f16(p.v, p.vs, v16, vB, vH, p.Skv, p.D, (uint32_t*)blk, stream)) != hipSuccess) return false;
+        e = mask_scratch ? launch_cast_rows_and_mask_pack(p.v, p.vs, v16, vB, vH, p.Skv, p.D, (uint32_t*)blk, q, mask_scratch, stream)
+                         : launch_cast_rows_bf16_to_f16(p.v, p.vs, v16, vB, vH, p.Skv, p.D, (uint32_t*)blk, stream);
+        if (e != hipSuccess) return false;
         q.v = v16;
         q.vs[0] = p.vs[0] == 0 ? 0 : (int64_t)vH * p.Skv * p.D; q.vs[1] = p.vs[1] == 0 ? 0 : (int64_t)p.Skv * p.D; q.vs[2] = p.D; q.vs[3] = 1;
         q.vsc = (const float*)blk;
@@ -111,20 +114,23 @@ hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p,
         // the one-wave-per-SIMD kernels take V as the dense fp16 image.  (Converting inside these kernels was built and measured: +15 %,
         // every workgroup re-converts every tile; the 128-row kernel below does convert in-kernel.)
         FwdParams pw = pv;
-        bool ok = !pv.pv16 || cast_v(pw);
-        if (!ok && e != hipSuccess) return e;
-        void* mk = nullptr;
-        if (ok && pw.mask_kind == MK_BOOL) {
-            // bool mask tensor on the one-wave-per-SIMD structure: one pre-pass re-packs it into per-lane bit words, per-wave tile
-            // classes and the visited-tile list of every 256-row block (fa_aux.hip mask_pack_kernel); the kernel then never stages
-            // a tile no row of the block attends to and reads no mask bytes at all
-            mk = sc.mflags.ensure(mask_pack_bytes(pw), stream);
-            ok = mk != nullptr;
-        }
+        // bool mask tensor on the one-wave-per-SIMD structure: one pre-pass re-packs it into per-lane bit words, per-wave tile classes
+        // and the visited-tile list of every 256-row block (fa_aux.hip mask_pack_kernel); the kernel then never stages a tile no row
+        // of the block attends to and reads no mask bytes at all.  Every block this family needs is asked for BEFORE anything is
+        // launched: a call that cannot have them (capture without a warm-up) goes to the 128-row kernel untouched.
+        void* mk = pw.mask_kind == MK_BOOL ? sc.mflags.ensure(mask_pack_bytes(pw), stream) : nullptr;
+        bool ok = pw.mask_kind != MK_BOOL || mk != nullptr;
         const FwdW64Plan plan = fwd_w64_plan(pw);
         char* w64 = ok ? sc.ensure_w64(plan.cnt_bytes, plan.buf_bytes, stream) : nullptr;
-        if (ok && w64) {
-            if (mk && (e = launch_mask_pack(pw, mk, stream)) != hipSuccess) return e;
+        ok = ok && w64 != nullptr;
+        bool packed = false;
+        if (ok && pv.pv16) {
+            ok = cast_v(pw, mk);  // (with a mask: the re-pack rides in the cast's launch)
+            if (!ok && e != hipSuccess) return e;
+            packed = ok && mk != nullptr;
+        }
+        if (ok) {
+            if (mk && !packed && (e = launch_mask_pack(pw, mk, stream)) != hipSuccess) return e;
             e = launch_fwd_w64(pw, (float*)(w64 + sc.w64_cnt_bytes), (uint32_t*)w64, stream, &name);
             done = true;
         } else if (p.rope_cos || !fwd_16_supported(p)) {
