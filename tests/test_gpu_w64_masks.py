@@ -67,18 +67,19 @@ KINDS = ["random_per_head", "random_2d", "padding", "blockdiag", "all_open", "em
 @pytest.mark.parametrize("kind", KINDS)
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("shape", [(2, 2, 512, 512), (1, 3, 1280, 777)])
-def test_w64_mask_tensor_vs_oracle(kind, dt, shape, umfa_opts):
+@pytest.mark.parametrize("D", [128, 64])  # (head_dim 64: round 5)
+def test_w64_mask_tensor_vs_oracle(kind, dt, shape, D, umfa_opts):
     import umfa_torch
     umfa_opts(force_w64=1)
     B, H, Sq, Skv = shape
     torch.manual_seed(Sq + Skv)
-    q = torch.randn(B, H, Sq, 128, device="cuda", dtype=dt)
-    k = torch.randn(B, H, Skv, 128, device="cuda", dtype=dt)
-    v = torch.randn(B, H, Skv, 128, device="cuda", dtype=dt)
+    q = torch.randn(B, H, Sq, D, device="cuda", dtype=dt)
+    k = torch.randn(B, H, Skv, D, device="cuda", dtype=dt)
+    v = torch.randn(B, H, Skv, D, device="cuda", dtype=dt)
     m = _mask(kind, B, H, Sq, Skv, seed=Sq)
     o, lse = umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32, return_lse=True)
     kern = umfa_torch.last_kernel()
-    assert kern in ("fa_fwd16_w64<bf16,128,pv16,mask>", "fa_fwd16_w64<fp16,128,mask>"), kern
+    assert kern in (f"fa_fwd16_w64<bf16,{D},pv16,mask>", f"fa_fwd16_w64<fp16,{D},mask>"), kern
     mfull = m.expand(B, H, Sq, Skv) if m.dim() == 4 else m.expand(Sq, Skv)
     ref, ref_lse = _oracle().sdpa_forward(npy(q), npy(k), npy(v), mask=np.ascontiguousarray(mfull.cpu().numpy()),
                                           mask_type=_oracle().MASK_BOOL, return_lse=True)
@@ -103,21 +104,22 @@ def test_w64_mask_tensor_vs_oracle(kind, dt, shape, umfa_opts):
 
 @pytest.mark.parametrize("kind", ["random_per_head", "padding", "blockdiag", "empty_rows_and_blocks", "strided_view", "one_tile"])
 @pytest.mark.parametrize("shape,grid", [((2, 2, 512, 512), 3), ((2, 2, 512, 512), 5), ((1, 3, 1280, 777), 4), ((1, 3, 1280, 777), 7), ((1, 3, 1280, 777), 14)])
-def test_w64_mask_cut_blocks(kind, shape, grid, umfa_opts):
-    """more blocks than workgroups with a remainder: the last n % grid blocks are cut ALONG THEIR TILE LISTS into grid equal slices (the
-    running sums of their list lengths come from mask_prefix_kernel) and folded like the unmasked kernel's cut items.  Forced here with
+@pytest.mark.parametrize("D", [128, 64])
+def test_w64_mask_cut_blocks(kind, shape, grid, D, umfa_opts):
+    """more blocks than workgroups with a remainder: the last n % grid blocks are cut ALONG THEIR TILE LISTS into grid equal slices (every
+    workgroup scans the running sums of their list lengths itself) and folded like the unmasked kernel's cut items.  Forced here with
     the lab option w64_grid on small shapes; the FLUX-shape test below meets it by itself (384 blocks on 256 CUs)."""
     import umfa_torch
     B, H, Sq, Skv = shape
     torch.manual_seed(Sq + Skv + grid)
-    q = torch.randn(B, H, Sq, 128, device="cuda", dtype=torch.bfloat16)
-    k = torch.randn(B, H, Skv, 128, device="cuda", dtype=torch.bfloat16)
-    v = torch.randn(B, H, Skv, 128, device="cuda", dtype=torch.bfloat16)
+    q = torch.randn(B, H, Sq, D, device="cuda", dtype=torch.bfloat16)
+    k = torch.randn(B, H, Skv, D, device="cuda", dtype=torch.bfloat16)
+    v = torch.randn(B, H, Skv, D, device="cuda", dtype=torch.bfloat16)
     m = _mask(kind, B, H, Sq, Skv, seed=Sq + grid)
     umfa_opts(force_w64=1, w64_grid=grid)
     o, lse = umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32, return_lse=True)
     kern = umfa_torch.last_kernel()
-    assert kern == "fa_fwd16_w64<bf16,128,pv16,mask>", kern
+    assert kern == f"fa_fwd16_w64<bf16,{D},pv16,mask>", kern
     assert torch.equal(o, umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32))  # whoever folds: the same bits
     mfull = m.expand(B, H, Sq, Skv)
     ref, ref_lse = _oracle().sdpa_forward(npy(q), npy(k), npy(v), mask=np.ascontiguousarray(mfull.cpu().numpy()),
@@ -262,7 +264,7 @@ def test_w64_mask_few_blocks_key_padding(umfa_opts):
 
 
 def test_w64_mask_routing_gate(umfa_opts):
-    """few items (fewer 256-row blocks than CUs), additive masks, causal + mask, head_dim 64 and bf16 P V stay on the 128-row kernel"""
+    """few items (fewer 256-row blocks than CUs), additive masks, causal + mask and bf16 P V stay on the 128-row kernel"""
     import umfa_torch
     umfa_opts(force_w64=0)
     torch.manual_seed(1)
@@ -283,4 +285,7 @@ def test_w64_mask_routing_gate(umfa_opts):
         assert umfa_torch.last_kernel() == "fa_fwd16<bf16,128>"
     q6, k6, v6 = (torch.randn(1, 4, 512, 64, device="cuda", dtype=torch.bfloat16) for _ in range(3))
     umfa_torch.attention_forward(q6, k6, v6, mask=mb)
-    assert umfa_torch.last_kernel().startswith("fa_fwd16<")
+    assert umfa_torch.last_kernel() == "fa_fwd16_w64<bf16,64,pv16,mask>"  # (head_dim 64 has the mask instantiations since round 5; forced here)
+    umfa_opts(force_w64=0)
+    umfa_torch.attention_forward(q6, k6, v6, mask=mb)
+    assert umfa_torch.last_kernel().startswith("fa_fwd16<")  # 8 blocks: the gate

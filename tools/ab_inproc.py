@@ -37,6 +37,7 @@ class Lib:
         _ffi._check_error(self.lib.mfa_create_context(ctypes.byref(self.ctx)))
         for kv in filter(None, opts.split(",")):
             k_, v_ = kv.split("=")
+            v_ = v_.replace(";", ",")  # (a list value: its commas are written as semicolons here)
             self.lib.umfa_set_option.restype = ctypes.c_int
             rc = self.lib.umfa_set_option(self.ctx, k_.encode(), v_.encode())
             assert rc == 0, (name, kv, rc)

@@ -382,9 +382,9 @@ bool fwd_w64_supported(const FwdParams& p) {
     if (tuning().no_w64.load(std::memory_order_relaxed) || !fwd_16_supported(p)) return false;
     if ((p.D != 128 && p.D != 64) || (p.mask_kind != MK_NONE && p.mask_kind != MK_WINDOW && p.mask_kind != MK_BOOL)) return false;
     if (p.mask_kind == MK_BOOL) {
-        // bool mask tensors (MASKT instantiations): head_dim 128, the fp16-P-V families (bf16 operands by default, fp16 operands), no
+        // bool mask tensors (MASKT instantiations): head_dim 128 and (round 5) 64, the fp16-P-V families (bf16 operands by default, fp16 operands), no
         // causal flag / rotation on top; whole items per workgroup, so at least one item per CU
-        if (tuning().no_w64_mask.load(std::memory_order_relaxed) || !p.mask || p.D != 128 || p.causal || p.rope_cos) return false;
+        if (tuning().no_w64_mask.load(std::memory_order_relaxed) || !p.mask || (p.D != 128 && p.D != 64) || p.causal || p.rope_cos) return false;
         if (p.in_prec == P_BF16 && !p.pv16) return false;
         if (p.Skv < 64 || p.Sq < 256 || (p.Sq % 256 != 0 && p.Sq < 1024) || ((p.Skv + 63) / 64) > 1024u) return false;  // (a block's tile list sits in 4 KiB of LDS)
         if (p.out_prec != P_FP32 && p.out_prec != p.in_prec) return false;
@@ -529,10 +529,10 @@ hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cn
     // and at head_dim 128 <operand type, causal, rope>
 #define W64_FAMILY(FAM, T16, HAS_ROPE)                                                                                         \
     do {                                                                                                                       \
-        if constexpr (HAS_ROPE == 2) {  /* families with mask-tensor instantiations */                                        \
+        if constexpr (HAS_ROPE >= 2) {  /* families with mask-tensor instantiations (3: head_dim 64, no fused rotation) */      \
             if (maskt) return fp32o ? launch_w64_kernel(FAM<float, false, false, false, true>, p, wp, stream) : launch_w64_kernel(FAM<T16, false, false, false, true>, p, wp, stream); \
         }                                                                                                                      \
-        if constexpr (HAS_ROPE != 0) {                                                                                         \
+        if constexpr (HAS_ROPE == 1 || HAS_ROPE == 2) {                                                                        \
             if (rope) return p.causal ? launch_w64_kernel(FAM<T16, true, true>, p, wp, stream) : launch_w64_kernel(FAM<T16, false, true>, p, wp, stream); \
         }                                                                                                                      \
         if (window) return fp32o ? launch_w64_kernel(FAM<float, false, false, true>, p, wp, stream) : launch_w64_kernel(FAM<T16, false, false, true>, p, wp, stream); \
@@ -548,12 +548,14 @@ hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cn
          {"fa_fwd16_w64<fp16,64>", "fa_fwd16_w64<fp16,64,rope>", "fa_fwd16_w64<fp16,64,window>"}}};
     if (p.D == 64 && rope) return hipErrorNotSupported;
     const int fam = p.in_prec == P_BF16 ? (p.pv16 ? 1 : 0) : 2;
-    if (maskt && (fam == 0 || p.D != 128)) return hipErrorNotSupported;
-    *name = maskt ? (fam == 1 ? "fa_fwd16_w64<bf16,128,pv16,mask>" : "fa_fwd16_w64<fp16,128,mask>") : names[fam][p.D == 64 ? 1 : 0][rope ? 1 : window ? 2 : 0];
+    if (maskt && fam == 0) return hipErrorNotSupported;
+    *name = maskt ? (p.D == 64 ? (fam == 1 ? "fa_fwd16_w64<bf16,64,pv16,mask>" : "fa_fwd16_w64<fp16,64,mask>")
+                               : (fam == 1 ? "fa_fwd16_w64<bf16,128,pv16,mask>" : "fa_fwd16_w64<fp16,128,mask>"))
+                  : names[fam][p.D == 64 ? 1 : 0][rope ? 1 : window ? 2 : 0];
     if (p.D == 64) {
         if (fam == 0) W64_FAMILY(fa_fwd16_w64d64_bf16, __bf16, 0);
-        if (fam == 1) W64_FAMILY(fa_fwd16_w64d64_bf16pv16, __bf16, 0);
-        W64_FAMILY(fa_fwd16_w64d64_f16, _Float16, 0);
+        if (fam == 1) W64_FAMILY(fa_fwd16_w64d64_bf16pv16, __bf16, 3);
+        W64_FAMILY(fa_fwd16_w64d64_f16, _Float16, 3);
     }
     if (fam == 0) W64_FAMILY(fa_fwd16_w64_bf16, __bf16, 1);
     if (fam == 1) W64_FAMILY(fa_fwd16_w64_bf16pv16, __bf16, 2);
