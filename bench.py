@@ -523,6 +523,42 @@ def run_rank(args) -> None:
             del q4, k4, v4, do4, o4, l4
         except Exception as exc:  # noqa: BLE001
             configs["cfg4_int8_bwd"] = {"error": repr(exc)}
+        # config 4's quantised forward WITH a mask, the way the reference's quantised entry takes one: a dense fp32 additive
+        # [B, H, Sq, Skv] tensor (MFABridge+Quantized.swift:227-358 -- 4.3 GB at this size: the call is bound by reading it once).
+        # Block-diagonal, four documents of 2048 tokens; rel against the oracle's quantised restatement with the same mask on the
+        # rows of four 64-row quantisation blocks of two heads.
+        try:
+            S4 = 8192
+            q4, k4, v4 = (torch.randn(1, 16, S4, D, device=dev, dtype=torch.bfloat16) for _ in range(3))
+            i4 = torch.arange(S4, device=dev)
+            mb = ((i4[:, None] // 2048) == (i4[None, :] // 2048))
+            m32 = torch.zeros(1, 16, S4, S4, device=dev, dtype=torch.float32).masked_fill_(~mb[None, None], float("-inf"))
+            out4 = torch.empty(1, 16, S4, D, device=dev, dtype=torch.float32)
+            lse4 = torch.empty(16 * S4, device=dev, dtype=torch.float32)
+            fn4 = lambda: umfa_torch.quantized_attention_forward_stream(q4, k4, v4, mask=m32, out=out4, lse=lse4)  # noqa: E731
+            tm = graph_ms(fn4, 6, warmup=2)
+            kn4 = umfa_torch.last_kernel()
+            fn4()
+            torch.cuda.synchronize()
+            from oracle import oracle as _orc4
+            import numpy as _np4
+            rows4 = _np4.concatenate([_np4.arange(b0, b0 + 64) for b0 in (0, 2048 + 640, 4096 + 1984, 8192 - 64)])
+            rel4 = 0.0
+            for h4 in (0, 9):
+                rq = _np4.ascontiguousarray(_par.bits(q4[:, h4:h4 + 1])[:, :, rows4])
+                mrow = _np4.ascontiguousarray(m32[0, h4][torch.as_tensor(rows4, device=dev)].cpu().numpy())[None, None]
+                ref4, _ = _orc4.quantized_forward(rq, _par.bits(k4[:, h4:h4 + 1]), _par.bits(v4[:, h4:h4 + 1]), mask=mrow)
+                got4 = out4[:, h4:h4 + 1][:, :, torch.as_tensor(rows4, device=dev)].cpu().numpy()
+                rel4 = max(rel4, float(_np4.abs(got4 - ref4).max() / _np4.abs(ref4).max()))
+            f4m = 4.0 * 16 * S4 * S4 * D
+            configs["cfg4_int8_mask_blockdiag"] = {"ms": round(tm, 4), "kernel": kn4, "visible_fraction": 0.25,
+                                                   "tflops_of_visible_work": round(f4m * 0.25 / tm / 1e9, 1),
+                                                   "mask_bytes": int(m32.numel() * 4), "mask_read_tbps_if_read_once": round(m32.numel() * 4 / tm / 1e9, 2),
+                                                   "rel_vs_quantised_oracle": rel4,
+                                                   "mask": "fp32 additive [1,16,8192,8192] (0 / -inf, four documents of 2048): the reference ABI's form"}
+            del q4, k4, v4, m32, out4, lse4
+        except Exception as exc:  # noqa: BLE001
+            configs["cfg4_int8_mask_blockdiag"] = {"error": repr(exc)}
         extra["configs"] = configs
         try:
             extra["int8"] = bench_int8(torch, umfa_torch, event_ms, med, graph_ms)

@@ -407,6 +407,10 @@ struct I8FwdParams {
     float* o;
     float* lse;
     const float* mask;  // fp32 additive [B,H,Sq,Skv] or NULL
+    // tile flags of the mask (fa_aux.hip mask_flags_kernel, as for fa_fwd16): one byte per (b, h, 32-row block, 64-key tile) -- 1: every element
+    // masked (the wave skips the tile), 2: every element attends with a zero term (the tile runs without reading the mask), 0: mixed
+    const uint8_t* mask_flags;
+    uint32_t mf_nrb, mf_ntiles;
     uint32_t B, H, Sq, Skv, D;
     uint32_t nqblk, nkblk;
     float scale;
@@ -519,6 +523,14 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
     float m = -INFINITY, l = 0.0f;
     const int tr_qq = (lane >> 2) & 3, tr_pp = lane & 3, tr_g1 = (lane >> 4) & 1;
     const int64_t mrow = HAS_MASK ? ((int64_t)bh * p.Sq + q_row) * p.Skv : 0;
+    const bool mvec = HAS_MASK && (p.Skv & 3u) == 0 && ((uintptr_t)p.mask & 15) == 0;  // aligned rows: four keys per load
+    // The reference ABI hands the quantised entry a DENSE fp32 [B,H,Sq,Skv] mask (MFABridge+Quantized.swift:227-358): 4.3 GB at config 4.
+    // Read per score it came in at 0.76-0.96 TB/s (each lane its own row: a quarter of every sector used) and the masked call took 10-14 x
+    // the unmasked one.  The tile-flag pre-pass reads it ONCE at streaming rate; a 0 / -inf mask then costs this kernel no mask read at all.
+    const uint8_t* mf_row = nullptr;
+    int mf_reg = 0;
+    if (HAS_MASK && p.mask_flags && BN == 64 && wave_q0 / 32 < p.mf_nrb)
+        mf_row = p.mask_flags + ((uint64_t)bh * p.mf_nrb + wave_q0 / 32) * p.mf_ntiles;
 
     stage_load(0);
     stage_write(0);
@@ -531,7 +543,16 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
         const char* Kt = Kbuf + cur * KT_BYTES;
         const char* Vt = Vbuf + cur * VT_BYTES;
         const uint32_t key_base = t * BN;
-        const bool active = !CAUSAL || key_base <= wave_q0 + 31;
+        bool active = !CAUSAL || key_base <= wave_q0 + 31;
+        int mflag = 0;
+        if (HAS_MASK && mf_row) {
+            if (t == 0 || (t & 63) == 0) {
+                const uint32_t t64 = t & ~63u;
+                mf_reg = t64 + lane < p.mf_ntiles ? (int)mf_row[t64 + lane] : 0;
+            }
+            mflag = __builtin_amdgcn_readlane(mf_reg, (int)(t & 63));
+            active = active && mflag != 1;
+        }
         if (active) {
             const float ct = sq * p.k_scale[bh * p.nkblk + key_base / QBLK];  // dequant * softmax scale * log2e, >= 0
             i32x16 s[NKB];
@@ -553,17 +574,39 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
                 // additive mask: scores go to the log2 domain first
                 float tv[NKB][16];
                 float mx = -INFINITY;
+                if (mvec) {
+                    // registers 4g .. 4g+3 of a 32-key block are keys 8g + 4hi + 0..3: ONE 16-byte load of the mask row (round 5; as sixteen
+                    // 4-byte loads per block, each touching 64 different cache lines, the reference ABI's dense fp32 mask -- 4.3 GB at
+                    // config 4 -- came in at 0.76 TB/s and the masked call took 14 x the unmasked one)
+#pragma unroll
+                    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const uint32_t key0 = key_base + 32 * kb + 8 * g + 4 * hi;
+                            f32x4 w = {0.0f, 0.0f, 0.0f, 0.0f};
+                            if (mflag != 2 && key0 < p.Skv && q_row < p.Sq) w = __builtin_nontemporal_load((const f32x4*)(p.mask + mrow + key0));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int r = 4 * g + e;
+                                float x = __builtin_fmaf(w[e], UMFA_LOG2E, (float)s[kb][r] * ct);
+                                if (edge && (key0 + e >= p.Skv || (CAUSAL && key0 + e > q_row))) x = -INFINITY;
+                                tv[kb][r] = x;
+                                mx = fmaxf(mx, x);
+                            }
+                        }
+                } else {
 #pragma unroll
                 for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const uint32_t key = key_base + 32 * kb + acc_row(r, hi);
                         float x = (float)s[kb][r] * ct;
-                        if (key < p.Skv && q_row < p.Sq) x += p.mask[mrow + key] * UMFA_LOG2E;
+                        if (mflag != 2 && key < p.Skv && q_row < p.Sq) x += p.mask[mrow + key] * UMFA_LOG2E;
                         if (edge && (key >= p.Skv || (CAUSAL && key > q_row))) x = -INFINITY;
                         tv[kb][r] = x;
                         mx = fmaxf(mx, x);
                     }
+                }
                 mx = fmaxf(mx, xor32(mx));
                 m_new = fmaxf(m, mx);
                 m_use = m_new == -INFINITY ? 0.0f : m_new;
@@ -652,7 +695,7 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline uint32_t dp_of(uint32_t D) { return D <= 64 ? 64 : D <= 128 ? 128 : 256; }
 
 struct WsLayout {
-    size_t q8, k8, v16, sq, sk, sv, f32q, f32k, f32v, total;
+    size_t q8, k8, v16, sq, sk, sv, f32q, f32k, f32v, mflags, total;
 };
 static WsLayout ws_layout(uint32_t B, uint32_t H, uint32_t Sq, uint32_t Skv, uint32_t D, bool want_f32) {
     const size_t BH = (size_t)B * H, DP = dp_of(D);
@@ -672,6 +715,7 @@ static WsLayout ws_layout(uint32_t B, uint32_t H, uint32_t Sq, uint32_t Skv, uin
         w.f32k = off; off = align256(off + BH * Skv * D * 4);
         w.f32v = off; off = align256(off + BH * Skv * D * 4);
     }
+    w.mflags = off; off = align256(off + BH * ((Sq + 31) / 32) * ((Skv + 63) / 64));  // tile flags of a mask (one byte per 32 x 64 tile)
     w.total = off;
     return w;
 }
@@ -792,6 +836,16 @@ hipError_t launch_quantized_fwd(const FwdParams& fp, int bits, int quant_mode, v
     p.q_scale = v.q_scale; p.k_scale = v.k_scale;
     p.o = (float*)fp.o; p.lse = fp.lse;
     p.mask = (const float*)fp.mask;
+    if (fp.mask && !tuning().no_mask_flags.load(std::memory_order_relaxed)) {
+        // the mask's tile flags (dense fp32 [B, H, Sq, Skv]): one streaming pass over it, into the workspace
+        FwdParams mp = fp;
+        mp.mask_kind = MK_F32;
+        mp.ms[0] = (int64_t)fp.H * fp.Sq * fp.Skv; mp.ms[1] = (int64_t)fp.Sq * fp.Skv; mp.ms[2] = fp.Skv; mp.ms[3] = 1;
+        uint8_t* fl = (uint8_t*)workspace + ws_layout(fp.B, fp.H, fp.Sq, fp.Skv, fp.D, false).mflags;
+        if (launch_mask_flags(mp, fl, stream) == hipSuccess && mp.mask_flags && mp.mf_bs == fp.H && mp.mf_hs == 1) {
+            p.mask_flags = mp.mask_flags; p.mf_nrb = mp.mf_nrb; p.mf_ntiles = mp.mf_ntiles;
+        }
+    }
     p.B = fp.B; p.H = fp.H; p.Sq = fp.Sq; p.Skv = fp.Skv; p.D = fp.D;
     p.nqblk = v.nqblk; p.nkblk = v.nkblk;
     p.scale = fp.scale;

@@ -243,8 +243,11 @@ def quantized_attention_forward_stream(q, k, v, *, scale=None, causal=False, mas
     assert out.dtype == torch.float32 and out.is_contiguous() and lse.dtype == torch.float32 and lse.numel() == B * H * Sq
     m32 = None
     if mask is not None:
-        m32 = torch.zeros((B, H, Sq, Skv), dtype=torch.float32, device=q.device)
-        m32 = (m32.masked_fill(~mask, float("-inf")) if mask.dtype == torch.bool else m32 + mask.float()).contiguous()
+        if mask.dtype == torch.float32 and tuple(mask.shape) == (B, H, Sq, Skv) and mask.is_contiguous():
+            m32 = mask  # already the ABI's form (dense fp32 additive): no copy -- at config 4 that tensor is 4.3 GB
+        else:
+            m32 = torch.zeros((B, H, Sq, Skv), dtype=torch.float32, device=q.device)
+            m32 = (m32.masked_fill(~mask, float("-inf")) if mask.dtype == torch.bool else m32 + mask.float()).contiguous()
     vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
     _check_error(_lib.umfa_quantized_forward_stream(
         context(), ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream), vp(q), vp(k), vp(v), vp(out),
