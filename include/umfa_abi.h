@@ -421,7 +421,11 @@ const char* umfa_last_kernel_name(mfa_context_t context);
  *                        fp16's subnormals: errors below 2^-39 of that largest value.
  *                        "0": the bf16 P V kernels throughout (8-bit P).
  *   "cast_two_pass"      "0" (default) | "1": tests -- the cast pre-pass as two launches (amax, then cast) whatever the slab size
- *                        (by default only slabs of more than CUs / 2 chunks of 64 rows take that form)
+ *                        (by default only slabs of more than 64 workgroups' worth of rows take that form)
+ *   "cast_wait_us"       "100" (default): in the one-launch form a workgroup of the cast pre-pass publishes its rows' amax and waits for
+ *                        the other workgroups of its (batch, KV head) slab; the wait is bounded by this many microseconds, after which
+ *                        the workgroup reads the whole slab for the amax itself (the same number) -- forward progress does not depend
+ *                        on the slab's workgroups being resident together (CU-masked streams, many streams).  "0": never wait (tests)
  * Returns MFA_ERROR_INVALID_ARGS for an unknown name or a value out of range.  Thread-safe; affects later launches. */
 mfa_error_t umfa_set_option(mfa_context_t context, const char* name, const char* value);
 

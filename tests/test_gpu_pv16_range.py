@@ -257,3 +257,27 @@ def test_broadcast_kv_heads_and_long_slabs():
         assert umfa_torch.last_kernel() == "fa_fwd16_w64<bf16,128,pv16>"
     refl = _oracle().sdpa_forward(bits(ql), bits(kl), bits(vl))
     assert torch.isfinite(ol).all() and _per_slab_err(ol.cpu().numpy(), refl) < NORTH_STAR
+
+
+@pytest.mark.parametrize("shape", [(1, 24, 4096, 128), (2, 16, 2300, 64), (2, 2, 16384, 128)])
+def test_cast_pass_workgroups_that_are_not_served_help_themselves(shape):
+    """The slab exchange of the cast pre-pass is a bounded wait (option cast_wait_us): a workgroup whose slab mates do not show up in time
+    -- they need not be resident: CU-masked streams, many streams at once -- reads the slab's amax itself.  With the bound at 0 every
+    workgroup that arrives before the last of its slab does so: same exponent, same fp16 image, bit-identical O; and the exchange words are
+    left clean for the next launch either way."""
+    import umfa_torch
+    B, H, S, D = shape
+    torch.manual_seed(43)
+    q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    v = _regime(v, "mixed")
+    v[0, 0, S - 1, D - 1] = -7.0e9
+    outs = []
+    for wait in (100, 0, 0, 100):
+        with umfa_torch.options(force_w64=1, cast_wait_us=wait):
+            outs.append(umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32))
+            assert "w64<bf16" in umfa_torch.last_kernel() and "pv16" in umfa_torch.last_kernel()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+    rows = slice(0, min(S, 512))
+    ref = _oracle().sdpa_forward(bits(q[:, :, rows].contiguous()), bits(k), bits(v))
+    assert _per_slab_err(outs[1][:, :, rows].cpu().numpy(), ref) < NORTH_STAR

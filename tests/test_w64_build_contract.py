@@ -58,7 +58,8 @@ def test_compiler_stays_in_the_lower_register_halves(asm):
     # + (round 4: pv_fp16 is the default bf16 arithmetic) its fused-rotation {causal, not} and window
     #   {fp32, bf16 O} forms at head_dim 128 and its window forms at head_dim 64
     # + bool mask tensors (MASKT): bf16-pv16 / fp16 x {fp32, 16-bit O} at head_dim 128
-    assert len(kernels) == 50, sorted(kernels)
+    # + (round 5) the same four at head_dim 64
+    assert len(kernels) == 54, sorted(kernels)
     for name, lines in kernels.items():
         in_asm, vmax, amax, n_mfma, loop_scratch = False, 0, 0, 0, 0
         mfma_seen = 0
@@ -98,7 +99,7 @@ def test_every_kernel_gets_512_registers(asm):
     nxt = [int(x) for x in re.findall(r"\.amdhsa_next_free_vgpr (\d+)", asm)]
     acc = [int(x) for x in re.findall(r"\.amdhsa_accum_offset (\d+)", asm)]
     # the hardware allocates in granules of 8 registers: 511 (clobbers name v254 / a254, the highest names hipcc does not reserve) is 512
-    assert len(nxt) == 50 and all((n + 7) // 8 * 8 == 512 for n in nxt), nxt
+    assert len(nxt) == 54 and all((n + 7) // 8 * 8 == 512 for n in nxt), nxt
     assert all(a == 256 for a in acc), acc
 
 

@@ -445,6 +445,7 @@ struct CastRowsArgs {
     _Float16* dst;
     uint32_t H, S, D8, chunks;
     uint32_t* hdr;
+    uint32_t wait_ticks;  // of the 100 MHz s_memtime clock
 };
 template <int U, bool FUSED>
 __device__ __forceinline__ void cast_rows_body(const CastRowsArgs& a, const uint32_t block) {
@@ -480,17 +481,33 @@ __device__ __forceinline__ void cast_rows_body(const CastRowsArgs& a, const uint
         if (threadIdx.x < 64) {
             // relaxed agent-scope accesses only (performed past the XCDs' L2s); the exchange carries nothing but these words
             if (threadIdx.x == 0) __hip_atomic_store(hw + chunk, 0x80000000u | amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // The wait is an optimisation, not a dependency: nothing promises that the slab's other workgroups are resident (a stream
+            // with a small CU mask, many streams' cast passes at once), so it is bounded -- a workgroup that is not served in time reads
+            // the whole slab for its amax itself (the same number: a max), below.
+            const uint64_t t_in = __builtin_amdgcn_s_memtime();
             unsigned f;
+            bool served = true;
             for (;;) {
                 f = threadIdx.x < chunks ? __hip_atomic_load(hw + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x80000000u;
                 if (__builtin_amdgcn_ballot_w64((f & 0x80000000u) == 0) == 0) break;
+                if (__builtin_amdgcn_s_memtime() - t_in >= a.wait_ticks) { served = false; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
             f = wave_umax(f & 0x7fffffffu);
-            if (threadIdx.x == 0) slab_amax = f;
+            if (threadIdx.x == 0) slab_amax = served ? f : 0xffffffffu;
         }
         __syncthreads();
-        amax = slab_amax;
+        if (slab_amax == 0xffffffffu) {  // (workgroup-uniform)
+            for (uint32_t r = tr; r < S && tr < rpw; r += rpw) {
+                const u32x4 v = *(const u32x4*)(sp + (int64_t)r * ss);
+                const unsigned r4[4] = {v[0], v[1], v[2], v[3]};
+                amax = bf16x8_amax(r4, amax);
+            }
+            __syncthreads();  // wmax is used a second time
+            amax = block_amax(amax, wmax);
+        } else {
+            amax = slab_amax;
+        }
     } else {
         amax = hw[VH_AMAX];  // vamax_rows_kernel, the launch before this one
     }
@@ -565,7 +582,8 @@ static hipError_t launch_cast_rows_u(const void* src, const int64_t* strides, vo
     const uint64_t chunks = ((uint64_t)S + U * rpw - 1) / (U * rpw), grid = (uint64_t)B * H * chunks;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     const bool fused = chunks <= 64 && !tuning().cast_two_pass.load(std::memory_order_relaxed);
-    const CastRowsArgs a = {(const uint16_t*)src, strides[0], strides[1], strides[2], (_Float16*)dst, H, S, D8, (uint32_t)chunks, hdr};
+    const CastRowsArgs a = {(const uint16_t*)src, strides[0], strides[1], strides[2], (_Float16*)dst, H, S, D8, (uint32_t)chunks, hdr,
+                            (uint32_t)std::min<int64_t>(std::max(tuning().cast_wait_us.load(std::memory_order_relaxed), 0), 1000000) * 100u};
     if (fused) {
         if (mk && mk->total) {
             // ... and the bool mask's re-pack for the one-wave-per-SIMD kernel in the SAME launch: its workgroups come behind the cast's

@@ -22,7 +22,8 @@ struct Tuning {
         bwd_separate_delta{0}, no_split{0}, force_split{0}, no_dma{0}, bn64{0}, pv_fp16{0}, bwd_ds_store{0}, no_w64_mask{0}, ksplit{0}, no_pipe{0}, no_w64_mask_lazy{0},
         cast_two_pass{0} /* V cast pre-pass: amax and cast as two launches whatever the slab size (tests) */, bwd_ds_lab{0} /* lab, timing only: BwdParams::ds_lab */,
         cast_u{0} /* lab: 16-byte loads per thread of the V cast pre-pass (4, 16, 32; 0 = the launcher's choice) */,
-        quant_block_wg{0} /* tests / A-B: the block-wise quantiser in its one-workgroup-per-block form everywhere */;
+        quant_block_wg{0} /* tests / A-B: the block-wise quantiser in its one-workgroup-per-block form everywhere */,
+        cast_wait_us{100} /* V cast pre-pass: how long a workgroup waits for its slab's other workgroups before it reads the slab's amax itself */;
 };
 Tuning& tuning();
 bool set_tuning(const char* name, const char* value);  // false: unknown name or value out of range
