@@ -285,9 +285,9 @@ def run_rank(args) -> None:
         torch.cuda.synchronize()
         return sorted(a.elapsed_time(b) for a, b in evs)
 
-    def graph_ms(fn, n, warmup=3):
+    def graph_ms(fn, n, warmup=3, reps=3):
         """steady-state milliseconds per call: n calls captured in one hipGraph (warm-up and capture on one side stream, as
-        in timed()), replayed once untimed, then timed with HIP events around the second replay -- the same launch regime
+        in timed()), replayed once untimed, then timed with HIP events around `reps` more replays -- the same launch regime
         as the headline; per-launch eager events (event_ms) also contain the launch gaps between a call's kernels"""
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -303,11 +303,12 @@ def run_rank(args) -> None:
             side.synchronize()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            g.replay()
+            for _ in range(reps):  # back to back: one replay's launch latency (tens of us) is 10 % of twenty 0.1-ms calls, and not steady state
+                g.replay()
             b.record()
             b.synchronize()
         torch.cuda.current_stream(dev).wait_stream(side)
-        return a.elapsed_time(b) / n
+        return a.elapsed_time(b) / (n * reps)
 
     # ---- headline: ONE FLUX problem (strong scaling).  N = 1: the whole problem on this GPU; N > 1: its heads dealt over the
     # ranks, the full O on every rank through all-gathers overlapped with the next head chunk

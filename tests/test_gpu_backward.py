@@ -182,6 +182,24 @@ def test_prequantized_backward_abi(ctx, bits, grouped, blockwise, causal, umfa_o
         assert np.abs(got - ref).max() < 2e-4 * max(1.0, np.abs(ref).max()), name
 
 
+@pytest.mark.parametrize("gain", [1e-9, 1e-6, 3e-4, 1e4])
+def test_prequantized_backward_over_the_range_of_dout(ctx, gain):
+    """Gradients are linear in dO, and the dO a training step hands over is routinely 1e-6 and below: fp16 subnormals or zero as a plain
+    cast.  The fp16 engine takes dO * 2^-e (one power of two per call, from the tensor's largest magnitude, on the device:
+    fa_aux.hip launch_cast_f16_unit) and gives 2^e back with the gradients; D, which the query call hands to the caller and the kv call
+    takes back, stays in true units.  Same relative bound as at |dO| ~ 1, no fall-back to the exact engine."""
+    from umfa.core import prequantized_backward
+    kwargs, (dq, dk, dv, dvec) = _prequant_case(8, True, True, False)
+    kwargs = dict(kwargs)
+    kwargs["dout"] = kwargs["dout"] * np.float32(gain)
+    gq, gk, gv, gd = prequantized_backward(ctx, **kwargs)
+    assert ctx.last_kernel.startswith("fa_bwd16<fp16"), ctx.last_kernel
+    for got, ref, name in ((gq, dq, "dq"), (gk, dk, "dk"), (gv, dv, "dv"), (gd, dvec.ravel(), "D")):
+        ref = ref * np.float64(np.float32(gain))
+        assert np.isfinite(got).all(), name
+        assert np.abs(got - ref).max() < 2e-3 * np.abs(ref).max(), (name, np.abs(got - ref).max() / np.abs(ref).max())
+
+
 def test_prequantized_backward_fp16_overflow_falls_back_to_the_exact_engine(ctx):
     """scales that put q * s outside fp16's range: the fast engine raises its device flag, the call repeats on the fp32
     path and the gradients are the exact engine's"""

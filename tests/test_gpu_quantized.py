@@ -300,3 +300,33 @@ def test_quantized_backward_stream_entry_matches_the_blocking_entry(ctx, D, dt):
             _, _, _, st = umfa_torch.quantized_attention_backward_stream(do, q, k, big, o, lse)
             torch.cuda.synchronize()
             assert int(st.item()) == 1
+
+
+@pytest.mark.parametrize("D,dt", [(128, "bf16"), (64, "bf16"), (128, "fp16")])
+@pytest.mark.parametrize("gain", [1e-9, 1e-6, 1e-3, 1e3])
+def test_quantized_backward_over_the_range_of_dout(D, dt, gain):
+    """mfa_quantized_backward's engine (fp16 images of the de-quantised operands, 16-bit MFMA backward) with the dO of a real training
+    step: 1e-6, 1e-9 -- as a plain fp16 cast those were subnormals / zeros and the gradients were off by 35 % / all zero with status 0
+    (tools/lab/qbwd_range_probe.py).  dO goes in as dO * 2^-e, e chosen on the device; against the fp32-exact engine on the same
+    inputs: the bound the engine meets at |dO| ~ 1 (fp16 P and dS), status 0."""
+    import torch
+    import umfa_torch
+    tdt = torch.bfloat16 if dt == "bf16" else torch.float16
+    if dt == "fp16" and gain < 1e-6:
+        pytest.skip("below fp16's own range: the CALLER's dO is already zero")
+    torch.manual_seed(17)
+    B, H, S = 1, 3, 512
+    q, k, v, do = (torch.randn(B, H, S, D, device="cuda", dtype=tdt) for _ in range(4))
+    do = (do.float() * gain).to(tdt)
+    o, lse = umfa_torch.quantized_attention_forward_stream(q, k, v, return_lse=True)
+    with umfa_torch.options(bwd_exact=1):
+        ref = umfa_torch.quantized_attention_backward_stream(do, q, k, v, o, lse)
+        assert umfa_torch.last_kernel().startswith("fa_bwd_exact")
+    got = umfa_torch.quantized_attention_backward_stream(do, q, k, v, o, lse)
+    torch.cuda.synchronize()
+    assert umfa_torch.last_kernel().startswith("fa_bwd16<fp16"), umfa_torch.last_kernel()
+    assert int(got[3].item()) == 0
+    for a, b, name in zip(got[:3], ref[:3], ("dq", "dk", "dv")):
+        a, b = a.double(), b.double()
+        assert torch.isfinite(a).all(), name
+        assert float((a - b).abs().max() / b.abs().max()) < 2e-3, (name, float((a - b).abs().max() / b.abs().max()))

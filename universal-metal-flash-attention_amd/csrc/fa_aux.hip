@@ -189,36 +189,12 @@ __global__ __launch_bounds__(256) void dequant_kernel(DequantParams p) {
     if (ovf && p.overflow) atomicOr(p.overflow, 1u);
 }
 
-// dense cast to fp16 (dO of the quantised backward entries: fp32 / bf16 at the ABI, fp16 for the MFMA backward)
-__global__ __launch_bounds__(256) void cast_f16_kernel(const void* src, int prec, _Float16* dst, int64_t n8, uint32_t* overflow) {
-    bool ovf = false;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
-        float x[8];
-        if (prec == P_FP32) {
-            const f32x4 lo = ((const f32x4*)src)[2 * i], hi = ((const f32x4*)src)[2 * i + 1];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { x[j] = lo[j]; x[4 + j] = hi[j]; }
-        } else {
-            const s16x8 raw = ((const s16x8*)src)[i];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = bf16_bits_to_float((uint16_t)raw[j]);
-        }
-        f16x8 o;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            ovf |= !(fabsf(x[j]) <= 65504.0f);
-            o[j] = (_Float16)x[j];
-        }
-        ((f16x8*)dst)[i] = o;
-    }
-    if (ovf && overflow) atomicOr(overflow, 1u);
-}
-
 // row constants of bwd16_dkdv from (LSE, D) when the dQ kernel that normally writes them ran in another call
-__global__ __launch_bounds__(256) void bwd16_rowc_kernel(const float* lse, const float* dvec, float* rowc, int64_t n) {
+__global__ __launch_bounds__(256) void bwd16_rowc_kernel(const float* lse, const float* dvec, float* rowc, int64_t n, const float* gscale) {
+    const float to_dout_units = gscale ? gscale[1] : 1.0f;  // the caller's D is in true units, the kernels' dO is dO * 2^-e
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         rowc[i] = -lse[i] * UMFA_LOG2E;
-        rowc[n + i] = -dvec[i];
+        rowc[n + i] = -dvec[i] * to_dout_units;
     }
 }
 
@@ -260,12 +236,93 @@ __global__ __launch_bounds__(256) void group_sum_scalar_kernel(const float* __re
     }
 }
 
-hipError_t launch_cast_f16(const void* src, int prec, void* dst, int64_t n, uint32_t* overflow, hipStream_t stream) {
-    if (!src || !dst || (n & 7) || (prec != P_FP32 && prec != P_BF16)) return hipErrorInvalidValue;
-    if (n == 0) return hipSuccess;
+// dO of the quantised backward entries as the fp16 MFMA backward takes it: dO * 2^-e with ONE power of two e per call, chosen on the
+// device so that the largest |dO| lands in [1, 2).  fp16 has five exponent bits; the gradients these entries see in bf16 / fp32 training
+// are routinely 1e-5 ... 1e-9 -- as a plain cast they were fp16 subnormals or zero (dQ off by 3 % at |dO| ~ 1e-5, 35 % at 1e-7, all zeros
+// at 1e-9, status 0: tools/lab/qbwd_range_probe.py), and dS = P (dP - D), rounded to fp16 inside the kernels, sank with them.  Every
+// gradient is linear in dO, so the kernels give 2^e back in their epilogues (BwdParams::gscale): exact both ways.
+// hdr: [0] largest |dO| as fp32 bits (zero on entry: the launcher's memset node), [1] 2^e, [2] 2^-e (floats, written here).
+template <int PREC>
+__device__ __forceinline__ void load8_as_float(const void* src, int64_t i, float (&x)[8]) {
+    if constexpr (PREC == P_FP32) {
+        const f32x4 lo = ((const f32x4*)src)[2 * i], hi = ((const f32x4*)src)[2 * i + 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { x[j] = lo[j]; x[4 + j] = hi[j]; }
+    } else if constexpr (PREC == P_BF16) {
+        const s16x8 raw = ((const s16x8*)src)[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = bf16_bits_to_float((uint16_t)raw[j]);
+    } else {
+        const f16x8 raw = ((const f16x8*)src)[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = (float)raw[j];
+    }
+}
+template <int PREC>
+__global__ __launch_bounds__(256) void amax_dense_kernel(const void* src, int64_t n8, uint32_t* hdr) {
+    __shared__ unsigned wmax[4];
+    unsigned amax = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        float x[8];
+        load8_as_float<PREC>(src, i, x);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned a = __float_as_uint(x[j]) & 0x7fffffffu;
+            amax = a > amax ? a : amax;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)amax, off, 64);
+        amax = o > amax ? o : amax;
+    }
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) amax = wmax[w] > amax ? wmax[w] : amax;
+        if (amax) (void)__hip_atomic_fetch_max(hdr, amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ int unit_exponent(unsigned amax_bits) {  // e with amax * 2^-e in [1, 2); 0 for an all-zero or non-finite tensor
+    if (amax_bits == 0 || amax_bits >= 0x7f800000u) return 0;
+    const int E = (int)(amax_bits >> 23);
+    const int e = (E ? E : 1) - 127;
+    return e < -126 ? -126 : e > 126 ? 126 : e;
+}
+template <int PREC>
+__global__ __launch_bounds__(256) void cast_f16_unit_kernel(const void* src, _Float16* dst, int64_t n8, uint32_t* hdr) {
+    const int e = unit_exponent(hdr[0]);
+    const float mul = __uint_as_float((unsigned)(127 - e) << 23);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        hdr[1] = (unsigned)(127 + e) << 23;
+        hdr[2] = (unsigned)(127 - e) << 23;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        float x[8];
+        load8_as_float<PREC>(src, i, x);
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (_Float16)(x[j] * mul);
+        ((f16x8*)dst)[i] = o;
+    }
+}
+
+hipError_t launch_cast_f16_unit(const void* src, int prec, void* dst, int64_t n, uint32_t* hdr, hipStream_t stream) {
+    if (!src || !dst || !hdr || (n & 7) || (prec != P_FP32 && prec != P_BF16 && prec != P_FP16)) return hipErrorInvalidValue;
+    if (hipError_t e = hipMemsetAsync(hdr, 0, 4, stream); e != hipSuccess) return e;
     const int64_t n8 = n / 8;
-    const unsigned grid = (unsigned)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : 8192);
-    hipLaunchKernelGGL(cast_f16_kernel, dim3(grid), dim3(256), 0, stream, src, prec, (_Float16*)dst, n8, overflow);
+    const unsigned grid = (unsigned)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : n8 ? 8192 : 1);
+    const unsigned agrid = grid < 1024 ? grid : 1024;  // one atomic per workgroup, all on one word: few, fat workgroups
+    if (prec == P_FP32) {
+        hipLaunchKernelGGL(amax_dense_kernel<P_FP32>, dim3(agrid), dim3(256), 0, stream, src, n8, hdr);
+        hipLaunchKernelGGL(cast_f16_unit_kernel<P_FP32>, dim3(grid), dim3(256), 0, stream, src, (_Float16*)dst, n8, hdr);
+    } else if (prec == P_BF16) {
+        hipLaunchKernelGGL(amax_dense_kernel<P_BF16>, dim3(agrid), dim3(256), 0, stream, src, n8, hdr);
+        hipLaunchKernelGGL(cast_f16_unit_kernel<P_BF16>, dim3(grid), dim3(256), 0, stream, src, (_Float16*)dst, n8, hdr);
+    } else {
+        hipLaunchKernelGGL(amax_dense_kernel<P_FP16>, dim3(agrid), dim3(256), 0, stream, src, n8, hdr);
+        hipLaunchKernelGGL(cast_f16_unit_kernel<P_FP16>, dim3(grid), dim3(256), 0, stream, src, (_Float16*)dst, n8, hdr);
+    }
     return hipGetLastError();
 }
 
@@ -619,10 +676,10 @@ static hipError_t launch_cast_rows_any(const void* src, const int64_t* strides, 
     return launch_cast_rows_u<16>(src, strides, dst, B, H, S, D, hdr, stream, mk);
 }
 
-hipError_t launch_bwd16_rowc(const float* lse, const float* dvec, float* rowc, int64_t n, hipStream_t stream) {
+hipError_t launch_bwd16_rowc(const float* lse, const float* dvec, float* rowc, int64_t n, const float* gscale, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(bwd16_rowc_kernel, dim3(grid), dim3(256), 0, stream, lse, dvec, rowc, n);
+    hipLaunchKernelGGL(bwd16_rowc_kernel, dim3(grid), dim3(256), 0, stream, lse, dvec, rowc, n, gscale);
     return hipGetLastError();
 }
 

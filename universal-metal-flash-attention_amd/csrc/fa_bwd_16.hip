@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void bwd16_delta_kernel(BwdParams p) {
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (lane == 0) p.dvec[row] = s;
+    if (lane == 0) p.dvec[row] = s * grad_unit(p);
 }
 
 // ------------------------------------------------------------------------------------------------ dQ
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256, DP == 256 ? 1 : 2) void bwd16_dq_kernel(BwdPar
     delta += __shfl_xor(delta, 32, 64);
     if (qok && hi == 0) {
         const int64_t ri = (int64_t)bh * p.Sq + q_row;
-        p.dvec[ri] = delta;
+        p.dvec[ri] = delta * grad_unit(p);  // (D in true units for the caller; the row constants below stay in dO's)
         // ... and, for bwd16_dkdv, the two row constants in the form it consumes them: the addend of the exponent FMA and
         // the initial value of the dP accumulator (dP - D comes out of the MFMA chain) -- 64 vector instructions per tile
         // (32 multiplies, 32 subtractions) that its loop no longer issues
@@ -354,14 +354,15 @@ __global__ __launch_bounds__(256, DP == 256 ? 1 : 2) void bwd16_dq_kernel(BwdPar
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    const float osc = p.scale * grad_unit(p);
     if (qok) {
         const int64_t orow = ((int64_t)bh * p.Sq + q_row) * DP;
 #pragma unroll
         for (int i = 0; i < NDB; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                f32x4 val = {acc[i][4 * g] * p.scale, acc[i][4 * g + 1] * p.scale, acc[i][4 * g + 2] * p.scale,
-                             acc[i][4 * g + 3] * p.scale};
+                f32x4 val = {acc[i][4 * g] * osc, acc[i][4 * g + 1] * osc, acc[i][4 * g + 2] * osc,
+                             acc[i][4 * g + 3] * osc};
                 store_grad4<T>(p.dq, orow + 32 * i + 8 * g + 4 * hi, val, p.grad_in_type != 0);
             }
     }
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(256, 1) void bwd16_dq2_kernel(BwdParams p) {
     delta += __shfl_xor(delta, 32, 64);
     if (qok && hi == 0) {
         const int64_t ri = (int64_t)bh * p.Sq + q_row;
-        p.dvec[ri] = delta;
+        p.dvec[ri] = delta * grad_unit(p);  // (D in true units for the caller; the row constants below stay in dO's)
         p.rowc[ri] = -L2;                                        // row constants for bwd16_dkdv (see bwd16_dq)
         p.rowc[(int64_t)p.B * p.H * p.Sq + ri] = -delta;
     }
@@ -574,6 +575,7 @@ __global__ __launch_bounds__(256, 1) void bwd16_dq2_kernel(BwdParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    const float osc = p.scale * grad_unit(p);
     if (p.grad_in_type) {  // operand-type dQ: through per-wave LDS rows, whole 256-byte rows out (see bwd16_dkdv's epilogue)
         char* stg = smem + wave * 8192;
         typedef T T4 __attribute__((ext_vector_type(4)));
@@ -582,8 +584,8 @@ __global__ __launch_bounds__(256, 1) void bwd16_dq2_kernel(BwdParams p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int ch = (4 * i + g) ^ (ql & 15);
-                *(T4*)(stg + ql * 256 + 16 * ch + 8 * hi) = T4{(T)(acc[i][4 * g] * p.scale), (T)(acc[i][4 * g + 1] * p.scale),
-                                                                (T)(acc[i][4 * g + 2] * p.scale), (T)(acc[i][4 * g + 3] * p.scale)};
+                *(T4*)(stg + ql * 256 + 16 * ch + 8 * hi) = T4{(T)(acc[i][4 * g] * osc), (T)(acc[i][4 * g + 1] * osc),
+                                                                (T)(acc[i][4 * g + 2] * osc), (T)(acc[i][4 * g + 3] * osc)};
             }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -602,8 +604,8 @@ __global__ __launch_bounds__(256, 1) void bwd16_dq2_kernel(BwdParams p) {
         for (int i = 0; i < NDB; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                f32x4 val = {acc[i][4 * g] * p.scale, acc[i][4 * g + 1] * p.scale, acc[i][4 * g + 2] * p.scale,
-                             acc[i][4 * g + 3] * p.scale};
+                f32x4 val = {acc[i][4 * g] * osc, acc[i][4 * g + 1] * osc, acc[i][4 * g + 2] * osc,
+                             acc[i][4 * g + 3] * osc};
                 store_grad4<T>(p.dq, orow + 32 * i + 8 * g + 4 * hi, val, false);
             }
     }
@@ -695,6 +697,7 @@ __global__ __launch_bounds__(256, 1) void bwd16_dq_gemm_kernel(BwdParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring's last (out-of-range) requests: the epilogue below reuses the tile area
     __syncthreads();
+    const float osc = p.scale * grad_unit(p);
     if (p.grad_in_type) {  // operand-type dQ through per-wave LDS rows (see bwd16_dq2)
         char* stg = smem + wave * 8192;
         typedef T T4 __attribute__((ext_vector_type(4)));
@@ -703,8 +706,8 @@ __global__ __launch_bounds__(256, 1) void bwd16_dq_gemm_kernel(BwdParams p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int ch = (4 * i + g) ^ (ql & 15);
-                *(T4*)(stg + ql * 256 + 16 * ch + 8 * hi) = T4{(T)(acc[i][4 * g] * p.scale), (T)(acc[i][4 * g + 1] * p.scale),
-                                                                (T)(acc[i][4 * g + 2] * p.scale), (T)(acc[i][4 * g + 3] * p.scale)};
+                *(T4*)(stg + ql * 256 + 16 * ch + 8 * hi) = T4{(T)(acc[i][4 * g] * osc), (T)(acc[i][4 * g + 1] * osc),
+                                                                (T)(acc[i][4 * g + 2] * osc), (T)(acc[i][4 * g + 3] * osc)};
             }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -723,8 +726,8 @@ __global__ __launch_bounds__(256, 1) void bwd16_dq_gemm_kernel(BwdParams p) {
         for (int i = 0; i < NDB; ++i)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                f32x4 val = {acc[i][4 * g] * p.scale, acc[i][4 * g + 1] * p.scale, acc[i][4 * g + 2] * p.scale,
-                             acc[i][4 * g + 3] * p.scale};
+                f32x4 val = {acc[i][4 * g] * osc, acc[i][4 * g + 1] * osc, acc[i][4 * g + 2] * osc,
+                             acc[i][4 * g + 3] * osc};
                 store_grad4<T>(p.dq, orow + 32 * i + 8 * g + 4 * hi, val, false);
             }
     }
@@ -1124,6 +1127,7 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
 #ifdef BWD16_LAB_STAMP
     rt_loop1 = __builtin_amdgcn_s_memrealtime();
 #endif
+    const float gsv = grad_unit(p), osc = p.scale * gsv;
     if (DP == 128 && p.grad_in_type && !p.dkdv_fp32) {
         // Gradients in the operand type (in-stream entry), head_dim 128: a lane holds 4 consecutive d of ONE key per register
         // group, so direct stores touch 32 rows x 8 bytes per instruction (64 scattered store instructions per wave and
@@ -1155,8 +1159,8 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         };
-        flush(p.dk, [&](int i, int g) { return f32x4{dk[i][4 * g] * p.scale, dk[i][4 * g + 1] * p.scale, dk[i][4 * g + 2] * p.scale, dk[i][4 * g + 3] * p.scale}; });
-        flush(p.dv, [&](int i, int g) { return f32x4{dv[i][4 * g], dv[i][4 * g + 1], dv[i][4 * g + 2], dv[i][4 * g + 3]}; });
+        flush(p.dk, [&](int i, int g) { return f32x4{dk[i][4 * g] * osc, dk[i][4 * g + 1] * osc, dk[i][4 * g + 2] * osc, dk[i][4 * g + 3] * osc}; });
+        flush(p.dv, [&](int i, int g) { return f32x4{dv[i][4 * g] * gsv, dv[i][4 * g + 1] * gsv, dv[i][4 * g + 2] * gsv, dv[i][4 * g + 3] * gsv}; });
     } else if (kok) {
         const int64_t krow = ((int64_t)bh * p.Skv + key) * DP;
 #pragma unroll
@@ -1164,8 +1168,8 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d0 = 32 * (i + hpass * NDBH) + 8 * g + 4 * hi;
-                f32x4 kv = {dk[i][4 * g] * p.scale, dk[i][4 * g + 1] * p.scale, dk[i][4 * g + 2] * p.scale, dk[i][4 * g + 3] * p.scale};
-                f32x4 vv = {dv[i][4 * g], dv[i][4 * g + 1], dv[i][4 * g + 2], dv[i][4 * g + 3]};
+                f32x4 kv = {dk[i][4 * g] * osc, dk[i][4 * g + 1] * osc, dk[i][4 * g + 2] * osc, dk[i][4 * g + 3] * osc};
+                f32x4 vv = {dv[i][4 * g] * gsv, dv[i][4 * g + 1] * gsv, dv[i][4 * g + 2] * gsv, dv[i][4 * g + 3] * gsv};
                 store_grad4<T>(p.dk, krow + d0, kv, p.grad_in_type != 0 && !p.dkdv_fp32);
                 store_grad4<T>(p.dv, krow + d0, vv, p.grad_in_type != 0 && !p.dkdv_fp32);
             }
@@ -1216,7 +1220,7 @@ static hipError_t launch_bwd16_t(const BwdParams& p, hipStream_t stream) {
             const BwdParams& p = pl;
             // dS-store form: D, row constants, dK / dV (+ dS to the scratch), dQ = scale dS K
             hipLaunchKernelGGL(bwd16_delta_kernel<DP>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, p);
-            if (hipError_t e = launch_bwd16_rowc(p.lse, p.dvec, p.rowc, rows, stream); e != hipSuccess) return e;
+            if (hipError_t e = launch_bwd16_rowc(p.lse, p.dvec, p.rowc, rows, p.gscale, stream); e != hipSuccess) return e;
             if (hipError_t e = ensure_dynamic_lds((const void*)bwd16_dkdv_kernel<T, false, DP, true>, lds_kv); e != hipSuccess) return e;
             hipLaunchKernelGGL((bwd16_dkdv_kernel<T, false, DP, true>), dim3(nkb * p.B * p.H), dim3(256), lds_kv, stream, p);
             const size_t lds_g = 4 * 2 * 64 * 2 * DP;  // four slots of (K tile, dS^T tile)
@@ -1226,7 +1230,7 @@ static hipError_t launch_bwd16_t(const BwdParams& p, hipStream_t stream) {
         }
     }
     if (!(ph & 3)) {
-        if (hipError_t e = launch_bwd16_rowc(p.lse, p.dvec, p.rowc, rows, stream); e != hipSuccess) return e;
+        if (hipError_t e = launch_bwd16_rowc(p.lse, p.dvec, p.rowc, rows, p.gscale, stream); e != hipSuccess) return e;
     } else
     if constexpr (DP == 128) {
         // one-workgroup-per-CU kernel for non-causal launches (same box, ms per backward, v2 / two-per-CU: FLUX 0.678 / 0.693,

@@ -148,7 +148,12 @@ struct BwdParams {
                     // type -- bwd16_dkdv writes dS = P (dP - D) there, bwd16_dq_gemm computes dQ = scale dS K from it: 5 products
                     // instead of 7 for B H Sq Skv 2 bytes of HBM (805 MB at the FLUX shape); NULL = the two recomputing kernels
     int ds_lab;     // lab (env UMFA_LAB_DS, timing only): bit 0 = every dS store goes to tile 0 of the slab (no HBM write stream)
+    const float* gscale;  // bwd16 only, device, NULL = 1: {2^e, 2^-e} when `dout` holds dO * 2^-e (the quantised entries' fp16 image of dO,
+                          // fa_aux.hip launch_cast_f16_unit).  Every gradient is linear in dO: the epilogues multiply by 2^e, D leaves in
+                          // true units (p.dvec) and is taken back into dO's units where it is read from the caller (bwd16_rowc_kernel)
 };
+
+__device__ __forceinline__ float grad_unit(const BwdParams& p) { return p.gscale ? p.gscale[0] : 1.0f; }
 
 __device__ __forceinline__ float bf16_bits_to_float(uint16_t b) {
     return __uint_as_float(((uint32_t)b) << 16);

@@ -101,8 +101,6 @@ struct DequantParams {
     int transposed;  // source slab stored [D, S]
 };
 hipError_t launch_dequant(const DequantParams& p, hipStream_t stream);
-// dense fp32 / bf16 -> fp16 (n % 8 == 0, 16-byte aligned); *overflow |= 1 when a value does not fit
-hipError_t launch_cast_f16(const void* src, int prec, void* dst, int64_t n, uint32_t* overflow, hipStream_t stream);
 // bf16 [B,H,S,D] with element strides (head_dim contiguous) -> dense fp16 [B,H,S,D] of V * 2^-e, one power of two per (batch, head)
 // slab chosen from the slab's largest |v| (no value leaves fp16's range); hdr: VSC_HDR_WORDS uint32 per slab, zero on entry except word
 // VSC_HDR_SCALE, which the pass leaves holding 2^e as fp32 (FwdParams::vsc reads it)
@@ -112,7 +110,10 @@ hipError_t launch_cast_rows_bf16_to_f16(const void* src, const int64_t* strides,
 // *flag |= 1 when any of x[0 .. n) (fp32, 16-byte aligned) is not finite
 hipError_t launch_nonfinite_flag(const float* x, int64_t n, uint32_t* flag, hipStream_t stream);
 // rowc[0 .. n) = -lse * log2 e, rowc[n .. 2n) = -dvec: what bwd16_dq leaves for bwd16_dkdv, for a dK / dV-only call
-hipError_t launch_bwd16_rowc(const float* lse, const float* dvec, float* rowc, int64_t n, hipStream_t stream);
+hipError_t launch_bwd16_rowc(const float* lse, const float* dvec, float* rowc, int64_t n, const float* gscale, hipStream_t stream);
+// dO of the quantised backward entries -> fp16 as dO * 2^-e, one power of two per call from the tensor's largest |dO| (device);
+// hdr = 3 words: amax bits, 2^e, 2^-e = what BwdParams::gscale points at (hdr + 1)
+hipError_t launch_cast_f16_unit(const void* src, int prec, void* dst, int64_t n, uint32_t* hdr, hipStream_t stream);
 // dst: [B, Hkv, slab] in out_prec (fp32 default; fp16 / bf16: rounded once after the fp32 sum)
 hipError_t launch_group_sum(const float* src, void* dst, uint32_t B, uint32_t H, uint32_t Hkv, int64_t slab, hipStream_t stream,
                             int out_prec = P_FP32);

@@ -356,11 +356,12 @@ int32_t mfa_quantized_backward(mfa_context_t context, mfa_buffer_t q, mfa_buffer
         if (fast) {
             p.q = views.qh; p.k = views.kh; p.v = views.vh;
             p.in_prec = P_FP16; p.dout_prec = P_FP16;
-            p.dout = bdo->dev;
-            if (prec != P_FP16) {
-                if (launch_cast_f16(bdo->dev, prec, ws + o_do16, (int64_t)nq, flag, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
-                p.dout = ws + o_do16;
-            }
+            // dO as dO * 2^-e in fp16, e from its largest magnitude on the device (gradients of 1e-7 are ordinary; as a plain cast they
+            // were fp16 subnormals): fa_aux.hip launch_cast_f16_unit, 2^e comes back in the kernels' epilogues
+            uint32_t* unit = (uint32_t*)(ws + o_flag) + 16;
+            if (launch_cast_f16_unit(bdo->dev, prec, ws + o_do16, (int64_t)nq, unit, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+            p.dout = ws + o_do16;
+            p.gscale = (const float*)(unit + 1);
             p.rowc = (float*)(ws + o_rowc);
             e = bwd_16_supported(p) ? launch_bwd_16(p, stream, &name) : hipErrorNotSupported;
             if (e == hipErrorNotSupported) continue;  // (alignment of a wrapped caller buffer): the exact path
@@ -435,11 +436,10 @@ mfa_error_t umfa_quantized_backward_stream(mfa_context_t context, void* stream_h
     if (fast) {
         p.q = views.qh; p.k = views.kh; p.v = views.vh;
         p.in_prec = P_FP16; p.dout_prec = P_FP16;
-        p.dout = dout;
-        if (prec != P_FP16) {
-            if (launch_cast_f16(dout, prec, ws + o_do16, (int64_t)nq, flag, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
-            p.dout = ws + o_do16;
-        }
+        uint32_t* unit = (uint32_t*)(ws + o_flag) + 16;  // dO * 2^-e in fp16, see mfa_quantized_backward
+        if (launch_cast_f16_unit(dout, prec, ws + o_do16, (int64_t)nq, unit, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+        p.dout = ws + o_do16;
+        p.gscale = (const float*)(unit + 1);
         p.rowc = (float*)(ws + o_rowc);
         if (!bwd_16_supported(p)) return MFA_ERROR_INVALID_ARGS;  // 16-byte alignment of the caller's tensors
         e = launch_bwd_16(p, stream, &name);
@@ -589,8 +589,10 @@ int32_t mfa_attention_backward_query_quantized_ex(
         hipError_t e;
         if (fast) {
             p.in_prec = P_FP16; p.dout_prec = P_FP16;
-            if (launch_cast_f16(bdo->dev, P_FP32, extra + o_do16, (int64_t)nq, flag, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+            uint32_t* unit = (uint32_t*)(extra + o_flag) + 16;  // dO * 2^-e in fp16 (the same e in the query and the kv call: the same dO), see mfa_quantized_backward
+            if (launch_cast_f16_unit(bdo->dev, P_FP32, extra + o_do16, (int64_t)nq, unit, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
             p.dout = extra + o_do16;
+            p.gscale = (const float*)(unit + 1);
             p.rowc = (float*)(extra + o_rowc);
             e = bwd_16_supported(p) ? launch_bwd_16(p, stream, &name) : hipErrorNotSupported;
             if (e == hipErrorNotSupported) continue;
@@ -668,8 +670,10 @@ int32_t mfa_attention_backward_kv_quantized_ex(
         hipError_t e;
         if (fast) {
             p.in_prec = P_FP16; p.dout_prec = P_FP16;
-            if (launch_cast_f16(bdo->dev, P_FP32, extra + o_do16, (int64_t)nq, flag, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+            uint32_t* unit = (uint32_t*)(extra + o_flag) + 16;  // dO * 2^-e in fp16 (the same e in the query and the kv call: the same dO), see mfa_quantized_backward
+            if (launch_cast_f16_unit(bdo->dev, P_FP32, extra + o_do16, (int64_t)nq, unit, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
             p.dout = extra + o_do16;
+            p.gscale = (const float*)(unit + 1);
             p.rowc = (float*)(extra + o_rowc);
             e = bwd_16_supported(p) ? launch_bwd_16(p, stream, &name) : hipErrorNotSupported;
             if (e == hipErrorNotSupported) continue;
