@@ -330,3 +330,65 @@ def test_quantized_backward_over_the_range_of_dout(D, dt, gain):
         a, b = a.double(), b.double()
         assert torch.isfinite(a).all(), name
         assert float((a - b).abs().max() / b.abs().max()) < 2e-3, (name, float((a - b).abs().max() / b.abs().max()))
+
+
+@pytest.mark.parametrize("gain", [1e-9, 1e-5, 3e4, 1e7, 1e20])
+@pytest.mark.parametrize("shape,mode,bits,dt", [((1, 3, 1024, 1024, 128), "blockwise", 8, "bf16"), ((2, 2, 512, 448, 128), "blockwise", 4, "fp16"),
+                                               ((1, 2, 768, 768, 128), "tensor", 8, "bf16"), ((1, 2, 16640, 16640, 128), "blockwise", 8, "bf16"),
+                                               ((1, 3, 200, 333, 64), "blockwise", 8, "bf16"), ((2, 2, 128, 256, 80), "tensor", 8, "fp32"),
+                                               ((1, 2, 1024, 512, 128), "blockwise", 8, "fp32"), ((1, 2, 512, 512, 64), "blockwise_fp8pv", 8, "bf16"),
+                                               ((1, 2, 1024, 1024, 128), "blockwise_fp8pv", 8, "bf16")])
+def test_quantized_forward_over_the_range_of_v(gain, shape, mode, bits, dt):
+    """The forward's P V product runs in fp16 on an fp16 image of the de-quantised V; fp16 has five exponent bits.  As plain q * s the
+    image was inf for |v| ~ 1e5 and subnormal below ~ 1e-4 (tools/lab/qfwd_range_probe.py: NaN / 1.5 % / all zero, no error).  It is
+    q * s * 2^-e now, one power of two per (batch, head) slab found on the device -- by an exchange among the wave quantiser's workgroups
+    (16-bit operands, head_dim 64 / 128, block-wise), or by a pass of its own (tensor-wise mode, fp32 operands, other head dims, slabs of
+    more than 256 blocks: the 16640-key case) -- and 2^e comes back in the kernels' epilogues.  Oracle parity per slab at every scale, with
+    one slab 1e6 times smaller than its neighbours on top."""
+    import torch
+    import umfa_torch
+    orc = _oracle()
+    B, H, Sq, Skv, D = shape
+    tdt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[dt]
+    if dt == "fp16" and not 1e-5 <= gain <= 1e4:
+        pytest.skip("outside fp16: the caller's V cannot hold it")
+    torch.manual_seed(Sq + Skv + D + bits)
+    q = torch.randn(B, H, Sq, D, device="cuda").to(tdt)
+    k = torch.randn(B, H, Skv, D, device="cuda").to(tdt)
+    v = torch.randn(B, H, Skv, D, device="cuda") * gain
+    if mode != "tensor" and dt != "fp16":
+        v[0, H - 1] *= 1e-6  # (a tensor-wide scale would quantise this slab to zero: the quantiser's business, not the image's)
+    v = v.to(tdt)
+    o = umfa_torch.quantized_attention_forward_stream(q, k, v, bits=bits, quant_mode=mode)
+    kern = umfa_torch.last_kernel()
+    o2 = umfa_torch.quantized_attention_forward_stream(q, k, v, bits=bits, quant_mode=mode)
+    torch.cuda.synchronize()
+    assert torch.equal(o, o2)
+    f32 = lambda t: t.float().cpu().numpy()
+    ref, _ = orc.quantized_forward(f32(q), f32(k), f32(v), bits=bits, quant_mode=0 if mode == "tensor" else 2)
+    o = o.cpu().numpy().astype(np.float64)
+    assert np.isfinite(o).all(), kern
+    tol = 6e-2 if kern.startswith("fa_fwd_w64_i8f8") else 2e-3
+    for b in range(B):
+        for h in range(H):
+            top = np.abs(ref[b, h]).max()
+            assert top > 0
+            assert np.abs(o[b, h] - ref[b, h]).max() < tol * top, (b, h, np.abs(o[b, h] - ref[b, h]).max() / top, kern)
+
+
+def test_quantized_forward_v_exchange_without_waiting():
+    """cast_wait_us = 0: a workgroup of the wave quantiser that is not served at once reads the slab's amax itself; cast_two_pass: the
+    amax pass of its own; quant_block_wg: the workgroup-per-block quantiser (same pass).  Same exponent every way: bit-identical O."""
+    import torch
+    import umfa_torch
+    torch.manual_seed(5)
+    q, k = (torch.randn(1, 4, 1024, 128, device="cuda", dtype=torch.bfloat16) for _ in range(2))
+    v = (torch.randn(1, 4, 1024, 128, device="cuda") * 1e-7).to(torch.bfloat16)
+    outs = []
+    for opts in ({}, {"cast_wait_us": 0}, {"cast_two_pass": 1}, {"quant_block_wg": 1}, {}):
+        with umfa_torch.options(**opts):
+            outs.append(umfa_torch.quantized_attention_forward_stream(q, k, v))
+            assert umfa_torch.last_kernel() == "fa_fwd_w64_i8<128>"
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])

@@ -502,7 +502,7 @@ struct CastRowsArgs {
     _Float16* dst;
     uint32_t H, S, D8, chunks;
     uint32_t* hdr;
-    uint32_t wait_ticks;  // of the 100 MHz s_memtime clock
+    uint32_t wait_ticks;  // of the 100 MHz s_memrealtime clock (s_memtime counts shader clocks: ~1.7 GHz here)
 };
 template <int U, bool FUSED>
 __device__ __forceinline__ void cast_rows_body(const CastRowsArgs& a, const uint32_t block) {
@@ -541,13 +541,13 @@ __device__ __forceinline__ void cast_rows_body(const CastRowsArgs& a, const uint
             // The wait is an optimisation, not a dependency: nothing promises that the slab's other workgroups are resident (a stream
             // with a small CU mask, many streams' cast passes at once), so it is bounded -- a workgroup that is not served in time reads
             // the whole slab for its amax itself (the same number: a max), below.
-            const uint64_t t_in = __builtin_amdgcn_s_memtime();
+            const uint64_t t_in = __builtin_amdgcn_s_memrealtime();
             unsigned f;
             bool served = true;
             for (;;) {
                 f = threadIdx.x < chunks ? __hip_atomic_load(hw + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x80000000u;
                 if (__builtin_amdgcn_ballot_w64((f & 0x80000000u) == 0) == 0) break;
-                if (__builtin_amdgcn_s_memtime() - t_in >= a.wait_ticks) { served = false; break; }
+                if (__builtin_amdgcn_s_memrealtime() - t_in >= a.wait_ticks) { served = false; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
             f = wave_umax(f & 0x7fffffffu);

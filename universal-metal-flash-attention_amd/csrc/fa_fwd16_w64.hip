@@ -84,6 +84,7 @@ struct W64I8Params {
     float tau;
     uint32_t lazy;          // lazy reference mode (fp16 P thresholds; the fp8 variant has no lazy bodies and ignores it)
     uint32_t skew;
+    const float* vsc;       // slab headers of the fp16 V image q * s * 2^-e (fa_quant.hip QuantParams::vhdr): 2^e in word 65 of slab bh; NULL = 1
 };
 
 #define W64_I8 0
@@ -221,6 +222,8 @@ struct W64I8Params {
 
 // runtime-quantised variant: int8 QK^T, fp16 PV
 #define W64_I8 1
+#undef W64_VSC
+#define W64_VSC 2                               /* the V image's 2^e per dense (batch, head) slab, nullable */
 #define W64_BODY_INC "fa_fwd_w64_i8_body.inc"
 #define W64_T _Float16
 #define W64_MFMA "v_mfma_f32_32x32x16_f16"
@@ -236,6 +239,8 @@ struct W64I8Params {
 #undef W64_BODY_INC
 
 // runtime-quantised, fp8 P V (opt-in fast mode, quant_mode 3): int8 QK^T, fp8 e4m3 P and V
+#undef W64_VSC
+#define W64_VSC 0                               /* (the fp8 image carries a power of two per TILE in the MFMA's scale operand) */
 #undef W64_F8
 #define W64_F8 1
 #undef W64_LAZY_PARTS
@@ -586,6 +591,7 @@ hipError_t launch_fwd_w64_i8(const FwdParams& p, const QuantViews& v, float* par
     wp.part_cnt = part_cnt;
     w64_softmax_policy(P_FP16, &wp.tau, &wp.lazy);  // fp16 P
     wp.skew = (uint32_t)tuning().w64_skew.load(std::memory_order_relaxed);
+    wp.vsc = v.v8 ? nullptr : p.vsc;
     const uint32_t grid = w64_grid(p);
     const size_t lds = 65536 + 4 * 32 * (512 + 16) + 16;
     const bool f8 = v.v8 != nullptr;

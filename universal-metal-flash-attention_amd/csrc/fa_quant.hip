@@ -48,7 +48,27 @@ struct QuantParams {
     float qmax;           // 127 or 7
     int qlo, qhi;         // clamp range
     int t_first, t_end;   // the tensors (0 Q, 1 K, 2 V) this launch covers: [t_first, t_end)
+    // The fp16 V image holds q * s * 2^-e, one power of two e per (batch, head) slab from the slab's largest |v| (fp16 has five exponent
+    // bits, the caller's V has eight: as plain q * s the image was inf from |v| ~ 1e5 and subnormal below ~ 1e-4).  vhdr: the slab headers
+    // of the bf16 forward's cast pass (kernels.h VSC_HDR_*: 128 words per slab, zero between launches except the scale word, which is left
+    // holding 2^e for the attention kernels' epilogues); NULL = plain q * s (no forward consumes the image: the backward entries).
+    // v_exchange 1: quantize_wave_kernel's V workgroups find the slab's amax among themselves (the cast pass's flag-word exchange, four
+    // blocks per workgroup); 0: word VSC_HDR_AMAX holds it (vimage_amax_kernel ran before, vimage_finish_kernel runs behind).
+    uint32_t* vhdr;
+    int v_exchange;
+    uint32_t wait_ticks;  // bound of the exchange's wait (100 MHz ticks), then the workgroup reads the slab itself
 };
+
+// e of the image: the slab's largest |v| (top 16 bits of its fp32 pattern) lands in [2^14, 2^15) -- one binade under fp16's last, because
+// q * s can exceed the block's amax by a rounding.  inf / NaN count as the largest finite exponent.
+__device__ __forceinline__ int vimage_exponent(unsigned amax_b16) {
+    if (amax_b16 == 0) return 0;
+    int E = (int)(amax_b16 >> 7);
+    E = E > 254 ? 254 : E;
+    const int e = (E ? E - 127 : -126) - 14;
+    return e < -100 ? -100 : e;
+}
+__device__ __forceinline__ float exp2i(int e) { return __uint_as_float((unsigned)(127 + e) << 23); }
 
 // mode 0: write block absmax only; mode 1: quantise with scales already in scale[]; mode 2: both (fused).
 // One workgroup per (tensor, batch*head, 64-row block).  The block (<= 64 x 256 elements) is read ONCE with
@@ -211,6 +231,8 @@ __global__ __launch_bounds__(256) void quantize_kernel(QuantParams p) {
     const float rcp0 = __builtin_amdgcn_rcpf(sc);
     const float rcp1 = __builtin_fmaf(__builtin_fmaf(-sc, rcp0, 1.0f), rcp0, rcp0);
     const bool fast_div = sc >= 0x1p-60f && sc <= 0x1p60f;
+    // (V image: q * s * 2^-e, e from the slab's amax that vimage_amax_kernel left in the slab's header)
+    const float scv = (t == 2 && p.vhdr) ? sc * exp2i(-vimage_exponent(p.vhdr[VSC_HDR_WORDS * (size_t)bh + VSC_HDR_AMAX])) : sc;
     bool f16_ovf = false;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
@@ -241,7 +263,7 @@ __global__ __launch_bounds__(256) void quantize_kernel(QuantParams p) {
             } else {
                 f16x8 hv;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) hv[j] = (_Float16)((float)q[j] * sc);
+                for (int j = 0; j < 8; ++j) hv[j] = (_Float16)((float)q[j] * scv);
                 *(f16x8*)(p.v16 + (orow0 + r) * p.DPQ + d0) = hv;
             }
             if (p.f16[t]) {
@@ -289,7 +311,7 @@ template <bool BF16> __device__ __forceinline__ float q16_elem(const u32x4_q& x,
 // one lane's CPL chunks -> int8 rows (Q / K) or de-quantised fp16 rows (V); FAST: the block's divisor allows the packed division
 template <int CPL, bool BF16, bool FAST, bool ISV>
 __device__ __forceinline__ void quantize_wave_convert(const u32x4_q (&xr)[CPL], int lane, uint32_t nchunks, float sc, float rcp1, int qlo, int qhi,
-                                                      int8_t* __restrict__ dst8, _Float16* __restrict__ dst16) {
+                                                      int8_t* __restrict__ dst8, _Float16* __restrict__ dst16, float scv) {
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
         const uint32_t ch = (uint32_t)lane + 64u * c;
@@ -315,7 +337,7 @@ __device__ __forceinline__ void quantize_wave_convert(const u32x4_q (&xr)[CPL], 
             } else {
                 f16x8 hv;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) hv[j] = (_Float16)((float)q[j] * sc);
+                for (int j = 0; j < 8; ++j) hv[j] = (_Float16)((float)q[j] * scv);
                 *(f16x8*)(dst16 + (int64_t)ch * 8) = hv;
             }
         }
@@ -353,6 +375,70 @@ __global__ __launch_bounds__(256) void quantize_wave_kernel(QuantParams p) {
     // shuffles -- 128 registers per lane at head_dim 128, two waves per SIMD instead of four)
 #pragma unroll
     for (int c = 0; c < CPL; ++c) asm volatile("" : "+v"(xr[c]));
+    int vexp = 0;  // V image: q * s * 2^-vexp, one exponent per (batch, head) slab
+    if (t == 2 && p.vhdr) {
+        uint32_t* const hw = p.vhdr + VSC_HDR_WORDS * (size_t)bh;
+        if (p.v_exchange) {
+            // The four waves of a workgroup hold four consecutive blocks of ONE slab (the launcher checked the alignment), the slab has
+            // <= 64 such workgroups: the V cast pass's exchange (fa_aux.hip cast_rows_body) -- a flag word per workgroup, wave 0 polls the
+            // slab's words with one load, a bounded wait, then it reads the slab for the amax itself; the last to leave cleans up.
+            __shared__ unsigned wg_amax[4], slab_amax;
+            const int wave = threadIdx.x >> 6;
+            if (lane == 0) wg_amax[wave] = __float_as_uint(amax) >> 16;
+            __syncthreads();
+            const uint32_t chunk = blk >> 2, chunks = p.nblk[2] >> 2;
+            if (wave == 0) {
+                unsigned m = wg_amax[0];
+                for (int w = 1; w < 4; ++w) m = wg_amax[w] > m ? wg_amax[w] : m;
+                if (lane == 0) __hip_atomic_store(hw + chunk, 0x80000000u | m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint64_t t_in = __builtin_amdgcn_s_memrealtime();
+                unsigned f;
+                bool served = true;
+                for (;;) {
+                    f = (uint32_t)lane < chunks ? __hip_atomic_load(hw + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x80000000u;
+                    if (__builtin_amdgcn_ballot_w64((f & 0x80000000u) == 0) == 0) break;
+                    if (__builtin_amdgcn_s_memrealtime() - t_in >= p.wait_ticks) { served = false; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                f &= 0x7fffffffu;
+                if (!served) {  // nobody promises that the slab's other workgroups are resident: help yourself
+                    const uint16_t* __restrict__ s0 = (const uint16_t*)p.src[2] + (int64_t)bh * p.rows[2] * (int64_t)(8 * cpr);
+                    const uint32_t total = p.rows[2] * cpr;
+                    f = 0;
+                    for (uint32_t i = (uint32_t)lane; i < total; i += 64) {
+                        const u32x4_q x = *(const u32x4_q*)(s0 + (int64_t)i * 8);
+                        float a = 0.0f;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) a = fmaxf(a, fabsf(q16_elem<BF16>(x, j)));
+                        const unsigned b = __float_as_uint(a) >> 16;
+                        f = b > f ? b : f;
+                    }
+                }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const unsigned o = (unsigned)__shfl_xor((int)f, off, 64);
+                    f = o > f ? o : f;
+                }
+                if (lane == 0) slab_amax = f;
+            }
+            __syncthreads();
+            vexp = vimage_exponent(slab_amax);
+            if (wave == 0) {  // leave: the last workgroup of the slab writes 2^e and zeroes the exchange words (every workgroup has read them by now)
+                unsigned d = 0;
+                if (lane == 0) d = __hip_atomic_fetch_add(hw + VSC_HDR_DEPART, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                d = (unsigned)__builtin_amdgcn_readfirstlane((int)d);
+                if (d == chunks - 1) {
+                    if ((uint32_t)lane < chunks) __hip_atomic_store(hw + lane, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane == 0) {
+                        hw[VSC_HDR_SCALE] = (unsigned)(127 + vexp) << 23;
+                        __hip_atomic_store(hw + VSC_HDR_DEPART, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+        } else {
+            vexp = vimage_exponent(hw[VSC_HDR_AMAX]);
+        }
+    }
     const float sc = amax > 0.0f ? amax / p.qmax : 1.0f;
     if (lane == 0) p.scale[t][bh * p.nblk[t] + blk] = sc;
     const float rcp0 = __builtin_amdgcn_rcpf(sc);
@@ -362,11 +448,12 @@ __global__ __launch_bounds__(256) void quantize_wave_kernel(QuantParams p) {
     int8_t* const d8 = (t == 0 ? p.q8 : p.k8) + base;
     _Float16* const d16 = p.v16 + base;
     if (t == 2) {
-        if (fast_div) quantize_wave_convert<CPL, BF16, true, true>(xr, lane, nchunks, sc, rcp1, p.qlo, p.qhi, d8, d16);
-        else quantize_wave_convert<CPL, BF16, false, true>(xr, lane, nchunks, sc, rcp1, p.qlo, p.qhi, d8, d16);
+        const float scv = sc * exp2i(-vexp);
+        if (fast_div) quantize_wave_convert<CPL, BF16, true, true>(xr, lane, nchunks, sc, rcp1, p.qlo, p.qhi, d8, d16, scv);
+        else quantize_wave_convert<CPL, BF16, false, true>(xr, lane, nchunks, sc, rcp1, p.qlo, p.qhi, d8, d16, scv);
     } else {
-        if (fast_div) quantize_wave_convert<CPL, BF16, true, false>(xr, lane, nchunks, sc, rcp1, p.qlo, p.qhi, d8, d16);
-        else quantize_wave_convert<CPL, BF16, false, false>(xr, lane, nchunks, sc, rcp1, p.qlo, p.qhi, d8, d16);
+        if (fast_div) quantize_wave_convert<CPL, BF16, true, false>(xr, lane, nchunks, sc, rcp1, p.qlo, p.qhi, d8, d16, sc);
+        else quantize_wave_convert<CPL, BF16, false, false>(xr, lane, nchunks, sc, rcp1, p.qlo, p.qhi, d8, d16, sc);
     }
 }
 
@@ -414,6 +501,7 @@ struct I8FwdParams {
     uint32_t B, H, Sq, Skv, D;
     uint32_t nqblk, nkblk;
     float scale;
+    const float* vsc;  // slab headers (kernels.h VSC_HDR_*): the V image is q * s * 2^-e, word VSC_HDR_SCALE of slab bh holds 2^e; NULL: plain q * s
 };
 
 template <int DP, bool CAUSAL, bool HAS_MASK, int BN>
@@ -674,7 +762,7 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
     }
 
     const float lt = l + xor32(l);
-    const float inv = lt > 0.0f ? 1.0f / lt : 0.0f;
+    const float inv = lt > 0.0f ? (1.0f / lt) * (p.vsc ? p.vsc[VSC_HDR_WORDS * (size_t)bh + VSC_HDR_SCALE] : 1.0f) : 0.0f;  // (2^e of the V image comes back here)
     if (q_row < p.Sq) {
         float* __restrict__ op = p.o + ((int64_t)bh * p.Sq + q_row) * D;
 #pragma unroll
@@ -689,6 +777,53 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
             }
         if (p.lse && hi == 0) p.lse[(int64_t)bh * p.Sq + q_row] = lt > 0.0f ? (m + log2f(lt)) * UMFA_LN2 : -INFINITY;
     }
+}
+
+// ---- V image exponent when the quantiser's own workgroups cannot exchange it (tensor-wise mode, fp32 operands, head dims without the
+// wave kernel, slabs of more than 64 x 4 blocks): the slab's amax first, into word VSC_HDR_AMAX of its header ...
+template <int PREC>
+__global__ __launch_bounds__(256) void vimage_amax_kernel(const void* __restrict__ src, int64_t slab8, uint32_t chunks, uint32_t* __restrict__ hdr) {
+    __shared__ unsigned wmax[4];
+    const uint32_t bh = blockIdx.x / chunks, chunk = blockIdx.x - bh * chunks;
+    constexpr int U = 8;
+    unsigned amax = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int64_t i = ((int64_t)chunk * U + u) * 256 + threadIdx.x;
+        if (i < slab8) {
+            float a = 0.0f;
+            if constexpr (PREC == P_FP32) {
+                const f32x4 lo = ((const f32x4*)src)[2 * ((int64_t)bh * slab8 + i)], hi = ((const f32x4*)src)[2 * ((int64_t)bh * slab8 + i) + 1];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a = fmaxf(a, fmaxf(fabsf(lo[j]), fabsf(hi[j])));
+            } else {
+                const u32x4_q x = ((const u32x4_q*)src)[(int64_t)bh * slab8 + i];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a = fmaxf(a, fabsf(PREC == P_BF16 ? q16_elem<true>(x, j) : q16_elem<false>(x, j)));
+            }
+            const unsigned b = __float_as_uint(a) >> 16;
+            amax = b > amax ? b : amax;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)amax, off, 64);
+        amax = o > amax ? o : amax;
+    }
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) amax = wmax[w] > amax ? wmax[w] : amax;
+        if (amax) (void)__hip_atomic_fetch_max(hdr + VSC_HDR_WORDS * (size_t)bh + VSC_HDR_AMAX, amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// ... and behind the quantiser: 2^e for the attention kernel's epilogue, the amax word back to zero
+__global__ __launch_bounds__(256) void vimage_finish_kernel(uint32_t* __restrict__ hdr, uint32_t slabs) {
+    const uint32_t s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= slabs) return;
+    uint32_t* const hw = hdr + VSC_HDR_WORDS * (size_t)s;
+    hw[VSC_HDR_SCALE] = (unsigned)(127 + vimage_exponent(hw[VSC_HDR_AMAX])) << 23;
+    hw[VSC_HDR_AMAX] = 0;
 }
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -728,7 +863,7 @@ bool quantized_supported(uint32_t D) { return D >= 8 && D % 8 == 0 && D <= 256; 
 
 hipError_t launch_quantize(const void* q, const void* k, const void* v, int in_prec, uint32_t B, uint32_t H,
                            uint32_t Sq, uint32_t Skv, uint32_t D, int bits, int quant_mode, void* workspace,
-                           int copies, QuantViews* views, hipStream_t stream, uint32_t* overflow) {
+                           int copies, QuantViews* views, hipStream_t stream, uint32_t* overflow, uint32_t* vhdr) {
     const bool want_f32 = copies != 0;  // the fp16 copies live in the (twice as large) fp32 regions
     const WsLayout w = ws_layout(B, H, Sq, Skv, D, want_f32);
     char* ws = (char*)workspace;
@@ -767,8 +902,27 @@ hipError_t launch_quantize(const void* q, const void* k, const void* v, int in_p
     if (quant_mode == 3) quant_mode = 2;
     const bool in16 = in_prec != P_FP32;
     qp.t_first = 0; qp.t_end = 3;
-    if (quant_mode == 2 && in16 && !want_f32 && !f8v && (D == 128 || D == 64) && !tuning().quant_block_wg.load(std::memory_order_relaxed) &&
-        ((uintptr_t)q & 15) == 0 && ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0) {
+    const bool wave_form = quant_mode == 2 && in16 && !want_f32 && !f8v && (D == 128 || D == 64) && !tuning().quant_block_wg.load(std::memory_order_relaxed) &&
+                           ((uintptr_t)q & 15) == 0 && ((uintptr_t)k & 15) == 0 && ((uintptr_t)v & 15) == 0;
+    // the fp16 V image as q * s * 2^-e (QuantParams::vhdr): the wave kernel's V workgroups exchange the slab's amax among themselves when
+    // they are whole (four blocks of one slab each) and <= 64 per slab; everything else gets the amax from a pass of its own
+    bool v_prepass = false;
+    if (vhdr && !f8v) {
+        qp.vhdr = vhdr;
+        qp.wait_ticks = (uint32_t)std::min<int64_t>(std::max(tuning().cast_wait_us.load(std::memory_order_relaxed), 0), 1000000) * 100u;
+        qp.v_exchange = wave_form && qp.nblk[2] % 4 == 0 && qp.nblk[2] / 4 <= 64 && ((uint64_t)qp.BH * (qp.nblk[0] + qp.nblk[1])) % 4 == 0 &&
+                        !tuning().cast_two_pass.load(std::memory_order_relaxed);
+        if (!qp.v_exchange) {
+            v_prepass = true;
+            const int64_t slab8 = (int64_t)Skv * D / 8;
+            const uint32_t chunks = (uint32_t)((slab8 + 8 * 256 - 1) / (8 * 256));
+            const dim3 g(qp.BH * chunks);
+            if (in_prec == P_FP32) hipLaunchKernelGGL(vimage_amax_kernel<P_FP32>, g, dim3(256), 0, stream, v, slab8, chunks, vhdr);
+            else if (in_prec == P_BF16) hipLaunchKernelGGL(vimage_amax_kernel<P_BF16>, g, dim3(256), 0, stream, v, slab8, chunks, vhdr);
+            else hipLaunchKernelGGL(vimage_amax_kernel<P_FP16>, g, dim3(256), 0, stream, v, slab8, chunks, vhdr);
+        }
+    }
+    if (wave_form) {
         // the hot configuration: one wave per block (quantize_wave_kernel).  (The fp8 P V mode keeps the workgroup form for all three
         // tensors: its V image needs the workgroup's LDS transpose, and a second launch for Q / K alone cost 4 us of a 165-us call.)
         QuantParams qw = qp;
@@ -790,6 +944,7 @@ hipError_t launch_quantize(const void* q, const void* k, const void* v, int in_p
         if (in16) hipLaunchKernelGGL((quantize_kernel<1, true>), dim3(grid), dim3(256), 0, stream, qp);
         else hipLaunchKernelGGL((quantize_kernel<1, false>), dim3(grid), dim3(256), 0, stream, qp);
     }
+    if (v_prepass) hipLaunchKernelGGL(vimage_finish_kernel, dim3((qp.BH + 255) / 256), dim3(256), 0, stream, vhdr, qp.BH);
     if (views) {
         views->q8 = qp.q8; views->k8 = qp.k8; views->v16 = qp.v16;
         views->v8 = qp.v8; views->v_e8 = qp.v_e8;
@@ -827,13 +982,15 @@ hipError_t launch_quantized_fwd(const FwdParams& fp, int bits, int quant_mode, v
     // block-wise int8 path (mode 2), which is the more accurate of the two
     if (quant_mode == 3 && !(bits == 8 && fp.part_buf && fp.part_cnt && fwd_w64_i8_supported(fp))) quant_mode = 2;
     QuantViews v;
+    // fp.vsc: the (device, stream) pool's slab headers (runtime: StreamScratch::ensure_v16) -- the fp16 V image goes in as q * s * 2^-e
     hipError_t e = launch_quantize(fp.q, fp.k, fp.v, fp.in_prec, fp.B, fp.H, fp.Sq, fp.Skv, fp.D, bits, quant_mode,
-                                   workspace, 0, &v, stream);
+                                   workspace, 0, &v, stream, nullptr, (uint32_t*)fp.vsc);
     if (e != hipSuccess) return e;
     I8FwdParams p;
     memset(&p, 0, sizeof(p));
     p.q8 = v.q8; p.k8 = v.k8; p.v16 = (const _Float16*)v.v16;
     p.q_scale = v.q_scale; p.k_scale = v.k_scale;
+    p.vsc = v.v8 ? nullptr : fp.vsc;
     p.o = (float*)fp.o; p.lse = fp.lse;
     p.mask = (const float*)fp.mask;
     if (fp.mask && !tuning().no_mask_flags.load(std::memory_order_relaxed)) {

@@ -104,7 +104,7 @@ hipError_t launch_dequant(const DequantParams& p, hipStream_t stream);
 // bf16 [B,H,S,D] with element strides (head_dim contiguous) -> dense fp16 [B,H,S,D] of V * 2^-e, one power of two per (batch, head)
 // slab chosen from the slab's largest |v| (no value leaves fp16's range); hdr: VSC_HDR_WORDS uint32 per slab, zero on entry except word
 // VSC_HDR_SCALE, which the pass leaves holding 2^e as fp32 (FwdParams::vsc reads it)
-constexpr uint32_t VSC_HDR_WORDS = 128, VSC_HDR_SCALE = 65;
+constexpr uint32_t VSC_HDR_WORDS = 128, VSC_HDR_DEPART = 64, VSC_HDR_SCALE = 65, VSC_HDR_AMAX = 66;
 hipError_t launch_cast_rows_bf16_to_f16(const void* src, const int64_t* strides, void* dst, uint32_t B, uint32_t H, uint32_t S, uint32_t D,
                                         uint32_t* hdr, hipStream_t stream);
 // *flag |= 1 when any of x[0 .. n) (fp32, 16-byte aligned) is not finite
@@ -142,7 +142,8 @@ size_t quant_workspace_bytes(uint32_t B, uint32_t H, uint32_t Sq, uint32_t Skv, 
 // MFMA backward; *overflow |= 1 when q * scale does not fit fp16)
 hipError_t launch_quantize(const void* q, const void* k, const void* v, int in_prec, uint32_t B, uint32_t H,
                            uint32_t Sq, uint32_t Skv, uint32_t D, int bits, int quant_mode, void* workspace,
-                           int copies, QuantViews* views, hipStream_t stream, uint32_t* overflow = nullptr);
+                           int copies, QuantViews* views, hipStream_t stream, uint32_t* overflow = nullptr,
+                           uint32_t* vhdr = nullptr /* slab headers (VSC_HDR_*): the fp16 V image becomes q * s * 2^-e, 2^e left in word VSC_HDR_SCALE */);
 // fp.q/k/v: contiguous BHSD in fp.in_prec; fp.o fp32; fp.mask: fp32 additive [B,H,Sq,Skv] or NULL.
 hipError_t launch_quantized_fwd(const FwdParams& fp, int bits, int quant_mode, void* workspace, hipStream_t stream,
                                 const char** name);

@@ -233,6 +233,11 @@ int32_t mfa_quantized_forward_with_lse(mfa_context_t context, mfa_buffer_t q, mf
         p.part_cnt = (uint32_t*)w64;
         p.part_buf = (float*)(w64 + sc.w64_cnt_bytes);
     }
+    {   // slab headers for the fp16 V image's power of two (fa_quant.hip QuantParams::vhdr): the default bf16 forward's pool, headers only
+        char* vh = ctx->pool(pool_dev, stream).ensure_v16((size_t)B * H, 0, stream);
+        if (!vh) return MFA_ERROR_MEMORY_ALLOCATION;
+        p.vsc = (const float*)vh; p.vsc_bs = H; p.vsc_hs = 1;
+    }
     LatencyScope lat(ctx, stream);
     const char* name = "none";
     hipError_t e = launch_quantized_fwd(p, bits, mode, ws, stream, &name);
@@ -280,6 +285,11 @@ mfa_error_t umfa_quantized_forward_stream(mfa_context_t context, void* stream, c
         if (!w64) return MFA_ERROR_MEMORY_ALLOCATION;
         p.part_cnt = (uint32_t*)w64;
         p.part_buf = (float*)(w64 + sc.w64_cnt_bytes);
+    }
+    {   // slab headers for the fp16 V image's power of two, see mfa_quantized_forward_with_lse
+        char* vh = ctx->pool(pool_dev, (hipStream_t)stream).ensure_v16((size_t)B * H, 0, (hipStream_t)stream);
+        if (!vh) return MFA_ERROR_MEMORY_ALLOCATION;
+        p.vsc = (const float*)vh; p.vsc_bs = H; p.vsc_hs = 1;
     }
     const char* name = "none";
     hipError_t e = launch_quantized_fwd(p, bits, mode, ws, (hipStream_t)stream, &name);
