@@ -381,8 +381,10 @@ mfa_error_t umfa_quantized_forward_stream(mfa_context_t context, void* stream, c
 
 /* MI355X extra: mfa_quantized_backward in-stream (dense BHSD device pointers, caller's stream, never synchronises).
  * Same engines as the blocking entry (16-bit MFMA backward on fp16 de-quantised operands at head_dim 64 / 128 / 256,
- * else fp32-exact).  status: optional device uint32, zeroed on the stream and set to 1 when an operand left fp16's range
- * (the gradients are then invalid: repeat through mfa_quantized_backward, which falls back by itself). */
+ * else fp32-exact).  Every operand enters the fp16 engine as a power-of-two multiple with its largest magnitude in [1, 2) -- the
+ * de-quantised Q, K, V and dO, exponents found on the device, handed back through the softmax scale, D and the gradients' epilogues
+ * -- so nothing in it can leave fp16's range (dO of 1e-9 or V of 1e12 included).  status: optional device uint32, zeroed on the
+ * stream; kept for callers written against round 4, which set it to 1 for an operand outside fp16's range -- it stays 0 now. */
 mfa_error_t umfa_quantized_backward_stream(mfa_context_t context, void* stream, const void* q, const void* k,
                                            const void* v, const float* out, const void* dout, const float* lse, float* dq,
                                            float* dk, float* dv, uint32_t* status, uint32_t batch_size, uint32_t seq_len_q,

@@ -262,8 +262,8 @@ def test_quantized_forward_stream_entry_matches_blocking(shape, causal, bits, mo
 @pytest.mark.parametrize("D,dt", [(128, "bf16"), (64, "fp16"), (80, "bf16")])
 def test_quantized_backward_stream_entry_matches_the_blocking_entry(ctx, D, dt):
     """umfa_quantized_backward_stream (in-stream, raw device pointers) = mfa_quantized_backward's numbers: the 16-bit MFMA
-    engine at head_dim 64 / 128 (status stays 0), the fp32-exact engine at head_dim 80; and a V beyond fp16's range raises
-    the status word instead of returning wrong gradients silently."""
+    engine at head_dim 64 / 128 (status stays 0), the fp32-exact engine at head_dim 80; and a V beyond fp16's range goes through the fp16
+    engine like any other (every operand enters it as a power-of-two multiple)."""
     import ctypes
     import torch
     import umfa_torch
@@ -296,10 +296,16 @@ def test_quantized_backward_stream_entry_matches_the_blocking_entry(ctx, D, dt):
         assert torch.equal(a, b)
     if D != 80:
         big = (v.float() * 3.0e5).to(tdt) if dt == "bf16" else None
-        if big is not None:  # bf16 V beyond 65504
-            _, _, _, st = umfa_torch.quantized_attention_backward_stream(do, q, k, big, o, lse)
+        if big is not None:  # bf16 V beyond 65504: the fp16 engine takes it as a power-of-two multiple (round 5; a status of 1 and no gradients before)
+            o2, lse2 = umfa_torch.quantized_attention_forward_stream(q, k, big, return_lse=True)
+            g2 = umfa_torch.quantized_attention_backward_stream(do, q, k, big, o2, lse2)
+            with umfa_torch.options(bwd_exact=1):
+                r2 = umfa_torch.quantized_attention_backward_stream(do, q, k, big, o2, lse2)
             torch.cuda.synchronize()
-            assert int(st.item()) == 1
+            assert int(g2[3].item()) == 0
+            for a, b in zip(g2[:3], r2[:3]):
+                assert torch.isfinite(a).all()
+                assert float((a.double() - b.double()).abs().max() / b.double().abs().max()) < 2e-3
 
 
 @pytest.mark.parametrize("D,dt", [(128, "bf16"), (64, "bf16"), (128, "fp16")])
@@ -392,3 +398,28 @@ def test_quantized_forward_v_exchange_without_waiting():
     torch.cuda.synchronize()
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
+
+
+@pytest.mark.parametrize("gq,gk,gv", [(1e-4, 1e4, 1e-7), (3e2, 3e-3, 1e6), (1.0, 1.0, 1e12), (1e-3, 1e3, 1.0)])
+@pytest.mark.parametrize("D,causal", [(128, False), (64, True), (256, False)])
+def test_quantized_backward_over_the_range_of_every_operand(D, causal, gq, gk, gv):
+    """Q, K, V of any magnitude (their product Q K^T kept where a softmax makes sense): the quantiser's fp16 copies are q * s * 2^-e with the
+    tensor's largest magnitude in [1, 2), dO likewise, the exponents come back through BwdParams::units (softmax scale, D, the three
+    gradients).  Against the fp32-exact engine on the same inputs; status 0; blocking entry = in-stream entry."""
+    import torch
+    import umfa_torch
+    torch.manual_seed(23)
+    B, H, S = 1, 2, 384
+    q, k, v, do = (torch.randn(B, H, S, D, device="cuda") for _ in range(4))
+    q, k, v, do = (q * gq).bfloat16(), (k * gk).bfloat16(), (v * gv).bfloat16(), (do * 1e-6).bfloat16()
+    o, lse = umfa_torch.quantized_attention_forward_stream(q, k, v, causal=causal, return_lse=True)
+    with umfa_torch.options(bwd_exact=1):
+        ref = umfa_torch.quantized_attention_backward_stream(do, q, k, v, o, lse, causal=causal)
+    got = umfa_torch.quantized_attention_backward_stream(do, q, k, v, o, lse, causal=causal)
+    torch.cuda.synchronize()
+    assert umfa_torch.last_kernel().startswith("fa_bwd16<fp16"), umfa_torch.last_kernel()
+    assert int(got[3].item()) == 0
+    for a, b, name in zip(got[:3], ref[:3], ("dq", "dk", "dv")):
+        a, b = a.double(), b.double()
+        assert torch.isfinite(a).all(), name
+        assert float((a - b).abs().max() / b.abs().max()) < 2e-3, (name, float((a - b).abs().max() / b.abs().max()))

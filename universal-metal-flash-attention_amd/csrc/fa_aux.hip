@@ -190,8 +190,8 @@ __global__ __launch_bounds__(256) void dequant_kernel(DequantParams p) {
 }
 
 // row constants of bwd16_dkdv from (LSE, D) when the dQ kernel that normally writes them ran in another call
-__global__ __launch_bounds__(256) void bwd16_rowc_kernel(const float* lse, const float* dvec, float* rowc, int64_t n, const float* gscale) {
-    const float to_dout_units = gscale ? gscale[1] : 1.0f;  // the caller's D is in true units, the kernels' dO is dO * 2^-e
+__global__ __launch_bounds__(256) void bwd16_rowc_kernel(const float* lse, const float* dvec, float* rowc, int64_t n, const float* d_mul) {
+    const float to_dout_units = d_mul ? d_mul[0] : 1.0f;  // the caller's D is in true units, the kernels' dO (and V) are power-of-two multiples
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         rowc[i] = -lse[i] * UMFA_LOG2E;
         rowc[n + i] = -dvec[i] * to_dout_units;
@@ -283,12 +283,6 @@ __global__ __launch_bounds__(256) void amax_dense_kernel(const void* src, int64_
         if (amax) (void)__hip_atomic_fetch_max(hdr, amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-__device__ __forceinline__ int unit_exponent(unsigned amax_bits) {  // e with amax * 2^-e in [1, 2); 0 for an all-zero or non-finite tensor
-    if (amax_bits == 0 || amax_bits >= 0x7f800000u) return 0;
-    const int E = (int)(amax_bits >> 23);
-    const int e = (E ? E : 1) - 127;
-    return e < -126 ? -126 : e > 126 ? 126 : e;
-}
 template <int PREC>
 __global__ __launch_bounds__(256) void cast_f16_unit_kernel(const void* src, _Float16* dst, int64_t n8, uint32_t* hdr) {
     const int e = unit_exponent(hdr[0]);
@@ -305,6 +299,35 @@ __global__ __launch_bounds__(256) void cast_f16_unit_kernel(const void* src, _Fl
         for (int j = 0; j < 8; ++j) o[j] = (_Float16)(x[j] * mul);
         ((f16x8*)dst)[i] = o;
     }
+}
+
+// the largest |x| of a dense tensor, as fp32 bits, max-ed into *word (the caller zeroes it)
+hipError_t launch_amax_dense(const void* src, int prec, int64_t n, uint32_t* word, hipStream_t stream) {
+    if (!src || !word || (n & 7) || (prec != P_FP32 && prec != P_BF16 && prec != P_FP16)) return hipErrorInvalidValue;
+    const int64_t n8 = n / 8;
+    const unsigned agrid = (unsigned)((n8 + 255) / 256 < 1024 ? ((n8 + 255) / 256 ? (n8 + 255) / 256 : 1) : 1024);
+    if (prec == P_FP32) hipLaunchKernelGGL(amax_dense_kernel<P_FP32>, dim3(agrid), dim3(256), 0, stream, src, n8, word);
+    else if (prec == P_BF16) hipLaunchKernelGGL(amax_dense_kernel<P_BF16>, dim3(agrid), dim3(256), 0, stream, src, n8, word);
+    else hipLaunchKernelGGL(amax_dense_kernel<P_FP16>, dim3(agrid), dim3(256), 0, stream, src, n8, word);
+    return hipGetLastError();
+}
+
+// BwdParams::units from the four tensors' largest magnitudes (fp32 bits): hdr[0] dO, hdr[4] Q, hdr[5] K, hdr[6] V -> floats hdr[8 ... 14]
+__global__ void bwd_units_kernel(uint32_t* hdr) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int edo = unit_exponent(hdr[0]), eq = unit_exponent(hdr[4]), ek = unit_exponent(hdr[5]), ev = unit_exponent(hdr[6]);
+    float* t = (float*)(hdr + 8);
+    t[0] = __builtin_amdgcn_ldexpf(1.0f, eq + ek);
+    t[1] = __builtin_amdgcn_ldexpf(1.0f, edo + ev + ek);
+    t[2] = __builtin_amdgcn_ldexpf(1.0f, edo + ev + eq);
+    t[3] = __builtin_amdgcn_ldexpf(1.0f, edo);
+    t[4] = __builtin_amdgcn_ldexpf(1.0f, -ev);
+    t[5] = __builtin_amdgcn_ldexpf(1.0f, edo);
+    t[6] = __builtin_amdgcn_ldexpf(1.0f, -(edo + ev));
+}
+hipError_t launch_bwd_units(uint32_t* hdr, hipStream_t stream) {
+    hipLaunchKernelGGL(bwd_units_kernel, dim3(1), dim3(64), 0, stream, hdr);
+    return hipGetLastError();
 }
 
 hipError_t launch_cast_f16_unit(const void* src, int prec, void* dst, int64_t n, uint32_t* hdr, hipStream_t stream) {
@@ -676,10 +699,10 @@ static hipError_t launch_cast_rows_any(const void* src, const int64_t* strides, 
     return launch_cast_rows_u<16>(src, strides, dst, B, H, S, D, hdr, stream, mk);
 }
 
-hipError_t launch_bwd16_rowc(const float* lse, const float* dvec, float* rowc, int64_t n, const float* gscale, hipStream_t stream) {
+hipError_t launch_bwd16_rowc(const float* lse, const float* dvec, float* rowc, int64_t n, const float* d_mul, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(bwd16_rowc_kernel, dim3(grid), dim3(256), 0, stream, lse, dvec, rowc, n, gscale);
+    hipLaunchKernelGGL(bwd16_rowc_kernel, dim3(grid), dim3(256), 0, stream, lse, dvec, rowc, n, d_mul);
     return hipGetLastError();
 }
 

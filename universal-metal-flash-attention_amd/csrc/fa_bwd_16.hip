@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void bwd16_delta_kernel(BwdParams p) {
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (lane == 0) p.dvec[row] = s * grad_unit(p);
+    if (lane == 0) p.dvec[row] = s * unit_dvec(p);
 }
 
 // ------------------------------------------------------------------------------------------------ dQ
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256, DP == 256 ? 1 : 2) void bwd16_dq_kernel(BwdPar
             for (int j = 0; j < 8; ++j) { qf[ks][j] = (T)0.0f; dof[ks][j] = (T)0.0f; }
         }
     }
-    const float c = p.scale * UMFA_LOG2E;
+    const float c = p.scale * UMFA_LOG2E * unit_c(p);  // (unit_c: operands that arrive as power-of-two multiples, BwdParams::units)
     const float L2 = qok ? p.lse[(int64_t)bh * p.Sq + q_row] * UMFA_LOG2E : INFINITY;  // +inf -> P = 0
     // D[q] = rowsum(dO o O), fused here (the reference zeroes and fills a D scratch in its own pass): this lane already
     // holds dO[q][16 ks + 8 hi .. +7] for every k-step -- half of the row -- so it reads the same half of O (fp32, or the
@@ -230,9 +230,11 @@ __global__ __launch_bounds__(256, DP == 256 ? 1 : 2) void bwd16_dq_kernel(BwdPar
         }
     }
     delta += __shfl_xor(delta, 32, 64);
+    const float delta_out = delta * unit_dvec(p);  // D in true units for the caller ...
+    delta *= unit_rowd(p);                         // ... and in dP's units (dO and V arrive as power-of-two multiples) for this kernel and bwd16_dkdv
     if (qok && hi == 0) {
         const int64_t ri = (int64_t)bh * p.Sq + q_row;
-        p.dvec[ri] = delta * grad_unit(p);  // (D in true units for the caller; the row constants below stay in dO's)
+        p.dvec[ri] = delta_out;
         // ... and, for bwd16_dkdv, the two row constants in the form it consumes them: the addend of the exponent FMA and
         // the initial value of the dP accumulator (dP - D comes out of the MFMA chain) -- 64 vector instructions per tile
         // (32 multiplies, 32 subtractions) that its loop no longer issues
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(256, DP == 256 ? 1 : 2) void bwd16_dq_kernel(BwdPar
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    const float osc = p.scale * grad_unit(p);
+    const float osc = p.scale * unit_dq(p);
     if (qok) {
         const int64_t orow = ((int64_t)bh * p.Sq + q_row) * DP;
 #pragma unroll
@@ -425,7 +427,7 @@ __global__ __launch_bounds__(256, 1) void bwd16_dq2_kernel(BwdParams p) {
             for (int j = 0; j < 8; ++j) { qf[ks][j] = (T)0.0f; dof[ks][j] = (T)0.0f; }
         }
     }
-    const float c = p.scale * UMFA_LOG2E;
+    const float c = p.scale * UMFA_LOG2E * unit_c(p);  // (unit_c: operands that arrive as power-of-two multiples, BwdParams::units)
     const float L2 = qok ? p.lse[(int64_t)bh * p.Sq + q_row] * UMFA_LOG2E : INFINITY;  // +inf -> P = 0
     // D[q] = rowsum(dO o O), fused here as in bwd16_dq (see there)
     float delta = 0.0f;
@@ -449,9 +451,11 @@ __global__ __launch_bounds__(256, 1) void bwd16_dq2_kernel(BwdParams p) {
         }
     }
     delta += __shfl_xor(delta, 32, 64);
+    const float delta_out = delta * unit_dvec(p);  // D in true units for the caller ...
+    delta *= unit_rowd(p);                         // ... and in dP's units (dO and V arrive as power-of-two multiples) for this kernel and bwd16_dkdv
     if (qok && hi == 0) {
         const int64_t ri = (int64_t)bh * p.Sq + q_row;
-        p.dvec[ri] = delta * grad_unit(p);  // (D in true units for the caller; the row constants below stay in dO's)
+        p.dvec[ri] = delta_out;
         p.rowc[ri] = -L2;                                        // row constants for bwd16_dkdv (see bwd16_dq)
         p.rowc[(int64_t)p.B * p.H * p.Sq + ri] = -delta;
     }
@@ -575,7 +579,7 @@ __global__ __launch_bounds__(256, 1) void bwd16_dq2_kernel(BwdParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    const float osc = p.scale * grad_unit(p);
+    const float osc = p.scale * unit_dq(p);
     if (p.grad_in_type) {  // operand-type dQ: through per-wave LDS rows, whole 256-byte rows out (see bwd16_dkdv's epilogue)
         char* stg = smem + wave * 8192;
         typedef T T4 __attribute__((ext_vector_type(4)));
@@ -697,7 +701,7 @@ __global__ __launch_bounds__(256, 1) void bwd16_dq_gemm_kernel(BwdParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the ring's last (out-of-range) requests: the epilogue below reuses the tile area
     __syncthreads();
-    const float osc = p.scale * grad_unit(p);
+    const float osc = p.scale * unit_dq(p);
     if (p.grad_in_type) {  // operand-type dQ through per-wave LDS rows (see bwd16_dq2)
         char* stg = smem + wave * 8192;
         typedef T T4 __attribute__((ext_vector_type(4)));
@@ -828,7 +832,7 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+a"(kf[ks]), "+a"(vf[ks]));
     }
-    const float c = p.scale * UMFA_LOG2E;
+    const float c = p.scale * UMFA_LOG2E * unit_c(p);  // (unit_c: operands that arrive as power-of-two multiples, BwdParams::units)
     // query tiles of 64 rows = two 32-row sub-tiles per barrier: both S/dP products are issued before the first
     // sub-tile's exp/convert work, so the wave has matrix work in flight while its VALU runs
     constexpr int QROWS = 64, QTILE_B = QROWS * ROW_B;
@@ -1127,7 +1131,7 @@ __global__ __launch_bounds__(256, DP == 64 ? 2 : 1) void bwd16_dkdv_kernel(BwdPa
 #ifdef BWD16_LAB_STAMP
     rt_loop1 = __builtin_amdgcn_s_memrealtime();
 #endif
-    const float gsv = grad_unit(p), osc = p.scale * gsv;
+    const float gsv = unit_dv(p), osc = p.scale * unit_dk(p);
     if (DP == 128 && p.grad_in_type && !p.dkdv_fp32) {
         // Gradients in the operand type (in-stream entry), head_dim 128: a lane holds 4 consecutive d of ONE key per register
         // group, so direct stores touch 32 rows x 8 bytes per instruction (64 scattered store instructions per wave and
@@ -1220,7 +1224,7 @@ static hipError_t launch_bwd16_t(const BwdParams& p, hipStream_t stream) {
             const BwdParams& p = pl;
             // dS-store form: D, row constants, dK / dV (+ dS to the scratch), dQ = scale dS K
             hipLaunchKernelGGL(bwd16_delta_kernel<DP>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, p);
-            if (hipError_t e = launch_bwd16_rowc(p.lse, p.dvec, p.rowc, rows, p.gscale, stream); e != hipSuccess) return e;
+            if (hipError_t e = launch_bwd16_rowc(p.lse, p.dvec, p.rowc, rows, p.units ? p.units + 6 : p.gscale ? p.gscale + 1 : nullptr, stream); e != hipSuccess) return e;
             if (hipError_t e = ensure_dynamic_lds((const void*)bwd16_dkdv_kernel<T, false, DP, true>, lds_kv); e != hipSuccess) return e;
             hipLaunchKernelGGL((bwd16_dkdv_kernel<T, false, DP, true>), dim3(nkb * p.B * p.H), dim3(256), lds_kv, stream, p);
             const size_t lds_g = 4 * 2 * 64 * 2 * DP;  // four slots of (K tile, dS^T tile)
@@ -1230,7 +1234,7 @@ static hipError_t launch_bwd16_t(const BwdParams& p, hipStream_t stream) {
         }
     }
     if (!(ph & 3)) {
-        if (hipError_t e = launch_bwd16_rowc(p.lse, p.dvec, p.rowc, rows, p.gscale, stream); e != hipSuccess) return e;
+        if (hipError_t e = launch_bwd16_rowc(p.lse, p.dvec, p.rowc, rows, p.units ? p.units + 6 : p.gscale ? p.gscale + 1 : nullptr, stream); e != hipSuccess) return e;
     } else
     if constexpr (DP == 128) {
         // one-workgroup-per-CU kernel for non-causal launches (same box, ms per backward, v2 / two-per-CU: FLUX 0.678 / 0.693,

@@ -55,6 +55,7 @@ struct QuantParams {
     // v_exchange 1: quantize_wave_kernel's V workgroups find the slab's amax among themselves (the cast pass's flag-word exchange, four
     // blocks per workgroup); 0: word VSC_HDR_AMAX holds it (vimage_amax_kernel ran before, vimage_finish_kernel runs behind).
     uint32_t* vhdr;
+    const uint32_t* famax;  // f16 copies (the backward's operands) as q * s * 2^-e_t, e_t from the tensor's largest magnitude (fp32 bits) in famax[t]; NULL: e_t = 0
     int v_exchange;
     uint32_t wait_ticks;  // bound of the exchange's wait (100 MHz ticks), then the workgroup reads the slab itself
 };
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(256) void quantize_kernel(QuantParams p) {
     const bool fast_div = sc >= 0x1p-60f && sc <= 0x1p60f;
     // (V image: q * s * 2^-e, e from the slab's amax that vimage_amax_kernel left in the slab's header)
     const float scv = (t == 2 && p.vhdr) ? sc * exp2i(-vimage_exponent(p.vhdr[VSC_HDR_WORDS * (size_t)bh + VSC_HDR_AMAX])) : sc;
+    const float scf = p.famax ? sc * exp2i(-unit_exponent(p.famax[t])) : sc;  // (the backward's fp16 operands: amax 2^-e in [1, 2))
     bool f16_ovf = false;
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(256) void quantize_kernel(QuantParams p) {
                 f16x8 hv;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float y = (float)q[j] * sc;
+                    const float y = (float)q[j] * scf;
                     f16_ovf |= !(fabsf(y) <= 65504.0f);
                     hv[j] = (_Float16)y;
                 }
@@ -863,7 +865,7 @@ bool quantized_supported(uint32_t D) { return D >= 8 && D % 8 == 0 && D <= 256; 
 
 hipError_t launch_quantize(const void* q, const void* k, const void* v, int in_prec, uint32_t B, uint32_t H,
                            uint32_t Sq, uint32_t Skv, uint32_t D, int bits, int quant_mode, void* workspace,
-                           int copies, QuantViews* views, hipStream_t stream, uint32_t* overflow, uint32_t* vhdr) {
+                           int copies, QuantViews* views, hipStream_t stream, uint32_t* overflow, uint32_t* vhdr, const uint32_t* famax) {
     const bool want_f32 = copies != 0;  // the fp16 copies live in the (twice as large) fp32 regions
     const WsLayout w = ws_layout(B, H, Sq, Skv, D, want_f32);
     char* ws = (char*)workspace;
@@ -885,6 +887,7 @@ hipError_t launch_quantize(const void* q, const void* k, const void* v, int in_p
         qp.f16[1] = (_Float16*)(ws + w.f32k);
         qp.f16[2] = (_Float16*)(ws + w.f32v);
         qp.overflow = overflow;
+        qp.famax = famax;
     }
     qp.rows[0] = Sq; qp.rows[1] = Skv; qp.rows[2] = Skv;
     for (int t = 0; t < 3; ++t) qp.nblk[t] = (qp.rows[t] + QBLK - 1) / QBLK;

@@ -110,10 +110,15 @@ hipError_t launch_cast_rows_bf16_to_f16(const void* src, const int64_t* strides,
 // *flag |= 1 when any of x[0 .. n) (fp32, 16-byte aligned) is not finite
 hipError_t launch_nonfinite_flag(const float* x, int64_t n, uint32_t* flag, hipStream_t stream);
 // rowc[0 .. n) = -lse * log2 e, rowc[n .. 2n) = -dvec: what bwd16_dq leaves for bwd16_dkdv, for a dK / dV-only call
-hipError_t launch_bwd16_rowc(const float* lse, const float* dvec, float* rowc, int64_t n, const float* gscale, hipStream_t stream);
+hipError_t launch_bwd16_rowc(const float* lse, const float* dvec, float* rowc, int64_t n, const float* d_mul /* one float onto D, or NULL */, hipStream_t stream);
 // dO of the quantised backward entries -> fp16 as dO * 2^-e, one power of two per call from the tensor's largest |dO| (device);
 // hdr = 3 words: amax bits, 2^e, 2^-e = what BwdParams::gscale points at (hdr + 1)
 hipError_t launch_cast_f16_unit(const void* src, int prec, void* dst, int64_t n, uint32_t* hdr, hipStream_t stream);
+// the quantised backward with EVERY operand as a power-of-two multiple (BwdParams::units): a 16-word header -- [0 ... 2] as above for dO,
+// [4 ... 6] the largest |q|, |k|, |v| as fp32 bits (launch_amax_dense into a zeroed word; the quantiser scales its fp16 copies by them:
+// launch_quantize's famax), [8 ... 14] the units table (launch_bwd_units, after all four)
+hipError_t launch_amax_dense(const void* src, int prec, int64_t n, uint32_t* word, hipStream_t stream);
+hipError_t launch_bwd_units(uint32_t* hdr, hipStream_t stream);
 // dst: [B, Hkv, slab] in out_prec (fp32 default; fp16 / bf16: rounded once after the fp32 sum)
 hipError_t launch_group_sum(const float* src, void* dst, uint32_t B, uint32_t H, uint32_t Hkv, int64_t slab, hipStream_t stream,
                             int out_prec = P_FP32);
@@ -143,7 +148,9 @@ size_t quant_workspace_bytes(uint32_t B, uint32_t H, uint32_t Sq, uint32_t Skv, 
 hipError_t launch_quantize(const void* q, const void* k, const void* v, int in_prec, uint32_t B, uint32_t H,
                            uint32_t Sq, uint32_t Skv, uint32_t D, int bits, int quant_mode, void* workspace,
                            int copies, QuantViews* views, hipStream_t stream, uint32_t* overflow = nullptr,
-                           uint32_t* vhdr = nullptr /* slab headers (VSC_HDR_*): the fp16 V image becomes q * s * 2^-e, 2^e left in word VSC_HDR_SCALE */);
+                           uint32_t* vhdr = nullptr /* slab headers (VSC_HDR_*): the fp16 V image becomes q * s * 2^-e, 2^e left in word VSC_HDR_SCALE */,
+                           const uint32_t* famax = nullptr /* copies == 2: three words, the largest |q|, |k|, |v| (fp32 bits): the fp16 copies
+                                                              become q * s * 2^-e_t with amax_t 2^-e_t in [1, 2) */);
 // fp.q/k/v: contiguous BHSD in fp.in_prec; fp.o fp32; fp.mask: fp32 additive [B,H,Sq,Skv] or NULL.
 hipError_t launch_quantized_fwd(const FwdParams& fp, int bits, int quant_mode, void* workspace, hipStream_t stream,
                                 const char** name);

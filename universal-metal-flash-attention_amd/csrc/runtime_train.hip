@@ -349,11 +349,17 @@ int32_t mfa_quantized_backward(mfa_context_t context, mfa_buffer_t q, mfa_buffer
         char* ws = (char*)ctx->pool(pool_dev, stream).workspace.ensure((fast ? o_flag + 256 : o_do16) + 256, stream);
         if (!ws) return MFA_ERROR_MEMORY_ALLOCATION;
         uint32_t* flag = (uint32_t*)(ws + o_flag);
-        if (fast && hipMemsetAsync(flag, 0, 4, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+        // FAST: every operand goes to the fp16 engine as a power-of-two multiple with its largest magnitude in [1, 2) -- the de-quantised Q, K, V
+        // (the quantiser's fp16 copies) and dO; the exponents are found on the device (one amax pass per tensor) and come back through
+        // BwdParams::units.  Nothing can leave fp16's range then, dS = P (dP - D) included (|dS| <= 8 head_dim): no flag to read, no repeat.
+        uint32_t* unit = flag + 16;  // 16 words: kernels.h launch_bwd_units
+        if (fast && hipMemsetAsync(flag, 0, 256, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
         LatencyScope lat(ctx, stream);
+        if (fast && (launch_amax_dense(bq->dev, prec, (int64_t)nq, unit + 4, stream) != hipSuccess || launch_amax_dense(bk->dev, prec, (int64_t)nkv, unit + 5, stream) != hipSuccess ||
+                     launch_amax_dense(bv->dev, prec, (int64_t)nkv, unit + 6, stream) != hipSuccess)) return MFA_ERROR_EXECUTION_FAILED;
         QuantViews views;
         hipError_t e = launch_quantize(bq->dev, bk->dev, bv->dev, prec, B, H, Sq, Skv, D, bits, mode, ws, fast ? 2 : 1, &views, stream,
-                                       fast ? flag : nullptr);
+                                       fast ? flag : nullptr, nullptr, fast ? unit + 4 : nullptr);
         if (e != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
         BwdParams p;
         memset(&p, 0, sizeof(p));
@@ -368,10 +374,10 @@ int32_t mfa_quantized_backward(mfa_context_t context, mfa_buffer_t q, mfa_buffer
             p.in_prec = P_FP16; p.dout_prec = P_FP16;
             // dO as dO * 2^-e in fp16, e from its largest magnitude on the device (gradients of 1e-7 are ordinary; as a plain cast they
             // were fp16 subnormals): fa_aux.hip launch_cast_f16_unit, 2^e comes back in the kernels' epilogues
-            uint32_t* unit = (uint32_t*)(ws + o_flag) + 16;
-            if (launch_cast_f16_unit(bdo->dev, prec, ws + o_do16, (int64_t)nq, unit, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+            if (launch_cast_f16_unit(bdo->dev, prec, ws + o_do16, (int64_t)nq, unit, stream) != hipSuccess || launch_bwd_units(unit, stream) != hipSuccess)
+                return MFA_ERROR_EXECUTION_FAILED;
             p.dout = ws + o_do16;
-            p.gscale = (const float*)(unit + 1);
+            p.units = (const float*)(unit + 8);
             p.rowc = (float*)(ws + o_rowc);
             e = bwd_16_supported(p) ? launch_bwd_16(p, stream, &name) : hipErrorNotSupported;
             if (e == hipErrorNotSupported) continue;  // (alignment of a wrapped caller buffer): the exact path
@@ -384,18 +390,11 @@ int32_t mfa_quantized_backward(mfa_context_t context, mfa_buffer_t q, mfa_buffer
         ctx->last_kernel = name;
         if (e != hipSuccess) return e == hipErrorInvalidValue ? MFA_ERROR_INVALID_ARGS : MFA_ERROR_EXECUTION_FAILED;
         lat.stop();
-        uint32_t overflow = 0;
-        // dS = P (dP - D) is rounded to fp16 inside the kernels and can leave fp16's range with every OPERAND inside it: the
-        // gradients then carry inf / NaN -- look at them (three HBM-speed passes, ~2 % of the call) before trusting the flag
-        if (fast && (launch_nonfinite_flag(p.dq, (int64_t)nq, flag, stream) != hipSuccess || launch_nonfinite_flag(p.dk, (int64_t)nkv, flag, stream) != hipSuccess ||
-                     launch_nonfinite_flag(p.dv, (int64_t)nkv, flag, stream) != hipSuccess)) return MFA_ERROR_EXECUTION_FAILED;
-        if (fast && hipMemcpyAsync(&overflow, flag, 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
         for (Buffer* b : {bdq, bdk, bdv})
             if (b->download(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
         if (hipStreamSynchronize(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
         lat.publish();
-        if (!fast || !overflow) break;
-        DBG("quantised backward: an operand left fp16's range, repeating on the fp32-exact path");
+        break;  // (the second attempt is the EXACT path for shapes / alignments the fp16 engine does not take: `continue` above)
     }
     return MFA_SUCCESS;
 }
@@ -431,9 +430,14 @@ mfa_error_t umfa_quantized_backward_stream(mfa_context_t context, void* stream_h
     char* ws = (char*)ctx->pool(dev, stream).workspace.ensure((fast ? o_flag + 256 : o_do16) + 256, stream);
     if (!ws) return MFA_ERROR_MEMORY_ALLOCATION;
     uint32_t* flag = status ? status : (uint32_t*)(ws + o_flag);
-    if ((fast || status) && hipMemsetAsync(flag, 0, 4, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+    if (status && hipMemsetAsync(status, 0, 4, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+    uint32_t* unit = (uint32_t*)(ws + o_flag) + 16;  // every operand as a power-of-two multiple, see mfa_quantized_backward
+    const size_t nkv_in = (size_t)B * H * Skv * D;
+    if (fast && (hipMemsetAsync(ws + o_flag, 0, 256, stream) != hipSuccess || launch_amax_dense(q, prec, (int64_t)nq, unit + 4, stream) != hipSuccess ||
+                 launch_amax_dense(k, prec, (int64_t)nkv_in, unit + 5, stream) != hipSuccess || launch_amax_dense(v, prec, (int64_t)nkv_in, unit + 6, stream) != hipSuccess))
+        return MFA_ERROR_EXECUTION_FAILED;
     QuantViews views;
-    if (launch_quantize(q, k, v, prec, B, H, Sq, Skv, D, bits, mode, ws, fast ? 2 : 1, &views, stream, fast ? flag : nullptr) != hipSuccess)
+    if (launch_quantize(q, k, v, prec, B, H, Sq, Skv, D, bits, mode, ws, fast ? 2 : 1, &views, stream, fast ? flag : nullptr, nullptr, fast ? unit + 4 : nullptr) != hipSuccess)
         return MFA_ERROR_EXECUTION_FAILED;
     BwdParams p;
     memset(&p, 0, sizeof(p));
@@ -446,17 +450,13 @@ mfa_error_t umfa_quantized_backward_stream(mfa_context_t context, void* stream_h
     if (fast) {
         p.q = views.qh; p.k = views.kh; p.v = views.vh;
         p.in_prec = P_FP16; p.dout_prec = P_FP16;
-        uint32_t* unit = (uint32_t*)(ws + o_flag) + 16;  // dO * 2^-e in fp16, see mfa_quantized_backward
-        if (launch_cast_f16_unit(dout, prec, ws + o_do16, (int64_t)nq, unit, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+        if (launch_cast_f16_unit(dout, prec, ws + o_do16, (int64_t)nq, unit, stream) != hipSuccess || launch_bwd_units(unit, stream) != hipSuccess)
+            return MFA_ERROR_EXECUTION_FAILED;
         p.dout = ws + o_do16;
-        p.gscale = (const float*)(unit + 1);
+        p.units = (const float*)(unit + 8);
         p.rowc = (float*)(ws + o_rowc);
         if (!bwd_16_supported(p)) return MFA_ERROR_INVALID_ARGS;  // 16-byte alignment of the caller's tensors
-        e = launch_bwd_16(p, stream, &name);
-        // dS is rounded to fp16 inside the kernels: it can overflow with every operand in range -- the gradients show it
-        const size_t nkv = (size_t)B * H * Skv * D;
-        if (e == hipSuccess && (launch_nonfinite_flag(dq, (int64_t)nq, flag, stream) != hipSuccess || launch_nonfinite_flag(dk, (int64_t)nkv, flag, stream) != hipSuccess ||
-                                launch_nonfinite_flag(dv, (int64_t)nkv, flag, stream) != hipSuccess)) return MFA_ERROR_EXECUTION_FAILED;
+        e = launch_bwd_16(p, stream, &name);  // (nothing in it can leave fp16's range: `status` stays 0)
     } else {
         p.dout = dout; p.q = views.qf; p.k = views.kf; p.v = views.vf;
         p.in_prec = P_FP32; p.dout_prec = prec;

@@ -260,8 +260,8 @@ def quantized_attention_backward_stream(dout, q, k, v, o32, lse, *, scale=None, 
                                         quant_mode: str = "blockwise"):
     """Backward of quantized_attention_forward_stream, in-stream (umfa_quantized_backward_stream): contiguous BHSD device
     tensors, O fp32 and LSE from the quantised forward.  Returns (dq, dk, dv, status): fp32 gradients and a device
-    uint32 that is non-zero when an operand left fp16's range on the 16-bit MFMA engine (then use the blocking
-    mfa_quantized_backward -- umfa_torch's autograd Function does -- or the option bwd_exact)."""
+    uint32 that round 4 set when an operand left fp16's range on the 16-bit MFMA engine; every operand enters that engine as
+    a power-of-two multiple now (exponents chosen on the device), so it stays 0."""
     B, H, Sq, D = q.shape
     Skv = k.shape[2]
     if scale is None:
