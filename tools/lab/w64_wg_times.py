@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Lab (-DW64_LAB_STAMPS build): per-workgroup start / end of one launch, grouped by XCD and by the workgroup's role in the
-stream-K schedule -- where does the launch's tail come from?   python tools/lab/w64_wg_times.py B H S D [lib [blockdiag<docs>]]"""
+stream-K schedule -- where does the launch's tail come from?   python tools/lab/w64_wg_times.py B H S D [lib [blockdiag<docs> | window<half width>]]"""
 import ctypes
 import os
 import sys
@@ -20,8 +20,11 @@ mask = None
 if len(sys.argv) > 6 and sys.argv[6].startswith("blockdiag"):
     i_ = torch.arange(S, device="cuda") // (S // int(sys.argv[6][9:] or 4))
     mask = (i_[:, None] == i_[None, :])[None, None].contiguous()
+window = None
+if len(sys.argv) > 6 and sys.argv[6].startswith("window"):
+    window = (int(sys.argv[6][6:] or 512),) * 2
 for rep in range(6):
-    o, lse = umfa_torch.attention_forward(q, k, v, return_lse=True, out=out, mask=mask)
+    o, lse = umfa_torch.attention_forward(q, k, v, return_lse=True, out=out, mask=mask, window=window)
 torch.cuda.synchronize()
 G = 256
 raw = lse.cpu().numpy().view(np.uint64)[: G * 8].reshape(G, 8)

@@ -287,8 +287,9 @@ static uint32_t w64_win_right(const FwdParams& p) { return p.causal ? 0u : (p.wi
 static uint32_t w64_tiles_per_item(const FwdParams& p) {
     const uint32_t T = (p.Skv + 63) / 64;
     if (!w64_is_window(p)) return T;
-    const uint64_t band = 256ull + w64_win_left(p) + w64_win_right(p);  // keys a 256-row block can see
-    const uint64_t tw = (band + 63) / 64 + 1;                          // + 1: the band need not start on a tile boundary
+    // key tiles the band of a 256-row block touches: blocks start on tile boundaries (q0 = 256 j), so the band [q0 - left, q0 + 255 + right]
+    // runs from tile q0 / 64 - ceil(left / 64) to tile q0 / 64 + floor((255 + right) / 64) -- 20 tiles for +-512, not the 21 of "band / 64 + 1"
+    const uint64_t tw = ((uint64_t)w64_win_left(p) + 63) / 64 + (255ull + w64_win_right(p)) / 64 + 1;
     return tw < T ? (uint32_t)tw : T;
 }
 
