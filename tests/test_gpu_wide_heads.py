@@ -1,4 +1,4 @@
-"""Head dims 257 ... 1024 (fa_fwd_wide.hip): the reference's callers admit head_dim <= 1024
+"""Head dims 257 ... 1024 (fa_fwd_wide.hip, fa_bwd_wide.hip): the reference's callers admit head_dim <= 1024
 (examples/pytorch-custom-op-ffi/src/metal_sdpa_backend.cpp:1078-1086, :1382-1384); until round 5 every entry here refused them.
 fp32 arithmetic for every operand type, so the bar is the fp32-exact kernel's: 1e-5 max-abs on fp32 inputs (the reference's own fp32
 tolerance, tests/test_scale_factor_fix.py:66), the operand format's rounding on 16-bit ones -- through the blocking C ABI, the in-stream
@@ -71,7 +71,7 @@ def test_in_stream_entry_masks_strides_lse(dtype, D):
         assert o16.dtype == dtype and float((o16.float() - o).abs().max()) <= float(o.abs().max()) * (2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11)
 
 
-def test_torch_sdpa_surface_takes_wide_heads_and_refuses_their_backward():
+def test_torch_sdpa_surface_takes_wide_heads_forward_and_backward():
     import umfa_torch
     torch.manual_seed(1)
     q, k, v = (torch.randn(1, 2, 64, 384, device="cuda", dtype=torch.bfloat16) for _ in range(3))
@@ -81,19 +81,74 @@ def test_torch_sdpa_surface_takes_wide_heads_and_refuses_their_backward():
     assert umfa_torch.last_kernel() == "fa_fwd_wide<512>"
     ref = torch.nn.functional.scaled_dot_product_attention(q.float(), k.float(), v.float(), is_causal=True)
     assert float((o.float() - ref).abs().max()) < 2.0 ** -7 * float(ref.abs().max())
+    # gradients: fa_bwd_wide behind the same autograd Function as every other head dim (a torch fall-back until the backward existed)
+    qg, kg, vg = (t.clone().requires_grad_(True) for t in (q, k, v))
+    og = umfa_torch.scaled_dot_product_attention(qg, kg, vg, is_causal=True)
+    w = torch.randn_like(og)
+    (og.float() * w.float()).sum().backward()
+    assert umfa_torch.last_kernel() == "fa_bwd_wide<512>", umfa_torch.last_kernel()
     assert sdpa.get_dispatch_stats()["pytorch_fallback"] == before
-    # gradients: no kernel above head_dim 256 -- the surface falls back to torch (as the reference does for what its backward cannot serve)
-    qg = q.clone().requires_grad_(True)
-    og = umfa_torch.scaled_dot_product_attention(qg, k, v)
-    og.float().sum().backward()
-    assert qg.grad is not None and torch.isfinite(qg.grad).all() and sdpa.get_dispatch_stats()["pytorch_fallback"] == before + 1
+    qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    (torch.nn.functional.scaled_dot_product_attention(qr, kr, vr, is_causal=True) * w.float()).sum().backward()
+    for g, r in ((qg.grad, qr.grad), (kg.grad, kr.grad), (vg.grad, vr.grad)):
+        assert g.dtype == torch.bfloat16 and float((g.float() - r).abs().max()) < 2.0 ** -6 * float(r.abs().max())
+
+
+@pytest.mark.parametrize("D", [320, 264, 512, 1024])
+@pytest.mark.parametrize("causal", [False, True])
+def test_backward_fp32_host_arrays_through_the_blocking_abi(D, causal):
+    """mfa_attention_backward above head_dim 256: the fp32-exact backward's bar (5e-5 of the largest gradient against the oracle's fp64), ragged
+    sizes (neither a multiple of the 32-row tiles), D returned"""
+    import umfa
+    orc = _oracle()
+    rng = np.random.default_rng(D + causal)
+    B, H, Sq, Skv = 1, 2, 70, 101
+    q = rng.standard_normal((B, H, Sq, D)).astype(np.float32)
+    k = rng.standard_normal((B, H, Skv, D)).astype(np.float32)
+    v = rng.standard_normal((B, H, Skv, D)).astype(np.float32)
+    do = rng.standard_normal((B, H, Sq, D)).astype(np.float32)
+    o, lse = orc.sdpa_forward(q, k, v, causal=causal, return_lse=True)
+    with umfa.MFAContext() as ctx:
+        dq, dk, dv, dvec = umfa.attention_backward(ctx, do, q, k, v, o, lse.ravel(), causal=causal, input_precision="fp32", intermediate_precision="fp32", layout="bhsd")
+        assert ctx.last_kernel == ("fa_bwd_wide<512>" if D <= 512 else "fa_bwd_wide<1024>"), ctx.last_kernel
+    rdq, rdk, rdv, rd = orc.sdpa_backward(do, q, k, v, o, lse, causal=causal)
+    for got, ref, name in ((dq, rdq, "dq"), (dk, rdk, "dk"), (dv, rdv, "dv"), (dvec.reshape(rd.shape), rd, "D")):
+        assert np.isfinite(got).all(), name
+        assert float(np.abs(got - ref).max()) < 5e-5 * max(1.0, float(np.abs(ref).max())), (name, float(np.abs(got - ref).max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("D,causal", [(320, True), (1024, False), (776, True)])
+def test_backward_in_stream_entry(dtype, D, causal):
+    """umfa_attention_backward_stream on device tensors of every operand type (fp32 arithmetic on the rounded operands; gradients fp32, cast by
+    the caller), against the oracle on the same rounded inputs; bitwise repeatable"""
+    import umfa_torch
+    orc = _oracle()
+    torch.manual_seed(D)
+    B, H, Sq, Skv = 2, 2, 97, 130
+    q, do = (torch.randn(B, H, Sq, D, device="cuda", dtype=dtype) for _ in range(2))
+    k, v = (torch.randn(B, H, Skv, D, device="cuda", dtype=dtype) for _ in range(2))
+    o, lse = umfa_torch.attention_forward(q, k, v, causal=causal, out_dtype=torch.float32, return_lse=True)
+    g1 = umfa_torch.attention_backward(do, q, k, v, o, lse, scale=D ** -0.5, causal=causal, keep_fp32=True)
+    assert umfa_torch.last_kernel().startswith("fa_bwd_wide<"), umfa_torch.last_kernel()
+    g2 = umfa_torch.attention_backward(do, q, k, v, o, lse, scale=D ** -0.5, causal=causal, keep_fp32=True)
+    ref = orc.sdpa_backward(npy(do), npy(q), npy(k), npy(v), o.cpu().numpy(), lse.cpu().numpy().reshape(B, H, Sq), causal=causal)
+    for a, b, r, name in zip(g1, g2, ref, ("dq", "dk", "dv")):
+        assert torch.equal(a, b), name
+        a = a.float().cpu().numpy()
+        assert float(np.abs(a - r).max()) < 5e-5 * max(1.0, float(np.abs(r).max())), (name, float(np.abs(a - r).max()))
 
 
 def test_limits():
-    """head_dim 1025 is refused (the reference: "Head dimension too large (max 1024)"), the backward stays at 256"""
+    """head_dim 1025 is refused, forward and backward (the reference: "Head dimension too large (max 1024)")"""
     import umfa_torch
     from umfa._ffi import MFAError
     q, k, v = (torch.randn(1, 1, 8, 1032, device="cuda", dtype=torch.float16) for _ in range(3))
     with pytest.raises(MFAError) as ei:
         umfa_torch.attention_forward(q, k, v)
+    assert ei.value.code == 1
+    o = torch.zeros(1, 1, 8, 1032, device="cuda", dtype=torch.float32)
+    lse = torch.zeros(8, device="cuda", dtype=torch.float32)
+    with pytest.raises(MFAError) as ei:
+        umfa_torch.attention_backward(q, q, k, v, o, lse, scale=1.0)
     assert ei.value.code == 1

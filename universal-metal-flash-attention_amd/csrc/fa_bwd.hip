@@ -240,8 +240,7 @@ hipError_t launch_bwd(const BwdParams& p, hipStream_t stream, const char** name)
     if (p.D <= 64) { *name = "fa_bwd_exact<64>"; return launch_bwd_dp<64>(p, stream); }
     if (p.D <= 128) { *name = "fa_bwd_exact<128>"; return launch_bwd_dp<128>(p, stream); }
     if (p.D <= 256) { *name = "fa_bwd_exact<256>"; return launch_bwd_dp<256>(p, stream); }
-    *name = "none";
-    return hipErrorInvalidValue;  // head_dim > 256
+    return launch_bwd_wide(p, stream, name);  // head dims 257 ... 1024 (fa_bwd_wide.hip); beyond: invalid
 }
 
 }  // namespace umfa

@@ -39,6 +39,8 @@ hipError_t launch_fwd_exact(const FwdParams& p, hipStream_t stream, const char**
 // head dims 257 ... 1024 (fa_fwd_wide.hip): fp32 arithmetic, any operand type / strides / mask; the reference's callers admit them
 // (metal_sdpa_backend.cpp:1078-1086), nothing tuned depends on them
 hipError_t launch_fwd_wide(const FwdParams& p, hipStream_t stream, const char** name);
+// ... and their backward (fa_bwd_wide.hip): dense contiguous BHSD, fp32 gradients, no mask
+hipError_t launch_bwd_wide(const BwdParams& p, hipStream_t stream, const char** name);
 
 // bf16 / fp16 MFMA forward.  Requires in_prec in {FP16, BF16}, D % 8 == 0, D <= 256,
 // 16-byte aligned operands/strides, scale > 0.  Returns hipErrorNotSupported otherwise

@@ -49,7 +49,7 @@ mfa_error_t mfa_attention_backward(mfa_context_t context, mfa_buffer_t dout, mfa
         !bl->fits(nr * 4) || !bdq->fits(nq * 4) || !bdk->fits(nkv * 4) || !bdv->fits(nkv * 4) || !bd->fits(nr * 4))
         return MFA_ERROR_INVALID_ARGS;
     if (nq == 0 || nkv == 0) return MFA_SUCCESS;
-    if (D > 256) return MFA_ERROR_INVALID_ARGS;  // like the forward: head_dim <= 256
+    if (D > 1024) return MFA_ERROR_INVALID_ARGS;  // like the forward: the reference callers' limit (metal_sdpa_backend.cpp:1078-1086)
 
     for (Buffer* b : {bdo, bq, bk, bv, bo, bl})
         if (b->upload(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
@@ -96,7 +96,7 @@ mfa_error_t umfa_attention_backward_stream(mfa_context_t context, void* stream, 
                                            bool out_in_input_type) {
     Context* ctx = as_ctx(context);
     if (!ctx || !dout || !q || !k || !v || !out || !softmax_lse || !dq || !dk || !dv || !d_buffer) return MFA_ERROR_INVALID_ARGS;
-    if (head_dim == 0 || head_dim > 256) return MFA_ERROR_INVALID_ARGS;
+    if (head_dim == 0 || head_dim > 1024) return MFA_ERROR_INVALID_ARGS;
     if ((size_t)batch_size * num_heads * seq_len_q * seq_len_kv == 0) return MFA_SUCCESS;
     BwdParams p;
     memset(&p, 0, sizeof(p));

@@ -109,7 +109,7 @@ def op_supports(q, k, v, attn_mask, dropout_p, needs_grad: bool, is_causal: bool
         return False
     if q.shape[0] != k.shape[0] or q.shape[1] != k.shape[1] or k.shape != v.shape or q.shape[3] != k.shape[3]:
         return False
-    if q.shape[3] == 0 or q.shape[3] > 1024 or (needs_grad and q.shape[3] > 256):  # (above 256: forward only)
+    if q.shape[3] == 0 or q.shape[3] > 1024:  # (the reference callers' limit; above 256: fa_fwd_wide / fa_bwd_wide)
         return False
     if attn_mask is not None:
         if needs_grad or attn_mask.dtype not in (torch.bool,) + _SUPPORTED or attn_mask.dim() > 4:

@@ -306,8 +306,8 @@ def scaled_dot_product_attention(query, key, value, attn_mask: Optional[torch.Te
         out = _QuantizedFlashAttentionFn.apply(q, k, v, bool(is_causal), sm_scale, _quant_precision, _quant_mode, mask)
         return out.to(query.dtype)
     if q.requires_grad or k.requires_grad or v.requires_grad:
-        if mask is not None or q.size(3) > 256:
-            return fallback()  # dense backward takes no mask (:1798-1803); head dims above 256 have a forward only (fa_fwd_wide.hip)
+        if mask is not None:
+            return fallback()  # dense backward takes no mask (:1798-1803)
         _bump("fp32_autograd")
         return _FlashAttentionFn.apply(q, k, v, bool(is_causal), sm_scale)
     # inference: in-stream, zero-copy, output directly in the input dtype (v)
