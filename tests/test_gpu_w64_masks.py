@@ -102,6 +102,45 @@ def test_w64_mask_tensor_vs_oracle(kind, dt, shape, D, umfa_opts):
     assert o16.dtype == dt and float((o16.float() - o).abs().max()) <= 2.0 ** -8 * float(o.abs().max()) * 1.01
 
 
+@pytest.mark.parametrize("kind", ["random_per_head", "random_2d", "padding", "blockdiag", "all_open", "empty_rows_and_blocks", "strided_view"])
+@pytest.mark.parametrize("dt,D", [(torch.bfloat16, 128), (torch.float16, 64)])
+@pytest.mark.parametrize("shape,grid", [((2, 2, 512, 512), 0), ((1, 3, 1280, 777), 0), ((1, 3, 1280, 1400), 5)])
+def test_w64_mask_with_the_causal_flag(kind, dt, D, shape, grid, umfa_opts):
+    """causal AND a bool mask tensor (a causal LM with key padding, packed documents): the pre-pass folds key <= row into the bits it packs, so
+    the mask kernel -- which has no causal instantiation -- sweeps lists that never contain a tile above the diagonal.  Oracle with both,
+    rows that see nothing (O = 0, LSE = -inf), cut blocks, and the 128-row kernel's numbers class."""
+    import umfa_torch
+    umfa_opts(force_w64=1)
+    if grid:
+        umfa_opts(w64_grid=grid)
+    B, H, Sq, Skv = shape
+    torch.manual_seed(Sq + Skv + D)
+    q = torch.randn(B, H, Sq, D, device="cuda", dtype=dt)
+    k = torch.randn(B, H, Skv, D, device="cuda", dtype=dt)
+    v = torch.randn(B, H, Skv, D, device="cuda", dtype=dt)
+    m = _mask(kind, B, H, Sq, Skv, seed=Sq + 1)
+    o, lse = umfa_torch.attention_forward(q, k, v, mask=m, causal=True, out_dtype=torch.float32, return_lse=True)
+    kern = umfa_torch.last_kernel()
+    assert kern in (f"fa_fwd16_w64<bf16,{D},pv16,mask>", f"fa_fwd16_w64<fp16,{D},mask>"), kern
+    mfull = (m.expand(B, H, Sq, Skv) if m.dim() == 4 else m.expand(Sq, Skv)[None, None].expand(B, H, Sq, Skv)).clone()
+    mfull &= (torch.arange(Skv, device="cuda")[None, :] <= torch.arange(Sq, device="cuda")[:, None])
+    ref, ref_lse = _oracle().sdpa_forward(npy(q), npy(k), npy(v), mask=np.ascontiguousarray(mfull.cpu().numpy()),
+                                          mask_type=_oracle().MASK_BOOL, return_lse=True)
+    on = o.cpu().numpy()
+    assert np.isfinite(on).all()
+    check_forward(on, ref, dt, kern, f"w64_mask_causal_{kind}")
+    dead = ~mfull.any(-1).cpu().numpy()
+    ln = lse.cpu().numpy().reshape(B, H, Sq)
+    assert (on[dead] == 0).all() and np.isneginf(ln[dead]).all()
+    assert np.abs(ln[~dead] - ref_lse[~dead]).max() < 2e-2
+    o2 = umfa_torch.attention_forward(q, k, v, mask=m, causal=True, out_dtype=torch.float32)
+    assert torch.equal(o, o2)
+    with umfa_torch.options(no_w64_mask=1, force_w64=0, w64_grid=0):
+        o3 = umfa_torch.attention_forward(q, k, v, mask=m, causal=True, out_dtype=torch.float32)
+        assert umfa_torch.last_kernel().startswith("fa_fwd16<"), umfa_torch.last_kernel()
+    assert float((o - o3).abs().max()) <= 2.0 ** -9 * float(o3.abs().max())
+
+
 @pytest.mark.parametrize("kind", ["random_per_head", "padding", "blockdiag", "empty_rows_and_blocks", "strided_view", "one_tile"])
 @pytest.mark.parametrize("shape,grid", [((2, 2, 512, 512), 3), ((2, 2, 512, 512), 5), ((1, 3, 1280, 777), 4), ((1, 3, 1280, 777), 7), ((1, 3, 1280, 777), 14)])
 @pytest.mark.parametrize("D", [128, 64])
@@ -264,7 +303,8 @@ def test_w64_mask_few_blocks_key_padding(umfa_opts):
 
 
 def test_w64_mask_routing_gate(umfa_opts):
-    """few items (fewer 256-row blocks than CUs), additive masks, causal + mask and bf16 P V stay on the 128-row kernel"""
+    """few items (fewer 256-row blocks than CUs), additive masks and bf16 P V stay on the 128-row kernel; causal + mask: the mask kernel, the
+    causal flag folded into the packed bits (late round 5)"""
     import umfa_torch
     umfa_opts(force_w64=0)
     torch.manual_seed(1)
@@ -277,7 +317,7 @@ def test_w64_mask_routing_gate(umfa_opts):
     umfa_torch.attention_forward(q, k, v, mask=mb)
     assert umfa_torch.last_kernel().endswith(",mask>")
     umfa_torch.attention_forward(q, k, v, mask=mb, causal=True)
-    assert umfa_torch.last_kernel().startswith("fa_fwd16<")
+    assert umfa_torch.last_kernel().endswith(",mask>")
     umfa_torch.attention_forward(q, k, v, mask=torch.zeros(1, 1, 512, 512, device="cuda"))
     assert umfa_torch.last_kernel().startswith("fa_fwd16<")
     with umfa_torch.options(pv_fp16=0):

@@ -368,9 +368,26 @@ struct MaskPackArgs {
     uint8_t* wflag;
     uint32_t Bm, Hm, nrb64, T;
     uint64_t total;  // wave-tiles = Bm Hm nrb64 T (0: nothing to pack)
+    int causal;      // the launch's causal flag folded into the bits (key <= row): the mask kernels have no causal instantiation and need none --
+                     // tiles above the diagonal come out "masked" and never enter a block's list
     bool vec16;      // contiguous 16-byte aligned rows, Skv % 16 == 0
     bool done;       // (launcher) the pack rode along with the V cast pass
 };
+// bits of the lane's word (bit 16 kb + 4 g + e = key 64 tile + 32 kb + 8 g + 4 hi + e) that a causal launch keeps: key <= row
+__device__ __forceinline__ uint32_t causal_word(uint32_t row, uint32_t tile, uint32_t hi) {
+    const uint32_t k0 = tile * 64;
+    if (k0 + 63 <= row) return 0xffffffffu;
+    if (k0 > row) return 0u;
+    uint32_t w = 0;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w |= (k0 + 32 * kb + 8 * g + 4 * hi + e <= row) ? 1u << (16 * kb + 4 * g + e) : 0u;
+    return w;
+}
+
 template <bool VEC16>
 __device__ __forceinline__ void mask_pack_body(const MaskPackArgs& p, const uint32_t block) {
     uint32_t* const bits = p.bits;
@@ -415,6 +432,7 @@ __device__ __forceinline__ void mask_pack_body(const MaskPackArgs& p, const uint
 #pragma unroll
                     for (int e = 0; e < 4; ++e) word |= ((four >> (8 * e)) & 0xffu) ? 1u << (16 * kb + 4 * g + e) : 0u;
                 }
+            if (p.causal) word &= causal_word(rb * 64 + r, tile, hi);
             if (rb * 64 + r < p.Sq) {
                 all_open = all_open && word == 0xffffffffu;
                 any_open = any_open || word != 0;
@@ -445,6 +463,7 @@ __device__ __forceinline__ void mask_pack_body(const MaskPackArgs& p, const uint
 #pragma unroll
                         for (int e = 0; e < 4; ++e) word |= ((four >> (8 * e)) & 0xffu) ? 1u << (16 * kb + 4 * g + e) : 0u;
                     }
+                if (p.causal) word &= causal_word(row, tile, hi);
                 all_open = all_open && word == 0xffffffffu;
                 any_open = any_open || word != 0;
             }
@@ -893,6 +912,7 @@ static hipError_t mask_pack_prepare(FwdParams& p, void* scratch, MaskPackArgs& a
     a.mask = p.mask;
     for (int i = 0; i < 4; ++i) a.ms[i] = p.ms[i];
     a.Sq = p.Sq; a.Skv = p.Skv;
+    a.causal = p.causal ? 1 : 0;
     a.bits = bits; a.wflag = wflag;
     a.Bm = Bm; a.Hm = Hm; a.nrb64 = nrb64; a.T = T;
     a.total = total;

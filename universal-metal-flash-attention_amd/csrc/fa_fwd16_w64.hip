@@ -389,8 +389,8 @@ bool fwd_w64_supported(const FwdParams& p) {
     if ((p.D != 128 && p.D != 64) || (p.mask_kind != MK_NONE && p.mask_kind != MK_WINDOW && p.mask_kind != MK_BOOL)) return false;
     if (p.mask_kind == MK_BOOL) {
         // bool mask tensors (MASKT instantiations): head_dim 128 and (round 5) 64, the fp16-P-V families (bf16 operands by default, fp16 operands), no
-        // causal flag / rotation on top; whole items per workgroup, so at least one item per CU
-        if (tuning().no_w64_mask.load(std::memory_order_relaxed) || !p.mask || (p.D != 128 && p.D != 64) || p.causal || p.rope_cos) return false;
+        // rotation on top (a causal flag is folded into the packed mask); whole items per workgroup, so at least one item per CU
+        if (tuning().no_w64_mask.load(std::memory_order_relaxed) || !p.mask || (p.D != 128 && p.D != 64) || p.rope_cos) return false;  // (a causal flag is folded into the packed bits)
         if (p.in_prec == P_BF16 && !p.pv16) return false;
         if (p.Skv < 64 || p.Sq < 256 || (p.Sq % 256 != 0 && p.Sq < 1024) || ((p.Skv + 63) / 64) > 1024u) return false;  // (a block's tile list sits in 4 KiB of LDS)
         if (p.out_prec != P_FP32 && p.out_prec != p.in_prec) return false;
@@ -401,6 +401,11 @@ bool fwd_w64_supported(const FwdParams& p) {
         // the host cannot know without reading it back
         const uint64_t blocks = (uint64_t)p.B * p.H * ((p.Sq + 255) / 256), cus = (uint64_t)w64_cu_count();
         if (tuning().force_w64.load(std::memory_order_relaxed)) return true;
+        // causal + mask (the causal flag folded into the packed bits: fa_aux.hip causal_word) runs here when asked for, not by default: measured
+        // level with the 128-row kernel (profiles/r5/causal_mask_timing.txt: 0.93-1.06 x at FLUX size, B4 H16 S4096, B2 H16 S8192 with key
+        // padding / four documents) -- the lists of a causal launch are as unequal as its blocks, and whole blocks per workgroup balance them no
+        // better than the 128-row kernel's dispatch order does
+        if (p.causal) return false;
         if (p.in_prec == P_BF16 && p.Sq < 1024) return false;  // (the fp16 image of V is re-read by too few q-blocks: see below)
         // (1024 <= Sq < 2048, masks shared by every (batch, head) or without a row dimension: B4 H12 S1536 window 78 us against 62, B4 H8 S1536 padding 72 / 65,
         // B1 H64 S1024 window 48 / 44 -- the pass and the per-block prologues against short lists)
@@ -523,7 +528,7 @@ hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cn
         wp.mk_prefix = p.mk_prefix;
         // the max chain, unless the mask has no row dimension (key padding: a listed tile holds a key for every row, the lazy bodies are as safe as
         // without a mask); with one, which rows have keys in a segment is not arithmetic
-        if (p.ms[2] != 0 || tuning().no_w64_mask_lazy.load(std::memory_order_relaxed)) wp.lazy = 0;
+        if (p.ms[2] != 0 || p.causal || tuning().no_w64_mask_lazy.load(std::memory_order_relaxed)) wp.lazy = 0;
     }
     if (rope && p.out_prec != p.in_prec) return hipErrorNotSupported;  // fused-RoPE instantiations: O in the operand type only (runtime.hip asks first)
     if (window) {
