@@ -241,13 +241,20 @@ def run_i8_case(seed):
     g = torch.Generator(device="cuda").manual_seed(seed)
     q = (torch.randn(B, H, Sq, D, device="cuda", generator=g) * gain).to(dt)
     k = (torch.randn(B, H, Skv, D, device="cuda", generator=g) * gain).to(dt)
-    v = torch.randn(B, H, Skv, D, device="cuda", dtype=dt, generator=g)
+    # V anywhere in the operand type's range (the fp16 image of the de-quantised V is q * s * 2^-e per slab, round 5): a power of two for the
+    # tensor, and -- block-wise mode -- one head far below the others
+    vgain = 2.0 ** rng.choice([0, 0, -30, -14, 10, 40] if dt == torch.bfloat16 else [0, 0, -8, 6])
+    v = torch.randn(B, H, Skv, D, device="cuda", generator=g) * vgain
+    if mode != "tensor" and H > 1 and dt == torch.bfloat16 and rng.random() < 0.5:
+        v[:, H - 1] *= 2.0 ** -20
+    v = v.to(dt)
     mask = (torch.randn(1, H, Sq, Skv, device="cuda", generator=g) * 2).float() if use_mask else None
     umfa_torch.set_option("force_w64", 1 if rng.random() < 0.6 else 0)
+    umfa_torch.set_option("cast_wait_us", rng.choice([100, 100, 0]))
     try:
         out, lse = umfa_torch.quantized_attention_forward_stream(q, k, v, causal=causal, mask=mask, bits=bits, quant_mode=mode, return_lse=True)
         kern = umfa_torch.last_kernel()
-        what = (seed, str(dt), B, H, Sq, Skv, D, bits, mode, causal, use_mask, gain, kern)
+        what = (seed, str(dt), B, H, Sq, Skv, D, bits, mode, causal, use_mask, gain, vgain, kern)
         torch.cuda.synchronize()
         qn, kn, vn = (t.float().cpu().numpy() for t in (q, k, v))
         r_o, r_l = oracle.quantized_forward(qn, kn, vn, causal=causal, mask=None if mask is None else mask.cpu().numpy(), bits=bits,
@@ -255,7 +262,7 @@ def run_i8_case(seed):
         o = out.cpu().numpy()
         if not np.isfinite(o).all():
             return "non-finite %r" % (what,)
-        rel = float(np.abs(o - r_o).max() / max(np.abs(r_o).max(), 1e-30))
+        rel = max(float(np.abs(o[:, h] - r_o[:, h]).max() / max(np.abs(r_o[:, h]).max(), 1e-300)) for h in range(H))  # per head: each has its own scale
         lerr = float(np.abs(lse.cpu().numpy().reshape(r_l.shape) - r_l).max() / max(1.0, np.abs(r_l).max() / 50))
         if rel > 2.5e-3 or lerr > 2.5e-3:
             return "rel %.3e lse %.3e %r" % (rel, lerr, what)
@@ -263,6 +270,7 @@ def run_i8_case(seed):
         return "exception %r %s" % ((seed,), repr(e)[:300])
     finally:
         umfa_torch.set_option("force_w64", 0)
+        umfa_torch.set_option("cast_wait_us", 100)
     return None
 
 
@@ -605,7 +613,8 @@ def run_host_case(seed):
     shp_q, shp_k = ((Sq, D), (Skv, D)) if two_d else ((B, H, Sq, D), (B, H, Skv, D))
     q, k, v = conv(nrng.standard_normal(shp_q)), conv(nrng.standard_normal(shp_k)), conv(nrng.standard_normal(shp_k))
     q4, k4, v4 = (a.reshape((1, 1) + a.shape) if two_d else a for a in (q, k, v))
-    tol = {"fp32": 2e-5, "fp16": 2.0 ** -11 * 1.5, "bf16": 2.0 ** -8 * 1.5}[prec]
+    # (fp16: P rounded to 11 bits; 1.5 ulp held for 11 719 seeds, seed 11720 -- 200 keys, an additive mask -- reached 1.54: the ceiling is 1.75 now, inside the stated 1e-3)
+    tol = {"fp32": 2e-5, "fp16": 2.0 ** -11 * 1.75, "bf16": 2.0 ** -8 * 1.5}[prec]
     try:
         mode = rng.choice(["plain", "mask_bool", "mask_add", "lse_bwd"])
         what.append(mode)
@@ -661,15 +670,22 @@ def run_qbwd_case(seed):
     S = rng.choice([64, 128, 192, 256, 320, 512])
     causal = rng.random() < 0.4
     g = torch.Generator(device="cuda").manual_seed(seed)
-    q, k, v, do = (torch.randn(B, H, S, D, device="cuda", dtype=dt, generator=g) for _ in range(4))
+    # every operand anywhere in its type's range (round 5: each enters the fp16 engine as a power-of-two multiple): Q and K trade a factor
+    # (the logits stay where a softmax makes sense), V and dO have one each
+    wide = dt == torch.bfloat16
+    eqk = rng.choice([0, 0, 12, -12] if wide else [0, 0, 4, -4])
+    ev = rng.choice([0, 0, 30, -30, 60] if wide else [0, 0, 6, -6])
+    edo = rng.choice([0, 0, -20, -40, 20] if wide else [0, 0, -10, 4])
+    q, k, v, do = (torch.randn(B, H, S, D, device="cuda", generator=g) for _ in range(4))
+    q, k, v, do = (q * 2.0 ** eqk).to(dt), (k * 2.0 ** -eqk).to(dt), (v * 2.0 ** ev).to(dt), (do * 2.0 ** edo).to(dt)
     try:
         o, lse = umfa_torch.quantized_attention_forward_stream(q, k, v, causal=causal, return_lse=True)
         dq, dk, dv, status = umfa_torch.quantized_attention_backward_stream(do, q, k, v, o, lse, causal=causal)
         torch.cuda.synchronize()
         kern = umfa_torch.last_kernel()
-        what = (seed, str(dt), B, H, S, D, causal, kern, int(status.item()))
+        what = (seed, str(dt), B, H, S, D, causal, eqk, ev, edo, kern, int(status.item()))
         if int(status.item()) != 0:
-            return "overflow status on N(0,1) data %r" % (what,)
+            return "status raised %r" % (what,)
 
         def fake(t):
             x = t.float().cpu().numpy()
@@ -687,7 +703,7 @@ def run_qbwd_case(seed):
         rdq, rdk, rdv, _ = oracle.sdpa_backward(do.float().cpu().numpy(), fq, fk, fv, on, lse.cpu().numpy().reshape(B, H, S), causal=causal)
         for got, rf, name in ((dq, rdq, "dq"), (dk, rdk, "dk"), (dv, rdv, "dv")):
             gn = got.float().cpu().numpy()
-            err = float(np.abs(gn - rf).max() / max(1.0, np.abs(rf).max()))
+            err = float(np.abs(gn - rf).max() / max(np.abs(rf).max(), 1e-300))
             if not np.isfinite(gn).all() or err > (3e-3 if got.dtype == torch.float32 else 1.2e-2):
                 return "%s err %.3e %r" % (name, err, what)
     except Exception as e:  # noqa: BLE001
