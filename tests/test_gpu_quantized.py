@@ -423,3 +423,47 @@ def test_quantized_backward_over_the_range_of_every_operand(D, causal, gq, gk, g
         a, b = a.double(), b.double()
         assert torch.isfinite(a).all(), name
         assert float((a - b).abs().max() / b.abs().max()) < 2e-3, (name, float((a - b).abs().max() / b.abs().max()))
+
+
+def test_quantized_forward_and_backward_replayed_in_a_graph_follow_the_data():
+    """ONE captured quantised forward + backward, replayed while V and dO change scale by 2^±20 between replays: the exponents of the fp16
+    images are found on the device inside the captured launches (memset nodes, amax passes, the quantiser's exchange), nothing is baked in at
+    capture -- every replay equals the eager call on the same data, bit for bit."""
+    import torch
+    import umfa_torch
+    torch.manual_seed(31)
+    B, H, S, D = 1, 4, 1024, 128
+    q, k = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(2))
+    v0, do0 = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(2))
+    v, do = v0.clone(), do0.clone()
+    out = torch.empty(B, H, S, D, device="cuda", dtype=torch.float32)
+    lse = torch.empty(B * H * S, device="cuda", dtype=torch.float32)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(2):  # warm the (device, stream) pools on the stream that will capture
+            umfa_torch.quantized_attention_forward_stream(q, k, v, return_lse=True, out=out, lse=lse)
+            g_eager = umfa_torch.quantized_attention_backward_stream(do, q, k, v, out, lse)
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            umfa_torch.quantized_attention_forward_stream(q, k, v, return_lse=True, out=out, lse=lse)
+            g_cap = umfa_torch.quantized_attention_backward_stream(do, q, k, v, out, lse)
+        for ev, edo in ((0, 0), (20, -20), (-20, 20), (0, -30)):
+            v.copy_((v0.float() * 2.0 ** ev).to(torch.bfloat16))
+            do.copy_((do0.float() * 2.0 ** edo).to(torch.bfloat16))
+            graph.replay()
+            side.synchronize()
+            o_r, grads_r = out.clone(), [t.clone() for t in g_cap[:3]]
+            o_e = umfa_torch.quantized_attention_forward_stream(q, k, v, return_lse=True)
+            g_e = umfa_torch.quantized_attention_backward_stream(do, q, k, v, o_e[0], o_e[1])
+            side.synchronize()
+            assert torch.equal(o_r, o_e[0]), (ev, edo)
+            for a, b in zip(grads_r, g_e[:3]):
+                assert torch.isfinite(a).all() and torch.equal(a, b), (ev, edo)
+            assert int(g_cap[3].item()) == 0
+            # and linear in the scales, to the engine's tolerance
+            if (ev, edo) == (0, 0):
+                base = [t.double() for t in grads_r]
+            else:
+                for a, b0, e in zip(grads_r, base, (ev + edo, ev + edo, edo)):
+                    assert float((a.double() * 2.0 ** -e - b0).abs().max() / b0.abs().max()) < 3e-3, (ev, edo)
