@@ -557,7 +557,25 @@ def run_rank(args) -> None:
                                                    "mask_bytes": int(m32.numel() * 4), "mask_read_tbps_if_read_once": round(m32.numel() * 4 / tm / 1e9, 2),
                                                    "rel_vs_quantised_oracle": rel4,
                                                    "mask": "fp32 additive [1,16,8192,8192] (0 / -inf, four documents of 2048): the reference ABI's form"}
-            del q4, k4, v4, m32, out4, lse4
+            # ... and the same mask the way a torch caller HAS it -- bool [1, 1, S, S], 64 MB -- through umfa_quantized_forward_masked_stream
+            # (read in place with its strides: nothing is expanded); same rows, same oracle
+            mbool = mb[None, None].contiguous()
+            fn4b = lambda: umfa_torch.quantized_attention_forward_stream(q4, k4, v4, mask=mbool, out=out4, lse=lse4)  # noqa: E731
+            tmb = graph_ms(fn4b, 6, warmup=2)
+            fn4b()
+            torch.cuda.synchronize()
+            rel4b = 0.0
+            for h4 in (0, 9):
+                rq = _np4.ascontiguousarray(_par.bits(q4[:, h4:h4 + 1])[:, :, rows4])
+                mrow = _np4.ascontiguousarray(m32[0, h4][torch.as_tensor(rows4, device=dev)].cpu().numpy())[None, None]
+                ref4, _ = _orc4.quantized_forward(rq, _par.bits(k4[:, h4:h4 + 1]), _par.bits(v4[:, h4:h4 + 1]), mask=mrow)
+                got4 = out4[:, h4:h4 + 1][:, :, torch.as_tensor(rows4, device=dev)].cpu().numpy()
+                rel4b = max(rel4b, float(_np4.abs(got4 - ref4).max() / _np4.abs(ref4).max()))
+            configs["cfg4_int8_mask_blockdiag_bool"] = {"ms": round(tmb, 4), "kernel": umfa_torch.last_kernel(), "visible_fraction": 0.25,
+                                                        "tflops_of_visible_work": round(f4m * 0.25 / tmb / 1e9, 1), "mask_bytes": int(mbool.numel()),
+                                                        "rel_vs_quantised_oracle": rel4b,
+                                                        "mask": "bool [1,1,8192,8192], the same four documents: umfa_quantized_forward_masked_stream (additive entry)"}
+            del q4, k4, v4, m32, out4, lse4, mbool
         except Exception as exc:  # noqa: BLE001
             configs["cfg4_int8_mask_blockdiag"] = {"error": repr(exc)}
         extra["configs"] = configs

@@ -379,6 +379,17 @@ mfa_error_t umfa_quantized_forward_stream(mfa_context_t context, void* stream, c
                                           float softmax_scale, bool causal, int32_t target_precision, int32_t quant_mode,
                                           int32_t input_precision);
 
+/* MI355X extra: umfa_quantized_forward_stream with the mask the caller has: any <= 4-D broadcastable bool / fp16 / bf16 / fp32 tensor with
+ * ELEMENT strides (the arguments of umfa_attention_forward_stream; mfa_prepare_mask's semantics, [B]:157-242) instead of the dense fp32
+ * [B,H,Sq,Skv] expansion -- a bool [1,1,Sq,Skv] mask stays Sq Skv bytes (64 MB at S 8192) where the expansion is 4 B H Sq Skv (4.3 GB at
+ * B1 H16).  mask_type MFA_MASK_TYPE_NONE or mask NULL: no mask. */
+mfa_error_t umfa_quantized_forward_masked_stream(mfa_context_t context, void* stream, const void* q, const void* k, const void* v, float* out,
+                                                 float* lse, const void* mask, const int64_t* mask_shape, const int64_t* mask_strides,
+                                                 uint32_t mask_ndim, int32_t mask_type, int32_t mask_scalar_type, uint32_t batch_size,
+                                                 uint32_t seq_len_q, uint32_t seq_len_kv, uint32_t num_heads, uint16_t head_dim,
+                                                 float softmax_scale, bool causal, int32_t target_precision, int32_t quant_mode,
+                                                 int32_t input_precision);
+
 /* MI355X extra: mfa_quantized_backward in-stream (dense BHSD device pointers, caller's stream, never synchronises).
  * Same engines as the blocking entry (16-bit MFMA backward on fp16 de-quantised operands at head_dim 64 / 128 / 256,
  * else fp32-exact).  Every operand enters the fp16 engine as a power-of-two multiple with its largest magnitude in [1, 2) -- the

@@ -467,3 +467,65 @@ def test_quantized_forward_and_backward_replayed_in_a_graph_follow_the_data():
             else:
                 for a, b0, e in zip(grads_r, base, (ev + edo, ev + edo, edo)):
                     assert float((a.double() * 2.0 ** -e - b0).abs().max() / b0.abs().max()) < 3e-3, (ev, edo)
+
+
+@pytest.mark.parametrize("kind", ["bool_2d", "bool_padding", "bool_per_head", "f16_3d", "f32_strided", "bf16_bias", "f32_dense"])
+@pytest.mark.parametrize("shape,causal", [((2, 3, 300, 333, 128), False), ((1, 2, 512, 512, 64), False), ((1, 2, 257, 257, 128), True)])
+def test_quantized_forward_with_the_callers_mask_tensor(kind, shape, causal):
+    """umfa_quantized_forward_masked_stream: the mask as the caller has it -- any <= 4-D broadcastable bool / fp16 / bf16 / fp32 tensor, read in
+    place with its strides (mfa_prepare_mask's semantics, MFABridge.swift:157-242) -- instead of the dense fp32 [B, H, Sq, Skv] expansion the
+    reference's quantised entry takes.  Against the oracle's quantised restatement with the expanded mask, and against this library's own dense
+    entry on the expansion (the same kernel reading different bytes)."""
+    import ctypes
+    import torch
+    import umfa_torch
+    from umfa_torch import ops
+    orc = _oracle()
+    B, H, Sq, Skv, D = shape
+    torch.manual_seed(Sq + D)
+    q = torch.randn(B, H, Sq, D, device="cuda", dtype=torch.bfloat16)
+    k, v = (torch.randn(B, H, Skv, D, device="cuda", dtype=torch.bfloat16) for _ in range(2))
+    g = torch.Generator(device="cuda").manual_seed(7)
+    if kind == "bool_2d":
+        m = torch.rand(Sq, Skv, device="cuda", generator=g) < 0.5
+        m[:, 0] = True
+        m[5] = False  # a row that attends to nothing
+    elif kind == "bool_padding":
+        m = (torch.arange(Skv, device="cuda")[None, None, None, :] < torch.tensor([Skv - 40 * (b + 1) for b in range(B)], device="cuda")[:, None, None, None])
+    elif kind == "bool_per_head":
+        m = torch.rand(1, H, Sq, Skv, device="cuda", generator=g) < 0.7
+        m[..., 3] = True
+    elif kind == "f16_3d":
+        m = (torch.randn(H, Sq, Skv, device="cuda", generator=g) * 2).half()
+    elif kind == "f32_strided":
+        m = (torch.randn(B, 1, Sq, 2 * Skv, device="cuda", generator=g) * 2)[..., ::2]
+    elif kind == "bf16_bias":
+        m = (torch.randn(1, 1, Sq, Skv, device="cuda", generator=g) * 3).bfloat16()
+        m[0, 0, :, Skv // 2:] = float("-inf")
+    else:
+        m = torch.randn(B, H, Sq, Skv, device="cuda", generator=g)
+    o, lse = umfa_torch.quantized_attention_forward_stream(q, k, v, mask=m, causal=causal, return_lse=True)
+    kern = umfa_torch.last_kernel()
+    assert kern.startswith("fa_fwd_i8<"), kern
+    full = torch.zeros(B, H, Sq, Skv, device="cuda", dtype=torch.float32)
+    full = full.masked_fill(~m, float("-inf")) if m.dtype == torch.bool else full + m.float()
+    full = full.contiguous()
+    ref, rlse = orc.quantized_forward(q.float().cpu().numpy(), k.float().cpu().numpy(), v.float().cpu().numpy(), causal=causal,
+                                      mask=full.cpu().numpy(), bits=8, quant_mode=2)
+    on = o.cpu().numpy()
+    assert np.isfinite(on).all()
+    assert rel_err(on, ref) < 2e-3, rel_err(on, ref)
+    dead = np.isneginf(rlse)
+    assert (on.reshape(-1, D)[dead.reshape(-1)] == 0).all()
+    # the reference ABI's form of the same mask through the dense entry
+    o2 = torch.empty_like(o)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    rc = ops._lib.umfa_quantized_forward_stream(ops.context(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream), vp(q), vp(k), vp(v), vp(o2), None,
+                                                vp(full), B, Sq, Skv, H, D, float(D) ** -0.5, causal, 3, 2, ops._PREC[q.dtype])
+    assert rc == 0
+    torch.cuda.synchronize()
+    if m.dtype == torch.bool:
+        assert torch.equal(o, o2)  # 0 / -inf terms: the same arithmetic whichever bytes they were read from
+    else:
+        # (16-byte loads fuse the log2(e) multiply into an fma, scalar reads do not: a last-bit difference in a score can flip the fp16 rounding of its P)
+        assert float((o - o2).abs().max()) <= 2e-4 * float(o2.abs().max())

@@ -1,0 +1,33 @@
+#!/bin/bash
+# trip ah: the quantised forward with the caller's own mask tensor -- tests, config 4 with a block-diagonal mask: bool [1,1,S,S] vs the dense fp32 expansion
+O=gpurun_out/r5ah; mkdir -p $O
+python3 -m pytest tests/test_gpu_quantized.py tests/test_gpu_sdpa.py tests/test_gpu_value_fuzz.py tests/test_gpu_compat_surfaces.py -m gpu -x -q > $O/pytest.txt 2>&1; tail -4 $O/pytest.txt
+python3 - <<'PY' 2>&1 | grep -v amdgpu | tee $O/masked_quantised_timing.txt
+import sys, torch
+sys.path[:0]=['.','universal-metal-flash-attention_amd']
+import umfa_torch
+def timeit(fn, n=6):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    g=torch.cuda.CUDAGraph(); s=torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        fn(); s.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(n): fn()
+        g.replay(); s.synchronize(); ts=[]
+        for r in range(5):
+            a,b=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
+            a.record(); g.replay(); b.record(); b.synchronize(); ts.append(a.elapsed_time(b)/n)
+    return sorted(ts)[2]
+B,H,S,D=1,16,8192,128
+q,k,v=(torch.randn(B,H,S,D,device='cuda',dtype=torch.bfloat16) for _ in range(3))
+o=torch.empty(B,H,S,D,device='cuda',dtype=torch.float32); l=torch.empty(B*H*S,device='cuda',dtype=torch.float32)
+i=torch.arange(S,device='cuda')
+mb=((i[:,None]//2048)==(i[None,:]//2048))[None,None].contiguous()
+dense=torch.zeros(B,H,S,S,device='cuda').masked_fill(~mb,float('-inf')).contiguous()
+t0=timeit(lambda: umfa_torch.quantized_attention_forward_stream(q,k,v,out=o,lse=l))
+print('config 4 unmasked', umfa_torch.last_kernel(), round(t0,4),'ms')
+for name,m in (('bool [1,1,S,S] (64 MB)',mb),('dense fp32 [B,H,S,S] (4.3 GB): the reference ABI form',dense),('padding bool [1,1,1,S]',(i<6000)[None,None,None,:].contiguous())):
+    t=timeit(lambda: umfa_torch.quantized_attention_forward_stream(q,k,v,mask=m,out=o,lse=l))
+    print('config 4 +', name, umfa_torch.last_kernel(), round(t,4),'ms')
+PY

@@ -495,7 +495,12 @@ struct I8FwdParams {
     const float* k_scale;
     float* o;
     float* lse;
-    const float* mask;  // fp32 additive [B,H,Sq,Skv] or NULL
+    const void* mask;   // NULL, or a mask of kind mask_kind with element strides ms[] over (batch, head, row, key) -- 0 = broadcast.  The reference ABI's
+                        // form is MK_F32 dense [B,H,Sq,Skv]; umfa_quantized_forward_masked_stream hands over what the caller has (a bool [1,1,Sq,Skv]
+                        // stays 1 byte per element instead of becoming 4 B H bytes)
+    int mask_kind;
+    int64_t ms[4];
+    uint32_t mf_bs, mf_hs;  // tile-flag slab strides of batch / head (0 = broadcast), as FwdParams
     // tile flags of the mask (fa_aux.hip mask_flags_kernel, as for fa_fwd16): one byte per (b, h, 32-row block, 64-key tile) -- 1: every element
     // masked (the wave skips the tile), 2: every element attends with a zero term (the tile runs without reading the mask), 0: mixed
     const uint8_t* mask_flags;
@@ -612,15 +617,17 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
     float m = -INFINITY, l = 0.0f;
     const int tr_qq = (lane >> 2) & 3, tr_pp = lane & 3, tr_g1 = (lane >> 4) & 1;
-    const int64_t mrow = HAS_MASK ? ((int64_t)bh * p.Sq + q_row) * p.Skv : 0;
-    const bool mvec = HAS_MASK && (p.Skv & 3u) == 0 && ((uintptr_t)p.mask & 15) == 0;  // aligned rows: four keys per load
+    const int64_t mrow = HAS_MASK ? (int64_t)(bh / p.H) * p.ms[0] + (int64_t)(bh % p.H) * p.ms[1] + (int64_t)q_row * p.ms[2] : 0;
+    // fp32 rows, contiguous and 16-byte aligned: four keys per load
+    const bool mvec = HAS_MASK && p.mask_kind == MK_F32 && p.ms[3] == 1 && (p.Skv & 3u) == 0 && ((uintptr_t)p.mask & 15) == 0 &&
+                      ((p.ms[0] | p.ms[1] | p.ms[2]) & 3) == 0;
     // The reference ABI hands the quantised entry a DENSE fp32 [B,H,Sq,Skv] mask (MFABridge+Quantized.swift:227-358): 4.3 GB at config 4.
     // Read per score it came in at 0.76-0.96 TB/s (each lane its own row: a quarter of every sector used) and the masked call took 10-14 x
     // the unmasked one.  The tile-flag pre-pass reads it ONCE at streaming rate; a 0 / -inf mask then costs this kernel no mask read at all.
     const uint8_t* mf_row = nullptr;
     int mf_reg = 0;
     if (HAS_MASK && p.mask_flags && BN == 64 && wave_q0 / 32 < p.mf_nrb)
-        mf_row = p.mask_flags + ((uint64_t)bh * p.mf_nrb + wave_q0 / 32) * p.mf_ntiles;
+        mf_row = p.mask_flags + (((uint64_t)(bh / p.H) * p.mf_bs + (uint64_t)(bh % p.H) * p.mf_hs) * p.mf_nrb + wave_q0 / 32) * p.mf_ntiles;
 
     stage_load(0);
     stage_write(0);
@@ -674,7 +681,7 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
                         for (int g = 0; g < 4; ++g) {
                             const uint32_t key0 = key_base + 32 * kb + 8 * g + 4 * hi;
                             f32x4 w = {0.0f, 0.0f, 0.0f, 0.0f};
-                            if (mflag != 2 && key0 < p.Skv && q_row < p.Sq) w = __builtin_nontemporal_load((const f32x4*)(p.mask + mrow + key0));
+                            if (mflag != 2 && key0 < p.Skv && q_row < p.Sq) w = __builtin_nontemporal_load((const f32x4*)((const float*)p.mask + mrow + key0));
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const int r = 4 * g + e;
@@ -691,7 +698,7 @@ __global__ __launch_bounds__(256, (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_f
                     for (int r = 0; r < 16; ++r) {
                         const uint32_t key = key_base + 32 * kb + acc_row(r, hi);
                         float x = (float)s[kb][r] * ct;
-                        if (mflag != 2 && key < p.Skv && q_row < p.Sq) x += p.mask[mrow + key] * UMFA_LOG2E;
+                        if (mflag != 2 && key < p.Skv && q_row < p.Sq) x += mask_term(p.mask, mrow + (int64_t)key * p.ms[3], p.mask_kind);
                         if (edge && (key >= p.Skv || (CAUSAL && key > q_row))) x = -INFINITY;
                         tv[kb][r] = x;
                         mx = fmaxf(mx, x);
@@ -995,15 +1002,24 @@ hipError_t launch_quantized_fwd(const FwdParams& fp, int bits, int quant_mode, v
     p.q_scale = v.q_scale; p.k_scale = v.k_scale;
     p.vsc = v.v8 ? nullptr : fp.vsc;
     p.o = (float*)fp.o; p.lse = fp.lse;
-    p.mask = (const float*)fp.mask;
-    if (fp.mask && !tuning().no_mask_flags.load(std::memory_order_relaxed)) {
-        // the mask's tile flags (dense fp32 [B, H, Sq, Skv]): one streaming pass over it, into the workspace
+    p.mask = fp.mask;
+    if (fp.mask) {
+        // fp.mask_kind == MK_NONE with a mask: the reference ABI's dense fp32 additive [B, H, Sq, Skv]; else what the caller normalised (runtime.hip normalise_mask)
         FwdParams mp = fp;
-        mp.mask_kind = MK_F32;
-        mp.ms[0] = (int64_t)fp.H * fp.Sq * fp.Skv; mp.ms[1] = (int64_t)fp.Sq * fp.Skv; mp.ms[2] = fp.Skv; mp.ms[3] = 1;
-        uint8_t* fl = (uint8_t*)workspace + ws_layout(fp.B, fp.H, fp.Sq, fp.Skv, fp.D, false).mflags;
-        if (launch_mask_flags(mp, fl, stream) == hipSuccess && mp.mask_flags && mp.mf_bs == fp.H && mp.mf_hs == 1) {
-            p.mask_flags = mp.mask_flags; p.mf_nrb = mp.mf_nrb; p.mf_ntiles = mp.mf_ntiles;
+        if (fp.mask_kind == MK_NONE) {
+            mp.mask_kind = MK_F32;
+            mp.ms[0] = (int64_t)fp.H * fp.Sq * fp.Skv; mp.ms[1] = (int64_t)fp.Sq * fp.Skv; mp.ms[2] = fp.Skv; mp.ms[3] = 1;
+        }
+        if (mp.mask_kind == MK_WINDOW) return hipErrorInvalidValue;
+        p.mask_kind = mp.mask_kind;
+        for (int i = 0; i < 4; ++i) p.ms[i] = mp.ms[i];
+        if (!tuning().no_mask_flags.load(std::memory_order_relaxed)) {
+            // the mask's tile flags: one streaming pass over every DISTINCT mask byte, into the workspace
+            uint8_t* fl = (uint8_t*)workspace + ws_layout(fp.B, fp.H, fp.Sq, fp.Skv, fp.D, false).mflags;
+            if (launch_mask_flags(mp, fl, stream) == hipSuccess && mp.mask_flags) {
+                p.mask_flags = mp.mask_flags; p.mf_nrb = mp.mf_nrb; p.mf_ntiles = mp.mf_ntiles;
+                p.mf_bs = mp.mf_bs; p.mf_hs = mp.mf_hs;
+            }
         }
     }
     p.B = fp.B; p.H = fp.H; p.Sq = fp.Sq; p.Skv = fp.Skv; p.D = fp.D;

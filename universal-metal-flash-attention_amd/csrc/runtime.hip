@@ -17,22 +17,6 @@ const bool g_debug = [] {
 }();
 std::mutex g_ctx_mu;
 Context* g_ctx = nullptr;
-}  // namespace umfa_rt
-
-namespace {
-
-int parse_precision(const char* s) {  // MFABridge.swift:1438-1451
-    if (!s) return MFA_PRECISION_FP32;
-    std::string t(s);
-    for (auto& ch : t) ch = (char)tolower(ch);
-    if (t == "fp16" || t == "float16") return MFA_PRECISION_FP16;
-    if (t == "bf16" || t == "bfloat16") return MFA_PRECISION_BF16;
-    if (t == "fp32" || t == "float32") return MFA_PRECISION_FP32;
-    if (t == "int8") return MFA_PRECISION_INT8;
-    if (t == "int4") return MFA_PRECISION_INT4;
-    return MFA_PRECISION_FP32;
-}
-
 
 // Normalise a <=4-D mask onto (b, h, q, k) strides; size-1 dims broadcast (MFABridge.swift:186-198).
 bool normalise_mask(const int64_t* shape, const int64_t* strides, uint32_t ndim, int type, int scalar,
@@ -53,6 +37,22 @@ bool normalise_mask(const int64_t* shape, const int64_t* strides, uint32_t ndim,
     }
     return p.mask_kind != MK_NONE;
 }
+}  // namespace umfa_rt
+
+namespace {
+
+int parse_precision(const char* s) {  // MFABridge.swift:1438-1451
+    if (!s) return MFA_PRECISION_FP32;
+    std::string t(s);
+    for (auto& ch : t) ch = (char)tolower(ch);
+    if (t == "fp16" || t == "float16") return MFA_PRECISION_FP16;
+    if (t == "bf16" || t == "bfloat16") return MFA_PRECISION_BF16;
+    if (t == "fp32" || t == "float32") return MFA_PRECISION_FP32;
+    if (t == "int8") return MFA_PRECISION_INT8;
+    if (t == "int4") return MFA_PRECISION_INT4;
+    return MFA_PRECISION_FP32;
+}
+
 
 void dense_strides(FwdParams& p, bool tq, bool tk, bool tv, bool to) {
     // row-major per head [S, D]; "transposed" = per-head [D, S] storage (mfa_ffi.h:266-269)

@@ -407,4 +407,7 @@ inline mfa_error_t wrap_pointer(void* ptr, size_t bytes, const int64_t* shape, c
 inline int dense_prec(int p) { return p == 0 ? umfa::P_FP16 : p == 1 ? umfa::P_BF16 : umfa::P_FP32; }
 inline size_t elem_bytes(int prec) { return prec == umfa::P_FP32 ? 4 : 2; }
 
+// Normalise a <= 4-D mask onto (b, h, q, k) element strides (runtime.hip; mfa_prepare_mask, MFABridge.swift:157-242); false: no mask
+bool normalise_mask(const int64_t* shape, const int64_t* strides, uint32_t ndim, int type, int scalar, umfa::FwdParams& p);
+
 }  // namespace umfa_rt

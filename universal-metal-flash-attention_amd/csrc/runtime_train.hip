@@ -255,11 +255,11 @@ int32_t mfa_quantized_forward_with_lse(mfa_context_t context, mfa_buffer_t q, mf
 // caller's stream, no upload / download / synchronise (the reference's entry blocks; a serving loop should not).
 // O is fp32 [B,H,Sq,D]; lse and mask (fp32 additive [B,H,Sq,Skv]) optional.  The quantiser workspace and the split-item
 // scratch belong to the (device, stream) pool, so calls on different streams do not interfere.
-mfa_error_t umfa_quantized_forward_stream(mfa_context_t context, void* stream, const void* q, const void* k,
-                                          const void* v, float* out, float* lse, const float* mask, uint32_t batch_size,
-                                          uint32_t seq_len_q, uint32_t seq_len_kv, uint32_t num_heads, uint16_t head_dim,
-                                          float softmax_scale, bool causal, int32_t target_precision, int32_t quant_mode,
-                                          int32_t input_precision) {
+static mfa_error_t quantized_forward_stream_impl(mfa_context_t context, void* stream, const void* q, const void* k, const void* v, float* out, float* lse,
+                                                const void* mask, const int64_t* mask_shape, const int64_t* mask_strides, uint32_t mask_ndim,
+                                                int32_t mask_type, int32_t mask_scalar_type, uint32_t batch_size, uint32_t seq_len_q, uint32_t seq_len_kv,
+                                                uint32_t num_heads, uint16_t head_dim, float softmax_scale, bool causal, int32_t target_precision,
+                                                int32_t quant_mode, int32_t input_precision) {
     Context* ctx = as_ctx(context);
     if (!ctx || !q || !k || !v || !out) return MFA_ERROR_INVALID_ARGS;
     const uint32_t B = batch_size, H = num_heads, Sq = seq_len_q, Skv = seq_len_kv, D = head_dim;
@@ -274,10 +274,16 @@ mfa_error_t umfa_quantized_forward_stream(mfa_context_t context, void* stream, c
     if (!ws) return MFA_ERROR_MEMORY_ALLOCATION;
     FwdParams p;
     memset(&p, 0, sizeof(p));
-    p.q = q; p.k = k; p.v = v; p.o = out; p.lse = lse; p.mask = mask;
+    p.q = q; p.k = k; p.v = v; p.o = out; p.lse = lse;
     p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv; p.D = D;
     p.scale = softmax_scale; p.causal = causal ? 1 : 0;
     p.in_prec = dense_prec(input_precision); p.out_prec = P_FP32;
+    if (mask && mask_ndim == 0) {
+        p.mask = mask;  // the reference ABI's form: dense fp32 additive [B, H, Sq, Skv] (launch_quantized_fwd: mask_kind MK_NONE + a mask)
+    } else if (mask && mask_type != MFA_MASK_TYPE_NONE) {
+        if (mask_ndim > 4 || !mask_shape || !mask_strides) return MFA_ERROR_INVALID_ARGS;
+        if (normalise_mask(mask_shape, mask_strides, mask_ndim, mask_type, mask_scalar_type, p)) p.mask = mask;  // (additive bytes: no mask, as on the dense path)
+    }
     if (fwd_w64_i8_supported(p)) {
         const FwdW64Plan plan = fwd_w64_plan(p);
         StreamScratch& sc = ctx->pool(pool_dev, (hipStream_t)stream);
@@ -295,6 +301,30 @@ mfa_error_t umfa_quantized_forward_stream(mfa_context_t context, void* stream, c
     hipError_t e = launch_quantized_fwd(p, bits, mode, ws, (hipStream_t)stream, &name);
     ctx->last_kernel = name;
     return e == hipSuccess ? MFA_SUCCESS : e == hipErrorInvalidValue ? MFA_ERROR_INVALID_ARGS : MFA_ERROR_EXECUTION_FAILED;
+}
+
+mfa_error_t umfa_quantized_forward_stream(mfa_context_t context, void* stream, const void* q, const void* k,
+                                          const void* v, float* out, float* lse, const float* mask, uint32_t batch_size,
+                                          uint32_t seq_len_q, uint32_t seq_len_kv, uint32_t num_heads, uint16_t head_dim,
+                                          float softmax_scale, bool causal, int32_t target_precision, int32_t quant_mode,
+                                          int32_t input_precision) {
+    return quantized_forward_stream_impl(context, stream, q, k, v, out, lse, mask, nullptr, nullptr, 0, MFA_MASK_TYPE_ADDITIVE, MFA_MASK_SCALAR_FP32, batch_size,
+                                         seq_len_q, seq_len_kv, num_heads, head_dim, softmax_scale, causal, target_precision, quant_mode, input_precision);
+}
+
+// MI355X extra: umfa_quantized_forward_stream with the mask the caller HAS -- any <= 4-D broadcastable bool / fp16 / bf16 / fp32 tensor with
+// element strides, as umfa_attention_forward_stream takes it (mfa_prepare_mask's semantics, MFABridge.swift:157-242) -- instead of the dense
+// fp32 [B, H, Sq, Skv] expansion the reference's quantised entry is handed (4.3 GB at B1 H16 S8192: the call was bound by reading it).
+mfa_error_t umfa_quantized_forward_masked_stream(mfa_context_t context, void* stream, const void* q, const void* k, const void* v, float* out,
+                                                 float* lse, const void* mask, const int64_t* mask_shape, const int64_t* mask_strides,
+                                                 uint32_t mask_ndim, int32_t mask_type, int32_t mask_scalar_type, uint32_t batch_size,
+                                                 uint32_t seq_len_q, uint32_t seq_len_kv, uint32_t num_heads, uint16_t head_dim,
+                                                 float softmax_scale, bool causal, int32_t target_precision, int32_t quant_mode,
+                                                 int32_t input_precision) {
+    if (mask && mask_type != MFA_MASK_TYPE_NONE && (mask_ndim == 0 || mask_ndim > 4)) return MFA_ERROR_INVALID_ARGS;
+    return quantized_forward_stream_impl(context, stream, q, k, v, out, lse, mask_type == MFA_MASK_TYPE_NONE ? nullptr : mask, mask_shape, mask_strides,
+                                         mask_type == MFA_MASK_TYPE_NONE ? 0 : mask_ndim, mask_type, mask_scalar_type, batch_size, seq_len_q, seq_len_kv,
+                                         num_heads, head_dim, softmax_scale, causal, target_precision, quant_mode, input_precision);
 }
 
 // The 16-bit MFMA backward as the engine of the quantised backward entries: head_dim 64 / 128 / 256, no mask, not forced off

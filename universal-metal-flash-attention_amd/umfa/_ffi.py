@@ -157,6 +157,9 @@ def _load_library(path: str | None = None) -> ctypes.CDLL:
         [mfa_context_t, _vp] + [_vp] * 10 + _DIMS + [_f32, _b, _i32, _i32, _b, _b])
     sig("umfa_quantized_forward_stream", mfa_error_t,
         [mfa_context_t, _vp] + [_vp] * 6 + _DIMS + [_f32, _b, _i32, _i32, _i32])
+    if path is None or hasattr(lib, "umfa_quantized_forward_masked_stream"):
+        sig("umfa_quantized_forward_masked_stream", mfa_error_t,
+            [mfa_context_t, _vp] + [_vp] * 6 + [_vp, _vp, _u32, _i32, _i32] + _DIMS + [_f32, _b, _i32, _i32, _i32])
     if path is None or hasattr(lib, "umfa_attention_backward_gqa_stream"):
         sig("umfa_attention_backward_gqa_stream", mfa_error_t,
             [mfa_context_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _u32, ctypes.c_uint16,

@@ -241,18 +241,23 @@ def quantized_attention_forward_stream(q, k, v, *, scale=None, causal=False, mas
     if lse is None:
         lse = torch.empty((B * H * Sq,), dtype=torch.float32, device=q.device)
     assert out.dtype == torch.float32 and out.is_contiguous() and lse.dtype == torch.float32 and lse.numel() == B * H * Sq
+    vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+    stream = ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream)
+    tail = (B, Sq, Skv, H, D, float(scale), bool(causal), 4 if bits == 4 else 3, _quant_mode(quant_mode), _PREC[q.dtype])
+    if mask is not None and hasattr(_lib, "umfa_quantized_forward_masked_stream"):
+        # the mask as the caller has it -- any <= 4-D broadcastable bool / float tensor, read in place with its strides -- instead of the dense
+        # fp32 [B, H, Sq, Skv] expansion of the reference's quantised entry (4.3 GB at config 4; a bool [1, 1, S, S] mask is 64 MB)
+        mptr, mshape, mstr, mnd, mt, ms = _mask_args(mask)
+        _check_error(_lib.umfa_quantized_forward_masked_stream(context(), stream, vp(q), vp(k), vp(v), vp(out), vp(lse), mptr, mshape, mstr, mnd, mt, ms, *tail))
+        return (out, lse) if return_lse else out
     m32 = None
-    if mask is not None:
+    if mask is not None:  # (a library without the masked entry: UMFA_LIBRARY pointing at an older build)
         if mask.dtype == torch.float32 and tuple(mask.shape) == (B, H, Sq, Skv) and mask.is_contiguous():
-            m32 = mask  # already the ABI's form (dense fp32 additive): no copy -- at config 4 that tensor is 4.3 GB
+            m32 = mask
         else:
             m32 = torch.zeros((B, H, Sq, Skv), dtype=torch.float32, device=q.device)
             m32 = (m32.masked_fill(~mask, float("-inf")) if mask.dtype == torch.bool else m32 + mask.float()).contiguous()
-    vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
-    _check_error(_lib.umfa_quantized_forward_stream(
-        context(), ctypes.c_void_p(torch.cuda.current_stream(q.device).cuda_stream), vp(q), vp(k), vp(v), vp(out),
-        vp(lse), vp(m32), B, Sq, Skv, H, D, float(scale), bool(causal), 4 if bits == 4 else 3,
-        _quant_mode(quant_mode), _PREC[q.dtype]))
+    _check_error(_lib.umfa_quantized_forward_stream(context(), stream, vp(q), vp(k), vp(v), vp(out), vp(lse), vp(m32), *tail))
     return (out, lse) if return_lse else out
 
 
