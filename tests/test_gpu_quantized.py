@@ -529,3 +529,25 @@ def test_quantized_forward_with_the_callers_mask_tensor(kind, shape, causal):
     else:
         # (16-byte loads fuse the log2(e) multiply into an fma, scalar reads do not: a last-bit difference in a score can flip the fp16 rounding of its P)
         assert float((o - o2).abs().max()) <= 2e-4 * float(o2.abs().max())
+
+
+def test_quantized_forward_tensorwise_slab_just_above_half_a_step():
+    """tensor-wise mode, fp32 operands: a slab whose largest |v| is just above s / 2 quantises to q = +-1, so its image entries q s are almost TWICE the
+    slab's amax -- with the amax at the top of a binade the image needs its second binade of headroom (vimage_exponent) or it rounds to inf."""
+    import torch
+    import umfa_torch
+    orc = _oracle()
+    torch.manual_seed(3)
+    B, H, S, D = 1, 2, 256, 128
+    q, k = (torch.randn(B, H, S, D, device="cuda") for _ in range(2))
+    v = torch.zeros(B, H, S, D, device="cuda")
+    step = 3.9992
+    v[0, 0] = torch.randn(S, D, device="cuda")
+    v[0, 0, 7, 3] = 127.0 * step                      # the tensor's amax: s = 3.9992
+    v[0, 1] = torch.where(torch.rand(S, D, device="cuda") < 0.5, 1.9998, -1.9998)  # slab 1: |v| = 1.9998 > s / 2 everywhere -> q = +-1, q s = 3.9992
+    o = umfa_torch.quantized_attention_forward_stream(q, k, v, quant_mode="tensor")
+    ref, _ = orc.quantized_forward(q.cpu().numpy(), k.cpu().numpy(), v.cpu().numpy(), bits=8, quant_mode=0)
+    on = o.cpu().numpy()
+    assert np.isfinite(on).all()
+    for h in range(H):
+        assert np.abs(on[0, h] - ref[0, h]).max() < 2e-3 * np.abs(ref[0, h]).max(), h

@@ -60,13 +60,14 @@ struct QuantParams {
     uint32_t wait_ticks;  // bound of the exchange's wait (100 MHz ticks), then the workgroup reads the slab itself
 };
 
-// e of the image: the slab's largest |v| (top 16 bits of its fp32 pattern) lands in [2^14, 2^15) -- one binade under fp16's last, because
-// q * s can exceed the block's amax by a rounding.  inf / NaN count as the largest finite exponent.
+// e of the image: the slab's largest |v| (top 16 bits of its fp32 pattern) lands in [2^13, 2^14) -- two binades under fp16's last: q * s can
+// exceed the block's amax by a rounding, and in tensor-wise mode (ONE s for the tensor) a slab whose amax is just above s / 2 quantises to
+// q = +-1, i.e. q * s up to twice the slab's amax.  inf / NaN count as the largest finite exponent.
 __device__ __forceinline__ int vimage_exponent(unsigned amax_b16) {
     if (amax_b16 == 0) return 0;
     int E = (int)(amax_b16 >> 7);
     E = E > 254 ? 254 : E;
-    const int e = (E ? E - 127 : -126) - 14;
+    const int e = (E ? E - 127 : -126) - 13;
     return e < -100 ? -100 : e;
 }
 __device__ __forceinline__ float exp2i(int e) { return __uint_as_float((unsigned)(127 + e) << 23); }
