@@ -7,7 +7,9 @@
 //     by a flash forward whose QK^T runs on the int8 MFMA (v_mfma_i32_32x32x32_i8, 2x the bf16 rate):
 //         S = (sum_d q8 k8) * sq[q-block] * sk[k-block]        exact int32 accumulation
 //     and whose PV runs on the fp16 MFMA with V de-quantised ONCE by the pre-pass to fp16
-//     (q_v * s_v has <= 7 significant bits times a scale: fp16's 11 bits hold it to 2^-12).
+//     (q_v * s_v has <= 7 significant bits times a scale: fp16's 11 bits hold it to 2^-12) -- as q_v * s_v * 2^-e, one
+//     power of two e per (batch, head) slab found on the device (fp16 has five exponent bits, the caller's V eight:
+//     QuantParams::vhdr), with 2^e handed back in the kernels' epilogues.
 // Quantiser = the reference's symmetric formula (Tests/QuantizationTests/QuantizationTests.swift:72-128):
 //   scale = absmax / 127 (INT8) or / 7 (INT4), q = clamp(round_half_away(x / scale)), zero point 0.
 // Block-wise mode (quant_mode 2): one scale per (batch, head, 64 consecutive rows) -- the block edge is
