@@ -551,3 +551,35 @@ def test_quantized_forward_tensorwise_slab_just_above_half_a_step():
     assert np.isfinite(on).all()
     for h in range(H):
         assert np.abs(on[0, h] - ref[0, h]).max() < 2e-3 * np.abs(ref[0, h]).max(), h
+
+
+def test_quantized_entries_on_three_streams_at_once():
+    """the quantised forward (V exchange among the quantiser's workgroups, slab headers of the stream's pool) and backward (amax passes, units table in the
+    stream's workspace) running on three streams at the same time, different shapes and scales: every stream's results equal its own serial run, bit for bit"""
+    import torch
+    import umfa_torch
+    torch.manual_seed(77)
+    cases = []
+    for i, (H, S, D, ev) in enumerate([(8, 1024, 128, -18), (4, 2048, 128, 0), (6, 1024, 64, 25)]):
+        q, k, v, do = (torch.randn(1, H, S, D, device="cuda") for _ in range(4))
+        cases.append([t.bfloat16() for t in (q, k, v * 2.0 ** ev, do * 2.0 ** (-ev - 10))])
+    serial = []
+    for q, k, v, do in cases:
+        o, lse = umfa_torch.quantized_attention_forward_stream(q, k, v, return_lse=True)
+        g = umfa_torch.quantized_attention_backward_stream(do, q, k, v, o, lse)
+        serial.append((o.clone(), [t.clone() for t in g[:3]]))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in cases]
+    for rep in range(6):
+        outs = []
+        for s, (q, k, v, do) in zip(streams, cases):
+            with torch.cuda.stream(s):
+                o, lse = umfa_torch.quantized_attention_forward_stream(q, k, v, return_lse=True)
+                g = umfa_torch.quantized_attention_backward_stream(do, q, k, v, o, lse)
+                outs.append((o, g))
+        torch.cuda.synchronize()
+        for (o, g), (so, sg) in zip(outs, serial):
+            assert torch.equal(o, so)
+            assert int(g[3].item()) == 0
+            for a, b in zip(g[:3], sg):
+                assert torch.equal(a, b)
