@@ -281,3 +281,38 @@ def test_cast_pass_workgroups_that_are_not_served_help_themselves(shape):
     rows = slice(0, min(S, 512))
     ref = _oracle().sdpa_forward(bits(q[:, :, rows].contiguous()), bits(k), bits(v))
     assert _per_slab_err(outs[1][:, :, rows].cpu().numpy(), ref) < NORTH_STAR
+
+
+def test_slab_exchanges_make_progress_on_a_stream_that_owns_four_cus():
+    """hipExtStreamCreateWithCUMask, CUs 0 ... 3: a slab of the V cast pass has 64 workgroups here (16384 keys) and about 20 fit on four CUs at once, so the
+    slab's amax exchange cannot complete by co-residency -- the bounded wait (cast_wait_us) has to, and does: no hang, and the bf16 forward and the
+    quantised forward (the same exchange among the quantiser's V workgroups) equal the full-chip stream's results bit for bit."""
+    import ctypes
+    import umfa_torch
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        fn = hip.hipExtStreamCreateWithCUMask
+    except (OSError, AttributeError):
+        pytest.skip("no hipExtStreamCreateWithCUMask")
+    stream = ctypes.c_void_p()
+    mask = (ctypes.c_uint32 * 8)(0x0000000F, 0, 0, 0, 0, 0, 0, 0)
+    if fn(ctypes.byref(stream), 8, mask) != 0:
+        pytest.skip("CU-masked streams not available")
+    ext = torch.cuda.ExternalStream(stream.value)
+    torch.manual_seed(0)
+    q = torch.randn(1, 2, 1024, 128, device="cuda", dtype=torch.bfloat16)
+    k, v = (torch.randn(1, 2, 16384, 128, device="cuda", dtype=torch.bfloat16) for _ in range(2))
+    v[0, 1] *= 1e-6
+    with umfa_torch.options(force_w64=1):
+        ref = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
+        assert umfa_torch.last_kernel() == "fa_fwd16_w64<bf16,128,pv16>"
+        qref = umfa_torch.quantized_attention_forward_stream(q, k, v)
+        assert umfa_torch.last_kernel() == "fa_fwd_w64_i8<128>"
+        torch.cuda.synchronize()
+        with torch.cuda.stream(ext):
+            for _ in range(2):
+                o = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
+                oq = umfa_torch.quantized_attention_forward_stream(q, k, v)
+                ext.synchronize()
+                assert torch.equal(o, ref) and torch.equal(oq, qref)
+    hip.hipStreamDestroy(stream)
