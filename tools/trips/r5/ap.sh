@@ -1,0 +1,30 @@
+#!/bin/bash
+# trip ap: the 128-row 16-bit kernel -- masked instantiation with an all-true mask against the unmasked instantiation (is there a slow masked body for open tiles, as fa_fwd_i8 had?)
+python3 - <<'PY' 2>&1 | grep -v amdgpu
+import sys, torch
+sys.path[:0]=['.','universal-metal-flash-attention_amd']
+import umfa_torch
+def timeit(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    g=torch.cuda.CUDAGraph(); s=torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        fn(); s.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            for _ in range(n): fn()
+        g.replay(); s.synchronize(); ts=[]
+        for r in range(5):
+            a,b=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
+            a.record(); g.replay(); g.replay(); b.record(); b.synchronize(); ts.append(a.elapsed_time(b)/(2*n))
+    return sorted(ts)[2]
+for (B,H,S,D) in ((1,24,4096,128),(2,16,2048,64),(1,8,4096,256)):
+    q,k,v=(torch.randn(B,H,S,D,device='cuda',dtype=torch.bfloat16) for _ in range(3))
+    o=torch.empty(B,H,S,D,device='cuda',dtype=torch.float32)
+    m=torch.ones(1,1,S,S,dtype=torch.bool,device='cuda')
+    mf=torch.zeros(1,1,S,S,dtype=torch.float16,device='cuda')
+    with umfa_torch.options(no_w64=1, no_w64_mask=1):
+        t0=timeit(lambda: umfa_torch.attention_forward(q,k,v,out=o)); k0=umfa_torch.last_kernel()
+        t1=timeit(lambda: umfa_torch.attention_forward(q,k,v,mask=m,out=o)); k1=umfa_torch.last_kernel()
+        t2=timeit(lambda: umfa_torch.attention_forward(q,k,v,mask=mf,out=o)); k2=umfa_torch.last_kernel()
+    print(f"B{B} H{H} S{S} D{D}: unmasked {k0} {t0:.4f} | all-true bool {k1} {t1:.4f} | all-zero fp16 {k2} {t2:.4f}")
+PY
