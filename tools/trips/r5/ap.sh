@@ -28,4 +28,3 @@ for (B,H,S,D) in ((1,24,4096,128),(2,16,2048,64),(1,8,4096,256)):
         t2=timeit(lambda: umfa_torch.attention_forward(q,k,v,mask=mf,out=o)); k2=umfa_torch.last_kernel()
     print(f"B{B} H{H} S{S} D{D}: unmasked {k0} {t0:.4f} | all-true bool {k1} {t1:.4f} | all-zero fp16 {k2} {t2:.4f}")
 PY
-python3 -m pytest tests/test_gpu_forward.py tests/test_gpu_w64_masks.py tests/test_gpu_value_fuzz.py tests/test_gpu_fuzz.py tests/test_gpu_pv16_range.py tests/test_gpu_sdpa.py tests/test_gpu_wide_heads.py -m gpu -x -q 2>&1 | tail -2
