@@ -258,18 +258,38 @@ __device__ __forceinline__ void load8_as_float(const void* src, int64_t i, float
         for (int j = 0; j < 8; ++j) x[j] = (float)raw[j];
     }
 }
+// up to four dense tensors per launch (blockIdx.y picks one): 8-element groups, eight groups per thread in flight per sweep step
+struct AmaxJob {
+    const void* src[4];
+    int64_t n8[4];
+    uint32_t* word[4];
+};
 template <int PREC>
-__global__ __launch_bounds__(256) void amax_dense_kernel(const void* src, int64_t n8, uint32_t* hdr) {
+__global__ __launch_bounds__(256) void amax_dense_kernel(AmaxJob job) {
     __shared__ unsigned wmax[4];
+    const void* const src = job.src[blockIdx.y];
+    const int64_t n8 = job.n8[blockIdx.y];
     unsigned amax = 0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
-        float x[8];
-        load8_as_float<PREC>(src, i, x);
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    constexpr int U = 8;  // 16-byte loads in flight per thread
+    for (int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x; i0 < n8; i0 += U * stride) {
+        float x[U][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const unsigned a = __float_as_uint(x[j]) & 0x7fffffffu;
-            amax = a > amax ? a : amax;
+        for (int u = 0; u < U; ++u) {
+            if (i0 + u * stride < n8) {
+                load8_as_float<PREC>(src, i0 + u * stride, x[u]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[u][j] = 0.0f;
+            }
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned a = __float_as_uint(x[u][j]) & 0x7fffffffu;
+                amax = a > amax ? a : amax;
+            }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -280,7 +300,10 @@ __global__ __launch_bounds__(256) void amax_dense_kernel(const void* src, int64_
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < 4; ++w) amax = wmax[w] > amax ? wmax[w] : amax;
-        if (amax) (void)__hip_atomic_fetch_max(hdr, amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (same-address atomics serialise at ~50 ns each -- 1024 workgroups per tensor spent 50 us of a 61-us launch in them: few workgroups, and none
+        // from a workgroup whose maximum is already covered)
+        if (amax > __hip_atomic_load(job.word[blockIdx.y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            (void)__hip_atomic_fetch_max(job.word[blockIdx.y], amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 template <int PREC>
@@ -301,15 +324,26 @@ __global__ __launch_bounds__(256) void cast_f16_unit_kernel(const void* src, _Fl
     }
 }
 
-// the largest |x| of a dense tensor, as fp32 bits, max-ed into *word (the caller zeroes it)
-hipError_t launch_amax_dense(const void* src, int prec, int64_t n, uint32_t* word, hipStream_t stream) {
-    if (!src || !word || (n & 7) || (prec != P_FP32 && prec != P_BF16 && prec != P_FP16)) return hipErrorInvalidValue;
-    const int64_t n8 = n / 8;
-    const unsigned agrid = (unsigned)((n8 + 255) / 256 < 1024 ? ((n8 + 255) / 256 ? (n8 + 255) / 256 : 1) : 1024);
-    if (prec == P_FP32) hipLaunchKernelGGL(amax_dense_kernel<P_FP32>, dim3(agrid), dim3(256), 0, stream, src, n8, word);
-    else if (prec == P_BF16) hipLaunchKernelGGL(amax_dense_kernel<P_BF16>, dim3(agrid), dim3(256), 0, stream, src, n8, word);
-    else hipLaunchKernelGGL(amax_dense_kernel<P_FP16>, dim3(agrid), dim3(256), 0, stream, src, n8, word);
+// the largest |x| of up to four dense tensors of one precision, as fp32 bits, max-ed into *word[i] (the caller zeroes them); one launch
+hipError_t launch_amax_dense_n(int count, const void* const* src, int prec, const int64_t* n, uint32_t* const* word, hipStream_t stream) {
+    if (count < 1 || count > 4 || (prec != P_FP32 && prec != P_BF16 && prec != P_FP16)) return hipErrorInvalidValue;
+    AmaxJob job = {};
+    int64_t n8max = 0;
+    for (int i = 0; i < count; ++i) {
+        if (!src[i] || !word[i] || (n[i] & 7)) return hipErrorInvalidValue;
+        job.src[i] = src[i]; job.n8[i] = n[i] / 8; job.word[i] = word[i];
+        n8max = job.n8[i] > n8max ? job.n8[i] : n8max;
+    }
+    // (at most one atomic per workgroup, all on one word per tensor: few, fat workgroups -- 256 per tensor (config 4, four tensors of 33.5 MB: 44 us at 128, 41 at 256; 61 at 1024 with four loads each; four separate launches of 1024: 75), each thread eight 16-byte loads in flight)
+    const int64_t want = (n8max + 8 * 256 - 1) / (8 * 256);
+    const dim3 grid((unsigned)(want < 1 ? 1 : want < 256 ? want : 256), (unsigned)count);
+    if (prec == P_FP32) hipLaunchKernelGGL(amax_dense_kernel<P_FP32>, grid, dim3(256), 0, stream, job);
+    else if (prec == P_BF16) hipLaunchKernelGGL(amax_dense_kernel<P_BF16>, grid, dim3(256), 0, stream, job);
+    else hipLaunchKernelGGL(amax_dense_kernel<P_FP16>, grid, dim3(256), 0, stream, job);
     return hipGetLastError();
+}
+hipError_t launch_amax_dense(const void* src, int prec, int64_t n, uint32_t* word, hipStream_t stream) {
+    return launch_amax_dense_n(1, &src, prec, &n, &word, stream);
 }
 
 // BwdParams::units from the four tensors' largest magnitudes (fp32 bits): hdr[0] dO, hdr[4] Q, hdr[5] K, hdr[6] V -> floats hdr[8 ... 14]
@@ -330,22 +364,17 @@ hipError_t launch_bwd_units(uint32_t* hdr, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_cast_f16_unit(const void* src, int prec, void* dst, int64_t n, uint32_t* hdr, hipStream_t stream) {
+hipError_t launch_cast_f16_unit(const void* src, int prec, void* dst, int64_t n, uint32_t* hdr, hipStream_t stream, bool amax_done) {
     if (!src || !dst || !hdr || (n & 7) || (prec != P_FP32 && prec != P_BF16 && prec != P_FP16)) return hipErrorInvalidValue;
-    if (hipError_t e = hipMemsetAsync(hdr, 0, 4, stream); e != hipSuccess) return e;
+    if (!amax_done) {  // (the quantised backward takes the amax of all four operands in ONE launch first: launch_amax_dense_n)
+        if (hipError_t e = hipMemsetAsync(hdr, 0, 4, stream); e != hipSuccess) return e;
+        if (hipError_t e = launch_amax_dense(src, prec, n, hdr, stream); e != hipSuccess) return e;
+    }
     const int64_t n8 = n / 8;
     const unsigned grid = (unsigned)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : n8 ? 8192 : 1);
-    const unsigned agrid = grid < 1024 ? grid : 1024;  // one atomic per workgroup, all on one word: few, fat workgroups
-    if (prec == P_FP32) {
-        hipLaunchKernelGGL(amax_dense_kernel<P_FP32>, dim3(agrid), dim3(256), 0, stream, src, n8, hdr);
-        hipLaunchKernelGGL(cast_f16_unit_kernel<P_FP32>, dim3(grid), dim3(256), 0, stream, src, (_Float16*)dst, n8, hdr);
-    } else if (prec == P_BF16) {
-        hipLaunchKernelGGL(amax_dense_kernel<P_BF16>, dim3(agrid), dim3(256), 0, stream, src, n8, hdr);
-        hipLaunchKernelGGL(cast_f16_unit_kernel<P_BF16>, dim3(grid), dim3(256), 0, stream, src, (_Float16*)dst, n8, hdr);
-    } else {
-        hipLaunchKernelGGL(amax_dense_kernel<P_FP16>, dim3(agrid), dim3(256), 0, stream, src, n8, hdr);
-        hipLaunchKernelGGL(cast_f16_unit_kernel<P_FP16>, dim3(grid), dim3(256), 0, stream, src, (_Float16*)dst, n8, hdr);
-    }
+    if (prec == P_FP32) hipLaunchKernelGGL(cast_f16_unit_kernel<P_FP32>, dim3(grid), dim3(256), 0, stream, src, (_Float16*)dst, n8, hdr);
+    else if (prec == P_BF16) hipLaunchKernelGGL(cast_f16_unit_kernel<P_BF16>, dim3(grid), dim3(256), 0, stream, src, (_Float16*)dst, n8, hdr);
+    else hipLaunchKernelGGL(cast_f16_unit_kernel<P_FP16>, dim3(grid), dim3(256), 0, stream, src, (_Float16*)dst, n8, hdr);
     return hipGetLastError();
 }
 

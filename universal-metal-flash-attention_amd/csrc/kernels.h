@@ -115,11 +115,12 @@ hipError_t launch_nonfinite_flag(const float* x, int64_t n, uint32_t* flag, hipS
 hipError_t launch_bwd16_rowc(const float* lse, const float* dvec, float* rowc, int64_t n, const float* d_mul /* one float onto D, or NULL */, hipStream_t stream);
 // dO of the quantised backward entries -> fp16 as dO * 2^-e, one power of two per call from the tensor's largest |dO| (device);
 // hdr = 3 words: amax bits, 2^e, 2^-e = what BwdParams::gscale points at (hdr + 1)
-hipError_t launch_cast_f16_unit(const void* src, int prec, void* dst, int64_t n, uint32_t* hdr, hipStream_t stream);
+hipError_t launch_cast_f16_unit(const void* src, int prec, void* dst, int64_t n, uint32_t* hdr, hipStream_t stream, bool amax_done = false /* hdr[0] already holds the amax */);
 // the quantised backward with EVERY operand as a power-of-two multiple (BwdParams::units): a 16-word header -- [0 ... 2] as above for dO,
 // [4 ... 6] the largest |q|, |k|, |v| as fp32 bits (launch_amax_dense into a zeroed word; the quantiser scales its fp16 copies by them:
 // launch_quantize's famax), [8 ... 14] the units table (launch_bwd_units, after all four)
 hipError_t launch_amax_dense(const void* src, int prec, int64_t n, uint32_t* word, hipStream_t stream);
+hipError_t launch_amax_dense_n(int count /* <= 4 */, const void* const* src, int prec, const int64_t* n, uint32_t* const* word, hipStream_t stream);  // one launch
 hipError_t launch_bwd_units(uint32_t* hdr, hipStream_t stream);
 // dst: [B, Hkv, slab] in out_prec (fp32 default; fp16 / bf16: rounded once after the fp32 sum)
 hipError_t launch_group_sum(const float* src, void* dst, uint32_t B, uint32_t H, uint32_t Hkv, int64_t slab, hipStream_t stream,

@@ -385,8 +385,12 @@ int32_t mfa_quantized_backward(mfa_context_t context, mfa_buffer_t q, mfa_buffer
         uint32_t* unit = flag + 16;  // 16 words: kernels.h launch_bwd_units
         if (fast && hipMemsetAsync(flag, 0, 256, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
         LatencyScope lat(ctx, stream);
-        if (fast && (launch_amax_dense(bq->dev, prec, (int64_t)nq, unit + 4, stream) != hipSuccess || launch_amax_dense(bk->dev, prec, (int64_t)nkv, unit + 5, stream) != hipSuccess ||
-                     launch_amax_dense(bv->dev, prec, (int64_t)nkv, unit + 6, stream) != hipSuccess)) return MFA_ERROR_EXECUTION_FAILED;
+        if (fast) {  // one launch for the four amax words (dO's is unit[0])
+            const void* const srcs[4] = {bq->dev, bk->dev, bv->dev, bdo->dev};
+            const int64_t ns[4] = {(int64_t)nq, (int64_t)nkv, (int64_t)nkv, (int64_t)nq};
+            uint32_t* const words[4] = {unit + 4, unit + 5, unit + 6, unit};
+            if (launch_amax_dense_n(4, srcs, prec, ns, words, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+        }
         QuantViews views;
         hipError_t e = launch_quantize(bq->dev, bk->dev, bv->dev, prec, B, H, Sq, Skv, D, bits, mode, ws, fast ? 2 : 1, &views, stream,
                                        fast ? flag : nullptr, nullptr, fast ? unit + 4 : nullptr);
@@ -404,7 +408,7 @@ int32_t mfa_quantized_backward(mfa_context_t context, mfa_buffer_t q, mfa_buffer
             p.in_prec = P_FP16; p.dout_prec = P_FP16;
             // dO as dO * 2^-e in fp16, e from its largest magnitude on the device (gradients of 1e-7 are ordinary; as a plain cast they
             // were fp16 subnormals): fa_aux.hip launch_cast_f16_unit, 2^e comes back in the kernels' epilogues
-            if (launch_cast_f16_unit(bdo->dev, prec, ws + o_do16, (int64_t)nq, unit, stream) != hipSuccess || launch_bwd_units(unit, stream) != hipSuccess)
+            if (launch_cast_f16_unit(bdo->dev, prec, ws + o_do16, (int64_t)nq, unit, stream, true) != hipSuccess || launch_bwd_units(unit, stream) != hipSuccess)
                 return MFA_ERROR_EXECUTION_FAILED;
             p.dout = ws + o_do16;
             p.units = (const float*)(unit + 8);
@@ -463,9 +467,13 @@ mfa_error_t umfa_quantized_backward_stream(mfa_context_t context, void* stream_h
     if (status && hipMemsetAsync(status, 0, 4, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
     uint32_t* unit = (uint32_t*)(ws + o_flag) + 16;  // every operand as a power-of-two multiple, see mfa_quantized_backward
     const size_t nkv_in = (size_t)B * H * Skv * D;
-    if (fast && (hipMemsetAsync(ws + o_flag, 0, 256, stream) != hipSuccess || launch_amax_dense(q, prec, (int64_t)nq, unit + 4, stream) != hipSuccess ||
-                 launch_amax_dense(k, prec, (int64_t)nkv_in, unit + 5, stream) != hipSuccess || launch_amax_dense(v, prec, (int64_t)nkv_in, unit + 6, stream) != hipSuccess))
-        return MFA_ERROR_EXECUTION_FAILED;
+    if (fast) {  // one launch for the four amax words (dO's is unit[0])
+        const void* const srcs[4] = {q, k, v, dout};
+        const int64_t ns[4] = {(int64_t)nq, (int64_t)nkv_in, (int64_t)nkv_in, (int64_t)nq};
+        uint32_t* const words[4] = {unit + 4, unit + 5, unit + 6, unit};
+        if (hipMemsetAsync(ws + o_flag, 0, 256, stream) != hipSuccess || launch_amax_dense_n(4, srcs, prec, ns, words, stream) != hipSuccess)
+            return MFA_ERROR_EXECUTION_FAILED;
+    }
     QuantViews views;
     if (launch_quantize(q, k, v, prec, B, H, Sq, Skv, D, bits, mode, ws, fast ? 2 : 1, &views, stream, fast ? flag : nullptr, nullptr, fast ? unit + 4 : nullptr) != hipSuccess)
         return MFA_ERROR_EXECUTION_FAILED;
@@ -480,7 +488,7 @@ mfa_error_t umfa_quantized_backward_stream(mfa_context_t context, void* stream_h
     if (fast) {
         p.q = views.qh; p.k = views.kh; p.v = views.vh;
         p.in_prec = P_FP16; p.dout_prec = P_FP16;
-        if (launch_cast_f16_unit(dout, prec, ws + o_do16, (int64_t)nq, unit, stream) != hipSuccess || launch_bwd_units(unit, stream) != hipSuccess)
+        if (launch_cast_f16_unit(dout, prec, ws + o_do16, (int64_t)nq, unit, stream, true) != hipSuccess || launch_bwd_units(unit, stream) != hipSuccess)
             return MFA_ERROR_EXECUTION_FAILED;
         p.dout = ws + o_do16;
         p.units = (const float*)(unit + 8);
