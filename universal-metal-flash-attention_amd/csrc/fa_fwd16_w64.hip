@@ -528,7 +528,9 @@ hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cn
         wp.mk_prefix = p.mk_prefix;
         // the max chain, unless the mask has no row dimension (key padding: a listed tile holds a key for every row, the lazy bodies are as safe as
         // without a mask); with one, which rows have keys in a segment is not arithmetic
+#ifndef W64_LAB_MASK_FORCE_LAZY  // (lab, timing only -- NOT safe for masks with a row dimension in general: what would the lazy bodies buy a mask whose listed tiles are all open?)
         if (p.ms[2] != 0 || p.causal || tuning().no_w64_mask_lazy.load(std::memory_order_relaxed)) wp.lazy = 0;
+#endif
     }
     if (rope && p.out_prec != p.in_prec) return hipErrorNotSupported;  // fused-RoPE instantiations: O in the operand type only (runtime.hip asks first)
     if (window) {
