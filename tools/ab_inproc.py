@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=12)
     ap.add_argument("--inner", type=int, default=20)
     ap.add_argument("--parity", action="store_true")
-    ap.add_argument("--mask", default="", help="blockdiag | padding | window_tensor | random: a bool mask tensor on every forward")
+    ap.add_argument("--mask", default="", help="blockdiag | padding | window_tensor | random | alltrue_keys | alltrue_2d: a bool mask tensor on every forward")
     ap.add_argument("--graph", action="store_true", help="time hipGraph replays of `inner` launches (short kernels: the Python launch path is not what is measured)")
     ap.add_argument("--quant", type=int, default=0, help="2 / 3: time umfa_quantized_forward_stream with that quant_mode (fp32 O)")
     ap.add_argument("libs", nargs="+")
@@ -94,6 +94,8 @@ def main():
         Lib.mask = {"blockdiag": lambda: ((i_[:, None] // 1024) == (i_[None, :] // 1024))[None, None].contiguous(),
                     "padding": lambda: (i_ < (3 * S) // 4)[None, None, None, :].contiguous(),
                     "window_tensor": lambda: ((i_[:, None] - i_[None, :]).abs() <= 512)[None, None].contiguous(),
+                    "alltrue_keys": lambda: torch.ones(1, 1, 1, S, dtype=torch.bool, device="cuda"),
+                    "alltrue_2d": lambda: torch.ones(1, 1, S, S, dtype=torch.bool, device="cuda"),
                     "random": lambda: torch.rand(1, H, S, S, device="cuda") > 0.5}[a.mask]()
     libs = [Lib(*s.split("=", 1)) for s in a.libs]
     if a.quant:
