@@ -124,3 +124,15 @@ def test_launch_size_random_cases(seed):
 def test_backward_random_shapes(seed):
     msg = _fuzz().run_bwd_shape_case(seed)
     assert msg is None, msg
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_wide_head_dims_forward_and_backward(seed):
+    msg = _fuzz().run_wide_case(seed)
+    assert msg is None, msg
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_quantized_forward_with_random_caller_masks(seed):
+    msg = _fuzz().run_qmask_case(seed)
+    assert msg is None, msg

@@ -14,6 +14,7 @@ runs the first seeds of each, `python tools/lab/value_fuzz.py <first seed> <n> [
   run_gqa_case        grouped K / V heads, inference and training;  run_rope_case: fused RoPE == rotate-then-attend, bit for bit
   run_aux_case        RoPE / Hadamard rotations against the oracle;  run_host_case: the blocking host-buffer ABI against the oracle
   run_streams_case    three streams at once;  run_threads_case: four host threads;  run_graph_case: hipGraph capture + replay
+  run_wide_case       head dims 257 ... 1024, forward and backward;  run_qmask_case: the quantised forward with the caller's own mask tensor
 """
 import os
 import random
@@ -1047,11 +1048,107 @@ def run_bwd_case(seed):
     return None
 
 
+def run_wide_case(seed):
+    """head dims 257 ... 1024 (fa_fwd_wide / fa_bwd_wide): random head dim (multiples of 8 and not), shapes, operand types, causal, strided K, masks on the
+    forward -- forward and gradients against the oracle on the rounded operands"""
+    import numpy as np
+    from oracle import oracle
+    rng = random.Random(seed + 7100000)
+    dt = rng.choice([torch.bfloat16, torch.float16, torch.float32])
+    D = rng.choice([264, 272, 320, 384, 392, 512, 520, 640, 1000, 1024])
+    B, H = rng.choice([1, 2]), rng.choice([1, 2, 3])
+    Sq = rng.choice([1, 17, 32, 33, 70, 128, 150])
+    Skv = Sq if rng.random() < 0.5 else rng.choice([1, 31, 64, 65, 101, 200])
+    causal = rng.random() < 0.4
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    q, do = (torch.randn(B, H, Sq, D, device="cuda", generator=g).to(dt) for _ in range(2))
+    k, v = (torch.randn(B, H, Skv, D, device="cuda", generator=g).to(dt) for _ in range(2))
+    npy = lambda t: (t.view(torch.int16).cpu().numpy().view(np.uint16) if t.dtype == torch.bfloat16 else t.cpu().numpy())  # noqa: E731
+    try:
+        o, lse = umfa_torch.attention_forward(q, k, v, causal=causal, out_dtype=torch.float32, return_lse=True)
+        kf = umfa_torch.last_kernel()
+        gq, gk, gv = umfa_torch.attention_backward(do, q, k, v, o, lse, scale=D ** -0.5, causal=causal, keep_fp32=True)
+        kb = umfa_torch.last_kernel()
+        torch.cuda.synchronize()
+        what = (seed, str(dt), B, H, Sq, Skv, D, causal, kf, kb)
+        if not (kf.startswith("fa_fwd_wide<") and kb.startswith("fa_bwd_wide<")):
+            return "kernels %r" % (what,)
+        ro, rl = oracle.sdpa_forward(npy(q), npy(k), npy(v), causal=causal, return_lse=True)
+        on = o.cpu().numpy()
+        if not np.isfinite(on).all() or np.abs(on - ro).max() > 3e-5:
+            return "forward %.3e %r" % (float(np.abs(on - ro).max()), what)
+        rdq, rdk, rdv, _ = oracle.sdpa_backward(npy(do), npy(q), npy(k), npy(v), on, lse.cpu().numpy().reshape(B, H, Sq), causal=causal)
+        for got, rf, name in ((gq, rdq, "dq"), (gk, rdk, "dk"), (gv, rdv, "dv")):
+            gn = got.float().cpu().numpy()
+            err = float(np.abs(gn - rf).max() / max(1.0, np.abs(rf).max()))
+            if not np.isfinite(gn).all() or err > 1e-4:
+                return "%s err %.3e %r" % (name, err, what)
+    except Exception as e:  # noqa: BLE001
+        return "exception %r %s" % ((seed,), repr(e)[:300])
+    return None
+
+
+def run_qmask_case(seed):
+    """the runtime-quantised forward with the CALLER's mask tensor (umfa_quantized_forward_masked_stream): bool / fp16 / bf16 / fp32, 1 ... 4 dims,
+    broadcast dims, strided views, rows and heads that see nothing, with and without causal -- against the oracle's quantised restatement on the expanded mask"""
+    import numpy as np
+    from oracle import oracle
+    rng = random.Random(seed + 8200000)
+    dt = rng.choice([torch.bfloat16, torch.float16])
+    D = rng.choice([64, 128, 128, 80])
+    B, H = rng.choice([1, 2]), rng.choice([1, 2, 3])
+    Sq = rng.choice([64, 100, 256, 300, 512])
+    Skv = Sq if rng.random() < 0.5 else rng.choice([64, 65, 200, 320, 511])
+    causal = rng.random() < 0.25
+    bits = rng.choice([8, 8, 4])
+    mode = rng.choice(["blockwise", "blockwise", "tensor"])
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    q = torch.randn(B, H, Sq, D, device="cuda", generator=g).to(dt)
+    k = torch.randn(B, H, Skv, D, device="cuda", generator=g).to(dt)
+    v = (torch.randn(B, H, Skv, D, device="cuda", generator=g) * 2.0 ** rng.choice([0, 0, -12, 9])).to(dt)
+    shape = rng.choice([(Sq, Skv), (1, Skv), (H, Sq, Skv), (1, 1, Sq, Skv), (B, 1, 1, Skv), (B, H, Sq, Skv), (1, H, 1, Skv), (Skv,)])
+    kind = rng.choice(["bool", "bool", "f32", "f16", "bf16"])
+    if kind == "bool":
+        m = torch.rand(*shape, device="cuda", generator=g) < rng.choice([0.3, 0.7, 0.95])
+        m[..., 0] = True
+        if len(shape) >= 2 and shape[-2] > 7 and rng.random() < 0.5:
+            m[..., 7, :] = False  # a row that sees nothing
+    else:
+        m = (torch.randn(*shape, device="cuda", generator=g) * 2).to({"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[kind])
+        if rng.random() < 0.5:
+            m[..., Skv // 2:] = float("-inf")
+    if rng.random() < 0.3 and m.dim() >= 1:  # a strided view
+        wide = torch.zeros(*m.shape[:-1], 2 * m.shape[-1], device="cuda", dtype=m.dtype)
+        wide[..., ::2] = m
+        m = wide[..., ::2]
+    try:
+        o, lse = umfa_torch.quantized_attention_forward_stream(q, k, v, mask=m, causal=causal, bits=bits, quant_mode=mode, return_lse=True)
+        kern = umfa_torch.last_kernel()
+        torch.cuda.synchronize()
+        what = (seed, str(dt), B, H, Sq, Skv, D, causal, bits, mode, kind, tuple(shape), kern)
+        full = torch.zeros(B, H, Sq, Skv, device="cuda", dtype=torch.float32)
+        full = full.masked_fill(~m, float("-inf")) if m.dtype == torch.bool else full + m.float()
+        ro, rl = oracle.quantized_forward(q.float().cpu().numpy(), k.float().cpu().numpy(), v.float().cpu().numpy(), causal=causal,
+                                          mask=full.contiguous().cpu().numpy(), bits=bits, quant_mode=0 if mode == "tensor" else 2)
+        on = o.cpu().numpy()
+        if not np.isfinite(on).all():
+            return "non-finite %r" % (what,)
+        rel = float(np.abs(on - ro).max() / max(np.abs(ro).max(), 1e-300))
+        if rel > 2.5e-3:
+            return "rel %.3e %r" % (rel, what)
+        dead = np.isneginf(rl).reshape(-1)
+        if dead.any() and np.abs(on.reshape(-1, D)[dead]).max() != 0:
+            return "rows that see nothing are not zero %r" % (what,)
+    except Exception as e:  # noqa: BLE001
+        return "exception %r %s" % ((seed,), repr(e)[:300])
+    return None
+
+
 if __name__ == "__main__":
     first, count = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 200)
     bad = 0
     for seed in range(first, first + count):
-        for fn in ((run_case, run_bwd_case, run_shape_case, run_i8_case, run_gqa_case, run_rope_case, run_streams_case, run_graph_case, run_mask_case, run_host_case, run_qbwd_case, run_prequant_case, run_aux_case, run_threads_case, run_big_case, run_bwd_shape_case) if len(sys.argv) < 4 else (globals()[sys.argv[3]],)):
+        for fn in ((run_case, run_bwd_case, run_shape_case, run_i8_case, run_gqa_case, run_rope_case, run_streams_case, run_graph_case, run_mask_case, run_host_case, run_qbwd_case, run_prequant_case, run_aux_case, run_threads_case, run_big_case, run_bwd_shape_case, run_wide_case, run_qmask_case) if len(sys.argv) < 4 else (globals()[sys.argv[3]],)):
             msg = fn(seed)
             if msg:
                 bad += 1
