@@ -145,10 +145,14 @@ hipError_t launch_hadamard(void* data, uint32_t block_size, uint32_t num_blocks,
 // x = (q - zero_point) * scale with one scale per tensor, or one per block of `block_size` consecutive rows of a
 // (batch, head) slab when block scales are given; INT4 = two values per byte, even index in the low nibble, stored
 // value + 8 (QuantizationTests.swift:72-128).  The source may hold fewer heads than the destination (grouped K/V).
-// dst16 != NULL: the result goes out as fp16 (operands of the 16-bit MFMA backward) and a value outside fp16's range raises
-// *overflow (the caller then repeats the call on the fp32 path)
-__device__ __forceinline__ void dequant_store(const DequantParams& p, int64_t i, float x, bool& ovf) {
-    if (p.dst16) {
+// dst16 != NULL: the result goes out as fp16 (operands of the 16-bit MFMA backward) -- since round 5 as x * 2^-e with the tensor's largest |x| in [1, 2)
+// (DequantParams::amax_word / unit_amax: two launches), so nothing leaves fp16's range; without unit_amax a value outside it raises *overflow
+__device__ __forceinline__ void dequant_store(const DequantParams& p, int64_t i, float x, bool& ovf, float mul, unsigned& amax) {
+    if (p.amax_word) {  // first launch: the tensor's largest magnitude only
+        const unsigned a = __float_as_uint(x) & 0x7fffffffu;
+        amax = a > amax ? a : amax;
+    } else if (p.dst16) {
+        x *= mul;
         ovf |= !(fabsf(x) <= 65504.0f);
         ((_Float16*)p.dst16)[i] = (_Float16)x;
     } else {
@@ -159,6 +163,8 @@ __device__ __forceinline__ void dequant_store(const DequantParams& p, int64_t i,
 __global__ __launch_bounds__(256) void dequant_kernel(DequantParams p) {
     const int64_t n = (int64_t)p.B * p.H_dst * p.S * p.D;
     bool ovf = false;
+    unsigned amax = 0;
+    const float mul = p.unit_amax ? __uint_as_float((unsigned)(127 - unit_exponent(p.unit_amax[0])) << 23) : 1.0f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const uint32_t d = (uint32_t)(i % p.D);
         const uint32_t s = (uint32_t)((i / p.D) % p.S);
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(256) void dequant_kernel(DequantParams p) {
             const uint8_t byte = ((const uint8_t*)p.src)[e >> 1];
             x = (float)(int)((e & 1) ? (byte >> 4) : (byte & 15)) - 8.0f;
         } else {
-            dequant_store(p, i, load_as_float(p.src, e, p.prec), ovf);  // fp16 / bf16 / fp32 operands pass through
+            dequant_store(p, i, load_as_float(p.src, e, p.prec), ovf, mul, amax);  // fp16 / bf16 / fp32 operands pass through
             continue;
         }
         float sc = p.scale;
@@ -184,9 +190,24 @@ __global__ __launch_bounds__(256) void dequant_kernel(DequantParams p) {
             sc = p.block_scales[blk];
             zp = p.block_zero_points ? p.block_zero_points[blk] : 0;
         }
-        dequant_store(p, i, (x - (float)zp) * sc, ovf);
+        dequant_store(p, i, (x - (float)zp) * sc, ovf, mul, amax);
     }
     if (ovf && p.overflow) atomicOr(p.overflow, 1u);
+    if (p.amax_word) {
+        __shared__ unsigned wmax[4];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned o = (unsigned)__shfl_xor((int)amax, off, 64);
+            amax = o > amax ? o : amax;
+        }
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = amax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; ++w) amax = wmax[w] > amax ? wmax[w] : amax;
+            if (amax > __hip_atomic_load(p.amax_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                (void)__hip_atomic_fetch_max(p.amax_word, amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // row constants of bwd16_dkdv from (LSE, D) when the dQ kernel that normally writes them ran in another call
@@ -758,7 +779,9 @@ hipError_t launch_dequant(const DequantParams& p, hipStream_t stream) {
     if (!p.src || (!p.dst && !p.dst16) || p.H_src == 0 || p.H_dst % p.H_src) return hipErrorInvalidValue;
     const int64_t n = (int64_t)p.B * p.H_dst * p.S * p.D;
     if (n == 0) return hipSuccess;
-    const unsigned grid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    // (the amax launch: one same-address atomic per workgroup at most -- few workgroups)
+    const unsigned cap = p.amax_word ? 512u : 4096u;
+    const unsigned grid = (unsigned)((n + 255) / 256 < cap ? (n + 255) / 256 : cap);
     hipLaunchKernelGGL(dequant_kernel, dim3(grid), dim3(256), 0, stream, p);
     return hipGetLastError();
 }

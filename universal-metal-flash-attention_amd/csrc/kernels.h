@@ -101,6 +101,11 @@ struct DequantParams {
     int zero_point;
     int prec;        // P_INT8 / P_INT4 / P_FP16 / P_BF16 / P_FP32
     int transposed;  // source slab stored [D, S]
+    // the fp16 images as power-of-two multiples (BwdParams::units): a first launch with amax_word set only takes the largest |x| of the
+    // de-quantised tensor (fp32 bits, max-ed into the zeroed word; nothing is stored), the second, with unit_amax pointing at that word,
+    // stores x * 2^-e (amax 2^-e in [1, 2)): nothing leaves fp16's range, `overflow` stays clear
+    uint32_t* amax_word;
+    const uint32_t* unit_amax;
 };
 hipError_t launch_dequant(const DequantParams& p, hipStream_t stream);
 // bf16 [B,H,S,D] with element strides (head_dim contiguous) -> dense fp16 [B,H,S,D] of V * 2^-e, one power of two per (batch, head)

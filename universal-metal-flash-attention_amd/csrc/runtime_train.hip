@@ -560,9 +560,11 @@ mfa_error_t prequant_stage(Context* ctx, const PreQuant& a, float** qf, float** 
     *extra = ws + fbytes;
     for (Buffer* b : {a.q, a.k, a.v, a.qs, a.qz, a.ks, a.kz, a.vs, a.vz})
         if (b && b->upload(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
-    if (half && hipMemsetAsync(*extra + overflow_off, 0, 4, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;  // the kernels below OR into it
+    // (half: the flag word the kernels below OR into + the 16-word units header behind it, kernels.h launch_bwd_units: word 0 dO's amax, 4 ... 6 those of Q, K, V)
+    if (half && hipMemsetAsync(*extra + overflow_off, 0, 256, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+    uint32_t* const unit = half ? (uint32_t*)(*extra + overflow_off) + 16 : nullptr;
     auto deq = [&](Buffer* src, float* dst, int prec, uint32_t hs, uint32_t S, float sc, int zp, Buffer* bsc, Buffer* bzp,
-                   uint32_t bs, bool t) {
+                   uint32_t bs, bool t, int which) {
         DequantParams d;
         memset(&d, 0, sizeof(d));
         d.src = src->dev; d.dst = half ? nullptr : dst;
@@ -572,11 +574,19 @@ mfa_error_t prequant_stage(Context* ctx, const PreQuant& a, float** qf, float** 
         d.block_zero_points = (bs && bsc && bzp) ? (const int32_t*)bzp->dev : nullptr;
         d.B = a.B; d.H_src = hs; d.H_dst = a.H; d.S = S; d.D = a.D; d.block_size = bs;
         d.scale = sc; d.zero_point = zp; d.prec = prec; d.transposed = t ? 1 : 0;
+        if (half) {
+            // fp16 images as power-of-two multiples with the tensor's largest magnitude in [1, 2) (BwdParams::units, as in mfa_quantized_backward):
+            // one launch for the amax of the de-quantised tensor, one that stores x * 2^-e -- caller-side scales of 1e-9 or 1e9 make no difference
+            d.amax_word = unit + 4 + which;
+            if (hipError_t e = launch_dequant(d, stream); e != hipSuccess) return e;
+            d.amax_word = nullptr;
+            d.unit_amax = unit + 4 + which;
+        }
         return launch_dequant(d, stream);
     };
-    if (deq(a.q, *qf, a.qp, a.H, a.Sq, a.q_scale, a.q_zp, a.qs, a.qz, a.qbs, a.tq) != hipSuccess ||
-        deq(a.k, *kf, a.kp, a.Hkv, a.Skv, a.k_scale, a.k_zp, a.ks, a.kz, a.kbs, a.tk) != hipSuccess ||
-        deq(a.v, *vf, a.vp, a.Hkv, a.Skv, a.v_scale, a.v_zp, a.vs, a.vz, a.vbs, a.tv) != hipSuccess)
+    if (deq(a.q, *qf, a.qp, a.H, a.Sq, a.q_scale, a.q_zp, a.qs, a.qz, a.qbs, a.tq, 0) != hipSuccess ||
+        deq(a.k, *kf, a.kp, a.Hkv, a.Skv, a.k_scale, a.k_zp, a.ks, a.kz, a.kbs, a.tk, 1) != hipSuccess ||
+        deq(a.v, *vf, a.vp, a.Hkv, a.Skv, a.v_scale, a.v_zp, a.vs, a.vz, a.vbs, a.tv, 2) != hipSuccess)
         return MFA_ERROR_EXECUTION_FAILED;
     return MFA_SUCCESS;
 }
@@ -612,8 +622,9 @@ int32_t mfa_attention_backward_query_quantized_ex(
     if (nq == 0 || a.Skv == 0) return MFA_SUCCESS;
     for (Buffer* b : {bo, bdo, bl})
         if (b->upload(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
-    // FAST: operands de-quantised to fp16, dO cast to fp16, the dQ kernel of the 16-bit MFMA backward (it also leaves D);
-    // a value outside fp16's range -> the flag -> the call is repeated on the EXACT (fp32) path.  See mfa_quantized_backward.
+    // FAST: operands de-quantised to fp16 and dO cast to fp16 -- each as a power-of-two multiple with its largest magnitude in [1, 2) (prequant_stage,
+    // BwdParams::units) --, the dQ kernel of the 16-bit MFMA backward (it also leaves D, in true units).  EXACT (fp32) for what that engine does not take.
+    // See mfa_quantized_backward.
     const bool try_fast = bwd16_shape_ok(a.D, false);
     for (int attempt = try_fast ? 0 : 1; attempt < 2; ++attempt) {
         const bool fast = attempt == 0;
@@ -623,7 +634,6 @@ int32_t mfa_attention_backward_query_quantized_ex(
         LatencyScope lat(ctx, stream);
         mfa_error_t st = prequant_stage(ctx, a, &qf, &kf, &vf, fast ? o_flag + 256 : 0, &extra, stream, fast, o_flag);
         if (st != MFA_SUCCESS) return st;
-        uint32_t* flag = (uint32_t*)(extra + o_flag);
         BwdParams p;
         memset(&p, 0, sizeof(p));
         p.dout = bdo->dev; p.q = qf; p.k = kf; p.v = vf;
@@ -637,10 +647,13 @@ int32_t mfa_attention_backward_query_quantized_ex(
         hipError_t e;
         if (fast) {
             p.in_prec = P_FP16; p.dout_prec = P_FP16;
-            uint32_t* unit = (uint32_t*)(extra + o_flag) + 16;  // dO * 2^-e in fp16 (the same e in the query and the kv call: the same dO), see mfa_quantized_backward
-            if (launch_cast_f16_unit(bdo->dev, P_FP32, extra + o_do16, (int64_t)nq, unit, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+            // every operand a power-of-two multiple (prequant_stage took Q, K, V; dO here: the same exponents in the query and the kv call -- the same
+            // tensors), see mfa_quantized_backward
+            uint32_t* unit = (uint32_t*)(extra + o_flag) + 16;
+            if (launch_cast_f16_unit(bdo->dev, P_FP32, extra + o_do16, (int64_t)nq, unit, stream) != hipSuccess || launch_bwd_units(unit, stream) != hipSuccess)
+                return MFA_ERROR_EXECUTION_FAILED;
             p.dout = extra + o_do16;
-            p.gscale = (const float*)(unit + 1);
+            p.units = (const float*)(unit + 8);
             p.rowc = (float*)(extra + o_rowc);
             e = bwd_16_supported(p) ? launch_bwd_16(p, stream, &name) : hipErrorNotSupported;
             if (e == hipErrorNotSupported) continue;
@@ -650,14 +663,10 @@ int32_t mfa_attention_backward_query_quantized_ex(
         ctx->last_kernel = name;
         if (e != hipSuccess) return e == hipErrorInvalidValue ? MFA_ERROR_INVALID_ARGS : MFA_ERROR_EXECUTION_FAILED;
         lat.stop();
-        uint32_t overflow = 0;
-        if (fast && launch_nonfinite_flag(p.dq, (int64_t)nq, flag, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;  // dS rounded to fp16: see mfa_quantized_backward
-        if (fast && hipMemcpyAsync(&overflow, flag, 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
         if (bdq->download(stream) != hipSuccess || bd->download(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
         if (hipStreamSynchronize(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
         lat.publish();
-        if (!fast || !overflow) break;
-        DBG("pre-quantised backward (query): an operand left fp16's range, repeating on the fp32-exact path");
+        break;  // (the second attempt exists for what the fp16 engine does not take -- `continue` above; nothing in it can leave fp16's range: no flag to read)
     }
     return MFA_SUCCESS;
 }
@@ -703,7 +712,6 @@ int32_t mfa_attention_backward_kv_quantized_ex(
         LatencyScope lat(ctx, stream);
         mfa_error_t st = prequant_stage(ctx, a, &qf, &kf, &vf, fast ? o_flag + 256 : o_do16, &extra, stream, fast, o_flag);
         if (st != MFA_SUCCESS) return st;
-        uint32_t* flag = (uint32_t*)(extra + o_flag);
         BwdParams p;
         memset(&p, 0, sizeof(p));
         p.dout = bdo->dev; p.q = qf; p.k = kf; p.v = vf;
@@ -718,10 +726,13 @@ int32_t mfa_attention_backward_kv_quantized_ex(
         hipError_t e;
         if (fast) {
             p.in_prec = P_FP16; p.dout_prec = P_FP16;
-            uint32_t* unit = (uint32_t*)(extra + o_flag) + 16;  // dO * 2^-e in fp16 (the same e in the query and the kv call: the same dO), see mfa_quantized_backward
-            if (launch_cast_f16_unit(bdo->dev, P_FP32, extra + o_do16, (int64_t)nq, unit, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+            // every operand a power-of-two multiple (prequant_stage took Q, K, V; dO here: the same exponents in the query and the kv call -- the same
+            // tensors), see mfa_quantized_backward
+            uint32_t* unit = (uint32_t*)(extra + o_flag) + 16;
+            if (launch_cast_f16_unit(bdo->dev, P_FP32, extra + o_do16, (int64_t)nq, unit, stream) != hipSuccess || launch_bwd_units(unit, stream) != hipSuccess)
+                return MFA_ERROR_EXECUTION_FAILED;
             p.dout = extra + o_do16;
-            p.gscale = (const float*)(unit + 1);
+            p.units = (const float*)(unit + 8);
             p.rowc = (float*)(extra + o_rowc);
             e = bwd_16_supported(p) ? launch_bwd_16(p, stream, &name) : hipErrorNotSupported;
             if (e == hipErrorNotSupported) continue;
@@ -737,16 +748,10 @@ int32_t mfa_attention_backward_kv_quantized_ex(
                 return MFA_ERROR_EXECUTION_FAILED;
         }
         lat.stop();
-        uint32_t overflow = 0;
-        if (fast && (launch_nonfinite_flag((const float*)bdk->dev, (int64_t)a.B * a.Hkv * a.Skv * a.D, flag, stream) != hipSuccess ||
-                     launch_nonfinite_flag((const float*)bdv->dev, (int64_t)a.B * a.Hkv * a.Skv * a.D, flag, stream) != hipSuccess))
-            return MFA_ERROR_EXECUTION_FAILED;  // dS rounded to fp16: see mfa_quantized_backward
-        if (fast && hipMemcpyAsync(&overflow, flag, 4, hipMemcpyDeviceToHost, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
         if (bdk->download(stream) != hipSuccess || bdv->download(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
         if (hipStreamSynchronize(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
         lat.publish();
-        if (!fast || !overflow) break;
-        DBG("pre-quantised backward (kv): an operand left fp16's range, repeating on the fp32-exact path");
+        break;  // (as in the query entry)
     }
     return MFA_SUCCESS;
 }
