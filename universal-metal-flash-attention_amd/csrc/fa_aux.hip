@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void group_sum_scalar_kernel(const float* __re
 // device so that the largest |dO| lands in [1, 2).  fp16 has five exponent bits; the gradients these entries see in bf16 / fp32 training
 // are routinely 1e-5 ... 1e-9 -- as a plain cast they were fp16 subnormals or zero (dQ off by 3 % at |dO| ~ 1e-5, 35 % at 1e-7, all zeros
 // at 1e-9, status 0: tools/lab/qbwd_range_probe.py), and dS = P (dP - D), rounded to fp16 inside the kernels, sank with them.  Every
-// gradient is linear in dO, so the kernels give 2^e back in their epilogues (BwdParams::gscale): exact both ways.
+// gradient is linear in dO, so the kernels give 2^e back in their epilogues (BwdParams::units): exact both ways.
 // hdr: [0] largest |dO| as fp32 bits (zero on entry: the launcher's memset node), [1] 2^e, [2] 2^-e (floats, written here).
 template <int PREC>
 __device__ __forceinline__ void load8_as_float(const void* src, int64_t i, float (&x)[8]) {
@@ -801,31 +801,6 @@ hipError_t launch_group_sum(const float* src, void* dst, uint32_t B, uint32_t H,
     hipLaunchKernelGGL(group_sum_kernel, dim3(grid), dim3(256), 0, stream, src, dst, B, H, Hkv, slab, out_prec);
     return hipGetLastError();
 }
-
-// *flag |= 1 when any of x[0 .. n) is not finite.  The 16-bit MFMA backward on fp16 operands (quantised backward entries) rounds
-// dS = P (dP - D) to fp16: dP is a sum of head_dim products and can pass 65504 while every operand is in range (|dO| ~ 1e2 with
-// |V| ~ 10, loss-scaled dO); the operand checks of the quantiser / cast do not see that, the gradients do (inf / NaN).
-__global__ __launch_bounds__(256) void nonfinite_flag_kernel(const float* __restrict__ x, int64_t n4, int64_t n, uint32_t* flag) {
-    float acc = 0.0f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        const f32x4 v = ((const f32x4*)x)[i];
-        acc = __builtin_fmaf(v[0], 0.0f, acc); acc = __builtin_fmaf(v[1], 0.0f, acc);
-        acc = __builtin_fmaf(v[2], 0.0f, acc); acc = __builtin_fmaf(v[3], 0.0f, acc);
-    }
-    for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)  // tail / unaligned x
-        acc = __builtin_fmaf(x[i], 0.0f, acc);
-    if (__builtin_amdgcn_ballot_w64(acc != acc) != 0 && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
-}
-
-hipError_t launch_nonfinite_flag(const float* x, int64_t n, uint32_t* flag, hipStream_t stream) {
-    if (!x || !flag || n <= 0) return hipSuccess;
-    const int64_t n4 = ((uintptr_t)x & 15) ? 0 : n / 4;  // an unaligned (wrapped caller) buffer: element by element
-    const int64_t work = n4 ? n4 : n;
-    const unsigned grid = (unsigned)((work + 255) / 256 < 4096 ? (work + 255) / 256 : 4096);
-    hipLaunchKernelGGL(nonfinite_flag_kernel, dim3(grid), dim3(256), 0, stream, x, n4, n, flag);
-    return hipGetLastError();
-}
-
 
 // ------------------------------------------------------------------ mask tile flags (tile early-exit of fa_fwd16)
 // One wave per (mask batch, mask head, 32-row block, 64-key tile): lane = key of the tile, 32 rows each.  Reads every

@@ -1224,7 +1224,7 @@ static hipError_t launch_bwd16_t(const BwdParams& p, hipStream_t stream) {
             const BwdParams& p = pl;
             // dS-store form: D, row constants, dK / dV (+ dS to the scratch), dQ = scale dS K
             hipLaunchKernelGGL(bwd16_delta_kernel<DP>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, p);
-            if (hipError_t e = launch_bwd16_rowc(p.lse, p.dvec, p.rowc, rows, p.units ? p.units + 6 : p.gscale ? p.gscale + 1 : nullptr, stream); e != hipSuccess) return e;
+            if (hipError_t e = launch_bwd16_rowc(p.lse, p.dvec, p.rowc, rows, p.units ? p.units + 6 : nullptr, stream); e != hipSuccess) return e;
             if (hipError_t e = ensure_dynamic_lds((const void*)bwd16_dkdv_kernel<T, false, DP, true>, lds_kv); e != hipSuccess) return e;
             hipLaunchKernelGGL((bwd16_dkdv_kernel<T, false, DP, true>), dim3(nkb * p.B * p.H), dim3(256), lds_kv, stream, p);
             const size_t lds_g = 4 * 2 * 64 * 2 * DP;  // four slots of (K tile, dS^T tile)
@@ -1234,7 +1234,7 @@ static hipError_t launch_bwd16_t(const BwdParams& p, hipStream_t stream) {
         }
     }
     if (!(ph & 3)) {
-        if (hipError_t e = launch_bwd16_rowc(p.lse, p.dvec, p.rowc, rows, p.units ? p.units + 6 : p.gscale ? p.gscale + 1 : nullptr, stream); e != hipSuccess) return e;
+        if (hipError_t e = launch_bwd16_rowc(p.lse, p.dvec, p.rowc, rows, p.units ? p.units + 6 : nullptr, stream); e != hipSuccess) return e;
     } else
     if constexpr (DP == 128) {
         // one-workgroup-per-CU kernel for non-causal launches (same box, ms per backward, v2 / two-per-CU: FLUX 0.678 / 0.693,

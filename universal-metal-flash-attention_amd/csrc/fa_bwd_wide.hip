@@ -254,7 +254,7 @@ static hipError_t launch_wide(const BwdParams& p, hipStream_t stream) {
 
 hipError_t launch_bwd_wide(const BwdParams& p, hipStream_t stream, const char** name) {
     *name = "none";
-    if (p.D <= 256 || p.D > 1024 || p.mask || p.units || p.gscale) return hipErrorInvalidValue;
+    if (p.D <= 256 || p.D > 1024 || p.mask || p.units) return hipErrorInvalidValue;
     if ((uint64_t)p.B * p.H * ((p.Sq + 31) / 32) > 0x7fffffffull || (uint64_t)p.B * p.H * ((p.Skv + 31) / 32) > 0x7fffffffull) return hipErrorInvalidValue;
     if (p.D <= 512) { *name = "fa_bwd_wide<512>"; return launch_wide<128>(p, stream); }
     *name = "fa_bwd_wide<1024>";

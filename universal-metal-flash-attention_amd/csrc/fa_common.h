@@ -148,9 +148,6 @@ struct BwdParams {
                     // type -- bwd16_dkdv writes dS = P (dP - D) there, bwd16_dq_gemm computes dQ = scale dS K from it: 5 products
                     // instead of 7 for B H Sq Skv 2 bytes of HBM (805 MB at the FLUX shape); NULL = the two recomputing kernels
     int ds_lab;     // lab (env UMFA_LAB_DS, timing only): bit 0 = every dS store goes to tile 0 of the slab (no HBM write stream)
-    const float* gscale;  // bwd16 only, device, NULL = 1: {2^e, 2^-e} when `dout` holds dO * 2^-e (the quantised entries' fp16 image of dO,
-                          // fa_aux.hip launch_cast_f16_unit).  Every gradient is linear in dO: the epilogues multiply by 2^e, D leaves in
-                          // true units (p.dvec) and is taken back into dO's units where it is read from the caller (bwd16_rowc_kernel)
     const float* units;   // bwd16 only, device, NULL = none: EVERY operand arrives as a power-of-two multiple (mfa_quantized_backward: fp16 images
                           // Q 2^-eq, K 2^-ek, V 2^-ev of the de-quantised operands, dO 2^-edo; fa_aux.hip bwd_units_kernel) --
                           // [0] 2^(eq+ek) onto the softmax scale, [1] 2^(edo+ev+ek) onto dQ, [2] 2^(edo+ev+eq) onto dK, [3] 2^edo onto dV,
@@ -158,13 +155,12 @@ struct BwdParams {
                           // D vector that comes in (bwd16_rowc_kernel).  dS = P (dP - D), rounded to fp16, is then bounded by 8 head_dim.
 };
 
-__device__ __forceinline__ float grad_unit(const BwdParams& p) { return p.gscale ? p.gscale[0] : 1.0f; }
 __device__ __forceinline__ float unit_c(const BwdParams& p) { return p.units ? p.units[0] : 1.0f; }
-__device__ __forceinline__ float unit_dq(const BwdParams& p) { return p.units ? p.units[1] : grad_unit(p); }
-__device__ __forceinline__ float unit_dk(const BwdParams& p) { return p.units ? p.units[2] : grad_unit(p); }
-__device__ __forceinline__ float unit_dv(const BwdParams& p) { return p.units ? p.units[3] : grad_unit(p); }
+__device__ __forceinline__ float unit_dq(const BwdParams& p) { return p.units ? p.units[1] : 1.0f; }
+__device__ __forceinline__ float unit_dk(const BwdParams& p) { return p.units ? p.units[2] : 1.0f; }
+__device__ __forceinline__ float unit_dv(const BwdParams& p) { return p.units ? p.units[3] : 1.0f; }
 __device__ __forceinline__ float unit_rowd(const BwdParams& p) { return p.units ? p.units[4] : 1.0f; }
-__device__ __forceinline__ float unit_dvec(const BwdParams& p) { return p.units ? p.units[5] : grad_unit(p); }
+__device__ __forceinline__ float unit_dvec(const BwdParams& p) { return p.units ? p.units[5] : 1.0f; }
 // e with amax * 2^-e in [1, 2) (amax as fp32 bits); 0 for an all-zero or non-finite tensor
 __device__ __forceinline__ int unit_exponent(unsigned amax_bits) {
     if (amax_bits == 0 || amax_bits >= 0x7f800000u) return 0;

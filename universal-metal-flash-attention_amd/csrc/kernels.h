@@ -114,12 +114,10 @@ hipError_t launch_dequant(const DequantParams& p, hipStream_t stream);
 constexpr uint32_t VSC_HDR_WORDS = 128, VSC_HDR_DEPART = 64, VSC_HDR_SCALE = 65, VSC_HDR_AMAX = 66;
 hipError_t launch_cast_rows_bf16_to_f16(const void* src, const int64_t* strides, void* dst, uint32_t B, uint32_t H, uint32_t S, uint32_t D,
                                         uint32_t* hdr, hipStream_t stream);
-// *flag |= 1 when any of x[0 .. n) (fp32, 16-byte aligned) is not finite
-hipError_t launch_nonfinite_flag(const float* x, int64_t n, uint32_t* flag, hipStream_t stream);
 // rowc[0 .. n) = -lse * log2 e, rowc[n .. 2n) = -dvec: what bwd16_dq leaves for bwd16_dkdv, for a dK / dV-only call
 hipError_t launch_bwd16_rowc(const float* lse, const float* dvec, float* rowc, int64_t n, const float* d_mul /* one float onto D, or NULL */, hipStream_t stream);
 // dO of the quantised backward entries -> fp16 as dO * 2^-e, one power of two per call from the tensor's largest |dO| (device);
-// hdr = 3 words: amax bits, 2^e, 2^-e = what BwdParams::gscale points at (hdr + 1)
+// hdr = 3 words: amax bits, 2^e, 2^-e (the first three words of the 16-word units header, launch_bwd_units)
 hipError_t launch_cast_f16_unit(const void* src, int prec, void* dst, int64_t n, uint32_t* hdr, hipStream_t stream, bool amax_done = false /* hdr[0] already holds the amax */);
 // the quantised backward with EVERY operand as a power-of-two multiple (BwdParams::units): a 16-word header -- [0 ... 2] as above for dO,
 // [4 ... 6] the largest |q|, |k|, |v| as fp32 bits (launch_amax_dense into a zeroed word; the quantiser scales its fp16 copies by them:
