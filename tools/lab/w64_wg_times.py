@@ -49,4 +49,7 @@ for name, m in (("w even (starts a shared item: folder)", w % 2 == 0), ("w odd (
 order = np.argsort(end)
 print("last 12 to finish (blockIdx, xcd, w, end):", [(int(i), int(i % 8), int(w[i]), round(float(end[i]), 1)) for i in order[-12:] if ok[i]])
 print("first 6 to finish:", [(int(i), int(i % 8), int(w[i]), round(float(end[i]), 1)) for i in order[:6] if ok[i]])
+acct = raw[:, 4:8].astype(np.float64).sum(1) / np.maximum(clk, 1e-9)
+print("per workgroup, outside the four stamped phases (kernel entry -> first segment, per-segment set-up, exit): med %.1f us, min %.1f, max %.1f" % (
+    float(np.median((end - start - acct)[ok])), float((end - start - acct)[ok].min()), float((end - start - acct)[ok].max())))
 print("pro/loop/drain/epi med us:", [round(float(np.median(raw[ok, 4 + j].astype(np.float64) / np.median(clk[ok]))), 1) for j in range(4)])
