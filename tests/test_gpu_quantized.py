@@ -583,3 +583,33 @@ def test_quantized_entries_on_three_streams_at_once():
             assert int(g[3].item()) == 0
             for a, b in zip(g[:3], sg):
                 assert torch.equal(a, b)
+
+
+def test_quantized_forward_with_the_callers_mask_replays_in_a_graph():
+    """umfa_quantized_forward_masked_stream captured once and replayed while the MASK's content changes: the tile flags are taken inside the captured launches"""
+    import torch
+    import umfa_torch
+    torch.manual_seed(2)
+    B, H, S, D = 1, 4, 1024, 128
+    q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    i = torch.arange(S, device="cuda")
+    masks = [((i[:, None] // 256) == (i[None, :] // 256))[None, None].contiguous(), (torch.rand(1, 1, S, S, device="cuda") < 0.5), torch.ones(1, 1, S, S, dtype=torch.bool, device="cuda")]
+    masks[1][..., 0] = True
+    m = masks[0].clone()
+    out = torch.empty(B, H, S, D, device="cuda", dtype=torch.float32)
+    lse = torch.empty(B * H * S, device="cuda", dtype=torch.float32)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            umfa_torch.quantized_attention_forward_stream(q, k, v, mask=m, out=out, lse=lse)
+        side.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            umfa_torch.quantized_attention_forward_stream(q, k, v, mask=m, out=out, lse=lse)
+        for mk in masks:
+            m.copy_(mk)
+            g.replay()
+            side.synchronize()
+            ref = umfa_torch.quantized_attention_forward_stream(q, k, v, mask=mk)
+            side.synchronize()
+            assert torch.equal(out, ref)
