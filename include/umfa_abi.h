@@ -438,7 +438,8 @@ const char* umfa_last_kernel_name(mfa_context_t context);
  *   "cast_wait_us"       "100" (default): in the one-launch form a workgroup of the cast pre-pass publishes its rows' amax and waits for
  *                        the other workgroups of its (batch, KV head) slab; the wait is bounded by this many microseconds, after which
  *                        the workgroup reads the whole slab for the amax itself (the same number) -- forward progress does not depend
- *                        on the slab's workgroups being resident together (CU-masked streams, many streams).  "0": never wait (tests)
+ *                        on the slab's workgroups being resident together (CU-masked streams, many streams).  "0": never wait (tests).
+ *                        The same bound serves the runtime quantiser's exchange of a slab's largest |v| (the fp16 V image of the int8 forward).
  * Returns MFA_ERROR_INVALID_ARGS for an unknown name or a value out of range.  Thread-safe; affects later launches. */
 mfa_error_t umfa_set_option(mfa_context_t context, const char* name, const char* value);
 
