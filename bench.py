@@ -413,7 +413,12 @@ def run_rank(args) -> None:
         t_e = med(event_ms(lambda: umfa_torch.attention_forward(*c2, causal=True, out=o2), 30))
         t = graph_ms(lambda: umfa_torch.attention_forward(*c2, causal=True, out=o2), 100)
         f2 = 2.0 * 4 * 16 * 1024 * 1024 * 64  # causal convention: half of 4 B H S^2 D
+        # this launch is HBM-bound, not MFMA-bound: 8.59 GFLOP over Q + K + V + O (bf16) = 33.5 MB is 256 FLOP / B, below the ridge (2500 / 8 = 312):
+        # its floor is bytes / the measured device-to-device copy rate (6.29 TB/s), `frac_hbm` is that floor over the time
+        b2 = 4.0 * (4 * 16 * 1024 * 64) * 2
         configs["cfg2_B4_H16_S1024_D64_bf16_causal_fwd"] = {"ms": round(t, 5), "ms_eager": round(t_e, 5), "tflops": round(f2 / t / 1e9, 1), "frac": round(f2 / t / 1e9 / PEAK_BF16_TFLOPS, 4),
+                                                             "bound": "hbm", "bytes": b2, "hbm_floor_ms": round(b2 / 6.29e12 * 1e3, 5), "gbps": round(b2 / t / 1e6, 1),
+                                                             "frac_hbm": round(b2 / 6.29e12 * 1e3 / t, 4),
                                                              "kernel": umfa_torch.last_kernel(), "flops": f2, "timer": GT}
         # the headline shape in the two regimes that meet / sit on the stated tolerance, beside the headline's (lazy reference):
         # exact running max (bf16 at its operand-format floor) and fp16 (inside 1e-3)
@@ -608,9 +613,13 @@ def run_rank(args) -> None:
             "unit": "TFLOP/s",
             "n_gpus": world,
             "steps": args.steps,
-            "warmup": settle["untimed_steps_before_the_timed_region"],
-            "warmup_arg": args.warmup,
+            "warmup": args.warmup,  # the CLI argument; every other untimed launch (graph upload, cold region, settle) is counted under `settle`
             "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "cold_start_ms_per_step": settle["cold_start_ms_per_step"],  # the same K steps right after the W warm-up steps, the board just out of idle
+            "ms_eager": round(durs[len(durs) // 2], 5),  # median of per-call HIP events on EAGER launches of the same step (what a PyTorch-eager caller sees)
+            "timer": {"version": 2, "headline": "wall clock around one hipGraph of K steps (barrier + synchronize on both sides), sustained state",
+                      "configs": "graph_ms: HIP events around 3 back-to-back replays of one hipGraph of n calls, / (3 n) -- since round 5; rounds 1-4 timed ONE replay "
+                                 "(one replay's launch latency, tens of us, was inside): not like-for-like with BENCH_r01 ... r04"},
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,

@@ -37,6 +37,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: the 54 entry points declared between this push and its pop are the ONLY
+ * dynamic symbols of libMFAFFI.so (tests/test_abi_symbols.py checks `nm -D`).  Harmless for callers. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 /* ---- status codes, [H]:17-26 -------------------------------------------- */
 typedef int mfa_error_t;
@@ -431,8 +436,10 @@ const char* umfa_last_kernel_name(mfa_context_t context);
  *                        the slab's e when e = 0 did not do), and 2^e comes back with the row's 1 / l: exact both ways, finite
  *                        and inside the tolerance for every bf16 V, in-stream, under hipGraph replay, with no status word and no
  *                        state in the context (round 4 had both).  V values more than 2^29 below their slab's largest round into
- *                        fp16's subnormals: errors below 2^-39 of that largest value.
- *                        "0": the bf16 P V kernels throughout (8-bit P).
+ *                        fp16's subnormals: errors below 2^-39 of that largest value -- small against the SLAB, not against a query
+ *                        row that attends only to such small rows (one exponent per slab serves values 2^29 apart; INTEGRATION.md
+ *                        "Range of V", tests/test_gpu_pv16_range.py test_documented_bound_of_the_per_slab_shift).
+ *                        "0": the bf16 P V kernels throughout (8-bit P, fp32's exponent range: the remedy for a V that spans more).
  *   "cast_two_pass"      "0" (default) | "1": tests -- the cast pre-pass as two launches (amax, then cast) whatever the slab size
  *                        (by default only slabs of more than 64 workgroups' worth of rows take that form)
  *   "cast_wait_us"       "100" (default): in the one-launch form a workgroup of the cast pre-pass publishes its rows' amax and waits for
@@ -458,6 +465,9 @@ mfa_error_t umfa_release_scratch(mfa_context_t context, void* stream, int32_t al
 #undef UMFA_QBWD_TAIL
 #undef UMFA_QBWD_BLOCKS
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

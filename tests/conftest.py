@@ -31,8 +31,9 @@ def golden_dir():
 
 @pytest.fixture(autouse=True)
 def _rearm_fp16_pv(request):
-    """GPU tests start with the bf16 forward on its default arithmetic (fp16 P V): a test that drove V out of fp16's range on
-    purpose leaves the in-stream entries on the bf16 P V kernels (sticky by design) -- the next test must not inherit that."""
+    """GPU tests start with the bf16 forward on its default arithmetic (fp16 P V, option pv_fp16): a test that switched the option
+    and failed before restoring it must not hand its setting to the next one.  (Nothing in the library is sticky since round 5:
+    V's range is handled per slab on the device)"""
     if request.node.get_closest_marker("gpu") is not None and request.node.get_closest_marker("no_gpu_init") is None:
         try:
             import umfa_torch

@@ -46,6 +46,20 @@ def test_header_declares_and_library_exports(lib):
         assert hasattr(lib, name), f"{name} declared but not exported by libMFAFFI.so"
 
 
+def test_dynamic_symbol_table_is_the_c_abi_and_nothing_else():
+    """`nm -D --defined-only` of libMFAFFI.so = the symbols umfa_abi.h declares: no C++ (umfa::) launchers, no kernel host stubs
+    (-fvisibility=hidden + csrc/exports.map)."""
+    import shutil
+    import subprocess
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    so = ROOT / "universal-metal-flash-attention_amd" / "lib" / "libMFAFFI.so"
+    out = subprocess.check_output([nm, "-D", "--defined-only", str(so)], text=True)
+    names = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    declared = set(re.findall(r"\b((?:mfa|umfa)_[a-z0-9_]+)\s*\(", HEADER.read_text()))
+    assert [n for n in names if n not in declared] == []
+    assert sum(n.startswith("mfa_") for n in names) == 42 and set(REFERENCE_SYMBOLS) <= set(names)
+
+
 def test_header_is_plain_c(tmp_path):
     # bindgen/cgo consume the header as C (examples/rust-ffi/build.rs:9-41)
     import subprocess

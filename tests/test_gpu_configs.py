@@ -86,7 +86,7 @@ def test_config2_causal_bf16_B4_H16_S1024_D64():
     # the WHOLE tensor against the oracle (8.6 GFLOP of fp64: seconds on the box's host cores)
     ref = _oracle().sdpa_forward(bits(q), bits(k), bits(v), causal=True)
     mx, _ = check_forward(o.cpu().numpy(), ref, torch.bfloat16, kern, "cfg2_full_fp32O")
-    assert mx < 1.25e-3  # measured 0.94e-3: at this key range bf16 sits at the north-star's 1e-3
+    assert mx < 1e-3  # the north-star's tolerance, fp32 O (measured 1.1e-4 with the default fp16 P V; check_forward holds the same bound)
     o16 = umfa_torch.attention_forward(q, k, v, causal=True)
     check_forward(o16.float().cpu().numpy(), ref, torch.bfloat16, kern, "cfg2_full_bf16O", out_dt=torch.bfloat16)
 

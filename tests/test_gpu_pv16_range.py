@@ -316,3 +316,63 @@ def test_slab_exchanges_make_progress_on_a_stream_that_owns_four_cus():
                 ext.synchronize()
                 assert torch.equal(o, ref) and torch.equal(oq, qref)
     hip.hipStreamDestroy(stream)
+
+
+def _row_rel_err(o, ref):
+    """max over rows of max|O_row - ref_row| / max|ref_row| -- a row is judged against ITS OWN size (the per-slab metric above cannot see a row of
+    ordinary size going wrong next to a row 1e12 times larger: slab-relative that error is 1e-12)"""
+    o, ref = np.asarray(o, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    den = np.abs(ref).max(axis=-1)
+    num = np.abs(o - ref).max(axis=-1)
+    ok = den > 0
+    return float((num[ok] / den[ok]).max())
+
+
+@pytest.mark.parametrize("force_w64", [0, 1])
+@pytest.mark.parametrize("log2_outlier", [12, 24])
+def test_rows_beside_an_outlier_row_keep_their_own_precision(force_w64, log2_outlier):
+    """In-slab dynamic range, ROW-relative (round-5 review, parity residue c).  One key's V row is 2^12 / 2^24 times the others, and the launch is causal
+    with that key LAST: every query row but the last never attends to it and its exact O is ordinary.  The slab's ONE power of two puts the outlier
+    at the top of fp16's range; rows 2^24 below it still sit in fp16's normal range (it spans 2^30), so every row keeps the north-star's tolerance against
+    its own size."""
+    import umfa_torch
+    torch.manual_seed(77)
+    B, H, S, D = 1, 2, 512, 128
+    q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    v[0, 0, S - 1] = (v[0, 0, S - 1].float() * 2.0 ** log2_outlier).to(torch.bfloat16)
+    with umfa_torch.options(force_w64=force_w64):
+        o = umfa_torch.attention_forward(q, k, v, causal=True, out_dtype=torch.float32)
+        kern = umfa_torch.last_kernel()
+    assert ",pv16" in kern and ("w64" in kern) == bool(force_w64), kern
+    ref = _oracle().sdpa_forward(bits(q), bits(k), bits(v), causal=True)
+    assert torch.isfinite(o).all()
+    e = _row_rel_err(o.cpu().numpy(), ref)
+    assert e < 2.0 * NORTH_STAR, (kern, log2_outlier, e)  # (row-relative: a row's own max, not the slab's; measured 3e-4 ... 6e-4)
+
+
+@pytest.mark.parametrize("force_w64", [0, 1])
+def test_documented_bound_of_the_per_slab_shift(force_w64):
+    """... and the bound (INTEGRATION.md 'Range of V', include/umfa_abi.h): ONE power of two per (batch, KV head) slab cannot serve values more than ~2^29
+    apart -- rows of V that far below their slab's largest value reach the fp16 product as subnormals or zero.  A 1e12 (2^40) row next to N(0, 1) rows: the
+    slab-relative error stays inside 1e-3 and everything is finite, but query rows that attend ONLY to the ordinary rows come out near zero.  The
+    documented remedy is the bf16 P V kernels (option pv_fp16 = 0: fp32's exponent range, 8-bit P): they return every row to bf16's own tolerance.
+    This test pins BOTH halves, so that the limitation cannot change silently (a kernel that starts handling it will fail the first half: tighten it)."""
+    import umfa_torch
+    torch.manual_seed(78)
+    B, H, S, D = 1, 2, 512, 128
+    q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    v[0, 0, S - 1] = (v[0, 0, S - 1].float() * 1e12).to(torch.bfloat16)
+    ref = _oracle().sdpa_forward(bits(q), bits(k), bits(v), causal=True)
+    with umfa_torch.options(force_w64=force_w64):
+        o = umfa_torch.attention_forward(q, k, v, causal=True, out_dtype=torch.float32)
+        kern = umfa_torch.last_kernel()
+        assert ",pv16" in kern, kern
+        assert torch.isfinite(o).all()
+        assert _per_slab_err(o.cpu().numpy(), ref) < NORTH_STAR
+        if force_w64:  # (the converting 128-row kernel shifts per WORKGROUP: only the workgroup that met the outlier loses its ordinary rows)
+            assert _row_rel_err(o[:, 0:1].cpu().numpy(), ref[:, 0:1]) > 0.5      # head 0, the documented loss: ordinary rows flushed
+        assert _row_rel_err(o[:, 1:2].cpu().numpy(), ref[:, 1:2]) < 2.0 * NORTH_STAR  # head 1: another slab, untouched
+        with umfa_torch.options(pv_fp16=0):
+            o8 = umfa_torch.attention_forward(q, k, v, causal=True, out_dtype=torch.float32)
+            assert ",pv16" not in umfa_torch.last_kernel()
+        assert _row_rel_err(o8.cpu().numpy(), ref) < 1.5e-2  # bf16 P V: 8-bit P, every row against its own size

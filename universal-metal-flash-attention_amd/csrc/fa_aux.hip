@@ -368,7 +368,7 @@ hipError_t launch_amax_dense(const void* src, int prec, int64_t n, uint32_t* wor
 }
 
 // BwdParams::units from the four tensors' largest magnitudes (fp32 bits): hdr[0] dO, hdr[4] Q, hdr[5] K, hdr[6] V -> floats hdr[8 ... 14]
-__global__ void bwd_units_kernel(uint32_t* hdr) {
+__global__ void bwd_units_kernel(uint32_t* hdr, uint32_t* flag) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int edo = unit_exponent(hdr[0]), eq = unit_exponent(hdr[4]), ek = unit_exponent(hdr[5]), ev = unit_exponent(hdr[6]);
     float* t = (float*)(hdr + 8);
@@ -379,9 +379,16 @@ __global__ void bwd_units_kernel(uint32_t* hdr) {
     t[4] = __builtin_amdgcn_ldexpf(1.0f, -ev);
     t[5] = __builtin_amdgcn_ldexpf(1.0f, edo);
     t[6] = __builtin_amdgcn_ldexpf(1.0f, -(edo + ev));
+    // The last reader of the four amax words leaves them zero for the next call (and the overflow word in front of the header, which nothing can
+    // raise any more): the in-stream entry then needs no memset node in front of amax_dense_kernel's agent-scope fetch_max (StreamScratch::ensure_qhdr)
+    if (flag) __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(hdr + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(hdr + 4, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(hdr + 5, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(hdr + 6, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-hipError_t launch_bwd_units(uint32_t* hdr, hipStream_t stream) {
-    hipLaunchKernelGGL(bwd_units_kernel, dim3(1), dim3(64), 0, stream, hdr);
+hipError_t launch_bwd_units(uint32_t* hdr, hipStream_t stream, uint32_t* flag) {
+    hipLaunchKernelGGL(bwd_units_kernel, dim3(1), dim3(64), 0, stream, hdr, flag);
     return hipGetLastError();
 }
 

@@ -400,6 +400,7 @@ bool fwd_w64_supported(const FwdParams& p) {
         // block-diagonal and window TENSORS 0.75-0.96 x (short lists: two parts + a fold per block) -- and how dense a [Sq, Skv] mask is
         // the host cannot know without reading it back
         const uint64_t blocks = (uint64_t)p.B * p.H * ((p.Sq + 255) / 256), cus = (uint64_t)w64_cu_count();
+        if (w64_grid(p) > 512u) return false;  // (the pre-pass and the kernel keep the shared blocks' running sums in 2 KiB of LDS: fa_aux.hip mask_pack_prepare refuses more)
         if (tuning().force_w64.load(std::memory_order_relaxed)) return true;
         // causal + mask (the causal flag folded into the packed bits: fa_aux.hip causal_word) runs here when asked for, not by default: measured
         // level with the 128-row kernel (profiles/r5/causal_mask_timing.txt: 0.93-1.06 x at FLUX size, B4 H16 S4096, B2 H16 S8192 with key

@@ -124,7 +124,7 @@ hipError_t launch_cast_f16_unit(const void* src, int prec, void* dst, int64_t n,
 // launch_quantize's famax), [8 ... 14] the units table (launch_bwd_units, after all four)
 hipError_t launch_amax_dense(const void* src, int prec, int64_t n, uint32_t* word, hipStream_t stream);
 hipError_t launch_amax_dense_n(int count /* <= 4 */, const void* const* src, int prec, const int64_t* n, uint32_t* const* word, hipStream_t stream);  // one launch
-hipError_t launch_bwd_units(uint32_t* hdr, hipStream_t stream);
+hipError_t launch_bwd_units(uint32_t* hdr, hipStream_t stream, uint32_t* clean_flag = nullptr);  // leaves hdr[0], hdr[4 ... 6] (and *clean_flag) zero behind it
 // dst: [B, Hkv, slab] in out_prec (fp32 default; fp16 / bf16: rounded once after the fp32 sum)
 hipError_t launch_group_sum(const float* src, void* dst, uint32_t B, uint32_t H, uint32_t Hkv, int64_t slab, hipStream_t stream,
                             int out_prec = P_FP32);

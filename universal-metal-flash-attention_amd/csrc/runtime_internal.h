@@ -137,6 +137,8 @@ struct StreamScratch {
     size_t v16_cnt_bytes = 0, v16_buf_hw = 0;
     GrowBuf rowc;       // bwd16: row constants [2][B*H*Sq] fp32 (-LSE log2 e, -D) from bwd16_dq for bwd16_dkdv
     GrowBuf dsbuf;      // bwd16, option bwd_ds_store: dS [B*H][Sq][Skv] in the operand type
+    GrowBuf qhdr;       // runtime-quantised backward: [16 words: the overflow word][16 words: amax of dO, -, -, -, Q, K, V as fp32 bits | BwdParams::units]
+                        // at a FIXED address, zeroed once when allocated and left zero by its last reader (fa_aux.hip bwd_units_kernel): no memset node
 
     // Ticketed scratch: tickets [0, cnt) zeroed on `stream` whenever the block is new -- and never again: the kernels leave
     // their tickets zero (the folding workgroup resets the word it drew from), so a captured graph carries no memset node.
@@ -183,8 +185,29 @@ struct StreamScratch {
     char* ensure_v16(size_t slabs, size_t image_bytes, hipStream_t stream) {
         return ensure_ticketed(v16, v16_cnt_bytes, v16_buf_hw, v16_header_bytes(slabs), image_bytes + 256, stream);
     }
+    // The amax words of the quantised backward are updated with agent-scope atomics (fetch_max) -- the pattern that, behind a per-launch memset NODE
+    // of a replayed graph, left ticket words stale in round 3 (see ensure_ticketed).  So they live in a block of their own at an address that does
+    // not depend on the call's shape, zeroed when the block is new and cleaned by the launch that reads them last.
+    uint32_t* ensure_qhdr(hipStream_t stream) {
+        bool grew = false;
+        char* b = (char*)qhdr.ensure(512, stream, &grew);
+        if (!b) return nullptr;
+        if (grew && hipMemsetAsync(b, 0, 512, stream) != hipSuccess) {
+            (void)hipGetLastError();
+            qhdr.retired.push_back(qhdr.ptr);
+            qhdr.ptr = nullptr;
+            qhdr.bytes = 0;
+            return nullptr;
+        }
+        return (uint32_t*)b;
+    }
+    void drop_qhdr() {  // a call failed between the amax launch and bwd_units_kernel: the words may be non-zero -- the next call takes a fresh block
+        if (qhdr.ptr) qhdr.retired.push_back(qhdr.ptr);
+        qhdr.ptr = nullptr;
+        qhdr.bytes = 0;
+    }
     void release() {
-        split.release(); w64.release(); mflags.release(); workspace.release(); v16.release(); rowc.release(); dsbuf.release();
+        split.release(); w64.release(); mflags.release(); workspace.release(); v16.release(); rowc.release(); dsbuf.release(); qhdr.release();
         w64_cnt_bytes = 0;
         split_cnt_bytes = 0;
         v16_cnt_bytes = 0;

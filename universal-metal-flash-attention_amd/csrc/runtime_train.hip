@@ -375,15 +375,16 @@ int32_t mfa_quantized_backward(mfa_context_t context, mfa_buffer_t q, mfa_buffer
         // workspace: quantiser output + copies | D vector the callee owns (MFABridge+Quantized.swift:470-474) | fast: dO fp16, row constants, flag
         const size_t wq = (quant_workspace_bytes(B, H, Sq, Skv, D, true) + 255) & ~(size_t)255;
         const size_t o_dvec = wq, o_do16 = o_dvec + ((nr * 4 + 255) & ~(size_t)255), o_rowc = o_do16 + ((nq * 2 + 255) & ~(size_t)255),
-                     o_flag = o_rowc + ((2 * nr * 4 + 255) & ~(size_t)255);
-        char* ws = (char*)ctx->pool(pool_dev, stream).workspace.ensure((fast ? o_flag + 256 : o_do16) + 256, stream);
+                     o_end = o_rowc + ((2 * nr * 4 + 255) & ~(size_t)255);
+        char* ws = (char*)ctx->pool(pool_dev, stream).workspace.ensure((fast ? o_end : o_do16) + 256, stream);
         if (!ws) return MFA_ERROR_MEMORY_ALLOCATION;
-        uint32_t* flag = (uint32_t*)(ws + o_flag);
+        // overflow word + units header: a block of its own at a fixed address, zero between calls (StreamScratch::ensure_qhdr; bwd_units_kernel cleans it)
+        uint32_t* flag = fast ? ctx->pool(pool_dev, stream).ensure_qhdr(stream) : nullptr;
+        if (fast && !flag) return MFA_ERROR_MEMORY_ALLOCATION;
         // FAST: every operand goes to the fp16 engine as a power-of-two multiple with its largest magnitude in [1, 2) -- the de-quantised Q, K, V
         // (the quantiser's fp16 copies) and dO; the exponents are found on the device (one amax pass per tensor) and come back through
         // BwdParams::units.  Nothing can leave fp16's range then, dS = P (dP - D) included (|dS| <= 8 head_dim): no flag to read, no repeat.
-        uint32_t* unit = flag + 16;  // 16 words: kernels.h launch_bwd_units
-        if (fast && hipMemsetAsync(flag, 0, 256, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+        uint32_t* unit = fast ? flag + 16 : nullptr;  // 16 words: kernels.h launch_bwd_units
         LatencyScope lat(ctx, stream);
         if (fast) {  // one launch for the four amax words (dO's is unit[0])
             const void* const srcs[4] = {bq->dev, bk->dev, bv->dev, bdo->dev};
@@ -391,10 +392,11 @@ int32_t mfa_quantized_backward(mfa_context_t context, mfa_buffer_t q, mfa_buffer
             uint32_t* const words[4] = {unit + 4, unit + 5, unit + 6, unit};
             if (launch_amax_dense_n(4, srcs, prec, ns, words, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
         }
+        auto dirty = [&](mfa_error_t rc) { if (fast) ctx->pool(pool_dev, stream).drop_qhdr(); return rc; };  // amax words set, bwd_units_kernel not reached
         QuantViews views;
         hipError_t e = launch_quantize(bq->dev, bk->dev, bv->dev, prec, B, H, Sq, Skv, D, bits, mode, ws, fast ? 2 : 1, &views, stream,
                                        fast ? flag : nullptr, nullptr, fast ? unit + 4 : nullptr);
-        if (e != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+        if (e != hipSuccess) return dirty(MFA_ERROR_EXECUTION_FAILED);
         BwdParams p;
         memset(&p, 0, sizeof(p));
         p.o = (const float*)bo->dev; p.lse = (const float*)bl->dev;
@@ -408,8 +410,8 @@ int32_t mfa_quantized_backward(mfa_context_t context, mfa_buffer_t q, mfa_buffer
             p.in_prec = P_FP16; p.dout_prec = P_FP16;
             // dO as dO * 2^-e in fp16, e from its largest magnitude on the device (gradients of 1e-7 are ordinary; as a plain cast they
             // were fp16 subnormals): fa_aux.hip launch_cast_f16_unit, 2^e comes back in the kernels' epilogues
-            if (launch_cast_f16_unit(bdo->dev, prec, ws + o_do16, (int64_t)nq, unit, stream, true) != hipSuccess || launch_bwd_units(unit, stream) != hipSuccess)
-                return MFA_ERROR_EXECUTION_FAILED;
+            if (launch_cast_f16_unit(bdo->dev, prec, ws + o_do16, (int64_t)nq, unit, stream, true) != hipSuccess || launch_bwd_units(unit, stream, flag) != hipSuccess)
+                return dirty(MFA_ERROR_EXECUTION_FAILED);
             p.dout = ws + o_do16;
             p.units = (const float*)(unit + 8);
             p.rowc = (float*)(ws + o_rowc);
@@ -460,23 +462,29 @@ mfa_error_t umfa_quantized_backward_stream(mfa_context_t context, void* stream_h
     const bool fast = bwd16_shape_ok(D, false);
     const size_t wq = (quant_workspace_bytes(B, H, Sq, Skv, D, true) + 255) & ~(size_t)255;
     const size_t o_dvec = wq, o_do16 = o_dvec + ((nr * 4 + 255) & ~(size_t)255), o_rowc = o_do16 + ((nq * 2 + 255) & ~(size_t)255),
-                 o_flag = o_rowc + ((2 * nr * 4 + 255) & ~(size_t)255);
-    char* ws = (char*)ctx->pool(dev, stream).workspace.ensure((fast ? o_flag + 256 : o_do16) + 256, stream);
+                 o_end = o_rowc + ((2 * nr * 4 + 255) & ~(size_t)255);
+    char* ws = (char*)ctx->pool(dev, stream).workspace.ensure((fast ? o_end : o_do16) + 256, stream);
     if (!ws) return MFA_ERROR_MEMORY_ALLOCATION;
-    uint32_t* flag = status ? status : (uint32_t*)(ws + o_flag);
-    if (status && hipMemsetAsync(status, 0, 4, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
-    uint32_t* unit = (uint32_t*)(ws + o_flag) + 16;  // every operand as a power-of-two multiple, see mfa_quantized_backward
+    // The overflow word and the units header (amax words updated by agent-scope fetch_max) sit in a block of their own at a fixed address: zeroed
+    // when it is allocated, left zero by bwd_units_kernel, their last reader -- NO per-call memset node in front of them.  (As a node of a replayed
+    // graph such a memset left the forward's ticket words stale in round 3, runtime_internal.h ensure_ticketed; a stale amax is max(previous,
+    // current): exponents too large, operands pushed towards fp16's subnormals, and nothing left in the engine that would say so.)
+    uint32_t* const qhdr = fast ? ctx->pool(dev, stream).ensure_qhdr(stream) : nullptr;
+    if (fast && !qhdr) return MFA_ERROR_MEMORY_ALLOCATION;  // (under capture: warm the shape up on the capture stream first, like every pool block)
+    uint32_t* flag = status ? status : qhdr;
+    if (status && hipMemsetAsync(status, 0, 4, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;  // the caller's word (kept in the signature; nothing raises it)
+    uint32_t* unit = fast ? qhdr + 16 : nullptr;  // every operand as a power-of-two multiple, see mfa_quantized_backward
     const size_t nkv_in = (size_t)B * H * Skv * D;
     if (fast) {  // one launch for the four amax words (dO's is unit[0])
         const void* const srcs[4] = {q, k, v, dout};
         const int64_t ns[4] = {(int64_t)nq, (int64_t)nkv_in, (int64_t)nkv_in, (int64_t)nq};
         uint32_t* const words[4] = {unit + 4, unit + 5, unit + 6, unit};
-        if (hipMemsetAsync(ws + o_flag, 0, 256, stream) != hipSuccess || launch_amax_dense_n(4, srcs, prec, ns, words, stream) != hipSuccess)
-            return MFA_ERROR_EXECUTION_FAILED;
+        if (launch_amax_dense_n(4, srcs, prec, ns, words, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
     }
+    auto dirty = [&](mfa_error_t rc) { if (fast) ctx->pool(dev, stream).drop_qhdr(); return rc; };  // amax words set, bwd_units_kernel not reached
     QuantViews views;
     if (launch_quantize(q, k, v, prec, B, H, Sq, Skv, D, bits, mode, ws, fast ? 2 : 1, &views, stream, fast ? flag : nullptr, nullptr, fast ? unit + 4 : nullptr) != hipSuccess)
-        return MFA_ERROR_EXECUTION_FAILED;
+        return dirty(MFA_ERROR_EXECUTION_FAILED);
     BwdParams p;
     memset(&p, 0, sizeof(p));
     p.o = out; p.lse = lse; p.dq = dq; p.dk = dk; p.dv = dv;
@@ -488,8 +496,8 @@ mfa_error_t umfa_quantized_backward_stream(mfa_context_t context, void* stream_h
     if (fast) {
         p.q = views.qh; p.k = views.kh; p.v = views.vh;
         p.in_prec = P_FP16; p.dout_prec = P_FP16;
-        if (launch_cast_f16_unit(dout, prec, ws + o_do16, (int64_t)nq, unit, stream, true) != hipSuccess || launch_bwd_units(unit, stream) != hipSuccess)
-            return MFA_ERROR_EXECUTION_FAILED;
+        if (launch_cast_f16_unit(dout, prec, ws + o_do16, (int64_t)nq, unit, stream, true) != hipSuccess || launch_bwd_units(unit, stream, qhdr) != hipSuccess)
+            return dirty(MFA_ERROR_EXECUTION_FAILED);
         p.dout = ws + o_do16;
         p.units = (const float*)(unit + 8);
         p.rowc = (float*)(ws + o_rowc);
@@ -561,6 +569,7 @@ mfa_error_t prequant_stage(Context* ctx, const PreQuant& a, float** qf, float** 
     for (Buffer* b : {a.q, a.k, a.v, a.qs, a.qz, a.ks, a.kz, a.vs, a.vz})
         if (b && b->upload(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
     // (half: the flag word the kernels below OR into + the 16-word units header behind it, kernels.h launch_bwd_units: word 0 dO's amax, 4 ... 6 those of Q, K, V)
+    // (a per-call memset is fine HERE: these entries are synchronous on the legacy stream and cannot be captured; the in-stream entry's header is self-cleaning)
     if (half && hipMemsetAsync(*extra + overflow_off, 0, 256, stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
     uint32_t* const unit = half ? (uint32_t*)(*extra + overflow_off) + 16 : nullptr;
     auto deq = [&](Buffer* src, float* dst, int prec, uint32_t hs, uint32_t S, float sc, int zp, Buffer* bsc, Buffer* bzp,

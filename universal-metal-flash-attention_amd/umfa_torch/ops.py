@@ -58,6 +58,12 @@ def get_option(name: str) -> str:
     return buf.value.decode()
 
 
+def pv_fp16_status() -> int:
+    """Round 4's status word of the fp16 P V product (1 = a V value left fp16's range).  Always 0 since round 5: V goes into the product as
+    V * 2^-e, one power of two per (batch, head) slab chosen on the device, so the condition no longer exists.  Kept for round-4 callers."""
+    return int(get_option("pv_fp16_status"))
+
+
 def set_option(name: str, value) -> None:
     """Context-wide launcher switch, e.g. set_option("softmax_reference", "exact") -- see umfa_set_option in the header."""
     _check_error(_lib.umfa_set_option(context(), name.encode(), str(value).encode()))
