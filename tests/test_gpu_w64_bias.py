@@ -1,0 +1,169 @@
+"""ADDITIVE fp16 mask tensors on the one-wave-per-SIMD forward (fa_fwd16_w64<., 128, bias>, round 6): the kernel DMAs the wave's 64 x 64 mask tile
+straight from the caller's tensor (any <= 4-D broadcastable fp16 tensor with 16-byte aligned rows) and adds mask / scale to the raw scores; a
+classification pre-pass gives per-wave tile classes (all -inf: masked, all zero: open, else mixed) and the visited-tile list of every 256-row block,
+so fully masked tiles are never staged.  Semantics are the reference's additive masks (MFABridge.swift:157-242: the value is added to the scaled
+score; -inf masks; a row with every key at -inf gives O = 0, LSE = -inf), checked against the CPU oracle WITH the mask, against the 128-row kernel
+(option no_w64_bias) and for run-to-run bitwise repeatability."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from tolerances import check_forward  # noqa: E402
+
+
+def _oracle():
+    from oracle import oracle
+    return oracle
+
+
+def bits(t):
+    return t.cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+def npy(t):
+    return bits(t) if t.dtype == torch.bfloat16 else t.cpu().contiguous().numpy()
+
+
+NEG = float("-inf")
+
+
+def _bias(kind, B, H, Sq, Skv, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    i = torch.arange(Sq, device="cuda")[:, None]
+    j = torch.arange(Skv, device="cuda")[None, :]
+    if kind == "rel_pos":                      # [1, 1, Sq, Skv]: -|i - j| / 64, every tile mixed
+        return (-(i - j).abs().float() / 64.0).to(torch.float16)[None, None].contiguous()
+    if kind == "per_head":                     # [1, H, Sq, Skv]: ALiBi-like slopes
+        sl = torch.tensor([2.0 ** -(h + 2) for h in range(H)], device="cuda")[:, None, None]
+        return (-(i - j).abs().float()[None] * sl).to(torch.float16)[None].contiguous()
+    if kind == "random":                       # [B, H, Sq, Skv]: N(0, 2) with 20 % -inf, a key always open
+        m = (torch.randn(B, H, Sq, Skv, device="cuda", generator=g) * 2.0).to(torch.float16)
+        m[torch.rand(B, H, Sq, Skv, device="cuda", generator=g) < 0.2] = NEG
+        m[..., 5] = 0.5
+        return m
+    if kind == "blockdiag_inf":                # [1, 1, Sq, Skv]: 0 inside documents of 192 rows / 160 keys, -inf outside: open / masked / mixed tiles
+        return torch.where((i // 192) == (j // 160), 0.0, NEG).to(torch.float16)[None, None].contiguous()
+    if kind == "padding_row_broadcast":        # [B, 1, 1, Skv]: 0 / -inf per batch element, no row dimension
+        lens = torch.tensor([max(1, Skv - 37 - 211 * b) for b in range(B)], device="cuda")
+        return torch.where(j[None] < lens[:, None, None], 0.0, NEG).to(torch.float16)[:, None].contiguous()
+    if kind == "all_zero":
+        return torch.zeros(1, 1, Sq, Skv, dtype=torch.float16, device="cuda")
+    if kind == "empty_rows_and_blocks":        # rows, a whole 256-row block and a whole head at -inf
+        m = (torch.randn(B, H, Sq, Skv, device="cuda", generator=g)).to(torch.float16)
+        m[:, :, 5::17] = NEG
+        m[:, 0, 256:512] = NEG
+        if H > 1:
+            m[:, 1] = NEG
+        return m
+    if kind == "large_negative":               # -30000 instead of -inf (the "large negative" idiom): finite, exp underflows
+        return torch.where((i // 256) >= (j // 256), 0.0, -30000.0).to(torch.float16)[None, None].contiguous()
+    if kind == "strided_rows":                 # a view with a row stride of its own: the left half of a wider tensor (rows stay 16-byte aligned)
+        wide = (torch.randn(B, 1, Sq, 2 * Skv, device="cuda", generator=g)).to(torch.float16)
+        return wide[..., :Skv]
+    raise ValueError(kind)
+
+
+KINDS = ["rel_pos", "per_head", "random", "blockdiag_inf", "padding_row_broadcast", "all_zero", "empty_rows_and_blocks", "large_negative", "strided_rows"]
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape,grid", [((2, 2, 512, 512), 0), ((1, 3, 1280, 768), 0), ((1, 3, 1280, 1408), 4), ((2, 2, 512, 512), 3)])
+def test_w64_additive_mask_vs_oracle(kind, dt, shape, grid, umfa_opts):
+    import umfa_torch
+    umfa_opts(force_w64=1)
+    if grid:
+        umfa_opts(w64_grid=grid)  # few workgroups: blocks cut along their tile lists, parts folded
+    B, H, Sq, Skv = shape
+    D = 128
+    torch.manual_seed(Sq + Skv)
+    q = torch.randn(B, H, Sq, D, device="cuda", dtype=dt)
+    k = torch.randn(B, H, Skv, D, device="cuda", dtype=dt)
+    v = torch.randn(B, H, Skv, D, device="cuda", dtype=dt)
+    m = _bias(kind, B, H, Sq, Skv, seed=Sq)
+    o, lse = umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32, return_lse=True)
+    kern = umfa_torch.last_kernel()
+    assert kern in ("fa_fwd16_w64<bf16,128,pv16,bias>", "fa_fwd16_w64<fp16,128,bias>"), kern
+    mfull = np.ascontiguousarray(m.expand(B, H, Sq, Skv).float().cpu().numpy())
+    ref, ref_lse = _oracle().sdpa_forward(npy(q), npy(k), npy(v), mask=mfull, mask_type=_oracle().MASK_ADDITIVE, return_lse=True)
+    on = o.cpu().numpy()
+    assert np.isfinite(on).all()
+    # (cut blocks: the fold's fp32 recombination of a block's parts sits on top of the kernel's own error -- key padding at 264 of 512 keys with fp16
+    # operands, three workgroups: 4.91e-4 against the 4.88e-4 of one fp16 ulp of P; 2 % of slack for the forced-grid cases, none for whole blocks)
+    check_forward(on, ref, dt, kern, f"w64_bias_{kind}", scale_max=1.02 if grid else 1.0)
+    dead = np.isneginf(mfull).all(-1)
+    ln = lse.cpu().numpy().reshape(B, H, Sq)
+    assert (on[dead] == 0).all() and np.isneginf(ln[dead]).all()          # rows whose every key is at -inf: O = 0, LSE = -inf
+    assert np.abs(ln[~dead] - ref_lse[~dead]).max() < 2e-2
+    # bitwise repeatable, and the 128-row kernel's numbers class
+    o2 = umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32)
+    assert torch.equal(o, o2)
+    with umfa_torch.options(no_w64_bias=1, force_w64=0, w64_grid=0):
+        o3 = umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32)
+        assert umfa_torch.last_kernel().startswith("fa_fwd16<"), umfa_torch.last_kernel()
+    assert float((o - o3).abs().max()) <= 2.0 ** -9 * float(o3.abs().max())
+    # 16-bit output epilogue
+    o16 = umfa_torch.attention_forward(q, k, v, mask=m)
+    assert o16.dtype == dt and float((o16.float() - o).abs().max()) <= 2.0 ** -8 * float(o.abs().max()) * 1.01
+
+
+def test_w64_additive_mask_routing_and_what_stays_on_the_128_row_kernel(umfa_opts):
+    """the route's conditions (fwd_w64_supported): fp16 masks with 16-byte aligned rows on whole tiles take the bias kernel by default from one
+    256-row block per CU on; bf16 / fp32 masks, ragged shapes, unaligned rows and causal + bias keep the 128-row kernel -- same answers either way"""
+    import umfa_torch
+    torch.manual_seed(5)
+    B, H, S, D = 1, 72, 1024, 128  # 288 blocks >= 256 CUs
+    q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    i = torch.arange(S, device="cuda")
+    bias = (-(i[:, None] - i[None, :]).abs().float() / 128.0)[None, None]
+    o = {}
+    for name, m in (("f16", bias.to(torch.float16)), ("bf16", bias.to(torch.bfloat16)), ("f32", bias.clone())):
+        o[name] = umfa_torch.attention_forward(q, k, v, mask=m.contiguous(), out_dtype=torch.float32)
+        kern = umfa_torch.last_kernel()
+        assert ("bias" in kern) == (name == "f16"), (name, kern)
+    # (the three masks hold the same numbers up to their own rounding of -|i - j| / 128)
+    assert float((o["f16"] - o["f32"]).abs().max()) < 2e-3 * float(o["f32"].abs().max())
+    assert float((o["bf16"] - o["f32"]).abs().max()) < 1e-2 * float(o["f32"].abs().max())
+    m16 = bias.to(torch.float16).contiguous()
+    umfa_torch.attention_forward(q, k, v, mask=m16, causal=True, out_dtype=torch.float32)
+    assert "bias" not in umfa_torch.last_kernel()
+    wide = torch.zeros(1, 1, S, S + 4, device="cuda", dtype=torch.float16)
+    umfa_torch.attention_forward(q, k, v, mask=wide[..., 4:], out_dtype=torch.float32)  # rows start 8 bytes off a 16-byte boundary
+    assert "bias" not in umfa_torch.last_kernel()
+    umfa_torch.attention_forward(q[:, :, :1000], k, v, mask=m16[:, :, :1000], out_dtype=torch.float32)  # Sq not a multiple of 64
+    assert "bias" not in umfa_torch.last_kernel()
+
+
+def test_w64_additive_mask_replays_in_a_graph_and_follows_the_mask():
+    """one captured call, the mask tensor's CONTENTS changed between replays (finite bias -> block-diagonal -inf -> all zero): classes, lists and the
+    result follow the data; the replay equals the eager call bit for bit"""
+    import umfa_torch
+    torch.manual_seed(9)
+    B, H, S, D = 1, 72, 1024, 128
+    q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    i = torch.arange(S, device="cuda")
+    m = torch.zeros(1, 1, S, S, device="cuda", dtype=torch.float16)
+    out = torch.empty(B, H, S, D, device="cuda", dtype=torch.float32)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        umfa_torch.attention_forward(q, k, v, mask=m, out=out)
+        assert "bias" in umfa_torch.last_kernel()
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            umfa_torch.attention_forward(q, k, v, mask=m, out=out)
+    contents = [(-(i[:, None] - i[None, :]).abs().float() / 100.0).to(torch.float16),
+                torch.where((i[:, None] // 256) == (i[None, :] // 256), 0.0, NEG).to(torch.float16),
+                torch.zeros(S, S, device="cuda", dtype=torch.float16)]
+    for c in contents:
+        m.copy_(c[None, None])
+        out.fill_(float("nan"))
+        g.replay()
+        torch.cuda.synchronize()
+        eager = umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32)
+        assert torch.isfinite(out).all() and torch.equal(eager, out)
+    plain = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
+    assert float((plain - out).abs().max()) <= 2.0 ** -9 * float(plain.abs().max())  # the all-zero mask: the unmasked answer

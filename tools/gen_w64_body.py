@@ -38,6 +38,7 @@ FSTAMP = [int(x) for x in os.environ.get("W64_LAB_FSTAMP", "").split(",") if x] 
 GAPSTAMP = [int(x) for x in os.environ.get("W64_LAB_GAPSTAMP", "").split(",") if x]  # lab: clock stamps in front of these gaps (steady-state parts)
 SPEC = os.environ.get("W64_SPEC", "1") == "1"  # steady-state tiles: e = s*c - m against the CURRENT reference first, row max of e, cheap decision (spec_streams)
 EARLY_MAX = os.environ.get("W64_EARLY_MAX", "1") == "1"  # row max of key-block 0 during the QK of key-block 1, e = s*c - m spread to the end
+MA_DEPTH = int(os.environ.get("W64_MA_DEPTH", "2"))  # additive-mask bodies (MASKA): mask fragments read this many 4-score groups ahead of their use (per score block)
 class Cfg:
     """16-bit kernels: S = K Q^T is 32 MFMAs (8 k-steps of 16); int8 kernel (fa_fwd_w64_i8): 16 MFMAs
     (v_mfma_i32_32x32x32_i8, 4 k-steps of 32).  The integer scores never pass through v_cvt_f32_i32: the first
@@ -46,14 +47,17 @@ class Cfg:
     row max runs on those floats (monotone in s) and the one v_fma_f32 per score that applies scale and reference max
     takes the bias out with its addend (nmb = -m - 12582912 c).  W64_I8_BIAS=0 (lab, with -DW64_I8_NOBIAS) keeps the
     explicit in-place conversion (I2F)."""
-    def __init__(self, i8, f8=False, d64=False):
+    def __init__(self, i8, f8=False, d64=False, madd=False):
         self.i8 = i8
+        # additive fp16 mask tensors (fa_fwd16_w64_bias_*, round 6): a body file of its own -- the masking bodies read the wave's mask tile from LDS (MLD) and add
+        # mask / scale with one v_fma_mix_f32 per score; EVERY body carries the eight LDS-DMA instructions of the next listed tile's mask image (DMAM)
+        self.madd = madd
         self.f8 = f8                     # fp8 (e4m3) P and V: O^T += V^T P^T on v_mfma_scale_f32_32x32x64_f8f6f4 (see Cfg8 notes)
         # head_dim 64 (16-bit kernels only, fa_fwd16_w64d64): half the k-steps of S = K Q^T and two d-blocks of O^T instead of
         # four -- 32 MFMAs per 64-key tile for the same softmax work, rows of 128 bytes in the K / V tile images (the int8
         # kernels' K geometry).  The O^T register map is head_dim 128's with d-blocks 0 and 1 of each q-block in use.
         self.d64 = d64
-        assert not (d64 and (i8 or f8))
+        assert not (d64 and (i8 or f8)) and not (madd and (i8 or f8 or d64))
         self.i2f = i8 and os.environ.get("W64_I8_BIAS", "1") == "0"
         # row sums on the matrix pipe (16-bit P kernels): l += sum of the ROUNDED P fragment by v_mfma_f32_4x4x4_16b against an
         # all-ones operand (a lane-local sum: block b = lane / 4, column j = lane % 4 -> the lane's own four values; 8-cycle
@@ -83,7 +87,7 @@ class Cfg:
         return self.NQK + 10 * qb + 2 * db
 
 
-COST = {"MSUM": 8, "LCHK": 12, "DEC2": 20, "MXINIT": 8, "MAXE": 4, "CVT8": 4, "VREAD8": 8, "UPDK": 4, "UPDV": 4, "BAR": 16, "KPRE": 4, "I2F": 4, "MASK": 8, "DMAK": 8, "DMAV": 8, "NOP": 32, "EXP": 8, "ADD": 4, "CVT": 4, "VREAD": 8, "KREAD": 4, "MAX": 4, "DEC": 44, "FMA": 4}
+COST = {"MLD": 8, "DMAM": 8, "MSUM": 8, "LCHK": 12, "DEC2": 20, "MXINIT": 8, "MAXE": 4, "CVT8": 4, "VREAD8": 8, "UPDK": 4, "UPDV": 4, "BAR": 16, "KPRE": 4, "I2F": 4, "MASK": 8, "DMAK": 8, "DMAV": 8, "NOP": 32, "EXP": 8, "ADD": 4, "CVT": 4, "VREAD": 8, "KREAD": 4, "MAX": 4, "DEC": 44, "FMA": 4}
 for _kv in filter(None, os.environ.get("W64_COST", "").split(",")):  # lab: W64_COST=EXP:16,ADD:4 overrides the model
     COST[_kv.split(":")[0]] = int(_kv.split(":")[1])
 
@@ -266,7 +270,22 @@ def op_text(R, op):
         # mask-tensor instantiations (MASKT): bit 16 kb + r of the lane's word mwc[qb] (fa_aux.hip mask_pack_kernel) says whether the
         # score attends: sign-extend the bit to a select mask, keep the score or take -inf
         mt = (f'asm volatile("v_bfe_i32 %0, %1, {16 * kb + r}, 1\\n\\tv_bfi_b32 v{v}, %0, v{v}, %2" : "=&v"(mtmp) : "v"(mwc[{qb}]), "v"(neg_inf));')
+        # additive fp16 mask tensors (MASKA, round 6): the lane's four mask values of score group g = r >> 2 (keys 8 g + 4 hi ... + 3 of key block kb: 8 bytes of
+        # the wave's mask tile in LDS, read by the MLD op) are added to the raw scores as mask / scale -- one v_fma_mix_f32 per score (f16 source half picked
+        # by op_sel), so that the row max and e = s * c - m see s + mask / scale, i.e. (s * scale + mask) * log2 e
+        # (temporaries per q-block, the eight groups of its two key blocks in ONE ordered stream: ma_slot)
+        if C.madd:
+            return (f'asm volatile("v_fma_mix_f32 v{v}, %0, %1, v{v} op_sel:[{r & 1},0,0] op_sel_hi:[1,0,0]" :: "v"(mta[{qb}][{ma_slot(kb, r >> 2)}][{(r & 3) >> 1}]), "s"(ma_k));')
         return f'if constexpr (MASKT) {{ {mt} }} else if constexpr (WINDOW) {{ {two} }} else {{ {one} }}'
+    if kind == "MLD":  # MASKA: the mask fragment of score group g of block (kb, qb) from the wave's mask tile ring (compiler-visible LDS read: hipcc counts the wait)
+        _, kb, qb, g = op
+        return f"mta[{qb}][{ma_slot(kb, g)}] = ma_read(W64_MOFF + {4096 * qb}, {16 * (4 * kb + g)});"
+    if kind == "DMAM":  # MASKA: piece j (8 rows) of the NEXT listed tile's mask image -> the other ring slot; skipped (wave-uniform) when this wave runs that tile unmasked
+        _, j = op
+        # (ONE running scalar for the source offset and the ring base + an immediate for M0: as sixteen distinct scalar operands per tile the pieces cost the
+        # kernel scalar-register spills into vector lanes, and those vector registers)
+        return (f'if (ma_col >= 0) {{ asm volatile("s_add_u32 m0, %0, %4\\n\\ts_nop 0\\n\\tbuffer_load_dwordx4 %1, %2, %3 offen{DMA_MOD} lds" ::"s"(ma_ring), '
+                f'"v"(ma_voff), "s"(ma_srd), "s"(ma_soff), "n"(W64_MDST + {j * 1024}) : "memory", "scc"); ma_soff += ma_rs8; }}')
     if kind == "DMAK" and DMASTAMP and op[1] == 0:
         return ('{ asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long d0_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); '
                 'asm volatile("s_mov_b32 m0, %0\\n\\ts_nop 0\\n\\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_wave_k + W64_KDST + 0), "v"(kdma[0]), "s"(k_srd) : "memory"); '
@@ -428,6 +447,9 @@ def dma_stream():
     if os.environ.get("W64_DMA_V" + sfx):
         vpos = [int(x) for x in os.environ["W64_DMA_V" + sfx].split(",")]
     ops = [(("DMAK", j), kpos[j], kpos[j] + 2) for j in range(C.KDMA)] + [(("DMAV", j), vpos[j], vpos[j] + 2) for j in range(C.VDMA)]
+    if C.madd:  # the eight 1-KiB pieces of the next listed tile's mask image, in the gaps the K / V pieces leave (W64_DMA_M overrides)
+        mpos = [int(x) for x in os.environ.get("W64_DMA_M", "3,7,11,15,19,23,27,31").split(",")]
+        ops += [(("DMAM", j), mpos[j], mpos[j] + 2) for j in range(8)]
     ops.sort(key=lambda o: o[1])
     return ops
 
@@ -435,8 +457,36 @@ def dma_stream():
 def dma_update_stream(dma_ops):
     """offset updates, UPD_DELAY gaps behind the deadline of their DMA instruction"""
     last = C.NG - 1
-    ups = [(("UPDK" if o[0][0] == "DMAK" else "UPDV", o[0][1]), min(last, o[2] + UPD_DELAY), min(last, o[2] + UPD_DELAY + 3)) for o in dma_ops]
+    ups = [(("UPDK" if o[0][0] == "DMAK" else "UPDV", o[0][1]), min(last, o[2] + UPD_DELAY), min(last, o[2] + UPD_DELAY + 3)) for o in dma_ops if o[0][0] != "DMAM"]
     return ups
+
+
+def mask_ops(kb, qb, st, dl):
+    """MASK ops of score block (kb, qb) in register order"""
+    return [(("MASK", kb, qb, r), st, dl) for r in range(16)]
+
+
+def ma_slot(kb, g):
+    """additive-mask bodies: which of the q-block's MA_DEPTH temporaries holds the mask fragment of score group g of key block kb (groups 4 kb + g run in order)"""
+    return (4 * kb + g) % MA_DEPTH
+
+
+def madd_chain(qb, per_kb, mld_from):
+    """Additive-mask bodies: ONE ordered stream per q-block over both key blocks -- the mask fragments are read MA_DEPTH groups ahead of the v_fma_mix that
+    consume them (a fragment does not depend on the scores: the read of key block 1's first groups is issued while key block 0 is still being masked), and a
+    temporary is rewritten only behind the group that used it.  per_kb[kb] = (earliest, deadline, ops that follow the block's MASK ops); mld_from: earliest gap of a read."""
+    groups = [(kb, g) for kb in (0, 1) for g in range(4)]
+    last = max(per_kb[kb][1] for kb in (0, 1))
+    ops = [(("MLD", kb, qb, g), mld_from, last) for kb, g in groups[:MA_DEPTH]]
+    for n, (kb, g) in enumerate(groups):
+        st, dl, tail = per_kb[kb]
+        ops += [(("MASK", kb, qb, r), st, dl) for r in range(4 * g, 4 * g + 4)]
+        if n + MA_DEPTH < len(groups):
+            k2, g2 = groups[n + MA_DEPTH]
+            ops.append((("MLD", k2, qb, g2), mld_from, last))
+        if g == 3:
+            ops += tail
+    return ops
 
 
 def start_streams(have_new, mfma_follows=True, masked=False):
@@ -458,13 +508,19 @@ def start_streams(have_new, mfma_follows=True, masked=False):
                 for r in range(16):
                     if C.i2f:
                         ops.append((("I2F", kb, qb, r), ready + qb, last))
-            if masked:
+            if masked and not C.madd:
                 for qb in (0, 1):
-                    for r in range(16):
-                        ops.append((("MASK", kb, qb, r), ready + qb, last))
+                    ops += mask_ops(kb, qb, ready + qb, last)
+            if masked and C.madd and kb == 1:  # (both key blocks at once, behind the NOP: one ordered chain per q-block, the two interleaved group by group)
+                ch = [madd_chain(qb, {0: (C.NQK, last, []), 1: (C.NQK, last, [])}, C.NQK) for qb in (0, 1)]
+                for a, b in zip(ch[0], ch[1]):
+                    ops += [a, b]
+            if masked and C.madd and kb == 0:
+                continue  # (the row max of key block 0 follows its masking: below, behind key block 1's)
             for r in range(0, 16, 2):
                 for qb in (0, 1):
-                    ops.append((("MAX", kb, qb, r, kb == 0 and r < 4), ready + qb, last))
+                    for kbm in ((0, 1) if (masked and C.madd) else (kb,)):
+                        ops.append((("MAX", kbm, qb, r, kbm == 0 and r < 4), ready + qb, last))
         ops.append((("DEC",), C.NQK + 2, last))
         for kb in (0, 1):
             for qb in (0, 1):
@@ -501,7 +557,7 @@ def start_streams(have_new, mfma_follows=True, masked=False):
                 streams.append([(("I2F", kb, qb, r), max(w["i2f"][kb][0], ready + qb), w["i2f"][kb][1]) for r in range(16)])
         if masked:
             for qb in (0, 1):
-                streams.append([(("MASK", kb, qb, r), max(w["mask"][kb][0], ready + qb), w["mask"][kb][1]) for r in range(16)])
+                streams.append(mask_ops(kb, qb, max(w["mask"][kb][0], ready + qb), w["mask"][kb][1]))
         mx = []
         for r in range(0, 16, 2):
             for qb in (0, 1):
@@ -522,13 +578,18 @@ def lazy_streams(masked):
     rebases by an exact power of two long before, and a segment that still overflows is re-run with the max chain)."""
     last = C.NG - 1
     streams = []
+    if masked and C.madd:
+        for qb in (0, 1):
+            per = {kb: (kb * C.HALF + C.HALF + qb, last, [(("FMA", kb, qb, r), kb * C.HALF + C.HALF + qb, last) for r in range(16)]) for kb in (0, 1)}
+            streams.append(madd_chain(qb, per, max(0, C.HALF - 6)))
+        return streams
     for kb in (0, 1):
         ready = kb * C.HALF + C.HALF
         for qb in (0, 1):
             st, dl = ready + qb, last
             ops = []
             if masked:
-                ops += [(("MASK", kb, qb, r), st, dl) for r in range(16)]
+                ops += mask_ops(kb, qb, st, dl)
             ops += [(("FMA", kb, qb, r), st, dl) for r in range(16)]
             streams.append(ops)
     return streams
@@ -545,6 +606,22 @@ def spec_streams(masked):
     last = C.NG - 1
     dec_at = last - 1
     streams = [[(("MXINIT",), 0, max(1, C.HALF - 2))]]
+    if masked and C.madd:
+        for qb in (0, 1):
+            per = {}
+            for kb in (0, 1):
+                st, dl = kb * C.HALF + C.HALF + qb, dec_at - 1
+                tail, pend = [], None
+                for r in range(0, 16, 2):
+                    tail += [(("FMA", kb, qb, r), st, dl), (("FMA", kb, qb, r + 1), st, dl)]
+                    if pend is not None:
+                        tail.append((("MAXE", kb, qb, pend), st, dl))
+                    pend = r
+                tail.append((("MAXE", kb, qb, pend), st, dl))
+                per[kb] = (st, dl, tail)
+            streams.append(madd_chain(qb, per, max(0, C.HALF - 6)))
+        streams.append([(("DEC2",), dec_at, dec_at)])
+        return streams
     for kb in (0, 1):
         ready = kb * C.HALF + C.HALF
         for qb in (0, 1):
@@ -553,7 +630,7 @@ def spec_streams(masked):
             if C.i2f:
                 ops += [(("I2F", kb, qb, r), st, dl) for r in range(16)]
             if masked:
-                ops += [(("MASK", kb, qb, r), st, dl) for r in range(16)]
+                ops += mask_ops(kb, qb, st, dl)
             pend = None
             for r in range(0, 16, 2):
                 ops += [(("FMA", kb, qb, r), st, dl), (("FMA", kb, qb, r + 1), st, dl)]
@@ -720,6 +797,16 @@ def check_part(placed, have_new, have_old, masked, pre=(), lazy=False):
                     assert before(("DEC",), ("FMA", kb, qb, r)), ("FMA before decision", kb, qb, r)
                     if masked:
                         assert pos[("MASK", kb, qb, r)][0] > last_mfma, ("mask on an unfinished score tile", kb, qb, r)
+    if C.madd and masked and have_new:
+        for qb in (0, 1):
+            groups = [(kb, g) for kb in (0, 1) for g in range(4)]
+            for n, (kb, g) in enumerate(groups):
+                ld = ("MLD", kb, qb, g)
+                for r in range(4 * g, 4 * g + 4):
+                    assert before(ld, ("MASK", kb, qb, r)), ("mask fragment read behind its use", ld)
+                if n >= MA_DEPTH:  # the temporary's previous tenant must have been consumed
+                    kp, gp = groups[n - MA_DEPTH]
+                    assert before(("MASK", kp, qb, 4 * gp + 3), ld), ("mask fragment read overwrites an unconsumed one", ld)
     if MIDBAR and have_new:
         bar = pos[("BAR",)]
         for op, at in pos.items():
@@ -977,6 +1064,8 @@ def main():
     emit_body(Path(os.environ["W64_OUT_I8F8"]) if os.environ.get("W64_OUT_I8F8") else csrc / "fa_fwd_w64_i8f8_body.inc")
     C = Cfg(False, d64=True)
     emit_body(Path(os.environ["W64_OUT_D64"]) if os.environ.get("W64_OUT_D64") else csrc / "fa_fwd16_w64d64_body.inc")
+    C = Cfg(False, madd=True)
+    emit_body(Path(os.environ["W64_OUT_BIAS"]) if os.environ.get("W64_OUT_BIAS") else csrc / "fa_fwd16_w64_bias_body.inc")
 
 
 if __name__ == "__main__":

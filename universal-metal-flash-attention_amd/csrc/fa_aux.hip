@@ -920,7 +920,11 @@ __global__ __launch_bounds__(64) void mask_list_kernel(const uint8_t* wflag, uin
     __builtin_amdgcn_s_waitcnt(0);
     for (uint32_t j = lane; j < n; j += 64) {
         const uint32_t j1 = j + 1 < n ? j + 1 : n - 1, j2 = j + 2 < n ? j + 2 : n - 1;
-        out[2 * j + 1] = (out[2 * j1] & 0xffffu) | ((out[2 * j2] & 0xffffu) << 16);
+        const uint32_t e1 = out[2 * j1];
+        out[2 * j + 1] = (e1 & 0xffffu) | ((out[2 * j2] & 0xffffu) << 16);
+        // bits 24 ... 31: the four waves' classes of the NEXT listed tile (the additive-mask kernel fetches a tile's mask image a tile ahead, and only
+        // for waves that will read it; behind the last entry: "open", nothing to fetch).  Only bits 0 ... 23 of an entry are read back above.
+        out[2 * j] |= (j + 1 < n ? (e1 >> 16) & 0xffu : 0xaau) << 24;
     }
 }
 
@@ -932,7 +936,7 @@ size_t mask_pack_bytes(const FwdParams& p) {
 
 // the scratch layout of the packed mask + the arguments of the pack kernel; fills p.mk_*
 static hipError_t mask_pack_prepare(FwdParams& p, void* scratch, MaskPackArgs& a, uint32_t*& list, uint32_t*& cnt, uint32_t& nqb, uint64_t& slabs) {
-    if (p.mask_kind != MK_BOOL || !p.mask || !scratch) return hipErrorInvalidValue;
+    if ((p.mask_kind != MK_BOOL && p.mask_kind != MK_F16) || !p.mask || !scratch) return hipErrorInvalidValue;
     const uint32_t Bm = p.ms[0] ? p.B : 1, Hm = p.ms[1] ? p.H : 1, nrb64 = (p.Sq + 63) / 64, T = (p.Skv + 63) / 64;
     nqb = (p.Sq + 255) / 256;
     slabs = (uint64_t)Bm * Hm;
@@ -974,6 +978,47 @@ hipError_t launch_mask_pack(FwdParams& p, void* scratch, hipStream_t stream) {
     uint32_t *list, *cnt, nqb;
     uint64_t slabs;
     if (hipError_t e = mask_pack_prepare(p, scratch, a, list, cnt, nqb, slabs); e != hipSuccess) return e;
+    return mask_pack_finish(a, list, cnt, nqb, slabs, stream);
+}
+
+// ---- additive fp16 masks on the one-wave-per-SIMD structure (MASKA, round 6): tile classes only -- the kernel DMAs the caller's tensor itself.
+// One wave per (mask batch, mask head, 64-row block, 64-key tile): a lane owns one 16-byte segment (8 keys) of a row, a wave-load covers 8 rows, 8 loads
+// the tile.  class 1 = every element -inf (the wave skips nothing but lists skip the tile when all four waves say so), 2 = every element +-0 (the plain
+// tile body, no mask read), 0 = mixed.  Preconditions (fwd_w64_supported): Sq, Skv multiples of 64, keys contiguous, 16-byte aligned rows.
+__global__ __launch_bounds__(256) void mask_classify_f16_kernel(MaskPackArgs p) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wid = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= p.total) return;
+    const uint32_t tile = (uint32_t)(wid % p.T);
+    const uint32_t rb = (uint32_t)((wid / p.T) % p.nrb64);
+    const uint32_t slab = (uint32_t)(wid / ((uint64_t)p.T * p.nrb64));
+    const uint32_t hm = slab % p.Hm, bm = slab / p.Hm;
+    const char* base = (const char*)p.mask + ((int64_t)bm * p.ms[0] + (int64_t)hm * p.ms[1] + (int64_t)(rb * 64 + (lane >> 3)) * p.ms[2] + tile * 64 + (lane & 7) * 8) * 2;
+    u32x4_t w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = *(const u32x4_t*)(base + (int64_t)(8 * i) * p.ms[2] * 2);
+    bool any_open = false, any_term = false;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t lo = w[i][j] & 0xffffu, hi16 = w[i][j] >> 16;
+            any_open |= lo != 0xfc00u || hi16 != 0xfc00u;
+            any_term |= (w[i][j] & 0x7fff7fffu) != 0;
+        }
+    const bool open = __builtin_amdgcn_ballot_w64(any_open) != 0, term = __builtin_amdgcn_ballot_w64(any_term) != 0;
+    if (lane == 0) p.wflag[wid] = !open ? 1 : (!term ? 2 : 0);
+}
+
+hipError_t launch_mask_classify(FwdParams& p, void* scratch, hipStream_t stream) {
+    if (p.mask_kind != MK_F16) return hipErrorInvalidValue;
+    MaskPackArgs a;
+    uint32_t *list, *cnt, nqb;
+    uint64_t slabs;
+    if (hipError_t e = mask_pack_prepare(p, scratch, a, list, cnt, nqb, slabs); e != hipSuccess) return e;
+    p.mk_bits = nullptr;
+    hipLaunchKernelGGL(mask_classify_f16_kernel, dim3((unsigned)((a.total + 3) / 4)), dim3(256), 0, stream, a);
+    a.done = true;  // (no bit image to pack)
     return mask_pack_finish(a, list, cnt, nqb, slabs, stream);
 }
 

@@ -24,68 +24,9 @@
 #include <cstdlib>
 #include <type_traits>
 
-#include "fa_common.h"
-#include "fa_fwd_16_kernel.h"
-#include "kernels.h"
+#include "fa_fwd16_w64_params.h"
 
 namespace umfa {
-
-struct W64Params {
-    const void* q;
-    const void* k;
-    const void* v;
-    void* o;
-    float* lse;
-    int64_t qs[3], ks[3], vs[3];  // batch, head, seq strides in elements (head_dim contiguous)
-    uint32_t B, H, Sq, Skv;
-    float scale;
-    uint32_t n_items, T;  // items = B*H*(Sq/256) blocks of 256 query rows; T = Skv/64 key tiles per item
-    float* part_buf;      // [2 * grid slots][wave 4][q-block 2][chunk 17][lane 64] x 16 bytes (see the kernel)
-    uint32_t* part_cnt;   // [n_items % grid] arrival tickets, zero between launches (the folding part resets its own)
-    float tau;            // deferred-max threshold (log2 units)
-    uint32_t lazy;        // bf16 kernels: lazy reference mode (no row max after a segment's first tile; see the kernel)
-    uint32_t skew;        // tiles moved from the folding part of a two-way cut item to the publishing part (see the kernel)
-    uint32_t Tw;          // WINDOW kernels: key tiles per item (the band of a 256-row block), <= T
-    int32_t win_left, win_right;  // WINDOW kernels: key attends iff row - win_left <= key <= row + win_right
-    const float* rope_cos;  // fused rotary embedding of Q (FwdParams::rope_*), NULL = none
-    const float* rope_sin;
-    int64_t rope_tb;
-    const uint32_t* mk_bits;  // MASKT kernels: the packed bool mask (FwdParams::mk_*, fa_aux.hip mask_pack_kernel)
-    const uint32_t* mk_list;
-    const uint32_t* mk_cnt;
-    uint32_t mk_bs, mk_hs, mk_nrb64;
-    const uint32_t* mk_prefix;  // [n_items % grid + 1] running sums of the shared blocks' list lengths (fa_aux.hip mask_prefix_kernel)
-    const float* vsc;         // bf16pv16 kernels: 2^e of the V image's slabs (FwdParams::vsc), slab (b, h) at vsc[128 (b vsc_bs + h vsc_hs) + 65]
-    uint32_t vsc_bs, vsc_hs;
-};
-
-// ---- asm-owned accumulator registers: helpers with literal register numbers (generated)
-#include "fa_fwd16_w64_regs.inc"
-
-// int8 K tile image: rows of 128 bytes, 16-byte chunks XOR-swizzled for conflict-free ds_read_b128 (same rule as
-// fa_quant.hip k8_off<128>)
-__device__ __forceinline__ constexpr int k8_off_128(int row, int ch) { return row * 128 + 16 * (ch ^ ((row >> 1) & 7)); }
-
-struct W64I8Params {
-    const int8_t* q8;       // [B*H*Sq][128] int8 (quantiser workspace)
-    const int8_t* k8;       // [B*H*Skv][128]
-    const _Float16* v16;    // [B*H*Skv][128] fp16, de-quantised
-    const uint8_t* v8;      // fp8 variant: [B*H][tile][8192] e4m3 in MFMA operand order (fa_quant.hip)
-    const uint32_t* v_e8;   // fp8 variant: [B*H][nkblk] E8M0 scale byte of the tile, replicated in the four bytes
-    const float* q_scale;   // [B*H][nqblk], one per 64 rows
-    const float* k_scale;   // [B*H][nkblk]
-    void* o;                // fp32 [B,H,Sq,128]
-    float* lse;
-    uint32_t B, H, Sq, Skv, nqblk, nkblk;
-    float scale;
-    uint32_t n_items, T;
-    float* part_buf;
-    uint32_t* part_cnt;
-    float tau;
-    uint32_t lazy;          // lazy reference mode (fp16 P thresholds; the fp8 variant has no lazy bodies and ignores it)
-    uint32_t skew;
-    const float* vsc;       // slab headers of the fp16 V image q * s * 2^-e (fa_quant.hip QuantParams::vhdr): 2^e in word 65 of slab bh; NULL = 1
-};
 
 #define W64_I8 0
 #define W64_BODY_INC "fa_fwd16_w64_body.inc"
@@ -386,7 +327,23 @@ double fwd_16_predict_us(const FwdParams& p) {
 
 bool fwd_w64_supported(const FwdParams& p) {
     if (tuning().no_w64.load(std::memory_order_relaxed) || !fwd_16_supported(p)) return false;
-    if ((p.D != 128 && p.D != 64) || (p.mask_kind != MK_NONE && p.mask_kind != MK_WINDOW && p.mask_kind != MK_BOOL)) return false;
+    if ((p.D != 128 && p.D != 64) || (p.mask_kind != MK_NONE && p.mask_kind != MK_WINDOW && p.mask_kind != MK_BOOL && p.mask_kind != MK_F16)) return false;
+    if (p.mask_kind == MK_F16) {
+        // ADDITIVE fp16 mask tensors (MASKA instantiations, round 6; the reference's additive masks: MFABridge.swift:157-242): head_dim 128, the fp16-P-V
+        // families, no causal flag / rotation on top; the wave's mask tile comes by LDS-DMA straight from the caller's tensor, so: keys contiguous,
+        // 16-byte aligned rows, Sq and Skv whole 64-row / 64-key tiles; at least one 256-row block per CU (whole blocks in rounds + a shared remainder,
+        // as for bool masks).  Everything else (bf16 / fp32 masks, ragged shapes, few blocks) stays on the 128-row kernel.
+        if (tuning().no_w64_mask.load(std::memory_order_relaxed) || tuning().no_w64_bias.load(std::memory_order_relaxed) || !p.mask || p.D != 128 || p.rope_cos || p.causal) return false;
+        if (p.in_prec == P_BF16 && !p.pv16) return false;
+        if (p.Sq < 256 || p.Sq % 64 != 0 || p.Skv % 64 != 0 || ((p.Skv + 63) / 64) > 1024u) return false;
+        if (p.out_prec != P_FP32 && p.out_prec != p.in_prec) return false;
+        if (p.ms[3] != 1 || ((uintptr_t)p.mask & 15) != 0 || (p.ms[0] & 7) != 0 || (p.ms[1] & 7) != 0 || (p.ms[2] & 7) != 0) return false;
+        if (p.ms[2] != 0 && (uint64_t)p.ms[2] * 2 * 64 > 0x7fffffffull) return false;  // (a wave's 64 rows behind one 32-bit descriptor)
+        if (w64_grid(p) > 512u) return false;
+        if (tuning().force_w64.load(std::memory_order_relaxed)) return true;
+        const uint64_t blocks = (uint64_t)p.B * p.H * ((p.Sq + 255) / 256), cus = (uint64_t)w64_cu_count();
+        return blocks >= cus;
+    }
     if (p.mask_kind == MK_BOOL) {
         // bool mask tensors (MASKT instantiations): head_dim 128 and (round 5) 64, the fp16-P-V families (bf16 operands by default, fp16 operands), no
         // rotation on top (a causal flag is folded into the packed mask); whole items per workgroup, so at least one item per CU
@@ -444,7 +401,7 @@ bool fwd_w64_supported(const FwdParams& p) {
 }
 
 static uint32_t w64_grid(const FwdParams& p) {
-    if (p.mask_kind == MK_BOOL) {  // mask tensors: one workgroup per CU at most; whole blocks in rounds, the last n % grid blocks cut along their tile lists
+    if (p.mask_kind == MK_BOOL || p.mask_kind == MK_F16) {  // mask tensors: one workgroup per CU at most; whole blocks in rounds, the last n % grid blocks cut along their tile lists
         const uint64_t items = (uint64_t)p.B * p.H * ((p.Sq + 255) / 256);
         const uint64_t cus = (uint64_t)w64_cu_count();
         if (const int gi = tuning().w64_grid.load(std::memory_order_relaxed)) {  // lab / tests: force the number of workgroups
@@ -521,15 +478,20 @@ hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cn
     wp.vsc = p.vsc; wp.vsc_bs = p.vsc_bs; wp.vsc_hs = p.vsc_hs;
     if (p.in_prec == P_BF16 && p.pv16 && !p.vsc) return hipErrorInvalidValue;  // the fp16 image of V comes with its slab exponents (runtime.hip)
     wp.Tw = wp.T; wp.win_left = wp.win_right = 0;
-    const bool rope = p.rope_cos != nullptr, window = w64_is_window(p), fp32o = p.out_prec == P_FP32, maskt = p.mask_kind == MK_BOOL;
+    const bool rope = p.rope_cos != nullptr, window = w64_is_window(p), fp32o = p.out_prec == P_FP32, maska = p.mask_kind == MK_F16, maskt = p.mask_kind == MK_BOOL || maska;
+    wp.mask = nullptr; wp.mask_s[0] = wp.mask_s[1] = wp.mask_s[2] = 0;
     if (maskt) {
-        if (!p.mk_bits || !p.mk_list || !p.mk_cnt) return hipErrorInvalidValue;  // runtime.hip packs the mask first (launch_mask_pack)
+        if ((!maska && !p.mk_bits) || !p.mk_list || !p.mk_cnt) return hipErrorInvalidValue;  // runtime.hip packs / classifies the mask first (launch_mask_pack, launch_mask_classify)
+        if (maska) { wp.mask = p.mask; wp.mask_s[0] = p.ms[0]; wp.mask_s[1] = p.ms[1]; wp.mask_s[2] = p.ms[2]; }
         wp.mk_bits = p.mk_bits; wp.mk_list = p.mk_list; wp.mk_cnt = p.mk_cnt;
         wp.mk_bs = p.mk_bs; wp.mk_hs = p.mk_hs; wp.mk_nrb64 = p.mk_nrb64;
         wp.mk_prefix = p.mk_prefix;
         // the max chain, unless the mask has no row dimension (key padding: a listed tile holds a key for every row, the lazy bodies are as safe as
         // without a mask); with one, which rows have keys in a segment is not arithmetic
 #ifndef W64_LAB_MASK_FORCE_LAZY  // (lab, timing only -- NOT safe for masks with a row dimension in general: what would the lazy bodies buy a mask whose listed tiles are all open?)
+        // (additive masks: the same rule -- a mask without a row dimension gives every row of a block the same keys in every listed tile, whatever the values;
+        // with one, finite terms move a row's reference tile by tile and a steep bias would overflow the lazy bodies' stale reference segment after segment:
+        // the max chain follows them)
         if (p.ms[2] != 0 || p.causal || tuning().no_w64_mask_lazy.load(std::memory_order_relaxed)) wp.lazy = 0;
 #endif
     }
@@ -563,7 +525,12 @@ hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cn
     if (p.D == 64 && rope) return hipErrorNotSupported;
     const int fam = p.in_prec == P_BF16 ? (p.pv16 ? 1 : 0) : 2;
     if (maskt && fam == 0) return hipErrorNotSupported;
-    *name = maskt ? (p.D == 64 ? (fam == 1 ? "fa_fwd16_w64<bf16,64,pv16,mask>" : "fa_fwd16_w64<fp16,64,mask>")
+    if (maska && (p.D != 128 || fam == 0)) return hipErrorNotSupported;
+    if (maska) {  // the additive-mask families: a translation unit of their own (generated bodies of their own)
+        *name = fam == 1 ? "fa_fwd16_w64<bf16,128,pv16,bias>" : "fa_fwd16_w64<fp16,128,bias>";
+        return launch_fwd_w64_bias(wp, fam, fp32o, w64_grid(p), 65536 + 4 * 32 * (512 + 16) + 64 + 4096 + 8192 + 2048 + 64, stream);
+    }
+    *name = maska ? (fam == 1 ? "fa_fwd16_w64<bf16,128,pv16,bias>" : "fa_fwd16_w64<fp16,128,bias>") : maskt ? (p.D == 64 ? (fam == 1 ? "fa_fwd16_w64<bf16,64,pv16,mask>" : "fa_fwd16_w64<fp16,64,mask>")
                                : (fam == 1 ? "fa_fwd16_w64<bf16,128,pv16,mask>" : "fa_fwd16_w64<fp16,128,mask>"))
                   : names[fam][p.D == 64 ? 1 : 0][rope ? 1 : window ? 2 : 0];
     if (p.D == 64) {
