@@ -69,9 +69,10 @@ KINDS = ["rel_pos", "per_head", "random", "blockdiag_inf", "padding_row_broadcas
 
 
 @pytest.mark.parametrize("kind", KINDS)
-@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("dt,mdt", [(torch.bfloat16, torch.float16), (torch.float16, torch.float16), (torch.bfloat16, torch.bfloat16)])
 @pytest.mark.parametrize("shape,grid", [((2, 2, 512, 512), 0), ((1, 3, 1280, 768), 0), ((1, 3, 1280, 1408), 4), ((2, 2, 512, 512), 3)])
-def test_w64_additive_mask_vs_oracle(kind, dt, shape, grid, umfa_opts):
+def test_w64_additive_mask_vs_oracle(kind, dt, mdt, shape, grid, umfa_opts):
+    """mdt = bfloat16: the mask as a bf16 model has it -- the classification pass writes the fp16 copy the kernel reads (exact where fp16 holds the value)"""
     import umfa_torch
     umfa_opts(force_w64=1)
     if grid:
@@ -83,6 +84,12 @@ def test_w64_additive_mask_vs_oracle(kind, dt, shape, grid, umfa_opts):
     k = torch.randn(B, H, Skv, D, device="cuda", dtype=dt)
     v = torch.randn(B, H, Skv, D, device="cuda", dtype=dt)
     m = _bias(kind, B, H, Sq, Skv, seed=Sq)
+    if mdt != torch.float16:
+        m = m.to(mdt) if m.is_contiguous() else m.to(mdt)  # (same values rounded to bf16; a strided view stays a strided view of a wider tensor)
+        if kind == "strided_rows":
+            wide = torch.zeros(m.shape[0], 1, Sq, 2 * Skv, device="cuda", dtype=mdt)
+            wide[..., :Skv] = m
+            m = wide[..., :Skv]
     o, lse = umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32, return_lse=True)
     kern = umfa_torch.last_kernel()
     assert kern in ("fa_fwd16_w64<bf16,128,pv16,bias>", "fa_fwd16_w64<fp16,128,bias>"), kern
@@ -110,8 +117,8 @@ def test_w64_additive_mask_vs_oracle(kind, dt, shape, grid, umfa_opts):
 
 
 def test_w64_additive_mask_routing_and_what_stays_on_the_128_row_kernel(umfa_opts):
-    """the route's conditions (fwd_w64_supported): fp16 masks with 16-byte aligned rows on whole tiles take the bias kernel by default from one
-    256-row block per CU on; bf16 / fp32 masks, ragged shapes, unaligned rows and causal + bias keep the 128-row kernel -- same answers either way"""
+    """the route's conditions (fwd_w64_supported): fp16 and bf16 masks with 16-byte aligned rows on whole tiles take the bias kernel by default from one
+    256-row block per CU on; fp32 masks, ragged shapes, unaligned rows and causal + bias keep the 128-row kernel -- same answers either way"""
     import umfa_torch
     torch.manual_seed(5)
     B, H, S, D = 1, 72, 1024, 128  # 288 blocks >= 256 CUs
@@ -122,7 +129,7 @@ def test_w64_additive_mask_routing_and_what_stays_on_the_128_row_kernel(umfa_opt
     for name, m in (("f16", bias.to(torch.float16)), ("bf16", bias.to(torch.bfloat16)), ("f32", bias.clone())):
         o[name] = umfa_torch.attention_forward(q, k, v, mask=m.contiguous(), out_dtype=torch.float32)
         kern = umfa_torch.last_kernel()
-        assert ("bias" in kern) == (name == "f16"), (name, kern)
+        assert ("bias" in kern) == (name in ("f16", "bf16")), (name, kern)
     # (the three masks hold the same numbers up to their own rounding of -|i - j| / 128)
     assert float((o["f16"] - o["f32"]).abs().max()) < 2e-3 * float(o["f32"].abs().max())
     assert float((o["bf16"] - o["f32"]).abs().max()) < 1e-2 * float(o["f32"].abs().max())

@@ -981,11 +981,15 @@ hipError_t launch_mask_pack(FwdParams& p, void* scratch, hipStream_t stream) {
     return mask_pack_finish(a, list, cnt, nqb, slabs, stream);
 }
 
-// ---- additive fp16 masks on the one-wave-per-SIMD structure (MASKA, round 6): tile classes only -- the kernel DMAs the caller's tensor itself.
+// ---- additive fp16 / bf16 masks on the one-wave-per-SIMD structure (MASKA, round 6): tile classes only -- the kernel DMAs the mask tensor itself.
 // One wave per (mask batch, mask head, 64-row block, 64-key tile): a lane owns one 16-byte segment (8 keys) of a row, a wave-load covers 8 rows, 8 loads
-// the tile.  class 1 = every element -inf (the wave skips nothing but lists skip the tile when all four waves say so), 2 = every element +-0 (the plain
-// tile body, no mask read), 0 = mixed.  Preconditions (fwd_w64_supported): Sq, Skv multiples of 64, keys contiguous, 16-byte aligned rows.
-__global__ __launch_bounds__(256) void mask_classify_f16_kernel(MaskPackArgs p) {
+// the tile.  class 1 = every element -inf (a tile all four waves of a block call masked is never listed), 2 = every element +-0 (the plain tile
+// body, no mask read), 0 = mixed.  Preconditions (fwd_w64_supported): Sq, Skv multiples of 64, keys contiguous, 16-byte aligned rows.
+// BF16: the mask is bf16 -- the same pass writes the dense fp16 copy the attention kernel reads instead (v_fma_mix_f32 takes f16 halves): exact for every
+// value fp16 holds (bf16's 8-bit significands fit), finite values beyond +-65504 clamped there (exp(x - max) of such a term is 0 or the row's only
+// survivor either way), magnitudes below 2^-24 flushed (e^x = 1 to fp32 precision), -inf / NaN kept.
+template <bool BF16>
+__global__ __launch_bounds__(256) void mask_classify_kernel(MaskPackArgs p, _Float16* copy, int64_t cb, int64_t ch, int64_t cr) {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t wid = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wid >= p.total) return;
@@ -993,10 +997,29 @@ __global__ __launch_bounds__(256) void mask_classify_f16_kernel(MaskPackArgs p) 
     const uint32_t rb = (uint32_t)((wid / p.T) % p.nrb64);
     const uint32_t slab = (uint32_t)(wid / ((uint64_t)p.T * p.nrb64));
     const uint32_t hm = slab % p.Hm, bm = slab / p.Hm;
-    const char* base = (const char*)p.mask + ((int64_t)bm * p.ms[0] + (int64_t)hm * p.ms[1] + (int64_t)(rb * 64 + (lane >> 3)) * p.ms[2] + tile * 64 + (lane & 7) * 8) * 2;
+    const uint32_t row0 = rb * 64 + (lane >> 3), key0 = tile * 64 + (lane & 7) * 8;
+    const char* base = (const char*)p.mask + ((int64_t)bm * p.ms[0] + (int64_t)hm * p.ms[1] + (int64_t)row0 * p.ms[2] + key0) * 2;
     u32x4_t w[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) w[i] = *(const u32x4_t*)(base + (int64_t)(8 * i) * p.ms[2] * 2);
+    if constexpr (BF16) {
+        const bool writer = p.ms[2] != 0 || rb == 0;  // (a mask without a row dimension: ONE row in the copy, written by the wave of row block 0 -- its lanes 0 ... 7)
+        _Float16* dst = copy + (int64_t)bm * cb + (int64_t)hm * ch + (int64_t)row0 * cr + key0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float lo = __uint_as_float(w[i][j] << 16), hi = __uint_as_float(w[i][j] & 0xffff0000u);
+                auto cv = [](float x) -> uint32_t {
+                    const float c = fabsf(x) <= 65504.0f ? x : (x > 0.0f ? 65504.0f : -65504.0f);  // (inf and NaN fail the first test too ...)
+                    const _Float16 h = (_Float16)((x != x || fabsf(x) == INFINITY) ? x : c);     // ... and are kept as they are
+                    return (uint32_t)__builtin_bit_cast(uint16_t, h);
+                };
+                w[i][j] = cv(lo) | (cv(hi) << 16);
+            }
+            if (writer && (p.ms[2] != 0 || (i == 0 && lane < 8))) *(u32x4_t*)(dst + (int64_t)(8 * i) * cr) = w[i];
+        }
+    }
     bool any_open = false, any_term = false;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -1010,14 +1033,34 @@ __global__ __launch_bounds__(256) void mask_classify_f16_kernel(MaskPackArgs p) 
     if (lane == 0) p.wflag[wid] = !open ? 1 : (!term ? 2 : 0);
 }
 
+// bytes of the dense fp16 copy of a bf16 additive mask (0 for fp16 masks): [Bm, Hm, Sq or 1, Skv]
+size_t mask_copy_bytes(const FwdParams& p) {
+    if (p.mask_kind != MK_BF16) return 0;
+    const uint64_t Bm = p.ms[0] ? p.B : 1, Hm = p.ms[1] ? p.H : 1, Sm = p.ms[2] ? p.Sq : 1;
+    return (size_t)((Bm * Hm * Sm * p.Skv * 2 + 255) & ~255ull);
+}
+
+// scratch = [the pack layout of mask_pack_bytes | the fp16 copy of a bf16 mask].  On return p describes what the attention kernel reads: an fp16 mask.
 hipError_t launch_mask_classify(FwdParams& p, void* scratch, hipStream_t stream) {
-    if (p.mask_kind != MK_F16) return hipErrorInvalidValue;
+    if (p.mask_kind != MK_F16 && p.mask_kind != MK_BF16) return hipErrorInvalidValue;
+    const bool bf = p.mask_kind == MK_BF16;
+    const size_t pack_bytes = (mask_pack_bytes(p) + 255) & ~(size_t)255;
     MaskPackArgs a;
     uint32_t *list, *cnt, nqb;
     uint64_t slabs;
+    if (bf) p.mask_kind = MK_F16;  // (the layout of the pack area does not depend on the kind; mask_pack_prepare takes bool / fp16)
     if (hipError_t e = mask_pack_prepare(p, scratch, a, list, cnt, nqb, slabs); e != hipSuccess) return e;
     p.mk_bits = nullptr;
-    hipLaunchKernelGGL(mask_classify_f16_kernel, dim3((unsigned)((a.total + 3) / 4)), dim3(256), 0, stream, a);
+    const unsigned grid = (unsigned)((a.total + 3) / 4);
+    if (bf) {
+        _Float16* copy = (_Float16*)((char*)scratch + pack_bytes);
+        const int64_t Sm = p.ms[2] ? p.Sq : 1, cr = p.ms[2] ? (int64_t)p.Skv : 0, chd = Sm * p.Skv, cbt = (int64_t)a.Hm * chd;
+        hipLaunchKernelGGL(mask_classify_kernel<true>, dim3(grid), dim3(256), 0, stream, a, copy, cbt, chd, cr);
+        p.mask = copy;
+        p.ms[0] = p.ms[0] ? cbt : 0; p.ms[1] = p.ms[1] ? chd : 0; p.ms[2] = cr; p.ms[3] = 1;
+    } else {
+        hipLaunchKernelGGL(mask_classify_kernel<false>, dim3(grid), dim3(256), 0, stream, a, (_Float16*)nullptr, 0, 0, 0);
+    }
     a.done = true;  // (no bit image to pack)
     return mask_pack_finish(a, list, cnt, nqb, slabs, stream);
 }

@@ -327,8 +327,8 @@ double fwd_16_predict_us(const FwdParams& p) {
 
 bool fwd_w64_supported(const FwdParams& p) {
     if (tuning().no_w64.load(std::memory_order_relaxed) || !fwd_16_supported(p)) return false;
-    if ((p.D != 128 && p.D != 64) || (p.mask_kind != MK_NONE && p.mask_kind != MK_WINDOW && p.mask_kind != MK_BOOL && p.mask_kind != MK_F16)) return false;
-    if (p.mask_kind == MK_F16) {
+    if ((p.D != 128 && p.D != 64) || (p.mask_kind != MK_NONE && p.mask_kind != MK_WINDOW && p.mask_kind != MK_BOOL && p.mask_kind != MK_F16 && p.mask_kind != MK_BF16)) return false;
+    if (p.mask_kind == MK_F16 || p.mask_kind == MK_BF16) {
         // ADDITIVE fp16 mask tensors (MASKA instantiations, round 6; the reference's additive masks: MFABridge.swift:157-242): head_dim 128, the fp16-P-V
         // families, no causal flag / rotation on top; the wave's mask tile comes by LDS-DMA straight from the caller's tensor, so: keys contiguous,
         // 16-byte aligned rows, Sq and Skv whole 64-row / 64-key tiles; at least one 256-row block per CU (whole blocks in rounds + a shared remainder,
@@ -339,6 +339,8 @@ bool fwd_w64_supported(const FwdParams& p) {
         if (p.out_prec != P_FP32 && p.out_prec != p.in_prec) return false;
         if (p.ms[3] != 1 || ((uintptr_t)p.mask & 15) != 0 || (p.ms[0] & 7) != 0 || (p.ms[1] & 7) != 0 || (p.ms[2] & 7) != 0) return false;
         if (p.ms[2] != 0 && (uint64_t)p.ms[2] * 2 * 64 > 0x7fffffffull) return false;  // (a wave's 64 rows behind one 32-bit descriptor)
+        // bf16 masks: the classification pass also writes the dense fp16 copy the kernel reads (bf16's significands fit fp16's; fa_aux.hip) -- up to 1 GiB of it
+        if (p.mask_kind == MK_BF16 && mask_copy_bytes(p) > ((size_t)1 << 30)) return false;
         if (w64_grid(p) > 512u) return false;
         if (tuning().force_w64.load(std::memory_order_relaxed)) return true;
         const uint64_t blocks = (uint64_t)p.B * p.H * ((p.Sq + 255) / 256), cus = (uint64_t)w64_cu_count();
@@ -401,7 +403,7 @@ bool fwd_w64_supported(const FwdParams& p) {
 }
 
 static uint32_t w64_grid(const FwdParams& p) {
-    if (p.mask_kind == MK_BOOL || p.mask_kind == MK_F16) {  // mask tensors: one workgroup per CU at most; whole blocks in rounds, the last n % grid blocks cut along their tile lists
+    if (p.mask_kind == MK_BOOL || p.mask_kind == MK_F16 || p.mask_kind == MK_BF16) {  // mask tensors: one workgroup per CU at most; whole blocks in rounds, the last n % grid blocks cut along their tile lists
         const uint64_t items = (uint64_t)p.B * p.H * ((p.Sq + 255) / 256);
         const uint64_t cus = (uint64_t)w64_cu_count();
         if (const int gi = tuning().w64_grid.load(std::memory_order_relaxed)) {  // lab / tests: force the number of workgroups

@@ -168,9 +168,10 @@ hipError_t launch_fwd_w64_i8(const FwdParams& p, const QuantViews& v, float* par
 // bool mask -> per-lane bit words + visited-tile lists for fa_fwd16_w64's MASKT instantiations (fa_aux.hip); fills p.mk_*
 size_t mask_pack_bytes(const FwdParams& p);
 hipError_t launch_mask_pack(FwdParams& p, void* scratch, hipStream_t stream);
-// additive fp16 mask -> per-wave tile classes + visited-tile lists for fa_fwd16_w64's MASKA instantiations (same scratch layout as the bool pack, no
+// additive fp16 / bf16 mask -> per-wave tile classes + visited-tile lists for fa_fwd16_w64's MASKA instantiations (same scratch layout as the bool pack, no
 // bit image: the kernel reads the caller's tensor itself); fills p.mk_list / mk_cnt / mk_bs / mk_hs / mk_nrb64
 hipError_t launch_mask_classify(FwdParams& p, void* scratch, hipStream_t stream);
+size_t mask_copy_bytes(const FwdParams& p);  // bf16 masks: the dense fp16 copy the kernel reads, behind the pack area (256-byte aligned) in the same scratch block
 // the V cast pass and the mask re-pack as ONE launch (the pack's workgroups behind the cast's), then the list kernel
 hipError_t launch_cast_rows_and_mask_pack(const void* src, const int64_t* strides, void* dst, uint32_t B, uint32_t H, uint32_t S, uint32_t D,
                                           uint32_t* hdr, FwdParams& p, void* mask_scratch, hipStream_t stream);

@@ -118,8 +118,9 @@ hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p,
         // and the visited-tile list of every 256-row block (fa_aux.hip mask_pack_kernel); the kernel then never stages a tile no row
         // of the block attends to and reads no mask bytes at all.  Every block this family needs is asked for BEFORE anything is
         // launched: a call that cannot have them (capture without a warm-up) goes to the 128-row kernel untouched.
-        const bool mask_w64 = pw.mask_kind == MK_BOOL || pw.mask_kind == MK_F16;  // (MK_F16: additive, classified only -- fa_aux.hip launch_mask_classify)
-        void* mk = mask_w64 ? sc.mflags.ensure(mask_pack_bytes(pw), stream) : nullptr;
+        const bool mask_add = pw.mask_kind == MK_F16 || pw.mask_kind == MK_BF16;  // additive: classified only (+ a bf16 mask's fp16 copy) -- fa_aux.hip launch_mask_classify
+        const bool mask_w64 = pw.mask_kind == MK_BOOL || mask_add;
+        void* mk = mask_w64 ? sc.mflags.ensure(((mask_pack_bytes(pw) + 255) & ~(size_t)255) + mask_copy_bytes(pw), stream) : nullptr;
         bool ok = !mask_w64 || mk != nullptr;
         const FwdW64Plan plan = fwd_w64_plan(pw);
         char* w64 = ok ? sc.ensure_w64(plan.cnt_bytes, plan.buf_bytes, stream) : nullptr;
@@ -131,7 +132,7 @@ hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p,
             packed = ok && mk != nullptr && pw.mask_kind == MK_BOOL;
         }
         if (ok) {
-            if (mk && !packed && (e = (pw.mask_kind == MK_F16 ? launch_mask_classify(pw, mk, stream) : launch_mask_pack(pw, mk, stream))) != hipSuccess) return e;
+            if (mk && !packed && (e = (mask_add ? launch_mask_classify(pw, mk, stream) : launch_mask_pack(pw, mk, stream))) != hipSuccess) return e;
             e = launch_fwd_w64(pw, (float*)(w64 + sc.w64_cnt_bytes), (uint32_t*)w64, stream, &name);
             done = true;
         } else if (p.rope_cos || !fwd_16_supported(p)) {
