@@ -48,7 +48,8 @@ class Lib:
         B, H, Sq, D = q.shape
         prec = {torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}
         m = Lib.mask
-        margs = (None, None, None, 0, 0, 0) if m is None else (ctypes.c_void_p(m.data_ptr()), i64(m.shape), i64(m.stride()), m.dim(), 1, 0)
+        margs = (None, None, None, 0, 0, 0) if m is None else (ctypes.c_void_p(m.data_ptr()), i64(m.shape), i64(m.stride()), m.dim(), 1 if m.dtype == torch.bool else 2,
+                                                          {torch.bool: 0, torch.float16: 1, torch.bfloat16: 2, torch.float32: 3}[m.dtype])
         rc = self.lib.umfa_attention_forward_stream(
             self.ctx, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream),
             ctypes.c_void_p(q.data_ptr()), i64(q.stride()), ctypes.c_void_p(k.data_ptr()), i64(k.stride()),
@@ -79,7 +80,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=12)
     ap.add_argument("--inner", type=int, default=20)
     ap.add_argument("--parity", action="store_true")
-    ap.add_argument("--mask", default="", help="blockdiag | padding | window_tensor | random | alltrue_keys | alltrue_2d: a bool mask tensor on every forward")
+    ap.add_argument("--mask", default="", help="blockdiag | padding | window_tensor | random | alltrue_keys | alltrue_2d: a bool mask tensor on every forward; bias | bias_per_head: an additive fp16 one")
     ap.add_argument("--graph", action="store_true", help="time hipGraph replays of `inner` launches (short kernels: the Python launch path is not what is measured)")
     ap.add_argument("--quant", type=int, default=0, help="2 / 3: time umfa_quantized_forward_stream with that quant_mode (fp32 O)")
     ap.add_argument("libs", nargs="+")
@@ -96,6 +97,8 @@ def main():
                     "window_tensor": lambda: ((i_[:, None] - i_[None, :]).abs() <= 512)[None, None].contiguous(),
                     "alltrue_keys": lambda: torch.ones(1, 1, 1, S, dtype=torch.bool, device="cuda"),
                     "alltrue_2d": lambda: torch.ones(1, 1, S, S, dtype=torch.bool, device="cuda"),
+                    "bias": lambda: (-(i_[:, None] - i_[None, :]).abs().to(torch.float16) / 256.0)[None, None].contiguous(),  # additive fp16, every tile mixed
+                    "bias_per_head": lambda: (-(i_[:, None] - i_[None, :]).abs().float()[None] / (64.0 * (1 + torch.arange(H, device="cuda")[:, None, None]))).to(torch.float16)[None].contiguous(),
                     "random": lambda: torch.rand(1, H, S, S, device="cuda") > 0.5}[a.mask]()
     libs = [Lib(*s.split("=", 1)) for s in a.libs]
     if a.quant:
