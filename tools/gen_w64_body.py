@@ -263,7 +263,11 @@ def op_text(R, op):
         c = 32 * kb - 32 * qb + (r & 3) + 8 * (r >> 2)
         one = (f'asm volatile("v_cmp_lt_i32 vcc, {-c}, %0\\n\\tv_cndmask_b32 v{v}, v{v}, %1, vcc" :: "v"(dmask[{qb}]), "v"(neg_inf) : "vcc");')
         if C.i8:
-            return one
+            if C.f8:
+                return one
+            # (round 6) bool mask tensors on the int8 kernel: the bit form of the 16-bit kernels (the biased integer score, a float, or -inf)
+            mt8 = (f'asm volatile("v_bfe_i32 %0, %1, {16 * kb + r}, 1\\n\\tv_bfi_b32 v{v}, %0, v{v}, %2" : "=&v"(mtmp) : "v"(mwc[{qb}]), "v"(neg_inf));')
+            return f'if constexpr (MASKT) {{ {mt8} }} else {{ {one} }}'
         # sliding-window instantiations (WINDOW): the other band edge as well, score masked <=> dleft + c < 0
         two = (f'asm volatile("v_cmp_lt_i32 vcc, {-c}, %0\\n\\tv_cndmask_b32 v{v}, v{v}, %1, vcc\\n\\tv_cmp_gt_i32 vcc, {-c}, %2\\n\\t'
                f'v_cndmask_b32 v{v}, v{v}, %1, vcc" :: "v"(dmask[{qb}]), "v"(neg_inf), "v"(dleft) : "vcc");')

@@ -27,7 +27,7 @@ def main():
     src_dir = Path(a.src_dir)
     extra = a.extra.split()
     mk = (CSRC / "Makefile").read_text()
-    m = re.search(r"build/%s: EXTRA \+= (.*)" % re.escape(Path(a.source).stem + ".o"), mk)
+    m = re.search(r"^(?:build/\S+\.o )*build/%s(?: build/\S+\.o)*: EXTRA \+= (.*)" % re.escape(Path(a.source).stem + ".o"), mk, re.M)  # (a rule may name several objects)
     if m:
         extra += m.group(1).split()
     with tempfile.TemporaryDirectory() as td:

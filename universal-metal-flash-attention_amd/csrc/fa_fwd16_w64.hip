@@ -548,10 +548,20 @@ hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cn
 
 // ---- runtime-quantised variant ---------------------------------------------------------------------------------
 bool fwd_w64_i8_supported(const FwdParams& p) {
-    if (tuning().no_w64.load(std::memory_order_relaxed) || p.D != 128 || p.mask_kind != MK_NONE || p.mask) return false;
+    if (tuning().no_w64.load(std::memory_order_relaxed) || p.D != 128) return false;
     if (!(p.scale > 0.0f)) return false;
     if (p.Skv < 64 || p.Sq < 256 || (p.Sq % 256 != 0 && p.Sq < 1024)) return false;
-    return true;
+    if (p.mask_kind == MK_BOOL && p.mask) {
+        // (round 6) a bool mask tensor the caller handed over as it is (umfa_quantized_forward_masked_stream, MFABridge+Quantized.swift:227-358 with
+        // mfa_prepare_mask's semantics): the MASKT instantiation of the int8 kernel -- packed bits, tile classes, block lists as on the 16-bit kernels.
+        // The 16-bit route's shape rules (fwd_w64_supported): one 256-row block per CU, or a mask with a batch / head dimension of its own from 3/8
+        if (tuning().no_w64_mask.load(std::memory_order_relaxed) || p.causal) return false;
+        if (((p.Skv + 63) / 64) > 1024u || w64_grid(p) > 512u) return false;
+        if (tuning().force_w64.load(std::memory_order_relaxed)) return true;
+        const uint64_t blocks = (uint64_t)p.B * p.H * ((p.Sq + 255) / 256), cus = (uint64_t)w64_cu_count();
+        return blocks >= cus || (p.ms[2] == 0 && blocks * ((p.Skv + 63) / 64) >= cus * 10) || ((p.ms[0] != 0 || p.ms[1] != 0) && blocks * 8 >= cus * 3);
+    }
+    return p.mask_kind == MK_NONE && !p.mask;
 }
 
 hipError_t launch_fwd_w64_i8(const FwdParams& p, const QuantViews& v, float* part_buf, uint32_t* part_cnt, hipStream_t stream) {
@@ -571,10 +581,19 @@ hipError_t launch_fwd_w64_i8(const FwdParams& p, const QuantViews& v, float* par
     wp.skew = (uint32_t)tuning().w64_skew.load(std::memory_order_relaxed);
     wp.vsc = v.v8 ? nullptr : p.vsc;
     const uint32_t grid = w64_grid(p);
-    const size_t lds = 65536 + 4 * 32 * (512 + 16) + 16;
-    const bool f8 = v.v8 != nullptr;
+    const bool f8 = v.v8 != nullptr, maskt = p.mask_kind == MK_BOOL;
+    wp.mk_bits = wp.mk_list = wp.mk_cnt = nullptr; wp.mk_bs = wp.mk_hs = wp.mk_nrb64 = 0;
+    if (maskt) {
+        if (f8 || p.causal || !p.mk_bits || !p.mk_list || !p.mk_cnt) return hipErrorInvalidValue;  // the runtime packs the mask first (launch_mask_pack)
+        wp.mk_bits = p.mk_bits; wp.mk_list = p.mk_list; wp.mk_cnt = p.mk_cnt;
+        wp.mk_bs = p.mk_bs; wp.mk_hs = p.mk_hs; wp.mk_nrb64 = p.mk_nrb64;
+        if (p.ms[2] != 0 || tuning().no_w64_mask_lazy.load(std::memory_order_relaxed)) wp.lazy = 0;  // (a mask with a row dimension: the max chain, as on the 16-bit kernels)
+    }
+    // K / V rings + output staging + flag words (+ the mask instantiation's bit-word ring, tile list and shared-block running sums: launch_w64_kernel's figure)
+    const size_t lds = maskt ? 65536 + 4 * 32 * (512 + 16) + 64 + 4096 + 8192 + 2048 + 64 : 65536 + 4 * 32 * (512 + 16) + 16;
     auto kfn = f8 ? (p.causal ? fa_fwd_w64_i8f8<float, true> : fa_fwd_w64_i8f8<float, false>)
-                  : (p.causal ? fa_fwd_w64_i8<float, true> : fa_fwd_w64_i8<float, false>);
+                  : maskt ? fa_fwd_w64_i8<float, false, true>
+                          : (p.causal ? fa_fwd_w64_i8<float, true> : fa_fwd_w64_i8<float, false>);
     if (hipError_t e = ensure_dynamic_lds((const void*)kfn, lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256), lds, stream, wp);
     return hipGetLastError();

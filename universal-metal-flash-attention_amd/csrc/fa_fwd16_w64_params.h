@@ -65,6 +65,10 @@ struct W64I8Params {
     float tau;
     uint32_t lazy;          // lazy reference mode (fp16 P thresholds; the fp8 variant has no lazy bodies and ignores it)
     uint32_t skew;
+    const uint32_t* mk_bits;  // MASKT instantiation: the packed bool mask, as in W64Params (FwdParams::mk_*, fa_aux.hip mask_pack_kernel)
+    const uint32_t* mk_list;
+    const uint32_t* mk_cnt;
+    uint32_t mk_bs, mk_hs, mk_nrb64;
     const float* vsc;       // slab headers of the fp16 V image q * s * 2^-e (fa_quant.hip QuantParams::vhdr): 2^e in word 65 of slab bh; NULL = 1
 };
 

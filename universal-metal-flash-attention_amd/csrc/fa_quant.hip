@@ -997,7 +997,7 @@ hipError_t launch_quantized_fwd(const FwdParams& fp, int bits, int quant_mode, v
     if (!quantized_supported(fp.D)) return hipErrorInvalidValue;
     // quant_mode 3 (fp8 P V, opt-in): only the 64-rows-per-wave kernel implements it; every other case runs the
     // block-wise int8 path (mode 2), which is the more accurate of the two
-    if (quant_mode == 3 && !(bits == 8 && fp.part_buf && fp.part_cnt && fwd_w64_i8_supported(fp))) quant_mode = 2;
+    if (quant_mode == 3 && !(bits == 8 && fp.part_buf && fp.part_cnt && fwd_w64_i8_supported(fp) && !fp.mask)) quant_mode = 2;  // (no mask instantiation of the fp8 kernel)
     QuantViews v;
     // fp.vsc: the (device, stream) pool's slab headers (runtime: StreamScratch::ensure_v16) -- the fp16 V image goes in as q * s * 2^-e
     hipError_t e = launch_quantize(fp.q, fp.k, fp.v, fp.in_prec, fp.B, fp.H, fp.Sq, fp.Skv, fp.D, bits, quant_mode,
@@ -1010,7 +1010,8 @@ hipError_t launch_quantized_fwd(const FwdParams& fp, int bits, int quant_mode, v
     p.vsc = v.v8 ? nullptr : fp.vsc;
     p.o = (float*)fp.o; p.lse = fp.lse;
     p.mask = fp.mask;
-    if (fp.mask) {
+    const bool w64 = fp.part_buf && fp.part_cnt && fwd_w64_i8_supported(fp);  // (with a bool mask tensor: its MASKT instantiation, the runtime has packed the mask)
+    if (fp.mask && !w64) {
         // fp.mask_kind == MK_NONE with a mask: the reference ABI's dense fp32 additive [B, H, Sq, Skv]; else what the caller normalised (runtime.hip normalise_mask)
         FwdParams mp = fp;
         if (fp.mask_kind == MK_NONE) {
@@ -1033,8 +1034,8 @@ hipError_t launch_quantized_fwd(const FwdParams& fp, int bits, int quant_mode, v
     p.nqblk = v.nqblk; p.nkblk = v.nkblk;
     p.scale = fp.scale;
     const uint32_t dp = dp_of(fp.D);
-    if (fp.part_buf && fp.part_cnt && fwd_w64_i8_supported(fp)) {
-        *name = v.v8 ? "fa_fwd_w64_i8f8<128>" : bits == 4 ? "fa_fwd_w64_i4<128>" : "fa_fwd_w64_i8<128>";
+    if (w64) {
+        *name = v.v8 ? "fa_fwd_w64_i8f8<128>" : fp.mask ? (bits == 4 ? "fa_fwd_w64_i4<128,mask>" : "fa_fwd_w64_i8<128,mask>") : bits == 4 ? "fa_fwd_w64_i4<128>" : "fa_fwd_w64_i8<128>";
         return launch_fwd_w64_i8(fp, v, fp.part_buf, fp.part_cnt, stream);
     }
     if (dp == 64) { *name = bits == 4 ? "fa_fwd_i4<64>" : "fa_fwd_i8<64>"; return launch_i8_flags<64>(p, fp.causal, stream); }

@@ -287,10 +287,16 @@ static mfa_error_t quantized_forward_stream_impl(mfa_context_t context, void* st
     if (fwd_w64_i8_supported(p)) {
         const FwdW64Plan plan = fwd_w64_plan(p);
         StreamScratch& sc = ctx->pool(pool_dev, (hipStream_t)stream);
-        char* w64 = sc.ensure_w64(plan.cnt_bytes, plan.buf_bytes, (hipStream_t)stream);
-        if (!w64) return MFA_ERROR_MEMORY_ALLOCATION;
-        p.part_cnt = (uint32_t*)w64;
-        p.part_buf = (float*)(w64 + sc.w64_cnt_bytes);
+        // a bool mask tensor on the one-wave-per-SIMD int8 kernel (round 6): packed once per call like the 16-bit route's (runtime.hip dispatch_forward); a pool
+        // that may not grow (capture without a warm-up) leaves the call to fa_fwd_i8, which reads the mask in place
+        void* mk = p.mask_kind == MK_BOOL ? sc.mflags.ensure(mask_pack_bytes(p), (hipStream_t)stream) : nullptr;
+        char* w64 = (p.mask_kind != MK_BOOL || mk) ? sc.ensure_w64(plan.cnt_bytes, plan.buf_bytes, (hipStream_t)stream) : nullptr;
+        if (!w64 && p.mask_kind != MK_BOOL) return MFA_ERROR_MEMORY_ALLOCATION;
+        if (w64) {
+            if (mk && launch_mask_pack(p, mk, (hipStream_t)stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+            p.part_cnt = (uint32_t*)w64;
+            p.part_buf = (float*)(w64 + sc.w64_cnt_bytes);
+        }
     }
     {   // slab headers for the fp16 V image's power of two, see mfa_quantized_forward_with_lse
         char* vh = ctx->pool(pool_dev, (hipStream_t)stream).ensure_v16((size_t)B * H, 0, (hipStream_t)stream);
