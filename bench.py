@@ -452,8 +452,11 @@ def run_rank(args) -> None:
         _i = torch.arange(S, device=dev)
         _masks = {"cfg3_flux_bf16_mask_padding": ((_i < 3000)[None, None, None, :]).contiguous(),
                   "cfg3_flux_bf16_mask_blockdiag": ((_i[:, None] // 1024) == (_i[None, :] // 1024))[None, None].contiguous(),
-                  # an ADDITIVE mask (fp16 relative-position bias [1,1,S,S], every tile mixed): these stay on the 128-row kernel (per-score reads, 16 bytes at a time)
-                  "cfg3_flux_bf16_mask_additive_bias": (-(_i[:, None] - _i[None, :]).abs().to(torch.float16) / 256.0)[None, None].contiguous()}
+                  # ADDITIVE masks (round 6: the one-wave-per-SIMD bias kernels, the mask tile by LDS-DMA straight from the caller's tensor): an fp16
+                  # relative-position bias shared by the heads [1,1,S,S], every tile mixed; and a per-head one [1,H,S,S] (ALiBi-like slopes: 805 MB, read once)
+                  "cfg3_flux_bf16_mask_additive_bias": (-(_i[:, None] - _i[None, :]).abs().to(torch.float16) / 256.0)[None, None].contiguous(),
+                  "cfg3_flux_bf16_mask_additive_bias_per_head": (-(_i[:, None] - _i[None, :]).abs().float()[None] /
+                                                                 (64.0 * (1 + torch.arange(H, device=dev)[:, None, None]))).to(torch.float16)[None].contiguous()}
         for _name, _m in _masks.items():
             fo = torch.empty(B, H, S, D, device=dev, dtype=torch.float32)
             tg = graph_ms(lambda: umfa_torch.attention_forward(q, k, v, mask=_m, out=fo), 20)
@@ -462,7 +465,11 @@ def run_rank(args) -> None:
             torch.cuda.synchronize()
             rows = _par.sample_rows(S)
             _add = _m.dtype != torch.bool
-            mrows = _np.ascontiguousarray(_np.broadcast_to((_m[0, 0].float() if _add else _m[0, 0]).cpu().numpy()[rows if _m.shape[2] > 1 else [0] * len(rows)], (len(rows), S)))
+            _ridx = torch.as_tensor(rows if _m.shape[2] > 1 else [0] * len(rows), device=dev)
+            if _m.shape[1] > 1:  # a mask with a head dimension of its own: [1, H, rows, S]
+                mrows = _np.ascontiguousarray(_m[:, :, _ridx].float().cpu().numpy())
+            else:
+                mrows = _np.ascontiguousarray(_np.broadcast_to((_m[0, 0].float() if _add else _m[0, 0])[_ridx].cpu().numpy(), (len(rows), S)))
             ref = _orc.sdpa_forward(_np.ascontiguousarray(_par.bits(q)[:, :, rows]), _par.bits(k), _par.bits(v), mask=mrows,
                                     mask_type=_orc.MASK_ADDITIVE if _add else _orc.MASK_BOOL).astype(_np.float64)
             dd = fo[:, :, rows].cpu().numpy().astype(_np.float64) - ref
@@ -472,7 +479,8 @@ def run_rank(args) -> None:
                               "frac_of_visible_work": round(FLOPS_PER_STEP * vis / tg / 1e9 / PEAK_BF16_TFLOPS, 4),
                               "rel": float(_np.abs(dd).max() / _np.abs(ref).max()), "fp32_out": True,
                               "mask": {"cfg3_flux_bf16_mask_padding": "bool [1,1,1,S], keys < 3000 attend", "cfg3_flux_bf16_mask_blockdiag": "bool [1,1,S,S], four blocks of 1024",
-                                       "cfg3_flux_bf16_mask_additive_bias": "fp16 additive [1,1,S,S], -|i - j| / 256: every tile mixed"}[_name]}
+                                       "cfg3_flux_bf16_mask_additive_bias": "fp16 additive [1,1,S,S], -|i - j| / 256: every tile mixed",
+                                       "cfg3_flux_bf16_mask_additive_bias_per_head": "fp16 additive [1,H,S,S], -|i - j| / (64 (h + 1)): 805 MB, every tile mixed, not classified"}[_name]}
             del fo
         # sliding window WITHOUT a mask tensor (the in-stream entry's UMFA_MASK_TYPE_WINDOW; the north-star's "sliding-window tile early-exit"):
         # +-512 keys around the row -- the same band as the window TENSORS of the mask tests, with no S x S mask anywhere

@@ -174,3 +174,30 @@ def test_w64_additive_mask_replays_in_a_graph_and_follows_the_mask():
         assert torch.isfinite(out).all() and torch.equal(eager, out)
     plain = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
     assert float((plain - out).abs().max()) <= 2.0 ** -9 * float(plain.abs().max())  # the all-zero mask: the unmasked answer
+
+
+@pytest.mark.parametrize("kind", ["random", "empty_rows_and_blocks", "per_head"])
+def test_w64_additive_mask_too_large_to_classify(kind, umfa_opts):
+    """a per-(batch, head) mask whose bytes exceed twice the call's Q + K + V + O traffic is not classified (the pass would cost what the attention costs):
+    every wave-tile counts as mixed and every tile is listed -- -inf tiles, -inf rows and whole -inf blocks then go through the masking body instead of
+    being skipped.  Same answers (oracle, O = 0 / LSE = -inf for rows that see nothing)."""
+    import umfa_torch
+    umfa_opts(force_w64=1)
+    B, H, Sq, Skv, D = 1, 2, 1024, 4096, 128
+    torch.manual_seed(3)
+    q = torch.randn(B, H, Sq, D, device="cuda", dtype=torch.bfloat16)
+    k, v = (torch.randn(B, H, Skv, D, device="cuda", dtype=torch.bfloat16) for _ in range(2))
+    m = _bias(kind, B, H, Sq, Skv, seed=5)
+    assert m.numel() * 2 > 2 * (B * H * D * (Sq * 6 + 2 * Skv * 2))  # the rule (fa_aux.hip mask_flags_worthwhile)
+    o, lse = umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32, return_lse=True)
+    kern = umfa_torch.last_kernel()
+    assert kern == "fa_fwd16_w64<bf16,128,pv16,bias>", kern
+    mfull = np.ascontiguousarray(m.expand(B, H, Sq, Skv).float().cpu().numpy())
+    ref, ref_lse = _oracle().sdpa_forward(npy(q), npy(k), npy(v), mask=mfull, mask_type=_oracle().MASK_ADDITIVE, return_lse=True)
+    on = o.cpu().numpy()
+    assert np.isfinite(on).all()
+    check_forward(on, ref, torch.bfloat16, kern, f"w64_bias_unclassified_{kind}")
+    dead = np.isneginf(mfull).all(-1)
+    ln = lse.cpu().numpy().reshape(B, H, Sq)
+    assert (on[dead] == 0).all() and np.isneginf(ln[dead]).all()
+    assert torch.equal(o, umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32))

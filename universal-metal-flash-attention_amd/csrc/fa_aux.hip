@@ -1058,8 +1058,13 @@ hipError_t launch_mask_classify(FwdParams& p, void* scratch, hipStream_t stream)
         hipLaunchKernelGGL(mask_classify_kernel<true>, dim3(grid), dim3(256), 0, stream, a, copy, cbt, chd, cr);
         p.mask = copy;
         p.ms[0] = p.ms[0] ? cbt : 0; p.ms[1] = p.ms[1] ? chd : 0; p.ms[2] = cr; p.ms[3] = 1;
-    } else {
+    } else if (mask_flags_worthwhile(p)) {
         hipLaunchKernelGGL(mask_classify_kernel<false>, dim3(grid), dim3(256), 0, stream, a, (_Float16*)nullptr, 0, 0, 0);
+    } else {
+        // a mask whose distinct bytes exceed twice the call's Q + K + V + O traffic (a dense per-head bias: 805 MB at the FLUX shape) is read ONCE, by the
+        // attention kernel: every wave-tile is called mixed (class 0, every tile listed) without looking -- the 128-row kernel's rule for its flags pass
+        // (mask_flags_worthwhile); a bias has nothing to skip, and the pass would cost what the attention itself costs
+        if (hipError_t e = hipMemsetAsync(a.wflag, 0, a.total, stream); e != hipSuccess) return e;
     }
     a.done = true;  // (no bit image to pack)
     return mask_pack_finish(a, list, cnt, nqb, slabs, stream);
