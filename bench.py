@@ -714,6 +714,13 @@ def bench_int8(torch, umfa_torch, event_ms, med, graph_ms):
         res["summary"] = (f"against the default bf16 forward, quantiser included: the reference's int8 arithmetic {c4['speedup']:.2f}x at config 4 "
                           f"({fx['speedup']:.2f}x at the FLUX shape); the SageAttention2-style fp8 P V mode {c4['fp8pv_speedup']:.2f}x "
                           f"({fx['fp8pv_speedup']:.2f}x) at 2x the quantisation error (parity.cfg4_fp8pv)")
+        # why the north-star's >= 1.3x is not reachable under the reference's arithmetic (mode 2), with this line's own numbers
+        res["why_not_1_3x"] = ("mode 2 keeps P V on a 1x-rate MFMA: K Q^T at 2x + P V at 1x = 3/4 of the bf16 kernel's matrix cycles, a ceiling of 1.33x for the KERNEL; "
+                               f"the separate quantiser pass (~29 us: reads Q, K, V, writes int8 Q, K and the fp16 V image) is {29.0 / (fx['bf16_ms'] * 1e3):.0%} of the "
+                               f"FLUX call, so the CALL's ceiling there is {1.0 / (0.75 + 29.0 / (fx['bf16_ms'] * 1e3)):.2f}x before any other cost, and both kernels sit on the "
+                               "board's power cap, where 25 % fewer matrix cycles return ~12 % of time.  A 2x-rate P V with an accurate (int8) P needs P <= 1, i.e. the exact "
+                               "running max: +46 % on the bf16 kernel (configs.cfg3_flux_bf16_pvbf16_exact against _lazy) for at most 1/6 of the matrix cycles -- not built. "
+                               "Only the opt-in fp8 P V mode (3-bit mantissas for P and V) passes 1.3x, at config 4.")
     except Exception:  # noqa: BLE001
         pass
     return res

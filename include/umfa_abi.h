@@ -422,7 +422,7 @@ const char* umfa_last_kernel_name(mfa_context_t context);
  *                        default = lazy for bf16, deferred for fp16 and the int8 kernels.
  *   "softmax_tau"        "0" ... "16" (log2 units, default 6)
  *   "force_w64" "no_w64" "w64_grid" "no_mask_flags" "bwd_exact" "bwd_dq" "bwd_persist" "no_split" "force_split"
- *   "no_dma" "bn64" "w64_skew" "no_w64_mask" "no_w64_mask_lazy" "ksplit" "no_pipe"
+ *   "no_dma" "bn64" "w64_skew" "no_w64_mask" "no_w64_mask_lazy" "no_w64_bias" "ksplit" "no_pipe"
  *                        kernel-selection overrides used by tests and A/B benches ("0" / "1" or a number)
  *   "bwd_ds_store"       "0" | "1": lab -- the dS-store form of the head_dim 128 non-causal backward (5 products, a
  *                        [B H Sq Skv] scratch in the operand type); measured level with the default (round 4), kept for A/B
