@@ -136,3 +136,12 @@ def test_wide_head_dims_forward_and_backward(seed):
 def test_quantized_forward_with_random_caller_masks(seed):
     msg = _fuzz().run_qmask_case(seed)
     assert msg is None, msg
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_w64_mask_kernels_random_cases(seed):
+    """(round 6) additive fp16 / bf16 mask tensors on fa_fwd16_w64<., 128, bias> and bool tensors on the int8 kernel's mask instantiation, forced, random whole-tile
+    shapes and forced small grids (cut blocks, several segments per workgroup -- the regime in which the additive kernels' first build was wrong)"""
+    msg = _fuzz().run_w64_mask_case(seed)
+    assert msg is None, msg
+

@@ -15,6 +15,7 @@ runs the first seeds of each, `python tools/lab/value_fuzz.py <first seed> <n> [
   run_aux_case        RoPE / Hadamard rotations against the oracle;  run_host_case: the blocking host-buffer ABI against the oracle
   run_streams_case    three streams at once;  run_threads_case: four host threads;  run_graph_case: hipGraph capture + replay
   run_wide_case       head dims 257 ... 1024, forward and backward;  run_qmask_case: the quantised forward with the caller's own mask tensor
+  run_w64_mask_case   (round 6) additive fp16 / bf16 masks and the int8 kernel's bool masks on the forced one-wave-per-SIMD mask kernels, cut blocks included
 """
 import os
 import random
@@ -1149,11 +1150,114 @@ def run_qmask_case(seed):
     return None
 
 
+def run_w64_mask_case(seed):
+    """(round 6) mask tensors through the FORCED one-wave-per-SIMD mask kernels: additive fp16 / bf16 tensors on fa_fwd16_w64<., 128, bias> and bool tensors on
+    the int8 kernel's mask instantiation -- random whole-tile shapes, forced small grids (cut blocks, several segments per workgroup), broadcast batch / head /
+    row dims, row-strided views, content from dense biases to -inf stripes, dead rows / blocks / heads, adversarial score shifts -- against fp64 (16-bit) or the
+    oracle's quantised restatement (int8); rows that see nothing give O = 0, LSE = -inf; bitwise repeatable"""
+    import numpy as np
+    rng = random.Random(seed + 9300000)
+    quant = rng.random() < 0.35
+    dt = rng.choice([torch.bfloat16, torch.float16]) if not quant else torch.bfloat16
+    B, H = rng.choice([1, 2]), rng.choice([1, 2, 3])
+    Sq = 64 * rng.choice([4, 5, 8, 12, 16, 20])
+    Skv = 64 * rng.choice([1, 2, 4, 7, 8, 11, 16, 22]) if not quant else rng.choice([64, 200, 512, 777, 1024, 1400])
+    if quant:
+        Sq = rng.choice([256, 512, 1024, 1280])
+    D = 128
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    q = torch.randn(B, H, Sq, D, device="cuda", generator=g).to(dt)
+    k = torch.randn(B, H, Skv, D, device="cuda", generator=g).to(dt)
+    v = torch.randn(B, H, Skv, D, device="cuda", generator=g).to(dt)
+    if rng.random() < 0.3 and not quant:  # a head whose scores are shifted by hundreds of nats (softmax is shift-invariant)
+        k[:, 0] = (k[:, 0].float() * rng.choice([6.0, 0.05])).to(dt)
+    i = torch.arange(Sq, device="cuda")[:, None]
+    j = torch.arange(Skv, device="cuda")[None, :]
+    content = rng.choice(["dense", "dense", "band_inf", "blockdiag_inf", "stripes_inf", "padding_inf", "zero", "dead", "large_negative"])
+    bshape = rng.choice([(1, 1), (B, 1), (1, H), (B, H)])
+    rows = 1 if content == "padding_inf" and rng.random() < 0.6 else Sq
+    shape = (bshape[0], bshape[1], rows, Skv)
+    val = torch.randn(*shape, device="cuda", generator=g) * rng.choice([0.5, 2.0, 6.0])
+    keep = torch.ones(*shape, dtype=torch.bool, device="cuda")
+    ii, jj = (i if rows > 1 else i[:1]), j
+    if content == "band_inf":
+        keep = ((ii * Skv // Sq - jj).abs() <= rng.choice([40, 200, 600]))[None, None].expand(shape).clone()
+    elif content == "blockdiag_inf":
+        bs = rng.choice([64, 96, 256, 320])
+        keep = ((ii // bs) == (jj * Sq // max(Skv, 1) // bs))[None, None].expand(shape).clone()
+    elif content == "stripes_inf":
+        keep = ((jj // rng.choice([3, 64, 128])) % 2 == 0)[None, None].expand(shape).clone()
+    elif content == "padding_inf":
+        keep = (jj < rng.randrange(1, Skv + 1))[None, None].expand(shape).clone()
+    elif content == "zero":
+        val = torch.zeros_like(val)
+    elif content == "dead":
+        keep = torch.rand(*shape, device="cuda", generator=g) < 0.6
+        if rows > 1:
+            keep[:, :, ::rng.choice([2, 5, 64])] = False
+            keep[:, 0, 256:512 if Sq >= 512 else 320] = False
+    elif content == "large_negative":
+        val = torch.where((ii // 128) >= (jj // 128), 0.0, -30000.0)[None, None].expand(shape).clone()
+    try:
+        opts = {"force_w64": 1}
+        if rng.random() < 0.5:
+            opts["w64_grid"] = rng.choice([3, 4, 5, 7])
+        with umfa_torch.options(**opts):
+            if quant:
+                mask = keep
+                qbits = rng.choice([8, 8, 4])
+                o, lse = umfa_torch.quantized_attention_forward_stream(q, k, v, mask=mask, bits=qbits, return_lse=True)
+                kern = umfa_torch.last_kernel()
+                o2 = umfa_torch.quantized_attention_forward_stream(q, k, v, mask=mask, bits=qbits)
+            else:
+                mdt = rng.choice([torch.float16, torch.float16, torch.bfloat16])
+                mask = val.masked_fill(~keep, float("-inf")).to(mdt)
+                if rng.random() < 0.25 and rows > 1:  # a view with a row stride of its own (rows stay 16-byte aligned)
+                    wide = torch.zeros(*shape[:-1], 2 * Skv, device="cuda", dtype=mdt)
+                    wide[..., :Skv] = mask
+                    mask = wide[..., :Skv]
+                o, lse = umfa_torch.attention_forward(q, k, v, mask=mask, out_dtype=torch.float32, return_lse=True)
+                kern = umfa_torch.last_kernel()
+                o2 = umfa_torch.attention_forward(q, k, v, mask=mask, out_dtype=torch.float32)
+        what = (seed, "quant" if quant else str(dt), B, H, Sq, Skv, content, tuple(shape), str(mask.dtype), opts, kern)
+        want = "fa_fwd_w64_i" if quant else ",bias>"
+        if want not in kern:
+            return "kernel %r" % (what,)
+        if not torch.isfinite(o).all():
+            return "non-finite %r" % (what,)
+        if not torch.equal(o, o2):
+            return "not bitwise repeatable %r" % (what,)
+        if quant:
+            from oracle import oracle
+            bits = 4 if "i4" in kern else 8
+            full = torch.zeros(B, H, Sq, Skv, device="cuda", dtype=torch.float32).masked_fill(~mask.expand(B, H, Sq, Skv), float("-inf"))
+            ro, rl = oracle.quantized_forward(q.float().cpu().numpy(), k.float().cpu().numpy(), v.float().cpu().numpy(), mask=full.contiguous().cpu().numpy(), bits=bits, quant_mode=2)
+            on = o.cpu().numpy()
+            rel = float(np.abs(on - ro).max() / max(np.abs(ro).max(), 1e-300))
+            dead = np.isneginf(rl).reshape(-1)
+            if rel > (2.5e-3 if bits == 8 else 4e-3) or (dead.any() and np.abs(on.reshape(-1, D)[dead]).max() != 0):
+                return "rel %.3e %r" % (rel, what)
+        else:
+            s_ = torch.matmul(q.double(), k.double().transpose(-1, -2)) * D ** -0.5 + mask.double()
+            rl = torch.logsumexp(s_, dim=-1)
+            ref = torch.matmul(torch.nan_to_num(torch.softmax(s_, dim=-1), nan=0.0), v.double())
+            rel = ((o.double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+            fin = torch.isfinite(rl)
+            lg = lse.view(B, H, Sq).double()
+            lerr = ((lg - rl)[fin].abs() / rl[fin].abs().clamp_min(50.0)).max().item() if fin.any() else 0.0
+            dead_ok = bool(torch.isneginf(lg[~fin]).all()) and bool((o[(~fin).unsqueeze(-1).expand_as(o)] == 0).all())
+            if rel > 2.0 ** -11 * 1.5 or lerr > 1e-3 or not dead_ok:
+                return "rel %.3e lse %.3e dead rows ok %s %r" % (rel, lerr, dead_ok, what)
+    except Exception as e:  # noqa: BLE001
+        return "exception %r %s" % ((seed, content), repr(e)[:300])
+    return None
+
+
 if __name__ == "__main__":
     first, count = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 200)
     bad = 0
     for seed in range(first, first + count):
-        for fn in ((run_case, run_bwd_case, run_shape_case, run_i8_case, run_gqa_case, run_rope_case, run_streams_case, run_graph_case, run_mask_case, run_host_case, run_qbwd_case, run_prequant_case, run_aux_case, run_threads_case, run_big_case, run_bwd_shape_case, run_wide_case, run_qmask_case) if len(sys.argv) < 4 else (globals()[sys.argv[3]],)):
+        for fn in ((run_case, run_bwd_case, run_shape_case, run_i8_case, run_gqa_case, run_rope_case, run_streams_case, run_graph_case, run_mask_case, run_host_case, run_qbwd_case, run_prequant_case, run_aux_case, run_threads_case, run_big_case, run_bwd_shape_case, run_wide_case, run_qmask_case, run_w64_mask_case) if len(sys.argv) < 4 else (globals()[sys.argv[3]],)):
             msg = fn(seed)
             if msg:
                 bad += 1

@@ -191,7 +191,11 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
     char* const Vbuf = smem + NS * TILE_BYTES;
 
     const int tid = tid_in, wave = tid >> 6, lane = tid & 63, ql = lane & 31, hi = lane >> 5;
+#ifdef UMFA_KS_ADJ  // lab (round 6): the two key halves of a row-wave on ADJACENT waves = different SIMDs (wave w runs on SIMD w % 4; as 4 kh + rw they share one)
+    const int rw = KS == 1 ? wave : (wave >> 1), kh = KS == 1 ? 0 : (wave & 1);
+#else
     const int rw = KS == 1 ? wave : (wave & 3), kh = KS == 1 ? 0 : (wave >> 2);  // row-wave, key half
+#endif
 #ifdef UMFA_LAB_STAMPS
     unsigned long long stamp[6];
     stamp[0] = __builtin_amdgcn_s_memrealtime();
