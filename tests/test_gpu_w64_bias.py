@@ -1,4 +1,4 @@
-"""ADDITIVE fp16 mask tensors on the one-wave-per-SIMD forward (fa_fwd16_w64<., 128, bias>, round 6): the kernel DMAs the wave's 64 x 64 mask tile
+"""ADDITIVE fp16 / bf16 mask tensors on the one-wave-per-SIMD forward (fa_fwd16_w64<., 128 | 64, bias>, round 6): the kernel DMAs the wave's 64 x 64 mask tile
 straight from the caller's tensor (any <= 4-D broadcastable fp16 tensor with 16-byte aligned rows) and adds mask / scale to the raw scores; a
 classification pre-pass gives per-wave tile classes (all -inf: masked, all zero: open, else mixed) and the visited-tile list of every 256-row block,
 so fully masked tiles are never staged.  Semantics are the reference's additive masks (MFABridge.swift:157-242: the value is added to the scaled
@@ -71,14 +71,14 @@ KINDS = ["rel_pos", "per_head", "random", "blockdiag_inf", "padding_row_broadcas
 @pytest.mark.parametrize("kind", KINDS)
 @pytest.mark.parametrize("dt,mdt", [(torch.bfloat16, torch.float16), (torch.float16, torch.float16), (torch.bfloat16, torch.bfloat16)])
 @pytest.mark.parametrize("shape,grid", [((2, 2, 512, 512), 0), ((1, 3, 1280, 768), 0), ((1, 3, 1280, 1408), 4), ((2, 2, 512, 512), 3)])
-def test_w64_additive_mask_vs_oracle(kind, dt, mdt, shape, grid, umfa_opts):
+@pytest.mark.parametrize("D", [128, 64])
+def test_w64_additive_mask_vs_oracle(kind, dt, mdt, shape, grid, D, umfa_opts):
     """mdt = bfloat16: the mask as a bf16 model has it -- the classification pass writes the fp16 copy the kernel reads (exact where fp16 holds the value)"""
     import umfa_torch
     umfa_opts(force_w64=1)
     if grid:
         umfa_opts(w64_grid=grid)  # few workgroups: blocks cut along their tile lists, parts folded
     B, H, Sq, Skv = shape
-    D = 128
     torch.manual_seed(Sq + Skv)
     q = torch.randn(B, H, Sq, D, device="cuda", dtype=dt)
     k = torch.randn(B, H, Skv, D, device="cuda", dtype=dt)
@@ -92,7 +92,7 @@ def test_w64_additive_mask_vs_oracle(kind, dt, mdt, shape, grid, umfa_opts):
             m = wide[..., :Skv]
     o, lse = umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32, return_lse=True)
     kern = umfa_torch.last_kernel()
-    assert kern in ("fa_fwd16_w64<bf16,128,pv16,bias>", "fa_fwd16_w64<fp16,128,bias>"), kern
+    assert kern in (f"fa_fwd16_w64<bf16,{D},pv16,bias>", f"fa_fwd16_w64<fp16,{D},bias>"), kern
     mfull = np.ascontiguousarray(m.expand(B, H, Sq, Skv).float().cpu().numpy())
     ref, ref_lse = _oracle().sdpa_forward(npy(q), npy(k), npy(v), mask=mfull, mask_type=_oracle().MASK_ADDITIVE, return_lse=True)
     on = o.cpu().numpy()
@@ -201,3 +201,40 @@ def test_w64_additive_mask_too_large_to_classify(kind, umfa_opts):
     ln = lse.cpu().numpy().reshape(B, H, Sq)
     assert (on[dead] == 0).all() and np.isneginf(ln[dead]).all()
     assert torch.equal(o, umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32))
+
+
+def test_bias_call_captured_without_a_warm_up_runs_on_the_kernel_that_needs_no_scratch():
+    """nothing is allocated under capture (runtime_internal.h): an additive-mask call whose stream has no class / list scratch yet -- a first capture without a
+    warm-up of that call -- goes to the 128-row kernel (mask read in place, V converted in the kernel); after an eager warm-up the same capture takes the bias
+    kernel.  Both replay to the eager answer."""
+    import umfa_torch
+    torch.manual_seed(13)
+    B, H, S, D = 1, 72, 1024, 128
+    q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    i = torch.arange(S, device="cuda")
+    m = (-(i[:, None] - i[None, :]).abs().float() / 128.0).to(torch.float16)[None, None].contiguous()
+    eager = umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32)
+    assert "bias" in umfa_torch.last_kernel()
+    out = torch.empty_like(eager)
+    cold = torch.cuda.Stream()  # a stream the library has never seen: empty pools
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(cold):
+        with torch.cuda.graph(g, stream=cold):
+            umfa_torch.attention_forward(q, k, v, mask=m, out=out)
+            assert umfa_torch.last_kernel().startswith("fa_fwd16<"), umfa_torch.last_kernel()
+    g.replay()
+    torch.cuda.synchronize()
+    assert float((out - eager).abs().max()) <= 2.0 ** -9 * float(eager.abs().max())
+    warm = torch.cuda.Stream()
+    with torch.cuda.stream(warm):
+        umfa_torch.attention_forward(q, k, v, mask=m, out=out)
+    warm.synchronize()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(warm):
+        with torch.cuda.graph(g2, stream=warm):
+            umfa_torch.attention_forward(q, k, v, mask=m, out=out)
+            assert "bias" in umfa_torch.last_kernel()
+    out.fill_(float("nan"))
+    g2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)

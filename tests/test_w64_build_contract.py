@@ -63,8 +63,8 @@ def test_compiler_stays_in_the_lower_register_halves(asm):
     # + bool mask tensors (MASKT): bf16-pv16 / fp16 x {fp32, 16-bit O} at head_dim 128
     # + (round 5) the same four at head_dim 64
     # + (round 6) additive fp16 mask tensors (MASKA, fa_fwd16_w64_bias.hip): bf16-pv16 / fp16 x {fp32, 16-bit O} at head_dim 128
-    # + (round 6) the int8 kernel's bool-mask instantiation (fp32 O)
-    assert len(kernels) == 59, sorted(kernels)
+    # + (round 6) the int8 kernel's bool-mask instantiation (fp32 O); the additive-mask kernels at head_dim 64 (four more)
+    assert len(kernels) == 63, sorted(kernels)
     for name, lines in kernels.items():
         in_asm, vmax, amax, n_mfma, loop_scratch = False, 0, 0, 0, 0
         if "w64_bias" in name:
@@ -109,7 +109,7 @@ def test_every_kernel_gets_512_registers(asm):
     nxt = [int(x) for x in re.findall(r"\.amdhsa_next_free_vgpr (\d+)", asm)]
     acc = [int(x) for x in re.findall(r"\.amdhsa_accum_offset (\d+)", asm)]
     # the hardware allocates in granules of 8 registers: 511 (clobbers name v254 / a254, the highest names hipcc does not reserve) is 512
-    assert len(nxt) == 59 and all((n + 7) // 8 * 8 == 512 for n in nxt), nxt
+    assert len(nxt) == 63 and all((n + 7) // 8 * 8 == 512 for n in nxt), nxt
     assert all(a == 256 for a in acc), acc
 
 
@@ -123,6 +123,7 @@ def test_generated_streams_are_current(tmp_path):
     env["W64_OUT_I8F8"] = str(tmp_path / "bi8f8.inc")
     env["W64_OUT_D64"] = str(tmp_path / "bd64.inc")
     env["W64_OUT_BIAS"] = str(tmp_path / "bbias.inc")
+    env["W64_OUT_BIAS_D64"] = str(tmp_path / "bbiasd64.inc")
     regs = (CSRC / "fa_fwd16_w64_regs.inc").read_text()
     subprocess.check_call([sys.executable, str(ROOT / "tools" / "gen_w64_body.py")], env=env, stdout=subprocess.DEVNULL)
     assert (tmp_path / "b16.inc").read_text() == (CSRC / "fa_fwd16_w64_body.inc").read_text()
@@ -130,6 +131,7 @@ def test_generated_streams_are_current(tmp_path):
     assert (tmp_path / "bi8.inc").read_text() == (CSRC / "fa_fwd_w64_i8_body.inc").read_text()
     assert (tmp_path / "bi8f8.inc").read_text() == (CSRC / "fa_fwd_w64_i8f8_body.inc").read_text()
     assert (tmp_path / "bbias.inc").read_text() == (CSRC / "fa_fwd16_w64_bias_body.inc").read_text()
+    assert (tmp_path / "bbiasd64.inc").read_text() == (CSRC / "fa_fwd16_w64d64_bias_body.inc").read_text()
     assert (CSRC / "fa_fwd16_w64_regs.inc").read_text() == regs  # the helper file is rewritten in place: unchanged
 
 

@@ -8,7 +8,7 @@ NAME=$1; shift
 TMP=$(mktemp -d)
 mkdir -p $ROOT/tools/lab_bin
 cp $CS/*.hip $CS/*.h $CS/*.inc $TMP/
-W64_OUT=$TMP/x1.inc W64_OUT_I8=$TMP/x2.inc W64_OUT_I8F8=$TMP/x3.inc W64_OUT_D64=$TMP/x4.inc W64_OUT_BIAS=$TMP/fa_fwd16_w64_bias_body.inc python3 $ROOT/tools/gen_w64_body.py > /dev/null
+W64_OUT=$TMP/x1.inc W64_OUT_I8=$TMP/x2.inc W64_OUT_I8F8=$TMP/x3.inc W64_OUT_D64=$TMP/x4.inc W64_OUT_BIAS=$TMP/fa_fwd16_w64_bias_body.inc W64_OUT_BIAS_D64=$TMP/fa_fwd16_w64d64_bias_body.inc python3 $ROOT/tools/gen_w64_body.py > /dev/null
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-function -fno-slp-vectorize -w "$@" -I$CS -c $TMP/fa_fwd16_w64_bias.hip -o $TMP/bias.o
 if /opt/rocm/lib/llvm/bin/llvm-objdump -d --offloading $TMP/bias.o 2>/dev/null | grep -q scratch_; then echo "WARNING: scratch in the variant"; fi
 OBJS=""

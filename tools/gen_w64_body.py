@@ -57,7 +57,7 @@ class Cfg:
         # four -- 32 MFMAs per 64-key tile for the same softmax work, rows of 128 bytes in the K / V tile images (the int8
         # kernels' K geometry).  The O^T register map is head_dim 128's with d-blocks 0 and 1 of each q-block in use.
         self.d64 = d64
-        assert not (d64 and (i8 or f8)) and not (madd and (i8 or f8 or d64))
+        assert not (d64 and (i8 or f8)) and not (madd and (i8 or f8))
         self.i2f = i8 and os.environ.get("W64_I8_BIAS", "1") == "0"
         # row sums on the matrix pipe (16-bit P kernels): l += sum of the ROUNDED P fragment by v_mfma_f32_4x4x4_16b against an
         # all-ones operand (a lane-local sum: block b = lane / 4, column j = lane % 4 -> the lane's own four values; 8-cycle
@@ -452,8 +452,9 @@ def dma_stream():
         vpos = [int(x) for x in os.environ["W64_DMA_V" + sfx].split(",")]
     ops = [(("DMAK", j), kpos[j], kpos[j] + 2) for j in range(C.KDMA)] + [(("DMAV", j), vpos[j], vpos[j] + 2) for j in range(C.VDMA)]
     if C.madd:  # the eight 1-KiB pieces of the next listed tile's mask image, in the gaps the K / V pieces leave (W64_DMA_M overrides)
-        mpos = [int(x) for x in os.environ.get("W64_DMA_M", "3,7,11,15,19,23,27,31").split(",")]
-        ops += [(("DMAM", j), mpos[j], mpos[j] + 2) for j in range(8)]
+        # (head_dim 64: half the gaps -- the pieces sit in every other gap between the two K and two V pieces)
+        mpos = [int(x) for x in os.environ.get("W64_DMA_M_D64" if C.d64 else "W64_DMA_M", "3,7,11,15,18,21,24,27" if C.d64 else "3,7,11,15,19,23,27,31").split(",")]
+        ops += [(("DMAM", j), mpos[j], min(C.NG - 2, mpos[j] + 2)) for j in range(8)]
     ops.sort(key=lambda o: o[1])
     return ops
 
@@ -1070,6 +1071,8 @@ def main():
     emit_body(Path(os.environ["W64_OUT_D64"]) if os.environ.get("W64_OUT_D64") else csrc / "fa_fwd16_w64d64_body.inc")
     C = Cfg(False, madd=True)
     emit_body(Path(os.environ["W64_OUT_BIAS"]) if os.environ.get("W64_OUT_BIAS") else csrc / "fa_fwd16_w64_bias_body.inc")
+    C = Cfg(False, d64=True, madd=True)
+    emit_body(Path(os.environ["W64_OUT_BIAS_D64"]) if os.environ.get("W64_OUT_BIAS_D64") else csrc / "fa_fwd16_w64d64_bias_body.inc")
 
 
 if __name__ == "__main__":

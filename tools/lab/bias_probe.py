@@ -32,7 +32,7 @@ def graph_ms(fn, n=20, reps=3):
     return a.elapsed_time(b) / (n * reps)
 
 
-shapes = [(1, 24, 4096, 128), (1, 16, 8192, 128), (4, 16, 2048, 128)]
+shapes = [(1, 24, 4096, 128), (1, 16, 8192, 128), (4, 16, 2048, 128), (2, 16, 4096, 64), (4, 16, 2048, 64)]
 for B, H, S, D in shapes:
     torch.manual_seed(0)
     q, k, v = (torch.randn(B, H, S, D, device=dev, dtype=torch.bfloat16) for _ in range(3))

@@ -1164,7 +1164,7 @@ def run_w64_mask_case(seed):
     Skv = 64 * rng.choice([1, 2, 4, 7, 8, 11, 16, 22]) if not quant else rng.choice([64, 200, 512, 777, 1024, 1400])
     if quant:
         Sq = rng.choice([256, 512, 1024, 1280])
-    D = 128
+    D = 128 if quant else rng.choice([128, 128, 64])
     g = torch.Generator(device="cuda").manual_seed(seed)
     q = torch.randn(B, H, Sq, D, device="cuda", generator=g).to(dt)
     k = torch.randn(B, H, Skv, D, device="cuda", generator=g).to(dt)

@@ -329,11 +329,11 @@ bool fwd_w64_supported(const FwdParams& p) {
     if (tuning().no_w64.load(std::memory_order_relaxed) || !fwd_16_supported(p)) return false;
     if ((p.D != 128 && p.D != 64) || (p.mask_kind != MK_NONE && p.mask_kind != MK_WINDOW && p.mask_kind != MK_BOOL && p.mask_kind != MK_F16 && p.mask_kind != MK_BF16)) return false;
     if (p.mask_kind == MK_F16 || p.mask_kind == MK_BF16) {
-        // ADDITIVE fp16 mask tensors (MASKA instantiations, round 6; the reference's additive masks: MFABridge.swift:157-242): head_dim 128, the fp16-P-V
+        // ADDITIVE fp16 / bf16 mask tensors (MASKA instantiations, round 6; the reference's additive masks: MFABridge.swift:157-242): head_dim 128 and 64, the fp16-P-V
         // families, no causal flag / rotation on top; the wave's mask tile comes by LDS-DMA straight from the caller's tensor, so: keys contiguous,
         // 16-byte aligned rows, Sq and Skv whole 64-row / 64-key tiles; at least one 256-row block per CU (whole blocks in rounds + a shared remainder,
         // as for bool masks).  Everything else (bf16 / fp32 masks, ragged shapes, few blocks) stays on the 128-row kernel.
-        if (tuning().no_w64_mask.load(std::memory_order_relaxed) || tuning().no_w64_bias.load(std::memory_order_relaxed) || !p.mask || p.D != 128 || p.rope_cos || p.causal) return false;
+        if (tuning().no_w64_mask.load(std::memory_order_relaxed) || tuning().no_w64_bias.load(std::memory_order_relaxed) || !p.mask || (p.D != 128 && p.D != 64) || p.rope_cos || p.causal) return false;
         if (p.in_prec == P_BF16 && !p.pv16) return false;
         if (p.Sq < 256 || p.Sq % 64 != 0 || p.Skv % 64 != 0 || ((p.Skv + 63) / 64) > 1024u) return false;
         if (p.out_prec != P_FP32 && p.out_prec != p.in_prec) return false;
@@ -527,10 +527,10 @@ hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cn
     if (p.D == 64 && rope) return hipErrorNotSupported;
     const int fam = p.in_prec == P_BF16 ? (p.pv16 ? 1 : 0) : 2;
     if (maskt && fam == 0) return hipErrorNotSupported;
-    if (maska && (p.D != 128 || fam == 0)) return hipErrorNotSupported;
+    if (maska && fam == 0) return hipErrorNotSupported;
     if (maska) {  // the additive-mask families: a translation unit of their own (generated bodies of their own)
-        *name = fam == 1 ? "fa_fwd16_w64<bf16,128,pv16,bias>" : "fa_fwd16_w64<fp16,128,bias>";
-        return launch_fwd_w64_bias(wp, fam, fp32o, w64_grid(p), 65536 + 4 * 32 * (512 + 16) + 64 + 4096 + 8192 + 2048 + 64, stream);
+        *name = p.D == 64 ? (fam == 1 ? "fa_fwd16_w64<bf16,64,pv16,bias>" : "fa_fwd16_w64<fp16,64,bias>") : (fam == 1 ? "fa_fwd16_w64<bf16,128,pv16,bias>" : "fa_fwd16_w64<fp16,128,bias>");
+        return launch_fwd_w64_bias(wp, fam, fp32o, w64_grid(p), 65536 + 4 * 32 * (512 + 16) + 64 + 4096 + 8192 + 2048 + 64, stream, (int)p.D);
     }
     *name = maska ? (fam == 1 ? "fa_fwd16_w64<bf16,128,pv16,bias>" : "fa_fwd16_w64<fp16,128,bias>") : maskt ? (p.D == 64 ? (fam == 1 ? "fa_fwd16_w64<bf16,64,pv16,mask>" : "fa_fwd16_w64<fp16,64,mask>")
                                : (fam == 1 ? "fa_fwd16_w64<bf16,128,pv16,mask>" : "fa_fwd16_w64<fp16,128,mask>"))

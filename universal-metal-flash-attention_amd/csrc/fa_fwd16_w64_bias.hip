@@ -33,6 +33,31 @@ namespace umfa {
 #define W64_KERNEL fa_fwd16_w64_bias_f16
 #include "fa_fwd16_w64_kernel.inc"
 
+#undef W64_T
+#undef W64_MFMA_QK
+#undef W64_KERNEL
+#undef W64_BODY_INC
+
+// head_dim 64 (the generator's Cfg(d64=True, madd=True)): the same two families
+#undef W64_DP
+#define W64_DP 64
+#define W64_BODY_INC "fa_fwd16_w64d64_bias_body.inc"
+#undef W64_VSC
+#define W64_VSC 1
+#define W64_T __bf16
+#define W64_MFMA_QK "v_mfma_f32_32x32x16_bf16"
+#define W64_KERNEL fa_fwd16_w64d64_bias_bf16pv16
+#include "fa_fwd16_w64_kernel.inc"
+#undef W64_VSC
+#define W64_VSC 0
+#undef W64_T
+#undef W64_MFMA_QK
+#undef W64_KERNEL
+#define W64_T _Float16
+#define W64_MFMA_QK "v_mfma_f32_32x32x16_f16"
+#define W64_KERNEL fa_fwd16_w64d64_bias_f16
+#include "fa_fwd16_w64_kernel.inc"
+
 template <typename KFN>
 static hipError_t launch_bias_kernel(KFN kfn, const W64Params& wp, uint32_t grid, size_t lds, hipStream_t stream) {
     if (hipError_t e = ensure_dynamic_lds((const void*)kfn, lds); e != hipSuccess) return e;
@@ -40,7 +65,16 @@ static hipError_t launch_bias_kernel(KFN kfn, const W64Params& wp, uint32_t grid
     return hipGetLastError();
 }
 
-hipError_t launch_fwd_w64_bias(const W64Params& wp, int family, bool fp32_out, uint32_t grid, size_t lds, hipStream_t stream) {
+hipError_t launch_fwd_w64_bias(const W64Params& wp, int family, bool fp32_out, uint32_t grid, size_t lds, hipStream_t stream, int head_dim) {
+    if (head_dim == 64) {
+        if (family == 1)
+            return fp32_out ? launch_bias_kernel(fa_fwd16_w64d64_bias_bf16pv16<float, false, false, false, true, true>, wp, grid, lds, stream)
+                            : launch_bias_kernel(fa_fwd16_w64d64_bias_bf16pv16<__bf16, false, false, false, true, true>, wp, grid, lds, stream);
+        if (family == 2)
+            return fp32_out ? launch_bias_kernel(fa_fwd16_w64d64_bias_f16<float, false, false, false, true, true>, wp, grid, lds, stream)
+                            : launch_bias_kernel(fa_fwd16_w64d64_bias_f16<_Float16, false, false, false, true, true>, wp, grid, lds, stream);
+        return hipErrorNotSupported;
+    }
     if (family == 1)
         return fp32_out ? launch_bias_kernel(fa_fwd16_w64_bias_bf16pv16<float, false, false, false, true, true>, wp, grid, lds, stream)
                         : launch_bias_kernel(fa_fwd16_w64_bias_bf16pv16<__bf16, false, false, false, true, true>, wp, grid, lds, stream);

@@ -73,6 +73,6 @@ struct W64I8Params {
 };
 
 // the additive-mask (MASKA) instantiations live in fa_fwd16_w64_bias.hip: family 1 = bf16 operands with fp16 P V, 2 = fp16 operands
-hipError_t launch_fwd_w64_bias(const W64Params& wp, int family, bool fp32_out, uint32_t grid, size_t lds, hipStream_t stream);
+hipError_t launch_fwd_w64_bias(const W64Params& wp, int family, bool fp32_out, uint32_t grid, size_t lds, hipStream_t stream, int head_dim);
 
 }  // namespace umfa
