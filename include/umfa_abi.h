@@ -447,6 +447,13 @@ const char* umfa_last_kernel_name(mfa_context_t context);
  *                        the workgroup reads the whole slab for the amax itself (the same number) -- forward progress does not depend
  *                        on the slab's workgroups being resident together (CU-masked streams, many streams).  "0": never wait (tests).
  *                        The same bound serves the runtime quantiser's exchange of a slab's largest |v| (the fp16 V image of the int8 forward).
+ *   "cbal"               "0" (default) | "1" | "2": balanced causal pairs on the 128-row forward kernel -- a head's q-blocks (i, last - i) dealt to
+ *                        two workgroups of EQUAL length (the long block's tail is published mid-sweep by the workgroup that goes on with the
+ *                        short block, the other folds it in): short causal launches no longer end with their longest q-block alone on its CU.
+ *                        0: where the plan expects a gain (head_dim 128: >= 8 q-blocks of 128 rows per head, <= 4 workgroups per CU; head_dim
+ *                        64: >= 16 q-blocks, <= 2 per CU; no mask tensor, even q-block count); 1: wherever the form exists; 2: never.
+ *                        Same results to rounding (another order of the row sums); bitwise repeatable.
+ *   "cbal_delta"         "-1" (default: the plan's choice) | "0" ... "16": key tiles by which the folding workgroup's share is shorter (tests, A/B)
  * Returns MFA_ERROR_INVALID_ARGS for an unknown name or a value out of range.  Thread-safe; affects later launches. */
 mfa_error_t umfa_set_option(mfa_context_t context, const char* name, const char* value);
 

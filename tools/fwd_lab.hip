@@ -74,16 +74,35 @@ int main(int argc, char** argv) {
     p.in_prec = P_BF16; p.out_prec = P_BF16;
     const uint32_t items = ((S + 127) / 128) * B * H;
     p.n_full = items; p.nsplit = 1;
+#ifndef UMFA_LAB_CBAL
+#define UMFA_LAB_CBAL 0   /* 1: balanced causal pairs (argv[5] = cbal_delta) */
+#endif
+    const size_t cb_bytes = UMFA_LAB_CBAL ? (size_t)(items / 2) * 4 * (4 * (UMFA_LAB_D / 32) + 1) * 1024 : 0;
+    unsigned long long* dbg = nullptr;
+    if (UMFA_LAB_CBAL) {
+        char* blk;
+        CK(hipMalloc(&blk, cb_bytes + (size_t)items * 160));
+        CK(hipMemset(blk, 0, cb_bytes + (size_t)items * 160));
+        p.part_buf = (float*)blk;
+        uint32_t* cnt;
+        CK(hipMalloc(&cnt, (size_t)items * 4));
+        CK(hipMemset(cnt, 0, (size_t)items * 4));
+        p.part_cnt = cnt;
+        p.cbal = 1;
+        p.cbal_delta = argc > 5 ? atoi(argv[5]) : 1;
+        dbg = (unsigned long long*)(blk + cb_bytes);
+    }
 #ifdef UMFA_LAB_STAMPS
-    unsigned long long* dbg;
-    CK(hipMalloc(&dbg, (size_t)items * 112));  // [items][8] stamps, then [items][6] loop buckets (UMFA_LAB_LOOP_STAMPS)
-    p.part_buf = (float*)dbg;
+    if (!UMFA_LAB_CBAL) {
+        CK(hipMalloc(&dbg, (size_t)items * 160));  // [items][8] stamps, then [items][6] loop buckets (UMFA_LAB_LOOP_STAMPS) / from [items][16] on: [items][4] CBAL stamps
+        p.part_buf = (float*)dbg;
+    }
 #endif
     #ifndef UMFA_LAB_BN
 #define UMFA_LAB_BN 64
 #endif
 #ifdef UMFA_LAB_DMA
-    auto kfn = fa_fwd16_kernel<__bf16, UMFA_LAB_D, UMFA_LAB_CAUSAL != 0, false, __bf16, true, UMFA_LAB_BN, UMFA_LAB_PV16, UMFA_LAB_KS, UMFA_LAB_PIPE>;
+    auto kfn = fa_fwd16_kernel<__bf16, UMFA_LAB_D, UMFA_LAB_CAUSAL != 0, false, __bf16, true, UMFA_LAB_BN, UMFA_LAB_PV16, UMFA_LAB_KS, UMFA_LAB_PIPE, UMFA_LAB_CBAL != 0>;
 #else
     auto kfn = fa_fwd16_kernel<__bf16, UMFA_LAB_D, UMFA_LAB_CAUSAL != 0, false, __bf16, false, UMFA_LAB_BN, UMFA_LAB_PV16>;
 #endif
@@ -140,6 +159,21 @@ int main(int argc, char** argv) {
                    "longest workgroup (%u, loop %.2f us) %llu %llu %llu %llu %llu %llu\n",
                    mean[0], mean[1], mean[2], mean[3], mean[4], mean[5], longest, us(hd[longest * 8 + 2]) - us(hd[longest * 8 + 1]), lp[longest * 6], lp[longest * 6 + 1],
                    lp[longest * 6 + 2], lp[longest * 6 + 3], lp[longest * 6 + 4], lp[longest * 6 + 5]);
+        }
+#endif
+#if UMFA_LAB_CBAL
+        {
+            std::vector<unsigned long long> cb((size_t)items * 4);
+            CK(hipMemcpy(cb.data(), dbg + (size_t)items * 16, cb.size() * 8, hipMemcpyDeviceToHost));
+            // parts B are blocks [0, items / 2), parts A the rest
+            double sw = 0, sw_at = 0, wait = 0, fold = 0, a_loop_end = 0, b_end = 0, a_end = 0; uint32_t nb = 0, na = 0;
+            for (uint32_t i = 0; i < items; ++i) {
+                const unsigned long long* c = &cb[i * 4]; const unsigned long long* d = &hd[i * 8];
+                if (i < items / 2) { if (c[0]) { sw += (double)(c[1] - c[0]) * 0.01; sw_at += us(c[0]); ++nb; } b_end += us(d[3]); }
+                else { if (c[2]) { wait += (double)(c[2] - d[2]) * 0.01; fold += (double)(c[3] - c[2]) * 0.01; ++na; } a_loop_end += us(d[2]); a_end += us(d[3]); }
+            }
+            printf("CBAL: parts B: switch at %.2f us, takes %.2f us (%u), end %.2f | parts A: loop ends %.2f, flag wait %.2f us, payload + fold %.2f us (%u), end %.2f\n",
+                   nb ? sw_at / nb : 0.0, nb ? sw / nb : 0.0, nb, b_end / (items / 2), a_loop_end / (items / 2), na ? wait / na : 0.0, na ? fold / na : 0.0, na, a_end / (items / 2));
         }
 #endif
         printf("mean prologue %.2f us, loop %.2f us, epilogue %.2f us; last end %.2f us; mean in-kernel clock %.3f GHz\n",

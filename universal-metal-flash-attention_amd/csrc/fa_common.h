@@ -83,6 +83,10 @@ struct FwdParams {
     int pv16;
     const float* vsc;
     uint32_t vsc_bs, vsc_hs;
+    // balanced causal pairs (fa_fwd_16_kernel.h CBAL; fwd_16_split_plan decides): a head's q-blocks (i, nqb - 1 - i) are dealt to two
+    // workgroups of equal length; part_buf holds one slot per pair, part_cnt one flag word per pair (zero between launches)
+    uint32_t cbal;        // 1 = the launch runs the CBAL instantiation
+    uint32_t cbal_delta;  // key tiles by which a pair's part A is shorter than half (it pays the fold)
 };
 
 // Interleaved-pair rotary rotation of 8 consecutive elements (4 pairs) given the 8 table entries of their columns

@@ -299,7 +299,17 @@ double fwd_16_predict_us(const FwdParams& p) {
     const uint64_t k = plan.nsplit > 1 ? plan.nsplit : 1;
     const double n = (double)(items * k) / (double)cus;
     double body;
-    if (p.causal) {
+    if (plan.cbal) {
+        // balanced causal pairs (round 6): every workgroup sweeps half a pair = h tiles; rounds of two workgroups per CU.  Piecewise-linear fit of
+        // profiles/r6/cbal_matrix.jsonl (the unpaired form's f2 does not carry over: here BOTH workgroups of a CU are busy all the way)
+        const uint64_t lastq = nqb - 1;
+        const double h = 0.5 * (double)(std::min<uint64_t>(T, 2) + std::min<uint64_t>(T, (lastq * 128 + 128 + 63) / 64));
+        const bool d64 = p.D == 64;
+        const double one = (d64 ? 8.3 : 11.85) + (d64 ? 1.22 : 1.64) * h, two = (d64 ? 11.7 : 23.5) + (d64 ? 1.34 : 1.97) * h;
+        const uint64_t full = (uint64_t)(n / 2.0);
+        const double rest = n - 2.0 * (double)full;
+        body = (double)full * two + (rest > 1e-9 ? (rest <= 1.0 ? one : two) : 0.0) - c.t0;  // (the intercepts include the launch)
+    } else if (p.causal) {
         uint64_t tot = 0, longest = 0;
         for (uint64_t qb = 0; qb < nqb; ++qb) {
             const uint64_t len = std::min<uint64_t>(T, (qb * 128 + 128 + 63) / 64);

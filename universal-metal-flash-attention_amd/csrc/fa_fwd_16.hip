@@ -66,6 +66,28 @@ FwdSplitPlan fwd_16_split_plan(const FwdParams& p) {
         // launch cost more than the halved critical path returns.  Off by default; results are identical to 1e-2.
         const int force = tuning().force_split.load(std::memory_order_relaxed);
         const bool want = force == 2;
+        // Round 6: balanced causal pairs (fa_fwd_16_kernel.h CBAL) -- the pair (i, nqb - 1 - i) of a head's q-blocks on two workgroups of
+        // EQUAL length, the long q-block's tail published mid-sweep by the part that goes on with the short one: as many workgroups as
+        // before, one fold per pair, nobody runs alone.  Where (profiles/r6/cbal_matrix.jsonl, graph-replayed, both schedules forced in one
+        // process; unpaired -> paired us): head_dim 128 from eight q-blocks per head up to four workgroups per CU -- B1 H8 S4096 102 -> 67,
+        // B2 H8 S2048 56 -> 40, B4 H8 S1024 32.6 -> 27.7, B8 H8 S2048 122 -> 109; at 2048 items level, S = 512 slower (two tiles against a
+        // fold); head_dim 64 from sixteen q-blocks up to two per CU -- B1 H8 S4096 58 -> 49, B4 H8 S2048 36.3 -> 34.6.  NOT BASELINE config 2
+        // (B4 H16 S1024 D64: 23.6 -> 24.3): in-kernel stamps show why -- with every CU holding two 9-tile workgroups for the whole launch
+        // a tile takes 1.83 us against 1.2 us for a workgroup alone (the SIMD's two waves do not overlap at head_dim 64), so 18 tile steps
+        // per CU cost what 16 alone + 2 shared did (profiles/r6/cbal_stamps_config2.txt).
+        const int cb = tuning().cbal.load(std::memory_order_relaxed);
+        const bool cb_shape = !(nqb & 1) && nqb >= 2 && (dp == 64 || dp == 128) && p.D == dp && p.mask_kind == MK_NONE && dma_enabled();
+        const bool cb_auto = p.Skv >= p.Sq && (dp == 128 ? (nqb >= 8 && items <= 4 * cus) : (nqb >= 16 && items <= 2 * cus));
+        if (!want && cb != 2 && cb_shape && (cb == 1 || cb_auto)) {
+            const int dl = tuning().cbal_delta.load(std::memory_order_relaxed);  // (< 0: the plan's own choice)
+            const size_t npairs = (size_t)items / 2;
+            plan.cbal = 1;
+            // the folding part is shorter by the fold's price in tiles: nothing while a CU holds one workgroup, two tiles from two per CU on (head_dim 128)
+            plan.cbal_delta = dl >= 0 ? (uint32_t)(dl > 16 ? 16 : dl) : (dp == 128 && items > cus ? 2u : 0u);
+            plan.buf_bytes = npairs * 4 * (4 * (dp / 32) + 1) * 1024;
+            plan.cnt_bytes = (npairs * sizeof(uint32_t) + 15) & ~(size_t)15;
+            return plan;
+        }
         if (!want || (nqb & 1) || nqb < 4 || p.Sq != p.Skv || dp > 128) return plan;
         plan.n_full = items / 2;
         plan.nsplit = 2;
@@ -125,6 +147,9 @@ static hipError_t launch_one(const FwdParams& p, hipStream_t stream) {
             if (form == 1) return launch_dma<T, DP, CAUSAL, HAS_MASK, OUT, true, 64, 0, 1, 1>(p, stream);
             if (form == 2) return launch_dma<T, DP, CAUSAL, HAS_MASK, OUT, true, 64, 0, 2>(p, stream);
 #endif
+        }
+        if constexpr (CAUSAL && !HAS_MASK && (DP == 64 || DP == 128)) {
+            if (p.cbal && p.part_buf && p.part_cnt) return launch_dma<T, DP, CAUSAL, HAS_MASK, OUT, true, 64, 0, 1, 0, true>(p, stream);
         }
         return launch_dma<T, DP, CAUSAL, HAS_MASK, OUT, true, 64>(p, stream);
     }

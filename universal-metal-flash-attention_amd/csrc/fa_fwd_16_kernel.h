@@ -128,12 +128,12 @@ __device__ __forceinline__ int vscale_exponent_of(unsigned amax_bits) {
 // the other (the first returns the exponent, 0 = done) with the second copy's inputs laundered through an empty asm, so that nothing
 // of the first copy stays live for it.  (Tried first: a loop around the sweep -- as a back-edge it cost every converting instantiation
 // 12-18 registers and the three-per-CU one 92 more spills; a noinline function -- the call ABI raised every kernel to 248 registers.)
-template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT, bool DMA, int BN, int PV16, int KS, int PIPE, bool RESWEEP, typename PRM>
+template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT, bool DMA, int BN, int PV16, int KS, int PIPE, bool CBAL, bool RESWEEP, typename PRM>
 __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const int tid_in, const uint32_t bid_in);
 
-template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT, bool DMA = false, int BN = 64, int PV16 = 0, int KS = 1, int PIPE = 0>
+template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT, bool DMA = false, int BN = 64, int PV16 = 0, int KS = 1, int PIPE = 0, bool CBAL = false>
 __global__ __launch_bounds__(256 * KS, KS * (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_fwd16_kernel(FwdParams p) {
-    int e2 = fa_fwd16_body<T, DP, CAUSAL, HAS_MASK, OUT, DMA, BN, PV16, KS, PIPE, false, const FwdParams>(p, 0, (int)threadIdx.x, blockIdx.x);
+    int e2 = fa_fwd16_body<T, DP, CAUSAL, HAS_MASK, OUT, DMA, BN, PV16, KS, PIPE, CBAL, false, const FwdParams>(p, 0, (int)threadIdx.x, blockIdx.x);
     if constexpr (PV16 == 1) {
         if (__builtin_expect(e2 != 0, 0)) {
             // the second copy reads the parameters through the kernel-argument segment (FwdParams is the only argument: offset 0), so that
@@ -144,14 +144,15 @@ __global__ __launch_bounds__(256 * KS, KS * (DP > 128 ? 1 : (BN == 32 ? 3 : 2)))
             uint32_t bx = blockIdx.x;
             asm volatile("" : "+s"(pp), "+v"(t), "+s"(bx), "+v"(e2));
             e2 = __builtin_amdgcn_readfirstlane(e2);  // (workgroup-uniform by construction)
-            (void)fa_fwd16_body<T, DP, CAUSAL, HAS_MASK, OUT, DMA, BN, PV16, KS, PIPE, true, KFwdParams>(*pp, e2, t, bx);
+            (void)fa_fwd16_body<T, DP, CAUSAL, HAS_MASK, OUT, DMA, BN, PV16, KS, PIPE, CBAL, true, KFwdParams>(*pp, e2, t, bx);
         }
     }
 }
 
-template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT, bool DMA, int BN, int PV16, int KS, int PIPE, bool RESWEEP, typename PRM>
+template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT, bool DMA, int BN, int PV16, int KS, int PIPE, bool CBAL, bool RESWEEP, typename PRM>
 __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const int tid_in, const uint32_t bid_in) {
     static_assert(!RESWEEP || PV16 == 1, "the second sweep exists for the converting kernels only");
+    static_assert(!CBAL || (CAUSAL && !HAS_MASK && DMA && BN == 64 && KS == 1 && !PIPE && DP <= 128), "balanced causal pairs: LDS-DMA staging, no mask tensor");
     static_assert(!PIPE || (DMA && !HAS_MASK && KS == 1 && DP <= 64 && BN == 64), "pipelined loop: head_dim <= 64, LDS-DMA staging, no mask tensor");
     static_assert(!PV16 || __is_same(T, __bf16), "PV16: bf16 operands");
     static_assert(KS == 1 || (KS == 2 && DMA && !HAS_MASK && DP == 64 && BN == 64), "key-split: head_dim 64, LDS-DMA staging, no mask tensor");
@@ -198,8 +199,12 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
 #endif
 #ifdef UMFA_LAB_STAMPS
     unsigned long long stamp[6];
+    unsigned long long cbs[4] = {0, 0, 0, 0};  // CBAL: switch begin / end, fold: flag seen / payload folded
     stamp[0] = __builtin_amdgcn_s_memrealtime();
     stamp[4] = __builtin_amdgcn_s_memtime();
+#define UMFA_CB_STAMP(i) cbs[i] = __builtin_amdgcn_s_memrealtime()
+#else
+#define UMFA_CB_STAMP(i)
 #endif
     const uint32_t nqb = (p.Sq + BM - 1) / BM;
     // work item = one 128-row query block of one (batch, head).  Items [0, n_full) are processed whole;
@@ -220,6 +225,29 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
     }
     uint32_t bh = item / nqb;
     uint32_t qb = item % nqb;
+    // CBAL state (all workgroup-uniform): cb_role 0 = one whole q-block, 1 = part A (tiles [0, cb_a) of q-block qb; folds part B in before it
+    // stores), 2 = part B (tiles [cb_a, n) of q-block qb, published at step cb_sw; then the pair's short q-block cb_qb2 whole)
+    uint32_t cb_role = 0, cb_a = 0, cb_sw = 0xffffffffu, cb_qb2 = 0, cb_n2 = 0, cb_pair = 0, cb_early = 0;
+    if constexpr (CBAL) {
+        const uint32_t h2 = nqb >> 1, npairs = p.B * p.H * h2;
+        const bool is_b = bid_in < npairs;  // parts B first: a part A waits for its part B, never the other way round, and a part B waits for nothing
+        cb_pair = xcd_remap(is_b ? bid_in : bid_in - npairs, npairs);
+        bh = cb_pair / h2;
+        const uint32_t qi = cb_pair % h2, qj = nqb - 1 - qi;
+        const uint32_t ntl = (p.Skv + BN - 1) / BN;
+        auto nt_of = [&](uint32_t q_) { const uint32_t lim = (q_ * BM + BM + BN - 1) / BN; return ntl < lim ? ntl : lim; };
+        const uint32_t ni = nt_of(qi), nj = nt_of(qj);
+        int a = (int)((ni + nj + 1) / 2) - (int)p.cbal_delta;
+        a = a < 1 ? 1 : a;
+        if ((uint32_t)a >= nj) {  // nothing to cut (Skv much shorter than Sq): both q-blocks whole
+            qb = is_b ? qi : qj;
+        } else {
+            qb = qj;
+            cb_a = (uint32_t)a;
+            if (is_b) { cb_role = 2; cb_sw = nj - cb_a; cb_qb2 = qi; cb_n2 = ni; }
+            else cb_role = 1;
+        }
+    } else
     if (causal_split) {
         const uint32_t h2 = nqb >> 1, idx = item < p.n_full ? item : item - p.n_full;
         bh = idx / h2;
@@ -248,8 +276,8 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
 #endif
     }
     const uint32_t b = bh / p.H, h = bh % p.H;
-    const uint32_t q_row = qb * BM + rw * 32 + ql;
-    const uint32_t wave_q0 = qb * BM + rw * 32;
+    uint32_t q_row = qb * BM + rw * 32 + ql;    // (CBAL: a part B moves on to its second q-block)
+    uint32_t wave_q0 = qb * BM + rw * 32;
     const int D = (int)p.D;
 
     // Hardware-bounds-checked buffer loads (T8): rows past the end of a (batch, head) slab and
@@ -265,12 +293,15 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
 
     // ---- Q^T fragments (B operand of S^T = K Q^T): lane (q, hi) holds Q[q][16 ks + 8 hi .. +7]
     V8 qf[NKS];
+    auto load_q = [&](const uint32_t row) {
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        const int d0 = 16 * ks + 8 * hi;
-        const int off = (q_row < p.Sq && d0 < D) ? (int)q_row * q_stride_b + d0 * 2 : OOB;
-        qf[ks] = __builtin_bit_cast(V8, __builtin_amdgcn_raw_buffer_load_b128(q_rsrc, off, 0, 0));
-    }
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int d0 = 16 * ks + 8 * hi;
+            const int off = (row < p.Sq && d0 < D) ? (int)row * q_stride_b + d0 * 2 : OOB;
+            qf[ks] = __builtin_bit_cast(V8, __builtin_amdgcn_raw_buffer_load_b128(q_rsrc, off, 0, 0));
+        }
+    };
+    load_q(q_row);
 
     // ---- tile staging (register path): thread owns chunks c = tid + 256 i  ->  (row, ch); offsets are tile-invariant
     constexpr int LPTR = DMA ? 1 : LPT;
@@ -337,10 +368,16 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
     // to back with the K half (LDS-DMA instructions in a row stall the MFMA behind them, profiles/r1/lab_notes.md).
     // Same-box A/B: head_dim 256 (16 DMA instructions per wave per tile) 1132 -> 1001-1029 us at B2 H24 S4096,
     // head_dim 64 non-causal +2.5 %, head_dim 128 neutral, the tiny causal head_dim-64 case -3 % (left unsplit).
+    // CBAL: the sweep's steps and the key tiles they visit differ for a part B (first the tail of the long q-block, then the short one from
+    // tile 0); the ring's slots go by STEP
+    auto tile_of = [&](uint32_t s_) -> uint32_t {
+        if constexpr (CBAL) return cb_role == 2 ? (s_ < cb_sw ? cb_a + s_ : s_ - cb_sw) : s_;
+        else return s_;
+    };
     auto stage_load = [&](uint32_t t, int which = 3, uint32_t tk_ahead = 0) {  // tk_ahead: the K tile requested is t + tk_ahead (PIPE)
         if constexpr (DMA) {
             const uint32_t tk = t + tk_ahead;
-            const int ktile = (int)(tk * BN) * k_stride_b, vtile = (int)(t * BN) * v_stride_b;
+            const int ktile = (int)(tile_of(tk) * BN) * k_stride_b, vtile = (int)(tile_of(t) * BN) * v_stride_b;
             const unsigned kdst = lds_wave + (tk % NS) * TILE_BYTES, vdst = lds_wave + (t % NS) * TILE_BYTES + NS * TILE_BYTES;
 #pragma unroll
             for (int j = 0; j < IPW; ++j) {
@@ -417,6 +454,10 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
     }
     uint32_t t_begin = (uint32_t)(((uint64_t)ntiles * part) / nparts);
     uint32_t t_end = (uint32_t)(((uint64_t)ntiles * (part + 1)) / nparts);
+    if constexpr (CBAL) {  // steps, not tiles (tile_of)
+        if (cb_role == 1) t_end = cb_a;
+        else if (cb_role == 2) t_end = cb_sw + cb_n2;
+    }
 
     f32x16 acc[NDB];
 #pragma unroll
@@ -497,6 +538,142 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
         t_end = hi1 < t_end ? hi1 : t_end;
         if (t_end < t_begin) t_end = t_begin;
     }
+    // `red`: four free words of LDS (behind the loop: the tile area -- every wave is behind the loop's last barrier)
+    auto v_range_check = [&](volatile uint32_t* const red) -> int {
+        // fp16's range, checked where it is free -- on this workgroup's own outputs, once per item: a V value >= 65536 went into LDS as
+        // +-inf and made every output it touches inf / NaN (P >= 0: 0 * inf = NaN, never a silent finite value); outputs that are ALL
+        // below 2^-11 may have met values of V under 2^-17, which fp16 no longer holds exactly (absolute error <= 2^-25, i.e. <= 2^-14 of
+        // an output of 2^-11).  Either way the workgroup takes the largest |v| of its slab and sweeps its keys again with V shifted by
+        // that power of two (the cast pre-pass's rule; fa_fwd16_resweep: this body once more, out of line, from its first instruction).
+        // Decided from the data alone: the same under graph replay, on any stream, and nothing for the host to read.
+        const float lsum = (l4[0] + l4[1]) + (l4[2] + l4[3]);
+        const float lrow = lsum + xor32(lsum);
+        const float inv_c = lrow > 0.0f ? 1.0f / lrow : 0.0f;
+        float chk_nan = 0.0f, chk_max = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NDB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float val = acc[i][r] * inv_c;
+                chk_nan = __builtin_fmaf(val, 0.0f, chk_nan);
+                chk_max = fmaxf(chk_max, __builtin_fabsf(val));
+            }
+        const bool rowok = q_row < p.Sq;  // (rows past Sq were computed on zero Q rows: their "outputs" are means of V, and say nothing)
+        const unsigned bits = (__builtin_amdgcn_ballot_w64(rowok && chk_nan != chk_nan) != 0 ? 1u : 0u) |
+                              (__builtin_amdgcn_ballot_w64(rowok && chk_max >= 0x1p-11f) != 0 ? 2u : 0u) |
+                              (__builtin_amdgcn_ballot_w64(rowok && lrow > 0.0f) != 0 ? 4u : 0u);
+        if (lane == 0) red[wave] = bits;
+        __syncthreads();
+        unsigned all = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < NT / 64; ++w2) all |= red[w2];
+        all = __builtin_amdgcn_readfirstlane(all);
+        // non-finite, or rows with keys and nothing above 2^-11  (otherwise on: the words stay -- the tile area is not read again, and the
+        // folds below write before they read)
+        if (__builtin_expect((all & 1u) || ((all & 4u) && !(all & 2u)), 0)) {
+            unsigned amax = 0;
+            const uint32_t d8 = (uint32_t)D / 8u, nch = p.Skv * d8;
+            for (uint32_t c = (uint32_t)tid; c < nch; c += NT) {
+                const uint32_t row = c / d8, ch = c - row * d8;
+                const u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, (int)(row * (uint32_t)v_stride_b + ch * 16u), 0, 0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned a = r4[j] & 0x7fff7fffu, m2 = (a & 0xffffu) > (a >> 16) ? (a & 0xffffu) : (a >> 16);
+                    amax = amax > m2 ? amax : m2;
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned o2 = (unsigned)__shfl_xor((int)amax, off, 64);
+                amax = amax > o2 ? amax : o2;
+            }
+            __syncthreads();
+            if (lane == 0) red[wave] = amax;
+            __syncthreads();
+            amax = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < NT / 64; ++w2) amax = amax > red[w2] ? amax : red[w2];
+            amax = __builtin_amdgcn_readfirstlane(amax);
+            __syncthreads();
+            // V all zero (the outputs were right), V with inf / NaN in it (they are what they should be: non-finite), V already where the
+            // shift would put it: nothing a second sweep improves
+            const int e2 = vscale_exponent_of(amax);
+            if (amax != 0 && amax < 0x7f80u && e2 != 0) {
+                return e2;  // -> the kernel runs the RESWEEP copy (the caller returns it)
+            }
+        }
+        return 0;
+    };
+    auto v_shift_back = [&]() {
+        if constexpr (RESWEEP) {  // the shift comes back (exact): everything below -- fold, output -- sees the values of the unshifted V
+            const float back = __uint_as_float((unsigned)(127 + vexp) << 23);
+    #pragma unroll
+            for (int i = 0; i < NDB; ++i)
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] *= back;
+        } else if constexpr (PV16 == 2) {
+            // the cast pre-pass shifted this slab's V by a power of two (FwdParams::vsc): back, before anything is published
+            if (p.vsc) {
+                const float back = p.vsc[128 * ((size_t)b * p.vsc_bs + (size_t)h * p.vsc_hs) + 65];
+    #pragma unroll
+                for (int i = 0; i < NDB; ++i)
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][r] *= back;
+            }
+        }
+    };
+    // ---- CBAL ("balanced causal pairs", round 6; short causal launches, BASELINE config 2) ----
+    // A causal launch whose workgroups are all resident at once ends when its longest item does: q-block nqb - 1 sweeps every key tile,
+    // most of the time alone on its CU (config 2: 2.5 us + 16 tiles x 1.2 us + 1.3 us of a 24-us launch whose mean item is 9 tiles).
+    // Here the items of a head are paired (qi, qj = nqb - 1 - qi) and every pair is dealt to TWO workgroups of equal length:
+    //   part A  tiles [0, a) of the long q-block qj, a = ceil((n_i + n_j) / 2) - cbal_delta (the fold's price, in tiles);
+    //   part B  tiles [a, n_j) of qj -- published to the pair's slot of part_buf the moment they are done -- then q-block qi whole,
+    //           in ONE sweep: the LDS ring never drains, only Q and the accumulators change at the switch.
+    // Part A folds B's (O^T, m, l) into its own registers and stores.  Parts B occupy the lower half of the grid, so they are dispatched
+    // first and wait for nothing: a part A's wait always ends.  Fence-free like the split-KV fold below: write-through (sc1) stores,
+    // vmcnt(0), barrier, a relaxed agent-scope flag.  Slot: [wave 4][chunk 4 NDB + 1][lane 64] x 16 bytes.
+    constexpr int CB_CH = 4 * NDB + 1;
+    auto cb_rsrc = [&]() {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)((char*)p.part_buf + (size_t)cb_pair * (4 * CB_CH * 1024)), 0, 4 * CB_CH * 1024, 0x00020000);
+    };
+    auto cb_switch = [&](uint32_t t) {
+        // part B, top of step t = cb_sw: the step's tile is in slot t % NS (landed and published by the barrier that ended step t - 1),
+        // the other slot is free (its request follows)
+        volatile uint32_t* const red = (volatile uint32_t*)(Kbuf + ((t + 1) % NS) * TILE_BYTES);
+        int e2 = 0;
+        if constexpr (VCONV && !RESWEEP) {
+            e2 = v_range_check(red);
+            __syncthreads();
+            if (tid < 4) red[tid] = 0;  // (the tile areas start from zeros: rows past Skv are never written)
+        }
+        if (e2) return e2;
+        v_shift_back();
+        const float lsum = (l4[0] + l4[1]) + (l4[2] + l4[3]);
+        const float lrow = lsum + xor32(lsum);
+        const auto prs = cb_rsrc();
+        const int base = (wave * CB_CH) * 1024 + lane * 16;
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int i = 0; i < NDB; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4{acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]}),
+                                                       prs, base + (4 * i + g) * 1024, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4{lrow > 0.0f ? m : -INFINITY, lrow, 0.0f, 0.0f}), prs, base + (4 * NDB) * 1024, 0, 16);
+        // (the flag follows at the END of this step, behind stage_write's vmcnt(0) and the step's barrier: nothing waits for the stores here)
+        // the second q-block: its Q fragments were requested during the step before (behind that step's Q K^T)
+        qb = cb_qb2;
+        q_row = qb * BM + rw * 32 + ql;
+        wave_q0 = qb * BM + rw * 32;
+#pragma unroll
+        for (int i = 0; i < NDB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+        m = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) l4[j] = 0.0f;
+        return 0;
+    };
     if constexpr (!PIPE) {
 #pragma unroll
         for (int i = 0; i < NS - 1; ++i) stage_load(t_begin + i);  // (tiles past the end: all zeros, same instruction count)
@@ -665,12 +842,21 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
     } else {
     for (uint32_t t = t_begin; t < t_end; ++t) {
         UMFA_LP_STAMP(lp_t0);
+        if constexpr (CBAL) {
+            // part A: a first look at the pair's flag, a step ahead of the fold (the load's round trip hides under the last tile)
+            if (cb_role == 1 && t + 1 == t_end && tid == 0) cb_early = __hip_atomic_load(p.part_cnt + cb_pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == cb_sw) {  // part B: the long q-block's tail is done -- publish it, go on with the short q-block
+                UMFA_CB_STAMP(0);
+                if (const int e2 = cb_switch(t)) return e2;
+                UMFA_CB_STAMP(1);
+            }
+        }
         const int cur = t % NS;
         // (KS = 2: this wave's half of the tile -- both swizzles depend on row bits below 32 / 4 only, so a whole number of
         // 32-key blocks is a pure byte offset)
         const char* Kt = Kbuf + cur * TILE_BYTES + kh * (32 * NKBW) * (2 * DP);
         const char* Vt = Vbuf + cur * TILE_BYTES + kh * (32 * NKBW) * (2 * DP);
-        const uint32_t key_base = t * BN + kh * (32 * NKBW);  // first key of this wave's part of the tile
+        const uint32_t key_base = tile_of(t) * BN + kh * (32 * NKBW);  // first key of this wave's part of the tile
         constexpr uint32_t BNW = BN / KS;                     // keys of it
         // wave-uniform: is any part of this tile visible to this wave's rows?
         bool active = !CAUSAL || key_base <= wave_q0 + 31;
@@ -725,6 +911,14 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
             UMFA_LP_STAMP(lp_tq);
             lp[4] += lp_tq - lp_t1;
 #endif
+            if constexpr (CBAL) {
+                // part B, last step of the long q-block: its Q fragments are dead from here on -- request the short q-block's under this tile's softmax
+                // and P V (stage_write's vmcnt(0) at the end of the step covers them)
+                if (t + 1 == cb_sw) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_q(cb_qb2 * BM + rw * 32 + ql);
+                }
+            }
             // first V^T fragments requested before the softmax so their LDS latency hides under it
             PV8 va[NSTW];
 #pragma unroll
@@ -824,7 +1018,7 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
             constexpr float TAU16 = 6.0f;
             const bool move = mx > m + TAU16;
             // (rows that have seen no key: under a mask tensor, and -- KS = 2 -- the rows of a causal diagonal block's second key half)
-            constexpr bool EMPTY_ROWS = HAS_MASK || KS == 2;
+            constexpr bool EMPTY_ROWS = HAS_MASK || KS == 2 || CBAL;  // (CBAL: a part B starts above tile 0)
             float m_use = (EMPTY_ROWS && m == -INFINITY) ? 0.0f : m;
             if (__any(move)) {
                 const float m_new = move ? mx : m;
@@ -879,6 +1073,9 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
             }
         }
 
+        if constexpr (CBAL) {
+            if (!active && t + 1 == cb_sw) load_q(cb_qb2 * BM + rw * 32 + ql);  // (a wave that sat this tile out)
+        }
         UMFA_LP_STAMP(lp_t2);
 #ifndef UMFA_ABL_NO_LOAD
         stage_write((t + 1) % NS);
@@ -887,6 +1084,11 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
 #ifndef UMFA_ABL_NO_BARRIER
         __syncthreads();
 #endif
+        if constexpr (CBAL) {
+            // part B, the step that began with the switch: every wave's write-through stores of the pair's slot are complete (vmcnt(0) in
+            // stage_write, then the barrier) -- raise the pair's flag
+            if (t == cb_sw && tid == 0) __hip_atomic_store(p.part_cnt + cb_pair, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
 #ifdef UMFA_LAB_LOOP_STAMPS
         {
             UMFA_LP_STAMP(lp_t4);
@@ -897,87 +1099,10 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
     }  // !PIPE
 
     if constexpr (VCONV && !RESWEEP) {
-        // fp16's range, checked where it is free -- on this workgroup's own outputs, once per item: a V value >= 65536 went into LDS as
-        // +-inf and made every output it touches inf / NaN (P >= 0: 0 * inf = NaN, never a silent finite value); outputs that are ALL
-        // below 2^-11 may have met values of V under 2^-17, which fp16 no longer holds exactly (absolute error <= 2^-25, i.e. <= 2^-14 of
-        // an output of 2^-11).  Either way the workgroup takes the largest |v| of its slab and sweeps its keys again with V shifted by
-        // that power of two (the cast pre-pass's rule; fa_fwd16_resweep: this body once more, out of line, from its first instruction).
-        // Decided from the data alone: the same under graph replay, on any stream, and nothing for the host to read.
         if constexpr (NS > 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the ring's youngest requests still land in the tile area)
-        const float lsum = (l4[0] + l4[1]) + (l4[2] + l4[3]);
-        const float lrow = lsum + xor32(lsum);
-        const float inv_c = lrow > 0.0f ? 1.0f / lrow : 0.0f;
-        float chk_nan = 0.0f, chk_max = 0.0f;
-#pragma unroll
-        for (int i = 0; i < NDB; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float val = acc[i][r] * inv_c;
-                chk_nan = __builtin_fmaf(val, 0.0f, chk_nan);
-                chk_max = fmaxf(chk_max, __builtin_fabsf(val));
-            }
-        const bool rowok = q_row < p.Sq;  // (rows past Sq were computed on zero Q rows: their "outputs" are means of V, and say nothing)
-        const unsigned bits = (__builtin_amdgcn_ballot_w64(rowok && chk_nan != chk_nan) != 0 ? 1u : 0u) |
-                              (__builtin_amdgcn_ballot_w64(rowok && chk_max >= 0x1p-11f) != 0 ? 2u : 0u) |
-                              (__builtin_amdgcn_ballot_w64(rowok && lrow > 0.0f) != 0 ? 4u : 0u);
-        volatile uint32_t* const red = (volatile uint32_t*)smem;  // the tile area: every wave is behind the loop's last barrier
-        if (lane == 0) red[wave] = bits;
-        __syncthreads();
-        unsigned all = 0;
-#pragma unroll
-        for (int w2 = 0; w2 < NT / 64; ++w2) all |= red[w2];
-        all = __builtin_amdgcn_readfirstlane(all);
-        // non-finite, or rows with keys and nothing above 2^-11  (otherwise on: the words stay -- the tile area is not read again, and the
-        // folds below write before they read)
-        if (__builtin_expect((all & 1u) || ((all & 4u) && !(all & 2u)), 0)) {
-            unsigned amax = 0;
-            const uint32_t d8 = (uint32_t)D / 8u, nch = p.Skv * d8;
-            for (uint32_t c = (uint32_t)tid; c < nch; c += NT) {
-                const uint32_t row = c / d8, ch = c - row * d8;
-                const u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, (int)(row * (uint32_t)v_stride_b + ch * 16u), 0, 0);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const unsigned a = r4[j] & 0x7fff7fffu, m2 = (a & 0xffffu) > (a >> 16) ? (a & 0xffffu) : (a >> 16);
-                    amax = amax > m2 ? amax : m2;
-                }
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const unsigned o2 = (unsigned)__shfl_xor((int)amax, off, 64);
-                amax = amax > o2 ? amax : o2;
-            }
-            __syncthreads();
-            if (lane == 0) red[wave] = amax;
-            __syncthreads();
-            amax = 0;
-#pragma unroll
-            for (int w2 = 0; w2 < NT / 64; ++w2) amax = amax > red[w2] ? amax : red[w2];
-            amax = __builtin_amdgcn_readfirstlane(amax);
-            __syncthreads();
-            // V all zero (the outputs were right), V with inf / NaN in it (they are what they should be: non-finite), V already where the
-            // shift would put it: nothing a second sweep improves
-            const int e2 = vscale_exponent_of(amax);
-            if (amax != 0 && amax < 0x7f80u && e2 != 0) {
-                return e2;  // -> the kernel runs the RESWEEP copy
-            }
-        }
+        if (const int e2 = v_range_check((volatile uint32_t*)smem)) return e2;
     }
-    if constexpr (RESWEEP) {  // the shift comes back (exact): everything below -- fold, output -- sees the values of the unshifted V
-        const float back = __uint_as_float((unsigned)(127 + vexp) << 23);
-#pragma unroll
-        for (int i = 0; i < NDB; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] *= back;
-    } else if constexpr (PV16 == 2) {
-        // the cast pre-pass shifted this slab's V by a power of two (FwdParams::vsc): back, before anything is published
-        if (p.vsc) {
-            const float back = p.vsc[128 * ((size_t)b * p.vsc_bs + (size_t)h * p.vsc_hs) + 65];
-#pragma unroll
-            for (int i = 0; i < NDB; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][r] *= back;
-        }
-    }
+    v_shift_back();
 
 #ifdef UMFA_LAB_STAMPS
     stamp[2] = __builtin_amdgcn_s_memrealtime();
@@ -1016,6 +1141,44 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
             for (int r = 0; r < 16; ++r) acc[i][r] = acc[i][r] * a0 + ex[(16 * i + r) * 64] * a1;
         lt = lt * a0 + lo * a1;
         m = mn;
+    }
+    if constexpr (CBAL) {
+        if (cb_role == 1) {
+            // part A: fold the pair's part B in (it was published tiles ago: B's share of the long q-block is the shorter one).  The wait is
+            // bounded all the same -- two seconds, then the rows come out NaN rather than the queue hanging
+            volatile uint32_t& flag_s = *(volatile uint32_t*)smem;  // (the tile area is free: every LDS-DMA write has landed, every wave is behind the loop's last barrier)
+            if (tid == 0) {
+                const uint64_t t_in = __builtin_amdgcn_s_memrealtime();
+                uint32_t f = cb_early;
+                while (f == 0 && __builtin_amdgcn_s_memrealtime() - t_in < 200000000ull) {
+                    __builtin_amdgcn_s_sleep(2);
+                    f = __hip_atomic_load(p.part_cnt + cb_pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (f != 0) __hip_atomic_store(p.part_cnt + cb_pair, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // zero between launches
+                flag_s = f;
+            }
+            __syncthreads();
+            UMFA_CB_STAMP(2);
+            const bool got = flag_s != 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler-only: the payload loads stay below the flag
+            const auto prs = cb_rsrc();
+            const int base = (wave * CB_CH) * 1024 + lane * 16;
+            typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+            f32x4 x[CB_CH];
+#pragma unroll
+            for (int c = 0; c < CB_CH; ++c) x[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, base + c * 1024, 0, 16));
+            const float mo = x[4 * NDB][0], lo = x[4 * NDB][1];
+            const float mn = fmaxf(m, mo);
+            const float mu = mn == -INFINITY ? 0.0f : mn;
+            const float a0 = got ? __builtin_amdgcn_exp2f(m - mu) : __builtin_nanf(""), a1 = __builtin_amdgcn_exp2f(mo - mu);
+#pragma unroll
+            for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] = acc[i][r] * a0 + x[4 * i + (r >> 2)][r & 3] * a1;
+            lt = lt * a0 + lo * a1;
+            m = mn;
+            UMFA_CB_STAMP(3);
+        }
     }
     if (KS == 1 && nparts > 1) {
         // Split-KV combine (cdna_hip_programming.md Guideline 16, "every load sc1" form -- the fold protocol of fa_fwd16_w64): every
@@ -1120,8 +1283,11 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     stamp[3] = __builtin_amdgcn_s_memrealtime();
     if (tid == 0) {  // a debug buffer of its own (lab only): [block][6]
-        unsigned long long* dbg = (unsigned long long*)p.part_buf + (size_t)bid_in * 8;
+        // (CBAL: behind the pairs' slots)
+        unsigned long long* const dbg0 = (unsigned long long*)p.part_buf + (CBAL ? (size_t)(gridDim.x / 2) * (4 * CB_CH * 1024 / 8) : 0);
+        unsigned long long* dbg = dbg0 + (size_t)bid_in * 8;
         for (int i = 0; i < 6; ++i) dbg[i] = stamp[i];
+        if (CBAL) for (int i = 0; i < 4; ++i) dbg0[(size_t)gridDim.x * 16 + (size_t)bid_in * 4 + i] = cbs[i];
         unsigned xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         dbg[6] = xcc;
@@ -1129,7 +1295,7 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         dbg[7] = hwid;
 #ifdef UMFA_LAB_LOOP_STAMPS
-        dbg = (unsigned long long*)p.part_buf + (size_t)gridDim.x * 8 + (size_t)bid_in * 6;
+        dbg = dbg0 + (size_t)gridDim.x * 8 + (size_t)bid_in * 6;
         for (int i = 0; i < 6; ++i) dbg[i] = lp[i];
 #endif
     }

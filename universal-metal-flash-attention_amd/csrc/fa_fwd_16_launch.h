@@ -6,18 +6,19 @@
 
 namespace umfa {
 
-template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT, bool DMA, int BN, int PV16 = 0, int KS = 1, int PIPE = 0>
+template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT, bool DMA, int BN, int PV16 = 0, int KS = 1, int PIPE = 0, bool CBAL = false>
 static inline hipError_t launch_dma(const FwdParams& pin, hipStream_t stream) {
     FwdParams p = pin;
     const uint32_t nqb = (p.Sq + 127) / 128;
     const uint32_t items = nqb * p.B * p.H;
-    if (KS != 1 || PIPE || p.nsplit < 2 || !p.part_buf || !p.part_cnt) { p.n_full = items; p.nsplit = 1; }
+    if (KS != 1 || PIPE || CBAL || p.nsplit < 2 || !p.part_buf || !p.part_cnt) { p.n_full = items; p.nsplit = 1; }
+    if (CBAL && (!p.part_buf || !p.part_cnt || (nqb & 1))) return hipErrorInvalidValue;  // (the plan's scratch: one slot and one flag per pair)
     const uint32_t grid = p.n_full + (items - p.n_full) * p.nsplit;
     // (p.part_cnt is zero on entry and on exit: the runtime zeroes a ticket block once, the folding workgroup resets its word)
     // 2 x ring depth (fa_fwd_16_kernel.h NS: 2, key-split form 4) tiles; the key halves' exchange (4 x 34 x 256 bytes at head_dim 64) fits inside
     const size_t lds = (KS == 2 ? 8 : 4) * BN * DP * 2;
     static_assert(KS == 1 || 8 * BN * DP * 2 >= 4 * (16 * (DP / 32) + 2) * 256, "exchange area");
-    auto kfn = fa_fwd16_kernel<T, DP, CAUSAL, HAS_MASK, OUT, DMA, BN, PV16, KS, PIPE>;
+    auto kfn = fa_fwd16_kernel<T, DP, CAUSAL, HAS_MASK, OUT, DMA, BN, PV16, KS, PIPE, CBAL>;
     if (hipError_t e = ensure_dynamic_lds((const void*)kfn, lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(256 * KS), lds, stream, p);
     return hipGetLastError();

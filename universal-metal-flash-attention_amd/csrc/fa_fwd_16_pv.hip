@@ -31,6 +31,11 @@ hipError_t launch_fwd16_pv(const FwdParams& p, hipStream_t stream) {
                                : launch_dma<__bf16, DP, CAUSAL, HAS_MASK, OUT, true, 64, 1, 2>(p, stream);
 #endif
     }
+    if constexpr (CAUSAL && !HAS_MASK && (DP == 64 || DP == 128)) {
+        if (dma && p.cbal && p.part_buf && p.part_cnt)  // balanced causal pairs (fwd_16_split_plan)
+            return p.pv16 == 2 ? launch_dma<__bf16, DP, CAUSAL, HAS_MASK, OUT, true, 64, 2, 1, 0, true>(p, stream)
+                               : launch_dma<__bf16, DP, CAUSAL, HAS_MASK, OUT, true, 64, 1, 1, 0, true>(p, stream);
+    }
     if (p.pv16 == 2)
         return dma ? launch_dma<__bf16, DP, CAUSAL, HAS_MASK, OUT, true, 64, 2>(p, stream) : launch_dma<__bf16, DP, CAUSAL, HAS_MASK, OUT, false, 64, 2>(p, stream);
     return dma ? launch_dma<__bf16, DP, CAUSAL, HAS_MASK, OUT, true, 64, 1>(p, stream) : launch_dma<__bf16, DP, CAUSAL, HAS_MASK, OUT, false, 64, 1>(p, stream);

@@ -163,6 +163,15 @@ hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p,
             pp.nsplit = plan.nsplit;
             pp.part_cnt = (uint32_t*)buf;
             pp.part_buf = (float*)(buf + sc.split_cnt_bytes);
+        } else if (plan.cbal) {
+            // balanced causal pairs: flags first, the pairs' slots behind them.  Without the block (the pool may not grow while the stream
+            // is capturing) the launch runs unpaired -- the same arithmetic per tile, another order of the row sums
+            if (char* buf = sc.ensure_split(plan.cnt_bytes, plan.buf_bytes, stream)) {
+                pp.cbal = 1;
+                pp.cbal_delta = plan.cbal_delta;
+                pp.part_cnt = (uint32_t*)buf;
+                pp.part_buf = (float*)(buf + sc.split_cnt_bytes);
+            }
         }
         if (pp.mask_kind != MK_NONE && !tuning().no_mask_flags.load(std::memory_order_relaxed) && mask_flags_worthwhile(pp)) {
             // tile early-exit for masks: one pre-pass over the distinct mask elements classifies every (32 rows x 64
