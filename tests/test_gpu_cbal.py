@@ -114,6 +114,23 @@ def test_each_part_decides_its_own_second_sweep(key, D):
     assert np.abs(ot.cpu().numpy() - reft).max() / np.abs(reft).max() < NORTH_STAR
 
 
+def test_second_sweep_publishes_once():
+    """a part B whose tail was fine (published, flag raised) and whose SHORT block then needs the second sweep must not publish again: the
+    flag would stay up behind the launch and the next launch's part A would fold a slot that is still being written (found by
+    tools/lab/value_fuzz.py run_cbal_case: launches after such a one were not repeatable)"""
+    torch.manual_seed(21)
+    q, k, v = (torch.randn(2, 3, 1024, 64, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    vx = v.clone()
+    vx[:, :, 40, 5] = 3.0e8  # tile 0: every short block and every part A see it, no long block's tail does
+    first, _ = _run(q, k, v, out_dtype=torch.float32)
+    for _ in range(6):
+        ox, _ = _run(q, k, vx, out_dtype=torch.float32)
+        assert torch.isfinite(ox).all()
+        again, _ = _run(q, k, v, out_dtype=torch.float32)
+        assert torch.equal(first, again)
+    assert _rel(first, _ref(q, k, v)) < NORTH_STAR
+
+
 def test_bitwise_repeatable_and_graph_replay_with_changing_data():
     """the fold is one fixed order (A's registers, then B's slot): launches repeat bit for bit; the pairs' flags are left zero, so a captured
     graph replays with other data and gives that data's result"""

@@ -145,3 +145,10 @@ def test_w64_mask_kernels_random_cases(seed):
     msg = _fuzz().run_w64_mask_case(seed)
     assert msg is None, msg
 
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_paired_causal_schedule_random_cases(seed):
+    """the 128-row kernel's balanced causal pairs (round 6, option cbal): random launches, every cut, ragged lengths, V outside fp16's range, graph replays"""
+    msg = _fuzz().run_cbal_case(seed)
+    assert msg is None, msg

@@ -1253,11 +1253,93 @@ def run_w64_mask_case(seed):
     return None
 
 
+def run_cbal_case(seed):
+    """(round 6) the paired causal schedule of the 128-row kernel (option cbal = 1, fa_fwd_16_kernel.h CBAL) on random causal launches: any even
+    number of 128-row q-blocks, ragged / unequal Sq and Skv, every cut position, head_dim 64 / 128, bf16 (converting kernel, bf16 P V) and fp16,
+    strided inputs, adversarial score patterns and V beyond fp16's range (either part of a pair may have to sweep again), LSE; each launch
+    twice (bitwise), sometimes inside a captured graph replayed with other data (the pairs' flags must come back to zero)"""
+    rng = random.Random(seed + 9700000)
+    dt = rng.choice([torch.bfloat16, torch.bfloat16, torch.float16])
+    D = rng.choice([64, 128])
+    B, H = rng.choice([1, 2, 3]), rng.choice([1, 2, 3, 5])
+    nqb = rng.choice([2, 2, 4, 4, 6, 8, 10, 16])
+    Sq = 128 * nqb - rng.choice([0, 0, 0, 1, 17, 64, 127])
+    Skv = rng.choice([Sq, Sq, Sq, Sq + 64, Sq + 1000, max(Sq - 100, 1), max(Sq // 2, 1), 65, 2 * Sq])
+    strided = rng.random() < 0.25
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    def mk(S):
+        if strided:
+            return torch.randn(B, S, H, D, device="cuda", generator=g).to(dt).transpose(1, 2)
+        return torch.randn(B, H, S, D, device="cuda", generator=g).to(dt)
+    q, k, v = mk(Sq), mk(Skv), mk(Skv)
+    kind = rng.choice(["plain", "plain"] + KINDS)
+    if kind != "plain":
+        q, k, v = transform(rng, q, k, v, kind)
+    # (V regimes on ordinary scores only: an outlier of 7e9 under a probability of 2^-18 is a product whose error is the 16-bit P's own -- fp16
+    # subnormal or bf16's 8 bits, paired or not: tools/lab/cbal_dbg45.py)
+    vreg = rng.choice(["plain", "plain", "plain", "outlier", "tiny", "row_scaled"]) if dt == torch.bfloat16 and kind == "plain" else "plain"
+    if vreg == "outlier":
+        v = v.clone(); v[rng.randrange(B), rng.randrange(H), rng.randrange(Skv), rng.randrange(D)] = rng.choice([3.0e8, -7.0e9, 70000.0])
+    elif vreg == "tiny":
+        v = (v.float() * 1e-7).to(dt)
+    elif vreg == "row_scaled":
+        v = v.clone(); v[:, :, Skv // 2:] = (v[:, :, Skv // 2:].float() * 4096.0).to(dt)
+    opts = {"cbal": 1, "no_w64": 1, "cbal_delta": rng.choice([-1, 0, 1, 2, 3, 7])}
+    if dt == torch.bfloat16 and rng.random() < 0.25:
+        opts["pv_fp16"] = 0
+    i = torch.arange(Sq, device="cuda")[:, None]
+    j = torch.arange(Skv, device="cuda")[None, :]
+    try:
+        with umfa_torch.options(**opts):
+            out, lse = umfa_torch.attention_forward(q, k, v, causal=True, out_dtype=torch.float32, return_lse=True)
+            kern = umfa_torch.last_kernel()
+            o2 = umfa_torch.attention_forward(q, k, v, causal=True, out_dtype=torch.float32)
+            graph_rel = None
+            if rng.random() < 0.3:
+                ob = torch.empty_like(out)
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    gr = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gr, stream=side):
+                        umfa_torch.attention_forward(q, k, v, causal=True, out=ob)
+                    q2 = (q.float() * 0.7 + 0.1).to(dt)
+                    q.copy_(q2)
+                    gr.replay(); gr.replay()
+                    side.synchronize()
+                torch.cuda.current_stream().wait_stream(side)
+                r2, _ = ref64(q, k, v, D ** -0.5, j <= i)
+                graph_rel = ((ob.double() - r2).abs().amax(dim=(2, 3)) / r2.abs().amax(dim=(2, 3)).clamp_min(1e-30)).max().item()
+        what = (seed, str(dt), B, H, Sq, Skv, D, kind, vreg, strided, opts, kern)
+        if not kern.startswith("fa_fwd16<"):
+            return "kernel %r" % (what,)
+        if graph_rel is None:
+            if not torch.isfinite(out).all():
+                return "non-finite %r" % (what,)
+            if not torch.equal(out, o2):
+                return "not bitwise repeatable %r" % (what,)
+            ref, rl = ref64(q, k, v, D ** -0.5, j <= i)
+            # per (batch, head) slab: a slab with a V of its own scale is judged against it
+            rel = ((out.double() - ref).abs().amax(dim=(2, 3)) / ref.abs().amax(dim=(2, 3)).clamp_min(1e-30)).max().item()
+            lg = lse.view(B, H, Sq).double()
+            lerr = ((lg - rl).abs() / rl.abs().clamp_min(50.0)).max().item()
+            bound = CEIL[dt] if opts.get("pv_fp16", 1) == 0 or dt == torch.float16 else 2.0 ** -11 * 1.5
+            if vreg == "row_scaled":
+                bound = max(bound, 1.5e-3)
+            if rel > bound or lerr > 1e-3:
+                return "rel %.3e lse %.3e %r" % (rel, lerr, what)
+        elif graph_rel > (CEIL[dt] if opts.get("pv_fp16", 1) == 0 or dt == torch.float16 else 1.5e-3):
+            return "graph replay rel %.3e %r" % (graph_rel, what)
+    except Exception as e:  # noqa: BLE001
+        return "exception %r %s" % ((seed, kind, vreg), repr(e)[:300])
+    return None
+
+
 if __name__ == "__main__":
     first, count = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 200)
     bad = 0
     for seed in range(first, first + count):
-        for fn in ((run_case, run_bwd_case, run_shape_case, run_i8_case, run_gqa_case, run_rope_case, run_streams_case, run_graph_case, run_mask_case, run_host_case, run_qbwd_case, run_prequant_case, run_aux_case, run_threads_case, run_big_case, run_bwd_shape_case, run_wide_case, run_qmask_case, run_w64_mask_case) if len(sys.argv) < 4 else (globals()[sys.argv[3]],)):
+        for fn in ((run_case, run_bwd_case, run_shape_case, run_i8_case, run_gqa_case, run_rope_case, run_streams_case, run_graph_case, run_mask_case, run_host_case, run_qbwd_case, run_prequant_case, run_aux_case, run_threads_case, run_big_case, run_bwd_shape_case, run_wide_case, run_qmask_case, run_w64_mask_case, run_cbal_case) if len(sys.argv) < 4 else (globals()[sys.argv[3]],)):
             msg = fn(seed)
             if msg:
                 bad += 1

@@ -244,8 +244,10 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
         } else {
             qb = qj;
             cb_a = (uint32_t)a;
-            if (is_b) { cb_role = 2; cb_sw = nj - cb_a; cb_qb2 = qi; cb_n2 = ni; }
-            else cb_role = 1;
+            if (!is_b) cb_role = 1;
+            else if (RESWEEP && (vexp_in & 0x10000)) qb = qi;  // second sweep of a part B whose tail was fine and IS published (the pair's flag is up or
+                                                              // already taken): the short q-block whole, nothing published twice
+            else { cb_role = 2; cb_sw = nj - cb_a; cb_qb2 = qi; cb_n2 = ni; }
         }
     } else
     if (causal_split) {
@@ -361,7 +363,8 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
         __syncthreads();
     }
     // VCONV: V is converted as v * 2^-vexp: 0 in the kernel proper, the slab's power of two in the second sweep (RESWEEP)
-    const int vexp = RESWEEP ? vexp_in : 0;
+    // (CBAL: bit 16 of the first sweep's return value says "part B, tail already published": see the work assignment)
+    const int vexp = RESWEEP ? (int)(int16_t)(vexp_in & 0xffff) : 0;
     const float vmul = __uint_as_float((unsigned)(127 - vexp) << 23);
     (void)vmul;
     // which: 1 = K tile, 2 = V tile, 3 = both.  SPLIT_DMA: the V half is issued behind the QK^T MFMAs instead of back
@@ -646,7 +649,7 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
             __syncthreads();
             if (tid < 4) red[tid] = 0;  // (the tile areas start from zeros: rows past Skv are never written)
         }
-        if (e2) return e2;
+        if (e2) return e2 & 0xffff;  // (nothing published yet: the second sweep publishes)
         v_shift_back();
         const float lsum = (l4[0] + l4[1]) + (l4[2] + l4[3]);
         const float lrow = lsum + xor32(lsum);
@@ -660,6 +663,11 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4{acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]}),
                                                        prs, base + (4 * i + g) * 1024, 0, 16);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4{lrow > 0.0f ? m : -INFINITY, lrow, 0.0f, 0.0f}), prs, base + (4 * NDB) * 1024, 0, 16);
+#ifdef UMFA_CB_LAB_IMMEDIATE_FLAG
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(p.part_cnt + cb_pair, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         // (the flag follows at the END of this step, behind stage_write's vmcnt(0) and the step's barrier: nothing waits for the stores here)
         // the second q-block: its Q fragments were requested during the step before (behind that step's Q K^T)
         qb = cb_qb2;
@@ -844,7 +852,9 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
         UMFA_LP_STAMP(lp_t0);
         if constexpr (CBAL) {
             // part A: a first look at the pair's flag, a step ahead of the fold (the load's round trip hides under the last tile)
+#ifndef UMFA_CB_LAB_NO_EARLY
             if (cb_role == 1 && t + 1 == t_end && tid == 0) cb_early = __hip_atomic_load(p.part_cnt + cb_pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
             if (t == cb_sw) {  // part B: the long q-block's tail is done -- publish it, go on with the short q-block
                 UMFA_CB_STAMP(0);
                 if (const int e2 = cb_switch(t)) return e2;
@@ -1087,7 +1097,9 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
         if constexpr (CBAL) {
             // part B, the step that began with the switch: every wave's write-through stores of the pair's slot are complete (vmcnt(0) in
             // stage_write, then the barrier) -- raise the pair's flag
+#ifndef UMFA_CB_LAB_IMMEDIATE_FLAG
             if (t == cb_sw && tid == 0) __hip_atomic_store(p.part_cnt + cb_pair, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
         }
 #ifdef UMFA_LAB_LOOP_STAMPS
         {
@@ -1100,7 +1112,7 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
 
     if constexpr (VCONV && !RESWEEP) {
         if constexpr (NS > 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the ring's youngest requests still land in the tile area)
-        if (const int e2 = v_range_check((volatile uint32_t*)smem)) return e2;
+        if (const int e2 = v_range_check((volatile uint32_t*)smem)) return (e2 & 0xffff) | (CBAL && cb_role == 2 ? 0x10000 : 0);
     }
     v_shift_back();
 
@@ -1146,7 +1158,8 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
         if (cb_role == 1) {
             // part A: fold the pair's part B in (it was published tiles ago: B's share of the long q-block is the shorter one).  The wait is
             // bounded all the same -- two seconds, then the rows come out NaN rather than the queue hanging
-            volatile uint32_t& flag_s = *(volatile uint32_t*)smem;  // (the tile area is free: every LDS-DMA write has landed, every wave is behind the loop's last barrier)
+            // (the tile area is free: every LDS-DMA write has landed, every wave is behind the loop's last barrier; word 16: the range check's four words may still be read)
+            volatile uint32_t& flag_s = *((volatile uint32_t*)smem + 16);
             if (tid == 0) {
                 const uint64_t t_in = __builtin_amdgcn_s_memrealtime();
                 uint32_t f = cb_early;
