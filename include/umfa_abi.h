@@ -248,7 +248,7 @@ mfa_error_t mfa_set_scale_arrays(mfa_context_t context, const float* q_scales,
  * a scale buffer is passed, one fp32 scale (+ optional int32 zero point) per block of `*_block_size` consecutive rows of
  * a (batch, head) slab, laid out [batch][head][block].  O, dO, LSE, D and the gradients are fp32 dense BHSD; softmax
  * scale 1/sqrt(head_dim); num_kv_heads may divide num_heads (grouped K/V: dK / dV are summed over the group).  The
- * query call writes dQ and D, the kv call reads D.  head_dim <= 256; transpose_o must be false. ---------------- */
+ * query call writes dQ and D, the kv call reads D.  head_dim <= 1024 (257 ... 1024: the wide fp32 backward); transpose_o must be false. -- */
 #define UMFA_QBWD_TAIL                                                                            \
     float q_scale, int32_t q_zero_point, float k_scale, int32_t k_zero_point, float v_scale,      \
         int32_t v_zero_point, int32_t q_precision, int32_t k_precision, int32_t v_precision,      \

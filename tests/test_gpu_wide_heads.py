@@ -152,3 +152,106 @@ def test_limits():
     with pytest.raises(MFAError) as ei:
         umfa_torch.attention_backward(q, q, k, v, o, lse, scale=1.0)
     assert ei.value.code == 1
+
+
+# ---- round 6: the quantised entries and the fused-RoPE entry above head_dim 256 (round 5 returned MFA_ERROR_INVALID_ARGS there) ----
+def _rel(a, ref):
+    return float(np.abs(np.asarray(a, np.float64) - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+@pytest.mark.parametrize("D", [320, 512, 1024])
+@pytest.mark.parametrize("bits,mode", [(8, "blockwise"), (8, "tensor"), (4, "blockwise")])
+@pytest.mark.parametrize("causal", [False, True])
+def test_quantized_forward_blocking_entry(D, bits, mode, causal):
+    """mfa_quantized_forward_with_lse (MFABridge+Quantized.swift:227-358) at head dims 257 ... 1024: the quantiser's integers per 64-row block
+    (two sweeps over the block), q * s as fp32 images, the wide fp32 forward -- against the oracle's quantised restatement"""
+    import umfa
+    orc = _oracle()
+    rng = np.random.default_rng(D + bits)
+    shape = (1, 2, 150, D)
+    q, k, v = (rng.standard_normal(shape).astype(np.float32) for _ in range(3))
+    with umfa.MFAContext() as ctx:
+        o, lse = umfa.quantized_attention(ctx, q, k, v, causal=causal, precision=f"int{bits}", quant_mode=mode, layout="bhsd", return_lse=True)
+        assert ctx.last_kernel.startswith("fa_fwd_wide<i"), ctx.last_kernel
+    ref, rlse = orc.quantized_forward(q, k, v, causal=causal, bits=bits, quant_mode=0 if mode == "tensor" else 2)
+    assert np.isfinite(o).all()
+    assert _rel(o, ref) < 2e-5, _rel(o, ref)  # same integers, fp32 arithmetic on both products: nothing rounded to 16 bits
+    assert np.abs(lse.reshape(rlse.shape) - rlse).max() < 1e-4
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_quantized_forward_stream_entry_with_masks(dt):
+    """in-stream, 16-bit operands, the ABI's dense fp32 mask and the caller's own bool tensor"""
+    import umfa_torch
+    orc = _oracle()
+    torch.manual_seed(3)
+    B, H, Sq, Skv, D = 1, 2, 130, 200, 384
+    q = torch.randn(B, H, Sq, D, device="cuda", dtype=dt)
+    k, v = (torch.randn(B, H, Skv, D, device="cuda", dtype=dt) for _ in range(2))
+    o, lse = umfa_torch.quantized_attention_forward_stream(q, k, v, bits=8, return_lse=True)
+    assert umfa_torch.last_kernel().startswith("fa_fwd_wide<i8")
+    ref, rlse = orc.quantized_forward(npy(q) if dt == torch.bfloat16 else q.cpu().numpy(), npy(k) if dt == torch.bfloat16 else k.cpu().numpy(),
+                                      npy(v) if dt == torch.bfloat16 else v.cpu().numpy(), bits=8, quant_mode=2)
+    assert _rel(o.cpu().numpy(), ref) < 2e-5
+    keep = torch.rand(1, 1, Sq, Skv, device="cuda") > 0.3
+    keep[..., 0] = True
+    om = umfa_torch.quantized_attention_forward_stream(q, k, v, mask=keep, bits=8)
+    full = torch.zeros(B, H, Sq, Skv).masked_fill(~keep.cpu().expand(B, H, Sq, Skv), float("-inf")).numpy()
+    refm, _ = orc.quantized_forward(npy(q) if dt == torch.bfloat16 else q.cpu().numpy(), npy(k) if dt == torch.bfloat16 else k.cpu().numpy(),
+                                    npy(v) if dt == torch.bfloat16 else v.cpu().numpy(), mask=full, bits=8, quant_mode=2)
+    assert _rel(om.cpu().numpy(), refm) < 2e-5
+
+
+@pytest.mark.parametrize("D", [320, 640])
+def test_quantized_backward_entries(D):
+    """mfa_quantized_backward / umfa_quantized_backward_stream (MFABridge+Quantized.swift:365-533) above head_dim 256: quantise -> q * s as fp32 ->
+    the wide fp32 backward; gradients of the de-quantised operands (STE) against the oracle's fp64 backward on the same operands"""
+    import umfa_torch
+    orc = _oracle()
+    torch.manual_seed(D)
+    B, H, S = 1, 2, 128
+    q, k, v, do = (torch.randn(B, H, S, D, device="cuda", dtype=torch.float32) for _ in range(4))
+    o, lse = umfa_torch.quantized_attention_forward_stream(q, k, v, bits=8, return_lse=True)
+    dq, dk, dv, status = umfa_torch.quantized_attention_backward_stream(do, q, k, v, o, lse, bits=8)
+    assert umfa_torch.last_kernel().startswith("fa_bwd_wide"), umfa_torch.last_kernel()
+    assert int(status.item()) == 0
+
+    def fake(x):
+        x = x.cpu().numpy()
+        out = np.empty_like(x)
+        for h in range(H):
+            qv, sc = orc.quantize_symmetric(x[0, h], group=64 * D)
+            out[0, h] = orc.dequantize(qv, sc, group=64 * D).reshape(S, D)
+        return out
+    fq, fk, fv = fake(q), fake(k), fake(v)
+    rdq, rdk, rdv, _ = orc.sdpa_backward(do.cpu().numpy(), fq, fk, fv, o.cpu().numpy(), lse.cpu().numpy().reshape(B, H, S))
+    for got, ref, name in [(dq, rdq, "dq"), (dk, rdk, "dk"), (dv, rdv, "dv")]:
+        assert np.abs(got.cpu().numpy() - ref).max() < 2e-4 * max(1.0, np.abs(ref).max()), name
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("D", [320, 1024])
+def test_fused_rope_entry(dt, D):
+    """umfa_rope_attention_forward_stream above head_dim 256: rotate Q and K (the rotate kernel), then the wide forward -- the reference's
+    sequence (metal_sdpa_backend.cpp:1472-1641); bit-identical to the three calls, and against the oracle"""
+    import umfa_torch
+    from umfa_torch import ops
+    from oracle import oracle
+    torch.manual_seed(D)
+    B, H, S = 2, 2, 96
+    q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=dt) for _ in range(3))
+    pos = torch.arange(S, device="cuda", dtype=torch.float32)[:, None]
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2, device="cuda", dtype=torch.float32) / D))
+    ang = (pos * inv[None, :]).repeat_interleave(2, dim=1)
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    out = ops.rope_attention_forward(q, k, v, cos, sin, causal=True, out_dtype=torch.float32)
+    assert umfa_torch.last_kernel().startswith("fa_fwd_wide<")
+    ref3 = ops.attention_forward(ops.rope_rotate(q, cos, sin), ops.rope_rotate(k, cos, sin), v, causal=True, out_dtype=torch.float32)
+    assert torch.equal(out, ref3)
+    c, s_ = cos.cpu().numpy(), sin.cpu().numpy()
+    if dt == torch.bfloat16:
+        qr, kr = oracle.f32_to_bf16_bits(oracle.rope_rotate(npy(q), c, s_)), oracle.f32_to_bf16_bits(oracle.rope_rotate(npy(k), c, s_))
+    else:
+        qr, kr = oracle.rope_rotate(npy(q), c, s_), oracle.rope_rotate(npy(k), c, s_)
+    ref = oracle.sdpa_forward(qr, kr, npy(v), causal=True)
+    assert _rel(out.cpu().numpy(), ref) < (2e-5 if dt == torch.float32 else 1e-4)  # (fp32 sums over up to 1024 products of operands rounded to bf16 after the rotation)

@@ -480,6 +480,48 @@ __global__ __launch_bounds__(256) void tensor_scale_kernel(float* s0, uint32_t n
     for (uint32_t i = threadIdx.x; i < n; i += 256) s[i] = sc;
 }
 
+// Head dims 257 ... 1024 (the reference's callers admit them: metal_sdpa_backend.cpp:1078-1086; its quantised entry has no limit of its own,
+// MFABridge+Quantized.swift:227-358): the quantiser's arithmetic per 64-row block -- absmax, s = absmax / qmax, q = clamp(round-half-away(x / s)) --
+// as two sweeps over the block in memory (a 64 x 1024 block does not fit a workgroup's registers), leaving q * s as fp32 for the wide fp32
+// forward / backward (fa_fwd_wide.hip, fa_bwd_wide.hip).  Correct to the oracle's integers like the register kernels; not tuned.
+// MODE as quantize_kernel: 0 block absmax only, 1 scales given, 2 both.
+template <int MODE>
+__global__ __launch_bounds__(256) void quantize_wide_kernel(QuantParams p) {
+    __shared__ float red[4];
+    uint32_t id = blockIdx.x;
+    int t = p.t_first;
+    while (t < p.t_end - 1 && id >= p.BH * p.nblk[t]) { id -= p.BH * p.nblk[t]; ++t; }
+    const uint32_t bh = id / p.nblk[t], blk = id % p.nblk[t];
+    const uint32_t row0 = blk * QBLK;
+    const uint32_t nrows = min((uint32_t)QBLK, p.rows[t] - row0);
+    const int64_t base = ((int64_t)bh * p.rows[t] + row0) * p.D;
+    const uint32_t n = nrows * p.D;
+    float sc;
+    if (MODE != 1) {
+        float amax = 0.0f;
+        for (uint32_t i = threadIdx.x; i < n; i += 256) amax = fmaxf(amax, fabsf(load_as_float(p.src[t], base + i, p.in_prec)));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+        __syncthreads();
+        amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (MODE == 0) {
+            if (threadIdx.x == 0) p.scale[t][bh * p.nblk[t] + blk] = amax;
+            return;
+        }
+        sc = amax > 0.0f ? amax / p.qmax : 1.0f;
+        if (threadIdx.x == 0) p.scale[t][bh * p.nblk[t] + blk] = sc;
+    } else {
+        sc = p.scale[t][bh * p.nblk[t] + blk];
+    }
+    float* const dst = p.f32[t] + base;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const float y = load_as_float(p.src[t], base + i, p.in_prec) / sc;  // (the correctly rounded divide the register kernels reproduce)
+        const int qv = max(min((int)(y + __builtin_copysignf(0x1.fffffep-2f, y)), p.qhi), p.qlo);
+        dst[i] = (float)qv * sc;
+    }
+}
+
 // ------------------------------------------------------------------ int8 QK^T forward
 template <int DP> __device__ __forceinline__ constexpr int k8_off(int row, int ch) {  // rows of DP bytes, 16-B chunks
     int sw = DP >= 256 ? (ch ^ (row & 15)) : DP == 128 ? (ch ^ ((row >> 1) & 7)) : (ch ^ ((row >> 2) & 3));
@@ -851,6 +893,18 @@ static WsLayout ws_layout(uint32_t B, uint32_t H, uint32_t Sq, uint32_t Skv, uin
     const size_t nqb = (Sq + QBLK - 1) / QBLK, nkb = (Skv + QBLK - 1) / QBLK;
     WsLayout w;
     size_t off = 0;
+    if (D > 256) {  // the wide path (quantize_wide_kernel): block scales and the fp32 images q * s only
+        w.q8 = w.k8 = w.v16 = 0;
+        w.sq = off; off = align256(off + BH * nqb * 4);
+        w.sk = off; off = align256(off + BH * nkb * 4);
+        w.sv = off; off = align256(off + BH * nkb * 4);
+        w.f32q = off; off = align256(off + BH * Sq * D * 4);
+        w.f32k = off; off = align256(off + BH * Skv * D * 4);
+        w.f32v = off; off = align256(off + BH * Skv * D * 4);
+        w.mflags = off;
+        w.total = off;
+        return w;
+    }
     w.q8 = off; off = align256(off + BH * Sq * DP);
     w.k8 = off; off = align256(off + BH * Skv * DP);
     w.v16 = off; off = align256(off + BH * Skv * DP * 2);
@@ -873,11 +927,51 @@ size_t quant_workspace_bytes(uint32_t B, uint32_t H, uint32_t Sq, uint32_t Skv, 
     return ws_layout(B, H, Sq, Skv, D, want_f32).total;
 }
 
-bool quantized_supported(uint32_t D) { return D >= 8 && D % 8 == 0 && D <= 256; }  // and softmax_scale > 0
+bool quantized_supported(uint32_t D) { return D >= 8 && D % 8 == 0 && D <= 1024; }  // and softmax_scale > 0  (257 ... 1024: the wide fp32 path)
+
+// head dims 257 ... 1024: q * s of the three operands as fp32 images in the workspace (views->qf / kf / vf), per-block scales beside them
+static hipError_t launch_quantize_wide(const void* q, const void* k, const void* v, int in_prec, uint32_t B, uint32_t H, uint32_t Sq, uint32_t Skv,
+                                       uint32_t D, int bits, int quant_mode, void* workspace, QuantViews* views, hipStream_t stream) {
+    const WsLayout w = ws_layout(B, H, Sq, Skv, D, true);
+    char* ws = (char*)workspace;
+    QuantParams qp;
+    memset(&qp, 0, sizeof(qp));
+    qp.src[0] = q; qp.src[1] = k; qp.src[2] = v;
+    qp.scale[0] = (float*)(ws + w.sq); qp.scale[1] = (float*)(ws + w.sk); qp.scale[2] = (float*)(ws + w.sv);
+    qp.f32[0] = (float*)(ws + w.f32q); qp.f32[1] = (float*)(ws + w.f32k); qp.f32[2] = (float*)(ws + w.f32v);
+    qp.rows[0] = Sq; qp.rows[1] = Skv; qp.rows[2] = Skv;
+    for (int t = 0; t < 3; ++t) qp.nblk[t] = (qp.rows[t] + QBLK - 1) / QBLK;
+    qp.BH = B * H; qp.D = D; qp.DPQ = D;
+    qp.in_prec = in_prec;
+    qp.qmax = bits == 4 ? 7.0f : 127.0f;
+    qp.qlo = bits == 4 ? -8 : -128;
+    qp.qhi = bits == 4 ? 7 : 127;
+    qp.t_first = 0; qp.t_end = 3;
+    const uint32_t grid = qp.BH * (qp.nblk[0] + qp.nblk[1] + qp.nblk[2]);
+    if (quant_mode == 2 || quant_mode == 3) {
+        hipLaunchKernelGGL(quantize_wide_kernel<2>, dim3(grid), dim3(256), 0, stream, qp);
+    } else {
+        hipLaunchKernelGGL(quantize_wide_kernel<0>, dim3(grid), dim3(256), 0, stream, qp);
+        hipLaunchKernelGGL(tensor_scale_kernel, dim3(3), dim3(256), 0, stream, qp.scale[0], qp.BH * qp.nblk[0], qp.scale[1], qp.BH * qp.nblk[1],
+                           qp.scale[2], qp.BH * qp.nblk[2], qp.qmax);
+        hipLaunchKernelGGL(quantize_wide_kernel<1>, dim3(grid), dim3(256), 0, stream, qp);
+    }
+    if (views) {
+        memset(views, 0, sizeof(*views));
+        views->q_scale = qp.scale[0]; views->k_scale = qp.scale[1]; views->v_scale = qp.scale[2];
+        views->qf = qp.f32[0]; views->kf = qp.f32[1]; views->vf = qp.f32[2];
+        views->nqblk = qp.nblk[0]; views->nkblk = qp.nblk[1]; views->dpq = D;
+    }
+    return hipGetLastError();
+}
 
 hipError_t launch_quantize(const void* q, const void* k, const void* v, int in_prec, uint32_t B, uint32_t H,
                            uint32_t Sq, uint32_t Skv, uint32_t D, int bits, int quant_mode, void* workspace,
                            int copies, QuantViews* views, hipStream_t stream, uint32_t* overflow, uint32_t* vhdr, const uint32_t* famax) {
+    if (D > 256) {  // head dims 257 ... 1024: fp32 images only (the fp32 engines); the fp16-copy form belongs to the 16-bit backward (head_dim <= 256)
+        if (copies == 2) return hipErrorInvalidValue;
+        return launch_quantize_wide(q, k, v, in_prec, B, H, Sq, Skv, D, bits, quant_mode, workspace, views, stream);
+    }
     const bool want_f32 = copies != 0;  // the fp16 copies live in the (twice as large) fp32 regions
     const WsLayout w = ws_layout(B, H, Sq, Skv, D, want_f32);
     char* ws = (char*)workspace;
@@ -995,6 +1089,28 @@ static hipError_t launch_i8_flags(const I8FwdParams& p, bool causal, hipStream_t
 hipError_t launch_quantized_fwd(const FwdParams& fp, int bits, int quant_mode, void* workspace, hipStream_t stream,
                                 const char** name) {
     if (!quantized_supported(fp.D)) return hipErrorInvalidValue;
+    if (fp.D > 256) {
+        // head dims 257 ... 1024: quantise -> q * s as fp32 -> the wide fp32 forward (both products as fp32 fma chains on exactly the values the
+        // int8 kernels multiply: the oracle's quantised restatement to fp32 rounding; P is not rounded to 16 bits here)
+        QuantViews v;
+        if (hipError_t e = launch_quantize_wide(fp.q, fp.k, fp.v, fp.in_prec, fp.B, fp.H, fp.Sq, fp.Skv, fp.D, bits, quant_mode, workspace, &v, stream); e != hipSuccess) return e;
+        FwdParams pw = fp;
+        pw.q = v.qf; pw.k = v.kf; pw.v = v.vf;
+        pw.in_prec = P_FP32; pw.out_prec = P_FP32;
+        const int64_t D = fp.D;
+        pw.qs[0] = (int64_t)fp.H * fp.Sq * D; pw.qs[1] = (int64_t)fp.Sq * D; pw.qs[2] = D; pw.qs[3] = 1;
+        pw.ks[0] = pw.vs[0] = (int64_t)fp.H * fp.Skv * D; pw.ks[1] = pw.vs[1] = (int64_t)fp.Skv * D; pw.ks[2] = pw.vs[2] = D; pw.ks[3] = pw.vs[3] = 1;
+        pw.os[0] = D; pw.os[1] = 1;
+        pw.part_buf = nullptr; pw.part_cnt = nullptr; pw.vsc = nullptr; pw.pv16 = 0;
+        if (fp.mask && fp.mask_kind == MK_NONE) {  // the ABI's dense fp32 additive [B, H, Sq, Skv]
+            pw.mask_kind = MK_F32;
+            pw.ms[0] = (int64_t)fp.H * fp.Sq * fp.Skv; pw.ms[1] = (int64_t)fp.Sq * fp.Skv; pw.ms[2] = fp.Skv; pw.ms[3] = 1;
+        }
+        const char* nm = "none";
+        const hipError_t e = launch_fwd_wide(pw, stream, &nm);
+        if (name) *name = bits == 4 ? "fa_fwd_wide<i4 images>" : "fa_fwd_wide<i8 images>";
+        return e;
+    }
     // quant_mode 3 (fp8 P V, opt-in): only the 64-rows-per-wave kernel implements it; every other case runs the
     // block-wise int8 path (mode 2), which is the more accurate of the two
     if (quant_mode == 3 && !(bits == 8 && fp.part_buf && fp.part_cnt && fwd_w64_i8_supported(fp) && !fp.mask)) quant_mode = 2;  // (no mask instantiation of the fp8 kernel)

@@ -460,7 +460,8 @@ mfa_error_t umfa_rope_attention_forward_stream(mfa_context_t context, void* stre
                                                int32_t input_precision, int32_t intermediate_precision) {
     Context* ctx = as_ctx(context);
     if (!ctx || !q || !k || !v || !out || !cos_table || !sin_table) return MFA_ERROR_INVALID_ARGS;
-    if (head_dim == 0 || head_dim > 256 || (head_dim & 1) || seq_len_q != seq_len_kv) return MFA_ERROR_INVALID_ARGS;
+    // head dims 257 ... 1024 (the callers' limit, metal_sdpa_backend.cpp:1078-1086): rotate, then the wide fp32 forward
+    if (head_dim == 0 || head_dim > 1024 || (head_dim & 1) || seq_len_q != seq_len_kv) return MFA_ERROR_INVALID_ARGS;
     FwdParams p;
     memset(&p, 0, sizeof(p));
     p.B = batch_size; p.H = num_heads; p.Sq = seq_len_q; p.Skv = seq_len_kv; p.D = head_dim;

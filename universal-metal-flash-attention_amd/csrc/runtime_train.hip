@@ -363,7 +363,7 @@ int32_t mfa_quantized_backward(mfa_context_t context, mfa_buffer_t q, mfa_buffer
         return MFA_ERROR_INVALID_ARGS;
     if (bm && !bm->fits(nr * Skv * 4)) return MFA_ERROR_INVALID_ARGS;
     if (nq == 0 || nkv == 0) return MFA_SUCCESS;
-    if (!quantized_supported(D)) return MFA_ERROR_INVALID_ARGS;  // head_dim <= 256, multiple of 8
+    if (!quantized_supported(D)) return MFA_ERROR_INVALID_ARGS;  // head_dim <= 1024, multiple of 8 (257 ... 1024: the fp32 engines on q * s images, no mask)
     const int bits = target_precision == MFA_PRECISION_INT4 ? 4 : 8;
     const int mode = quant_mode == 2 ? 2 : 0;
 
@@ -551,7 +551,7 @@ int raw_prec(int32_t v) { return (v >= 0 && v <= 4) ? (int)v : P_FP16; }  // unk
 // 16-bit MFMA backward), fp16 in the same slots with *overflow raised by values outside fp16's range
 mfa_error_t prequant_stage(Context* ctx, const PreQuant& a, float** qf, float** kf, float** vf, size_t extra_bytes,
                            char** extra, hipStream_t stream, bool half = false, size_t overflow_off = 0) {
-    if (a.D == 0 || a.D > 256 || a.H == 0 || a.Hkv == 0 || a.H % a.Hkv) return MFA_ERROR_INVALID_ARGS;
+    if (a.D == 0 || a.D > 1024 || a.H == 0 || a.Hkv == 0 || a.H % a.Hkv) return MFA_ERROR_INVALID_ARGS;  // (257 ... 1024: de-quantise -> the wide fp32 backward)
     const size_t nq = (size_t)a.B * a.H * a.Sq * a.D, nkv_src = (size_t)a.B * a.Hkv * a.Skv * a.D;
     const size_t nkv = (size_t)a.B * a.H * a.Skv * a.D;
     if (!a.q->fits(quant_bytes(a.qp, nq)) || !a.k->fits(quant_bytes(a.kp, nkv_src)) || !a.v->fits(quant_bytes(a.vp, nkv_src)))
@@ -805,7 +805,7 @@ int32_t umfa_quantize_rows(mfa_context_t context, void* stream_handle, const voi
                            uint32_t batch_heads, uint32_t rows, uint32_t head_dim, int32_t bits, int32_t quant_mode,
                            void* q8_out, void* scales_out, uint32_t* padded_row_bytes) {
     Context* ctx = as_ctx(context);
-    if (!ctx || !src || !q8_out || !scales_out || !quantized_supported(head_dim)) return MFA_ERROR_INVALID_ARGS;
+    if (!ctx || !src || !q8_out || !scales_out || !quantized_supported(head_dim) || head_dim > 256) return MFA_ERROR_INVALID_ARGS;  // (int8 rows: the register kernels' head dims)
     std::lock_guard<std::mutex> lock(ctx->mu);
     hipStream_t stream = (hipStream_t)stream_handle;
     const int pool_dev = stream_device(stream);

@@ -403,7 +403,7 @@ def rope_scaled_dot_product_attention(query, key, value, rope_cos, rope_sin, att
         return eager()
     B, Hq, Sq, D = query.shape
     Hkv, Skv = key.shape[1], key.shape[2]
-    if (D % 2 or D > 256 or key.shape[0] != B or value.shape[:3] != key.shape[:3] or key.shape[3] != D
+    if (D % 2 or D > 1024 or key.shape[0] != B or value.shape[:3] != key.shape[:3] or key.shape[3] != D
             or value.shape[3] != D or (Hq != Hkv and (Hkv == 0 or Hq % Hkv)) or Sq != Skv):
         return eager()
     cos_t, sin_t = rope_cos, rope_sin
