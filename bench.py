@@ -420,6 +420,26 @@ def run_rank(args) -> None:
                                                              "bound": "hbm", "bytes": b2, "hbm_floor_ms": round(b2 / 6.29e12 * 1e3, 5), "gbps": round(b2 / t / 1e6, 1),
                                                              "frac_hbm": round(b2 / 6.29e12 * 1e3 / t, 4),
                                                              "kernel": umfa_torch.last_kernel(), "flops": f2, "timer": GT}
+        # short causal launches, round 6: the 128-row kernel's balanced causal pairs (option cbal; DESIGN.md section 3.1 "CBAL") against the unpaired
+        # schedule, same process, same timer.  Config 2 itself is NOT routed there (forced here to show why: level / slower -- at head_dim 64 two
+        # co-resident workgroups do not overlap, profiles/r6/cbal_stamps_config2.txt)
+        try:
+            cp = {}
+            for (nm, B_, H_, S_, D_) in (("B1_H8_S4096_D128", 1, 8, 4096, 128), ("B2_H8_S2048_D128", 2, 8, 2048, 128), ("B4_H8_S1024_D128", 4, 8, 1024, 128),
+                                          ("B1_H8_S4096_D64", 1, 8, 4096, 64), ("cfg2_B4_H16_S1024_D64", 4, 16, 1024, 64)):
+                cq = [torch.randn(B_, H_, S_, D_, device=dev, dtype=torch.bfloat16) for _ in range(3)]
+                co = torch.empty_like(cq[0])
+                ent = {}
+                for tag, opts in (("default", {}), ("paired", {"cbal": 1}), ("unpaired", {"cbal": 2})):
+                    with umfa_torch.options(no_w64=1, **opts):
+                        ent[tag + "_ms"] = round(graph_ms(lambda: umfa_torch.attention_forward(*cq, causal=True, out=co), 50), 5)
+                ent["kernel"] = umfa_torch.last_kernel()
+                ent["tflops_default"] = round(2.0 * B_ * H_ * S_ * S_ * D_ / ent["default_ms"] / 1e9, 1)
+                cp[nm] = ent
+            cp["note"] = "causal bf16 forward on the 128-row kernel (no_w64 = 1 for all three columns); default = what the plan picks (fwd_16_split_plan)"
+            configs["causal_pairs_128row"] = cp
+        except Exception as exc:  # noqa: BLE001
+            configs["causal_pairs_128row"] = {"error": repr(exc)}
         # the headline shape in the two regimes that meet / sit on the stated tolerance, beside the headline's (lazy reference):
         # exact running max (bf16 at its operand-format floor) and fp16 (inside 1e-3)
         from oracle import parity as _par
