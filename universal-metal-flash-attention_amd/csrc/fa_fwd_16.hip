@@ -91,7 +91,7 @@ FwdSplitPlan fwd_16_split_plan(const FwdParams& p) {
         if (!want || (nqb & 1) || nqb < 4 || p.Sq != p.Skv || dp > 128) return plan;
         plan.n_full = items / 2;
         plan.nsplit = 2;
-        plan.buf_bytes = (size_t)(items / 2) * 2 * 4 * (16 * (dp / 32) + 2) * 64 * sizeof(float);
+        plan.buf_bytes = (size_t)(items / 2) * 2 * 4 * (16 * (dp / 32) + 4) * 64 * sizeof(float);
         plan.cnt_bytes = ((size_t)(items / 2) * sizeof(uint32_t) + 15) & ~(size_t)15;
         return plan;
     }
@@ -99,7 +99,10 @@ FwdSplitPlan fwd_16_split_plan(const FwdParams& p) {
     // items x k workgroups puts w = ceil(items k / CUs) of them on the fullest CU; two co-resident workgroups run ~1.6 x as fast as one after the
     // other, a third waits for a slot (R = 2 workgroups fit; one at head_dim 256); a part costs the fold ~3 key tiles (the folding workgroup reads the
     // parts one after the other, a dependent round trip of write-through memory each).  In key tiles:
-    //     cost(k) = ntiles / k x f(w) + 3 k,   f(1) = 1, f(2) = 1.25, f(3) = 2.25, f(4) = 2.5, ...
+    //     cost(k) = ntiles / k x f(w) + c k,   f(1) = 1, f(2) = 1.25, f(3) = 2.25, f(4) = 2.5, ...
+    // c = 3 in rounds 4-5; round 6: 2 -- the fold takes 16-byte loads, reads part o + 1 while it folds part o, and waves without rows (decode: three of
+    // four) stay out of it: B1 H8 Sq1 Skv131072 202 -> 139 us, B1 H32 Sq1 Skv8192 55 -> 34, B16 H8 Sq1 Skv4096 65 -> 48.  Over 16 launch sizes with every part
+    // count forced (profiles/r6/split_plan_probe.jsonl) c = 2 picks within 4 % of the best count everywhere (geometric mean 0.7 %); c = 3 was 21 % off at worst.
     // and the plan is its minimum over k = 1 ... min(kmax, ntiles / 4).  This replaces three rules that each fitted one regime: "one workgroup per CU"
     // (left 192 workgroups on 256 CUs at 96 items), "two per CU for decode-like calls" (B1 H32 Sq1 Skv8192: 16 parts 75 us, 8 parts 51), "no split
     // above half an item per CU" (160 items, three parts: 92.7 -> 69.5 us).  Checked against every forced part count: split_plan_random*.jsonl.
@@ -116,14 +119,14 @@ FwdSplitPlan fwd_16_split_plan(const FwdParams& p) {
             const uint64_t w = ((uint64_t)items * kk + cus - 1) / cus;
             const uint64_t rounds = (w + R - 1) / R, last = w - (rounds - 1) * R;  // full rounds of R co-resident workgroups, then `last`
             const double f = (double)(rounds - 1) * (R == 2 ? 1.25 : 1.0) + (last == 2 ? 1.25 : 1.0);
-            const double cost = (double)ntiles / kk * f + (kk > 1 ? 3.0 * kk : 0.0);
+            const double cost = (double)ntiles / kk * f + (kk > 1 ? 2.0 * kk : 0.0);  // (round 6: 2 tiles per part -- the fold reads a part ahead, below)
             if (cost < best * 0.97) { best = cost; k = kk; }  // (a tie goes to fewer parts)
         }
     }
     if (k < 2) return plan;
     plan.n_full = 0;
     plan.nsplit = k;
-    plan.buf_bytes = (size_t)items * k * 4 * (16 * (dp / 32) + 2) * 64 * sizeof(float);
+    plan.buf_bytes = (size_t)items * k * 4 * (16 * (dp / 32) + 4) * 64 * sizeof(float);
     plan.cnt_bytes = ((size_t)items * sizeof(uint32_t) + 15) & ~(size_t)15;
     return plan;
 }

@@ -179,7 +179,7 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
     // KS = 2 (key-split): FOUR -- there a wave's share of a tile is ~500 issue cycles, less than an L2 -> LDS round trip, and with
     // two slots every iteration ended waiting for the tile it had requested at its start.
 #ifdef UMFA_LAB_NS
-    constexpr int NS = UMFA_LAB_NS;
+    constexpr int NS = (CBAL || CAUSAL || HAS_MASK) ? 2 : UMFA_LAB_NS;  // (lab: the plain non-causal kernels only)
 #else
     constexpr int NS = KS == 2 ? 4 : 2;
 #endif
@@ -1199,22 +1199,33 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
         // that draws the last ticket folds the others with sc1 loads.  No release / acquire fence anywhere: an agent-scope release is
         // a write-back of the XCD's whole L2, and a launch of a few hundred parts paid for a few hundred of them (round 3: the causal
         // half-split 2 x SLOWER than no split, profiles/r3/cfg2_causal_split_ab.json; round 4 with this protocol: lab notes section 6).
-        constexpr int NREG = 16 * NDB + 2;
+        // Slot layout (round 6): [part][wave 4][chunk 4 NDB + 1][lane 64] x 16 bytes -- chunk 4 i + g = O^T registers 16 i + 4 g .. + 3 of block i,
+        // the last chunk {m, l, 0, 0}: 16-byte stores and loads (a part is 4 NDB + 1 memory instructions per wave instead of 16 NDB + 2).  A wave whose 32
+        // rows lie past Sq (decode-like calls: one query row, one wave) publishes and folds nothing.  The fold reads part o + 1 while it folds part o
+        // (two register buffers): a launch of 8 heads x 32 parts spent 64 of its 202 us reading parts one after the other, a dependent round trip of
+        // write-through memory each (profiles/r6/decode_fold.txt).  Same values in the same order as before: bitwise the same results.
+        constexpr int NCHK = 4 * NDB + 1;
+        // (fwd_16_split_plan sizes the buffer: 16 NDB + 4 words per lane, wave and part)
         // every static __shared__ object would shift the dynamic LDS base (Guideline 17): reuse the tile area
-        volatile uint32_t& ticket_s = *(volatile uint32_t*)smem;
+        volatile uint32_t& ticket_s = *((volatile uint32_t*)smem + 16);
         const uint32_t sidx = item - p.n_full;
-        const size_t item_floats = (size_t)nparts * 4 * (size_t)(NREG * 64);
-        const auto prs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.part_buf + (size_t)sidx * item_floats), 0, (int)(item_floats * 4), 0x00020000);
-        auto slot = [&](uint32_t part_, int reg) -> int { return (int)(((part_ * 4 + (uint32_t)wave) * NREG + (uint32_t)reg) * 256u); };
+        const size_t item_bytes = (size_t)nparts * 4 * (size_t)(NCHK * 1024);
+        const auto prs = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)p.part_buf + (size_t)sidx * item_bytes), 0, (int)item_bytes, 0x00020000);
+        auto slot = [&](uint32_t part_, int chunk) -> int { return (int)(((part_ * 4 + (uint32_t)wave) * NCHK + (uint32_t)chunk) * 1024u) + lane * 16; };
         constexpr int SC1 = 16;  // cache policy bit of the buffer builtins: system-coherent level 1 = write-through / read-around the XCD's L2
+        typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+        const bool wave_rows = wave_q0 < p.Sq;  // (wave-uniform)
+        if (wave_rows) {
 #pragma unroll
-        for (int i = 0; i < NDB; ++i)
+            for (int i = 0; i < NDB; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][r]), prs, lane * 4, slot(part, 16 * i + r), SC1);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m), prs, lane * 4, slot(part, 16 * NDB), SC1);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(lt), prs, lane * 4, slot(part, 16 * NDB + 1), SC1);
+                for (int g = 0; g < 4; ++g)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4{acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]}),
+                                                           prs, slot(part, 4 * i + g), 0, SC1);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, f32x4{m, lt, 0.0f, 0.0f}), prs, slot(part, 4 * NDB), 0, SC1);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // also: every wave is done with the K/V tiles, so smem[0..3] is free
+        __syncthreads();  // also: every wave is done with the K/V tiles, so the tile area is free
         if (tid == 0) ticket_s = __hip_atomic_fetch_add(p.part_cnt + sidx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const uint32_t ticket = ticket_s;
@@ -1223,39 +1234,23 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
         // memset node in a captured graph)
         if (tid == 0) __hip_atomic_store(p.part_cnt + sidx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // compiler-only: the payload loads stay below the ticket
-        // fold the parts in index order (own part from registers: the same values): the result does not depend on
-        // which part arrived last, so two launches are bitwise identical
-        auto ld = [&](uint32_t part_, int reg) -> float {
-            return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(prs, lane * 4, slot(part_, reg), SC1));
+        if (!wave_rows) return 0;  // (behind the workgroup's last barrier)
+        // fold the parts in index order (this workgroup's own part from its slot like the others: the same values): the result does not
+        // depend on which part arrived last, so two launches are bitwise identical
+        auto ldp = [&](uint32_t o, f32x4 (&x)[NCHK]) {
+#pragma unroll
+            for (int c = 0; c < NCHK; ++c) x[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, slot(o, c), 0, SC1));
         };
-        f32x16 own[NDB];
-#pragma unroll
-        for (int i = 0; i < NDB; ++i) own[i] = acc[i];
-        const float m_own = m, l_own = lt;
-        bool first = true;
-        for (uint32_t o = 0; o < nparts; ++o) {
-            f32x16 x[NDB];
-            float mo, lo;
-            if (o == part) {
-#pragma unroll
-                for (int i = 0; i < NDB; ++i) x[i] = own[i];
-                mo = m_own;
-                lo = l_own;
-            } else {
+        auto foldp = [&](const f32x4 (&x)[NCHK], const bool first) {
+            const float mo = x[4 * NDB][0], lo = x[4 * NDB][1];
+            if (first) {
 #pragma unroll
                 for (int i = 0; i < NDB; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) x[i][r] = ld(o, 16 * i + r);
-                mo = ld(o, 16 * NDB);
-                lo = ld(o, 16 * NDB + 1);
-            }
-            if (first) {
-#pragma unroll
-                for (int i = 0; i < NDB; ++i) acc[i] = x[i];
+                    for (int r = 0; r < 16; ++r) acc[i][r] = x[4 * i + (r >> 2)][r & 3];
                 m = mo;
                 lt = lo;
-                first = false;
-                continue;
+                return;
             }
             const float mn = fmaxf(m, mo);
             const float mu = mn == -INFINITY ? 0.0f : mn;
@@ -1263,9 +1258,19 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
 #pragma unroll
             for (int i = 0; i < NDB; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][r] = acc[i][r] * a0 + x[i][r] * a1;
+                for (int r = 0; r < 16; ++r) acc[i][r] = acc[i][r] * a0 + x[4 * i + (r >> 2)][r & 3] * a1;
             lt = lt * a0 + lo * a1;
             m = mn;
+        };
+        f32x4 xa[NCHK], xb[NCHK];
+        ldp(0, xa);
+        for (uint32_t o = 0; o < nparts; o += 2) {
+            if (o + 1 < nparts) ldp(o + 1, xb);
+            foldp(xa, o == 0);
+            if (o + 1 < nparts) {
+                if (o + 2 < nparts) ldp(o + 2, xa);
+                foldp(xb, false);
+            }
         }
     }
     const float inv = lt > 0.0f ? 1.0f / lt : 0.0f;

@@ -16,7 +16,11 @@ static inline hipError_t launch_dma(const FwdParams& pin, hipStream_t stream) {
     const uint32_t grid = p.n_full + (items - p.n_full) * p.nsplit;
     // (p.part_cnt is zero on entry and on exit: the runtime zeroes a ticket block once, the folding workgroup resets its word)
     // 2 x ring depth (fa_fwd_16_kernel.h NS: 2, key-split form 4) tiles; the key halves' exchange (4 x 34 x 256 bytes at head_dim 64) fits inside
+#ifdef UMFA_LAB_NS
+    const size_t lds = 2 * ((CBAL || CAUSAL || HAS_MASK) ? 2 : UMFA_LAB_NS) * BN * DP * 2;  // lab: ring depth of the LDS-DMA staging (fa_fwd_16_kernel.h NS)
+#else
     const size_t lds = (KS == 2 ? 8 : 4) * BN * DP * 2;
+#endif
     static_assert(KS == 1 || 8 * BN * DP * 2 >= 4 * (16 * (DP / 32) + 2) * 256, "exchange area");
     auto kfn = fa_fwd16_kernel<T, DP, CAUSAL, HAS_MASK, OUT, DMA, BN, PV16, KS, PIPE, CBAL>;
     if (hipError_t e = ensure_dynamic_lds((const void*)kfn, lds); e != hipSuccess) return e;
