@@ -83,7 +83,7 @@ def split_parts(items, nqb, T):  # fa_fwd_16.hip fwd_16_split_plan
         w = cdiv(items * kk, CUS)
         rounds = cdiv(w, 2)
         last = w - (rounds - 1) * 2
-        cost = T / kk * ((rounds - 1) * 1.25 + (1.25 if last == 2 else 1.0)) + (3.0 * kk if kk > 1 else 0)
+        cost = T / kk * ((rounds - 1) * 1.25 + (1.25 if last == 2 else 1.0)) + (2.0 * kk if kk > 1 else 0)  # (round 6: 2 tiles per part)
         if cost < best * 0.97:
             best, k = cost, kk
     return k
@@ -103,6 +103,34 @@ def r128_features(r):
         k = split_parts(items, nqb, T)
         f.update(k=k, n=items * k / CUS, tot=items * T, longest=T / k)
     return f
+
+
+def cbal_applies(r):  # fa_fwd_16.hip fwd_16_split_plan: balanced causal pairs (round 6), the plan's own gate
+    if not r["causal"] or r["D"] not in (64, 128) or r["Skv"] < r["Sq"]:
+        return False
+    nqb = cdiv(r["Sq"], 128)
+    items = r["B"] * r["H"] * nqb
+    if nqb % 2 or nqb < 2:
+        return False
+    return (nqb >= 8 and items <= 4 * CUS) if r["D"] == 128 else (nqb >= 16 and items <= 2 * CUS)
+
+
+def cbal_features(r):
+    nqb, T = cdiv(r["Sq"], 128), cdiv(r["Skv"], 64)
+    vbytes = r["B"] * r["H"] * r["Skv"] * r["D"] * 2
+    return dict(h=0.5 * (min(T, 2) + min(T, cdiv((nqb - 1) * 128 + 128, 64))), n=r["B"] * r["H"] * nqb / CUS, fp16=r["fp16"],
+                cast=1 if (not r["fp16"] and vbytes >= (16 << 20) and r["Sq"] >= 1024) else 0, vmb=vbytes / 1e6)
+
+
+def cbal_predict(p, f, base):  # base: the (head_dim, causal) row of the 128-row table (cast pass, fp16 factor)
+    a1, b1, a2, b2 = p
+    full = int(f["n"] // 2)
+    rest = f["n"] - 2 * full
+    one, two = a1 + b1 * f["h"], a2 + b2 * f["h"]
+    body = full * two + ((one if rest <= 1.0 else two) if rest > 1e-9 else 0.0)
+    if f["fp16"]:
+        body *= base[8]
+    return f["cast"] * (base[5] + f["vmb"] * 2 / base[6]) + body
 
 
 def r128_predict(p, f):
@@ -125,7 +153,7 @@ def r128_predict(p, f):
 
 
 def main():
-    paths = sys.argv[1:] or sorted(glob.glob(str(ROOT / "profiles" / "r5" / "routing_random_*.jsonl")))
+    paths = sys.argv[1:] or sorted(glob.glob(str(ROOT / "profiles" / "r6" / "routing_random_*.jsonl")))
     recs = load(paths)
     print(f"{len(recs)} launches with both kernels measured, from {len(paths)} files")
     fit = {}
@@ -134,17 +162,31 @@ def main():
             ("r128", r128_features, r128_predict, [5, 3, 1.0, 1.25, 1.8, 3, 4.0, 2.0, 0.9], [0, 0, 0.05, 1, 1, 0, 0.5, 0, 0.5], [40, 30, 5, 2, 3, 30, 20, 20, 1.2])):
         for D in (64, 128):
             for causal in (False, True):
-                rs = [r for r in recs if r["D"] == D and r["causal"] == causal]
+                rs = [r for r in recs if r["D"] == D and r["causal"] == causal and not (kind == "r128" and cbal_applies(r))]
                 F = [feat(r) for r in rs]
                 y = np.log(np.array([r[kind] for r in rs]))
                 sol = least_squares(lambda p: np.log(np.array([pred(p, f) for f in F])) - y, x0, bounds=(lo, hi))
                 e = np.exp(np.abs(np.log(np.array([pred(sol.x, f) for f in F])) - y))
                 print(f"{kind:4s} head_dim {D:3d} {'causal' if causal else 'full  '} n {len(rs):3d}: error median {np.median(e):.3f} p90 {np.quantile(e, 0.9):.3f} max {e.max():.3f}")
                 fit[(kind, D, causal)] = sol.x
+    for D in (64, 128):  # paired causal launches of the 128-row kernel: their own four constants per head dim
+        rs = [r for r in recs if r["D"] == D and cbal_applies(r)]
+        base = fit[("r128", D, True)]
+        if len(rs) >= 6:
+            F = [cbal_features(r) for r in rs]
+            y = np.log(np.array([r["r128"] for r in rs]))
+            sol = least_squares(lambda p: np.log(np.array([cbal_predict(p, f, base) for f in F])) - y, [10, 1.5, 20, 1.8], bounds=([0, 0.1, 0, 0.1], [60, 5, 80, 8]))
+            e = np.exp(np.abs(np.log(np.array([cbal_predict(sol.x, f, base) for f in F])) - y))
+            print(f"cbal head_dim {D:3d} n {len(rs):3d}: error median {np.median(e):.3f} p90 {np.quantile(e, 0.9):.3f} max {e.max():.3f}")
+            fit[("cbal", D)] = sol.x
+        else:
+            fit[("cbal", D)] = np.array([8.3, 1.22, 11.7, 1.34] if D == 64 else [11.85, 1.64, 23.5, 1.97])
+            print(f"cbal head_dim {D}: {len(rs)} launches -- the hand-fitted constants stay")
     loss = []
     for r in recs:
         pw = w64_predict(fit[("w64", r["D"], r["causal"])], w64_features(r))
-        pr = r128_predict(fit[("r128", r["D"], r["causal"])], r128_features(r))
+        pr = (cbal_predict(fit[("cbal", r["D"])], cbal_features(r), fit[("r128", r["D"], True)]) if cbal_applies(r)
+              else r128_predict(fit[("r128", r["D"], r["causal"])], r128_features(r)))
         loss.append((r["w64"] if pw < pr else r["r128"]) / min(r["w64"], r["r128"]))
     loss = np.array(loss)
     cur = np.array([r["dflt"] / min(r["w64"], r["r128"]) for r in recs])
@@ -155,6 +197,7 @@ def main():
         for D in (64, 128):
             rows.append("    {" + ", ".join("{" + ", ".join(f"{x:.4f}f" for x in fit[(kind, D, c)]) + "}" for c in (False, True)) + "}")
         print(f"static const {typ}[2][2] = {{\n" + ",\n".join(rows) + "};")
+    print("static const CbalCost kCbalCost[2] = {" + ", ".join("{" + ", ".join(f"{x:.4f}f" for x in fit[("cbal", D)]) + "}" for D in (64, 128)) + "};")
 
 
 if __name__ == "__main__":

@@ -256,6 +256,9 @@ static const W64Cost kW64Cost[2][2] = {
 static const R128Cost kR128Cost[2][2] = {
     {{1.7650f, 4.0233f, 0.6673f, 1.9430f, 1.0003f, 0.0000f, 20.0000f, 2.0672f, 0.8992f}, {0.0000f, 6.2266f, 0.7644f, 1.3369f, 3.0000f, 0.0000f, 7.0307f, 0.8890f, 0.9126f}},
     {{0.0000f, 8.2792f, 1.1413f, 1.9875f, 2.9244f, 3.2052f, 20.0000f, 3.5374f, 0.9652f}, {0.0000f, 8.3522f, 1.3922f, 1.2808f, 1.0856f, 0.0000f, 6.2498f, 0.7743f, 0.9168f}}};
+// balanced causal pairs (128-row kernel, round 6): microseconds of a round with one / two workgroups per CU as a + b h, h = key tiles per workgroup (half a pair)
+struct CbalCost { float a1, b1, a2, b2; };
+static const CbalCost kCbalCost[2] = {{8.3f, 1.22f, 11.7f, 1.34f}, {11.85f, 1.64f, 23.5f, 1.97f}};
 // (fit of round 5, 1339 launches: each model's error against the measurement: median 3-10 %, 90th percentile 12-25 %; routing by the pair:
 // within 5 % of the faster kernel on 97.8 % of the launches, worst 1.14 x -- the thresholds it replaces, measured on 980 of them: 93.4 %,
 // worst 1.26 x)
@@ -304,11 +307,11 @@ double fwd_16_predict_us(const FwdParams& p) {
         // profiles/r6/cbal_matrix.jsonl (the unpaired form's f2 does not carry over: here BOTH workgroups of a CU are busy all the way)
         const uint64_t lastq = nqb - 1;
         const double h = 0.5 * (double)(std::min<uint64_t>(T, 2) + std::min<uint64_t>(T, (lastq * 128 + 128 + 63) / 64));
-        const bool d64 = p.D == 64;
-        const double one = (d64 ? 8.3 : 11.85) + (d64 ? 1.22 : 1.64) * h, two = (d64 ? 11.7 : 23.5) + (d64 ? 1.34 : 1.97) * h;
+        const CbalCost& cb = kCbalCost[p.D == 64 ? 0 : 1];
+        const double one = cb.a1 + cb.b1 * h, two = cb.a2 + cb.b2 * h;
         const uint64_t full = (uint64_t)(n / 2.0);
         const double rest = n - 2.0 * (double)full;
-        body = (double)full * two + (rest > 1e-9 ? (rest <= 1.0 ? one : two) : 0.0) - c.t0;  // (the intercepts include the launch)
+        body = ((double)full * two + (rest > 1e-9 ? (rest <= 1.0 ? one : two) : 0.0)) * (p.in_prec == P_BF16 && p.pv16 ? 1.0 : (double)c.g16) - c.t0;  // (the intercepts include the launch)
     } else if (p.causal) {
         uint64_t tot = 0, longest = 0;
         for (uint64_t qb = 0; qb < nqb; ++qb) {

@@ -204,10 +204,23 @@ def _gqa_zero_copy(q, k, v, attn_mask, dropout_p, is_causal, scale):
     for t, h in ((q, Hq), (k, Hkv), (v, Hkv)):
         if t.stride(3) != 1 or (B > 1 and t.stride(0) != h * t.stride(1)):
             return None
+    sm_scale = float(scale) if scale is not None else float(D) ** -0.5
+    if (attn_mask is None and not is_causal and g * Sq <= 128 and (Sq == 1 or q.stride(1) == Sq * q.stride(2)) and q.stride(1) % 8 == 0
+            and os.environ.get("UMFA_GQA_PACK_ROWS", "1") != "0"):
+        # decode-like calls (round 6): the g query heads of a KV head become ROWS of one 128-row tile -- [B * Hkv, 1, g * Sq, D] is a plain view of a
+        # head-major q -- so a KV head's keys and values are staged once, by one workgroup (and its split-KV parts), instead of once per query head.
+        # No mask, not causal: rows of different query heads see the same keys, so nothing else changes.  B8 Hq32 Hkv8 Sq1 Skv8192: see
+        # profiles/r6/gqa_decode_pack_rows.txt
+        row_stride = q.stride(1) if Sq == 1 else q.stride(2)  # (one row per head: the heads ARE the rows, whatever the size-1 dimension's stride says)
+        qp = q.as_strided((B * Hkv, 1, g * Sq, D), (g * q.stride(1), g * q.stride(1), row_stride, 1), q.storage_offset())
+        kp = k.as_strided((B * Hkv, 1, Skv, D), (k.stride(1), k.stride(1), k.stride(2), 1), k.storage_offset())
+        vp = v.as_strided((B * Hkv, 1, Skv, D), (v.stride(1), v.stride(1), v.stride(2), 1), v.storage_offset())
+        _bump("fp32_instream")
+        out = ops.attention_forward(qp, kp, vp, scale=sm_scale, causal=False, out_dtype=q.dtype)
+        return out.view(B, Hq, Sq, D)
     qv = q.as_strided((B * Hkv, g, Sq, D), (g * q.stride(1), q.stride(1), q.stride(2), 1), q.storage_offset())
     kv = k.as_strided((B * Hkv, g, Skv, D), (k.stride(1), 0, k.stride(2), 1), k.storage_offset())
     vv = v.as_strided((B * Hkv, g, Skv, D), (v.stride(1), 0, v.stride(2), 1), v.storage_offset())
-    sm_scale = float(scale) if scale is not None else float(D) ** -0.5
     _bump("fp32_instream")
     out = ops.attention_forward(qv, kv, vv, scale=sm_scale, causal=bool(is_causal), mask=attn_mask, out_dtype=q.dtype)
     return out.view(B, Hq, Sq, D)
