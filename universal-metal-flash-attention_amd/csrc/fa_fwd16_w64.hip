@@ -239,7 +239,7 @@ static uint32_t w64_grid(const FwdParams& p);
 // ---- routing cost model ------------------------------------------------------------------------------------------------------------
 // Predicted microseconds of one launch, per structure.  The FORMS follow the kernels' schedules; the constants are least-squares fits
 // (log time) to launches measured on MI355X at 256 CUs, both kernels forced in turn (tools/fit_route_model.py prints this table from
-// profiles/r5/routing_*.jsonl together with its residuals: median error 5-9 %, which is why the comparison below is only trusted as a
+// profiles/r6/routing_*.jsonl together with its residuals: median error 4-9 %, which is why the comparison below is only trusted as a
 // comparison -- both predictions share most of their inputs).  Other CU counts enter through the schedule arithmetic (rounds, slices),
 // not through the constants.
 //   w64 (one persistent workgroup per CU):  t0 + cast + segments c_seg + tile_steps t_step + folded_parts c_fold
@@ -251,17 +251,17 @@ struct W64Cost { float t0, c_seg, t_step, c_fold, cast_a, cast_tbps; };
 struct R128Cost { float t0, c_item, tau1, f2, f3, cast_a, cast_tbps, c_tail, g16; };  // g16: tau1 factor without the bf16 -> fp16 conversion of V (fp16 operands)
 // [head_dim 64 | 128][full | causal]
 static const W64Cost kW64Cost[2][2] = {
-    {{2.3807f, 5.4886f, 1.0809f, 1.8609f, 4.3829f, 3.8557f}, {9.2507f, 0.0000f, 1.1396f, 14.5701f, 2.5974f, 2.1145f}},
-    {{0.4497f, 9.9841f, 1.6534f, 3.2625f, 3.5524f, 3.7822f}, {0.0000f, 6.7085f, 1.4716f, 11.2816f, 2.1262f, 2.5206f}}};
+    {{1.9654f, 5.6596f, 1.0164f, 1.8670f, 4.8672f, 4.1271f}, {9.3795f, 0.0000f, 1.1237f, 48.8617f, 2.7924f, 2.2478f}},
+    {{0.4243f, 10.5808f, 1.5482f, 3.2266f, 3.4018f, 3.8643f}, {0.0000f, 6.7763f, 1.4334f, 52.2072f, 2.5095f, 2.6358f}}};
 static const R128Cost kR128Cost[2][2] = {
-    {{1.7650f, 4.0233f, 0.6673f, 1.9430f, 1.0003f, 0.0000f, 20.0000f, 2.0672f, 0.8992f}, {0.0000f, 6.2266f, 0.7644f, 1.3369f, 3.0000f, 0.0000f, 7.0307f, 0.8890f, 0.9126f}},
-    {{0.0000f, 8.2792f, 1.1413f, 1.9875f, 2.9244f, 3.2052f, 20.0000f, 3.5374f, 0.9652f}, {0.0000f, 8.3522f, 1.3922f, 1.2808f, 1.0856f, 0.0000f, 6.2498f, 0.7743f, 0.9168f}}};
+    {{1.9627f, 3.9851f, 0.6098f, 2.0000f, 1.0000f, 0.0000f, 20.0000f, 1.3083f, 0.9054f}, {0.2449f, 5.9446f, 0.7894f, 1.4608f, 1.0000f, 0.0000f, 20.0000f, 0.6456f, 0.8727f}},
+    {{0.0000f, 8.3967f, 1.0624f, 2.0000f, 2.8549f, 5.1811f, 20.0000f, 3.2320f, 1.0191f}, {0.0000f, 8.4229f, 1.2922f, 1.7176f, 1.0000f, 0.0000f, 12.7398f, 0.4806f, 0.8916f}}};
 // balanced causal pairs (128-row kernel, round 6): microseconds of a round with one / two workgroups per CU as a + b h, h = key tiles per workgroup (half a pair)
 struct CbalCost { float a1, b1, a2, b2; };
-static const CbalCost kCbalCost[2] = {{8.3f, 1.22f, 11.7f, 1.34f}, {11.85f, 1.64f, 23.5f, 1.97f}};
-// (fit of round 5, 1339 launches: each model's error against the measurement: median 3-10 %, 90th percentile 12-25 %; routing by the pair:
-// within 5 % of the faster kernel on 97.8 % of the launches, worst 1.14 x -- the thresholds it replaces, measured on 980 of them: 93.4 %,
-// worst 1.26 x)
+static const CbalCost kCbalCost[2] = {{8.5243f, 1.1660f, 11.3665f, 1.3999f}, {11.7677f, 1.5652f, 21.1185f, 1.7844f}};
+// (fit of round 6, 1420 launches of profiles/r6/routing_random_*.jsonl -- the 128-row kernel changed: balanced causal pairs, the split-KV fold's read-ahead: each
+// model's error against the measurement: median 4-9 %, 90th percentile 11-24 %, the paired launches 1.5-3 % / 5-10 %; routing by the pair: within 5 % of the faster
+// kernel on 97.8 % of the launches, worst 1.17 x -- the round-5 constants, measured on the same launches: 90.6 %, worst 1.33 x)
 
 static double route_v_megabytes(const FwdParams& p) {  // distinct V slabs (broadcast batch / head strides: one slab)
     return (double)(p.vs[0] == 0 ? 1u : p.B) * (p.vs[1] == 0 ? 1u : p.H) * p.Skv * p.D * 2.0 * 1e-6;
