@@ -451,7 +451,7 @@ const char* umfa_last_kernel_name(mfa_context_t context);
  *                        two workgroups of EQUAL length (the long block's tail is published mid-sweep by the workgroup that goes on with the
  *                        short block, the other folds it in): short causal launches no longer end with their longest q-block alone on its CU.
  *                        0: where the plan expects a gain (head_dim 128: >= 8 q-blocks of 128 rows per head, <= 4 workgroups per CU; head_dim
- *                        64: >= 16 q-blocks, <= 2 per CU; no mask tensor, even q-block count); 1: wherever the form exists; 2: never.
+ *                        64: >= 16 q-blocks, <= 2 per CU; no mask tensor; an odd count leaves the middle q-block -- as long as half a pair -- whole); 1: wherever the form exists; 2: never.
  *                        Same results to rounding (another order of the row sums); bitwise repeatable.
  *   "cbal_delta"         "-1" (default: the plan's choice) | "0" ... "16": key tiles by which the folding workgroup's share is shorter (tests, A/B)
  * Returns MFA_ERROR_INVALID_ARGS for an unknown name or a value out of range.  Thread-safe; affects later launches. */

@@ -76,10 +76,11 @@ def test_every_cut_position(delta, D):
     assert _rel(o, _ref(q, k, v)) < NORTH_STAR, (delta, D, kern)
 
 
-@pytest.mark.parametrize("Sq,Skv", [(512, 640), (512, 300), (500, 500), (384, 1024), (1024, 64), (256, 130)])
+@pytest.mark.parametrize("Sq,Skv", [(512, 640), (512, 300), (500, 500), (384, 1024), (1024, 64), (256, 130), (384, 384), (640, 640), (1152, 1152), (1100, 1100), (640, 200)])
 @pytest.mark.parametrize("D", [64, 128])
 def test_ragged_and_unequal_lengths(Sq, Skv, D):
-    """causal is top-left aligned (key <= row): Skv < Sq caps the long blocks (pairs that need no cut stay whole), ragged last tiles and rows"""
+    """causal is top-left aligned (key <= row): Skv < Sq caps the long blocks (pairs that need no cut stay whole), ragged last tiles and rows; an ODD
+    number of q-blocks leaves the middle one -- as long as half a pair -- whole, behind the pairs in the grid"""
     torch.manual_seed(Sq + Skv)
     q = torch.randn(2, 2, Sq, D, device="cuda", dtype=torch.bfloat16)
     k, v = (torch.randn(2, 2, Skv, D, device="cuda", dtype=torch.bfloat16) for _ in range(2))

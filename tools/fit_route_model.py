@@ -110,7 +110,7 @@ def cbal_applies(r):  # fa_fwd_16.hip fwd_16_split_plan: balanced causal pairs (
         return False
     nqb = cdiv(r["Sq"], 128)
     items = r["B"] * r["H"] * nqb
-    if nqb % 2 or nqb < 2:
+    if nqb < 2:
         return False
     return (nqb >= 8 and items <= 4 * CUS) if r["D"] == 128 else (nqb >= 16 and items <= 2 * CUS)
 

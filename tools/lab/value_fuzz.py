@@ -1254,15 +1254,15 @@ def run_w64_mask_case(seed):
 
 
 def run_cbal_case(seed):
-    """(round 6) the paired causal schedule of the 128-row kernel (option cbal = 1, fa_fwd_16_kernel.h CBAL) on random causal launches: any even
-    number of 128-row q-blocks, ragged / unequal Sq and Skv, every cut position, head_dim 64 / 128, bf16 (converting kernel, bf16 P V) and fp16,
+    """(round 6) the paired causal schedule of the 128-row kernel (option cbal = 1, fa_fwd_16_kernel.h CBAL) on random causal launches: any
+    number of 128-row q-blocks (odd: the middle one whole), ragged / unequal Sq and Skv, every cut position, head_dim 64 / 128, bf16 (converting kernel, bf16 P V) and fp16,
     strided inputs, adversarial score patterns and V beyond fp16's range (either part of a pair may have to sweep again), LSE; each launch
     twice (bitwise), sometimes inside a captured graph replayed with other data (the pairs' flags must come back to zero)"""
     rng = random.Random(seed + 9700000)
     dt = rng.choice([torch.bfloat16, torch.bfloat16, torch.float16])
     D = rng.choice([64, 128])
     B, H = rng.choice([1, 2, 3]), rng.choice([1, 2, 3, 5])
-    nqb = rng.choice([2, 2, 4, 4, 6, 8, 10, 16])
+    nqb = rng.choice([2, 2, 3, 4, 4, 5, 6, 7, 8, 9, 10, 13, 16])
     Sq = 128 * nqb - rng.choice([0, 0, 0, 1, 17, 64, 127])
     Skv = rng.choice([Sq, Sq, Sq, Sq + 64, Sq + 1000, max(Sq - 100, 1), max(Sq // 2, 1), 65, 2 * Sq])
     strided = rng.random() < 0.25

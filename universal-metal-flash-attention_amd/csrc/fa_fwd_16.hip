@@ -76,11 +76,11 @@ FwdSplitPlan fwd_16_split_plan(const FwdParams& p) {
         // a tile takes 1.83 us against 1.2 us for a workgroup alone (the SIMD's two waves do not overlap at head_dim 64), so 18 tile steps
         // per CU cost what 16 alone + 2 shared did (profiles/r6/cbal_stamps_config2.txt).
         const int cb = tuning().cbal.load(std::memory_order_relaxed);
-        const bool cb_shape = !(nqb & 1) && nqb >= 2 && (dp == 64 || dp == 128) && p.D == dp && p.mask_kind == MK_NONE && dma_enabled();
+        const bool cb_shape = nqb >= 2 && (dp == 64 || dp == 128) && p.D == dp && p.mask_kind == MK_NONE && dma_enabled();  // (odd nqb: the middle q-block whole)
         const bool cb_auto = p.Skv >= p.Sq && (dp == 128 ? (nqb >= 8 && items <= 4 * cus) : (nqb >= 16 && items <= 2 * cus));
         if (!want && cb != 2 && cb_shape && (cb == 1 || cb_auto)) {
             const int dl = tuning().cbal_delta.load(std::memory_order_relaxed);  // (< 0: the plan's own choice)
-            const size_t npairs = (size_t)items / 2;
+            const size_t npairs = (size_t)p.B * p.H * (nqb / 2);
             plan.cbal = 1;
             // the folding part is shorter by the fold's price in tiles: nothing while a CU holds one workgroup, two tiles from two per CU on (head_dim 128)
             plan.cbal_delta = dl >= 0 ? (uint32_t)(dl > 16 ? 16 : dl) : (dp == 128 && items > cus ? 2u : 0u);

@@ -231,15 +231,18 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
     if constexpr (CBAL) {
         const uint32_t h2 = nqb >> 1, npairs = p.B * p.H * h2;
         const bool is_b = bid_in < npairs;  // parts B first: a part A waits for its part B, never the other way round, and a part B waits for nothing
-        cb_pair = xcd_remap(is_b ? bid_in : bid_in - npairs, npairs);
-        bh = cb_pair / h2;
-        const uint32_t qi = cb_pair % h2, qj = nqb - 1 - qi;
+        const bool is_mid = bid_in >= 2 * npairs;  // an odd number of q-blocks: the middle one (as long as half a pair) runs whole, behind the pairs
+        cb_pair = is_mid ? 0 : xcd_remap(is_b ? bid_in : bid_in - npairs, npairs);
+        bh = is_mid ? xcd_remap(bid_in - 2 * npairs, p.B * p.H) : cb_pair / h2;
+        const uint32_t qi = is_mid ? h2 : cb_pair % h2, qj = nqb - 1 - qi;
         const uint32_t ntl = (p.Skv + BN - 1) / BN;
         auto nt_of = [&](uint32_t q_) { const uint32_t lim = (q_ * BM + BM + BN - 1) / BN; return ntl < lim ? ntl : lim; };
         const uint32_t ni = nt_of(qi), nj = nt_of(qj);
         int a = (int)((ni + nj + 1) / 2) - (int)p.cbal_delta;
         a = a < 1 ? 1 : a;
-        if ((uint32_t)a >= nj) {  // nothing to cut (Skv much shorter than Sq): both q-blocks whole
+        if (is_mid) {
+            qb = qi;
+        } else if ((uint32_t)a >= nj) {  // nothing to cut (Skv much shorter than Sq): both q-blocks whole
             qb = is_b ? qi : qj;
         } else {
             qb = qj;

@@ -12,7 +12,7 @@ static inline hipError_t launch_dma(const FwdParams& pin, hipStream_t stream) {
     const uint32_t nqb = (p.Sq + 127) / 128;
     const uint32_t items = nqb * p.B * p.H;
     if (KS != 1 || PIPE || CBAL || p.nsplit < 2 || !p.part_buf || !p.part_cnt) { p.n_full = items; p.nsplit = 1; }
-    if (CBAL && (!p.part_buf || !p.part_cnt || (nqb & 1))) return hipErrorInvalidValue;  // (the plan's scratch: one slot and one flag per pair)
+    if (CBAL && (!p.part_buf || !p.part_cnt || nqb < 2)) return hipErrorInvalidValue;  // (the plan's scratch: one slot and one flag per pair)
     const uint32_t grid = p.n_full + (items - p.n_full) * p.nsplit;
     // (p.part_cnt is zero on entry and on exit: the runtime zeroes a ticket block once, the folding workgroup resets its word)
     // 2 x ring depth (fa_fwd_16_kernel.h NS: 2, key-split form 4) tiles; the key halves' exchange (4 x 34 x 256 bytes at head_dim 64) fits inside
