@@ -520,7 +520,7 @@ def test_w64_dispatch_gate_fp16_operands_keep_short_query_ranges():
 
 @pytest.mark.parametrize("shape,causal,expect_w64", [((1, 24, 4096, 4096), False, True), ((8, 16, 2048, 2048), False, True), ((8, 16, 1024, 1024), False, False),
                                                      ((1, 40, 1024, 1024), False, False), ((4, 16, 1024, 1024), True, False),
-                                                     ((5, 16, 1024, 1024), True, False), ((8, 16, 1024, 1024), True, False), ((8, 16, 2048, 2048), True, False),  # (round 6 refit: 123 us against 225 forced, tools/lab/dbg_mask_d80.py)
+                                                     ((5, 16, 1024, 1024), True, False), ((8, 16, 1024, 1024), True, False), ((8, 16, 2048, 2048), True, False),  # (round 6 refit: 123 us against 225 forced, tools/lab/archive/dbg_mask_d80.py)
                                                      ((4, 16, 4096, 4096), True, True)])
 def test_w64_dispatch_gate_head_dim_64(shape, causal, expect_w64):
     """head_dim 64: half the MFMA time per tile step, so the gate sits higher (BASELINE config 2 stays on the 128-row kernel)"""
