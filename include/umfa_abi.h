@@ -453,6 +453,10 @@ const char* umfa_last_kernel_name(mfa_context_t context);
  *                        0: where the plan expects a gain (head_dim 128: >= 8 q-blocks of 128 rows per head, <= 4 workgroups per CU; head_dim
  *                        64: >= 16 q-blocks, <= 2 per CU; no mask tensor; an odd count leaves the middle q-block -- as long as half a pair -- whole); 1: wherever the form exists; 2: never.
  *                        Same results to rounding (another order of the row sums); bitwise repeatable.
+ *   "decode_ks"          "0" (default) | "1" | "2": the decode form of the 128-row forward kernel -- at most 32 query rows per (batch, head), no mask, not
+ *                        causal, head_dim 64 / 128: the four waves of a workgroup all serve those rows, each owning a key quarter of every 128-key tile (in
+ *                        the plain form three of four waves compute rows that do not exist).  0: while the items fit one round of its residency (the
+ *                        split-KV plan then counts parts for it); 1: whenever the shape allows; 2: never.  Same results to rounding; bitwise repeatable.
  *   "cbal_delta"         "-1" (default: the plan's choice) | "0" ... "16": key tiles by which the folding workgroup's share is shorter (tests, A/B)
  * Returns MFA_ERROR_INVALID_ARGS for an unknown name or a value out of range.  Thread-safe; affects later launches. */
 mfa_error_t umfa_set_option(mfa_context_t context, const char* name, const char* value);

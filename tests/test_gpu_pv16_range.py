@@ -117,7 +117,7 @@ def test_split_kv_parts_shift_on_their_own(kind):
     if kind == "outlier":
         v[1, 3, 5000, 100] = 2.0e10
     o, lse = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32, return_lse=True)
-    assert umfa_torch.last_kernel() == "fa_fwd16<bf16,128,pv16>"
+    assert umfa_torch.last_kernel() == "fa_fwd16<bf16,128,pv16,dec>"  # (three query rows: the decode form, four key quarters per 128-key tile)
     assert torch.isfinite(o).all()
     ref, ref_lse = _oracle().sdpa_forward(bits(q), bits(k), bits(v), return_lse=True)
     assert _per_slab_err(o.cpu().numpy(), ref) < NORTH_STAR

@@ -152,3 +152,10 @@ def test_paired_causal_schedule_random_cases(seed):
     """the 128-row kernel's balanced causal pairs (round 6, option cbal): random launches, every cut, ragged lengths, V outside fp16's range, graph replays"""
     msg = _fuzz().run_cbal_case(seed)
     assert msg is None, msg
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_decode_like_launches_random_cases(seed):
+    """1 ... 32 query rows: the decode form and the plain form of the 128-row kernel, forced split-KV part counts (round 6: the fold's 16-byte slots and read-ahead)"""
+    msg = _fuzz().run_decode_case(seed)
+    assert msg is None, msg

@@ -1335,11 +1335,63 @@ def run_cbal_case(seed):
     return None
 
 
+def run_decode_case(seed):
+    """(round 6) decode-like launches: 1 ... 32 query rows, any key count -- the decode form of the 128-row kernel (four key quarters per 128-key tile, option
+    decode_ks) and the plain form, forced part counts of the split-KV plan (the fold's 16-byte slots and read-ahead), strided K / V, adversarial score patterns,
+    V beyond fp16's range; fp64 reference, LSE, bitwise repeatability"""
+    rng = random.Random(seed + 9900000)
+    dt = rng.choice([torch.bfloat16, torch.bfloat16, torch.float16])
+    D = rng.choice([64, 128, 128])
+    B, H = rng.choice([1, 2, 5]), rng.choice([1, 3, 8])
+    Sq = rng.choice([1, 1, 1, 2, 3, 4, 8, 15, 16, 31, 32])
+    Skv = rng.choice([1, 31, 32, 33, 64, 100, 127, 128, 129, 255, 256, 300, 1000, 2048, 4097, 9000])
+    strided = rng.random() < 0.3
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    q = torch.randn(B, H, Sq, D, device="cuda", generator=g).to(dt)
+    mk = (lambda: torch.randn(B, Skv, H, D, device="cuda", generator=g).to(dt).transpose(1, 2)) if strided else (lambda: torch.randn(B, H, Skv, D, device="cuda", generator=g).to(dt))
+    k, v = mk(), mk()
+    kind = rng.choice(["plain", "plain"] + KINDS) if Skv >= 8 else "plain"
+    if kind != "plain":
+        q, k, v = transform(rng, q, k.contiguous(), v.contiguous(), kind)
+    vreg = rng.choice(["plain", "plain", "outlier", "tiny"]) if dt == torch.bfloat16 and kind == "plain" else "plain"
+    if vreg == "outlier":
+        v = v.clone(); v[rng.randrange(B), rng.randrange(H), rng.randrange(Skv), rng.randrange(D)] = rng.choice([3.0e8, -7.0e9])
+    elif vreg == "tiny":
+        v = (v.float() * 1e-7).to(dt)
+    opts = {"decode_ks": rng.choice([0, 0, 1, 2])}
+    fs = rng.choice([0, 0, 2, 3, 7, 16, 32])
+    if fs:
+        opts["force_split"] = fs
+    if dt == torch.bfloat16 and rng.random() < 0.2:
+        opts["pv_fp16"] = 0
+    try:
+        with umfa_torch.options(**opts):
+            out, lse = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32, return_lse=True)
+            kern = umfa_torch.last_kernel()
+            o2 = umfa_torch.attention_forward(q, k, v, out_dtype=torch.float32)
+        what = (seed, str(dt), B, H, Sq, Skv, D, kind, vreg, strided, opts, kern)
+        if not kern.startswith("fa_fwd16<") or (opts["decode_ks"] == 1 and not kern.endswith(",dec>")) or (opts["decode_ks"] == 2 and kern.endswith(",dec>")):
+            return "kernel %r" % (what,)
+        if not torch.isfinite(out).all():
+            return "non-finite %r" % (what,)
+        if not torch.equal(out, o2):
+            return "not bitwise repeatable %r" % (what,)
+        ref, rl = ref64(q, k, v, D ** -0.5, None)
+        rel = ((out.double() - ref).abs().amax(dim=(2, 3)) / ref.abs().amax(dim=(2, 3)).clamp_min(1e-30)).max().item()
+        lerr = ((lse.view(B, H, Sq).double() - rl).abs() / rl.abs().clamp_min(50.0)).max().item()
+        bound = CEIL[dt] if opts.get("pv_fp16", 1) == 0 or dt == torch.float16 else 2.0 ** -11 * 1.5
+        if rel > bound or lerr > 1e-3:
+            return "rel %.3e lse %.3e %r" % (rel, lerr, what)
+    except Exception as e:  # noqa: BLE001
+        return "exception %r %s" % ((seed, kind, vreg), repr(e)[:300])
+    return None
+
+
 if __name__ == "__main__":
     first, count = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 200)
     bad = 0
     for seed in range(first, first + count):
-        for fn in ((run_case, run_bwd_case, run_shape_case, run_i8_case, run_gqa_case, run_rope_case, run_streams_case, run_graph_case, run_mask_case, run_host_case, run_qbwd_case, run_prequant_case, run_aux_case, run_threads_case, run_big_case, run_bwd_shape_case, run_wide_case, run_qmask_case, run_w64_mask_case, run_cbal_case) if len(sys.argv) < 4 else (globals()[sys.argv[3]],)):
+        for fn in ((run_case, run_bwd_case, run_shape_case, run_i8_case, run_gqa_case, run_rope_case, run_streams_case, run_graph_case, run_mask_case, run_host_case, run_qbwd_case, run_prequant_case, run_aux_case, run_threads_case, run_big_case, run_bwd_shape_case, run_wide_case, run_qmask_case, run_w64_mask_case, run_cbal_case, run_decode_case) if len(sys.argv) < 4 else (globals()[sys.argv[3]],)):
             msg = fn(seed)
             if msg:
                 bad += 1

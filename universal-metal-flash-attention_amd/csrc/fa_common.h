@@ -85,6 +85,7 @@ struct FwdParams {
     uint32_t vsc_bs, vsc_hs;
     // balanced causal pairs (fa_fwd_16_kernel.h CBAL; fwd_16_split_plan decides): a head's q-blocks (i, nqb - 1 - i) are dealt to two
     // workgroups of equal length; part_buf holds one slot per pair, part_cnt one flag word per pair (zero between launches)
+    uint32_t decode_form; // 1 = the launch runs the decode form (fa_fwd_16_kernel.h KS = 4: <= 32 query rows, four key quarters per 128-key tile); the plan decides
     uint32_t cbal;        // 1 = the launch runs the CBAL instantiation
     uint32_t cbal_delta;  // key tiles by which a pair's part A is shorter than half (it pays the fold)
 };

@@ -56,7 +56,11 @@ FwdSplitPlan fwd_16_split_plan(const FwdParams& p) {
     plan.n_full = items;
     plan.nsplit = 1;
     plan.buf_bytes = plan.cnt_bytes = 0;
-    if (items == 0 || tuning().no_split.load(std::memory_order_relaxed)) return plan;
+    if (items == 0) return plan;
+    if (tuning().no_split.load(std::memory_order_relaxed)) {  // (lab: no parts; the decode form's gate as below)
+        plan.decode = (!p.causal && fwd16_decode_shape(p) && (uint64_t)items * (dp == 128 ? 2u : 1u) <= cus) ? 1u : 0u;
+        return plan;
+    }
     if (p.causal) {
         // Causal items are uneven already; what a SHORT causal launch (every item resident at once) waits for is its
         // longest item: q-block nqb - 1 sweeps every key tile alone.  Lab option force_split = 2: cut the heavy half of each
@@ -106,8 +110,15 @@ FwdSplitPlan fwd_16_split_plan(const FwdParams& p) {
     // and the plan is its minimum over k = 1 ... min(kmax, ntiles / 4).  This replaces three rules that each fitted one regime: "one workgroup per CU"
     // (left 192 workgroups on 256 CUs at 96 items), "two per CU for decode-like calls" (B1 H32 Sq1 Skv8192: 16 parts 75 us, 8 parts 51), "no split
     // above half an item per CU" (160 items, three parts: 92.7 -> 69.5 us).  Checked against every forced part count: split_plan_random*.jsonl.
+    // Decode form of the kernel (fa_fwd_16_kernel.h KS = 4, round 6: <= 32 query rows, the four waves split every 128-key tile's keys): one workgroup per CU at
+    // head_dim 128 (128 KiB of LDS), two at 64 -- so it is taken while the items fit one round of that residency, and the part count below is chosen for it.
+    // Graph-replayed, both forms alternating in one process, each with its best part count (profiles/r6/decode_form_ab.txt): B1 H8 Sq4 Skv8192 35.4 -> 26.3-29.5 us,
+    // B1 H64 Sq1 Skv4096 D64 21.1 -> 17.8, B2 H16 Sq16 Skv16384 56.1 -> 50.5, B16 H8 Sq1 Skv4096 48.9 -> 45.9; from one item per CU on the plain form's two
+    // workgroups per CU win (B8 H32 Sq1 Skv8192 185 against 204) and keep the launch.
+    const int dks = tuning().decode_ks.load(std::memory_order_relaxed);
+    plan.decode = (fwd16_decode_shape(p) && (dks == 1 || (uint64_t)items * (dp == 128 ? 2u : 1u) <= cus)) ? 1u : 0u;
     const uint32_t kmax = nqb == 1 ? 32u : 8u;
-    const uint32_t R = dp > 128 ? 1u : 2u;
+    const uint32_t R = (dp > 128 || (plan.decode && dp == 128)) ? 1u : 2u;
     const int force = tuning().force_split.load(std::memory_order_relaxed);  // experiments: split every item k ways
     uint32_t k = 1;
     if (force >= 2 && force <= 32) {
@@ -138,6 +149,9 @@ static hipError_t launch_one(const FwdParams& p, hipStream_t stream) {
         if (p.pv16) return launch_fwd16_pv<DP, CAUSAL, HAS_MASK, OUT>(p, stream);  // bf16 operands, fp16 P V (the default): fa_fwd_16_pv.hip
     }
     if ((int)p.D == DP && dma_enabled()) {
+        if constexpr (!CAUSAL && !HAS_MASK && (DP == 64 || DP == 128)) {
+            if (fwd16_decode_form(p)) return launch_dma<T, DP, CAUSAL, HAS_MASK, OUT, true, 128, 0, 4>(p, stream);  // decode form: four key quarters per tile
+        }
         // 32-key tiles + LDS-DMA at head_dim 128: 166 VGPR / 32 KiB LDS -> three resident workgroups per CU
         // (lab, same box: FLUX 768 items 264 -> 242 us; 3072 items 895 -> 870 us; never slower)
         // (causal launches lose with it: 184 vs 146 us at the FLUX shape, so they keep 64-key tiles)
@@ -184,9 +198,15 @@ static hipError_t launch_dp(const FwdParams& p, hipStream_t stream, const char**
         if (form == 1) *name = pv ? "fa_fwd16<bf16,64,pv16,pipe>" : bf ? "fa_fwd16<bf16,64,pipe>" : "fa_fwd16<fp16,64,pipe>";
         else if (form == 2) *name = pv ? "fa_fwd16<bf16,64,pv16,ks2>" : bf ? "fa_fwd16<bf16,64,ks2>" : "fa_fwd16<fp16,64,ks2>";
         else *name = pv ? "fa_fwd16<bf16,64,pv16>" : bf ? "fa_fwd16<bf16,64>" : "fa_fwd16<fp16,64>";
+        if (fwd16_decode_form(p)) *name = pv ? "fa_fwd16<bf16,64,pv16,dec>" : bf ? "fa_fwd16<bf16,64,dec>" : "fa_fwd16<fp16,64,dec>";
         return launch_out<T, 64>(p, stream);
     }
-    if (p.D <= 128) { *name = pv ? "fa_fwd16<bf16,128,pv16>" : bf ? "fa_fwd16<bf16,128>" : "fa_fwd16<fp16,128>"; return launch_out<T, 128>(p, stream); }
+    const bool dec = fwd16_decode_form(p);  // (launch_one / launch_fwd16_pv take the decode form then)
+    if (p.D <= 128) {
+        *name = dec ? (pv ? "fa_fwd16<bf16,128,pv16,dec>" : bf ? "fa_fwd16<bf16,128,dec>" : "fa_fwd16<fp16,128,dec>")
+                    : (pv ? "fa_fwd16<bf16,128,pv16>" : bf ? "fa_fwd16<bf16,128>" : "fa_fwd16<fp16,128>");
+        return launch_out<T, 128>(p, stream);
+    }
     *name = pv ? "fa_fwd16<bf16,256,pv16>" : bf ? "fa_fwd16<bf16,256>" : "fa_fwd16<fp16,256>";
     return launch_out<T, 256>(p, stream);
 }

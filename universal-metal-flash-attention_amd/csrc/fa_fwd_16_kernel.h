@@ -131,8 +131,13 @@ __device__ __forceinline__ int vscale_exponent_of(unsigned amax_bits) {
 template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT, bool DMA, int BN, int PV16, int KS, int PIPE, bool CBAL, bool RESWEEP, typename PRM>
 __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const int tid_in, const uint32_t bid_in);
 
+// threads of a workgroup / resident workgroups per CU the register budget is set for (KS = 4, the decode form: four waves, 128-key tiles -- 128 KiB of LDS at
+// head_dim 128: one workgroup per CU, two at head_dim 64)
+constexpr int fwd16_threads(int KS) { return KS == 4 ? 256 : 256 * KS; }
+constexpr int fwd16_resident(int DP, int BN, int KS) { return KS == 4 ? (DP > 64 ? 1 : 2) : KS * (DP > 128 ? 1 : (BN == 32 ? 3 : 2)); }
+
 template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT, bool DMA = false, int BN = 64, int PV16 = 0, int KS = 1, int PIPE = 0, bool CBAL = false>
-__global__ __launch_bounds__(256 * KS, KS * (DP > 128 ? 1 : (BN == 32 ? 3 : 2))) void fa_fwd16_kernel(FwdParams p) {
+__global__ __launch_bounds__(fwd16_threads(KS), fwd16_resident(DP, BN, KS)) void fa_fwd16_kernel(FwdParams p) {
     int e2 = fa_fwd16_body<T, DP, CAUSAL, HAS_MASK, OUT, DMA, BN, PV16, KS, PIPE, CBAL, false, const FwdParams>(p, 0, (int)threadIdx.x, blockIdx.x);
     if constexpr (PV16 == 1) {
         if (__builtin_expect(e2 != 0, 0)) {
@@ -155,15 +160,21 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
     static_assert(!CBAL || (CAUSAL && !HAS_MASK && DMA && BN == 64 && KS == 1 && !PIPE && DP <= 128), "balanced causal pairs: LDS-DMA staging, no mask tensor");
     static_assert(!PIPE || (DMA && !HAS_MASK && KS == 1 && DP <= 64 && BN == 64), "pipelined loop: head_dim <= 64, LDS-DMA staging, no mask tensor");
     static_assert(!PV16 || __is_same(T, __bf16), "PV16: bf16 operands");
-    static_assert(KS == 1 || (KS == 2 && DMA && !HAS_MASK && DP == 64 && BN == 64), "key-split: head_dim 64, LDS-DMA staging, no mask tensor");
-    constexpr int NT = 256 * KS;            // threads per workgroup
+    // KS = 4 ("decode form", round 6): at most 32 query rows per item (decode-like calls, after umfa_torch packed a KV head's query heads into rows) -- the FOUR waves
+    // of a workgroup all serve those rows, wave w owning key quarter w of every 128-key tile, and meet in LDS behind the sweep like KS = 2's halves.  In the plain form
+    // three of the four waves compute rows that do not exist and the launch waits for wave 0's chain through a whole 64-key tile (1.2-1.5 us per tile of a lone
+    // workgroup); here that chain covers 32 keys per wave and step.
+    static_assert(KS == 1 || (KS == 2 && DMA && !HAS_MASK && DP == 64 && BN == 64) || (KS == 4 && DMA && !HAS_MASK && !CAUSAL && !PIPE && !CBAL && BN == 128 && (DP == 64 || DP == 128)),
+                  "key-split: head_dim 64, LDS-DMA staging, no mask tensor; decode form: 128-key tiles, head_dim 64 / 128, no mask, not causal");
+    constexpr int NT = fwd16_threads(KS);   // threads per workgroup
+    constexpr int NW = NT / 64;             // waves
     constexpr bool VCONV = PV16 == 1;  // convert V in the kernel
     typedef Mma16<T> M;
     typedef typename M::V8 V8;
     typedef Mma16<typename std::conditional<PV16 != 0, _Float16, T>::type> MP;  // the P V product
     typedef typename MP::V8 PV8;
     typedef typename std::conditional<PV16 != 0, _Float16, T>::type PT;
-    constexpr int BM = 128;
+    constexpr int BM = KS == 4 ? 32 : 128;  // query rows per item
     constexpr int NKB = BN / 32;            // 32-key blocks per tile
     constexpr int NST = BN / 16;            // 16-key MFMA k-steps of PV per tile
     constexpr int NCH = DP / 8;             // 16-byte chunks per row
@@ -195,7 +206,7 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
 #ifdef UMFA_KS_ADJ  // lab (round 6): the two key halves of a row-wave on ADJACENT waves = different SIMDs (wave w runs on SIMD w % 4; as 4 kh + rw they share one)
     const int rw = KS == 1 ? wave : (wave >> 1), kh = KS == 1 ? 0 : (wave & 1);
 #else
-    const int rw = KS == 1 ? wave : (wave & 3), kh = KS == 1 ? 0 : (wave >> 2);  // row-wave, key half
+    const int rw = KS == 1 ? wave : KS == 4 ? 0 : (wave & 3), kh = KS == 1 ? 0 : KS == 4 ? wave : (wave >> 2);  // row-wave, key half (KS = 4: key quarter)
 #endif
 #ifdef UMFA_LAB_STAMPS
     unsigned long long stamp[6];
@@ -333,7 +344,7 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
     // r = l / NCH, chunk slot c = l % NCH and therefore FETCHES source chunk c ^ swz(row) (rule 21: the swizzle
     // goes on the source address; k_off / v_off are involutions in the chunk index).
     constexpr int RPI = 1024 / (2 * DP);          // rows per wave-instruction
-    constexpr int IPW = TILE_BYTES / 1024 / (4 * KS);  // instructions per wave per tile (K and V each)
+    constexpr int IPW = TILE_BYTES / 1024 / NW;  // instructions per wave per tile (K and V each)
     static_assert(!DMA || IPW >= 1, "tile too small for the workgroup's waves");
     constexpr int IPWR = DMA ? IPW : 1;
     int kdma[IPWR], vdma[IPWR];
@@ -873,7 +884,7 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
         constexpr uint32_t BNW = BN / KS;                     // keys of it
         // wave-uniform: is any part of this tile visible to this wave's rows?
         bool active = !CAUSAL || key_base <= wave_q0 + 31;
-        if (KS == 2) active = active && key_base < p.Skv;  // (the second half of a ragged last tile may hold no key at all)
+        if (KS >= 2) active = active && key_base < p.Skv;  // (the second half of a ragged last tile may hold no key at all)
         int mflag = 0;  // 1: every element of this wave's tile is masked (skip), 2: none is (no mask reads)
         if (HAS_MASK && mf_row) {
             if (t == t_begin || (t & 63) == 0) {
@@ -1031,7 +1042,7 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
             constexpr float TAU16 = 6.0f;
             const bool move = mx > m + TAU16;
             // (rows that have seen no key: under a mask tensor, and -- KS = 2 -- the rows of a causal diagonal block's second key half)
-            constexpr bool EMPTY_ROWS = HAS_MASK || KS == 2 || CBAL;  // (CBAL: a part B starts above tile 0)
+            constexpr bool EMPTY_ROWS = HAS_MASK || KS >= 2 || CBAL;  // (CBAL: a part B starts above tile 0)
             float m_use = (EMPTY_ROWS && m == -INFINITY) ? 0.0f : m;
             if (__any(move)) {
                 const float m_new = move ? mx : m;
@@ -1126,17 +1137,20 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
     // ---------------- epilogue ----------------
     float l = (l4[0] + l4[1]) + (l4[2] + l4[3]);
     float lt = l + xor32(l);
-    if constexpr (KS == 2) {
-        // the two key halves of a row-wave meet in LDS: half 1 publishes its un-normalised (O^T, m, l), half 0 folds it in
+    bool lead = true;  // this wave holds rows to store (KS = 4: key quarter 0, once the others are folded in)
+    if constexpr (KS >= 2) {
+        // the key halves (KS = 4: quarters) of a row-wave meet in LDS: the others publish their un-normalised (O^T, m, l), part 0 folds them in
         // (the split-KV fold's arithmetic) and stores.  The tile area is free: every LDS-DMA write has landed (the loop's last
         // stage_write waited vmcnt(0)) and the loop's last barrier is behind every wave's last tile read.
         constexpr int NREG = 16 * NDB + 2;
-        float* const ex = (float*)smem + rw * (NREG * 64) + lane;
+        constexpr int NOTH = KS == 4 ? 3 : 1;  // publishing parts per row-wave
+        float* const ex0 = (float*)smem + (KS == 4 ? 0 : rw * (NREG * 64)) + lane;  // (KS = 4: areas 0 .. 2 for quarters 1 .. 3)
         if constexpr (NS > 2) {  // the ring's youngest requests (tiles past the end) are still on their way into the tile area
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
-        if (kh == 1) {
+        if (kh != 0) {
+            float* const ex = ex0 + (KS == 4 ? (kh - 1) * (NREG * 64) : 0);
 #pragma unroll
             for (int i = 0; i < NDB; ++i)
 #pragma unroll
@@ -1145,17 +1159,25 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
             ex[(16 * NDB + 1) * 64] = lt;
         }
         __syncthreads();
-        if (kh == 1) return 0;
-        const float mo = ex[(16 * NDB) * 64], lo = ex[(16 * NDB + 1) * 64];
-        const float mn = fmaxf(m, mo);
-        const float mu = mn == -INFINITY ? 0.0f : mn;
-        const float a0 = __builtin_amdgcn_exp2f(m - mu), a1 = __builtin_amdgcn_exp2f(mo - mu);
+        if (kh != 0) {
+            if constexpr (KS == 2) return 0;
+            lead = false;  // (KS = 4: stays for the barriers of a split-KV fold, stores nothing)
+        } else {
 #pragma unroll
-        for (int i = 0; i < NDB; ++i)
+            for (int o = 0; o < NOTH; ++o) {
+                const float* const ex = ex0 + o * (NREG * 64);
+                const float mo = ex[(16 * NDB) * 64], lo = ex[(16 * NDB + 1) * 64];
+                const float mn = fmaxf(m, mo);
+                const float mu = mn == -INFINITY ? 0.0f : mn;
+                const float a0 = __builtin_amdgcn_exp2f(m - mu), a1 = __builtin_amdgcn_exp2f(mo - mu);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = acc[i][r] * a0 + ex[(16 * i + r) * 64] * a1;
-        lt = lt * a0 + lo * a1;
-        m = mn;
+                for (int i = 0; i < NDB; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][r] = acc[i][r] * a0 + ex[(16 * i + r) * 64] * a1;
+                lt = lt * a0 + lo * a1;
+                m = mn;
+            }
+        }
     }
     if constexpr (CBAL) {
         if (cb_role == 1) {
@@ -1196,7 +1218,7 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
             UMFA_CB_STAMP(3);
         }
     }
-    if (KS == 1 && nparts > 1) {
+    if ((KS == 1 || KS == 4) && nparts > 1) {
         // Split-KV combine (cdna_hip_programming.md Guideline 16, "every load sc1" form -- the fold protocol of fa_fwd16_w64): every
         // part publishes its un-normalised (O^T, m, l) with WRITE-THROUGH (sc1) stores -> vmcnt(0) -> barrier -> relaxed ticket; the part
         // that draws the last ticket folds the others with sc1 loads.  No release / acquire fence anywhere: an agent-scope release is
@@ -1217,7 +1239,8 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
         auto slot = [&](uint32_t part_, int chunk) -> int { return (int)(((part_ * 4 + (uint32_t)wave) * NCHK + (uint32_t)chunk) * 1024u) + lane * 16; };
         constexpr int SC1 = 16;  // cache policy bit of the buffer builtins: system-coherent level 1 = write-through / read-around the XCD's L2
         typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-        const bool wave_rows = wave_q0 < p.Sq;  // (wave-uniform)
+        if constexpr (KS == 4) __syncthreads();  // (the exchange areas above sit in the tile area the ticket word below is in)
+        const bool wave_rows = wave_q0 < p.Sq && lead;  // (wave-uniform)
         if (wave_rows) {
 #pragma unroll
             for (int i = 0; i < NDB; ++i)
@@ -1277,7 +1300,7 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
         }
     }
     const float inv = lt > 0.0f ? 1.0f / lt : 0.0f;
-    if (q_row < p.Sq) {
+    if (q_row < p.Sq && lead) {
         OUT* __restrict__ op = (OUT*)p.o + ((int64_t)bh * p.Sq + q_row) * D;
 #pragma unroll
         for (int i = 0; i < NDB; ++i)

@@ -14,6 +14,11 @@ hipError_t launch_fwd16_pv(const FwdParams& p, hipStream_t stream) {
     // B16 H16 Sq512 Skv512 51.8 / 55.2, B4 H32 Sq768 Skv2048 120 / 129, FLUX 218 / 225, B1 H24 Sq4096 Skv77 19.6 / 24.1; split launches lose
     // (twice the barriers per part: B1 H2 S4096 47.1 / 40.7, B2 H8 S1024 27.9 / 24.3), so they keep 64-key tiles.
     const bool dma = (int)p.D == DP && dma_enabled();
+    if constexpr (!CAUSAL && !HAS_MASK && (DP == 64 || DP == 128)) {
+        if (dma && fwd16_decode_form(p))  // decode form: four key quarters per tile (fa_fwd_16_kernel.h KS = 4)
+            return p.pv16 == 2 ? launch_dma<__bf16, DP, CAUSAL, HAS_MASK, OUT, true, 128, 2, 4>(p, stream)
+                               : launch_dma<__bf16, DP, CAUSAL, HAS_MASK, OUT, true, 128, 1, 4>(p, stream);
+    }
     if constexpr (DP == 128 && !HAS_MASK && !CAUSAL) {
         const uint64_t items = (uint64_t)((p.Sq + 127) / 128) * p.B * p.H;
         if (dma && !tuning().bn64.load(std::memory_order_relaxed) && (p.nsplit < 2 || !p.part_buf) && items >= 2 * (uint64_t)device_cu_count())

@@ -24,6 +24,7 @@ struct Tuning {
         cast_u{0} /* lab: 16-byte loads per thread of the V cast pre-pass (4, 16, 32; 0 = the launcher's choice) */,
         quant_block_wg{0} /* tests / A-B: the block-wise quantiser in its one-workgroup-per-block form everywhere */,
         cast_wait_us{100} /* V cast pre-pass: how long a workgroup waits for its slab's other workgroups before it reads the slab's amax itself */,
+        decode_ks{0} /* decode form of the 128-row kernel (<= 32 query rows: four key quarters per tile): 0 = where it applies, 2 = never */,
         cbal{0} /* balanced causal pairs on the 128-row kernel: 0 = where the plan wants them, 1 = wherever they exist, 2 = never */,
         cbal_delta{-1} /* ... key tiles by which a pair's folding part is shorter than half; < 0 = the plan's choice */;
 };
@@ -53,6 +54,7 @@ bool fwd_16_supported(const FwdParams& p);
 struct FwdSplitPlan {
     uint32_t n_full, nsplit;
     size_t buf_bytes, cnt_bytes;
+    uint32_t decode = 0;                // the decode form of the kernel (FwdParams::decode_form): the part count was chosen for ITS residency
     uint32_t cbal = 0, cbal_delta = 0;  // balanced causal pairs (FwdParams::cbal): nsplit stays 1, the scratch is the pairs'
 };
 FwdSplitPlan fwd_16_split_plan(const FwdParams& p);

@@ -155,6 +155,7 @@ hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p,
             if (!cast_v(pp) && e != hipSuccess) return e;
         }
         const FwdSplitPlan plan = fwd_16_split_plan(p);
+        pp.decode_form = plan.decode;
         if (plan.nsplit > 1) {
             // tickets first (16-byte multiple at the allocation start), partials behind them
             char* buf = sc.ensure_split(plan.cnt_bytes, plan.buf_bytes, stream);  // tickets zero: at allocation, then by the kernel

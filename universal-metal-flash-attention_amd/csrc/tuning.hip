@@ -67,6 +67,7 @@ Tuning& tuning() {
         x->cast_wait_us.store(env_int("UMFA_CAST_WAIT_US", 100));
         x->bwd_ds_lab.store(env_int("UMFA_LAB_DS", 0));
         x->cbal.store(env_int("UMFA_CBAL", 0));
+        x->decode_ks.store(env_int("UMFA_DECODE_KS", 0));
         x->cbal_delta.store(env_int("UMFA_CBAL_DELTA", -1));
         return x;
     }();
@@ -100,7 +101,7 @@ bool set_tuning(const char* name, const char* value) {
         {"no_split", &t.no_split, true}, {"force_split", &t.force_split, false}, {"no_dma", &t.no_dma, true},
         {"bn64", &t.bn64, true}, {"pv_fp16", &t.pv_fp16, true}, {"bwd_ds_store", &t.bwd_ds_store, true}, {"no_w64_mask", &t.no_w64_mask, true}, {"ksplit", &t.ksplit, true}, {"no_pipe", &t.no_pipe, true}, {"no_w64_mask_lazy", &t.no_w64_mask_lazy, true}, {"no_w64_bias", &t.no_w64_bias, true},
         {"cast_two_pass", &t.cast_two_pass, true}, {"bwd_ds_lab", &t.bwd_ds_lab, false}, {"cast_u", &t.cast_u, false}, {"quant_block_wg", &t.quant_block_wg, true},
-        {"cast_wait_us", &t.cast_wait_us, false}, {"cbal", &t.cbal, false}, {"cbal_delta", &t.cbal_delta, false},
+        {"cast_wait_us", &t.cast_wait_us, false}, {"cbal", &t.cbal, false}, {"cbal_delta", &t.cbal_delta, false}, {"decode_ks", &t.decode_ks, false},
     };
     for (auto& e : tab)
         if (!strcmp(name, e.n)) {
@@ -127,7 +128,7 @@ bool get_tuning(const char* name, char* out, size_t n) {
             {"bwd_separate_delta", &t.bwd_separate_delta}, {"no_split", &t.no_split}, {"force_split", &t.force_split},
             {"no_dma", &t.no_dma}, {"bn64", &t.bn64}, {"pv_fp16", &t.pv_fp16}, {"bwd_ds_store", &t.bwd_ds_store}, {"no_w64_mask", &t.no_w64_mask}, {"ksplit", &t.ksplit}, {"no_pipe", &t.no_pipe}, {"no_w64_mask_lazy", &t.no_w64_mask_lazy}, {"no_w64_bias", &t.no_w64_bias},
             {"cast_two_pass", &t.cast_two_pass}, {"bwd_ds_lab", &t.bwd_ds_lab}, {"cast_u", &t.cast_u}, {"quant_block_wg", &t.quant_block_wg},
-            {"cast_wait_us", &t.cast_wait_us}, {"cbal", &t.cbal}, {"cbal_delta", &t.cbal_delta},
+            {"cast_wait_us", &t.cast_wait_us}, {"cbal", &t.cbal}, {"cbal_delta", &t.cbal_delta}, {"decode_ks", &t.decode_ks},
         };
         const std::atomic<int>* v = nullptr;
         for (auto& e : tab)
