@@ -477,6 +477,13 @@ def run_rank(args) -> None:
                   "cfg3_flux_bf16_mask_additive_bias": (-(_i[:, None] - _i[None, :]).abs().to(torch.float16) / 256.0)[None, None].contiguous(),
                   "cfg3_flux_bf16_mask_additive_bias_per_head": (-(_i[:, None] - _i[None, :]).abs().float()[None] /
                                                                  (64.0 * (1 + torch.arange(H, device=dev)[:, None, None]))).to(torch.float16)[None].contiguous()}
+        # fp32 ADDITIVE masks (end of round 6; what the reference's callers build: metal_sdpa_backend.cpp:3210-3231).  The classification pass writes an fp16 copy and
+        # decides on the device whether it is exact; the bias kernel (on the copy) and the 128-row kernel (on the fp32 tensor) are both enqueued, guarded by that verdict.
+        # "_fp32": the fp16 bias above widened (exact: the bias kernel runs); "_fp32_inexact": the same bias computed in fp32 (|i - j| / 256 above 2048 does not fit fp16:
+        # the 128-row kernel runs, the pass and one empty launch are the cost); "_blockdiag_fp32": a bool mask as the reference's torch path converts it (0 / -inf)
+        _masks["cfg3_flux_bf16_mask_additive_bias_fp32"] = _masks["cfg3_flux_bf16_mask_additive_bias"].float()
+        _masks["cfg3_flux_bf16_mask_additive_bias_fp32_inexact"] = (-(_i[:, None] - _i[None, :]).abs().float() / 256.0)[None, None].contiguous()
+        _masks["cfg3_flux_bf16_mask_blockdiag_fp32"] = torch.where(_masks["cfg3_flux_bf16_mask_blockdiag"], 0.0, float("-inf")).contiguous()
         for _name, _m in _masks.items():
             fo = torch.empty(B, H, S, D, device=dev, dtype=torch.float32)
             tg = graph_ms(lambda: umfa_torch.attention_forward(q, k, v, mask=_m, out=fo), 20)
@@ -494,13 +501,22 @@ def run_rank(args) -> None:
                                     mask_type=_orc.MASK_ADDITIVE if _add else _orc.MASK_BOOL).astype(_np.float64)
             dd = fo[:, :, rows].cpu().numpy().astype(_np.float64) - ref
             vis = 1.0 if _add else float(_m.float().mean().item())  # fraction of (row, key) pairs that attend: the work a skipping kernel has to do
+            if _add and bool(torch.isinf(_m).any().item()):
+                vis = float((~torch.isinf(_m)).float().mean().item())
             configs[_name] = {"ms": round(tg, 5), "kernel": kn, "visible_fraction": round(vis, 4),
                               "tflops_of_visible_work": round(FLOPS_PER_STEP * vis / tg / 1e9, 1),
                               "frac_of_visible_work": round(FLOPS_PER_STEP * vis / tg / 1e9 / PEAK_BF16_TFLOPS, 4),
                               "rel": float(_np.abs(dd).max() / _np.abs(ref).max()), "fp32_out": True,
                               "mask": {"cfg3_flux_bf16_mask_padding": "bool [1,1,1,S], keys < 3000 attend", "cfg3_flux_bf16_mask_blockdiag": "bool [1,1,S,S], four blocks of 1024",
                                        "cfg3_flux_bf16_mask_additive_bias": "fp16 additive [1,1,S,S], -|i - j| / 256: every tile mixed",
-                                       "cfg3_flux_bf16_mask_additive_bias_per_head": "fp16 additive [1,H,S,S], -|i - j| / (64 (h + 1)): 805 MB, every tile mixed, not classified"}[_name]}
+                                       "cfg3_flux_bf16_mask_additive_bias_per_head": "fp16 additive [1,H,S,S], -|i - j| / (64 (h + 1)): 805 MB, every tile mixed, not classified",
+                                       "cfg3_flux_bf16_mask_additive_bias_fp32": "fp32 additive [1,1,S,S]: the fp16 bias widened -- fp16 holds every value: the bias kernel of the guarded pair runs",
+                                       "cfg3_flux_bf16_mask_additive_bias_fp32_inexact": "fp32 additive [1,1,S,S], -|i - j| / 256 in fp32 -- fp16 does not hold it: the 128-row kernel of the guarded pair runs",
+                                       "cfg3_flux_bf16_mask_blockdiag_fp32": "fp32 additive [1,1,S,S], 0 / -inf, four blocks of 1024 (a bool mask as the reference's torch path converts it)"}[_name]}
+            if _m.dtype == torch.float32:  # ... and the 128-row kernel alone (the route before this build)
+                with umfa_torch.options(no_w64_f32_mask=1):
+                    configs[_name]["ms_128row_alone"] = round(graph_ms(lambda: umfa_torch.attention_forward(q, k, v, mask=_m, out=fo), 20), 5)
+                    configs[_name]["kernel_128row_alone"] = umfa_torch.last_kernel()
             del fo
         # sliding window WITHOUT a mask tensor (the in-stream entry's UMFA_MASK_TYPE_WINDOW; the north-star's "sliding-window tile early-exit"):
         # +-512 keys around the row -- the same band as the window TENSORS of the mask tests, with no S x S mask anywhere

@@ -422,7 +422,7 @@ const char* umfa_last_kernel_name(mfa_context_t context);
  *                        default = lazy for bf16, deferred for fp16 and the int8 kernels.
  *   "softmax_tau"        "0" ... "16" (log2 units, default 6)
  *   "force_w64" "no_w64" "w64_grid" "no_mask_flags" "bwd_exact" "bwd_dq" "bwd_persist" "no_split" "force_split"
- *   "no_dma" "bn64" "w64_skew" "no_w64_mask" "no_w64_mask_lazy" "no_w64_bias" "ksplit" "no_pipe"
+ *   "no_dma" "bn64" "w64_skew" "no_w64_mask" "no_w64_mask_lazy" "no_w64_bias" "no_w64_f32_mask" "ksplit" "no_pipe"
  *                        kernel-selection overrides used by tests and A/B benches ("0" / "1" or a number)
  *   "bwd_ds_store"       "0" | "1": lab -- the dS-store form of the head_dim 128 non-causal backward (5 products, a
  *                        [B H Sq Skv] scratch in the operand type); measured level with the default (round 4), kept for A/B
@@ -457,6 +457,12 @@ const char* umfa_last_kernel_name(mfa_context_t context);
  *                        causal, head_dim 64 / 128: the four waves of a workgroup all serve those rows, each owning a key quarter of every 128-key tile (in
  *                        the plain form three of four waves compute rows that do not exist).  0: while the items fit one round of its residency (the
  *                        split-KV plan then counts parts for it); 1: whenever the shape allows; 2: never.  Same results to rounding; bitwise repeatable.
+ *   "no_w64_f32_mask"    "0" (default) | "1": fp32 ADDITIVE mask tensors.  By default a mask the one-wave-per-SIMD bias kernels could take as fp16 (<= 4-D
+ *                        broadcastable, 16-byte aligned contiguous rows, whole 64 x 64 tiles, bytes within twice the call's tensor traffic) is
+ *                        classified and copied to fp16 by a pre-pass that also decides ON THE DEVICE whether fp16 holds every value exactly
+ *                        (0 / -inf masks, masks built in 16 bits and widened, dyadic biases: yes).  Both routes are enqueued -- the bias kernel on the copy,
+ *                        the 128-row kernel on the caller's tensor -- and each checks the verdict word first: exactly one runs, with the numbers that kernel
+ *                        gives an fp16 (resp. fp32) mask.  umfa_last_kernel_name then names both.  "1": the 128-row kernel alone, as before.
  *   "cbal_delta"         "-1" (default: the plan's choice) | "0" ... "16": key tiles by which the folding workgroup's share is shorter (tests, A/B)
  * Returns MFA_ERROR_INVALID_ARGS for an unknown name or a value out of range.  Thread-safe; affects later launches. */
 mfa_error_t umfa_set_option(mfa_context_t context, const char* name, const char* value);

@@ -319,7 +319,11 @@ def test_w64_mask_routing_gate(umfa_opts):
     umfa_torch.attention_forward(q, k, v, mask=mb, causal=True)
     assert umfa_torch.last_kernel().endswith(",mask>")
     umfa_torch.attention_forward(q, k, v, mask=torch.zeros(1, 1, 512, 512, device="cuda"))
-    assert umfa_torch.last_kernel().startswith("fa_fwd16<")
+    # (an fp32 additive mask under force_w64: the guarded pair since the end of round 6 -- tests/test_gpu_w64_f32_mask.py; without force, 8 items stay on the 128-row kernel)
+    assert " | fa_fwd16<" in umfa_torch.last_kernel(), umfa_torch.last_kernel()
+    with umfa_torch.options(force_w64=0):
+        umfa_torch.attention_forward(q, k, v, mask=torch.zeros(1, 1, 512, 512, device="cuda"))
+        assert umfa_torch.last_kernel().startswith("fa_fwd16<")
     with umfa_torch.options(pv_fp16=0):
         umfa_torch.attention_forward(q, k, v, mask=mb)
         assert umfa_torch.last_kernel() == "fa_fwd16<bf16,128>"

@@ -1210,8 +1210,12 @@ def run_w64_mask_case(seed):
                 kern = umfa_torch.last_kernel()
                 o2 = umfa_torch.quantized_attention_forward_stream(q, k, v, mask=mask, bits=qbits)
             else:
-                mdt = rng.choice([torch.float16, torch.float16, torch.bfloat16])
+                mdt = rng.choice([torch.float16, torch.float16, torch.bfloat16, torch.float32, torch.float32])
                 mask = val.masked_fill(~keep, float("-inf")).to(mdt)
+                if mdt == torch.float32 and rng.random() < 0.6:
+                    # (end of round 6) an fp32 mask whose values fp16 holds: the bias kernel of the guarded pair runs; raw fp32 values: the 128-row kernel.  Either way
+                    # both launches are enqueued (when the mask is small enough for the pass to read it) and the answer must be the fp64 one
+                    mask = mask.to(torch.float16).float()
                 if rng.random() < 0.25 and rows > 1:  # a view with a row stride of its own (rows stay 16-byte aligned)
                     wide = torch.zeros(*shape[:-1], 2 * Skv, device="cuda", dtype=mdt)
                     wide[..., :Skv] = mask
@@ -1221,7 +1225,7 @@ def run_w64_mask_case(seed):
                 o2 = umfa_torch.attention_forward(q, k, v, mask=mask, out_dtype=torch.float32)
         what = (seed, "quant" if quant else str(dt), B, H, Sq, Skv, content, tuple(shape), str(mask.dtype), opts, kern)
         want = "fa_fwd_w64_i" if quant else ",bias>"
-        if want not in kern:
+        if want not in kern and not (mask.dtype == torch.float32 and kern.startswith("fa_fwd16<")):  # (an fp32 mask too large for the pass: the 128-row kernel alone)
             return "kernel %r" % (what,)
         if not torch.isfinite(o).all():
             return "non-finite %r" % (what,)

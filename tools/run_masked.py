@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Profiling driver: FLUX-shape forward with a mask tensor / window (python tools/run_masked.py n kind [dtype]);
-kind: blockdiag | padding | window_tensor | window | causal | random | additive_blockdiag"""
+kind: blockdiag | padding | window_tensor | window | causal | random | additive_blockdiag | bias_f32 (fp16 holds it) | bias_f32_inexact"""
 import sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -21,6 +21,10 @@ if kind == "blockdiag":
 elif kind == "additive_blockdiag":
     m = ((i[:, None] // 1024) == (i[None, :] // 1024))[None, None]
     kw["mask"] = torch.where(m, 0.0, float("-inf")).to(torch.float32).contiguous()
+elif kind == "bias_f32":
+    kw["mask"] = (-(i[:, None] - i[None, :]).abs().float() / 256.0).to(torch.float16).float()[None, None].contiguous()
+elif kind == "bias_f32_inexact":
+    kw["mask"] = (-(i[:, None] - i[None, :]).abs().float() / 256.0)[None, None].contiguous()
 elif kind == "padding":
     kw["mask"] = (i < 3000)[None, None, None, :].contiguous()
 elif kind == "window_tensor":

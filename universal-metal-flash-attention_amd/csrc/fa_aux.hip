@@ -871,6 +871,16 @@ __global__ __launch_bounds__(256) void mask_flags_kernel(FwdParams p, uint8_t* f
     if (lane == 0) flags[wid] = !open ? 1 : (!term ? 2 : 0);
 }
 
+// the flag array's geometry (FwdParams::mf_*) for `flags` filled elsewhere: mask_classify_f32_kernel writes the same bytes on its way through an fp32 mask
+void mask_flags_describe(FwdParams& p, const uint8_t* flags) {
+    const uint32_t Hm = p.ms[1] != 0 ? p.H : 1;
+    p.mf_nrb = (p.Sq + 31) / 32;
+    p.mf_ntiles = (p.Skv + 63) / 64;
+    p.mf_bs = p.ms[0] != 0 ? Hm : 0;
+    p.mf_hs = p.ms[1] != 0 ? 1 : 0;
+    p.mask_flags = flags;
+}
+
 hipError_t launch_mask_flags(FwdParams& p, uint8_t* flags, hipStream_t stream) {
     const uint32_t Bm = p.ms[0] != 0 ? p.B : 1, Hm = p.ms[1] != 0 ? p.H : 1;
     p.mf_nrb = (p.Sq + 31) / 32;
@@ -891,8 +901,29 @@ hipError_t launch_mask_flags(FwdParams& p, uint8_t* flags, hipStream_t stream) {
 // for banded / padded ones).  Additive float masks are usually dense biases with nothing to skip: only when the distinct
 // mask bytes stay below twice the Q + K + V + O traffic (e.g. one [Sq, Skv] bias shared by the heads).
 // one wave per (mask batch, mask head, 256-row block): compact the visited tiles
-__global__ __launch_bounds__(64) void mask_list_kernel(const uint8_t* wflag, uint32_t* list, uint32_t* cnt, uint32_t nrb64, uint32_t nqb, uint32_t T) {
+// fp32 masks (xflag != NULL): workgroup 0 also folds the wave-tiles' exactness bytes (mask_classify_f32_kernel) into the verdict word the two guarded attention
+// launches read (FwdParams::guard): 1 if any tile's fp16 copy is not exact, else 0 -- a plain store, every launch (a few KiB of bytes for every mask the route
+// admits: mask_flags_worthwhile bounds the mask by twice the call's tensor traffic)
+__global__ __launch_bounds__(64) void mask_list_kernel(const uint8_t* wflag, uint32_t* list, uint32_t* cnt, uint32_t nrb64, uint32_t nqb, uint32_t T,
+                                                       const uint8_t* __restrict__ xflag, uint64_t xtotal, uint32_t* __restrict__ guard) {
     const uint32_t lane = threadIdx.x, qblk = blockIdx.x % nqb, slab = blockIdx.x / nqb;
+    if (xflag != nullptr && blockIdx.x == 0) {
+        uint32_t a = 0;
+        const uint64_t n16 = xtotal / 16;
+        for (uint64_t i0 = 0; i0 < n16; i0 += 256) {  // four 16-byte loads per lane in flight
+            u32x4_t w4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint64_t i = i0 + 64 * u + lane;
+                w4[u] = i < n16 ? ((const u32x4_t*)xflag)[i] : u32x4_t{0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a |= w4[u][0] | w4[u][1] | w4[u][2] | w4[u][3];
+        }
+        for (uint64_t i = n16 * 16 + lane; i < xtotal; i += 64) a |= xflag[i];
+        const bool any = __builtin_amdgcn_ballot_w64(a != 0) != 0;
+        if (lane == 0) *guard = any ? 1u : 0u;
+    }
     const uint8_t* wf = wflag + (uint64_t)slab * nrb64 * T;
     uint32_t* out = list + (uint64_t)blockIdx.x * T * 2;
     uint32_t n = 0;
@@ -964,12 +995,13 @@ static hipError_t mask_pack_prepare(FwdParams& p, void* scratch, MaskPackArgs& a
     return hipSuccess;
 }
 
-static hipError_t mask_pack_finish(const MaskPackArgs& a, uint32_t* list, uint32_t* cnt, uint32_t nqb, uint64_t slabs, hipStream_t stream) {
+static hipError_t mask_pack_finish(const MaskPackArgs& a, uint32_t* list, uint32_t* cnt, uint32_t nqb, uint64_t slabs, hipStream_t stream,
+                                   const uint8_t* xflag = nullptr, uint32_t* guard = nullptr) {
     if (!a.done) {
         if (a.vec16) hipLaunchKernelGGL(mask_pack_kernel<true>, dim3((unsigned)((a.total + 3) / 4)), dim3(256), 0, stream, a);
         else hipLaunchKernelGGL(mask_pack_kernel<false>, dim3((unsigned)((a.total + 3) / 4)), dim3(256), 0, stream, a);
     }
-    hipLaunchKernelGGL(mask_list_kernel, dim3((unsigned)(slabs * nqb)), dim3(64), 0, stream, a.wflag, list, cnt, a.nrb64, nqb, a.T);
+    hipLaunchKernelGGL(mask_list_kernel, dim3((unsigned)(slabs * nqb)), dim3(64), 0, stream, a.wflag, list, cnt, a.nrb64, nqb, a.T, xflag, (uint64_t)a.total, guard);
     return hipGetLastError();
 }
 
@@ -1033,29 +1065,139 @@ __global__ __launch_bounds__(256) void mask_classify_kernel(MaskPackArgs p, _Flo
     if (lane == 0) p.wflag[wid] = !open ? 1 : (!term ? 2 : 0);
 }
 
-// bytes of the dense fp16 copy of a bf16 additive mask (0 for fp16 masks): [Bm, Hm, Sq or 1, Skv]
+// ---- fp32 additive masks on the same structure (end of round 6; the reference's additive masks are fp32 wherever its own callers build them:
+// metal_sdpa_backend.cpp:3210-3231, MFABridge.swift:157-242).  The bias kernels read fp16 (v_fma_mix_f32 takes f16 halves; a 64 x 64 fp32 tile would not fit the
+// wave's staging ring), so the classification pass writes a dense fp16 copy as for bf16 masks -- but fp32 values need not fit fp16, and rounding a term of
+// magnitude m moves the logit by up to m 2^-11: 8e-3 at m = 16, past the 1e-3 bound.  So the pass also records, per wave-tile, whether fp16 holds every value
+// EXACTLY (xflag; "exactly" = the copy is within 2^-24 of the value in absolute terms: +-inf and NaN kept, every fp16 value, and what flushes to a
+// subnormal without moving e^x in fp32), mask_list_kernel's first workgroup folds the bytes into one verdict word, and the two attention launches the runtime enqueues -- the bias
+// kernel on the copy, the 128-row kernel on the caller's tensor -- are guarded by it (FwdParams::guard): exactly one of them runs.  0 / -inf masks, masks
+// built in fp16 / bf16 and widened, small-integer and dyadic biases take the fast kernel; anything else keeps today's kernel and today's numbers.
+// One WORKGROUP per (mask batch, mask head, 256-row block, 64-key tile), its four waves = the block's four 64-row wave-tiles (what the attention kernel's four
+// waves see of the tile): a lane owns one 16-byte segment (4 keys) of a row, a wave-load covers 4 rows, 16 loads the wave-tile.
+__global__ __launch_bounds__(256) void mask_classify_f32_kernel(MaskPackArgs p, uint32_t nqb, _Float16* copy, int64_t cb, int64_t ch, int64_t cr, uint8_t* xflag, uint8_t* flags128) {
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    __shared__ uint32_t wave_class[4];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x % p.T;
+    const uint32_t qblk = (blockIdx.x / p.T) % nqb;
+    const uint32_t slab = blockIdx.x / (p.T * nqb);
+    const uint32_t rb = 4 * qblk + wv;
+    if (rb >= p.nrb64) wave_class[wv] = 1u;  // (a wave past Sq: nothing there)
+    const bool live = rb < p.nrb64;
+    const uint64_t wid = ((uint64_t)slab * p.nrb64 + (live ? rb : 0u)) * p.T + tile;
+    const uint32_t hm = slab % p.Hm, bm = slab / p.Hm;
+    const uint32_t row0 = rb * 64 + (lane >> 4), key0 = tile * 64 + (lane & 15) * 4;
+    const char* base = (const char*)p.mask + ((int64_t)bm * p.ms[0] + (int64_t)hm * p.ms[1] + (int64_t)row0 * p.ms[2] + key0) * 4;
+    u32x4_t w[16];  // the whole tile in flight: 16 loads of 4 rows each
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w[i] = live ? *(const u32x4_t*)(base + (int64_t)(4 * i) * p.ms[2] * 4) : u32x4_t{0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u};
+    // the 128-row route's tile flags (FwdParams::mask_flags: per 32-row block and 64-key tile, from the fp32 VALUES as mask_flags_kernel reads them) come from
+    // the same read: rows 0 ... 31 of the tile are loads 0 ... 7, rows 32 ... 63 loads 8 ... 15
+    bool open32[2] = {false, false}, term32[2] = {false, false};
+    bool any_open = false, any_term = false, inexact = false;
+    u32x2_t o[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        uint32_t hb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x = __uint_as_float(w[i][j]);
+            open32[i >> 3] |= w[i][j] != 0xff800000u;
+            term32[i >> 3] |= (w[i][j] & 0x7fffffffu) != 0;
+            const bool fin = fabsf(x) < INFINITY;  // (false for NaN too)
+            // finite values whose log2-domain term overflows (x log2 e = -inf in fp32: torch.finfo(torch.float32).min, the "large negative" idiom at its
+            // largest) ARE -inf to every kernel of this library (fa_common.h mask_term): -inf in the copy, and exact
+            const bool as_ninf = fin && x * UMFA_LOG2E == -INFINITY;
+            const float cl = fabsf(x) <= 65504.0f ? x : (x > 0.0f ? 65504.0f : -65504.0f);
+            const _Float16 h = as_ninf ? (_Float16)(-INFINITY) : (_Float16)(fin ? cl : x);
+            inexact |= fin && !as_ninf && fabsf((float)h - x) > 0x1p-24f;
+            hb[j] = (uint32_t)__builtin_bit_cast(uint16_t, h);
+            any_open |= hb[j] != 0xfc00u;
+            any_term |= (hb[j] & 0x7fffu) != 0;
+        }
+        o[i] = u32x2_t{hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16)};
+    }
+    const bool open = __builtin_amdgcn_ballot_w64(any_open) != 0, term = __builtin_amdgcn_ballot_w64(any_term) != 0;
+    const bool bad = __builtin_amdgcn_ballot_w64(inexact) != 0;
+    // Who reads the copy: a wave whose class for a LISTED tile is not "all zero" (fa_fwd16_w64_kernel.inc: mk_cls != 2 -- a wave-tile at -inf throughout
+    // reads its -inf like any other), and a tile is listed when any of the block's four waves is not masked there (mask_list_kernel).  Nothing else is
+    // written: the masked tiles of a 0 / -inf document or window mask cost their read, not a write.
+    const uint32_t my_class = !open ? 1u : (!term ? 2u : 0u);
+    if (live && lane == 0) wave_class[wv] = my_class;
+    __syncthreads();
+    // (tile 0 as well: a block that sees nothing anywhere lists its tile 0, every wave masked -- mask_list_kernel -- and its waves read their -inf there)
+    const bool listed = tile == 0 || wave_class[0] != 1u || wave_class[1] != 1u || wave_class[2] != 1u || wave_class[3] != 1u;
+    if (live && my_class != 2u && listed) {
+        const bool writer = p.ms[2] != 0 || rb == 0;  // (a mask without a row dimension: ONE row in the copy, written by the wave of row block 0 -- its lanes 0 ... 15)
+        _Float16* dst = copy + (int64_t)bm * cb + (int64_t)hm * ch + (int64_t)row0 * cr + key0;
+        if (writer) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (p.ms[2] != 0 || (i == 0 && lane < 16)) *(u32x2_t*)(dst + (int64_t)(4 * i) * cr) = o[i];
+        }
+    }
+    bool f_open[2], f_term[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        f_open[hf] = __builtin_amdgcn_ballot_w64(open32[hf]) != 0;
+        f_term[hf] = __builtin_amdgcn_ballot_w64(term32[hf]) != 0;
+    }
+    if (live && lane == 0) {
+        p.wflag[wid] = (uint8_t)my_class;
+        xflag[wid] = bad ? 1 : 0;  // (always written: nothing to clean between launches, nothing atomic)
+        if (flags128) {
+            uint8_t* f = flags128 + ((uint64_t)slab * (2 * p.nrb64) + 2 * rb) * p.T + tile;
+            f[0] = !f_open[0] ? 1 : (!f_term[0] ? 2 : 0);
+            f[p.T] = !f_open[1] ? 1 : (!f_term[1] ? 2 : 0);
+        }
+    }
+}
+
+static inline size_t up256(uint64_t n) { return (size_t)((n + 255) & ~255ull); }
+
+// bytes behind the pack area of an additive mask's scratch block: bf16 masks -- the dense fp16 copy [Bm, Hm, Sq or 1, Skv]; fp32 masks -- that copy, the
+// wave-tiles' exactness bytes, the verdict word (a 256-byte block of its own) and the 128-row route's tile flags (mask_flags_bytes); 0 for fp16 masks
 size_t mask_copy_bytes(const FwdParams& p) {
-    if (p.mask_kind != MK_BF16) return 0;
+    if (p.mask_kind != MK_BF16 && p.mask_kind != MK_F32) return 0;
     const uint64_t Bm = p.ms[0] ? p.B : 1, Hm = p.ms[1] ? p.H : 1, Sm = p.ms[2] ? p.Sq : 1;
-    return (size_t)((Bm * Hm * Sm * p.Skv * 2 + 255) & ~255ull);
+    const size_t copy = up256(Bm * Hm * Sm * p.Skv * 2);
+    if (p.mask_kind == MK_BF16) return copy;
+    return copy + up256(Bm * Hm * ((p.Sq + 63) / 64) * ((p.Skv + 63) / 64)) + 256 + up256(mask_flags_bytes(p));
 }
 
 // scratch = [the pack layout of mask_pack_bytes | the fp16 copy of a bf16 mask].  On return p describes what the attention kernel reads: an fp16 mask.
+// fp32 masks: scratch = [pack | fp16 copy | exactness bytes | verdict word (256 bytes) | the 128-row route's tile flags]; p.guard = the verdict word, guard_want = 0
+// (the bias kernel's side: runtime.hip enqueues the 128-row kernel behind it with guard_want = 1 and its flags at (uint8_t*)p.guard + 256).
 hipError_t launch_mask_classify(FwdParams& p, void* scratch, hipStream_t stream) {
-    if (p.mask_kind != MK_F16 && p.mask_kind != MK_BF16) return hipErrorInvalidValue;
-    const bool bf = p.mask_kind == MK_BF16;
+    if (p.mask_kind != MK_F16 && p.mask_kind != MK_BF16 && p.mask_kind != MK_F32) return hipErrorInvalidValue;
+    const bool bf = p.mask_kind == MK_BF16, f32 = p.mask_kind == MK_F32;
     const size_t pack_bytes = (mask_pack_bytes(p) + 255) & ~(size_t)255;
     MaskPackArgs a;
     uint32_t *list, *cnt, nqb;
     uint64_t slabs;
-    if (bf) p.mask_kind = MK_F16;  // (the layout of the pack area does not depend on the kind; mask_pack_prepare takes bool / fp16)
-    if (hipError_t e = mask_pack_prepare(p, scratch, a, list, cnt, nqb, slabs); e != hipSuccess) return e;
+    const int kind_in = p.mask_kind;
+    if (bf || f32) p.mask_kind = MK_F16;  // (the layout of the pack area does not depend on the kind; mask_pack_prepare takes bool / fp16)
+    if (hipError_t e = mask_pack_prepare(p, scratch, a, list, cnt, nqb, slabs); e != hipSuccess) { p.mask_kind = kind_in; return e; }
     p.mk_bits = nullptr;
     const unsigned grid = (unsigned)((a.total + 3) / 4);
-    if (bf) {
+    const uint8_t* xflag_f32 = nullptr;
+    if (bf || f32) {
         _Float16* copy = (_Float16*)((char*)scratch + pack_bytes);
         const int64_t Sm = p.ms[2] ? p.Sq : 1, cr = p.ms[2] ? (int64_t)p.Skv : 0, chd = Sm * p.Skv, cbt = (int64_t)a.Hm * chd;
-        hipLaunchKernelGGL(mask_classify_kernel<true>, dim3(grid), dim3(256), 0, stream, a, copy, cbt, chd, cr);
+        if (f32) {
+            uint8_t* xflag = (uint8_t*)copy + up256((uint64_t)a.Bm * a.Hm * Sm * p.Skv * 2);
+            uint32_t* guard = (uint32_t*)(xflag + up256(a.total));
+            // ... and the 128-row route's tile flags behind the verdict word: [Bm Hm][2 nrb64][T] bytes = the layout of launch_mask_flags (Sq is a multiple of 64 here)
+            const uint64_t wgs = slabs * nqb * a.T;
+            if (wgs > 0x7fffffffull) { p.mask_kind = kind_in; return hipErrorInvalidValue; }
+            hipLaunchKernelGGL(mask_classify_f32_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, a, nqb, copy, cbt, chd, cr, xflag, (uint8_t*)guard + 256);
+            xflag_f32 = xflag;
+            p.guard = guard;
+            p.guard_want = 0;
+        } else {
+            hipLaunchKernelGGL(mask_classify_kernel<true>, dim3(grid), dim3(256), 0, stream, a, copy, cbt, chd, cr);
+        }
         p.mask = copy;
         p.ms[0] = p.ms[0] ? cbt : 0; p.ms[1] = p.ms[1] ? chd : 0; p.ms[2] = cr; p.ms[3] = 1;
     } else if (mask_flags_worthwhile(p)) {
@@ -1067,7 +1209,7 @@ hipError_t launch_mask_classify(FwdParams& p, void* scratch, hipStream_t stream)
         if (hipError_t e = hipMemsetAsync(a.wflag, 0, a.total, stream); e != hipSuccess) return e;
     }
     a.done = true;  // (no bit image to pack)
-    return mask_pack_finish(a, list, cnt, nqb, slabs, stream);
+    return mask_pack_finish(a, list, cnt, nqb, slabs, stream, xflag_f32, const_cast<uint32_t*>(p.guard));
 }
 
 hipError_t launch_cast_rows_bf16_to_f16(const void* src, const int64_t* strides, void* dst, uint32_t B, uint32_t H, uint32_t S, uint32_t D,

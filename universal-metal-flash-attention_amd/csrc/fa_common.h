@@ -88,6 +88,13 @@ struct FwdParams {
     uint32_t decode_form; // 1 = the launch runs the decode form (fa_fwd_16_kernel.h KS = 4: <= 32 query rows, four key quarters per 128-key tile); the plan decides
     uint32_t cbal;        // 1 = the launch runs the CBAL instantiation
     uint32_t cbal_delta;  // key tiles by which a pair's part A is shorter than half (it pays the fold)
+    // fp32 additive masks on the one-wave-per-SIMD structure (end of round 6): whether fp16 holds every mask value is known on the DEVICE only
+    // (fa_aux.hip mask_classify_f32_kernel, folded by mask_list_kernel), so the call enqueues both routes and `guard` points at the verdict word
+    // (0 = every value exact in fp16: the bias kernel on the fp16 copy; 1 = not: the 128-row kernel on the caller's fp32 tensor).  A guarded
+    // kernel -- MASKA instantiations of fa_fwd16_w64, HAS_MASK instantiations of fa_fwd16 -- leaves at once unless
+    // *guard == guard_want.  NULL: not guarded.  No host read-back, the same under hipGraph replay whatever the mask holds then.
+    const uint32_t* guard;
+    uint32_t guard_want;
 };
 
 // Interleaved-pair rotary rotation of 8 consecutive elements (4 pairs) given the 8 table entries of their columns

@@ -340,8 +340,8 @@ double fwd_16_predict_us(const FwdParams& p) {
 
 bool fwd_w64_supported(const FwdParams& p) {
     if (tuning().no_w64.load(std::memory_order_relaxed) || !fwd_16_supported(p)) return false;
-    if ((p.D != 128 && p.D != 64) || (p.mask_kind != MK_NONE && p.mask_kind != MK_WINDOW && p.mask_kind != MK_BOOL && p.mask_kind != MK_F16 && p.mask_kind != MK_BF16)) return false;
-    if (p.mask_kind == MK_F16 || p.mask_kind == MK_BF16) {
+    if ((p.D != 128 && p.D != 64) || (p.mask_kind != MK_NONE && p.mask_kind != MK_WINDOW && p.mask_kind != MK_BOOL && p.mask_kind != MK_F16 && p.mask_kind != MK_BF16 && p.mask_kind != MK_F32)) return false;
+    if (p.mask_kind == MK_F16 || p.mask_kind == MK_BF16 || p.mask_kind == MK_F32) {
         // ADDITIVE fp16 / bf16 mask tensors (MASKA instantiations, round 6; the reference's additive masks: MFABridge.swift:157-242): head_dim 128 and 64, the fp16-P-V
         // families, no causal flag / rotation on top; the wave's mask tile comes by LDS-DMA straight from the caller's tensor, so: keys contiguous,
         // 16-byte aligned rows, Sq and Skv whole 64-row / 64-key tiles; at least one 256-row block per CU (whole blocks in rounds + a shared remainder,
@@ -350,10 +350,15 @@ bool fwd_w64_supported(const FwdParams& p) {
         if (p.in_prec == P_BF16 && !p.pv16) return false;
         if (p.Sq < 256 || p.Sq % 64 != 0 || p.Skv % 64 != 0 || ((p.Skv + 63) / 64) > 1024u) return false;
         if (p.out_prec != P_FP32 && p.out_prec != p.in_prec) return false;
-        if (p.ms[3] != 1 || ((uintptr_t)p.mask & 15) != 0 || (p.ms[0] & 7) != 0 || (p.ms[1] & 7) != 0 || (p.ms[2] & 7) != 0) return false;
-        if (p.ms[2] != 0 && (uint64_t)p.ms[2] * 2 * 64 > 0x7fffffffull) return false;  // (a wave's 64 rows behind one 32-bit descriptor)
+        const int64_t al = p.mask_kind == MK_F32 ? 3 : 7;  // 16-byte aligned rows: 4 fp32 / 8 fp16 elements
+        if (p.ms[3] != 1 || ((uintptr_t)p.mask & 15) != 0 || (p.ms[0] & al) != 0 || (p.ms[1] & al) != 0 || (p.ms[2] & al) != 0) return false;
+        if (p.mask_kind != MK_F32 && p.ms[2] != 0 && (uint64_t)p.ms[2] * 2 * 64 > 0x7fffffffull) return false;  // (a wave's 64 rows behind one 32-bit descriptor; fp32: the kernel reads the dense copy)
         // bf16 masks: the classification pass also writes the dense fp16 copy the kernel reads (bf16's significands fit fp16's; fa_aux.hip) -- up to 1 GiB of it
-        if (p.mask_kind == MK_BF16 && mask_copy_bytes(p) > ((size_t)1 << 30)) return false;
+        if (p.mask_kind != MK_F16 && mask_copy_bytes(p) > ((size_t)1 << 30)) return false;
+        // fp32 masks (end of round 6): the same copy, taken by the bias kernel only when the pass finds it EXACT -- the verdict is a device word, so the call
+        // enqueues the 128-row kernel on the caller's tensor as well and the kernels guard themselves (FwdParams::guard).  Only masks the pass may read
+        // (its bytes within twice the call's tensor traffic: a dense per-head fp32 bias is read once, by the 128-row kernel, as before).
+        if (p.mask_kind == MK_F32 && (!mask_flags_worthwhile(p) || tuning().no_w64_f32_mask.load(std::memory_order_relaxed))) return false;
         if (w64_grid(p) > 512u) return false;
         if (tuning().force_w64.load(std::memory_order_relaxed)) return true;
         const uint64_t blocks = (uint64_t)p.B * p.H * ((p.Sq + 255) / 256), cus = (uint64_t)w64_cu_count();
@@ -495,6 +500,8 @@ hipError_t launch_fwd_w64(const FwdParams& p, float* part_buf, uint32_t* part_cn
     wp.Tw = wp.T; wp.win_left = wp.win_right = 0;
     const bool rope = p.rope_cos != nullptr, window = w64_is_window(p), fp32o = p.out_prec == P_FP32, maska = p.mask_kind == MK_F16, maskt = p.mask_kind == MK_BOOL || maska;
     wp.mask = nullptr; wp.mask_s[0] = wp.mask_s[1] = wp.mask_s[2] = 0;
+    wp.guard = maska ? p.guard : nullptr;  // (fp32 masks: the launch runs iff the classification pass found the fp16 copy exact -- FwdParams::guard)
+    if (p.guard && (!maska || p.guard_want != 0u)) return hipErrorInvalidValue;
     if (maskt) {
         if ((!maska && !p.mk_bits) || !p.mk_list || !p.mk_cnt) return hipErrorInvalidValue;  // runtime.hip packs / classifies the mask first (launch_mask_pack, launch_mask_classify)
         if (maska) { wp.mask = p.mask; wp.mask_s[0] = p.ms[0]; wp.mask_s[1] = p.ms[1]; wp.mask_s[2] = p.ms[2]; }

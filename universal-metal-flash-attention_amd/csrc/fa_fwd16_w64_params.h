@@ -38,6 +38,7 @@ struct W64Params {
     int64_t mask_s[3];        // its batch, head and row strides in elements (0 = broadcast; keys contiguous)
     const float* vsc;         // bf16pv16 kernels: 2^e of the V image's slabs (FwdParams::vsc), slab (b, h) at vsc[128 (b vsc_bs + h vsc_hs) + 65]
     uint32_t vsc_bs, vsc_hs;
+    const uint32_t* guard;    // MASKA kernels: FwdParams::guard (the launch runs iff NULL or *guard == 0: an fp32 mask whose fp16 copy is exact)
 };
 
 // ---- asm-owned accumulator registers: helpers with literal register numbers (generated)

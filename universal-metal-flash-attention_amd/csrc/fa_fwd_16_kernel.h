@@ -138,6 +138,10 @@ constexpr int fwd16_resident(int DP, int BN, int KS) { return KS == 4 ? (DP > 64
 
 template <typename T, int DP, bool CAUSAL, bool HAS_MASK, typename OUT, bool DMA = false, int BN = 64, int PV16 = 0, int KS = 1, int PIPE = 0, bool CBAL = false>
 __global__ __launch_bounds__(fwd16_threads(KS), fwd16_resident(DP, BN, KS)) void fa_fwd16_kernel(FwdParams p) {
+    if constexpr (HAS_MASK) {
+        // guarded launches (FwdParams::guard: an fp32 mask whose fp16 copy may or may not be exact -- the other route is enqueued too): uniform, before anything else
+        if (p.guard != nullptr && *p.guard != p.guard_want) return;
+    }
     int e2 = fa_fwd16_body<T, DP, CAUSAL, HAS_MASK, OUT, DMA, BN, PV16, KS, PIPE, CBAL, false, const FwdParams>(p, 0, (int)threadIdx.x, blockIdx.x);
     if constexpr (PV16 == 1) {
         if (__builtin_expect(e2 != 0, 0)) {

@@ -19,7 +19,7 @@ struct Tuning {
     std::atomic<int> sm_mode{SM_DEFAULT};
     std::atomic<float> sm_tau{6.0f};
     std::atomic<int> force_w64{0}, no_w64{0}, w64_grid{0}, w64_skew{0}, no_mask_flags{0}, bwd_exact{0}, bwd_dq{0}, bwd_persist{0},
-        bwd_separate_delta{0}, no_split{0}, force_split{0}, no_dma{0}, bn64{0}, pv_fp16{0}, bwd_ds_store{0}, no_w64_mask{0}, ksplit{0}, no_pipe{0}, no_w64_mask_lazy{0}, no_w64_bias{0},
+        bwd_separate_delta{0}, no_split{0}, force_split{0}, no_dma{0}, bn64{0}, pv_fp16{0}, bwd_ds_store{0}, no_w64_mask{0}, ksplit{0}, no_pipe{0}, no_w64_mask_lazy{0}, no_w64_bias{0}, no_w64_f32_mask{0} /* fp32 additive masks stay on the 128-row kernel (no classification pass, no guarded pair of launches) */,
         cast_two_pass{0} /* V cast pre-pass: amax and cast as two launches whatever the slab size (tests) */, bwd_ds_lab{0} /* lab, timing only: BwdParams::ds_lab */,
         cast_u{0} /* lab: 16-byte loads per thread of the V cast pre-pass (4, 16, 32; 0 = the launcher's choice) */,
         quant_block_wg{0} /* tests / A-B: the block-wise quantiser in its one-workgroup-per-block form everywhere */,
@@ -173,15 +173,17 @@ hipError_t launch_fwd_w64_i8(const FwdParams& p, const QuantViews& v, float* par
 // bool mask -> per-lane bit words + visited-tile lists for fa_fwd16_w64's MASKT instantiations (fa_aux.hip); fills p.mk_*
 size_t mask_pack_bytes(const FwdParams& p);
 hipError_t launch_mask_pack(FwdParams& p, void* scratch, hipStream_t stream);
-// additive fp16 / bf16 mask -> per-wave tile classes + visited-tile lists for fa_fwd16_w64's MASKA instantiations (same scratch layout as the bool pack, no
-// bit image: the kernel reads the caller's tensor itself); fills p.mk_list / mk_cnt / mk_bs / mk_hs / mk_nrb64
+// additive fp16 / bf16 / fp32 mask -> per-wave tile classes + visited-tile lists for fa_fwd16_w64's MASKA instantiations (same scratch layout as the bool pack, no
+// bit image: the kernel reads the caller's tensor itself -- or the fp16 copy this pass writes of a bf16 / fp32 one); fills p.mk_list / mk_cnt / mk_bs / mk_hs / mk_nrb64.
+// fp32: also the exactness verdict word (p.guard, guard_want = 0) and, 256 bytes behind it, the 128-row kernel's tile flags (mask_flags_describe)
 hipError_t launch_mask_classify(FwdParams& p, void* scratch, hipStream_t stream);
-size_t mask_copy_bytes(const FwdParams& p);  // bf16 masks: the dense fp16 copy the kernel reads, behind the pack area (256-byte aligned) in the same scratch block
+size_t mask_copy_bytes(const FwdParams& p);  // bf16 / fp32 masks: the dense fp16 copy the kernel reads (fp32: + exactness bytes, verdict word, 128-row tile flags), behind the pack area (256-byte aligned) in the same scratch block
 // the V cast pass and the mask re-pack as ONE launch (the pack's workgroups behind the cast's), then the list kernel
 hipError_t launch_cast_rows_and_mask_pack(const void* src, const int64_t* strides, void* dst, uint32_t B, uint32_t H, uint32_t S, uint32_t D,
                                           uint32_t* hdr, FwdParams& p, void* mask_scratch, hipStream_t stream);
 // mask tile flags for fa_fwd16's tile early-exit (fa_aux.hip); launch_mask_flags fills p.mask_flags / mf_*
 size_t mask_flags_bytes(const FwdParams& p);
+void mask_flags_describe(FwdParams& p, const uint8_t* flags);  // fills FwdParams::mf_* / mask_flags for a flag array written elsewhere (fp32 masks: by the classification pass)
 bool mask_flags_worthwhile(const FwdParams& p);
 hipError_t launch_mask_flags(FwdParams& p, uint8_t* flags, hipStream_t stream);
 

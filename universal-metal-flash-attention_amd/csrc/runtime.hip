@@ -78,6 +78,14 @@ mfa_error_t rc_of(hipError_t e) {
                                       : MFA_ERROR_EXECUTION_FAILED;
 }
 
+// the name of a call that enqueued two guarded routes (an fp32 mask: the device picks); ctx->mu held, the strings live as long as the library
+const char* both_kernels(const char* first, const char* second) {
+    static std::map<std::pair<const char*, const char*>, std::string> names;
+    std::string& s = names[std::make_pair(first, second)];
+    if (s.empty()) s = std::string(first) + " | " + second + " (fp32 mask: chosen on the device)";
+    return s.c_str();
+}
+
 // Kernel selection for the dense forward.  Call with ctx->mu held; `sc` is the scratch pool of (device, stream).
 hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p, int intermediate_prec, hipStream_t stream) {
     const char* name = "none";
@@ -110,6 +118,13 @@ hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p,
         return true;
     };
     bool done = false;
+    // fp32 additive masks the bias kernels could take as fp16 (fwd_w64_supported): whether the fp16 copy is exact is known on the device only, so BOTH routes
+    // are enqueued and guarded by the classification pass's verdict word (FwdParams::guard) -- first the bias kernel on the copy, then, below, the 128-row
+    // kernel on the caller's tensor; exactly one of them runs
+    const uint32_t* guard = nullptr;
+    const char* guarded_first = nullptr;
+    FwdParams v16_from;  // ... and the second route takes the fp16 image of V the first one's cast pass wrote
+    bool have_v16 = false;
     if (lowp && fwd_w64_supported(pv)) {
         // the one-wave-per-SIMD kernels take V as the dense fp16 image.  (Converting inside these kernels was built and measured: +15 %,
         // every workgroup re-converts every tile; the 128-row kernel below does convert in-kernel.)
@@ -118,7 +133,8 @@ hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p,
         // and the visited-tile list of every 256-row block (fa_aux.hip mask_pack_kernel); the kernel then never stages a tile no row
         // of the block attends to and reads no mask bytes at all.  Every block this family needs is asked for BEFORE anything is
         // launched: a call that cannot have them (capture without a warm-up) goes to the 128-row kernel untouched.
-        const bool mask_add = pw.mask_kind == MK_F16 || pw.mask_kind == MK_BF16;  // additive: classified only (+ a bf16 mask's fp16 copy) -- fa_aux.hip launch_mask_classify
+        const bool mask_f32 = pw.mask_kind == MK_F32;
+        const bool mask_add = pw.mask_kind == MK_F16 || pw.mask_kind == MK_BF16 || mask_f32;  // additive: classified only (+ a bf16 / fp32 mask's fp16 copy) -- fa_aux.hip launch_mask_classify
         const bool mask_w64 = pw.mask_kind == MK_BOOL || mask_add;
         void* mk = mask_w64 ? sc.mflags.ensure(((mask_pack_bytes(pw) + 255) & ~(size_t)255) + mask_copy_bytes(pw), stream) : nullptr;
         bool ok = !mask_w64 || mk != nullptr;
@@ -134,7 +150,14 @@ hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p,
         if (ok) {
             if (mk && !packed && (e = (mask_add ? launch_mask_classify(pw, mk, stream) : launch_mask_pack(pw, mk, stream))) != hipSuccess) return e;
             e = launch_fwd_w64(pw, (float*)(w64 + sc.w64_cnt_bytes), (uint32_t*)w64, stream, &name);
-            done = true;
+            if (mask_f32) {
+                if (e != hipSuccess) return e;
+                guard = pw.guard;
+                guarded_first = name;
+                if (pw.pv16 == 2) { v16_from = pw; have_v16 = true; }
+            } else {
+                done = true;
+            }
         } else if (p.rope_cos || !fwd_16_supported(p)) {
             return hipErrorOutOfMemory;  // (only this kernel family rotates Q in registers)
         }
@@ -146,7 +169,11 @@ hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p,
         return hipErrorNotSupported;  // only the 256-row kernel rotates Q in registers (the entry asks before it sets this)
     } else if (lowp && fwd_16_supported(p)) {
         FwdParams pp = pv;
-        if (pp.pv16 && (size_t)(p.vs[0] == 0 ? 1u : p.B) * (p.vs[1] == 0 ? 1u : p.H) * p.Skv * p.D * 2 >= ((size_t)16 << 20) && p.Sq >= 1024) {
+        if (guard) { pp.guard = guard; pp.guard_want = 1; }
+        if (have_v16) {
+            pp.v = v16_from.v; pp.vsc = v16_from.vsc; pp.vsc_bs = v16_from.vsc_bs; pp.vsc_hs = v16_from.vsc_hs; pp.pv16 = 2;
+            for (int i = 0; i < 4; ++i) pp.vs[i] = v16_from.vs[i];
+        } else if (pp.pv16 && (size_t)(p.vs[0] == 0 ? 1u : p.B) * (p.vs[1] == 0 ? 1u : p.H) * p.Skv * p.D * 2 >= ((size_t)16 << 20) && p.Sq >= 1024) {
             // the 128-row kernel converts V in-kernel (24 ... 48 vector instructions per tile per wave in a vector-bound kernel, repeated
             // by every workgroup): right for short launches, where a pre-pass costs its launch; from 16 MB of V on the HBM-speed cast
             // pass is cheaper (FLUX-size masked calls: ~11 us against ~15 % of the kernel) -- IF the tiles are re-read: with fewer than eight
@@ -174,7 +201,10 @@ hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p,
                 pp.part_buf = (float*)(buf + sc.split_cnt_bytes);
             }
         }
-        if (pp.mask_kind != MK_NONE && !tuning().no_mask_flags.load(std::memory_order_relaxed) && mask_flags_worthwhile(pp)) {
+        if (guard) {
+            // (guarded: the classification pass of the first route wrote this route's tile flags on its way through the mask -- behind the verdict word)
+            if (!tuning().no_mask_flags.load(std::memory_order_relaxed)) mask_flags_describe(pp, (const uint8_t*)guard + 256);
+        } else if (pp.mask_kind != MK_NONE && !tuning().no_mask_flags.load(std::memory_order_relaxed) && mask_flags_worthwhile(pp)) {
             // tile early-exit for masks: one pre-pass over the distinct mask elements classifies every (32 rows x 64
             // keys) tile; fully masked tiles are skipped, fully open ones run without reading the mask.  Results are
             // bit-identical with and without the flags, so a pool that may not grow (capture) just runs without them.
@@ -182,6 +212,7 @@ hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p,
             if (fl && launch_mask_flags(pp, (uint8_t*)fl, stream) != hipSuccess) pp.mask_flags = nullptr;
         }
         e = launch_fwd_16(pp, stream, &name);
+        if (guard && e == hipSuccess) name = both_kernels(guarded_first, name);
     } else {
         e = p.D > 256 ? launch_fwd_wide(p, stream, &name) : launch_fwd_exact(p, stream, &name);
     }
