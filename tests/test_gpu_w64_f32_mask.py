@@ -264,3 +264,39 @@ def test_fp32_mask_blocks_that_see_nothing_and_a_ragged_last_block(dt, Sq, exact
     lg = lse.view(B, H, Sq)
     assert bool(torch.isneginf(lg[dead]).all()) and bool((o[dead.unsqueeze(-1).expand_as(o)] == 0).all())
     assert float((lg.double() - rl)[~dead].abs().max()) < 2e-2
+
+
+def test_fp32_mask_call_captured_without_a_warm_up_runs_the_128_row_kernel_alone():
+    """nothing is allocated under capture: a first capture on a stream the library has never seen has no scratch for the pass, so the call is the 128-row kernel
+    alone (unguarded, the mask read in place); after an eager warm-up on the stream the same capture takes the guarded pair.  Both replay to the eager answer."""
+    import umfa_torch
+    torch.manual_seed(13)
+    B, H, S, D = 1, 72, 1024, 128
+    q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    i = torch.arange(S, device="cuda")
+    m = (-(i[:, None] - i[None, :]).abs().float() / 128.0)[None, None].contiguous()
+    eager = umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32)
+    assert " | " in umfa_torch.last_kernel()
+    out = torch.empty_like(eager)
+    cold = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(cold):
+        with torch.cuda.graph(g, stream=cold):
+            umfa_torch.attention_forward(q, k, v, mask=m, out=out)
+            assert umfa_torch.last_kernel().startswith("fa_fwd16<") and " | " not in umfa_torch.last_kernel(), umfa_torch.last_kernel()
+    g.replay()
+    torch.cuda.synchronize()
+    assert float((out - eager).abs().max()) <= 2.0 ** -9 * float(eager.abs().max())
+    warm = torch.cuda.Stream()
+    with torch.cuda.stream(warm):
+        umfa_torch.attention_forward(q, k, v, mask=m, out=out)
+    warm.synchronize()
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(warm):
+        with torch.cuda.graph(g2, stream=warm):
+            umfa_torch.attention_forward(q, k, v, mask=m, out=out)
+            assert " | " in umfa_torch.last_kernel()
+    out.fill_(float("nan"))
+    g2.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)

@@ -1021,9 +1021,9 @@ hipError_t launch_mask_pack(FwdParams& p, void* scratch, hipStream_t stream) {
 // value fp16 holds (bf16's 8-bit significands fit), finite values beyond +-65504 clamped there (exp(x - max) of such a term is 0 or the row's only
 // survivor either way), magnitudes below 2^-24 flushed (e^x = 1 to fp32 precision), -inf / NaN kept.
 template <bool BF16>
-__global__ __launch_bounds__(256) void mask_classify_kernel(MaskPackArgs p, _Float16* copy, int64_t cb, int64_t ch, int64_t cr) {
+__device__ __forceinline__ void mask_classify_body(const MaskPackArgs& p, _Float16* copy, int64_t cb, int64_t ch, int64_t cr, const uint32_t block) {
     const uint32_t lane = threadIdx.x & 63;
-    const uint64_t wid = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t wid = (uint64_t)block * 4 + (threadIdx.x >> 6);
     if (wid >= p.total) return;
     const uint32_t tile = (uint32_t)(wid % p.T);
     const uint32_t rb = (uint32_t)((wid / p.T) % p.nrb64);
@@ -1064,24 +1064,29 @@ __global__ __launch_bounds__(256) void mask_classify_kernel(MaskPackArgs p, _Flo
     const bool open = __builtin_amdgcn_ballot_w64(any_open) != 0, term = __builtin_amdgcn_ballot_w64(any_term) != 0;
     if (lane == 0) p.wflag[wid] = !open ? 1 : (!term ? 2 : 0);
 }
+template <bool BF16>
+__global__ __launch_bounds__(256) void mask_classify_kernel(MaskPackArgs p, _Float16* copy, int64_t cb, int64_t ch, int64_t cr) {
+    mask_classify_body<BF16>(p, copy, cb, ch, cr, blockIdx.x);
+}
 
 // ---- fp32 additive masks on the same structure (end of round 6; the reference's additive masks are fp32 wherever its own callers build them:
 // metal_sdpa_backend.cpp:3210-3231, MFABridge.swift:157-242).  The bias kernels read fp16 (v_fma_mix_f32 takes f16 halves; a 64 x 64 fp32 tile would not fit the
 // wave's staging ring), so the classification pass writes a dense fp16 copy as for bf16 masks -- but fp32 values need not fit fp16, and rounding a term of
 // magnitude m moves the logit by up to m 2^-11: 8e-3 at m = 16, past the 1e-3 bound.  So the pass also records, per wave-tile, whether fp16 holds every value
-// EXACTLY (xflag; "exactly" = the copy is within 2^-24 of the value in absolute terms: +-inf and NaN kept, every fp16 value, and what flushes to a
-// subnormal without moving e^x in fp32), mask_list_kernel's first workgroup folds the bytes into one verdict word, and the two attention launches the runtime enqueues -- the bias
+// EXACTLY (xflag; "exactly" = the round trip through fp16 returns the value -- every fp16 value, +-inf --, or the magnitude is below 2^-24 (flushed
+// without moving e^x in fp32), or the value is -inf to every kernel anyway: see the kernel), mask_list_kernel's first workgroup folds the bytes into one verdict word, and the two attention launches the runtime enqueues -- the bias
 // kernel on the copy, the 128-row kernel on the caller's tensor -- are guarded by it (FwdParams::guard): exactly one of them runs.  0 / -inf masks, masks
 // built in fp16 / bf16 and widened, small-integer and dyadic biases take the fast kernel; anything else keeps today's kernel and today's numbers.
 // One WORKGROUP per (mask batch, mask head, 256-row block, 64-key tile), its four waves = the block's four 64-row wave-tiles (what the attention kernel's four
 // waves see of the tile): a lane owns one 16-byte segment (4 keys) of a row, a wave-load covers 4 rows, 16 loads the wave-tile.
-__global__ __launch_bounds__(256) void mask_classify_f32_kernel(MaskPackArgs p, uint32_t nqb, _Float16* copy, int64_t cb, int64_t ch, int64_t cr, uint8_t* xflag, uint8_t* flags128) {
+__device__ __forceinline__ void mask_classify_f32_body(const MaskPackArgs& p, uint32_t nqb, _Float16* copy, int64_t cb, int64_t ch, int64_t cr, uint8_t* xflag, uint8_t* flags128,
+                                                       const uint32_t block) {
     typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
     __shared__ uint32_t wave_class[4];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t tile = blockIdx.x % p.T;
-    const uint32_t qblk = (blockIdx.x / p.T) % nqb;
-    const uint32_t slab = blockIdx.x / (p.T * nqb);
+    const uint32_t tile = block % p.T;
+    const uint32_t qblk = (block / p.T) % nqb;
+    const uint32_t slab = block / (p.T * nqb);
     const uint32_t rb = 4 * qblk + wv;
     if (rb >= p.nrb64) wave_class[wv] = 1u;  // (a wave past Sq: nothing there)
     const bool live = rb < p.nrb64;
@@ -1093,30 +1098,40 @@ __global__ __launch_bounds__(256) void mask_classify_f32_kernel(MaskPackArgs p, 
 #pragma unroll
     for (int i = 0; i < 16; ++i) w[i] = live ? *(const u32x4_t*)(base + (int64_t)(4 * i) * p.ms[2] * 4) : u32x4_t{0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u};
     // the 128-row route's tile flags (FwdParams::mask_flags: per 32-row block and 64-key tile, from the fp32 VALUES as mask_flags_kernel reads them) come from
-    // the same read: rows 0 ... 31 of the tile are loads 0 ... 7, rows 32 ... 63 loads 8 ... 15
-    bool open32[2] = {false, false}, term32[2] = {false, false};
-    bool any_open = false, any_term = false, inexact = false;
+    // the same read: rows 0 ... 31 of the tile are loads 0 ... 7, rows 32 ... 63 loads 8 ... 15.
+    // ~8 vector instructions per element (the first build's ~25 made the pass compute-bound: 4096 elements per wave, four waves per SIMD): "every element is -inf" /
+    // "every element is +-0" are read off the running OR and AND of the words; exactness is the round trip through fp16 (round-to-nearest-even, overflow -> +-inf,
+    // so finite values beyond +-65504 fail it) OR a magnitude fp16 flushes harmlessly OR a value that IS -inf to every kernel of this library -- a finite x whose
+    // log2-domain term x log2 e overflows in fp32 (torch.finfo(torch.float32).min, the "large negative" idiom at its largest; fa_common.h mask_term): its copy is
+    // -inf (the conversion's own overflow).  NaN fails the round trip: the 128-row kernel gets it.
+    constexpr float NINF_LIM = -0x1.62e42ep+127f;  // x < this  =>  x * UMFA_LOG2E == -inf in fp32 (0x1.62e42fefp+127 = FLT_MAX ln 2, rounded towards zero: a few ulps of slack stay finite-and-inexact)
+    uint32_t or32[2] = {0u, 0u}, and32[2] = {0xffffffffu, 0xffffffffu}, or16 = 0u, and16 = 0xffffffffu;
+    bool inexact = false;
     u32x2_t o[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        uint32_t hb[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float x = __uint_as_float(w[i][j]);
-            open32[i >> 3] |= w[i][j] != 0xff800000u;
-            term32[i >> 3] |= (w[i][j] & 0x7fffffffu) != 0;
-            const bool fin = fabsf(x) < INFINITY;  // (false for NaN too)
-            // finite values whose log2-domain term overflows (x log2 e = -inf in fp32: torch.finfo(torch.float32).min, the "large negative" idiom at its
-            // largest) ARE -inf to every kernel of this library (fa_common.h mask_term): -inf in the copy, and exact
-            const bool as_ninf = fin && x * UMFA_LOG2E == -INFINITY;
-            const float cl = fabsf(x) <= 65504.0f ? x : (x > 0.0f ? 65504.0f : -65504.0f);
-            const _Float16 h = as_ninf ? (_Float16)(-INFINITY) : (_Float16)(fin ? cl : x);
-            inexact |= fin && !as_ninf && fabsf((float)h - x) > 0x1p-24f;
-            hb[j] = (uint32_t)__builtin_bit_cast(uint16_t, h);
-            any_open |= hb[j] != 0xfc00u;
-            any_term |= (hb[j] & 0x7fffu) != 0;
+        for (int j = 0; j < 2; ++j) {
+            const uint32_t w0 = w[i][2 * j], w1 = w[i][2 * j + 1];
+            const float x0 = __uint_as_float(w0), x1 = __uint_as_float(w1);
+            uint32_t pk;
+            asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk) : "v"(x0), "v"(x1));
+            const float b0 = (float)__builtin_bit_cast(_Float16, (uint16_t)(pk & 0xffffu)), b1 = (float)__builtin_bit_cast(_Float16, (uint16_t)(pk >> 16));
+            const bool ok0 = b0 == x0 || fabsf(x0) <= 0x1p-24f || x0 < NINF_LIM, ok1 = b1 == x1 || fabsf(x1) <= 0x1p-24f || x1 < NINF_LIM;
+            inexact = inexact || !ok0 || !ok1;
+            or32[i >> 3] |= w0 | w1;
+            and32[i >> 3] &= w0 & w1;
+            or16 |= pk;
+            and16 &= pk;
+            o[i][j] = pk;
         }
-        o[i] = u32x2_t{hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16)};
+    }
+    const bool any_open = !(and16 == 0xfc00fc00u && or16 == 0xfc00fc00u), any_term = (or16 & 0x7fff7fffu) != 0;
+    bool open32[2], term32[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        open32[hf] = !(and32[hf] == 0xff800000u && or32[hf] == 0xff800000u);
+        term32[hf] = (or32[hf] & 0x7fffffffu) != 0;
     }
     const bool open = __builtin_amdgcn_ballot_w64(any_open) != 0, term = __builtin_amdgcn_ballot_w64(any_term) != 0;
     const bool bad = __builtin_amdgcn_ballot_w64(inexact) != 0;
@@ -1153,6 +1168,42 @@ __global__ __launch_bounds__(256) void mask_classify_f32_kernel(MaskPackArgs p, 
         }
     }
 }
+__global__ __launch_bounds__(256) void mask_classify_f32_kernel(MaskPackArgs p, uint32_t nqb, _Float16* copy, int64_t cb, int64_t ch, int64_t cr, uint8_t* xflag, uint8_t* flags128) {
+    mask_classify_f32_body(p, nqb, copy, cb, ch, cr, xflag, flags128, blockIdx.x);
+}
+
+// The classification pass in the V cast pass's launch (bf16 operands: every additive-mask call on the bias kernels has one): blocks [0, cast_blocks) cast -- slab-major,
+// first: their exchange relies on it --, the rest classify.  The two passes read different tensors and are each short of the chip's bandwidth on their own (12 us of cast,
+// 8 ... 26 us of classification at FLUX size); in one launch they overlap and the call is a launch shorter -- as the bool masks' re-pack has ridden there since round 5.
+// KIND: 0 fp16 mask (classes only), 1 bf16 (+ the fp16 copy), 2 fp32 (+ the copy, exactness bytes, the 128-row kernel's tile flags)
+struct MaskClassifyExtra {
+    uint32_t nqb;
+    _Float16* copy;
+    int64_t cb, ch, cr;
+    uint8_t* xflag;
+    uint8_t* flags128;
+};
+template <int U, int KIND>
+__global__ __launch_bounds__(256) void cast_rows_and_mask_classify_kernel(CastRowsArgs a, uint32_t cast_blocks, MaskPackArgs mk, MaskClassifyExtra x) {
+    if (blockIdx.x < cast_blocks) cast_rows_body<U, true>(a, blockIdx.x);
+    else if constexpr (KIND == 2) mask_classify_f32_body(mk, x.nqb, x.copy, x.cb, x.ch, x.cr, x.xflag, x.flags128, blockIdx.x - cast_blocks);
+    else mask_classify_body<KIND == 1>(mk, x.copy, x.cb, x.ch, x.cr, blockIdx.x - cast_blocks);
+}
+// false: the cast takes its two-launch form (or the grids do not fit one launch): the caller launches the two passes one after the other
+template <int U>
+static bool launch_cast_and_classify_u(const void* src, const int64_t* strides, void* dst, uint32_t B, uint32_t H, uint32_t S, uint32_t D, uint32_t* hdr, hipStream_t stream,
+                                       const MaskPackArgs& mk, const MaskClassifyExtra& x, int kind, unsigned classify_grid) {
+    const uint32_t D8 = D / 8, rpw = 256u / D8;
+    const uint64_t chunks = ((uint64_t)S + U * rpw - 1) / (U * rpw), grid = (uint64_t)B * H * chunks;
+    if (chunks > 64 || tuning().cast_two_pass.load(std::memory_order_relaxed) || grid + classify_grid > 0x7fffffffull) return false;
+    const CastRowsArgs a = {(const uint16_t*)src, strides[0], strides[1], strides[2], (_Float16*)dst, H, S, D8, (uint32_t)chunks, hdr,
+                            (uint32_t)std::min<int64_t>(std::max(tuning().cast_wait_us.load(std::memory_order_relaxed), 0), 1000000) * 100u};
+    const dim3 g((unsigned)grid + classify_grid);
+    if (kind == 2) hipLaunchKernelGGL((cast_rows_and_mask_classify_kernel<U, 2>), g, dim3(256), 0, stream, a, (unsigned)grid, mk, x);
+    else if (kind == 1) hipLaunchKernelGGL((cast_rows_and_mask_classify_kernel<U, 1>), g, dim3(256), 0, stream, a, (unsigned)grid, mk, x);
+    else hipLaunchKernelGGL((cast_rows_and_mask_classify_kernel<U, 0>), g, dim3(256), 0, stream, a, (unsigned)grid, mk, x);
+    return true;
+}
 
 static inline size_t up256(uint64_t n) { return (size_t)((n + 255) & ~255ull); }
 
@@ -1169,7 +1220,9 @@ size_t mask_copy_bytes(const FwdParams& p) {
 // scratch = [the pack layout of mask_pack_bytes | the fp16 copy of a bf16 mask].  On return p describes what the attention kernel reads: an fp16 mask.
 // fp32 masks: scratch = [pack | fp16 copy | exactness bytes | verdict word (256 bytes) | the 128-row route's tile flags]; p.guard = the verdict word, guard_want = 0
 // (the bias kernel's side: runtime.hip enqueues the 128-row kernel behind it with guard_want = 1 and its flags at (uint8_t*)p.guard + 256).
-hipError_t launch_mask_classify(FwdParams& p, void* scratch, hipStream_t stream) {
+// cast != NULL: the V cast pass of the same call (launch_cast_rows_bf16_to_f16's arguments) rides in the classification's launch when its one-launch form applies;
+// else it is launched here, in front of the classification
+hipError_t launch_mask_classify(FwdParams& p, void* scratch, hipStream_t stream, const CastRowsCall* cast) {
     if (p.mask_kind != MK_F16 && p.mask_kind != MK_BF16 && p.mask_kind != MK_F32) return hipErrorInvalidValue;
     const bool bf = p.mask_kind == MK_BF16, f32 = p.mask_kind == MK_F32;
     const size_t pack_bytes = (mask_pack_bytes(p) + 255) & ~(size_t)255;
@@ -1182,31 +1235,64 @@ hipError_t launch_mask_classify(FwdParams& p, void* scratch, hipStream_t stream)
     p.mk_bits = nullptr;
     const unsigned grid = (unsigned)((a.total + 3) / 4);
     const uint8_t* xflag_f32 = nullptr;
+    MaskClassifyExtra x = {nqb, nullptr, 0, 0, 0, nullptr, nullptr};
+    unsigned cgrid = grid;
+    int kind = bf ? 1 : f32 ? 2 : 0;
+    bool classify = true;  // (false: the mask is too large to be read twice -- every wave-tile is called mixed without looking)
     if (bf || f32) {
         _Float16* copy = (_Float16*)((char*)scratch + pack_bytes);
         const int64_t Sm = p.ms[2] ? p.Sq : 1, cr = p.ms[2] ? (int64_t)p.Skv : 0, chd = Sm * p.Skv, cbt = (int64_t)a.Hm * chd;
+        x.copy = copy; x.cb = cbt; x.ch = chd; x.cr = cr;
         if (f32) {
             uint8_t* xflag = (uint8_t*)copy + up256((uint64_t)a.Bm * a.Hm * Sm * p.Skv * 2);
             uint32_t* guard = (uint32_t*)(xflag + up256(a.total));
             // ... and the 128-row route's tile flags behind the verdict word: [Bm Hm][2 nrb64][T] bytes = the layout of launch_mask_flags (Sq is a multiple of 64 here)
             const uint64_t wgs = slabs * nqb * a.T;
             if (wgs > 0x7fffffffull) { p.mask_kind = kind_in; return hipErrorInvalidValue; }
-            hipLaunchKernelGGL(mask_classify_f32_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, a, nqb, copy, cbt, chd, cr, xflag, (uint8_t*)guard + 256);
+            cgrid = (unsigned)wgs;
+            x.xflag = xflag; x.flags128 = (uint8_t*)guard + 256;
             xflag_f32 = xflag;
             p.guard = guard;
             p.guard_want = 0;
-        } else {
-            hipLaunchKernelGGL(mask_classify_kernel<true>, dim3(grid), dim3(256), 0, stream, a, copy, cbt, chd, cr);
         }
         p.mask = copy;
         p.ms[0] = p.ms[0] ? cbt : 0; p.ms[1] = p.ms[1] ? chd : 0; p.ms[2] = cr; p.ms[3] = 1;
-    } else if (mask_flags_worthwhile(p)) {
-        hipLaunchKernelGGL(mask_classify_kernel<false>, dim3(grid), dim3(256), 0, stream, a, (_Float16*)nullptr, 0, 0, 0);
-    } else {
-        // a mask whose distinct bytes exceed twice the call's Q + K + V + O traffic (a dense per-head bias: 805 MB at the FLUX shape) is read ONCE, by the
-        // attention kernel: every wave-tile is called mixed (class 0, every tile listed) without looking -- the 128-row kernel's rule for its flags pass
-        // (mask_flags_worthwhile); a bias has nothing to skip, and the pass would cost what the attention itself costs
-        if (hipError_t e = hipMemsetAsync(a.wflag, 0, a.total, stream); e != hipSuccess) return e;
+    } else if (!mask_flags_worthwhile(p)) {
+        classify = false;
+    }
+    bool cast_done = false;
+    if (cast && classify) {
+        // the same choice of loads per thread as launch_cast_rows_any
+        const uint32_t rpw = 256u / (cast->D / 8);
+        const uint64_t wg16 = (uint64_t)cast->B * cast->H * (((uint64_t)cast->S + 16 * rpw - 1) / (16 * rpw)), chunks16 = ((uint64_t)cast->S + 16 * rpw - 1) / (16 * rpw);
+        const int lab = tuning().cast_u.load(std::memory_order_relaxed);
+        const bool ok_args = cast->src && cast->dst && cast->hdr && !(cast->D & 7) && cast->D <= 2048 && cast->strides[3] == 1 &&
+                             !((cast->strides[0] | cast->strides[1] | cast->strides[2]) % 8) && !((uintptr_t)cast->src & 15) && (int64_t)cast->B * cast->H * cast->S * cast->D != 0;
+        if (ok_args) {
+            if (lab == 32 || (!lab && chunks16 > 64 && chunks16 <= 128))
+                cast_done = launch_cast_and_classify_u<32>(cast->src, cast->strides, cast->dst, cast->B, cast->H, cast->S, cast->D, cast->hdr, stream, a, x, kind, cgrid);
+            else if (lab == 4 || (!lab && wg16 < (uint64_t)device_cu_count()))
+                cast_done = launch_cast_and_classify_u<4>(cast->src, cast->strides, cast->dst, cast->B, cast->H, cast->S, cast->D, cast->hdr, stream, a, x, kind, cgrid);
+            else
+                cast_done = launch_cast_and_classify_u<16>(cast->src, cast->strides, cast->dst, cast->B, cast->H, cast->S, cast->D, cast->hdr, stream, a, x, kind, cgrid);
+        }
+    }
+    if (cast && !cast_done) {
+        if (hipError_t e = launch_cast_rows_any(cast->src, cast->strides, cast->dst, cast->B, cast->H, cast->S, cast->D, cast->hdr, stream, nullptr); e != hipSuccess) { p.mask_kind = kind_in; return e; }
+    }
+    if (!cast_done || !classify) {
+        if (!classify) {
+            // a mask whose distinct bytes exceed twice the call's Q + K + V + O traffic (a dense per-head bias: 805 MB at the FLUX shape) is read ONCE, by the
+            // attention kernel: every wave-tile is called mixed (class 0, every tile listed) without looking -- the 128-row kernel's rule for its flags pass
+            // (mask_flags_worthwhile); a bias has nothing to skip, and the pass would cost what the attention itself costs
+            if (hipError_t e = hipMemsetAsync(a.wflag, 0, a.total, stream); e != hipSuccess) return e;
+        } else if (f32) {
+            hipLaunchKernelGGL(mask_classify_f32_kernel, dim3(cgrid), dim3(256), 0, stream, a, nqb, x.copy, x.cb, x.ch, x.cr, x.xflag, x.flags128);
+        } else if (bf) {
+            hipLaunchKernelGGL(mask_classify_kernel<true>, dim3(grid), dim3(256), 0, stream, a, x.copy, x.cb, x.ch, x.cr);
+        } else {
+            hipLaunchKernelGGL(mask_classify_kernel<false>, dim3(grid), dim3(256), 0, stream, a, (_Float16*)nullptr, 0, 0, 0);
+        }
     }
     a.done = true;  // (no bit image to pack)
     return mask_pack_finish(a, list, cnt, nqb, slabs, stream, xflag_f32, const_cast<uint32_t*>(p.guard));

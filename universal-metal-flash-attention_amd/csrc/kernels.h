@@ -176,7 +176,16 @@ hipError_t launch_mask_pack(FwdParams& p, void* scratch, hipStream_t stream);
 // additive fp16 / bf16 / fp32 mask -> per-wave tile classes + visited-tile lists for fa_fwd16_w64's MASKA instantiations (same scratch layout as the bool pack, no
 // bit image: the kernel reads the caller's tensor itself -- or the fp16 copy this pass writes of a bf16 / fp32 one); fills p.mk_list / mk_cnt / mk_bs / mk_hs / mk_nrb64.
 // fp32: also the exactness verdict word (p.guard, guard_want = 0) and, 256 bytes behind it, the 128-row kernel's tile flags (mask_flags_describe)
-hipError_t launch_mask_classify(FwdParams& p, void* scratch, hipStream_t stream);
+// cast != NULL: the arguments of the same call's V cast pass (launch_cast_rows_bf16_to_f16) -- it rides in the classification's launch (the cast's workgroups first, as
+// with the bool re-pack below) when its one-launch form applies, and is launched in front of the classification otherwise
+struct CastRowsCall {
+    const void* src;
+    int64_t strides[4];
+    void* dst;
+    uint32_t B, H, S, D;
+    uint32_t* hdr;
+};
+hipError_t launch_mask_classify(FwdParams& p, void* scratch, hipStream_t stream, const CastRowsCall* cast = nullptr);
 size_t mask_copy_bytes(const FwdParams& p);  // bf16 / fp32 masks: the dense fp16 copy the kernel reads (fp32: + exactness bytes, verdict word, 128-row tile flags), behind the pack area (256-byte aligned) in the same scratch block
 // the V cast pass and the mask re-pack as ONE launch (the pack's workgroups behind the cast's), then the list kernel
 hipError_t launch_cast_rows_and_mask_pack(const void* src, const int64_t* strides, void* dst, uint32_t B, uint32_t H, uint32_t S, uint32_t D,

@@ -101,14 +101,21 @@ hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p,
     // its slab is cast once.  false with e == hipSuccess: no block (the pool may not grow while the stream is capturing) -- the caller
     // takes a kernel that converts V itself.
     // mask_scratch != NULL: the bool mask of `q` is re-packed for the one-wave-per-SIMD kernel in the same launch (fills q.mk_*)
-    auto cast_v = [&](FwdParams& q, void* mask_scratch = nullptr) -> bool {
+    // defer != NULL: nothing is launched here -- *defer receives the pass's arguments and the caller hands them to a launch the pass rides in (additive masks:
+    // the classification pass, fa_aux.hip launch_mask_classify)
+    auto cast_v = [&](FwdParams& q, void* mask_scratch = nullptr, CastRowsCall* defer = nullptr) -> bool {
         const uint32_t vB = p.vs[0] == 0 ? 1u : p.B, vH = p.vs[1] == 0 ? 1u : p.H;
         const size_t slabs = (size_t)vB * vH, vbytes = slabs * p.Skv * p.D * 2;
         char* blk = sc.ensure_v16(slabs, vbytes, stream);
         if (!blk) return false;
         void* v16 = blk + sc.v16_cnt_bytes;
-        e = mask_scratch ? launch_cast_rows_and_mask_pack(p.v, p.vs, v16, vB, vH, p.Skv, p.D, (uint32_t*)blk, q, mask_scratch, stream)
-                         : launch_cast_rows_bf16_to_f16(p.v, p.vs, v16, vB, vH, p.Skv, p.D, (uint32_t*)blk, stream);
+        if (defer) {
+            *defer = CastRowsCall{p.v, {p.vs[0], p.vs[1], p.vs[2], p.vs[3]}, v16, vB, vH, p.Skv, p.D, (uint32_t*)blk};
+            e = hipSuccess;
+        } else {
+            e = mask_scratch ? launch_cast_rows_and_mask_pack(p.v, p.vs, v16, vB, vH, p.Skv, p.D, (uint32_t*)blk, q, mask_scratch, stream)
+                             : launch_cast_rows_bf16_to_f16(p.v, p.vs, v16, vB, vH, p.Skv, p.D, (uint32_t*)blk, stream);
+        }
         if (e != hipSuccess) return false;
         q.v = v16;
         q.vs[0] = p.vs[0] == 0 ? 0 : (int64_t)vH * p.Skv * p.D; q.vs[1] = p.vs[1] == 0 ? 0 : (int64_t)p.Skv * p.D; q.vs[2] = p.D; q.vs[3] = 1;
@@ -142,13 +149,17 @@ hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p,
         char* w64 = ok ? sc.ensure_w64(plan.cnt_bytes, plan.buf_bytes, stream) : nullptr;
         ok = ok && w64 != nullptr;
         bool packed = false;
+        CastRowsCall cast_call;
+        const bool cast_rides = mask_add && mk != nullptr;  // (additive masks: the cast pass rides in the classification's launch)
+        bool cast_deferred = false;
         if (ok && pv.pv16) {
-            ok = cast_v(pw, pw.mask_kind == MK_BOOL ? mk : nullptr);  // (with a bool mask: the re-pack rides in the cast's launch)
+            ok = cast_v(pw, pw.mask_kind == MK_BOOL ? mk : nullptr, cast_rides ? &cast_call : nullptr);  // (with a bool mask: the re-pack rides in the cast's launch)
             if (!ok && e != hipSuccess) return e;
             packed = ok && mk != nullptr && pw.mask_kind == MK_BOOL;
+            cast_deferred = ok && cast_rides;
         }
         if (ok) {
-            if (mk && !packed && (e = (mask_add ? launch_mask_classify(pw, mk, stream) : launch_mask_pack(pw, mk, stream))) != hipSuccess) return e;
+            if (mk && !packed && (e = (mask_add ? launch_mask_classify(pw, mk, stream, cast_deferred ? &cast_call : nullptr) : launch_mask_pack(pw, mk, stream))) != hipSuccess) return e;
             e = launch_fwd_w64(pw, (float*)(w64 + sc.w64_cnt_bytes), (uint32_t*)w64, stream, &name);
             if (mask_f32) {
                 if (e != hipSuccess) return e;
