@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=12)
     ap.add_argument("--inner", type=int, default=20)
     ap.add_argument("--parity", action="store_true")
-    ap.add_argument("--mask", default="", help="blockdiag | padding | window_tensor | random | alltrue_keys | alltrue_2d: a bool mask tensor on every forward; bias | bias_per_head: an additive fp16 one")
+    ap.add_argument("--mask", default="", help="blockdiag | padding | window_tensor | random | alltrue_keys | alltrue_2d: a bool mask tensor on every forward; bias | bias_per_head: an additive fp16 one; bias_bf16 | bias_f32 | blockdiag_bf16: additive bf16 / fp32 ones")
     ap.add_argument("--graph", action="store_true", help="time hipGraph replays of `inner` launches (short kernels: the Python launch path is not what is measured)")
     ap.add_argument("--quant", type=int, default=0, help="2 / 3: time umfa_quantized_forward_stream with that quant_mode (fp32 O)")
     ap.add_argument("libs", nargs="+")
@@ -98,6 +98,9 @@ def main():
                     "alltrue_keys": lambda: torch.ones(1, 1, 1, S, dtype=torch.bool, device="cuda"),
                     "alltrue_2d": lambda: torch.ones(1, 1, S, S, dtype=torch.bool, device="cuda"),
                     "bias": lambda: (-(i_[:, None] - i_[None, :]).abs().to(torch.float16) / 256.0)[None, None].contiguous(),  # additive fp16, every tile mixed
+                    "bias_bf16": lambda: (-(i_[:, None] - i_[None, :]).abs().to(torch.float16) / 256.0).to(torch.bfloat16)[None, None].contiguous(),  # the same as a bf16 tensor (a bf16 model's mask)
+                    "bias_f32": lambda: (-(i_[:, None] - i_[None, :]).abs().to(torch.float16) / 256.0).float()[None, None].contiguous(),  # ... widened to fp32 (fp16 holds it)
+                    "blockdiag_bf16": lambda: torch.where((i_[:, None] // 1024) == (i_[None, :] // 1024), 0.0, float("-inf")).to(torch.bfloat16)[None, None].contiguous(),
                     "bias_per_head": lambda: (-(i_[:, None] - i_[None, :]).abs().float()[None] / (64.0 * (1 + torch.arange(H, device="cuda")[:, None, None]))).to(torch.float16)[None].contiguous(),
                     "random": lambda: torch.rand(1, H, S, S, device="cuda") > 0.5}[a.mask]()
     libs = [Lib(*s.split("=", 1)) for s in a.libs]

@@ -1020,53 +1020,85 @@ hipError_t launch_mask_pack(FwdParams& p, void* scratch, hipStream_t stream) {
 // BF16: the mask is bf16 -- the same pass writes the dense fp16 copy the attention kernel reads instead (v_fma_mix_f32 takes f16 halves): exact for every
 // value fp16 holds (bf16's 8-bit significands fit), finite values beyond +-65504 clamped there (exp(x - max) of such a term is 0 or the row's only
 // survivor either way), magnitudes below 2^-24 flushed (e^x = 1 to fp32 precision), -inf / NaN kept.
+// BF16 (third session): as for fp32 masks one WORKGROUP per (mask batch, mask head, 256-row block, 64-key tile) -- nqb blocks per slab -- whose four waves are the block's
+// four wave-tiles: they exchange their classes in LDS and the copy is written only where the bias kernel will read it (see mask_classify_f32_body).  fp16 masks (no copy):
+// four consecutive tiles of one 64-row block per workgroup, as before.
 template <bool BF16>
-__device__ __forceinline__ void mask_classify_body(const MaskPackArgs& p, _Float16* copy, int64_t cb, int64_t ch, int64_t cr, const uint32_t block) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint64_t wid = (uint64_t)block * 4 + (threadIdx.x >> 6);
-    if (wid >= p.total) return;
-    const uint32_t tile = (uint32_t)(wid % p.T);
-    const uint32_t rb = (uint32_t)((wid / p.T) % p.nrb64);
-    const uint32_t slab = (uint32_t)(wid / ((uint64_t)p.T * p.nrb64));
+__device__ __forceinline__ void mask_classify_body(const MaskPackArgs& p, uint32_t nqb, _Float16* copy, int64_t cb, int64_t ch, int64_t cr, const uint32_t block) {
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ uint32_t wave_class16[4];
+    uint64_t wid;
+    uint32_t tile, rb, slab;
+    bool live = true;
+    if constexpr (BF16) {
+        tile = block % p.T;
+        const uint32_t qblk = (block / p.T) % nqb;
+        slab = block / (p.T * nqb);
+        rb = 4 * qblk + wv;
+        live = rb < p.nrb64;
+        if (!live) wave_class16[wv] = 1u;  // (a wave past Sq: nothing there)
+        wid = ((uint64_t)slab * p.nrb64 + (live ? rb : 0u)) * p.T + tile;
+    } else {
+        wid = (uint64_t)block * 4 + wv;
+        if (wid >= p.total) return;
+        tile = (uint32_t)(wid % p.T);
+        rb = (uint32_t)((wid / p.T) % p.nrb64);
+        slab = (uint32_t)(wid / ((uint64_t)p.T * p.nrb64));
+    }
     const uint32_t hm = slab % p.Hm, bm = slab / p.Hm;
     const uint32_t row0 = rb * 64 + (lane >> 3), key0 = tile * 64 + (lane & 7) * 8;
     const char* base = (const char*)p.mask + ((int64_t)bm * p.ms[0] + (int64_t)hm * p.ms[1] + (int64_t)row0 * p.ms[2] + key0) * 2;
     u32x4_t w[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) w[i] = *(const u32x4_t*)(base + (int64_t)(8 * i) * p.ms[2] * 2);
+    for (int i = 0; i < 8; ++i) w[i] = live ? *(const u32x4_t*)(base + (int64_t)(8 * i) * p.ms[2] * 2) : u32x4_t{0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u};
     if constexpr (BF16) {
-        const bool writer = p.ms[2] != 0 || rb == 0;  // (a mask without a row dimension: ONE row in the copy, written by the wave of row block 0 -- its lanes 0 ... 7)
-        _Float16* dst = copy + (int64_t)bm * cb + (int64_t)hm * ch + (int64_t)row0 * cr + key0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float lo = __uint_as_float(w[i][j] << 16), hi = __uint_as_float(w[i][j] & 0xffff0000u);
-                auto cv = [](float x) -> uint32_t {
-                    const float c = fabsf(x) <= 65504.0f ? x : (x > 0.0f ? 65504.0f : -65504.0f);  // (inf and NaN fail the first test too ...)
-                    const _Float16 h = (_Float16)((x != x || fabsf(x) == INFINITY) ? x : c);     // ... and are kept as they are
-                    return (uint32_t)__builtin_bit_cast(uint16_t, h);
-                };
-                w[i][j] = cv(lo) | (cv(hi) << 16);
+                // finite values clamped to +-65504 (one v_med3_f32), inf and NaN kept as they are, one packed conversion per pair: ~5 vector instructions per
+                // element (the first form -- two compares, two selects, a scalar conversion and the re-pack per element -- cost 14 and made the pass compute-bound,
+                // like the fp32 one's first build: profiles/r6/lab_notes.md section 16)
+                auto cl = [](float x) -> float { return fabsf(x) < INFINITY ? __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f) : x; };
+                const float y0 = cl(lo), y1 = cl(hi);
+                uint32_t pk;
+                asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk) : "v"(y0), "v"(y1));
+                w[i][j] = pk;
             }
-            if (writer && (p.ms[2] != 0 || (i == 0 && lane < 8))) *(u32x4_t*)(dst + (int64_t)(8 * i) * cr) = w[i];
         }
     }
-    bool any_open = false, any_term = false;
+    // "every element is -inf" / "every element is +-0" off the running AND / OR of the packed words (two instructions per pair)
+    uint32_t or16 = 0u, and16 = 0xffffffffu;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t lo = w[i][j] & 0xffffu, hi16 = w[i][j] >> 16;
-            any_open |= lo != 0xfc00u || hi16 != 0xfc00u;
-            any_term |= (w[i][j] & 0x7fff7fffu) != 0;
+            or16 |= w[i][j];
+            and16 &= w[i][j];
         }
+    const bool any_open = !(and16 == 0xfc00fc00u && or16 == 0xfc00fc00u), any_term = (or16 & 0x7fff7fffu) != 0;
     const bool open = __builtin_amdgcn_ballot_w64(any_open) != 0, term = __builtin_amdgcn_ballot_w64(any_term) != 0;
-    if (lane == 0) p.wflag[wid] = !open ? 1 : (!term ? 2 : 0);
+    const uint32_t my_class = !open ? 1u : (!term ? 2u : 0u);
+    if constexpr (BF16) {
+        if (live && lane == 0) wave_class16[wv] = my_class;
+        __syncthreads();
+        const bool listed = tile == 0 || wave_class16[0] != 1u || wave_class16[1] != 1u || wave_class16[2] != 1u || wave_class16[3] != 1u;
+        if (live && my_class != 2u && listed) {
+            const bool writer = p.ms[2] != 0 || rb == 0;  // (a mask without a row dimension: ONE row in the copy, written by the wave of row block 0 -- its lanes 0 ... 7)
+            _Float16* dst = copy + (int64_t)bm * cb + (int64_t)hm * ch + (int64_t)row0 * cr + key0;
+            if (writer) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (p.ms[2] != 0 || (i == 0 && lane < 8)) *(u32x4_t*)(dst + (int64_t)(8 * i) * cr) = w[i];
+            }
+        }
+    }
+    if (live && lane == 0) p.wflag[wid] = (uint8_t)my_class;
 }
 template <bool BF16>
-__global__ __launch_bounds__(256) void mask_classify_kernel(MaskPackArgs p, _Float16* copy, int64_t cb, int64_t ch, int64_t cr) {
-    mask_classify_body<BF16>(p, copy, cb, ch, cr, blockIdx.x);
+__global__ __launch_bounds__(256) void mask_classify_kernel(MaskPackArgs p, uint32_t nqb, _Float16* copy, int64_t cb, int64_t ch, int64_t cr) {
+    mask_classify_body<BF16>(p, nqb, copy, cb, ch, cr, blockIdx.x);
 }
 
 // ---- fp32 additive masks on the same structure (end of round 6; the reference's additive masks are fp32 wherever its own callers build them:
@@ -1187,7 +1219,7 @@ template <int U, int KIND>
 __global__ __launch_bounds__(256) void cast_rows_and_mask_classify_kernel(CastRowsArgs a, uint32_t cast_blocks, MaskPackArgs mk, MaskClassifyExtra x) {
     if (blockIdx.x < cast_blocks) cast_rows_body<U, true>(a, blockIdx.x);
     else if constexpr (KIND == 2) mask_classify_f32_body(mk, x.nqb, x.copy, x.cb, x.ch, x.cr, x.xflag, x.flags128, blockIdx.x - cast_blocks);
-    else mask_classify_body<KIND == 1>(mk, x.copy, x.cb, x.ch, x.cr, blockIdx.x - cast_blocks);
+    else mask_classify_body<KIND == 1>(mk, x.nqb, x.copy, x.cb, x.ch, x.cr, blockIdx.x - cast_blocks);
 }
 // false: the cast takes its two-launch form (or the grids do not fit one launch): the caller launches the two passes one after the other
 template <int U>
@@ -1243,13 +1275,15 @@ hipError_t launch_mask_classify(FwdParams& p, void* scratch, hipStream_t stream,
         _Float16* copy = (_Float16*)((char*)scratch + pack_bytes);
         const int64_t Sm = p.ms[2] ? p.Sq : 1, cr = p.ms[2] ? (int64_t)p.Skv : 0, chd = Sm * p.Skv, cbt = (int64_t)a.Hm * chd;
         x.copy = copy; x.cb = cbt; x.ch = chd; x.cr = cr;
+        {
+            const uint64_t wgs = slabs * nqb * a.T;  // one workgroup per (256-row block, key tile)
+            if (wgs > 0x7fffffffull) { p.mask_kind = kind_in; return hipErrorInvalidValue; }
+            cgrid = (unsigned)wgs;
+        }
         if (f32) {
             uint8_t* xflag = (uint8_t*)copy + up256((uint64_t)a.Bm * a.Hm * Sm * p.Skv * 2);
             uint32_t* guard = (uint32_t*)(xflag + up256(a.total));
             // ... and the 128-row route's tile flags behind the verdict word: [Bm Hm][2 nrb64][T] bytes = the layout of launch_mask_flags (Sq is a multiple of 64 here)
-            const uint64_t wgs = slabs * nqb * a.T;
-            if (wgs > 0x7fffffffull) { p.mask_kind = kind_in; return hipErrorInvalidValue; }
-            cgrid = (unsigned)wgs;
             x.xflag = xflag; x.flags128 = (uint8_t*)guard + 256;
             xflag_f32 = xflag;
             p.guard = guard;
@@ -1289,9 +1323,9 @@ hipError_t launch_mask_classify(FwdParams& p, void* scratch, hipStream_t stream,
         } else if (f32) {
             hipLaunchKernelGGL(mask_classify_f32_kernel, dim3(cgrid), dim3(256), 0, stream, a, nqb, x.copy, x.cb, x.ch, x.cr, x.xflag, x.flags128);
         } else if (bf) {
-            hipLaunchKernelGGL(mask_classify_kernel<true>, dim3(grid), dim3(256), 0, stream, a, x.copy, x.cb, x.ch, x.cr);
+            hipLaunchKernelGGL(mask_classify_kernel<true>, dim3(cgrid), dim3(256), 0, stream, a, nqb, x.copy, x.cb, x.ch, x.cr);
         } else {
-            hipLaunchKernelGGL(mask_classify_kernel<false>, dim3(grid), dim3(256), 0, stream, a, (_Float16*)nullptr, 0, 0, 0);
+            hipLaunchKernelGGL(mask_classify_kernel<false>, dim3(grid), dim3(256), 0, stream, a, nqb, (_Float16*)nullptr, 0, 0, 0);
         }
     }
     a.done = true;  // (no bit image to pack)
