@@ -1045,6 +1045,26 @@ def run_bwd_case(seed):
                 for t in (got, ref):
                     t[:, info["h"]] -= (t[:, info["h"]] * u).sum(-1, keepdim=True) * u
             rel = ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-3)).item()
+            if rel > GTOL[dt] and name == "dq":
+                # Second reference (end of round 6, soak seed 401643: 'sink_mid' + causal, dq 0.34 -- and 0.34 from the fp32-EXACT engine too, on the same two rows): the
+                # backward is a function of (q, k, v, O, LSE, dO), and the O autograd saved is the forward's 16-bit output.  Where P is one-hot on a key 450 x the others,
+                # dS = P (dP - D) is a difference of two nearly equal numbers and D = rowsum(dO O) carries O's 2^-9; times that key it is a sizeable piece of dQ -- in any
+                # backward that is handed a 16-bit O (tools/lab/bwd_sink_mid_probe.py, profiles/r6/bwd_sink_mid_probe.txt).  So: fp64 gradients of the SAME function, D taken from
+                # the O the kernels were given.  (dK / dV do not have the large factor: they stay on the first reference.)
+                with torch.no_grad():
+                    s2 = torch.matmul(q.double(), k.double().transpose(-1, -2)) * D ** -0.5
+                    if causal:
+                        s2 = s2.masked_fill(~torch.ones(Sq, Skv, dtype=torch.bool, device="cuda").tril(), float("-inf"))
+                    p2 = torch.softmax(s2, dim=-1)
+                    dp2 = torch.matmul(do.double(), v.double().transpose(-1, -2))
+                    dvec = (do.double() * out.detach().double()).sum(-1, keepdim=True)
+                    ref2 = torch.matmul(p2 * (dp2 - dvec), k.double()) * D ** -0.5
+                    if "dir" in info:
+                        ref2[:, info["h"]] -= (ref2[:, info["h"]] * info["dir"].double()).sum(-1, keepdim=True) * info["dir"].double()
+                    rel2 = ((got - ref2).abs().max() / ref2.abs().max().clamp_min(1e-3)).item()
+                if rel2 <= GTOL[dt]:
+                    continue
+                return "%s rel %.3e (%.3e against the reference that takes D from the rounded O) %r" % (name, rel, rel2, what)
             if rel > GTOL[dt]:
                 return "%s rel %.3e %r" % (name, rel, what)
     except Exception as e:  # noqa: BLE001

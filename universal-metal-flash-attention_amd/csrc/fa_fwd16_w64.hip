@@ -358,7 +358,13 @@ bool fwd_w64_supported(const FwdParams& p) {
         // fp32 masks (end of round 6): the same copy, taken by the bias kernel only when the pass finds it EXACT -- the verdict is a device word, so the call
         // enqueues the 128-row kernel on the caller's tensor as well and the kernels guard themselves (FwdParams::guard).  Only masks the pass may read
         // (its bytes within twice the call's tensor traffic: a dense per-head fp32 bias is read once, by the 128-row kernel, as before).
-        if (p.mask_kind == MK_F32 && (!mask_flags_worthwhile(p) || tuning().no_w64_f32_mask.load(std::memory_order_relaxed))) return false;
+        if (p.mask_kind == MK_F32) {
+            if (tuning().no_w64_f32_mask.load(std::memory_order_relaxed)) return false;
+            const uint64_t Bm = p.ms[0] != 0 ? p.B : 1, Hm = p.ms[1] != 0 ? p.H : 1, eb = 2;
+            const uint64_t mask_bytes = Bm * Hm * p.Sq * p.Skv * 4, qkvo = (uint64_t)p.B * p.H * p.D * ((uint64_t)p.Sq * (eb + 4) + 2ull * p.Skv * eb);
+            const int ratio = tuning().f32_mask_ratio.load(std::memory_order_relaxed);
+            if (mask_bytes > (uint64_t)(ratio > 0 ? ratio : 0) * qkvo) return false;
+        }
         if (w64_grid(p) > 512u) return false;
         if (tuning().force_w64.load(std::memory_order_relaxed)) return true;
         const uint64_t blocks = (uint64_t)p.B * p.H * ((p.Sq + 255) / 256), cus = (uint64_t)w64_cu_count();
