@@ -463,6 +463,8 @@ const char* umfa_last_kernel_name(mfa_context_t context);
  *                        (0 / -inf masks, masks built in 16 bits and widened, dyadic biases: yes).  Both routes are enqueued -- the bias kernel on the copy,
  *                        the 128-row kernel on the caller's tensor -- and each checks the verdict word first: exactly one runs, with the numbers that kernel
  *                        gives an fp16 (resp. fp32) mask.  umfa_last_kernel_name then names both.  "1": the 128-row kernel alone, as before.
+ *   "f32_mask_ratio"     "2" (default): lab -- the size rule above: fp32 masks of up to this many times the call's Q + K + V + O bytes take the guarded pair
+ *                        (profiles/r6/f32_mask_size_rule_probe.jsonl: what larger values buy and cost)
  *   "cbal_delta"         "-1" (default: the plan's choice) | "0" ... "16": key tiles by which the folding workgroup's share is shorter (tests, A/B)
  * Returns MFA_ERROR_INVALID_ARGS for an unknown name or a value out of range.  Thread-safe; affects later launches. */
 mfa_error_t umfa_set_option(mfa_context_t context, const char* name, const char* value);
