@@ -42,6 +42,32 @@ def test_backward_adversarial_values(seed):
     assert msg is None, msg
 
 
+def test_backward_is_a_function_of_the_o_it_is_given():
+    """seed 401643 of the round-6 soak ('sink_mid' + causal, bf16, B1 H3 S256 D64): dQ 0.34 of the largest gradient away from fp64 autograd on two rows -- and the
+    fp32-EXACT engine lands on the same numbers (tools/lab/bwd_sink_mid_probe.py, profiles/r6/bwd_sink_mid_probe.txt): P is one-hot on a key 57 x the median there,
+    dS = P (dP - D) cancels, and D = rowsum(dO O) is taken from the forward's 16-bit O, as in any backward that autograd hands a saved 16-bit output.  Against fp64
+    gradients of the same function WITH that O the kernels are inside the leg's tolerance; the exact engine and the 16-bit engine agree with each other."""
+    import umfa_torch
+    fz = _fuzz()
+    assert fz.run_bwd_case(401643) is None
+    import random
+    rng = random.Random(401643 + 100000)
+    kind = rng.choice([k_ for k_ in fz.KINDS if k_ != "zero_rows"])
+    assert kind == "sink_mid"
+    g = torch.Generator(device="cuda").manual_seed(401643)
+    q, k, v, do = (torch.randn(1, 3, 256, 64, device="cuda", dtype=torch.bfloat16, generator=g) for _ in range(4))
+    for _ in range(5):
+        rng.random()  # (the leg's draws of dtype, head_dim, heads, lengths, causal: fixed above)
+    q, k, v = fz.transform(random.Random(1), q, k, v, "sink_mid", {})
+    grads = {}
+    for name, opts in (("bwd16", {}), ("exact", {"bwd_exact": 1})):
+        qg, kg, vg = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
+        with umfa_torch.options(**opts):
+            umfa_torch.scaled_dot_product_attention(qg, kg, vg, is_causal=True).backward(do)
+        grads[name] = qg.grad.float()
+    assert float((grads["bwd16"] - grads["exact"]).abs().max()) <= fz.GTOL[torch.bfloat16] * float(grads["exact"].abs().max())
+
+
 @pytest.mark.parametrize("seed", range(120))
 def test_w64_families_random_shapes(seed):
     msg = _fuzz().run_shape_case(seed)
