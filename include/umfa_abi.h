@@ -458,13 +458,16 @@ const char* umfa_last_kernel_name(mfa_context_t context);
  *                        the plain form three of four waves compute rows that do not exist).  0: while the items fit one round of its residency (the
  *                        split-KV plan then counts parts for it); 1: whenever the shape allows; 2: never.  Same results to rounding; bitwise repeatable.
  *   "no_w64_f32_mask"    "0" (default) | "1": fp32 ADDITIVE mask tensors.  By default a mask the one-wave-per-SIMD bias kernels could take as fp16 (<= 4-D
- *                        broadcastable, 16-byte aligned contiguous rows, whole 64 x 64 tiles, bytes within twice the call's tensor traffic) is
+ *                        broadcastable, 16-byte aligned contiguous rows, whole 64 x 64 tiles, bytes within twice the call's tensor traffic -- eight times for [B,1,Sq,Skv] --) is
  *                        classified and copied to fp16 by a pre-pass that also decides ON THE DEVICE whether fp16 holds every value exactly
  *                        (0 / -inf masks, masks built in 16 bits and widened, dyadic biases: yes).  Both routes are enqueued -- the bias kernel on the copy,
  *                        the 128-row kernel on the caller's tensor -- and each checks the verdict word first: exactly one runs, with the numbers that kernel
  *                        gives an fp16 (resp. fp32) mask.  umfa_last_kernel_name then names both.  "1": the 128-row kernel alone, as before.
- *   "f32_mask_ratio"     "2" (default): lab -- the size rule above: fp32 masks of up to this many times the call's Q + K + V + O bytes take the guarded pair
- *                        (profiles/r6/f32_mask_size_rule_probe.jsonl: what larger values buy and cost)
+ *   "mask_pass_ratio" "f32_mask_ratio"   "0" (default: the rule's own constants): lab -- the size rule of the mask pre-passes: a float mask is read by a pre-pass (tile
+ *                        flags for the 128-row kernel, classes / lists / the fp16 copy for the bias kernels) when its bytes stay within 2 x the call's
+ *                        Q + K + V + O bytes, 8 x for a mask with a batch dimension and no head dimension (padding / document masks in additive form);
+ *                        a positive value replaces the constant (f32_mask_ratio: for the fp32 route alone).  profiles/r6/mask_pass_rule_probe.jsonl,
+ *                        f32_mask_size_rule_probe.jsonl: what larger values buy and cost
  *   "cbal_delta"         "-1" (default: the plan's choice) | "0" ... "16": key tiles by which the folding workgroup's share is shorter (tests, A/B)
  * Returns MFA_ERROR_INVALID_ARGS for an unknown name or a value out of range.  Thread-safe; affects later launches. */
 mfa_error_t umfa_set_option(mfa_context_t context, const char* name, const char* value);

@@ -189,6 +189,18 @@ def test_fp32_mask_routing_conditions(umfa_opts):
     per_head = bias.expand(1, H, S, S).contiguous()  # 302 MB of mask against 2 x 94 MB of tensors: read once, by the 128-row kernel
     umfa_torch.attention_forward(q, k, v, mask=per_head, out_dtype=torch.float32)
     assert " | " not in umfa_torch.last_kernel(), umfa_torch.last_kernel()
+    del per_head
+    # the size rule is shape-aware (fa_aux.hip mask_flags_worthwhile): 3.2 x the tensors' bytes is too much for a mask with a head dimension (a bias) and fine for one
+    # with a batch dimension and none for the heads (a padding / document mask in additive form: up to 8 x) -- same bytes, same answers
+    B2, H2, S2 = 4, 4, 4096  # 256 blocks; a [4,1,S,S] / [1,4,S,S] fp32 mask = 268 MB = 3.2 x the tensors
+    q2, k2, v2 = (torch.randn(B2, H2, S2, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    j = torch.arange(S2, device="cuda")
+    docs = torch.where((j[:, None] // 1024) == (j[None, :] // 1024), 0.0, NEG)
+    o_b = umfa_torch.attention_forward(q2, k2, v2, mask=docs[None, None].expand(B2, 1, S2, S2).contiguous(), out_dtype=torch.float32)
+    assert " | " in umfa_torch.last_kernel(), umfa_torch.last_kernel()
+    o_h = umfa_torch.attention_forward(q2, k2, v2, mask=docs[None, None].expand(1, H2, S2, S2).contiguous(), out_dtype=torch.float32)
+    assert " | " not in umfa_torch.last_kernel(), umfa_torch.last_kernel()
+    assert float((o_b - o_h).abs().max()) <= 2.0 ** -9 * float(o_h.abs().max())
 
 
 def test_fp32_mask_graph_replay_follows_the_contents_across_the_verdict():

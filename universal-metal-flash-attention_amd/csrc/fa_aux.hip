@@ -1354,7 +1354,13 @@ bool mask_flags_worthwhile(const FwdParams& p) {
     const uint64_t es = p.mask_kind == MK_F32 ? 4 : 2, eb = p.in_prec == P_FP32 ? 4 : 2;
     const uint64_t mask_bytes = Bm * Hm * p.Sq * p.Skv * es;
     const uint64_t qkvo = (uint64_t)p.B * p.H * p.D * ((uint64_t)p.Sq * (eb + 4) + 2ull * p.Skv * eb);
-    return mask_bytes <= 2 * qkvo;
+    // ... 2 x: set for dense per-head biases, where the pass is pure cost.  A float mask with a BATCH dimension and no head dimension ([B, 1, Sq, Skv]: what a padding /
+    // document / causal + padding mask looks like once it is additive -- the transformers idiom, 0 / finfo.min) is rarely a bias: up to 8 x.  Measured at 3.2 and 6.4 x
+    // (profiles/r6/mask_pass_rule_probe.jsonl, rule 2 -> 8): documents -40 ... -75 %, per-sample key padding -12 ... -45 %, a dense bias of that shape +10 ... +17 % on the
+    // bias kernels and +16 ... +35 % on the 128-row kernel.  Lab option mask_pass_ratio overrides both.
+    const int lab = tuning().mask_pass_ratio.load(std::memory_order_relaxed);
+    const uint64_t limit = lab > 0 ? (uint64_t)lab : (p.ms[0] != 0 && p.ms[1] == 0 ? 8u : 2u);
+    return mask_bytes <= limit * qkvo;
 }
 
 size_t mask_flags_bytes(const FwdParams& p) {

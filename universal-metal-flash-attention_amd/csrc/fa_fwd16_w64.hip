@@ -360,10 +360,16 @@ bool fwd_w64_supported(const FwdParams& p) {
         // (its bytes within twice the call's tensor traffic: a dense per-head fp32 bias is read once, by the 128-row kernel, as before).
         if (p.mask_kind == MK_F32) {
             if (tuning().no_w64_f32_mask.load(std::memory_order_relaxed)) return false;
-            const uint64_t Bm = p.ms[0] != 0 ? p.B : 1, Hm = p.ms[1] != 0 ? p.H : 1, eb = 2;
-            const uint64_t mask_bytes = Bm * Hm * p.Sq * p.Skv * 4, qkvo = (uint64_t)p.B * p.H * p.D * ((uint64_t)p.Sq * (eb + 4) + 2ull * p.Skv * eb);
+            // the size rule of every mask pre-pass (fa_aux.hip mask_flags_worthwhile: 2 x the call's tensor bytes; 8 x for a mask with a batch and no head dimension);
+            // lab option f32_mask_ratio > 0 puts its own constant in its place
             const int ratio = tuning().f32_mask_ratio.load(std::memory_order_relaxed);
-            if (mask_bytes > (uint64_t)(ratio > 0 ? ratio : 0) * qkvo) return false;
+            if (ratio > 0) {
+                const uint64_t Bm = p.ms[0] != 0 ? p.B : 1, Hm = p.ms[1] != 0 ? p.H : 1, eb = 2;
+                const uint64_t mask_bytes = Bm * Hm * p.Sq * p.Skv * 4, qkvo = (uint64_t)p.B * p.H * p.D * ((uint64_t)p.Sq * (eb + 4) + 2ull * p.Skv * eb);
+                if (mask_bytes > (uint64_t)ratio * qkvo) return false;
+            } else if (!mask_flags_worthwhile(p)) {
+                return false;
+            }
         }
         if (w64_grid(p) > 512u) return false;
         if (tuning().force_w64.load(std::memory_order_relaxed)) return true;
