@@ -240,3 +240,34 @@ def test_bias_call_captured_without_a_warm_up_runs_on_the_kernel_that_needs_no_s
     g2.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, eager)
+
+
+@pytest.mark.parametrize("D", [128, 64])
+def test_bf16_mask_with_finfo_min_is_minus_inf_on_both_routes(D, umfa_opts):
+    """the transformers idiom: an additive bf16 mask 0 / torch.finfo(torch.bfloat16).min, causal + padding, one per batch element.  Its log2-domain term overflows to
+    -inf in fp32, so the 128-row kernel (which reads the bf16 tensor itself) treats it as -inf: rows with every key masked give O = 0, LSE = -inf.  The bias route's
+    fp16 copy clamped it to -65504 until the third session of round 6 (finite: such rows came out as softmax(s) V, and no tile was ever skipped); now it copies -inf:
+    bit for bit what a -inf mask gives, and the 128-row kernel's answer."""
+    import umfa_torch
+    umfa_opts(force_w64=1)
+    B, H, S = 2, 2, 512
+    torch.manual_seed(D)
+    q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    i = torch.arange(S, device="cuda")
+    lens = torch.tensor([S - 100, S - 300], device="cuda")
+    keep = (i[None, :, None] >= i[None, None, :]) & (i[None, None, :] < lens[:, None, None]) & (i[None, :, None] < lens[:, None, None])  # causal + padding; padded QUERY rows see nothing
+    m_min = torch.where(keep, 0.0, torch.finfo(torch.bfloat16).min).to(torch.bfloat16)[:, None].contiguous()
+    m_inf = torch.where(keep, 0.0, NEG).to(torch.bfloat16)[:, None].contiguous()
+    o, lse = umfa_torch.attention_forward(q, k, v, mask=m_min, out_dtype=torch.float32, return_lse=True)
+    assert "bias>" in umfa_torch.last_kernel()
+    o2, lse2 = umfa_torch.attention_forward(q, k, v, mask=m_inf, out_dtype=torch.float32, return_lse=True)
+    assert torch.equal(o, o2) and torch.equal(lse, lse2)
+    dead = ~keep.any(-1)  # [B, S]
+    assert bool(dead.any())
+    de = dead[:, None, :].expand(B, H, S)
+    assert bool((o[de] == 0).all()) and bool(torch.isneginf(lse.view(B, H, S)[de]).all())
+    with umfa_torch.options(no_w64_bias=1, force_w64=0):
+        o3, lse3 = umfa_torch.attention_forward(q, k, v, mask=m_min, out_dtype=torch.float32, return_lse=True)
+        assert umfa_torch.last_kernel().startswith("fa_fwd16<")
+    assert float((o - o3).abs().max()) <= 2.0 ** -9 * float(o3.abs().max())
+    assert bool((o3[de] == 0).all()) and bool(torch.isneginf(lse3.view(B, H, S)[de]).all())

@@ -314,3 +314,33 @@ def test_fp32_mask_call_captured_without_a_warm_up_runs_the_128_row_kernel_alone
     g2.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, eager)
+
+
+@pytest.mark.parametrize("mdt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+def test_finfo_min_masks_on_the_128_row_kernel_are_minus_inf_and_their_tiles_are_skipped(mdt, dt, umfa_opts):
+    """the transformers idiom on a launch too small for the bias kernels (8 blocks): an additive mask 0 / torch.finfo(mask dtype).min, causal + padding per batch element.
+    The term the 128-row kernel adds is value x log2 e = -inf in fp32 (fa_common.h mask_term), so these ARE -inf masks: bit for bit the answer of the -inf mask, rows with
+    every key masked give O = 0 / LSE = -inf -- and since the third session of round 6 the tile-flag pass says so too (it compared raw bits with -inf's before and skipped
+    nothing): bit-identical with and without the flags, as every flagged launch is."""
+    import umfa_torch
+    B, H, S, D = 2, 2, 512, 128
+    torch.manual_seed(3)
+    q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=dt) for _ in range(3))
+    i = torch.arange(S, device="cuda")
+    lens = torch.tensor([S - 100, S - 300], device="cuda")
+    keep = (i[None, :, None] >= i[None, None, :]) & (i[None, None, :] < lens[:, None, None]) & (i[None, :, None] < lens[:, None, None])
+    m_min = torch.where(keep, 0.0, torch.finfo(mdt).min).to(mdt)[:, None].contiguous()
+    m_inf = torch.where(keep, 0.0, NEG).to(mdt)[:, None].contiguous()
+    o, lse = umfa_torch.attention_forward(q, k, v, mask=m_min, out_dtype=torch.float32, return_lse=True)
+    assert umfa_torch.last_kernel().startswith("fa_fwd16<"), umfa_torch.last_kernel()
+    o2, lse2 = umfa_torch.attention_forward(q, k, v, mask=m_inf, out_dtype=torch.float32, return_lse=True)
+    assert torch.equal(o, o2) and torch.equal(lse, lse2)
+    with umfa_torch.options(no_mask_flags=1):
+        o3, lse3 = umfa_torch.attention_forward(q, k, v, mask=m_min, out_dtype=torch.float32, return_lse=True)
+    assert torch.equal(o, o3) and torch.equal(lse, lse3)
+    de = (~keep.any(-1))[:, None, :].expand(B, H, S)
+    assert bool(de.any()) and bool((o[de] == 0).all()) and bool(torch.isneginf(lse.view(B, H, S)[de]).all())
+    s_ = torch.matmul(q.double(), k.double().transpose(-1, -2)) * D ** -0.5 + m_inf.double()
+    ref = torch.matmul(torch.nan_to_num(torch.softmax(s_, dim=-1), nan=0.0), v.double())
+    assert float((o.double() - ref).abs().max() / ref.abs().max()) < 2.0 ** -11 * 1.5

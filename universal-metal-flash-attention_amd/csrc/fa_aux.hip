@@ -845,10 +845,16 @@ __global__ __launch_bounds__(256) void mask_flags_kernel(FwdParams p, uint8_t* f
                             any_open |= nz != 0;
                             any_term |= nz != 0x80808080u;
                         } else if (p.mask_kind == MK_F32) {
-                            any_open |= w[j] != 0xff800000u;           // not -inf
+                            // "masked" = the TERM the kernel adds is -inf (fa_common.h mask_term: value x log2 e): -inf itself, and finite values whose product
+                            // overflows -- torch.finfo(torch.float32).min, the transformers idiom: its tiles are skipped like -inf ones (third session of round 6;
+                            // the scalar path below has always classified the term)
+                            any_open |= __uint_as_float(w[j]) * UMFA_LOG2E != -INFINITY;
                             any_term |= (w[j] & 0x7fffffffu) != 0;     // not +-0
+                        } else if (p.mask_kind == MK_BF16) {
+                            any_open |= __uint_as_float(w[j] << 16) * UMFA_LOG2E != -INFINITY || __uint_as_float(w[j] & 0xffff0000u) * UMFA_LOG2E != -INFINITY;  // (finfo(bfloat16).min too)
+                            any_term |= (w[j] & 0x7fff7fffu) != 0;
                         } else {
-                            const uint32_t ninf = p.mask_kind == MK_F16 ? 0xfc00u : 0xff80u;
+                            const uint32_t ninf = 0xfc00u;  // fp16: every finite value has a finite term
                             const uint32_t lo = w[j] & 0xffffu, hi16 = w[j] >> 16;
                             any_open |= lo != ninf || hi16 != ninf;
                             any_term |= (w[j] & 0x7fff7fffu) != 0;
@@ -1060,7 +1066,12 @@ __device__ __forceinline__ void mask_classify_body(const MaskPackArgs& p, uint32
                 // finite values clamped to +-65504 (one v_med3_f32), inf and NaN kept as they are, one packed conversion per pair: ~5 vector instructions per
                 // element (the first form -- two compares, two selects, a scalar conversion and the re-pack per element -- cost 14 and made the pass compute-bound,
                 // like the fp32 one's first build: profiles/r6/lab_notes.md section 16)
-                auto cl = [](float x) -> float { return fabsf(x) < INFINITY ? __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f) : x; };
+                // ... and a finite value whose log2-domain term overflows in fp32 (x log2 e = -inf: torch.finfo(torch.bfloat16).min, the transformers idiom for "masked") IS
+                // -inf to the 128-row kernel, which reads the bf16 tensor itself (fa_common.h mask_term) -- so it is -inf in the copy too: the same answers on both routes (rows
+                // with every key masked: O = 0, LSE = -inf), and tiles that hold nothing else are never staged.  (Before the third session it was clamped to -65504: finite.)
+                auto cl = [](float x) -> float {
+                    return fabsf(x) < INFINITY ? (x * UMFA_LOG2E == -INFINITY ? -INFINITY : __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f)) : x;
+                };
                 const float y0 = cl(lo), y1 = cl(hi);
                 uint32_t pk;
                 asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pk) : "v"(y0), "v"(y1));
@@ -1137,8 +1148,8 @@ __device__ __forceinline__ void mask_classify_f32_body(const MaskPackArgs& p, ui
     // log2-domain term x log2 e overflows in fp32 (torch.finfo(torch.float32).min, the "large negative" idiom at its largest; fa_common.h mask_term): its copy is
     // -inf (the conversion's own overflow).  NaN fails the round trip: the 128-row kernel gets it.
     constexpr float NINF_LIM = -0x1.62e42ep+127f;  // x < this  =>  x * UMFA_LOG2E == -inf in fp32 (0x1.62e42fefp+127 = FLT_MAX ln 2, rounded towards zero: a few ulps of slack stay finite-and-inexact)
-    uint32_t or32[2] = {0u, 0u}, and32[2] = {0xffffffffu, 0xffffffffu}, or16 = 0u, and16 = 0xffffffffu;
-    bool inexact = false;
+    uint32_t or32[2] = {0u, 0u}, or16 = 0u, and16 = 0xffffffffu;
+    bool open32[2] = {false, false}, inexact = false;
     u32x2_t o[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -1152,19 +1163,16 @@ __device__ __forceinline__ void mask_classify_f32_body(const MaskPackArgs& p, ui
             const bool ok0 = b0 == x0 || fabsf(x0) <= 0x1p-24f || x0 < NINF_LIM, ok1 = b1 == x1 || fabsf(x1) <= 0x1p-24f || x1 < NINF_LIM;
             inexact = inexact || !ok0 || !ok1;
             or32[i >> 3] |= w0 | w1;
-            and32[i >> 3] &= w0 & w1;
+            open32[i >> 3] = open32[i >> 3] || x0 * UMFA_LOG2E != -INFINITY || x1 * UMFA_LOG2E != -INFINITY;  // (the 128-row kernel's definition of "masked": the term is -inf)
             or16 |= pk;
             and16 &= pk;
             o[i][j] = pk;
         }
     }
     const bool any_open = !(and16 == 0xfc00fc00u && or16 == 0xfc00fc00u), any_term = (or16 & 0x7fff7fffu) != 0;
-    bool open32[2], term32[2];
+    bool term32[2];
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-        open32[hf] = !(and32[hf] == 0xff800000u && or32[hf] == 0xff800000u);
-        term32[hf] = (or32[hf] & 0x7fffffffu) != 0;
-    }
+    for (int hf = 0; hf < 2; ++hf) term32[hf] = (or32[hf] & 0x7fffffffu) != 0;
     const bool open = __builtin_amdgcn_ballot_w64(any_open) != 0, term = __builtin_amdgcn_ballot_w64(any_term) != 0;
     const bool bad = __builtin_amdgcn_ballot_w64(inexact) != 0;
     // Who reads the copy: a wave whose class for a LISTED tile is not "all zero" (fa_fwd16_w64_kernel.inc: mk_cls != 2 -- a wave-tile at -inf throughout
