@@ -271,3 +271,70 @@ def test_bf16_mask_with_finfo_min_is_minus_inf_on_both_routes(D, umfa_opts):
         assert umfa_torch.last_kernel().startswith("fa_fwd16<")
     assert float((o - o3).abs().max()) <= 2.0 ** -9 * float(o3.abs().max())
     assert bool((o3[de] == 0).all()) and bool(torch.isneginf(lse3.view(B, H, S)[de]).all())
+
+
+RAGGED = [(1, 3, 1288, 776), (2, 2, 1024, 1000), (1, 6, 1096, 2056), (2, 1, 2000, 72)]
+
+
+@pytest.mark.parametrize("kind", ["rel_pos", "random", "blockdiag_inf", "padding_row_broadcast", "empty_rows_and_blocks", "all_zero"])
+@pytest.mark.parametrize("dt,mdt", [(torch.bfloat16, torch.float16), (torch.float16, torch.float16), (torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32), (torch.float16, torch.float32)])
+@pytest.mark.parametrize("shape,grid", [(RAGGED[0], 0), (RAGGED[1], 3), (RAGGED[2], 0), (RAGGED[3], 4)])
+@pytest.mark.parametrize("D", [128, 64])
+def test_w64_additive_mask_ragged_shapes_vs_oracle(kind, dt, mdt, shape, grid, D, umfa_opts):
+    """(end of round 6) Sq from 1024 on and Skv that are not multiples of 64 -- Skv a multiple of 8 (16-bit masks; fp32: of 4): the classification pass writes the fp16 copy
+    PADDED to whole 64 x 64 tiles, keys past Skv and rows past Sq at -inf, and the bias kernel runs on that (fp32 masks: as one of the guarded pair).  Against the oracle with
+    the mask, against the 128-row kernel (option no_w64_ragged_mask), repeatable; rows that see nothing give O = 0 / LSE = -inf."""
+    import umfa_torch
+    umfa_opts(force_w64=1)
+    if grid:
+        umfa_opts(w64_grid=grid)
+    B, H, Sq, Skv = shape
+    torch.manual_seed(Sq + Skv + D)
+    q = torch.randn(B, H, Sq, D, device="cuda", dtype=dt)
+    k = torch.randn(B, H, Skv, D, device="cuda", dtype=dt)
+    v = torch.randn(B, H, Skv, D, device="cuda", dtype=dt)
+    m = _bias(kind, B, 1, Sq, Skv, seed=Sq)  # (masks without a head dimension: a ragged mask must be small enough for the pass to read it -- it needs the padded copy)
+    if mdt == torch.float32:
+        m = m.float()  # (fp16-born values: fp16 holds them -- the bias kernel of the pair runs)
+    elif mdt != torch.float16:
+        m = m.to(mdt)
+    o, lse = umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32, return_lse=True)
+    kern = umfa_torch.last_kernel()
+    assert "bias>" in kern and (" | " in kern) == (mdt == torch.float32), kern
+    mfull = np.ascontiguousarray(m.expand(B, H, Sq, Skv).float().cpu().numpy())
+    ref, ref_lse = _oracle().sdpa_forward(npy(q), npy(k), npy(v), mask=mfull, mask_type=_oracle().MASK_ADDITIVE, return_lse=True)
+    on = o.cpu().numpy()
+    assert np.isfinite(on).all()
+    check_forward(on, ref, dt, kern.split(" | ")[0], f"w64_bias_ragged_{kind}", scale_max=1.02 if grid else 1.0)
+    dead = np.isneginf(mfull).all(-1)
+    ln = lse.cpu().numpy().reshape(B, H, Sq)
+    assert (on[dead] == 0).all() and np.isneginf(ln[dead]).all()
+    assert np.abs(ln[~dead] - ref_lse[~dead]).max() < 2e-2
+    assert torch.equal(o, umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32))
+    with umfa_torch.options(no_w64_ragged_mask=1):
+        o3 = umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32)
+        assert umfa_torch.last_kernel().startswith("fa_fwd16<"), umfa_torch.last_kernel()
+    assert float((o - o3).abs().max()) <= 2.0 ** -9 * float(o3.abs().max())
+    o16 = umfa_torch.attention_forward(q, k, v, mask=m)
+    assert o16.dtype == dt and float((o16.float() - o).abs().max()) <= 2.0 ** -8 * float(o.abs().max()) * 1.01
+
+
+def test_w64_additive_mask_ragged_routing(umfa_opts):
+    """which ragged shapes take the bias kernels by default: Sq >= 1024, Skv >= 64 and a multiple of 8 (fp32 masks: 4), a block per CU; the rest -- and the option -- the 128-row kernel"""
+    import umfa_torch
+    torch.manual_seed(5)
+    B, H, D = 1, 72, 128
+    for (Sq, Skv, mdt, want) in [(1000, 1000, torch.float16, False), (1096, 1000, torch.float16, True), (1096, 1000, torch.bfloat16, True), (1096, 1004, torch.float32, True),
+                                 (1096, 1004, torch.float16, False), (1096, 1001, torch.float32, False), (1096, 56, torch.float16, False)]:
+        q = torch.randn(B, H, Sq, D, device="cuda", dtype=torch.bfloat16)
+        k, v = (torch.randn(B, H, Skv, D, device="cuda", dtype=torch.bfloat16) for _ in range(2))
+        i = torch.arange(Sq, device="cuda")[:, None]
+        j = torch.arange(Skv, device="cuda")[None, :]
+        m = (-(i - j).abs().float() / 128.0).to(torch.float16).to(mdt)[None, None].contiguous()
+        o = umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32)
+        kern = umfa_torch.last_kernel()
+        assert ("bias>" in kern) == want, (Sq, Skv, mdt, kern)
+        with umfa_torch.options(no_w64_ragged_mask=1):
+            o2 = umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32)
+            assert "bias>" not in umfa_torch.last_kernel()
+        assert float((o - o2).abs().max()) <= 2.0 ** -9 * float(o2.abs().max())

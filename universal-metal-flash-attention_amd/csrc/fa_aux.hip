@@ -1029,14 +1029,20 @@ hipError_t launch_mask_pack(FwdParams& p, void* scratch, hipStream_t stream) {
 // BF16 (third session): as for fp32 masks one WORKGROUP per (mask batch, mask head, 256-row block, 64-key tile) -- nqb blocks per slab -- whose four waves are the block's
 // four wave-tiles: they exchange their classes in LDS and the copy is written only where the bias kernel will read it (see mask_classify_f32_body).  fp16 masks (no copy):
 // four consecutive tiles of one 64-row block per workgroup, as before.
-template <bool BF16>
+// SRC: 0 = fp16 mask on whole tiles, read in place by the attention kernel (classes only); 1 = bf16 mask (-> fp16 copy); 3 = fp16 mask of a RAGGED shape (Sq or Skv not a
+// multiple of 64; end of round 6): the attention kernel's mask DMA wants whole 64 x 64 tiles, so the pass writes a copy PADDED to whole tiles -- keys past Skv and rows past Sq
+// at -inf (a padded key must not attend; a padded row's answers are never stored) -- as it does for every bf16 / fp32 mask now.  Chunks of 16 bytes are entirely inside or
+// outside the mask (the route asks for Skv % 8 == 0 with 16-bit masks, % 4 with fp32 ones).
+template <int SRC>
 __device__ __forceinline__ void mask_classify_body(const MaskPackArgs& p, uint32_t nqb, _Float16* copy, int64_t cb, int64_t ch, int64_t cr, const uint32_t block) {
+    constexpr bool BF16 = SRC == 1, COPY = SRC != 0;
+    constexpr uint32_t NINF2 = BF16 ? 0xff80ff80u : 0xfc00fc00u;  // two -inf of the source type
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     __shared__ uint32_t wave_class16[4];
     uint64_t wid;
     uint32_t tile, rb, slab;
     bool live = true;
-    if constexpr (BF16) {
+    if constexpr (COPY) {
         tile = block % p.T;
         const uint32_t qblk = (block / p.T) % nqb;
         slab = block / (p.T * nqb);
@@ -1056,7 +1062,10 @@ __device__ __forceinline__ void mask_classify_body(const MaskPackArgs& p, uint32
     const char* base = (const char*)p.mask + ((int64_t)bm * p.ms[0] + (int64_t)hm * p.ms[1] + (int64_t)row0 * p.ms[2] + key0) * 2;
     u32x4_t w[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) w[i] = live ? *(const u32x4_t*)(base + (int64_t)(8 * i) * p.ms[2] * 2) : u32x4_t{0xff80ff80u, 0xff80ff80u, 0xff80ff80u, 0xff80ff80u};
+    for (int i = 0; i < 8; ++i) {
+        const bool in = live && (!COPY || (key0 < p.Skv && (p.ms[2] == 0 || row0 + 8u * (uint32_t)i < p.Sq)));
+        w[i] = in ? *(const u32x4_t*)(base + (int64_t)(8 * i) * p.ms[2] * 2) : u32x4_t{NINF2, NINF2, NINF2, NINF2};
+    }
     if constexpr (BF16) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -1091,7 +1100,7 @@ __device__ __forceinline__ void mask_classify_body(const MaskPackArgs& p, uint32
     const bool any_open = !(and16 == 0xfc00fc00u && or16 == 0xfc00fc00u), any_term = (or16 & 0x7fff7fffu) != 0;
     const bool open = __builtin_amdgcn_ballot_w64(any_open) != 0, term = __builtin_amdgcn_ballot_w64(any_term) != 0;
     const uint32_t my_class = !open ? 1u : (!term ? 2u : 0u);
-    if constexpr (BF16) {
+    if constexpr (COPY) {
         if (live && lane == 0) wave_class16[wv] = my_class;
         __syncthreads();
         const bool listed = tile == 0 || wave_class16[0] != 1u || wave_class16[1] != 1u || wave_class16[2] != 1u || wave_class16[3] != 1u;
@@ -1107,9 +1116,9 @@ __device__ __forceinline__ void mask_classify_body(const MaskPackArgs& p, uint32
     }
     if (live && lane == 0) p.wflag[wid] = (uint8_t)my_class;
 }
-template <bool BF16>
+template <int SRC>
 __global__ __launch_bounds__(256) void mask_classify_kernel(MaskPackArgs p, uint32_t nqb, _Float16* copy, int64_t cb, int64_t ch, int64_t cr) {
-    mask_classify_body<BF16>(p, nqb, copy, cb, ch, cr, blockIdx.x);
+    mask_classify_body<SRC>(p, nqb, copy, cb, ch, cr, blockIdx.x);
 }
 
 // ---- fp32 additive masks on the same structure (end of round 6; the reference's additive masks are fp32 wherever its own callers build them:
@@ -1139,7 +1148,10 @@ __device__ __forceinline__ void mask_classify_f32_body(const MaskPackArgs& p, ui
     const char* base = (const char*)p.mask + ((int64_t)bm * p.ms[0] + (int64_t)hm * p.ms[1] + (int64_t)row0 * p.ms[2] + key0) * 4;
     u32x4_t w[16];  // the whole tile in flight: 16 loads of 4 rows each
 #pragma unroll
-    for (int i = 0; i < 16; ++i) w[i] = live ? *(const u32x4_t*)(base + (int64_t)(4 * i) * p.ms[2] * 4) : u32x4_t{0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u};
+    for (int i = 0; i < 16; ++i) {  // (ragged shapes: chunks outside the mask -- keys past Skv, rows past Sq -- count and are copied as -inf; see mask_classify_body)
+        const bool in = live && key0 < p.Skv && (p.ms[2] == 0 || row0 + 4u * (uint32_t)i < p.Sq);
+        w[i] = in ? *(const u32x4_t*)(base + (int64_t)(4 * i) * p.ms[2] * 4) : u32x4_t{0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u};
+    }
     // the 128-row route's tile flags (FwdParams::mask_flags: per 32-row block and 64-key tile, from the fp32 VALUES as mask_flags_kernel reads them) come from
     // the same read: rows 0 ... 31 of the tile are loads 0 ... 7, rows 32 ... 63 loads 8 ... 15.
     // ~8 vector instructions per element (the first build's ~25 made the pass compute-bound: 4096 elements per wave, four waves per SIMD): "every element is -inf" /
@@ -1202,9 +1214,10 @@ __device__ __forceinline__ void mask_classify_f32_body(const MaskPackArgs& p, ui
         p.wflag[wid] = (uint8_t)my_class;
         xflag[wid] = bad ? 1 : 0;  // (always written: nothing to clean between launches, nothing atomic)
         if (flags128) {
-            uint8_t* f = flags128 + ((uint64_t)slab * (2 * p.nrb64) + 2 * rb) * p.T + tile;
+            const uint32_t nrb32 = (p.Sq + 31) / 32;  // (= FwdParams::mf_nrb; a ragged Sq may leave the last 64-row block one 32-row block only)
+            uint8_t* f = flags128 + ((uint64_t)slab * nrb32 + 2 * rb) * p.T + tile;
             f[0] = !f_open[0] ? 1 : (!f_term[0] ? 2 : 0);
-            f[p.T] = !f_open[1] ? 1 : (!f_term[1] ? 2 : 0);
+            if (2 * rb + 1 < nrb32) f[p.T] = !f_open[1] ? 1 : (!f_term[1] ? 2 : 0);
         }
     }
 }
@@ -1215,7 +1228,7 @@ __global__ __launch_bounds__(256) void mask_classify_f32_kernel(MaskPackArgs p, 
 // The classification pass in the V cast pass's launch (bf16 operands: every additive-mask call on the bias kernels has one): blocks [0, cast_blocks) cast -- slab-major,
 // first: their exchange relies on it --, the rest classify.  The two passes read different tensors and are each short of the chip's bandwidth on their own (12 us of cast,
 // 8 ... 26 us of classification at FLUX size); in one launch they overlap and the call is a launch shorter -- as the bool masks' re-pack has ridden there since round 5.
-// KIND: 0 fp16 mask (classes only), 1 bf16 (+ the fp16 copy), 2 fp32 (+ the copy, exactness bytes, the 128-row kernel's tile flags)
+// KIND: 0 fp16 mask (classes only), 1 bf16 (+ the fp16 copy), 2 fp32 (+ the copy, exactness bytes, the 128-row kernel's tile flags), 3 fp16 of a ragged shape (+ the padded copy)
 struct MaskClassifyExtra {
     uint32_t nqb;
     _Float16* copy;
@@ -1227,7 +1240,7 @@ template <int U, int KIND>
 __global__ __launch_bounds__(256) void cast_rows_and_mask_classify_kernel(CastRowsArgs a, uint32_t cast_blocks, MaskPackArgs mk, MaskClassifyExtra x) {
     if (blockIdx.x < cast_blocks) cast_rows_body<U, true>(a, blockIdx.x);
     else if constexpr (KIND == 2) mask_classify_f32_body(mk, x.nqb, x.copy, x.cb, x.ch, x.cr, x.xflag, x.flags128, blockIdx.x - cast_blocks);
-    else mask_classify_body<KIND == 1>(mk, x.nqb, x.copy, x.cb, x.ch, x.cr, blockIdx.x - cast_blocks);
+    else mask_classify_body<KIND>(mk, x.nqb, x.copy, x.cb, x.ch, x.cr, blockIdx.x - cast_blocks);
 }
 // false: the cast takes its two-launch form (or the grids do not fit one launch): the caller launches the two passes one after the other
 template <int U>
@@ -1240,6 +1253,7 @@ static bool launch_cast_and_classify_u(const void* src, const int64_t* strides, 
                             (uint32_t)std::min<int64_t>(std::max(tuning().cast_wait_us.load(std::memory_order_relaxed), 0), 1000000) * 100u};
     const dim3 g((unsigned)grid + classify_grid);
     if (kind == 2) hipLaunchKernelGGL((cast_rows_and_mask_classify_kernel<U, 2>), g, dim3(256), 0, stream, a, (unsigned)grid, mk, x);
+    else if (kind == 3) hipLaunchKernelGGL((cast_rows_and_mask_classify_kernel<U, 3>), g, dim3(256), 0, stream, a, (unsigned)grid, mk, x);
     else if (kind == 1) hipLaunchKernelGGL((cast_rows_and_mask_classify_kernel<U, 1>), g, dim3(256), 0, stream, a, (unsigned)grid, mk, x);
     else hipLaunchKernelGGL((cast_rows_and_mask_classify_kernel<U, 0>), g, dim3(256), 0, stream, a, (unsigned)grid, mk, x);
     return true;
@@ -1250,10 +1264,12 @@ static inline size_t up256(uint64_t n) { return (size_t)((n + 255) & ~255ull); }
 // bytes behind the pack area of an additive mask's scratch block: bf16 masks -- the dense fp16 copy [Bm, Hm, Sq or 1, Skv]; fp32 masks -- that copy, the
 // wave-tiles' exactness bytes, the verdict word (a 256-byte block of its own) and the 128-row route's tile flags (mask_flags_bytes); 0 for fp16 masks
 size_t mask_copy_bytes(const FwdParams& p) {
-    if (p.mask_kind != MK_BF16 && p.mask_kind != MK_F32) return 0;
-    const uint64_t Bm = p.ms[0] ? p.B : 1, Hm = p.ms[1] ? p.H : 1, Sm = p.ms[2] ? p.Sq : 1;
-    const size_t copy = up256(Bm * Hm * Sm * p.Skv * 2);
-    if (p.mask_kind == MK_BF16) return copy;
+    const bool ragged = p.Sq % 64 != 0 || p.Skv % 64 != 0;
+    if (p.mask_kind != MK_BF16 && p.mask_kind != MK_F32 && !(p.mask_kind == MK_F16 && ragged)) return 0;
+    // the copy is padded to whole 64 x 64 tiles (the attention kernel's mask DMA reads whole tiles)
+    const uint64_t Bm = p.ms[0] ? p.B : 1, Hm = p.ms[1] ? p.H : 1, Sm = p.ms[2] ? ((p.Sq + 63) / 64) * 64ull : 1, Skp = ((p.Skv + 63) / 64) * 64ull;
+    const size_t copy = up256(Bm * Hm * Sm * Skp * 2);
+    if (p.mask_kind != MK_F32) return copy;
     return copy + up256(Bm * Hm * ((p.Sq + 63) / 64) * ((p.Skv + 63) / 64)) + 256 + up256(mask_flags_bytes(p));
 }
 
@@ -1265,6 +1281,7 @@ size_t mask_copy_bytes(const FwdParams& p) {
 hipError_t launch_mask_classify(FwdParams& p, void* scratch, hipStream_t stream, const CastRowsCall* cast) {
     if (p.mask_kind != MK_F16 && p.mask_kind != MK_BF16 && p.mask_kind != MK_F32) return hipErrorInvalidValue;
     const bool bf = p.mask_kind == MK_BF16, f32 = p.mask_kind == MK_F32;
+    const bool f16c = p.mask_kind == MK_F16 && (p.Sq % 64 != 0 || p.Skv % 64 != 0);  // fp16 mask of a ragged shape: the padded copy
     const size_t pack_bytes = (mask_pack_bytes(p) + 255) & ~(size_t)255;
     MaskPackArgs a;
     uint32_t *list, *cnt, nqb;
@@ -1277,11 +1294,11 @@ hipError_t launch_mask_classify(FwdParams& p, void* scratch, hipStream_t stream,
     const uint8_t* xflag_f32 = nullptr;
     MaskClassifyExtra x = {nqb, nullptr, 0, 0, 0, nullptr, nullptr};
     unsigned cgrid = grid;
-    int kind = bf ? 1 : f32 ? 2 : 0;
+    int kind = bf ? 1 : f32 ? 2 : f16c ? 3 : 0;
     bool classify = true;  // (false: the mask is too large to be read twice -- every wave-tile is called mixed without looking)
-    if (bf || f32) {
+    if (bf || f32 || f16c) {
         _Float16* copy = (_Float16*)((char*)scratch + pack_bytes);
-        const int64_t Sm = p.ms[2] ? p.Sq : 1, cr = p.ms[2] ? (int64_t)p.Skv : 0, chd = Sm * p.Skv, cbt = (int64_t)a.Hm * chd;
+        const int64_t Skp = (int64_t)a.T * 64, Sm = p.ms[2] ? (int64_t)a.nrb64 * 64 : 1, cr = p.ms[2] ? Skp : 0, chd = Sm * Skp, cbt = (int64_t)a.Hm * chd;  // padded to whole tiles
         x.copy = copy; x.cb = cbt; x.ch = chd; x.cr = cr;
         {
             const uint64_t wgs = slabs * nqb * a.T;  // one workgroup per (256-row block, key tile)
@@ -1289,7 +1306,7 @@ hipError_t launch_mask_classify(FwdParams& p, void* scratch, hipStream_t stream,
             cgrid = (unsigned)wgs;
         }
         if (f32) {
-            uint8_t* xflag = (uint8_t*)copy + up256((uint64_t)a.Bm * a.Hm * Sm * p.Skv * 2);
+            uint8_t* xflag = (uint8_t*)copy + up256((uint64_t)a.Bm * a.Hm * Sm * Skp * 2);
             uint32_t* guard = (uint32_t*)(xflag + up256(a.total));
             // ... and the 128-row route's tile flags behind the verdict word: [Bm Hm][2 nrb64][T] bytes = the layout of launch_mask_flags (Sq is a multiple of 64 here)
             x.xflag = xflag; x.flags128 = (uint8_t*)guard + 256;
@@ -1298,6 +1315,7 @@ hipError_t launch_mask_classify(FwdParams& p, void* scratch, hipStream_t stream,
             p.guard_want = 0;
         }
         p.mask = copy;
+        p.mask_padded = 1;
         p.ms[0] = p.ms[0] ? cbt : 0; p.ms[1] = p.ms[1] ? chd : 0; p.ms[2] = cr; p.ms[3] = 1;
     } else if (!mask_flags_worthwhile(p)) {
         classify = false;
@@ -1331,9 +1349,11 @@ hipError_t launch_mask_classify(FwdParams& p, void* scratch, hipStream_t stream,
         } else if (f32) {
             hipLaunchKernelGGL(mask_classify_f32_kernel, dim3(cgrid), dim3(256), 0, stream, a, nqb, x.copy, x.cb, x.ch, x.cr, x.xflag, x.flags128);
         } else if (bf) {
-            hipLaunchKernelGGL(mask_classify_kernel<true>, dim3(cgrid), dim3(256), 0, stream, a, nqb, x.copy, x.cb, x.ch, x.cr);
+            hipLaunchKernelGGL(mask_classify_kernel<1>, dim3(cgrid), dim3(256), 0, stream, a, nqb, x.copy, x.cb, x.ch, x.cr);
+        } else if (f16c) {
+            hipLaunchKernelGGL(mask_classify_kernel<3>, dim3(cgrid), dim3(256), 0, stream, a, nqb, x.copy, x.cb, x.ch, x.cr);
         } else {
-            hipLaunchKernelGGL(mask_classify_kernel<false>, dim3(grid), dim3(256), 0, stream, a, nqb, (_Float16*)nullptr, 0, 0, 0);
+            hipLaunchKernelGGL(mask_classify_kernel<0>, dim3(grid), dim3(256), 0, stream, a, nqb, (_Float16*)nullptr, 0, 0, 0);
         }
     }
     a.done = true;  // (no bit image to pack)

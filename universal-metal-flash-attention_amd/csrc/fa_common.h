@@ -95,6 +95,7 @@ struct FwdParams {
     // *guard == guard_want.  NULL: not guarded.  No host read-back, the same under hipGraph replay whatever the mask holds then.
     const uint32_t* guard;
     uint32_t guard_want;
+    uint32_t mask_padded;  // 1: `mask` is the classification pass's fp16 copy, padded to whole 64 x 64 tiles with -inf (fa_aux.hip launch_mask_classify) -- a ragged Sq / Skv is fine
 };
 
 // Interleaved-pair rotary rotation of 8 consecutive elements (4 pairs) given the 8 table entries of their columns

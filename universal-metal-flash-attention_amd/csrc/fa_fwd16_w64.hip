@@ -348,13 +348,20 @@ bool fwd_w64_supported(const FwdParams& p) {
         // as for bool masks).  Everything else (bf16 / fp32 masks, ragged shapes, few blocks) stays on the 128-row kernel.
         if (tuning().no_w64_mask.load(std::memory_order_relaxed) || tuning().no_w64_bias.load(std::memory_order_relaxed) || !p.mask || (p.D != 128 && p.D != 64) || p.rope_cos || p.causal) return false;
         if (p.in_prec == P_BF16 && !p.pv16) return false;
-        if (p.Sq < 256 || p.Sq % 64 != 0 || p.Skv % 64 != 0 || ((p.Skv + 63) / 64) > 1024u) return false;
+        // whole 64 x 64 tiles -- or (end of round 6) a ragged shape through the classification pass's PADDED fp16 copy (fa_aux.hip mask_classify_body: keys past Skv and rows
+        // past Sq at -inf): Sq from 1024 on (a ragged last block wastes its empty waves, as for the unmasked kernels), Skv >= 64, the mask's 16-byte chunks entirely inside or
+        // outside it (Skv a multiple of 8 with 16-bit masks, of 4 with fp32 ones)
+        const bool ragged = !p.mask_padded && (p.Sq % 64 != 0 || p.Skv % 64 != 0);  // (a padded copy: the pass has dealt with the shape; its chunk rule was the SOURCE's)
+        if (p.Sq < 256 || p.Skv < 64 || (p.Sq % 64 != 0 && p.Sq < 1024) || ((p.Skv + 63) / 64) > 1024u) return false;
+        if (ragged && p.Skv % (p.mask_kind == MK_F32 ? 4u : 8u) != 0) return false;
+        // (a ragged fp16 mask is always read by the pass -- it needs the padded copy --, like every bf16 mask: up to 1 GiB of copy, below)
+        if (ragged && tuning().no_w64_ragged_mask.load(std::memory_order_relaxed)) return false;
         if (p.out_prec != P_FP32 && p.out_prec != p.in_prec) return false;
         const int64_t al = p.mask_kind == MK_F32 ? 3 : 7;  // 16-byte aligned rows: 4 fp32 / 8 fp16 elements
         if (p.ms[3] != 1 || ((uintptr_t)p.mask & 15) != 0 || (p.ms[0] & al) != 0 || (p.ms[1] & al) != 0 || (p.ms[2] & al) != 0) return false;
         if (p.mask_kind != MK_F32 && p.ms[2] != 0 && (uint64_t)p.ms[2] * 2 * 64 > 0x7fffffffull) return false;  // (a wave's 64 rows behind one 32-bit descriptor; fp32: the kernel reads the dense copy)
         // bf16 masks: the classification pass also writes the dense fp16 copy the kernel reads (bf16's significands fit fp16's; fa_aux.hip) -- up to 1 GiB of it
-        if (p.mask_kind != MK_F16 && mask_copy_bytes(p) > ((size_t)1 << 30)) return false;
+        if (mask_copy_bytes(p) > ((size_t)1 << 30)) return false;  // (0 for an fp16 mask on whole tiles)
         // fp32 masks (end of round 6): the same copy, taken by the bias kernel only when the pass finds it EXACT -- the verdict is a device word, so the call
         // enqueues the 128-row kernel on the caller's tensor as well and the kernels guard themselves (FwdParams::guard).  Only masks the pass may read
         // (its bytes within twice the call's tensor traffic: a dense per-head fp32 bias is read once, by the 128-row kernel, as before).

@@ -20,6 +20,7 @@ struct Tuning {
     std::atomic<float> sm_tau{6.0f};
     std::atomic<int> force_w64{0}, no_w64{0}, w64_grid{0}, w64_skew{0}, no_mask_flags{0}, bwd_exact{0}, bwd_dq{0}, bwd_persist{0},
         bwd_separate_delta{0}, no_split{0}, force_split{0}, no_dma{0}, bn64{0}, pv_fp16{0}, bwd_ds_store{0}, no_w64_mask{0}, ksplit{0}, no_pipe{0}, no_w64_mask_lazy{0}, no_w64_bias{0}, no_w64_f32_mask{0} /* fp32 additive masks stay on the 128-row kernel (no classification pass, no guarded pair of launches) */,
+        no_w64_ragged_mask{0} /* additive masks of ragged shapes (Sq or Skv not a multiple of 64) stay on the 128-row kernel */,
         mask_pass_ratio{0} /* lab: the constant of mask_flags_worthwhile (float masks are read by a pre-pass when their bytes stay within this many times the call's Q + K + V + O bytes); 0 = the rule's own */,
         f32_mask_ratio{0} /* ... lab: > 0 = the pair is taken for fp32 masks of up to this many times the call's Q + K + V + O bytes, in place of mask_flags_worthwhile's rule */,
         cast_two_pass{0} /* V cast pre-pass: amax and cast as two launches whatever the slab size (tests) */, bwd_ds_lab{0} /* lab, timing only: BwdParams::ds_lab */,
