@@ -139,8 +139,13 @@ def test_w64_additive_mask_routing_and_what_stays_on_the_128_row_kernel(umfa_opt
     umfa_torch.attention_forward(q, k, v, mask=m16, causal=True, out_dtype=torch.float32)
     assert "bias" not in umfa_torch.last_kernel()
     wide = torch.zeros(1, 1, S, S + 4, device="cuda", dtype=torch.float16)
-    umfa_torch.attention_forward(q, k, v, mask=wide[..., 4:], out_dtype=torch.float32)  # rows start 8 bytes off a 16-byte boundary
-    assert "bias" not in umfa_torch.last_kernel()
+    wide[..., 4:] = m16
+    ou = umfa_torch.attention_forward(q, k, v, mask=wide[..., 4:], out_dtype=torch.float32)  # rows start 8 bytes off a 16-byte boundary: the kernel cannot DMA them in place ...
+    assert "bias" in umfa_torch.last_kernel()  # ... so (end of round 6) the pass reads them element by element into its padded copy; before: the 128-row kernel
+    assert torch.equal(ou, o["f16"])
+    with umfa_torch.options(no_w64_ragged_mask=1):
+        umfa_torch.attention_forward(q, k, v, mask=wide[..., 4:], out_dtype=torch.float32)
+        assert "bias" not in umfa_torch.last_kernel()
     umfa_torch.attention_forward(q[:, :, :1000], k, v, mask=m16[:, :, :1000], out_dtype=torch.float32)  # Sq not a multiple of 64
     assert "bias" not in umfa_torch.last_kernel()
 
@@ -273,7 +278,7 @@ def test_bf16_mask_with_finfo_min_is_minus_inf_on_both_routes(D, umfa_opts):
     assert bool((o3[de] == 0).all()) and bool(torch.isneginf(lse3.view(B, H, S)[de]).all())
 
 
-RAGGED = [(1, 3, 1288, 776), (2, 2, 1024, 1000), (1, 6, 1096, 2056), (2, 1, 2000, 72)]
+RAGGED = [(1, 3, 1288, 776), (2, 2, 1024, 1001), (1, 6, 1096, 2056), (2, 1, 2001, 75)]  # (Skv 1001, 75: rows that are not 16-byte aligned -- the pass reads them element by element)
 
 
 @pytest.mark.parametrize("kind", ["rel_pos", "random", "blockdiag_inf", "padding_row_broadcast", "empty_rows_and_blocks", "all_zero"])
@@ -281,7 +286,7 @@ RAGGED = [(1, 3, 1288, 776), (2, 2, 1024, 1000), (1, 6, 1096, 2056), (2, 1, 2000
 @pytest.mark.parametrize("shape,grid", [(RAGGED[0], 0), (RAGGED[1], 3), (RAGGED[2], 0), (RAGGED[3], 4)])
 @pytest.mark.parametrize("D", [128, 64])
 def test_w64_additive_mask_ragged_shapes_vs_oracle(kind, dt, mdt, shape, grid, D, umfa_opts):
-    """(end of round 6) Sq from 1024 on and Skv that are not multiples of 64 -- Skv a multiple of 8 (16-bit masks; fp32: of 4): the classification pass writes the fp16 copy
+    """(end of round 6) Sq from 1024 on and Skv that are not multiples of 64 (any Skv >= 64): the classification pass writes the fp16 copy
     PADDED to whole 64 x 64 tiles, keys past Skv and rows past Sq at -inf, and the bias kernel runs on that (fp32 masks: as one of the guarded pair).  Against the oracle with
     the mask, against the 128-row kernel (option no_w64_ragged_mask), repeatable; rows that see nothing give O = 0 / LSE = -inf."""
     import umfa_torch
@@ -320,12 +325,13 @@ def test_w64_additive_mask_ragged_shapes_vs_oracle(kind, dt, mdt, shape, grid, D
 
 
 def test_w64_additive_mask_ragged_routing(umfa_opts):
-    """which ragged shapes take the bias kernels by default: Sq >= 1024, Skv >= 64 and a multiple of 8 (fp32 masks: 4), a block per CU; the rest -- and the option -- the 128-row kernel"""
+    """which ragged shapes take the bias kernels by default: Sq >= 1024, Skv >= 64 (any Skv: rows that are not 16-byte aligned are read element by element), a block per CU; the
+    rest -- and the option -- the 128-row kernel"""
     import umfa_torch
     torch.manual_seed(5)
     B, H, D = 1, 72, 128
     for (Sq, Skv, mdt, want) in [(1000, 1000, torch.float16, False), (1096, 1000, torch.float16, True), (1096, 1000, torch.bfloat16, True), (1096, 1004, torch.float32, True),
-                                 (1096, 1004, torch.float16, False), (1096, 1001, torch.float32, False), (1096, 56, torch.float16, False)]:
+                                 (1096, 1004, torch.float16, True), (1096, 1001, torch.float32, True), (1097, 1001, torch.bfloat16, True), (1096, 56, torch.float16, False)]:
         q = torch.randn(B, H, Sq, D, device="cuda", dtype=torch.bfloat16)
         k, v = (torch.randn(B, H, Skv, D, device="cuda", dtype=torch.bfloat16) for _ in range(2))
         i = torch.arange(Sq, device="cuda")[:, None]

@@ -182,8 +182,9 @@ def test_fp32_mask_routing_conditions(umfa_opts):
     umfa_torch.attention_forward(q, k, v, mask=bias, causal=True, out_dtype=torch.float32)
     assert " | " not in umfa_torch.last_kernel()
     wide = torch.zeros(1, 1, S, S + 2, device="cuda", dtype=torch.float32)
-    umfa_torch.attention_forward(q, k, v, mask=wide[..., 2:], out_dtype=torch.float32)  # rows start 8 bytes off a 16-byte boundary
-    assert " | " not in umfa_torch.last_kernel()
+    wide[..., 2:] = bias
+    ou = umfa_torch.attention_forward(q, k, v, mask=wide[..., 2:], out_dtype=torch.float32)  # rows start 8 bytes off a 16-byte boundary: read element by element by the pass
+    assert " | " in umfa_torch.last_kernel() and torch.equal(ou, o)
     umfa_torch.attention_forward(q[:, :, :1000], k, v, mask=bias[:, :, :1000], out_dtype=torch.float32)  # Sq not a multiple of 64
     assert " | " not in umfa_torch.last_kernel()
     per_head = bias.expand(1, H, S, S).contiguous()  # 302 MB of mask against 2 x 94 MB of tensors: read once, by the 128-row kernel

@@ -9,7 +9,7 @@ import umfa_torch
 from bench_mask_f32 import graph_us
 
 out = open(sys.argv[1], "w") if len(sys.argv) > 1 else None
-for (B, H, S, D) in [(1, 24, 4000, 128), (1, 24, 4104, 128), (2, 16, 3000, 64), (4, 16, 2040, 128), (1, 16, 8000, 128), (8, 8, 1500 // 4 * 4, 128)]:
+for (B, H, S, D) in [(1, 24, 4000, 128), (1, 24, 4097, 128), (2, 16, 3001, 64), (4, 16, 2040, 128), (8, 8, 1500, 128), (4, 16, 1111, 128)]:
     q, k, v = (torch.randn(B, H, S, D, device="cuda", dtype=torch.bfloat16) for _ in range(3))
     o = torch.empty(B, H, S, D, device="cuda", dtype=torch.float32)
     i = torch.arange(S, device="cuda")

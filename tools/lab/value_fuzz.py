@@ -1183,9 +1183,9 @@ def run_w64_mask_case(seed):
     Sq = 64 * rng.choice([4, 5, 8, 12, 16, 20])
     Skv = 64 * rng.choice([1, 2, 4, 7, 8, 11, 16, 22]) if not quant else rng.choice([64, 200, 512, 777, 1024, 1400])
     if not quant and rng.random() < 0.3:
-        # (end of round 6) ragged shapes on the additive-mask kernels: the pass writes a copy padded to whole tiles; Skv a multiple of 8 (fp32 masks would do with 4)
+        # (end of round 6) ragged shapes on the additive-mask kernels: the pass writes a copy padded to whole tiles; any Skv (rows that are not 16-byte aligned: element by element)
         Sq = rng.choice([1024, 1032, 1096, 1100, 1279, 1288])
-        Skv = 8 * rng.choice([8, 9, 15, 16, 33, 97, 125, 128, 200, 257])
+        Skv = rng.choice([64, 72, 77, 120, 129, 264, 776, 1000, 1001, 1031, 1600, 2056])
     if quant:
         Sq = rng.choice([256, 512, 1024, 1280])
     D = 128 if quant else rng.choice([128, 128, 64])

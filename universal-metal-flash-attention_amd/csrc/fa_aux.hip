@@ -1064,7 +1064,17 @@ __device__ __forceinline__ void mask_classify_body(const MaskPackArgs& p, uint32
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const bool in = live && (!COPY || (key0 < p.Skv && (p.ms[2] == 0 || row0 + 8u * (uint32_t)i < p.Sq)));
-        w[i] = in ? *(const u32x4_t*)(base + (int64_t)(8 * i) * p.ms[2] * 2) : u32x4_t{NINF2, NINF2, NINF2, NINF2};
+        if (!COPY || p.vec16) {
+            w[i] = in ? *(const u32x4_t*)(base + (int64_t)(8 * i) * p.ms[2] * 2) : u32x4_t{NINF2, NINF2, NINF2, NINF2};
+        } else {
+            // rows that are not 16-byte aligned, or an Skv that is not a multiple of 8 (any length, any view): element by element, each key checked against Skv
+            const uint16_t* e = (const uint16_t*)(base + (int64_t)(8 * i) * p.ms[2] * 2);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t lo = (in && key0 + 2u * j < p.Skv) ? e[2 * j] : (NINF2 & 0xffffu), hi = (in && key0 + 2u * j + 1u < p.Skv) ? e[2 * j + 1] : (NINF2 & 0xffffu);
+                w[i][j] = lo | (hi << 16);
+            }
+        }
     }
     if constexpr (BF16) {
 #pragma unroll
@@ -1150,7 +1160,13 @@ __device__ __forceinline__ void mask_classify_f32_body(const MaskPackArgs& p, ui
 #pragma unroll
     for (int i = 0; i < 16; ++i) {  // (ragged shapes: chunks outside the mask -- keys past Skv, rows past Sq -- count and are copied as -inf; see mask_classify_body)
         const bool in = live && key0 < p.Skv && (p.ms[2] == 0 || row0 + 4u * (uint32_t)i < p.Sq);
-        w[i] = in ? *(const u32x4_t*)(base + (int64_t)(4 * i) * p.ms[2] * 4) : u32x4_t{0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u};
+        if (p.vec16) {
+            w[i] = in ? *(const u32x4_t*)(base + (int64_t)(4 * i) * p.ms[2] * 4) : u32x4_t{0xff800000u, 0xff800000u, 0xff800000u, 0xff800000u};
+        } else {  // (unaligned rows / an Skv that is not a multiple of 4: element by element)
+            const uint32_t* e = (const uint32_t*)(base + (int64_t)(4 * i) * p.ms[2] * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[i][j] = (in && key0 + (uint32_t)j < p.Skv) ? e[j] : 0xff800000u;
+        }
     }
     // the 128-row route's tile flags (FwdParams::mask_flags: per 32-row block and 64-key tile, from the fp32 VALUES as mask_flags_kernel reads them) come from
     // the same read: rows 0 ... 31 of the tile are loads 0 ... 7, rows 32 ... 63 loads 8 ... 15.
@@ -1263,9 +1279,21 @@ static inline size_t up256(uint64_t n) { return (size_t)((n + 255) & ~255ull); }
 
 // bytes behind the pack area of an additive mask's scratch block: bf16 masks -- the dense fp16 copy [Bm, Hm, Sq or 1, Skv]; fp32 masks -- that copy, the
 // wave-tiles' exactness bytes, the verdict word (a 256-byte block of its own) and the 128-row route's tile flags (mask_flags_bytes); 0 for fp16 masks
+// 16-byte chunks of the mask's rows are aligned and entirely inside or outside the mask (the classification passes' vector loads; the bias kernels' DMA of an fp16 mask in place)
+static bool mask_rows_vector(const FwdParams& p) {
+    const int64_t chunk = p.mask_kind == MK_F32 ? 4 : 8;
+    return p.ms[3] == 1 && ((uintptr_t)p.mask & 15) == 0 && (p.ms[0] % chunk) == 0 && (p.ms[1] % chunk) == 0 && (p.ms[2] % chunk) == 0 && (p.Skv % chunk) == 0;
+}
+// does the bias route read a COPY of this additive mask (written by the classification pass, fp16, padded to whole tiles)?  bf16 / fp32: always; fp16: when the attention kernel's
+// DMA cannot read the caller's tensor in place -- a ragged shape, unaligned rows
+bool mask_needs_copy(const FwdParams& p) {
+    if (p.mask_kind == MK_BF16 || p.mask_kind == MK_F32) return true;
+    if (p.mask_kind != MK_F16 || p.mask_padded) return false;
+    return p.Sq % 64 != 0 || p.Skv % 64 != 0 || !mask_rows_vector(p);
+}
+
 size_t mask_copy_bytes(const FwdParams& p) {
-    const bool ragged = p.Sq % 64 != 0 || p.Skv % 64 != 0;
-    if (p.mask_kind != MK_BF16 && p.mask_kind != MK_F32 && !(p.mask_kind == MK_F16 && ragged)) return 0;
+    if (!mask_needs_copy(p)) return 0;
     // the copy is padded to whole 64 x 64 tiles (the attention kernel's mask DMA reads whole tiles)
     const uint64_t Bm = p.ms[0] ? p.B : 1, Hm = p.ms[1] ? p.H : 1, Sm = p.ms[2] ? ((p.Sq + 63) / 64) * 64ull : 1, Skp = ((p.Skv + 63) / 64) * 64ull;
     const size_t copy = up256(Bm * Hm * Sm * Skp * 2);
@@ -1281,7 +1309,8 @@ size_t mask_copy_bytes(const FwdParams& p) {
 hipError_t launch_mask_classify(FwdParams& p, void* scratch, hipStream_t stream, const CastRowsCall* cast) {
     if (p.mask_kind != MK_F16 && p.mask_kind != MK_BF16 && p.mask_kind != MK_F32) return hipErrorInvalidValue;
     const bool bf = p.mask_kind == MK_BF16, f32 = p.mask_kind == MK_F32;
-    const bool f16c = p.mask_kind == MK_F16 && (p.Sq % 64 != 0 || p.Skv % 64 != 0);  // fp16 mask of a ragged shape: the padded copy
+    const bool f16c = p.mask_kind == MK_F16 && mask_needs_copy(p);  // fp16 mask of a ragged shape / with unaligned rows: the padded copy
+    const bool vec_rows = mask_rows_vector(p);
     const size_t pack_bytes = (mask_pack_bytes(p) + 255) & ~(size_t)255;
     MaskPackArgs a;
     uint32_t *list, *cnt, nqb;
@@ -1290,6 +1319,7 @@ hipError_t launch_mask_classify(FwdParams& p, void* scratch, hipStream_t stream,
     if (bf || f32) p.mask_kind = MK_F16;  // (the layout of the pack area does not depend on the kind; mask_pack_prepare takes bool / fp16)
     if (hipError_t e = mask_pack_prepare(p, scratch, a, list, cnt, nqb, slabs); e != hipSuccess) { p.mask_kind = kind_in; return e; }
     p.mk_bits = nullptr;
+    a.vec16 = vec_rows;  // (for the classification bodies: vector loads of the source rows)
     const unsigned grid = (unsigned)((a.total + 3) / 4);
     const uint8_t* xflag_f32 = nullptr;
     MaskClassifyExtra x = {nqb, nullptr, 0, 0, 0, nullptr, nullptr};

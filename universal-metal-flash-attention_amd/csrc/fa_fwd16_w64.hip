@@ -353,12 +353,17 @@ bool fwd_w64_supported(const FwdParams& p) {
         // outside it (Skv a multiple of 8 with 16-bit masks, of 4 with fp32 ones)
         const bool ragged = !p.mask_padded && (p.Sq % 64 != 0 || p.Skv % 64 != 0);  // (a padded copy: the pass has dealt with the shape; its chunk rule was the SOURCE's)
         if (p.Sq < 256 || p.Skv < 64 || (p.Sq % 64 != 0 && p.Sq < 1024) || ((p.Skv + 63) / 64) > 1024u) return false;
-        if (ragged && p.Skv % (p.mask_kind == MK_F32 ? 4u : 8u) != 0) return false;
+        // (any Skv, any row alignment since the very end of the round: the pass reads such rows element by element)
         // (a ragged fp16 mask is always read by the pass -- it needs the padded copy --, like every bf16 mask: up to 1 GiB of copy, below)
         if (ragged && tuning().no_w64_ragged_mask.load(std::memory_order_relaxed)) return false;
         if (p.out_prec != P_FP32 && p.out_prec != p.in_prec) return false;
-        const int64_t al = p.mask_kind == MK_F32 ? 3 : 7;  // 16-byte aligned rows: 4 fp32 / 8 fp16 elements
-        if (p.ms[3] != 1 || ((uintptr_t)p.mask & 15) != 0 || (p.ms[0] & al) != 0 || (p.ms[1] & al) != 0 || (p.ms[2] & al) != 0) return false;
+        // contiguous keys; an fp16 mask the kernel reads IN PLACE needs 16-byte aligned rows (mask_needs_copy says when it is not read in place: the copy is aligned by construction)
+        if (p.ms[3] != 1) return false;
+        if (!mask_needs_copy(p)) {
+            if (((uintptr_t)p.mask & 15) != 0 || (p.ms[0] & 7) != 0 || (p.ms[1] & 7) != 0 || (p.ms[2] & 7) != 0) return false;
+        } else if (tuning().no_w64_ragged_mask.load(std::memory_order_relaxed) && p.mask_kind == MK_F16) {
+            return false;  // (the option keeps fp16 masks that would need the copy on the 128-row kernel)
+        }
         if (p.mask_kind != MK_F32 && p.ms[2] != 0 && (uint64_t)p.ms[2] * 2 * 64 > 0x7fffffffull) return false;  // (a wave's 64 rows behind one 32-bit descriptor; fp32: the kernel reads the dense copy)
         // bf16 masks: the classification pass also writes the dense fp16 copy the kernel reads (bf16's significands fit fp16's; fa_aux.hip) -- up to 1 GiB of it
         if (mask_copy_bytes(p) > ((size_t)1 << 30)) return false;  // (0 for an fp16 mask on whole tiles)

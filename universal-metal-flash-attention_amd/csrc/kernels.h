@@ -189,6 +189,7 @@ struct CastRowsCall {
     uint32_t* hdr;
 };
 hipError_t launch_mask_classify(FwdParams& p, void* scratch, hipStream_t stream, const CastRowsCall* cast = nullptr);
+bool mask_needs_copy(const FwdParams& p);  // the bias route reads the classification pass's padded fp16 copy of this additive mask (bf16 / fp32: always; fp16: ragged shape or unaligned rows)
 size_t mask_copy_bytes(const FwdParams& p);  // bf16 / fp32 masks: the dense fp16 copy the kernel reads (fp32: + exactness bytes, verdict word, 128-row tile flags), behind the pack area (256-byte aligned) in the same scratch block
 // the V cast pass and the mask re-pack as ONE launch (the pack's workgroups behind the cast's), then the list kernel
 hipError_t launch_cast_rows_and_mask_pack(const void* src, const int64_t* strides, void* dst, uint32_t B, uint32_t H, uint32_t S, uint32_t D,
