@@ -463,6 +463,8 @@ const char* umfa_last_kernel_name(mfa_context_t context);
  *                        (0 / -inf masks, masks built in 16 bits and widened, dyadic biases: yes).  Both routes are enqueued -- the bias kernel on the copy,
  *                        the 128-row kernel on the caller's tensor -- and each checks the verdict word first: exactly one runs, with the numbers that kernel
  *                        gives an fp16 (resp. fp32) mask.  umfa_last_kernel_name then names both.  "1": the 128-row kernel alone, as before.
+ *   "no_mask_realign"    "0" (default) | "1": the 128-row kernel reads a mask whose rows are not aligned to four elements (an odd sequence length, a view, strided keys) in
+ *                        place, per score, as before the realigned copy (rows padded to four keys with -inf / false: 1.5-2.4 x on dense biases)
  *   "no_w64_ragged_mask" "0" (default) | "1": additive masks whose Sq or Skv is not a multiple of 64 stay on the 128-row kernel (by default Sq >= 1024 and any Skv >= 64 run on the
  *                        bias kernels through a copy padded to whole tiles with -inf; so do fp16 masks whose rows are not 16-byte aligned)
  *   "mask_pass_ratio" "f32_mask_ratio"   "0" (default: the rule's own constants): lab -- the size rule of the mask pre-passes: a float mask is read by a pre-pass (tile

@@ -345,3 +345,57 @@ def test_finfo_min_masks_on_the_128_row_kernel_are_minus_inf_and_their_tiles_are
     s_ = torch.matmul(q.double(), k.double().transpose(-1, -2)) * D ** -0.5 + m_inf.double()
     ref = torch.matmul(torch.nan_to_num(torch.softmax(s_, dim=-1), nan=0.0), v.double())
     assert float((o.double() - ref).abs().max() / ref.abs().max()) < 2.0 ** -11 * 1.5
+
+
+@pytest.mark.parametrize("mdt", [torch.bool, torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("shape,causal", [((2, 3, 333, 777), False), ((1, 4, 500, 1001), False), ((2, 2, 257, 513), True), ((1, 2, 64, 130), False)])
+@pytest.mark.parametrize("form", ["dense", "row_broadcast", "offset_view", "strided_keys"])
+def test_128_row_kernel_reads_a_realigned_copy_of_masks_with_unaligned_rows(mdt, dt, shape, causal, form, umfa_opts):
+    """fa_fwd16 reads a mask four keys at a time only when rows are contiguous and aligned to four elements and Skv is a multiple of four; anything else -- an odd length -- it
+    read per score with scalar loads (B4 H16 S1111, fp16 bias: 464 us against ~130 at S 1112).  Since the very end of round 6 the runtime hands it a copy with rows padded to four
+    keys (fa_aux.hip launch_mask_realign; -inf / false in the pad).  Same answers as the in-place read (option no_mask_realign) and as the oracle; rows that see nothing: O = 0."""
+    import umfa_torch
+    B, H, Sq, Skv = shape
+    D = 128
+    torch.manual_seed(Sq + Skv)
+    q = torch.randn(B, H, Sq, D, device="cuda", dtype=dt)
+    k = torch.randn(B, H, Skv, D, device="cuda", dtype=dt)
+    v = torch.randn(B, H, Skv, D, device="cuda", dtype=dt)
+    g = torch.Generator(device="cuda").manual_seed(Skv)
+    rows = 1 if form == "row_broadcast" else Sq
+    keep = torch.rand(B, 1, rows, Skv, device="cuda", generator=g) < 0.7
+    keep[..., 1] = True
+    if rows > 1:
+        keep[:, :, 5::11] = False  # rows that see nothing
+    if mdt == torch.bool:
+        m = keep
+    else:
+        m = (torch.randn(B, 1, rows, Skv, device="cuda", generator=g)).to(torch.float16).float().masked_fill(~keep, NEG).to(mdt)
+    if form == "offset_view":  # rows start one element into a wider tensor
+        wide = torch.zeros(B, 1, rows, Skv + 3, device="cuda", dtype=m.dtype)
+        wide[..., 1:Skv + 1] = m
+        m = wide[..., 1:Skv + 1]
+    elif form == "strided_keys":  # every other element of a tensor twice as wide
+        wide = torch.zeros(B, 1, rows, 2 * Skv, device="cuda", dtype=m.dtype)
+        wide[..., ::2] = m
+        m = wide[..., ::2]
+    o, lse = umfa_torch.attention_forward(q, k, v, mask=m, causal=causal, out_dtype=torch.float32, return_lse=True)
+    assert umfa_torch.last_kernel().startswith("fa_fwd16<"), umfa_torch.last_kernel()
+    with umfa_torch.options(no_mask_realign=1):
+        o1, lse1 = umfa_torch.attention_forward(q, k, v, mask=m, causal=causal, out_dtype=torch.float32, return_lse=True)
+    # (two code paths of the kernel -- four keys per load against one: the same terms, another contraction of score x scale + term; each is checked against fp64 below)
+    assert float((o - o1).abs().max()) <= 2.0 ** -9 * float(o1.abs().max()) + 1e-30
+    madd = torch.zeros(B, 1, rows, Skv, device="cuda", dtype=torch.float64).masked_fill(~m, NEG) if mdt == torch.bool else m.double()
+    s_ = torch.matmul(q.double(), k.double().transpose(-1, -2)) * D ** -0.5 + madd
+    if causal:
+        s_ = s_.masked_fill(~torch.ones(Sq, Skv, dtype=torch.bool, device="cuda").tril(), NEG)
+    rl = torch.logsumexp(s_, dim=-1)
+    ref = torch.matmul(torch.nan_to_num(torch.softmax(s_, dim=-1), nan=0.0), v.double())
+    assert torch.isfinite(o).all()
+    assert float((o.double() - ref).abs().max() / ref.abs().max()) < 2.0 ** -11 * 1.5
+    dead = ~torch.isfinite(rl)
+    lg = lse.view(B, H, Sq)
+    if bool(dead.any()):
+        assert bool(torch.isneginf(lg[dead]).all()) and bool((o[dead.unsqueeze(-1).expand_as(o)] == 0).all())
+    assert float((lg.double() - rl)[~dead].abs().max()) < 2e-2

@@ -903,6 +903,71 @@ hipError_t launch_mask_flags(FwdParams& p, uint8_t* flags, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// ---- realigned copy of a mask for the 128-row kernel (very end of round 6).  fa_fwd16 reads a mask four keys at a time (one dword / 8 / 16 bytes per register group) when
+// rows are contiguous and aligned to four elements and Skv is a multiple of four; ANY other mask -- an odd sequence length is enough -- it reads per score with scalar loads:
+// B4 H16 S1111 with an fp16 bias 464 us where S 1112 takes ~130.  One pass copies such a mask into rows padded to a multiple of four keys (pad: -inf / false), dense over its
+// own batch / head / row dimensions (broadcast ones stay broadcast); FwdParams::mask_padded tells the kernel that a group starting below Skv may be read whole.
+template <int ES>
+__global__ __launch_bounds__(256) void mask_realign_kernel(const void* __restrict__ src, int64_t s0, int64_t s1, int64_t s2, int64_t s3, uint32_t Hm, uint32_t Sm, uint32_t Skv,
+                                                           uint32_t G, void* __restrict__ dst, uint64_t total, uint32_t pad) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (t >= total) return;
+    const uint32_t g = (uint32_t)(t % G);
+    const uint64_t r = t / G;
+    const uint32_t row = (uint32_t)(r % Sm);
+    const uint64_t slab = r / Sm;
+    const uint32_t hm = (uint32_t)(slab % Hm), bm = (uint32_t)(slab / Hm);
+    const int64_t base = (int64_t)bm * s0 + (int64_t)hm * s1 + (int64_t)row * s2;
+    uint32_t v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint32_t key = 4 * g + e;
+        if (key < Skv) {
+            const int64_t at = base + (int64_t)key * s3;
+            v[e] = ES == 1 ? ((const uint8_t*)src)[at] : ES == 2 ? ((const uint16_t*)src)[at] : ((const uint32_t*)src)[at];
+        } else {
+            v[e] = pad;
+        }
+    }
+    const uint64_t o = (r * G + g) * 4;
+    if constexpr (ES == 1) ((uint32_t*)dst)[o / 4] = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+    else if constexpr (ES == 2) ((uint2*)dst)[o / 4] = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+    else ((uint4*)dst)[o / 4] = make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+static int mask_elem_bytes(int kind) { return kind == MK_BOOL ? 1 : kind == MK_F32 ? 4 : 2; }
+// fa_fwd16 would read this mask per score (the negation of its `mvec`)
+bool mask_rows_scalar(const FwdParams& p) {
+    if (p.mask_kind != MK_BOOL && p.mask_kind != MK_F16 && p.mask_kind != MK_BF16 && p.mask_kind != MK_F32) return false;
+    if (!p.mask || p.mask_padded) return false;
+    const int es = mask_elem_bytes(p.mask_kind);
+    return !(p.ms[3] == 1 && (p.Skv & 3) == 0 && ((p.ms[0] | p.ms[1] | p.ms[2]) & 3) == 0 && ((uintptr_t)p.mask & (uintptr_t)(4 * es - 1)) == 0);
+}
+size_t mask_realign_bytes(const FwdParams& p) {
+    const uint64_t Bm = p.ms[0] ? p.B : 1, Hm = p.ms[1] ? p.H : 1, Sm = p.ms[2] ? p.Sq : 1, G = (p.Skv + 3) / 4;
+    return (size_t)(Bm * Hm * Sm * G * 4 * mask_elem_bytes(p.mask_kind));
+}
+// dst: 16-byte aligned, mask_realign_bytes(p) bytes.  On return p describes the copy.
+hipError_t launch_mask_realign(FwdParams& p, void* dst, hipStream_t stream) {
+    if (!mask_rows_scalar(p) || !dst || ((uintptr_t)dst & 15)) return hipErrorInvalidValue;
+    const uint32_t Bm = p.ms[0] ? p.B : 1, Hm = p.ms[1] ? p.H : 1, Sm = p.ms[2] ? p.Sq : 1, G = (p.Skv + 3) / 4;
+    const uint64_t total = (uint64_t)Bm * Hm * Sm * G;
+    if (total == 0 || (total + 255) / 256 > 0x7fffffffull) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((total + 255) / 256));
+    const uint32_t pad = p.mask_kind == MK_BOOL ? 0u : p.mask_kind == MK_F16 ? 0xfc00u : p.mask_kind == MK_BF16 ? 0xff80u : 0xff800000u;
+    if (p.mask_kind == MK_BOOL) hipLaunchKernelGGL(mask_realign_kernel<1>, grid, dim3(256), 0, stream, p.mask, p.ms[0], p.ms[1], p.ms[2], p.ms[3], Hm, Sm, p.Skv, G, dst, total, pad);
+    else if (p.mask_kind == MK_F32) hipLaunchKernelGGL(mask_realign_kernel<4>, grid, dim3(256), 0, stream, p.mask, p.ms[0], p.ms[1], p.ms[2], p.ms[3], Hm, Sm, p.Skv, G, dst, total, pad);
+    else hipLaunchKernelGGL(mask_realign_kernel<2>, grid, dim3(256), 0, stream, p.mask, p.ms[0], p.ms[1], p.ms[2], p.ms[3], Hm, Sm, p.Skv, G, dst, total, pad);
+    const int64_t row = 4ll * G;
+    p.mask = dst;
+    p.ms[0] = p.ms[0] ? (int64_t)Hm * Sm * row : 0;
+    p.ms[1] = p.ms[1] ? (int64_t)Sm * row : 0;
+    p.ms[2] = p.ms[2] ? row : 0;
+    p.ms[3] = 1;
+    p.mask_padded = 1;
+    return hipGetLastError();
+}
+
 // Is the pre-pass worth its read of the mask?  Byte masks: always (at worst +15 % for a dense random per-head mask, 2-4x
 // for banded / padded ones).  Additive float masks are usually dense biases with nothing to skip: only when the distinct
 // mask bytes stay below twice the Q + K + V + O traffic (e.g. one [Sq, Skv] bias shared by the heads).

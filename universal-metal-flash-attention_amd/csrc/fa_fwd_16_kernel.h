@@ -506,7 +506,9 @@ __device__ __forceinline__ int fa_fwd16_body(PRM& p, const int vexp_in, const in
     // masks with contiguous rows aligned to four elements: the four keys a lane owns per register group are ONE load
     // (dword for bytes, 8 bytes for fp16 / bf16, 16 bytes for fp32)
     const int mes = p.mask_kind == MK_BOOL ? 1 : (p.mask_kind == MK_F32 ? 4 : 2);
-    const bool mvec = HAS_MASK && p.mask_kind != MK_WINDOW && p.ms[3] == 1 && (p.Skv & 3) == 0 && ((p.ms[0] | p.ms[1] | p.ms[2]) & 3) == 0 &&
+    // (mask_padded: the runtime's realigned copy of a mask whose rows were not -- rows padded to a multiple of four keys, so a group that starts below Skv may be read whole;
+    // the edge tile's per-key compare masks what lies past Skv, as always)
+    const bool mvec = HAS_MASK && p.mask_kind != MK_WINDOW && p.ms[3] == 1 && ((p.Skv & 3) == 0 || p.mask_padded) && ((p.ms[0] | p.ms[1] | p.ms[2]) & 3) == 0 &&
                       ((uintptr_t)p.mask & (uintptr_t)(4 * mes - 1)) == 0;
     // mask tile flags (FwdParams::mask_flags): this wave's 32 rows are one flag row; 64 tiles per register
     const uint8_t* mf_row = nullptr;

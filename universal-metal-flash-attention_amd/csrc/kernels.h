@@ -20,6 +20,7 @@ struct Tuning {
     std::atomic<float> sm_tau{6.0f};
     std::atomic<int> force_w64{0}, no_w64{0}, w64_grid{0}, w64_skew{0}, no_mask_flags{0}, bwd_exact{0}, bwd_dq{0}, bwd_persist{0},
         bwd_separate_delta{0}, no_split{0}, force_split{0}, no_dma{0}, bn64{0}, pv_fp16{0}, bwd_ds_store{0}, no_w64_mask{0}, ksplit{0}, no_pipe{0}, no_w64_mask_lazy{0}, no_w64_bias{0}, no_w64_f32_mask{0} /* fp32 additive masks stay on the 128-row kernel (no classification pass, no guarded pair of launches) */,
+        no_mask_realign{0} /* the 128-row kernel reads a mask whose rows are not aligned to four elements in place (per score), as before the realigned copy */,
         no_w64_ragged_mask{0} /* additive masks of ragged shapes (Sq or Skv not a multiple of 64) stay on the 128-row kernel */,
         mask_pass_ratio{0} /* lab: the constant of mask_flags_worthwhile (float masks are read by a pre-pass when their bytes stay within this many times the call's Q + K + V + O bytes); 0 = the rule's own */,
         f32_mask_ratio{0} /* ... lab: > 0 = the pair is taken for fp32 masks of up to this many times the call's Q + K + V + O bytes, in place of mask_flags_worthwhile's rule */,
@@ -198,6 +199,10 @@ hipError_t launch_cast_rows_and_mask_pack(const void* src, const int64_t* stride
 size_t mask_flags_bytes(const FwdParams& p);
 void mask_flags_describe(FwdParams& p, const uint8_t* flags);  // fills FwdParams::mf_* / mask_flags for a flag array written elsewhere (fp32 masks: by the classification pass)
 bool mask_flags_worthwhile(const FwdParams& p);
+// a mask fa_fwd16 would read per score with scalar loads (rows not aligned to four elements, an Skv that is not a multiple of four, strided keys) -> a copy with rows padded to four keys
+bool mask_rows_scalar(const FwdParams& p);
+size_t mask_realign_bytes(const FwdParams& p);
+hipError_t launch_mask_realign(FwdParams& p, void* dst, hipStream_t stream);
 hipError_t launch_mask_flags(FwdParams& p, uint8_t* flags, hipStream_t stream);
 
 }  // namespace umfa

@@ -212,6 +212,19 @@ hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p,
                 pp.part_buf = (float*)(buf + sc.split_cnt_bytes);
             }
         }
+        // a mask the kernel would read per score with scalar loads (rows not aligned to four elements: any odd sequence length): one pass makes an aligned copy, rows padded
+        // to four keys (fa_aux.hip launch_mask_realign), in the block the tile flags sit in front of.  Not under a guard (the pair's second route reads the caller's tensor), not
+        // when the block cannot be had (capture without a warm-up: in place, as before)
+        void* realign_blk = nullptr;
+        if (!guard && mask_rows_scalar(pp) && !tuning().no_mask_realign.load(std::memory_order_relaxed)) {
+            const size_t fb = (mask_flags_bytes(pp) + 255) & ~(size_t)255, rbytes = mask_realign_bytes(pp);
+            if (rbytes <= ((size_t)1 << 30)) {
+                if (void* blk = sc.mflags.ensure(fb + rbytes, stream)) {
+                    if ((e = launch_mask_realign(pp, (char*)blk + fb, stream)) != hipSuccess) return e;
+                    realign_blk = blk;
+                }
+            }
+        }
         if (guard) {
             // (guarded: the classification pass of the first route wrote this route's tile flags on its way through the mask -- behind the verdict word)
             if (!tuning().no_mask_flags.load(std::memory_order_relaxed)) mask_flags_describe(pp, (const uint8_t*)guard + 256);
@@ -219,7 +232,7 @@ hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p,
             // tile early-exit for masks: one pre-pass over the distinct mask elements classifies every (32 rows x 64
             // keys) tile; fully masked tiles are skipped, fully open ones run without reading the mask.  Results are
             // bit-identical with and without the flags, so a pool that may not grow (capture) just runs without them.
-            void* fl = sc.mflags.ensure(mask_flags_bytes(pp), stream);
+            void* fl = realign_blk ? realign_blk : sc.mflags.ensure(mask_flags_bytes(pp), stream);
             if (fl && launch_mask_flags(pp, (uint8_t*)fl, stream) != hipSuccess) pp.mask_flags = nullptr;
         }
         e = launch_fwd_16(pp, stream, &name);
