@@ -399,3 +399,34 @@ def test_128_row_kernel_reads_a_realigned_copy_of_masks_with_unaligned_rows(mdt,
     if bool(dead.any()):
         assert bool(torch.isneginf(lg[dead]).all()) and bool((o[dead.unsqueeze(-1).expand_as(o)] == 0).all())
     assert float((lg.double() - rl)[~dead].abs().max()) < 2e-2
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("D", [128, 64])
+def test_fp32_mask_of_an_odd_length_that_fp16_does_not_hold(dt, D, umfa_opts):
+    """the guarded pair's second route on a mask with unaligned rows (Skv 1001): the 128-row kernel reads a realigned copy made by a launch that checks the same verdict
+    (it read the caller's tensor per score before: S 4097, fp32 bias, ~1850 us).  Same answer as the 128-row kernel alone, and the oracle's."""
+    import umfa_torch
+    umfa_opts(force_w64=1)
+    B, H, Sq, Skv = 2, 2, 1031, 1001
+    torch.manual_seed(D)
+    q = torch.randn(B, H, Sq, D, device="cuda", dtype=dt)
+    k = torch.randn(B, H, Skv, D, device="cuda", dtype=dt)
+    v = torch.randn(B, H, Skv, D, device="cuda", dtype=dt)
+    i = torch.arange(Sq, device="cuda")[:, None]
+    j = torch.arange(Skv, device="cuda")[None, :]
+    m = (-(i - j).abs().float() / 3.0)[None, None].contiguous()
+    m[0, 0, 7::13] = NEG
+    out = torch.full((B, H, Sq, D), float("nan"), device="cuda", dtype=torch.float32)
+    o, lse = umfa_torch.attention_forward(q, k, v, mask=m, out=out, return_lse=True)
+    assert " | " in umfa_torch.last_kernel(), umfa_torch.last_kernel()
+    with umfa_torch.options(no_w64_f32_mask=1):
+        o1 = umfa_torch.attention_forward(q, k, v, mask=m, out_dtype=torch.float32)
+        assert umfa_torch.last_kernel().startswith("fa_fwd16<")
+    assert float((o - o1).abs().max()) <= 2.0 ** -12 * float(o1.abs().max())
+    s_ = torch.matmul(q.double(), k.double().transpose(-1, -2)) * D ** -0.5 + m.double()
+    rl = torch.logsumexp(s_, dim=-1)
+    ref = torch.matmul(torch.nan_to_num(torch.softmax(s_, dim=-1), nan=0.0), v.double())
+    assert torch.isfinite(o).all() and float((o.double() - ref).abs().max() / ref.abs().max()) < 2.0 ** -11 * 1.5
+    dead = ~torch.isfinite(rl)
+    assert bool(dead.any()) and bool((o[dead.unsqueeze(-1).expand_as(o)] == 0).all())

@@ -909,9 +909,10 @@ hipError_t launch_mask_flags(FwdParams& p, uint8_t* flags, hipStream_t stream) {
 // own batch / head / row dimensions (broadcast ones stay broadcast); FwdParams::mask_padded tells the kernel that a group starting below Skv may be read whole.
 template <int ES>
 __global__ __launch_bounds__(256) void mask_realign_kernel(const void* __restrict__ src, int64_t s0, int64_t s1, int64_t s2, int64_t s3, uint32_t Hm, uint32_t Sm, uint32_t Skv,
-                                                           uint32_t G, void* __restrict__ dst, uint64_t total, uint32_t pad) {
+                                                           uint32_t G, void* __restrict__ dst, uint64_t total, uint32_t pad, const uint32_t* guard, uint32_t guard_want) {
     const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (t >= total) return;
+    if (guard != nullptr && *guard != guard_want) return;  // (FwdParams::guard: the copy serves the 128-row route of an fp32 mask's guarded pair -- not taken: nothing to do)
     const uint32_t g = (uint32_t)(t % G);
     const uint64_t r = t / G;
     const uint32_t row = (uint32_t)(r % Sm);
@@ -955,9 +956,9 @@ hipError_t launch_mask_realign(FwdParams& p, void* dst, hipStream_t stream) {
     if (total == 0 || (total + 255) / 256 > 0x7fffffffull) return hipErrorInvalidValue;
     const dim3 grid((unsigned)((total + 255) / 256));
     const uint32_t pad = p.mask_kind == MK_BOOL ? 0u : p.mask_kind == MK_F16 ? 0xfc00u : p.mask_kind == MK_BF16 ? 0xff80u : 0xff800000u;
-    if (p.mask_kind == MK_BOOL) hipLaunchKernelGGL(mask_realign_kernel<1>, grid, dim3(256), 0, stream, p.mask, p.ms[0], p.ms[1], p.ms[2], p.ms[3], Hm, Sm, p.Skv, G, dst, total, pad);
-    else if (p.mask_kind == MK_F32) hipLaunchKernelGGL(mask_realign_kernel<4>, grid, dim3(256), 0, stream, p.mask, p.ms[0], p.ms[1], p.ms[2], p.ms[3], Hm, Sm, p.Skv, G, dst, total, pad);
-    else hipLaunchKernelGGL(mask_realign_kernel<2>, grid, dim3(256), 0, stream, p.mask, p.ms[0], p.ms[1], p.ms[2], p.ms[3], Hm, Sm, p.Skv, G, dst, total, pad);
+    if (p.mask_kind == MK_BOOL) hipLaunchKernelGGL(mask_realign_kernel<1>, grid, dim3(256), 0, stream, p.mask, p.ms[0], p.ms[1], p.ms[2], p.ms[3], Hm, Sm, p.Skv, G, dst, total, pad, p.guard, p.guard_want);
+    else if (p.mask_kind == MK_F32) hipLaunchKernelGGL(mask_realign_kernel<4>, grid, dim3(256), 0, stream, p.mask, p.ms[0], p.ms[1], p.ms[2], p.ms[3], Hm, Sm, p.Skv, G, dst, total, pad, p.guard, p.guard_want);
+    else hipLaunchKernelGGL(mask_realign_kernel<2>, grid, dim3(256), 0, stream, p.mask, p.ms[0], p.ms[1], p.ms[2], p.ms[3], Hm, Sm, p.Skv, G, dst, total, pad, p.guard, p.guard_want);
     const int64_t row = 4ll * G;
     p.mask = dst;
     p.ms[0] = p.ms[0] ? (int64_t)Hm * Sm * row : 0;
@@ -1363,7 +1364,8 @@ size_t mask_copy_bytes(const FwdParams& p) {
     const uint64_t Bm = p.ms[0] ? p.B : 1, Hm = p.ms[1] ? p.H : 1, Sm = p.ms[2] ? ((p.Sq + 63) / 64) * 64ull : 1, Skp = ((p.Skv + 63) / 64) * 64ull;
     const size_t copy = up256(Bm * Hm * Sm * Skp * 2);
     if (p.mask_kind != MK_F32) return copy;
-    return copy + up256(Bm * Hm * ((p.Sq + 63) / 64) * ((p.Skv + 63) / 64)) + 256 + up256(mask_flags_bytes(p));
+    // (... and, when the 128-row kernel would read the caller's tensor per score -- rows not aligned to four elements --, its realigned copy: launch_mask_realign under the guard)
+    return copy + up256(Bm * Hm * ((p.Sq + 63) / 64) * ((p.Skv + 63) / 64)) + 256 + up256(mask_flags_bytes(p)) + (mask_rows_scalar(p) ? up256(mask_realign_bytes(p)) : 0);
 }
 
 // scratch = [the pack layout of mask_pack_bytes | the fp16 copy of a bf16 mask].  On return p describes what the attention kernel reads: an fp16 mask.

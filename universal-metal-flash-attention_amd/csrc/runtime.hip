@@ -226,8 +226,14 @@ hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p,
             }
         }
         if (guard) {
-            // (guarded: the classification pass of the first route wrote this route's tile flags on its way through the mask -- behind the verdict word)
-            if (!tuning().no_mask_flags.load(std::memory_order_relaxed)) mask_flags_describe(pp, (const uint8_t*)guard + 256);
+            // (guarded: the classification pass of the first route wrote this route's tile flags on its way through the mask -- behind the verdict word; behind them,
+            // the realigned copy of a mask with unaligned rows, made by a launch that checks the same verdict)
+            uint8_t* const fl = (uint8_t*)const_cast<uint32_t*>(guard) + 256;
+            const size_t fb = (mask_flags_bytes(pp) + 255) & ~(size_t)255;
+            if (mask_rows_scalar(pp) && !tuning().no_mask_realign.load(std::memory_order_relaxed) && mask_realign_bytes(pp) <= ((size_t)1 << 30)) {
+                if ((e = launch_mask_realign(pp, fl + fb, stream)) != hipSuccess) return e;
+            }
+            if (!tuning().no_mask_flags.load(std::memory_order_relaxed)) mask_flags_describe(pp, fl);
         } else if (pp.mask_kind != MK_NONE && !tuning().no_mask_flags.load(std::memory_order_relaxed) && mask_flags_worthwhile(pp)) {
             // tile early-exit for masks: one pre-pass over the distinct mask elements classifies every (32 rows x 64
             // keys) tile; fully masked tiles are skipped, fully open ones run without reading the mask.  Results are
