@@ -636,6 +636,10 @@ def run_rank(args) -> None:
             extra["int8"] = bench_int8(torch, umfa_torch, event_ms, med, graph_ms)
         except Exception as exc:  # noqa: BLE001  reported, never silently replaced by another path
             extra["int8"] = {"error": repr(exc)}
+        try:
+            extra["host_boundary"] = bench_host_boundary(B, H, S, D)
+        except Exception as exc:  # noqa: BLE001
+            extra["host_boundary"] = {"error": repr(exc)}
         if not args.no_parity:
             try:
                 extra["parity"] = measure_parity(torch, umfa_torch)
@@ -760,6 +764,48 @@ def bench_int8(torch, umfa_torch, event_ms, med, graph_ms):
     except Exception:  # noqa: BLE001
         pass
     return res
+
+
+def bench_host_boundary(B, H, S, D, calls: int = 5):
+    """The PCIe-inclusive rate of the reference ABI's SYNCHRONOUS entry: mfa_attention_forward on buffers that wrap HOST memory
+    (mfa_buffer_from_ptr, MFABridge.swift:1074-1433) -- every call uploads Q, K, V, runs the same kernels as the headline and
+    downloads the fp32 O.  Reported beside `value`, never as it: `value` starts with the operands resident in HBM."""
+    import time
+
+    import numpy as np
+    import umfa
+    from umfa import core as _core
+
+    rng = np.random.default_rng(1234)
+    # bf16 bit patterns of N(0,1) (the top halves of fp32 words)
+    q, k, v = ((rng.standard_normal((B, H, S, D), dtype=np.float32).view(np.uint32) >> 16).astype(np.uint16) for _ in range(3))
+    o = np.zeros((B, H, S, D), np.float32)
+    with umfa.MFAContext() as ctx:
+        bufs = [_core.MFABuffer(ctx, a) for a in (q, k, v, o)]
+        try:
+            def call():
+                _core._check_error(_core._lib.mfa_attention_forward(
+                    ctx.handle, *(x.handle for x in bufs), B, S, S, H, D, float(D) ** -0.5, False, _core.MFA_PRECISION_BF16,
+                    _core.MFA_PRECISION_BF16, _core.MFA_PRECISION_FP32, False, False, False, False, None, 0, None, None, 0,
+                    _core.MFA_MASK_TYPE_NONE, _core.MFA_MASK_SCALAR_BYTE))
+            call()  # (pools, pinned staging)
+            ts = []
+            for _ in range(calls):
+                t0 = time.perf_counter()
+                call()
+                ts.append(time.perf_counter() - t0)
+            kern = ctx.last_kernel
+        finally:
+            for x in bufs:
+                x.close()
+    ts.sort()
+    t = ts[len(ts) // 2]
+    moved = q.nbytes * 3 + o.nbytes
+    return {"entry": "mfa_attention_forward on mfa_buffer_from_ptr(host) buffers: upload Q, K, V + kernels + download fp32 O, synchronous",
+            "ms_per_call": round(t * 1e3, 3), "tflops_pcie_inclusive": round(4.0 * B * H * S * S * D / t / 1e12, 2),
+            "host_bytes_moved": int(moved), "host_link_gbps": round(moved / t / 1e9, 2), "calls": calls, "kernel": kern,
+            "finite": bool(np.isfinite(o).all() and np.abs(o).max() > 0),
+            "note": "not `value`: the headline starts with the operands resident in HBM (the in-stream entry, as the reference's torch extension calls it)"}
 
 
 def measure_parity(torch, umfa_torch):

@@ -30,7 +30,9 @@ struct Tuning {
         cast_wait_us{100} /* V cast pre-pass: how long a workgroup waits for its slab's other workgroups before it reads the slab's amax itself */,
         decode_ks{0} /* decode form of the 128-row kernel (<= 32 query rows: four key quarters per tile): 0 = where it applies, 2 = never */,
         cbal{0} /* balanced causal pairs on the 128-row kernel: 0 = where the plan wants them, 1 = wherever they exist, 2 = never */,
-        cbal_delta{-1} /* ... key tiles by which a pair's folding part is shorter than half; < 0 = the plan's choice */;
+        cbal_delta{-1} /* ... key tiles by which a pair's folding part is shorter than half; < 0 = the plan's choice */,
+        sync_chunks{0} /* synchronous forward on host-wrapping buffers: head chunks whose upload / kernels / download overlap on side streams; 0 = by size, 1 = never (one upload, the kernels, one download on the null stream), n = n chunks */,
+        sync_chunked_calls{0} /* read-out for tests: synchronous forwards that took the chunked form */;
 };
 Tuning& tuning();
 bool set_tuning(const char* name, const char* value);  // false: unknown name or value out of range

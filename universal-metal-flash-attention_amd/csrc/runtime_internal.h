@@ -220,6 +220,9 @@ struct Context {
     uint32_t magic = 0x4d464143;  // 'MFAC'
     int device = 0;               // device of the synchronous entries (current when the singleton was created)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // the chunked synchronous forward (runtime.hip forward_sync): three non-blocking side streams and an event pair per chunk, made on first use
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> chunk_ev;
     double last_latency = 0.0;
     const char* last_kernel = "none";
     void* scratch = nullptr;  // host-mask staging of the synchronous entries (used under mu, then synchronised)
@@ -368,6 +371,7 @@ struct Buffer {
     void* dev = nullptr;    // what kernels read/write
     size_t bytes = 0;       // 0 = unknown (mfa_buffer_from_mtl_buffer with size 0)
     bool owns_host = false, owns_dev = false;
+    bool registered = false;  // wrap_pointer pinned the caller's host range (hipHostRegister): copies on it are asynchronous
     std::vector<int64_t> shape, strides;
 
     hipError_t upload(hipStream_t s) const {
@@ -377,6 +381,14 @@ struct Buffer {
     hipError_t download(hipStream_t s) const {
         if (!host || host == dev || bytes == 0) return hipSuccess;
         return hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s);
+    }
+    bool mirrored() const { return host && dev && host != dev && bytes > 0; }
+    // a byte range of the mirror (the chunked synchronous forward)
+    hipError_t upload_range(size_t off, size_t n, hipStream_t s) const {
+        return hipMemcpyAsync((char*)dev + off, (const char*)host + off, n, hipMemcpyHostToDevice, s);
+    }
+    hipError_t download_range(size_t off, size_t n, hipStream_t s) const {
+        return hipMemcpyAsync((char*)host + off, (const char*)dev + off, n, hipMemcpyDeviceToHost, s);
     }
     // bytes == 0: size unknown (device wraps only); a host pointer of unknown size has no HBM mirror (dev == NULL)
     bool fits(size_t need) const { return dev != nullptr && (bytes == 0 || need <= bytes); }
@@ -415,6 +427,13 @@ inline mfa_error_t wrap_pointer(void* ptr, size_t bytes, const int64_t* shape, c
                 return MFA_ERROR_MEMORY_ALLOCATION;
             }
             b->owns_dev = true;
+            // Large host ranges are pinned for as long as the wrapper lives: copies on pinned memory are asynchronous, which is what lets the
+            // synchronous forward overlap a chunk's upload with another's download (runtime.hip forward_sync).  Small ranges (< 1 MiB: they may
+            // share pages with other allocations of the caller's) and ranges the runtime refuses (already registered, ...) stay pageable.
+            if (bytes >= (1u << 20) && umfa::tuning().sync_chunks.load(std::memory_order_relaxed) != 1) {
+                if (hipHostRegister(ptr, bytes, hipHostRegisterDefault) == hipSuccess) b->registered = true;
+                else (void)hipGetLastError();
+            }
         }
     }
     if (shape && strides && ndim) {
