@@ -473,11 +473,12 @@ const char* umfa_last_kernel_name(mfa_context_t context);
  *                        a positive value replaces the constant (f32_mask_ratio: for the fp32 route alone).  profiles/r6/mask_pass_rule_probe.jsonl,
  *                        f32_mask_size_rule_probe.jsonl: what larger values buy and cost
  *   "cbal_delta"         "-1" (default: the plan's choice) | "0" ... "16": key tiles by which the folding workgroup's share is shorter (tests, A/B)
- *   "sync_chunks"        "0" (default: by size -- about 14 MB over the link per chunk, at most 8, calls of >= 32 MB) | "1": off | "2" ... "16": the synchronous forwards (mfa_attention_forward, _with_lse) on buffers that wrap HOST
- *                        memory send the heads through in chunks on side streams -- one chunk's download under the next ones' uploads, the
- *                        kernels under both (FLUX shape: 2.49 -> see profiles/r6/host_boundary_probe.jsonl) -- when the call moves >= 16 MB, the operands
- *                        are dense row-major, a mask has no batch / head extent, and mfa_buffer_from_ptr could pin the ranges (hipHostRegister at wrap
- *                        time, >= 1 MiB each, released by mfa_destroy_buffer; read at WRAP time as well: "1" also turns the pinning off)
+ *   "sync_chunks"        "0" (default: by size -- about 14 MB over the link per chunk, at most 8, calls of >= 64 MB) | "1": off | "2" ... "16" (calls of >= 16 MB):
+ *                        the synchronous entries (mfa_attention_forward, _with_lse, mfa_attention_backward) on buffers that wrap HOST memory send the
+ *                        heads through in chunks on side streams -- one chunk's download under the next ones' uploads, the kernels under both (FLUX
+ *                        shape forward, host to host: 2.49 -> 1.89 ms, profiles/r6/host_boundary_probe.jsonl) -- when the operands are dense row-major,
+ *                        a mask has no batch / head extent, and the host ranges (>= 1 MiB each) could be pinned: hipHostRegister by the first call
+ *                        that wants chunks, for as long as the wrapper lives (mfa_destroy_buffer releases it)
  *   "sync_chunked_calls" read-out: how many synchronous forwards took the chunked form (tests)
  * Returns MFA_ERROR_INVALID_ARGS for an unknown name or a value out of range.  Thread-safe; affects later launches. */
 mfa_error_t umfa_set_option(mfa_context_t context, const char* name, const char* value);

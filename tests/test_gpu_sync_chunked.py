@@ -47,7 +47,7 @@ PLANS = [
     (8, 3, 1024, 128, 6),    # B >= chunks: whole batches, 2 at a time
     (7, 3, 1024, 128, 3),    # ... 3 + 3 + 1 batches
     (1, 16, 2048, 64, 16),   # head_dim 64, one head per chunk
-    (1, 24, 2048, 128, 0),   # the default: by size (63 MB over the link -> 4 chunks of 6 heads)
+    (1, 32, 2048, 128, 0),   # the default: by size (84 MB over the link -> 6 chunks)
 ]
 
 
@@ -125,3 +125,34 @@ def test_small_calls_and_transposed_operands_stay_on_one_upload(ctx):
     n0 = int(umfa_torch.get_option("sync_chunked_calls"))
     o = umfa.flash_attention_forward(ctx, q, k, v, input_precision="bf16", intermediate_precision="bf16", layout="bhsd")
     assert int(umfa_torch.get_option("sync_chunked_calls")) == n0 and np.isfinite(o).all()
+
+
+@pytest.mark.parametrize("B,H,S,D,chunks,causal", [(1, 12, 1024, 128, 6, False), (1, 24, 1024, 128, 0, True), (4, 3, 1024, 64, 4, True), (2, 5, 1024, 128, 6, False)])
+def test_backward_chunked_equals_one_upload_and_oracle(ctx, B, H, S, D, chunks, causal):
+    """mfa_attention_backward (MFABridge.swift:3171-3282) on host arrays: the same chunk plan, gradients against the one-upload form and the oracle."""
+    import umfa
+    import umfa_torch
+    from oracle import oracle
+    rng = np.random.default_rng(100 + B + H + chunks)
+    q, k, v, do = (bf16_bits(rng, (B, H, S, D)) for _ in range(4))
+    with umfa_torch.options(sync_chunks=1):
+        o, lse = umfa.flash_attention_forward(ctx, q, k, v, input_precision="bf16", intermediate_precision="bf16", layout="bhsd", causal=causal, return_lse=True)
+
+    def bwd(c):
+        n0 = int(umfa_torch.get_option("sync_chunked_calls"))
+        with umfa_torch.options(sync_chunks=c):
+            g = umfa.attention_backward(ctx, do, q, k, v, o, lse, causal=causal, input_precision="bf16", layout="bhsd")
+        assert int(umfa_torch.get_option("sync_chunked_calls")) - n0 == int(c != 1), c
+        assert ctx.last_kernel.startswith("fa_bwd16"), ctx.last_kernel
+        return g
+
+    g1, gc = bwd(1), bwd(chunks)
+    for a, b_, name in zip(gc, g1, ("dq", "dk", "dv", "D")):
+        assert np.isfinite(a).all()
+        assert rel(a, b_) < 2e-3, (name, rel(a, b_))  # (the 16-bit engine's own repeatability across launch shapes; BWD16_TOL against the oracle is 8e-3)
+    for b, h in ((0, 0), (B - 1, H - 1)):
+        sl = (slice(b, b + 1), slice(h, h + 1))
+        ro, rl = oracle.sdpa_forward(q[sl], k[sl], v[sl], causal=causal, return_lse=True)
+        rdq, rdk, rdv, _ = oracle.sdpa_backward(do[sl], q[sl], k[sl], v[sl], ro, rl, causal=causal)
+        for a, r, name in ((gc[0][sl], rdq, "dq"), (gc[1][sl], rdk, "dk"), (gc[2][sl], rdv, "dv")):
+            assert rel(a, r) < 8e-3, (name, rel(a, r))  # tests/test_gpu_configs.py BWD16_TOL

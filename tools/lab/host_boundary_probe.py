@@ -34,7 +34,22 @@ for shape in ((1, 24, 4096, 128), (1, 32, 8192, 128), (2, 16, 2048, 64), (8, 8, 
                     umfa.flash_attention_forward(ctx, q, k, v, input_precision="bf16", intermediate_precision="bf16", layout="bhsd")
                     ts.append(time.perf_counter() - t0)
                 wrap.setdefault(c, []).append(round(sorted(ts)[2] * 1e3, 3))
+    # ... and mfa_attention_backward on host arrays (wrapper time: ten arrays wrapped per call)
+    bw = {}
+    if shape[2] <= 4096:
+        do = q.copy()
+        with umfa.MFAContext() as ctx:
+            o, lse = umfa.flash_attention_forward(ctx, q, k, v, input_precision="bf16", intermediate_precision="bf16", layout="bhsd", return_lse=True)
+            for c in (1, 0, 1, 0):
+                with umfa_torch.options(sync_chunks=c):
+                    ts = []
+                    for _ in range(5):
+                        t0 = time.perf_counter()
+                        umfa.attention_backward(ctx, do, q, k, v, o, lse, input_precision="bf16", layout="bhsd")
+                        ts.append(time.perf_counter() - t0)
+                    bw.setdefault(c, []).append(round(sorted(ts)[2] * 1e3, 3))
     moved = 5 * q.nbytes
     print(json.dumps({"shape": shape, "MB_over_the_link": round(moved / 1e6, 1),
                       "ms_per_call_by_sync_chunks": {str(c): sorted(v)[1] for c, v in ms.items()}, "all": {str(c): v for c, v in ms.items()},
-                      "python_wrapper_ms": {str(c): v for c, v in wrap.items()}}), flush=True)
+                      "python_wrapper_ms": {str(c): v for c, v in wrap.items()},
+                      "python_wrapper_backward_ms": {str(c): v for c, v in bw.items()}}), flush=True)

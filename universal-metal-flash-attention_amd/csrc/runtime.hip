@@ -252,47 +252,18 @@ hipError_t dispatch_forward(Context* ctx, StreamScratch& sc, const FwdParams& p,
     return e;
 }
 
-// The synchronous forward in head chunks (see forward_sync).  ctx->mu held, the context's device current; p holds the whole call (device mirrors,
-// dense strides).  A chunk is either whole batches or a head range of one batch, so the kernels' dense O / LSE indexing ((b H + h) Sq) holds with
-// the chunk's own B and H while the operand strides stay the whole tensors'.
+// The synchronous forward in head chunks (see forward_sync; the plan: runtime_internal.h plan_sync_chunks).  ctx->mu held, the context's device
+// current; p holds the whole call (device mirrors, dense strides): the operand strides stay the whole tensors'.
 mfa_error_t forward_sync_chunked(Context* ctx, Buffer* bq, Buffer* bk, Buffer* bv, Buffer* bo, Buffer* bl, const FwdParams& p, int inter, uint32_t want) {
-    struct Chunk { uint32_t b0, nb, h0, nh; };
-    std::vector<Chunk> chunks;
-    if (p.B >= want) {
-        const uint32_t per = (p.B + want - 1) / want;
-        for (uint32_t b = 0; b < p.B; b += per) chunks.push_back({b, std::min(per, p.B - b), 0, p.H});
-    } else {
-        const uint32_t pieces = std::min(p.H, (want + p.B - 1) / p.B), per = (p.H + pieces - 1) / pieces;
-        for (uint32_t b = 0; b < p.B; ++b)
-            for (uint32_t h = 0; h < p.H; h += per) chunks.push_back({b, 1, h, std::min(per, p.H - h)});
-    }
-    for (auto& s : ctx->side)
-        if (!s && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
-    while (ctx->chunk_ev.size() < 2 * chunks.size()) {
-        hipEvent_t e = nullptr;
-        if (hipEventCreate(&e) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
-        ctx->chunk_ev.push_back(e);
-    }
-    tuning().sync_chunked_calls.fetch_add(1, std::memory_order_relaxed);
-    // whatever the null stream holds (the mask's upload above) comes first
-    (void)hipEventRecord(ctx->ev0, nullptr);
-    for (auto s : ctx->side) (void)hipStreamWaitEvent(s, ctx->ev0, 0);
-    auto drain = [&]() {
-        hipError_t e = hipSuccess;
-        for (auto s : ctx->side) {
-            const hipError_t e2 = hipStreamSynchronize(s);
-            if (e == hipSuccess) e = e2;
-        }
-        return e;
-    };
+    const std::vector<SyncChunk> chunks = plan_sync_chunks(p.B, p.H, want);
+    if (!sync_chunks_begin(ctx, chunks.size())) return MFA_ERROR_EXECUTION_FAILED;
     const size_t eb = elem_bytes(p.in_prec);
     const size_t qslab = (size_t)p.Sq * p.D, kslab = (size_t)p.Skv * p.D;
-    hipError_t e = hipSuccess;
     mfa_error_t rc = MFA_SUCCESS;
     for (size_t c = 0; c < chunks.size() && rc == MFA_SUCCESS; ++c) {
-        const Chunk& ch = chunks[c];
+        const SyncChunk& ch = chunks[c];
         hipStream_t s = ctx->side[c % 3];
-        const size_t slab0 = (size_t)ch.b0 * p.H + ch.h0, nslab = (size_t)ch.nb * ch.nh;  // (nb > 1 only with nh == H: contiguous either way)
+        const size_t slab0 = (size_t)ch.b0 * p.H + ch.h0, nslab = (size_t)ch.nb * ch.nh;
         if (bq->upload_range(slab0 * qslab * eb, nslab * qslab * eb, s) != hipSuccess || bk->upload_range(slab0 * kslab * eb, nslab * kslab * eb, s) != hipSuccess ||
             bv->upload_range(slab0 * kslab * eb, nslab * kslab * eb, s) != hipSuccess) { rc = MFA_ERROR_EXECUTION_FAILED; break; }
         FwdParams pc = p;
@@ -303,22 +274,15 @@ mfa_error_t forward_sync_chunked(Context* ctx, Buffer* bq, Buffer* bk, Buffer* b
         pc.o = (char*)p.o + slab0 * qslab * 4;
         pc.lse = p.lse ? p.lse + slab0 * p.Sq : nullptr;
         (void)hipEventRecord(ctx->chunk_ev[2 * c], s);
-        e = dispatch_forward(ctx, ctx->pool(ctx->device, s), pc, inter, s);
+        const hipError_t e = dispatch_forward(ctx, ctx->pool(ctx->device, s), pc, inter, s);
         if (e != hipSuccess) { rc = rc_of(e); break; }
         (void)hipEventRecord(ctx->chunk_ev[2 * c + 1], s);
         if (bo->download_range(slab0 * qslab * 4, nslab * qslab * 4, s) != hipSuccess) { rc = MFA_ERROR_EXECUTION_FAILED; break; }
         if (bl && bl->mirrored() && bl->download_range(slab0 * p.Sq * 4, nslab * p.Sq * 4, s) != hipSuccess) { rc = MFA_ERROR_EXECUTION_FAILED; break; }
     }
-    e = drain();
+    const hipError_t e = sync_chunks_end(ctx, chunks.size(), rc == MFA_SUCCESS);
     if (rc != MFA_SUCCESS) return rc;
-    if (e != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
-    double sum = 0.0;  // kernel-only GPU time -> mfa_get_gpu_latency: the chunks' launches, not the copies they ran under
-    for (size_t c = 0; c < chunks.size(); ++c) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, ctx->chunk_ev[2 * c], ctx->chunk_ev[2 * c + 1]) == hipSuccess) sum += ms * 1e-3;
-    }
-    ctx->last_latency = sum;
-    return MFA_SUCCESS;
+    return e == hipSuccess ? MFA_SUCCESS : MFA_ERROR_EXECUTION_FAILED;
 }
 
 // Shared body of the synchronous dense forwards.
@@ -376,19 +340,13 @@ mfa_error_t forward_sync(mfa_context_t context, mfa_buffer_t q, mfa_buffer_t k, 
 
     // Host-wrapping buffers at sizes where the host link is the call (FLUX shape: 126 MB over the link, 2.3 ms, against 0.19 ms of kernels):
     // the heads go through in chunks on three side streams, so that one chunk's download runs under the next ones' uploads (the link is full
-    // duplex) and the kernels under both.  Dense row-major operands, pinned ranges (wrap_pointer), a mask only if it has no batch / head
+    // duplex) and the kernels under both.  Dense row-major operands, host ranges that could be pinned (pin_for_chunks), a mask only if it has no batch / head
     // extent; everything else takes the one-upload form below.  Same kernels, same numbers: a chunk is a launch of its own over whole heads.
     {
         const size_t moved = nq * eb + 2 * nkv * eb + nq * 4;
-        int want = tuning().sync_chunks.load(std::memory_order_relaxed);
-        // 0 = by size: about 14 MB over the link per chunk, at most 8, from 32 MB on (profiles/r6/host_boundary_probe.jsonl: below that the
-        // chunks' launches and copy set-ups cost what the overlap returns)
-        if (want == 0) want = moved >= (32u << 20) ? (int)std::min<size_t>(8, moved / (14u << 20)) : 1;
-        const bool dense = !tq && !tk && !tv && !to;
-        const bool pinned = bq->mirrored() && bk->mirrored() && bv->mirrored() && bo->mirrored() && bq->registered && bk->registered &&
-                            bv->registered && bo->registered;
-        if (want > 1 && dense && pinned && (uint64_t)B * H >= 2 && moved >= (16u << 20) && (!p.mask || (p.ms[0] == 0 && p.ms[1] == 0)))
-            return forward_sync_chunked(ctx, bq, bk, bv, bo, want_lse ? bl : nullptr, p, inter, (uint32_t)std::min(want, 16));
+        const int want = sync_chunk_count(moved);
+        if (want > 1 && !tq && !tk && !tv && !to && (uint64_t)B * H >= 2 && (!p.mask || (p.ms[0] == 0 && p.ms[1] == 0)) && pin_for_chunks({bq, bk, bv, bo}))
+            return forward_sync_chunked(ctx, bq, bk, bv, bo, want_lse ? bl : nullptr, p, inter, (uint32_t)want);
     }
     if (bq->upload(stream) != hipSuccess || bk->upload(stream) != hipSuccess || bv->upload(stream) != hipSuccess)
         return MFA_ERROR_EXECUTION_FAILED;

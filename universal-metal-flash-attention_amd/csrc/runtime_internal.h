@@ -2,10 +2,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <map>
 #include <mutex>
 #include <new>
@@ -427,13 +429,6 @@ inline mfa_error_t wrap_pointer(void* ptr, size_t bytes, const int64_t* shape, c
                 return MFA_ERROR_MEMORY_ALLOCATION;
             }
             b->owns_dev = true;
-            // Large host ranges are pinned for as long as the wrapper lives: copies on pinned memory are asynchronous, which is what lets the
-            // synchronous forward overlap a chunk's upload with another's download (runtime.hip forward_sync).  Small ranges (< 1 MiB: they may
-            // share pages with other allocations of the caller's) and ranges the runtime refuses (already registered, ...) stay pageable.
-            if (bytes >= (1u << 20) && umfa::tuning().sync_chunks.load(std::memory_order_relaxed) != 1) {
-                if (hipHostRegister(ptr, bytes, hipHostRegisterDefault) == hipSuccess) b->registered = true;
-                else (void)hipGetLastError();
-            }
         }
     }
     if (shape && strides && ndim) {
@@ -444,6 +439,79 @@ inline mfa_error_t wrap_pointer(void* ptr, size_t bytes, const int64_t* shape, c
     return MFA_SUCCESS;
 }
 
+
+// ---- the synchronous entries on host-wrapping buffers, in head chunks (runtime.hip forward_sync_chunked, runtime_train.hip) ----
+// A chunk is either whole batches or a head range of one batch: slabs [slab0, slab0 + nslab) of the dense [B, H, ., .] tensors are contiguous,
+// and the kernels' dense indexing ((b H + h) S) holds with the chunk's own B and H.
+struct SyncChunk {
+    uint32_t b0, nb, h0, nh;
+};
+inline std::vector<SyncChunk> plan_sync_chunks(uint32_t B, uint32_t H, uint32_t want) {
+    std::vector<SyncChunk> chunks;
+    if (B >= want) {
+        const uint32_t per = (B + want - 1) / want;
+        for (uint32_t b = 0; b < B; b += per) chunks.push_back({b, std::min(per, B - b), 0, H});
+    } else {
+        const uint32_t pieces = std::min(H, (want + B - 1) / B), per = (H + pieces - 1) / pieces;
+        for (uint32_t b = 0; b < B; ++b)
+            for (uint32_t h = 0; h < H; h += per) chunks.push_back({b, 1, h, std::min(per, H - h)});
+    }
+    return chunks;
+}
+// the option's chunk count for a call that moves `moved` bytes over the host link: 0 = by size -- about 14 MB per chunk, at most 8, from 64 MB
+// on (profiles/r6/host_boundary_probe.jsonl: at 42 MB the chunks' launches, copy set-ups and the pinning cost what the overlap returns); 1: one upload
+inline int sync_chunk_count(size_t moved) {
+    int want = umfa::tuning().sync_chunks.load(std::memory_order_relaxed);
+    if (want == 0) want = moved >= (64u << 20) ? (int)std::min<size_t>(8, moved / (14u << 20)) : 1;
+    return moved >= (16u << 20) ? std::min(want, 16) : 1;
+}
+// side streams + an event pair per chunk; ctx->mu held.  The side streams then wait for whatever the null stream holds.
+inline bool sync_chunks_begin(Context* ctx, size_t nchunks) {
+    for (auto& s : ctx->side)
+        if (!s && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return false;
+    while (ctx->chunk_ev.size() < 2 * nchunks) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return false;
+        ctx->chunk_ev.push_back(e);
+    }
+    umfa::tuning().sync_chunked_calls.fetch_add(1, std::memory_order_relaxed);
+    (void)hipEventRecord(ctx->ev0, nullptr);
+    for (auto s : ctx->side) (void)hipStreamWaitEvent(s, ctx->ev0, 0);
+    return true;
+}
+// drains the side streams; kernel-only GPU time of the chunks' launches (not of the copies they ran under) -> mfa_get_gpu_latency
+inline hipError_t sync_chunks_end(Context* ctx, size_t nchunks, bool ok) {
+    hipError_t e = hipSuccess;
+    for (auto s : ctx->side) {
+        const hipError_t e2 = hipStreamSynchronize(s);
+        if (e == hipSuccess) e = e2;
+    }
+    if (!ok || e != hipSuccess) return e;
+    double sum = 0.0;
+    for (size_t c = 0; c < nchunks; ++c) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->chunk_ev[2 * c], ctx->chunk_ev[2 * c + 1]) == hipSuccess) sum += ms * 1e-3;
+    }
+    ctx->last_latency = sum;
+    return hipSuccess;
+}
+// A chunked call needs every host range pinned (copies on pinned memory are asynchronous: that is what lets one chunk's download run under another's
+// upload).  Pinned here, by the first call that wants chunks -- not at wrap time: a wrapper that only ever serves small calls costs what it did --
+// and for as long as the wrapper lives (mfa_destroy_buffer releases it).  Ranges under 1 MiB (they may share pages with other allocations of the
+// caller's) and ranges the runtime refuses (registered by the caller already, ...) stay pageable, and the call takes the one-upload form.
+inline bool pin_for_chunks(std::initializer_list<Buffer*> bs) {
+    for (Buffer* b : bs)
+        if (!b->mirrored() || (!b->registered && b->bytes < (1u << 20))) return false;
+    for (Buffer* b : bs) {
+        if (b->registered) continue;
+        if (hipHostRegister(b->host, b->bytes, hipHostRegisterDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        b->registered = true;
+    }
+    return true;
+}
 
 // dense path: any precision value other than 0/1 means FP32 (gemmPrecision, MFABridge.swift:1453-1462)
 inline int dense_prec(int p) { return p == 0 ? umfa::P_FP16 : p == 1 ? umfa::P_BF16 : umfa::P_FP32; }

@@ -51,8 +51,6 @@ mfa_error_t mfa_attention_backward(mfa_context_t context, mfa_buffer_t dout, mfa
     if (nq == 0 || nkv == 0) return MFA_SUCCESS;
     if (D > 1024) return MFA_ERROR_INVALID_ARGS;  // like the forward: the reference callers' limit (metal_sdpa_backend.cpp:1078-1086)
 
-    for (Buffer* b : {bdo, bq, bk, bv, bo, bl})
-        if (b->upload(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
     BwdParams p;
     memset(&p, 0, sizeof(p));
     p.dout = bdo->dev; p.q = bq->dev; p.k = bk->dev; p.v = bv->dev;
@@ -61,10 +59,58 @@ mfa_error_t mfa_attention_backward(mfa_context_t context, mfa_buffer_t dout, mfa
     p.B = B; p.H = H; p.Sq = Sq; p.Skv = Skv; p.D = D;
     p.scale = softmax_scale; p.causal = causal ? 1 : 0;
     p.in_prec = prec; p.dout_prec = prec;
-    LatencyScope lat(ctx, stream);
     const char* name = "none";
     // 16-bit operands with 16-bit intermediates -> MFMA backward; everything else -> fp32-exact backward
     const bool lowp = dense_prec(intermediate_precision) != P_FP32 && !tuning().bwd_exact.load(std::memory_order_relaxed);
+    // Host-wrapping buffers where the host link is the call (FLUX shape: 302 MB over it): head chunks on side streams, as the synchronous forward
+    // (runtime.hip forward_sync_chunked) -- a chunk's gradients go down under the next ones' operands coming up.  The small per-row tensors (LSE in,
+    // D out) travel whole on the null stream, before and after.
+    {
+        const size_t moved = 2 * nq * eb + 2 * nkv * eb + nq * 4 + nq * 4 + 2 * nkv * 4;
+        const int want = sync_chunk_count(moved);
+        if (want > 1 && (uint64_t)B * H >= 2 && pin_for_chunks({bdo, bq, bk, bv, bo, bdq, bdk, bdv})) {
+            if (bl->upload(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+            const std::vector<SyncChunk> chunks = plan_sync_chunks(B, H, (uint32_t)want);
+            if (!sync_chunks_begin(ctx, chunks.size())) return MFA_ERROR_EXECUTION_FAILED;
+            const size_t qslab = (size_t)Sq * D, kslab = (size_t)Skv * D;
+            mfa_error_t rc = MFA_SUCCESS;
+            for (size_t c = 0; c < chunks.size(); ++c) {
+                const SyncChunk& ch = chunks[c];
+                hipStream_t s = ctx->side[c % 3];
+                const size_t slab0 = (size_t)ch.b0 * H + ch.h0, nslab = (size_t)ch.nb * ch.nh;
+                if (bdo->upload_range(slab0 * qslab * eb, nslab * qslab * eb, s) != hipSuccess || bq->upload_range(slab0 * qslab * eb, nslab * qslab * eb, s) != hipSuccess ||
+                    bk->upload_range(slab0 * kslab * eb, nslab * kslab * eb, s) != hipSuccess || bv->upload_range(slab0 * kslab * eb, nslab * kslab * eb, s) != hipSuccess ||
+                    bo->upload_range(slab0 * qslab * 4, nslab * qslab * 4, s) != hipSuccess) { rc = MFA_ERROR_EXECUTION_FAILED; break; }
+                BwdParams pc = p;
+                pc.B = ch.nb; pc.H = ch.nh;
+                pc.dout = (const char*)p.dout + slab0 * qslab * eb;
+                pc.q = (const char*)p.q + slab0 * qslab * eb;
+                pc.k = (const char*)p.k + slab0 * kslab * eb;
+                pc.v = (const char*)p.v + slab0 * kslab * eb;
+                pc.o = p.o + slab0 * qslab; pc.lse = p.lse + slab0 * Sq;
+                pc.dq = p.dq + slab0 * qslab; pc.dk = p.dk + slab0 * kslab; pc.dv = p.dv + slab0 * kslab; pc.dvec = p.dvec + slab0 * Sq;
+                const bool m16 = lowp && bwd_16_supported(pc);
+                if (m16) {
+                    pc.rowc = (float*)ctx->pool(ctx->device, s).rowc.ensure(2 * nslab * Sq * sizeof(float), s);
+                    if (!pc.rowc) { rc = MFA_ERROR_MEMORY_ALLOCATION; break; }
+                }
+                (void)hipEventRecord(ctx->chunk_ev[2 * c], s);
+                const hipError_t e = m16 ? launch_bwd_16(pc, s, &name) : launch_bwd(pc, s, &name);
+                ctx->last_kernel = name;
+                if (e != hipSuccess) { rc = e == hipErrorInvalidValue ? MFA_ERROR_INVALID_ARGS : MFA_ERROR_EXECUTION_FAILED; break; }
+                (void)hipEventRecord(ctx->chunk_ev[2 * c + 1], s);
+                if (bdq->download_range(slab0 * qslab * 4, nslab * qslab * 4, s) != hipSuccess || bdk->download_range(slab0 * kslab * 4, nslab * kslab * 4, s) != hipSuccess ||
+                    bdv->download_range(slab0 * kslab * 4, nslab * kslab * 4, s) != hipSuccess) { rc = MFA_ERROR_EXECUTION_FAILED; break; }
+            }
+            const hipError_t e = sync_chunks_end(ctx, chunks.size(), rc == MFA_SUCCESS);
+            if (rc != MFA_SUCCESS) return rc;
+            if (e != hipSuccess || bd->download(stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+            return MFA_SUCCESS;
+        }
+    }
+    for (Buffer* b : {bdo, bq, bk, bv, bo, bl})
+        if (b->upload(stream) != hipSuccess) return MFA_ERROR_EXECUTION_FAILED;
+    LatencyScope lat(ctx, stream);
     const bool mfma16 = lowp && bwd_16_supported(p);
     if (mfma16) {
         p.rowc = (float*)ctx->pool(ctx->device, stream).rowc.ensure(2 * nr * sizeof(float), stream);
