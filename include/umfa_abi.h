@@ -480,6 +480,8 @@ const char* umfa_last_kernel_name(mfa_context_t context);
  *                        a mask has no batch / head extent, and the host ranges (>= 1 MiB each) could be pinned: hipHostRegister by the first call
  *                        that wants chunks, for as long as the wrapper lives (mfa_destroy_buffer releases it)
  *   "sync_chunked_calls" read-out: how many synchronous forwards took the chunked form (tests)
+ *   "mirror_cache_hits"  read-out: host wrappers (mfa_buffer_from_ptr*) whose HBM mirror was taken from the mirrors of destroyed wrappers (same size, same
+ *                        device; at most 32 blocks / 4 GiB are kept, umfa_release_scratch(context, NULL, 1) frees them) instead of a hipMalloc (tests)
  * Returns MFA_ERROR_INVALID_ARGS for an unknown name or a value out of range.  Thread-safe; affects later launches. */
 mfa_error_t umfa_set_option(mfa_context_t context, const char* name, const char* value);
 

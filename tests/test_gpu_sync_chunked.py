@@ -156,3 +156,32 @@ def test_backward_chunked_equals_one_upload_and_oracle(ctx, B, H, S, D, chunks, 
         rdq, rdk, rdv, _ = oracle.sdpa_backward(do[sl], q[sl], k[sl], v[sl], ro, rl, causal=causal)
         for a, r, name in ((gc[0][sl], rdq, "dq"), (gc[1][sl], rdk, "dk"), (gc[2][sl], rdv, "dv")):
             assert rel(a, r) < 8e-3, (name, rel(a, r))  # tests/test_gpu_configs.py BWD16_TOL
+
+
+def test_hbm_mirrors_of_destroyed_wrappers_are_reused(ctx):
+    """A caller that wraps its arrays per call (umfa.flash_attention_forward does) gets the HBM mirrors of the wrappers it destroyed: no hipMalloc /
+    hipFree per array per call; umfa_release_scratch(all) frees what is kept; results do not depend on it."""
+    import ctypes
+
+    import umfa
+    import umfa_torch
+    from umfa import core
+    rng = np.random.default_rng(9)
+    q, k, v = (bf16_bits(rng, (1, 4, 512, 64)) for _ in range(3))
+    kw = dict(input_precision="bf16", intermediate_precision="bf16", layout="bhsd")
+    o0 = umfa.flash_attention_forward(ctx, q, k, v, **kw)
+    assert core._lib.umfa_release_scratch(ctx.handle, None, 1) == 0  # the cache is empty from here
+    h0 = int(umfa_torch.get_option("mirror_cache_hits"))
+    o1 = umfa.flash_attention_forward(ctx, q, k, v, **kw)   # four fresh mirrors, handed to the cache on destroy
+    assert int(umfa_torch.get_option("mirror_cache_hits")) == h0
+    o2 = umfa.flash_attention_forward(ctx, q, k, v, **kw)   # ... and taken again
+    assert int(umfa_torch.get_option("mirror_cache_hits")) == h0 + 4
+    assert np.array_equal(o1, o0) and np.array_equal(o2, o0)
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(20):
+        umfa.flash_attention_forward(ctx, q, k, v, **kw)
+    assert abs(torch.cuda.mem_get_info()[0] - free0) < (8 << 20)  # flat
+    assert core._lib.umfa_release_scratch(ctx.handle, None, 1) == 0
+    h1 = int(umfa_torch.get_option("mirror_cache_hits"))
+    umfa.flash_attention_forward(ctx, q, k, v, **kw)
+    assert int(umfa_torch.get_option("mirror_cache_hits")) == h1

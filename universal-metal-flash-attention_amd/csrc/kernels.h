@@ -32,7 +32,8 @@ struct Tuning {
         cbal{0} /* balanced causal pairs on the 128-row kernel: 0 = where the plan wants them, 1 = wherever they exist, 2 = never */,
         cbal_delta{-1} /* ... key tiles by which a pair's folding part is shorter than half; < 0 = the plan's choice */,
         sync_chunks{0} /* synchronous forward on host-wrapping buffers: head chunks whose upload / kernels / download overlap on side streams; 0 = by size, 1 = never (one upload, the kernels, one download on the null stream), n = n chunks */,
-        sync_chunked_calls{0} /* read-out for tests: synchronous forwards that took the chunked form */;
+        sync_chunked_calls{0} /* read-out for tests: synchronous forwards that took the chunked form */,
+        mirror_cache_hits{0} /* read-out for tests: host wrappers whose HBM mirror came from the cache of destroyed wrappers' mirrors (runtime_internal.h MirrorCache) */;
 };
 Tuning& tuning();
 bool set_tuning(const char* name, const char* value);  // false: unknown name or value out of range

@@ -453,7 +453,8 @@ void mfa_destroy_buffer(mfa_buffer_t buffer) {
     Buffer* b = as_buf(buffer);
     if (!b) return;
     if (b->registered && b->host && hipHostUnregister(b->host) != hipSuccess) (void)hipGetLastError();  // (the caller may have freed the range already)
-    if (b->owns_dev && b->dev) (void)hipFree(b->dev);
+    // (every synchronous entry has synchronised before it returned: nothing in flight reads or writes the mirror)
+    if (b->owns_dev && b->dev && !(b->cached_mirror && mirror_cache().give(b->dev, b->bytes, b->mirror_dev))) (void)hipFree(b->dev);
     if (b->owns_host && b->host) (void)hipHostFree(b->host);
     b->magic = 0;
     delete b;
@@ -698,6 +699,7 @@ mfa_error_t umfa_release_scratch(mfa_context_t context, void* stream, int32_t al
         (void)hipSetDevice(prev);
     }
     c->release_pools((hipStream_t)stream, all_streams != 0);
+    if (all_streams) mirror_cache().clear();  // HBM mirrors of destroyed host wrappers, kept for the next wrap
     return MFA_SUCCESS;
 }
 

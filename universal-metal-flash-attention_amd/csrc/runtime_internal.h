@@ -373,6 +373,8 @@ struct Buffer {
     void* dev = nullptr;    // what kernels read/write
     size_t bytes = 0;       // 0 = unknown (mfa_buffer_from_mtl_buffer with size 0)
     bool owns_host = false, owns_dev = false;
+    bool cached_mirror = false;  // `dev` is an HBM mirror made by wrap_pointer: goes back to mirror_cache() on destroy
+    int mirror_dev = 0;
     bool registered = false;  // wrap_pointer pinned the caller's host range (hipHostRegister): copies on it are asynchronous
     std::vector<int64_t> shape, strides;
 
@@ -395,6 +397,51 @@ struct Buffer {
     // bytes == 0: size unknown (device wraps only); a host pointer of unknown size has no HBM mirror (dev == NULL)
     bool fits(size_t need) const { return dev != nullptr && (bytes == 0 || need <= bytes); }
 };
+
+// HBM mirrors of host-wrapping buffers, kept between wrappers: a caller that wraps its arrays per call (the reference's Python binding does:
+// examples/python-ffi/src/umfa/core.py) paid a hipMalloc per array and -- the expensive half, ~0.7 ms each at the FLUX shape: it waits for the device and
+// unmaps -- a hipFree per array on every call (profiles/r6/wrapper_cost_probe.jsonl).  mfa_destroy_buffer hands the block here, the next wrap of the
+// same size on the same device takes it.  Bounded (32 blocks, 4 GiB); umfa_release_scratch(all) empties it.  A recycled mirror holds old bytes
+// where a fresh one held arbitrary ones: every synchronous entry uploads what it reads and downloads only what its kernels wrote or the caller's own bytes.
+struct MirrorCache {
+    struct Blk {
+        void* p;
+        size_t bytes;
+        int dev;
+    };
+    std::mutex mu;
+    std::vector<Blk> blocks;
+    size_t held = 0;
+    void* take(size_t bytes, int dev) {
+        std::lock_guard<std::mutex> lock(mu);
+        for (size_t i = 0; i < blocks.size(); ++i)
+            if (blocks[i].bytes == bytes && blocks[i].dev == dev) {
+                void* p = blocks[i].p;
+                umfa::tuning().mirror_cache_hits.fetch_add(1, std::memory_order_relaxed);
+                held -= bytes;
+                blocks.erase(blocks.begin() + (long)i);
+                return p;
+            }
+        return nullptr;
+    }
+    bool give(void* p, size_t bytes, int dev) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (blocks.size() >= 32 || held + bytes > ((size_t)4 << 30)) return false;
+        blocks.push_back({p, bytes, dev});
+        held += bytes;
+        return true;
+    }
+    void clear() {
+        std::lock_guard<std::mutex> lock(mu);
+        for (auto& b : blocks) (void)hipFree(b.p);
+        blocks.clear();
+        held = 0;
+    }
+};
+inline MirrorCache& mirror_cache() {
+    static MirrorCache* c = new MirrorCache();  // (never destroyed: no HIP calls from static destructors)
+    return *c;
+}
 
 inline Buffer* as_buf(mfa_buffer_t b) {
     Buffer* x = (Buffer*)b;
@@ -424,11 +471,17 @@ inline mfa_error_t wrap_pointer(void* ptr, size_t bytes, const int64_t* shape, c
         // MFABridge.swift:892-904); staged around every synchronous op.
         b->host = ptr;
         if (bytes > 0) {
-            if (hipMalloc(&b->dev, bytes) != hipSuccess) {
-                delete b;
-                return MFA_ERROR_MEMORY_ALLOCATION;
+            if (hipGetDevice(&b->mirror_dev) != hipSuccess) b->mirror_dev = 0;
+            b->dev = mirror_cache().take(bytes, b->mirror_dev);
+            if (!b->dev && hipMalloc(&b->dev, bytes) != hipSuccess) {
+                mirror_cache().clear();  // (memory held for the next wrap must not fail this one)
+                if (hipMalloc(&b->dev, bytes) != hipSuccess) {
+                    delete b;
+                    return MFA_ERROR_MEMORY_ALLOCATION;
+                }
             }
             b->owns_dev = true;
+            b->cached_mirror = true;
         }
     }
     if (shape && strides && ndim) {

@@ -103,7 +103,7 @@ bool set_tuning(const char* name, const char* value) {
         {"no_split", &t.no_split, true}, {"force_split", &t.force_split, false}, {"no_dma", &t.no_dma, true},
         {"bn64", &t.bn64, true}, {"pv_fp16", &t.pv_fp16, true}, {"bwd_ds_store", &t.bwd_ds_store, true}, {"no_w64_mask", &t.no_w64_mask, true}, {"ksplit", &t.ksplit, true}, {"no_pipe", &t.no_pipe, true}, {"no_w64_mask_lazy", &t.no_w64_mask_lazy, true}, {"no_w64_bias", &t.no_w64_bias, true}, {"no_w64_f32_mask", &t.no_w64_f32_mask, true}, {"f32_mask_ratio", &t.f32_mask_ratio, false}, {"mask_pass_ratio", &t.mask_pass_ratio, false}, {"no_w64_ragged_mask", &t.no_w64_ragged_mask, true}, {"no_mask_realign", &t.no_mask_realign, true},
         {"cast_two_pass", &t.cast_two_pass, true}, {"bwd_ds_lab", &t.bwd_ds_lab, false}, {"cast_u", &t.cast_u, false}, {"quant_block_wg", &t.quant_block_wg, true},
-        {"cast_wait_us", &t.cast_wait_us, false}, {"cbal", &t.cbal, false}, {"cbal_delta", &t.cbal_delta, false}, {"decode_ks", &t.decode_ks, false}, {"sync_chunks", &t.sync_chunks, false}, {"sync_chunked_calls", &t.sync_chunked_calls, false},
+        {"cast_wait_us", &t.cast_wait_us, false}, {"cbal", &t.cbal, false}, {"cbal_delta", &t.cbal_delta, false}, {"decode_ks", &t.decode_ks, false}, {"sync_chunks", &t.sync_chunks, false}, {"sync_chunked_calls", &t.sync_chunked_calls, false}, {"mirror_cache_hits", &t.mirror_cache_hits, false},
     };
     for (auto& e : tab)
         if (!strcmp(name, e.n)) {
@@ -130,7 +130,7 @@ bool get_tuning(const char* name, char* out, size_t n) {
             {"bwd_separate_delta", &t.bwd_separate_delta}, {"no_split", &t.no_split}, {"force_split", &t.force_split},
             {"no_dma", &t.no_dma}, {"bn64", &t.bn64}, {"pv_fp16", &t.pv_fp16}, {"bwd_ds_store", &t.bwd_ds_store}, {"no_w64_mask", &t.no_w64_mask}, {"ksplit", &t.ksplit}, {"no_pipe", &t.no_pipe}, {"no_w64_mask_lazy", &t.no_w64_mask_lazy}, {"no_w64_bias", &t.no_w64_bias}, {"no_w64_f32_mask", &t.no_w64_f32_mask}, {"f32_mask_ratio", &t.f32_mask_ratio}, {"mask_pass_ratio", &t.mask_pass_ratio}, {"no_w64_ragged_mask", &t.no_w64_ragged_mask}, {"no_mask_realign", &t.no_mask_realign},
             {"cast_two_pass", &t.cast_two_pass}, {"bwd_ds_lab", &t.bwd_ds_lab}, {"cast_u", &t.cast_u}, {"quant_block_wg", &t.quant_block_wg},
-            {"cast_wait_us", &t.cast_wait_us}, {"cbal", &t.cbal}, {"cbal_delta", &t.cbal_delta}, {"decode_ks", &t.decode_ks}, {"sync_chunks", &t.sync_chunks}, {"sync_chunked_calls", &t.sync_chunked_calls},
+            {"cast_wait_us", &t.cast_wait_us}, {"cbal", &t.cbal}, {"cbal_delta", &t.cbal_delta}, {"decode_ks", &t.decode_ks}, {"sync_chunks", &t.sync_chunks}, {"sync_chunked_calls", &t.sync_chunked_calls}, {"mirror_cache_hits", &t.mirror_cache_hits},
         };
         const std::atomic<int>* v = nullptr;
         for (auto& e : tab)

@@ -48,7 +48,7 @@ def release_scratch(stream=None, all_streams: bool = False) -> None:
 # environment: UMFA_FORCE_W64, UMFA_W64_TAU, ...); this module only reads and writes it.
 _OPTION_NAMES = ("softmax_reference", "softmax_tau", "w64_tau", "force_w64", "no_w64", "w64_grid", "w64_skew", "no_mask_flags", "bwd_exact",
                  "bwd_dq", "bwd_persist", "bwd_separate_delta", "no_split", "force_split", "no_dma", "bn64", "pv_fp16", "bwd_ds_store", "no_w64_mask", "ksplit", "no_pipe", "no_w64_mask_lazy", "no_w64_bias", "no_w64_f32_mask", "f32_mask_ratio", "mask_pass_ratio", "no_w64_ragged_mask", "no_mask_realign",
-                 "cast_two_pass", "bwd_ds_lab", "cast_u", "quant_block_wg", "cast_wait_us", "cbal", "cbal_delta", "decode_ks", "sync_chunks", "sync_chunked_calls")
+                 "cast_two_pass", "bwd_ds_lab", "cast_u", "quant_block_wg", "cast_wait_us", "cbal", "cbal_delta", "decode_ks", "sync_chunks", "sync_chunked_calls", "mirror_cache_hits")
 
 
 def get_option(name: str) -> str:
