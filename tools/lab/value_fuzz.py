@@ -617,6 +617,12 @@ def run_host_case(seed):
     q4, k4, v4 = (a.reshape((1, 1) + a.shape) if two_d else a for a in (q, k, v))
     # (fp16: P rounded to 11 bits; 1.5 ulp held for 11 719 seeds, seed 11720 -- 200 keys, an additive mask -- reached 1.54: the ceiling is 1.75 now, inside the stated 1e-3)
     tol = {"fp32": 2e-5, "fp16": 2.0 ** -11 * 1.75, "bf16": 2.0 ** -8 * 1.5}[prec]
+    # the option of the chunked synchronous form, at random (these cases are far below its floors -- 16 MB over the link, 1 MiB per pinned range -- so every
+    # value must give the one-upload form; the chunk plans themselves: tests/test_gpu_sync_chunked.py, tools/lab/sync_chunk_stress.py)
+    import umfa_torch
+    chunks = rng.choice([1, 0, 2, 3, 4, 7, 16])
+    umfa_torch.set_option("sync_chunks", chunks)
+    what.append(("sync_chunks", chunks))
     try:
         mode = rng.choice(["plain", "mask_bool", "mask_add", "lse_bwd"])
         what.append(mode)
@@ -656,6 +662,8 @@ def run_host_case(seed):
                     return "%s rel %.3e %r" % (name, r, what + [ctx.last_kernel])
     except Exception as e:  # noqa: BLE001
         return "exception %r %s" % (what, repr(e)[:300])
+    finally:
+        umfa_torch.set_option("sync_chunks", 0)
     return None
 
 

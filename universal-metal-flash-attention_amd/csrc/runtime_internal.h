@@ -553,6 +553,9 @@ inline hipError_t sync_chunks_end(Context* ctx, size_t nchunks, bool ok) {
 // and for as long as the wrapper lives (mfa_destroy_buffer releases it).  Ranges under 1 MiB (they may share pages with other allocations of the
 // caller's) and ranges the runtime refuses (registered by the caller already, ...) stay pageable, and the call takes the one-upload form.
 inline bool pin_for_chunks(std::initializer_list<Buffer*> bs) {
+    // (1 MiB: a lab build that pinned the sub-page arrays of the fuzz's host leg ran 6000 seeds of that leg clean and then died in the all-legs soak --
+    // "write access to a read-only page" on a host heap address, profiles/r6/lab_notes.md section 24: small heap ranges share their pages with the
+    // process's other objects.  Not offered as an option.)
     for (Buffer* b : bs)
         if (!b->mirrored() || (!b->registered && b->bytes < (1u << 20))) return false;
     for (Buffer* b : bs) {
