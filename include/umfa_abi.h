@@ -473,7 +473,8 @@ const char* umfa_last_kernel_name(mfa_context_t context);
  *                        a positive value replaces the constant (f32_mask_ratio: for the fp32 route alone).  profiles/r6/mask_pass_rule_probe.jsonl,
  *                        f32_mask_size_rule_probe.jsonl: what larger values buy and cost
  *   "cbal_delta"         "-1" (default: the plan's choice) | "0" ... "16": key tiles by which the folding workgroup's share is shorter (tests, A/B)
- *   "sync_chunks"        "0" (default: by size -- about 14 MB over the link per chunk, at most 8, calls of >= 64 MB) | "1": off | "2" ... "16" (calls of >= 16 MB):
+ *   "sync_chunks"        "1" (default: off) | "0": by size -- about 14 MB over the link per chunk, at most 8, calls of >= 64 MB | "2" ... "16" (calls of >= 16 MB).  OPT-IN
+ *                        (pinning and un-pinning caller memory per call: one of three stress runs under heap churn aborted):
  *                        the synchronous entries (mfa_attention_forward, _with_lse, mfa_attention_backward) on buffers that wrap HOST memory send the
  *                        heads through in chunks on side streams -- one chunk's download under the next ones' uploads, the kernels under both (FLUX
  *                        shape forward, host to host: 2.49 -> 1.89 ms, profiles/r6/host_boundary_probe.jsonl) -- when the operands are dense row-major,

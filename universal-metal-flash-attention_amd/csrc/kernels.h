@@ -31,7 +31,7 @@ struct Tuning {
         decode_ks{0} /* decode form of the 128-row kernel (<= 32 query rows: four key quarters per tile): 0 = where it applies, 2 = never */,
         cbal{0} /* balanced causal pairs on the 128-row kernel: 0 = where the plan wants them, 1 = wherever they exist, 2 = never */,
         cbal_delta{-1} /* ... key tiles by which a pair's folding part is shorter than half; < 0 = the plan's choice */,
-        sync_chunks{0} /* synchronous forward on host-wrapping buffers: head chunks whose upload / kernels / download overlap on side streams; 0 = by size, 1 = never (one upload, the kernels, one download on the null stream), n = n chunks */,
+        sync_chunks{1} /* synchronous forward / backward on host-wrapping buffers: head chunks whose upload / kernels / download overlap on side streams (pinned host ranges); 1 = never (the default: one upload, the kernels, one download on the null stream), 0 = by size, n = n chunks.  OPT-IN: one of three runs of tools/lab/sync_chunk_stress.py (pin / unpin per call under heap churn, torch in-process) aborted, profiles/r6/lab_notes.md section 24 */,
         sync_chunked_calls{0} /* read-out for tests: synchronous forwards that took the chunked form */,
         mirror_cache_hits{0} /* read-out for tests: host wrappers whose HBM mirror came from the cache of destroyed wrappers' mirrors (runtime_internal.h MirrorCache) */;
 };

@@ -70,7 +70,7 @@ Tuning& tuning() {
         x->cbal.store(env_int("UMFA_CBAL", 0));
         x->decode_ks.store(env_int("UMFA_DECODE_KS", 0));
         x->cbal_delta.store(env_int("UMFA_CBAL_DELTA", -1));
-        x->sync_chunks.store(env_int("UMFA_SYNC_CHUNKS", 0));
+        x->sync_chunks.store(env_int("UMFA_SYNC_CHUNKS", 1));
         return x;
     }();
     return *t;
